@@ -1,0 +1,100 @@
+"""ctypes binding of libmeshraster_hip.so (the C-ABI declared in include/meshraster_hip.h).
+
+The product path has NO fallback: if the shared library is missing, does not export a
+symbol of the header, or a call returns non-zero, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmeshraster_hip.so")
+ABI_VERSION = 1
+FLAG_REFERENCE_ALGO = 1
+
+_c = ctypes
+_P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
+
+# name -> (restype, argtypes); must list every MR_API prototype of include/meshraster_hip.h
+SIGNATURES = {
+    "mr_abi_version": (_I, []),
+    "mr_device_ok": (_I, []),
+    "mr_forward_face_index_map": (_I, [_P] * 6 + [_I, _I, _I, _F, _F, _I, _I, _I, _P]),
+    "mr_forward_texture_sampling": (_I, [_P] * 8 + [_I, _I, _I, _I, _F, _P]),
+    "mr_backward_pixel_map": (_I, [_P] * 7 + [_I, _I, _I, _F, _I, _I, _P]),
+    "mr_backward_textures": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
+    "mr_backward_depth_map": (_I, [_P] * 7 + [_I, _I, _I, _P]),
+    "mr_render_workspace_bytes": (_L, [_I, _I, _I]),
+    "mr_render_forward": (_I, [_P, _P, _P, _I] + [_P] * 7 + [_L, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
+    "mr_face_inv_map": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mr_render_backward": (_I, [_P] * 11 + [_L, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
+    "mr_warp_forward": (_I, [_P] * 4 + [_I, _I, _I, _I, _F, _I, _P]),
+    "mr_warp_backward": (_I, [_P] * 5 + [_I, _I, _I, _I, _F, _I, _P]),
+    "mr_occlusion_mask": (_I, [_P] * 4 + [_L, _P, _P, _I, _I, _I, _F, _F, _P]),
+    "mr_pair_consist_workspace_bytes": (_L, [_I, _I, _I]),
+    "mr_pair_consist_forward": (_I, [_P] * 6 + [_I, _P, _L] + [_P] * 11 + [_I, _I, _I, _F, _P]),
+    "mr_pair_consist_backward": (_I, [_P] * 6 + [_I] + [_P] * 5 + [_I, _I, _I, _F, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once) and bind every entry point; raise if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `python handobjectconsist_amd/build.py`). "
+            "There is no CPU / PyTorch fallback for the render + warp path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI {lib.mr_abi_version()}, expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def check_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise TypeError("handobjectconsist_amd kernels support only cuda (ROCm) tensors")
+
+
+def call(name, *args):
+    """Invoke an entry point; non-zero status -> RuntimeError (the reference's C++ asserts
+    surface as RuntimeError too)."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "not implemented"}.get(rc, f"hipError_t {rc}")
+        raise RuntimeError(f"{name} failed: {kind}")
+    return rc
+
+
+def contig(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()

@@ -1,0 +1,179 @@
+// mr_common.hpp -- shared device helpers for libmeshraster_hip (gfx950 only).
+//
+// All parity-critical arithmetic is written one IEEE fp32 operation per C++ operator and
+// the library is compiled with -ffp-contract=off, so the results are bit-identical to the
+// CPU oracle (oracle/raster_oracle.c) wherever the summation order is the same.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/meshraster_hip.h"
+
+#define MR_WAVE 64
+
+#define MR_CHECK_LAUNCH()                          \
+    do {                                           \
+        hipError_t e_ = hipGetLastError();         \
+        if (e_ != hipSuccess) return (int)e_;      \
+    } while (0)
+
+namespace mr {
+
+// Pixel-space bounding box of a face (inclusive); empty when x0 > x1.
+struct __attribute__((aligned(8))) FaceBox {
+    int16_t x0, x1, y0, y1;
+};
+
+// A face as the rasteriser sees it: NDC x,y + metric z per vertex, and the pixel-space
+// inverse of [[x0 x1 x2],[y0 y1 y2],[1 1 1]] (upstream kernel forward_face_index_map_1).
+struct Face {
+    float v[9];
+    float inv[9];
+};
+
+__device__ __forceinline__ bool backfacing(const float* f) {
+    return (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]);
+}
+
+__device__ __forceinline__ void face_inverse(const float* f, float* inv, int is) {
+    const float fis = (float)is;
+    float p[3][2];
+#pragma unroll
+    for (int n = 0; n < 3; n++)
+#pragma unroll
+        for (int d = 0; d < 2; d++) p[n][d] = 0.5f * (f[3 * n + d] * fis + fis - 1.0f);
+    float a[9] = {p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                  p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                  p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+    const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
+                       p[1][0] * (p[2][1] - p[0][1]));
+#pragma unroll
+    for (int k = 0; k < 9; k++) inv[k] = a[k] / den;
+}
+
+__device__ __forceinline__ void load_face(const float* __restrict__ g, Face& f, int is) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) f.v[k] = g[k];
+    face_inverse(f.v, f.inv, is);
+}
+
+// Conservative pixel bounding box: every pixel the coverage test can accept is inside.
+// Back-facing faces and faces with a NaN coordinate can never win a pixel -> empty.
+// Degenerate (zero pixel-space determinant) or infinite faces get the whole screen so
+// that the exact per-pixel test decides, as in the brute-force upstream loop.
+__device__ __forceinline__ FaceBox face_box(const float* f, int is) {
+    FaceBox b;
+    b.x0 = 1; b.x1 = 0; b.y0 = 1; b.y1 = 0;
+    bool anynan = false;
+#pragma unroll
+    for (int k = 0; k < 9; k++) anynan |= (f[k] != f[k]);
+    if (anynan || backfacing(f)) return b;
+    const float fis = (float)is;
+    float px[3], py[3];
+#pragma unroll
+    for (int n = 0; n < 3; n++) {
+        px[n] = 0.5f * (f[3 * n + 0] * fis + fis - 1.0f);
+        py[n] = 0.5f * (f[3 * n + 1] * fis + fis - 1.0f);
+    }
+    const float den = (px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]));
+    bool full = !(den != 0.0f) || !(fabsf(den) <= 3.0e38f);
+#pragma unroll
+    for (int n = 0; n < 3; n++) full |= !(fabsf(px[n]) <= 3.0e38f) || !(fabsf(py[n]) <= 3.0e38f);
+    if (full) {
+        b.x0 = 0; b.x1 = (int16_t)(is - 1); b.y0 = 0; b.y1 = (int16_t)(is - 1);
+        return b;
+    }
+    const float lim = fis - 1.0f;
+    float xlo = floorf(fminf(px[0], fminf(px[1], px[2])));
+    float xhi = ceilf(fmaxf(px[0], fmaxf(px[1], px[2])));
+    float ylo = floorf(fminf(py[0], fminf(py[1], py[2])));
+    float yhi = ceilf(fmaxf(py[0], fmaxf(py[1], py[2])));
+    if (xhi < 0.0f || yhi < 0.0f || xlo > lim || ylo > lim) return b;
+    b.x0 = (int16_t)fmaxf(xlo, 0.0f);
+    b.x1 = (int16_t)fminf(xhi, lim);
+    b.y0 = (int16_t)fmaxf(ylo, 0.0f);
+    b.y1 = (int16_t)fminf(yhi, lim);
+    return b;
+}
+
+// Barycentric weights (clamped, normalised) and perspective-correct depth of pixel (xi, yi)
+// on face f -- the arithmetic of the upstream face loop after the inside test.
+__device__ __forceinline__ void bary(const Face& f, int xi, int yi, float& zp, float* w) {
+    const float fx = (float)xi, fy = (float)yi;
+    w[0] = f.inv[0] * fx + f.inv[1] * fy + f.inv[2];
+    w[1] = f.inv[3] * fx + f.inv[4] * fy + f.inv[5];
+    w[2] = f.inv[6] * fx + f.inv[7] * fy + f.inv[8];
+    float ws = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        w[k] = fminf(fmaxf(w[k], 0.0f), 1.0f);
+        ws += w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) w[k] /= ws;
+    zp = 1.0f / (w[0] / f.v[2] + w[1] / f.v[5] + w[2] / f.v[8]);
+}
+
+// Coverage + barycentric weights + perspective-correct depth of one pixel against one
+// front-facing face (upstream kernel forward_face_index_map_2, body of the face loop).
+__device__ __forceinline__ bool cover(const Face& f, int xi, int yi, int is, float near_, float far_,
+                                      float& zp, float* w) {
+    const float fis = (float)is;
+    const float yp = (float)(2 * yi + 1 - is) / fis;
+    const float xp = (float)(2 * xi + 1 - is) / fis;
+    const float* v = f.v;
+    if (((yp - v[1]) * (v[3] - v[0]) < (xp - v[0]) * (v[4] - v[1])) ||
+        ((yp - v[4]) * (v[6] - v[3]) < (xp - v[3]) * (v[7] - v[4])) ||
+        ((yp - v[7]) * (v[0] - v[6]) < (xp - v[6]) * (v[1] - v[7])))
+        return false;
+    bary(f, xi, yi, zp, w);
+    if (zp <= near_ || far_ <= zp) return false;
+    return true;
+}
+
+// Order-preserving map float -> uint32 (so that an unsigned min is a float min).
+__device__ __forceinline__ uint32_t f2ord(float x) {
+    uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// Texture-space coordinates of a hit pixel (upstream forward_texture_sampling).
+__device__ __forceinline__ void tex_coords(const float* w, float depth, const float* v, int ts,
+                                           float eps, float* tif) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float t = w[k] * (float)(ts - 1) * (depth / v[3 * k + 2]);
+        t = fmaxf(t, 0.0f);
+        t = fminf(t, (float)(ts - 1) - eps);
+        tif[k] = t;
+    }
+}
+
+__device__ __forceinline__ void tex_tap(const float* tif, int pn, int ts, float& wgt, int& isc) {
+    wgt = 1.0f;
+    int ti[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int fl = (int)tif[k];
+        if (((pn >> k) & 1) == 0) {
+            wgt *= 1.0f - (tif[k] - (float)fl);
+            ti[k] = fl;
+        } else {
+            wgt *= tif[k] - (float)fl;
+            ti[k] = fl + 1;
+        }
+    }
+    isc = ti[0] * ts * ts + ti[1] * ts + ti[2];
+}
+
+// XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a
+// contiguous range of logical ids so the tiles / faces of one image share one L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    if ((nblocks & 7u) != 0u) return bid;
+    return (bid & 7u) * (nblocks >> 3) + (bid >> 3);
+}
+
+}  // namespace mr

@@ -1,0 +1,544 @@
+// raster_bwd.hip -- backward of the rasteriser for gfx950 (MI355X).
+//
+// Replaces upstream kernels backward_pixel_map / backward_textures / backward_depth_map
+// (/root/reference/meshreg/neurender/rasterize.py:269-315).
+//
+// Design:
+//   * texture + depth gradients (upstream kernels E, F) are computed by a FACE-PARALLEL
+//     GATHER instead of per-pixel global atomics: one lane owns one face, walks the face's
+//     pixel bounding box in the face_index_map and, for the pixels it won, recomputes the
+//     barycentrics / sampling weights from the vertices (nothing but face_index_map is read
+//     back from the forward pass) and accumulates the 24 texel and 9 vertex gradients in
+//     registers, in ascending pixel order -- the order of the serial CPU oracle, so the
+//     result is deterministic and, for one-lane faces, bit-identical to it.  Faces whose
+//     bbox is large are walked by the whole wave (lane per pixel) and tree-reduced.
+//     Every output element is written exactly once: no memset, no atomics.
+//   * the pixel-map pseudo-gradient (upstream kernel D) keeps upstream's per-face edge
+//     walks but spreads the six (edge, axis) walks of a face over six lanes.
+//   * generic-texture-size / upstream-compatible variants (per-pixel atomics on stored or
+//     recomputed sampling weights) back the five-entry-point API.
+#include "mr_common.hpp"
+
+namespace mr {
+
+constexpr int GATHER_SMALL_MAX = 64;  // bbox area up to which one lane walks a face
+
+// ---------------------------------------------------------------------------------------
+// map accessors: IMG = image orientation (vertically flipped, NCHW rgb), else raster NHWC
+// ---------------------------------------------------------------------------------------
+template <bool IMG>
+__device__ __forceinline__ int64_t idx1(int b, int yi, int xi, int is) {
+    return IMG ? ((int64_t)b * is + (is - 1 - yi)) * is + xi : ((int64_t)b * is + yi) * is + xi;
+}
+template <bool IMG>
+__device__ __forceinline__ int64_t idx3(int b, int yi, int xi, int c, int is) {
+    return IMG ? (((int64_t)b * 3 + c) * is + (is - 1 - yi)) * is + xi
+               : (((int64_t)b * is + yi) * is + xi) * 3 + c;
+}
+
+// ---------------------------------------------------------------------------------------
+// E + F: face-parallel gather (texture size 2)
+// ---------------------------------------------------------------------------------------
+struct GatherParams {
+    const float* faces;
+    const int32_t* fim;       // raster orientation
+    const float* grad_rgb;    // nullable
+    const float* grad_depth;  // nullable
+    float* grad_faces;        // nullable
+    float* grad_textures;     // nullable (ts == 2 only)
+    int B, F, is;
+    float eps;
+    int accumulate_faces;     // 1: grad_faces already holds the pixel-map term
+};
+
+template <bool IMG>
+__device__ __forceinline__ void gather_pixel(const GatherParams& p, const Face& f, int b, int xi, int yi,
+                                             float* gt, float* gf) {
+    float w[3], zp;
+    bary(f, xi, yi, zp, w);
+    const int is = p.is;
+    if (p.grad_textures) {
+        float tif[3];
+        tex_coords(w, zp, f.v, 2, p.eps, tif);
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) g[c] = p.grad_rgb[idx3<IMG>(b, yi, xi, c, is)];
+#pragma unroll
+        for (int pn = 0; pn < 8; pn++) {
+            // ts == 2 and 0 <= tif < 1: floor is 0, the tap index is the bit pattern of pn
+            float wg = 1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) wg *= ((pn >> k) & 1) ? (tif[k] - 0.0f) : (1.0f - (tif[k] - 0.0f));
+            const int isc = ((pn & 1) << 2) | (((pn >> 1) & 1) << 1) | ((pn >> 2) & 1);
+#pragma unroll
+            for (int c = 0; c < 3; c++) gt[isc * 3 + c] += wg * g[c];
+        }
+    }
+    if (p.grad_depth && p.grad_faces) {
+        const float gd = p.grad_depth[idx1<IMG>(b, yi, xi, is)];
+        const float d2 = zp * zp;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float zk = f.v[3 * k + 2];
+            gf[3 * k + 2] += gd * w[k] * d2 / (zk * zk);
+        }
+        float tmp[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int l = 0; l < 3; l++) tmp[k] += -f.inv[3 * l + k] / f.v[3 * l + 2];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int l = 0; l < 2; l++) gf[3 * k + l] += -gd * tmp[l] * w[k] * d2 * (float)is / 2.0f;
+    }
+}
+
+template <bool IMG>
+__global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
+    const int64_t total = (int64_t)p.B * p.F;
+    const int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < total;
+    const int b = valid ? (int)(i / p.F) : 0;
+    const int fn = valid ? (int)(i % p.F) : 0;
+    const int is = p.is;
+
+    Face f;
+    FaceBox bx;
+    bx.x0 = 1; bx.x1 = 0; bx.y0 = 1; bx.y1 = 0;
+    float gt[24], gf[9];
+#pragma unroll
+    for (int k = 0; k < 24; k++) gt[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) gf[k] = 0.0f;
+    if (valid) {
+        load_face(p.faces + i * 9, f, is);
+        bx = face_box(f.v, is);
+        if (p.grad_faces && p.accumulate_faces)
+#pragma unroll
+            for (int k = 0; k < 9; k++) gf[k] = p.grad_faces[i * 9 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) { f.v[k] = 0.0f; f.inv[k] = 0.0f; }
+    }
+    const bool nonempty = valid && bx.x0 <= bx.x1;
+    const int bw = bx.x1 - bx.x0 + 1, bh = bx.y1 - bx.y0 + 1;
+    const bool big = nonempty && bw * bh > GATHER_SMALL_MAX;
+
+    if (nonempty && !big) {
+        const int32_t* fim_b = p.fim + (int64_t)b * is * is;
+        for (int yi = bx.y0; yi <= bx.y1; yi++)
+            for (int xi = bx.x0; xi <= bx.x1; xi++)
+                if (fim_b[yi * is + xi] == fn) gather_pixel<IMG>(p, f, b, xi, yi, gt, gf);
+    }
+
+    unsigned long long m_big = __ballot(big);
+    while (m_big) {
+        const int src = __ffsll((long long)m_big) - 1;
+        m_big &= m_big - 1;
+        Face fb;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { fb.v[k] = __shfl(f.v[k], src); fb.inv[k] = __shfl(f.inv[k], src); }
+        const int x0 = __shfl((int)bx.x0, src), y0 = __shfl((int)bx.y0, src);
+        const int w_ = __shfl(bw, src), n = w_ * __shfl(bh, src);
+        const int bb = __shfl(b, src), ff = __shfl(fn, src);
+        const int32_t* fim_b = p.fim + (int64_t)bb * is * is;
+        float pt[24], pf[9];
+#pragma unroll
+        for (int k = 0; k < 24; k++) pt[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; k++) pf[k] = 0.0f;
+        for (int j = lane; j < n; j += MR_WAVE) {
+            const int xi = x0 + j % w_, yi = y0 + j / w_;
+            if (fim_b[yi * is + xi] == ff) gather_pixel<IMG>(p, fb, bb, xi, yi, pt, pf);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 24; k++) pt[k] += __shfl_xor(pt[k], off);
+#pragma unroll
+            for (int k = 0; k < 9; k++) pf[k] += __shfl_xor(pf[k], off);
+        }
+        if (lane == src) {
+#pragma unroll
+            for (int k = 0; k < 24; k++) gt[k] += pt[k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) gf[k] += pf[k];
+        }
+    }
+
+    if (!valid) return;
+    if (p.grad_textures) {
+        float4* o = reinterpret_cast<float4*>(p.grad_textures + i * 24);
+#pragma unroll
+        for (int k = 0; k < 6; k++) o[k] = make_float4(gt[4 * k], gt[4 * k + 1], gt[4 * k + 2], gt[4 * k + 3]);
+    }
+    if (p.grad_faces)
+#pragma unroll
+        for (int k = 0; k < 9; k++) p.grad_faces[i * 9 + k] = gf[k];
+}
+
+// ---------------------------------------------------------------------------------------
+// E, generic texture size: per-pixel atomics on recomputed sampling weights
+// ---------------------------------------------------------------------------------------
+template <bool IMG>
+__global__ void __launch_bounds__(256) textures_atomic_recompute_kernel(
+    const float* __restrict__ faces, const int32_t* __restrict__ fim, const float* __restrict__ grad_rgb,
+    float* __restrict__ grad_textures, int64_t npx, int F, int is, int ts, float eps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const int fn = fim[i];
+    if (fn < 0) return;
+    const int b = (int)(i / ((int64_t)is * is));
+    const int pn_ = (int)(i % ((int64_t)is * is));
+    const int yi = pn_ / is, xi = pn_ % is;
+    Face f;
+    load_face(faces + ((int64_t)b * F + fn) * 9, f, is);
+    float w[3], zp, tif[3];
+    bary(f, xi, yi, zp, w);
+    tex_coords(w, zp, f.v, ts, eps, tif);
+    float g[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) g[c] = grad_rgb[idx3<IMG>(b, yi, xi, c, is)];
+    float* gt = grad_textures + ((int64_t)b * F + fn) * ts * ts * ts * 3;
+#pragma unroll
+    for (int pn = 0; pn < 8; pn++) {
+        float wg; int isc;
+        tex_tap(tif, pn, ts, wg, isc);
+#pragma unroll
+        for (int c = 0; c < 3; c++) atomicAdd(&gt[isc * 3 + c], wg * g[c]);
+    }
+}
+
+// upstream backward_textures on stored sampling maps (raster NHWC)
+__global__ void __launch_bounds__(256) textures_atomic_stored_kernel(
+    const int32_t* __restrict__ fim, const float* __restrict__ swgt, const int32_t* __restrict__ sidx,
+    const float* __restrict__ grad_rgb, float* __restrict__ grad_textures, int64_t npx, int F, int is,
+    int ts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const int fn = fim[i];
+    if (fn < 0) return;
+    const int64_t b = i / ((int64_t)is * is);
+    float* gt = grad_textures + (b * F + fn) * ts * ts * ts * 3;
+    const float g[3] = {grad_rgb[i * 3], grad_rgb[i * 3 + 1], grad_rgb[i * 3 + 2]};
+#pragma unroll
+    for (int pn = 0; pn < 8; pn++) {
+        const float w = swgt[i * 8 + pn];
+        const int isc = sidx[i * 8 + pn];
+#pragma unroll
+        for (int c = 0; c < 3; c++) atomicAdd(&gt[isc * 3 + c], w * g[c]);
+    }
+}
+
+// upstream backward_depth_map on stored maps (raster orientation)
+__global__ void __launch_bounds__(256) depth_atomic_stored_kernel(
+    const float* __restrict__ faces, const float* __restrict__ depth_map, const int32_t* __restrict__ fim,
+    const float* __restrict__ face_inv_map, const float* __restrict__ weight_map,
+    const float* __restrict__ grad_depth, float* __restrict__ grad_faces, int64_t npx, int F, int is) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const int fn = fim[i];
+    if (fn < 0) return;
+    const int64_t b = i / ((int64_t)is * is);
+    const float* face = faces + (b * F + fn) * 9;
+    float* gface = grad_faces + (b * F + fn) * 9;
+    const float depth = depth_map[i];
+    const float d2 = depth * depth;
+    const float gd = grad_depth[i];
+    const float* inv = face_inv_map + i * 9;
+    const float w[3] = {weight_map[i * 3], weight_map[i * 3 + 1], weight_map[i * 3 + 2]};
+    const float z[3] = {face[2], face[5], face[8]};
+#pragma unroll
+    for (int k = 0; k < 3; k++) atomicAdd(&gface[3 * k + 2], gd * w[k] * d2 / (z[k] * z[k]));
+    float tmp[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int l = 0; l < 3; l++) tmp[k] += -inv[3 * l + k] / z[l];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int l = 0; l < 2; l++) atomicAdd(&gface[3 * k + l], -gd * tmp[l] * w[k] * d2 * (float)is / 2.0f);
+}
+
+// ---------------------------------------------------------------------------------------
+// D: NMR pixel-map pseudo-gradient.  8 lanes per face, lanes 0..5 = (edge, axis) walks.
+// ---------------------------------------------------------------------------------------
+struct PixelMapParams {
+    const float* faces;
+    const int32_t* fim;  // raster orientation
+    const float* rgb;
+    const float* alpha;
+    const float* grad_rgb;
+    const float* grad_alpha;
+    float* grad_faces;
+    int B, F, is;
+    float eps;
+    int return_rgb, return_alpha;
+    int write_backfacing;  // fused path: also zero the rows of culled faces
+};
+
+template <bool IMG>
+__device__ __forceinline__ float diff_grad_at(const PixelMapParams& p, int b, int yi, int xi, float a_ref,
+                                              const float* rgb_ref) {
+    float d = 0.0f;
+    const int is = p.is;
+    if (p.return_alpha) {
+        const int64_t ia = idx1<IMG>(b, yi, xi, is);
+        d += (p.alpha[ia] - a_ref) * p.grad_alpha[ia];
+    }
+    if (p.return_rgb) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int64_t ic = idx3<IMG>(b, yi, xi, k, is);
+            d += (p.rgb[ic] - rgb_ref[k]) * p.grad_rgb[ic];
+        }
+    }
+    return d;
+}
+
+template <bool IMG>
+__global__ void __launch_bounds__(256) pixel_map_kernel(PixelMapParams p) {
+    const int64_t total = (int64_t)p.B * p.F;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gtid >> 3;
+    const int item = (int)(gtid & 7);
+    const bool valid = i < total;
+    const int is = p.is;
+    const float fis = (float)is;
+    float g0 = 0.0f, g1 = 0.0f;  // gradients of vertices pi[0], pi[1], component (1 - axis)
+    bool front = false;
+    const int edge_num = item >> 1, axis = item & 1;
+    const int b = valid ? (int)(i / p.F) : 0;
+    const int fn = valid ? (int)(i % p.F) : 0;
+    if (valid) {
+        float face[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) face[k] = p.faces[i * 9 + k];
+        front = !backfacing(face);
+        if (front && item < 6) {
+            int pi[3];
+            float pp[3][2];
+            for (int num = 0; num < 3; num++) pi[num] = (edge_num + num) % 3;
+            for (int num = 0; num < 3; num++)
+                for (int dim = 0; dim < 2; dim++) pp[num][dim] = 0.5f * (face[3 * pi[num] + dim] * fis + fis - 1.0f);
+            float q[3][2];
+            for (int num = 0; num < 3; num++)
+                for (int dim = 0; dim < 2; dim++) q[num][dim] = pp[num][(dim + axis) % 2];
+            int direction;
+            if (axis == 0)
+                direction = (q[0][0] < q[1][0]) ? -1 : 1;
+            else
+                direction = (q[0][0] < q[1][0]) ? 1 : -1;
+            const int d0_from = (int)fmaxf(ceilf(fminf(q[0][0], q[1][0])), 0.0f);
+            const int d0_to = (int)fminf(fmaxf(q[0][0], q[1][0]), fis - 1.0f);
+            for (int d0 = d0_from; d0 <= d0_to; d0++) {
+                const float fd0 = (float)d0;
+                const float d1_cross = (q[1][1] - q[0][1]) / (q[1][0] - q[0][0]) * (fd0 - q[0][0]) + q[0][1];
+                const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
+                const int d1_out = d1_in + direction;
+                if (d1_in < 0 || is <= d1_in) continue;
+                if (d1_out < 0 || is <= d1_out) continue;
+                // pixel (x, y) of (d0, d1): axis 0 -> (d0, d1), axis 1 -> (d1, d0)
+                const int xin = axis == 0 ? d0 : d1_in, yin = axis == 0 ? d1_in : d0;
+                const int xout = axis == 0 ? d0 : d1_out, yout = axis == 0 ? d1_out : d0;
+                float a_in = 0.0f, a_out = 0.0f, rgb_in[3] = {0, 0, 0}, rgb_out[3] = {0, 0, 0};
+                if (p.return_alpha) {
+                    a_in = p.alpha[idx1<IMG>(b, yin, xin, is)];
+                    a_out = p.alpha[idx1<IMG>(b, yout, xout, is)];
+                }
+                if (p.return_rgb)
+                    for (int k = 0; k < 3; k++) {
+                        rgb_in[k] = p.rgb[idx3<IMG>(b, yin, xin, k, is)];
+                        rgb_out[k] = p.rgb[idx3<IMG>(b, yout, xout, k, is)];
+                    }
+                const float c0 = (q[1][0] - q[0][0]) / (q[1][0] - fd0);
+                const float c1 = (q[1][0] - q[0][0]) / (fd0 - q[0][0]);
+                const bool use0 = q[1][0] != fd0, use1 = q[0][0] != fd0;
+                const int32_t* fim_b = p.fim + (int64_t)b * is * is;
+
+                // out sweep
+                if (fim_b[yin * is + xin] == fn) {
+                    const int d1_limit = (0 < direction) ? is - 1 : 0;
+                    const int d1_from = max(min(d1_out, d1_limit), 0);
+                    const int d1_to = min(max(d1_out, d1_limit), is - 1);
+                    for (int d1 = d1_from; d1 <= d1_to; d1++) {
+                        const int xi = axis == 0 ? d0 : d1, yi = axis == 0 ? d1 : d0;
+                        const float dg = diff_grad_at<IMG>(p, b, yi, xi, a_in, rgb_in);
+                        if (dg <= 0) continue;
+                        if (use0) {
+                            float dist = c0 * ((float)d1 - d1_cross) * 2.0f / fis;
+                            dist = (0 < dist) ? dist + p.eps : dist - p.eps;
+                            g0 -= dg / dist;
+                        }
+                        if (use1) {
+                            float dist = c1 * ((float)d1 - d1_cross) * 2.0f / fis;
+                            dist = (0 < dist) ? dist + p.eps : dist - p.eps;
+                            g1 -= dg / dist;
+                        }
+                    }
+                }
+                // in sweep
+                {
+                    float d0_cross2;
+                    if ((fd0 - q[0][0]) * (fd0 - q[2][0]) < 0)
+                        d0_cross2 = (q[2][1] - q[0][1]) / (q[2][0] - q[0][0]) * (fd0 - q[0][0]) + q[0][1];
+                    else
+                        d0_cross2 = (q[1][1] - q[2][1]) / (q[1][0] - q[2][0]) * (fd0 - q[2][0]) + q[2][1];
+                    const int d1_limit = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
+                    const int d1_from = max(min(d1_in, d1_limit), 0);
+                    const int d1_to = min(max(d1_in, d1_limit), is - 1);
+                    for (int d1 = d1_from; d1 <= d1_to; d1++) {
+                        const int xi = axis == 0 ? d0 : d1, yi = axis == 0 ? d1 : d0;
+                        if (fim_b[yi * is + xi] != fn) continue;
+                        const float dg = diff_grad_at<IMG>(p, b, yi, xi, a_out, rgb_out);
+                        if (dg <= 0) continue;
+                        if (use0) {
+                            float dist = c0 * ((float)d1 - d1_cross) * 2.0f / fis;
+                            dist = (0 < dist) ? dist + p.eps : dist - p.eps;
+                            g0 -= dg / dist;
+                        }
+                        if (use1) {
+                            float dist = c1 * ((float)d1 - d1_cross) * 2.0f / fis;
+                            dist = (0 < dist) ? dist + p.eps : dist - p.eps;
+                            g1 -= dg / dist;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // combine inside the 8-lane group.  Slot (vertex v, component c) receives g0 of the walk
+    // (edge v, axis 1 - c) and g1 of the walk (edge (v + 2) % 3, axis 1 - c), added in
+    // upstream's edge order.
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane & ~7;
+    float out[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) out[k] = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 3; v++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int ax = 1 - c;
+            const int ea = v, eb = (v + 2) % 3;
+            const float ga = __shfl(g0, gbase + ea * 2 + ax);
+            const float gb = __shfl(g1, gbase + eb * 2 + ax);
+            out[3 * v + c] = (ea < eb) ? (ga + gb) : (gb + ga);
+        }
+    if (valid && item == 0 && (front || p.write_backfacing))
+#pragma unroll
+        for (int k = 0; k < 9; k++) p.grad_faces[i * 9 + k] = out[k];
+}
+
+template <typename K, typename... A>
+static int launch1d(K kernel, int64_t n, hipStream_t s, A... args) {
+    if (n <= 0) return MR_OK;
+    const int64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, s, args...);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+extern "C" int mr_backward_pixel_map(const float* faces, const int32_t* face_index_map,
+                                     const float* rgb_map, const float* alpha_map,
+                                     const float* grad_rgb_map, const float* grad_alpha_map,
+                                     float* grad_faces, int batch_size, int num_faces, int image_size,
+                                     float eps, int return_rgb, int return_alpha, mr_stream_t stream) {
+    if (!faces || !face_index_map || !grad_faces) return MR_ERR_BADARG;
+    if (return_rgb && (!rgb_map || !grad_rgb_map)) return MR_ERR_BADARG;
+    if (return_alpha && (!alpha_map || !grad_alpha_map)) return MR_ERR_BADARG;
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0) return MR_ERR_BADARG;
+    if (!return_rgb && !return_alpha) return MR_OK;
+    PixelMapParams p{faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
+                     batch_size, num_faces, image_size, eps, return_rgb, return_alpha, 0};
+    return launch1d(pixel_map_kernel<false>, (int64_t)batch_size * num_faces * 8, (hipStream_t)stream, p);
+}
+
+extern "C" int mr_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
+                                    const int32_t* sampling_index_map, const float* grad_rgb_map,
+                                    float* grad_textures, int batch_size, int num_faces, int image_size,
+                                    int texture_size, mr_stream_t stream) {
+    if (!face_index_map || !sampling_weight_map || !sampling_index_map || !grad_rgb_map || !grad_textures)
+        return MR_ERR_BADARG;
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0 || texture_size < 2) return MR_ERR_BADARG;
+    const int64_t npx = (int64_t)batch_size * image_size * image_size;
+    return launch1d(textures_atomic_stored_kernel, npx, (hipStream_t)stream, face_index_map,
+                    sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures, npx, num_faces,
+                    image_size, texture_size);
+}
+
+extern "C" int mr_backward_depth_map(const float* faces, const float* depth_map,
+                                     const int32_t* face_index_map, const float* face_inv_map,
+                                     const float* weight_map, const float* grad_depth_map,
+                                     float* grad_faces, int batch_size, int num_faces, int image_size,
+                                     mr_stream_t stream) {
+    if (!faces || !depth_map || !face_index_map || !face_inv_map || !weight_map || !grad_depth_map ||
+        !grad_faces)
+        return MR_ERR_BADARG;
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0) return MR_ERR_BADARG;
+    const int64_t npx = (int64_t)batch_size * image_size * image_size;
+    return launch1d(depth_atomic_stored_kernel, npx, (hipStream_t)stream, faces, depth_map, face_index_map,
+                    face_inv_map, weight_map, grad_depth_map, grad_faces, npx, num_faces, image_size);
+}
+
+extern "C" int mr_render_backward(const float* faces, const float* textures,
+                                  const int32_t* face_index_map, const float* rgb_img,
+                                  const float* alpha_img, const float* grad_rgb_img,
+                                  const float* grad_alpha_img, const float* grad_depth_img,
+                                  float* grad_faces, float* grad_textures, void* workspace,
+                                  int64_t workspace_bytes, int batch_size, int num_faces,
+                                  int image_size, int texture_size, float near_, float far_, float eps,
+                                  int return_rgb, int return_alpha, int return_depth, int flags,
+                                  mr_stream_t stream) {
+    (void)textures; (void)workspace; (void)workspace_bytes; (void)near_; (void)far_;
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0) return MR_ERR_BADARG;
+    if (batch_size == 0 || num_faces == 0) return MR_OK;
+    if (!faces || !face_index_map) return MR_ERR_BADARG;
+    if (grad_textures && (!return_rgb || !grad_rgb_img || texture_size < 2)) return MR_ERR_BADARG;
+    if (batch_size == 0 || num_faces == 0) return MR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nfaces = (int64_t)batch_size * num_faces;
+    const int64_t npx = (int64_t)batch_size * image_size * image_size;
+    int rc = MR_OK;
+
+    // D: pixel-map term (writes all 9 slots of every face row)
+    const bool want_d = grad_faces && ((return_rgb && grad_rgb_img && rgb_img) ||
+                                       (return_alpha && grad_alpha_img && alpha_img));
+    if (want_d) {
+        const int rr = return_rgb && grad_rgb_img && rgb_img, ra = return_alpha && grad_alpha_img && alpha_img;
+        PixelMapParams p{faces, face_index_map, rgb_img, alpha_img, grad_rgb_img, grad_alpha_img,
+                         grad_faces, batch_size, num_faces, image_size, eps, rr, ra, 1};
+        rc = launch1d(pixel_map_kernel<true>, nfaces * 8, s, p);
+        if (rc != MR_OK) return rc;
+    }
+    const bool want_f = grad_faces && return_depth && grad_depth_img;
+    const bool gather_tex = grad_textures && texture_size == 2 && eps >= 1e-6f && !(flags & 1);
+    if (grad_textures && !gather_tex) {
+        const size_t bytes = (size_t)nfaces * texture_size * texture_size * texture_size * 3 * sizeof(float);
+        hipError_t e = hipMemsetAsync(grad_textures, 0, bytes, s);
+        if (e != hipSuccess) return (int)e;
+        rc = launch1d(textures_atomic_recompute_kernel<true>, npx, s, faces, face_index_map, grad_rgb_img,
+                      grad_textures, npx, num_faces, image_size, texture_size, eps);
+        if (rc != MR_OK) return rc;
+    }
+    if (gather_tex || grad_faces) {
+        GatherParams g{};
+        g.faces = faces; g.fim = face_index_map;
+        g.grad_rgb = gather_tex ? grad_rgb_img : nullptr;
+        g.grad_depth = want_f ? grad_depth_img : nullptr;
+        g.grad_faces = grad_faces;
+        g.grad_textures = gather_tex ? grad_textures : nullptr;
+        g.B = batch_size; g.F = num_faces; g.is = image_size; g.eps = eps;
+        g.accumulate_faces = want_d ? 1 : 0;
+        if (gather_tex || want_f || !want_d) rc = launch1d(gather_kernel<true>, nfaces, s, g);
+    }
+    return rc;
+}

@@ -1,0 +1,474 @@
+// raster_fwd.hip -- forward rasteriser for gfx950 (MI355X).
+//
+// Replaces upstream kernels forward_face_index_map_{1,2} + forward_texture_sampling and the
+// Python epilogue of RasterizeFunction.forward / rasterize_rgbad
+// (/root/reference/meshreg/neurender/rasterize.py:87-103, 413-428).
+//
+// Design (not the upstream "every pixel loops over every face" scheme):
+//   1. face_setup_kernel   one thread per face: back-face cull + conservative pixel bbox
+//                          (8 B record), optional faces_inv for the upstream-compatible API.
+//   2. raster_tile_kernel  one 256-thread workgroup per 32x32 screen tile.  Each of the 4
+//                          waves scans a quarter of the image's bbox records (coalesced 8-B
+//                          loads), ballots the faces that touch the tile and compacts them
+//                          (wave64 ballot + popcount prefix) into a wave-private LDS queue.
+//                          Small faces are drained 64 at a time, ONE LANE PER FACE walking
+//                          the face's few bbox pixels; large faces are walked by the whole
+//                          wave, one lane per pixel.  Depth test = ds_min_u64 on a per-tile
+//                          LDS z-buffer holding (ordered(zp) << 32 | face_index): a
+//                          lexicographic min, i.e. exactly upstream's "strict < in ascending
+//                          face order" (nearest face, lowest index on ties), independent of
+//                          processing order.
+//   3. resolve (same kernel) each thread owns 4 pixels: decode winner, recompute its
+//                          barycentrics (bit-identical to the winning test), sample the
+//                          texture, blend background, write every output plane once,
+//                          already vertically flipped / NCHW for the image-space outputs.
+// HBM traffic: faces 36 B + 8 B record per face, outputs written exactly once; no
+// per-pixel memset, no sampling maps, no separate flip / permute / alpha / background pass.
+#include "mr_common.hpp"
+
+namespace mr {
+
+constexpr int TILE = 32;              // tile edge in pixels
+constexpr int TPB = 256;              // threads per workgroup (4 waves)
+constexpr int PX_PER_THREAD = TILE * TILE / TPB;
+constexpr int SMALL_MAX = 32;         // bbox-in-tile area up to which one lane walks a face
+constexpr int QCAP = 128;             // wave-private queue capacity (>= 2 * 64)
+
+__global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict__ faces,
+                                                         FaceBox* __restrict__ boxes,
+                                                         float* __restrict__ faces_inv,
+                                                         int64_t total, int is) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[k] = faces[i * 9 + k];
+    if (boxes) boxes[i] = face_box(f, is);
+    if (faces_inv && !backfacing(f)) {
+        float inv[9];
+        face_inverse(f, inv, is);
+#pragma unroll
+        for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = inv[k];
+    }
+}
+
+struct FwdParams {
+    const float* faces;
+    const FaceBox* boxes;
+    const float* textures;
+    const float* background;
+    int bg_stride;
+    float* rgb;            // FUSED: [B,3,is,is] image orientation
+    float* alpha;          // FUSED: [B,is,is] image orientation
+    float* depth;          // FUSED: image orientation; COMPAT: raster orientation
+    int32_t* fim;          // raster orientation
+    float* weight;         // [B,is,is,3] raster orientation
+    float* face_inv_map;   // [B,is,is,9] raster orientation (nullable)
+    int B, F, is, ts;
+    float near_, far_, eps;
+    int tiles_x;           // tiles per row (= per column)
+    const unsigned long long* keys;  // validation only: precomputed z-buffer keys (skip the scan)
+};
+
+__device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float zp, int fn) {
+    const unsigned long long key = ((unsigned long long)f2ord(zp) << 32) | (unsigned)fn;
+    atomicMin(&zb[idx], key);
+}
+
+// FUSED = true : write every pixel of every requested plane (fused epilogue).
+// FUSED = false: upstream-compatible forward_face_index_map: touch hit pixels only.
+template <bool FUSED>
+__global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
+    __shared__ unsigned long long zbuf[TILE * TILE];
+    __shared__ int queue[TPB / MR_WAVE][QCAP];
+
+    const unsigned nblocks = gridDim.x;
+    const unsigned lid = xcd_remap(blockIdx.x, nblocks);
+    const int tiles_per_img = p.tiles_x * p.tiles_x;
+    const int b = lid / tiles_per_img;
+    const int t = lid % tiles_per_img;
+    const int tx0 = (t % p.tiles_x) * TILE, ty0 = (t / p.tiles_x) * TILE;
+    const int tx1 = min(tx0 + TILE, p.is) - 1, ty1 = min(ty0 + TILE, p.is) - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int is = p.is;
+
+#pragma unroll
+    for (int j = 0; j < PX_PER_THREAD; j++) zbuf[tid + j * TPB] = ~0ull;
+    __syncthreads();
+
+    const float* faces_b = p.faces + (int64_t)b * p.F * 9;
+    const FaceBox* boxes_b = p.boxes + (int64_t)b * p.F;
+    int* q = queue[wave];
+    int qn = 0;  // wave-uniform
+
+    // one lane per small face: walk its bbox clipped to the tile
+    auto drain = [&](int count) {
+        if (lane < count) {
+            const int fn = q[lane];
+            const FaceBox bx = boxes_b[fn];
+            Face f;
+            load_face(faces_b + (int64_t)fn * 9, f, is);
+            const int x0 = max((int)bx.x0, tx0), x1 = min((int)bx.x1, tx1);
+            const int y0 = max((int)bx.y0, ty0), y1 = min((int)bx.y1, ty1);
+            for (int yi = y0; yi <= y1; yi++)
+                for (int xi = x0; xi <= x1; xi++) {
+                    float zp, w[3];
+                    if (cover(f, xi, yi, is, p.near_, p.far_, zp, w))
+                        zbuf_min(zbuf, (yi - ty0) * TILE + (xi - tx0), zp, fn);
+                }
+        }
+    };
+
+    // each wave scans a contiguous quarter of the face records
+    const int per_wave = (p.F + 3) / 4;
+    const int f_begin = wave * per_wave;
+    const int f_end = p.keys ? f_begin : min(f_begin + per_wave, p.F);
+    for (int base = f_begin; base < f_end; base += MR_WAVE) {
+        const int fn = base + lane;
+        bool hit = false, big = false;
+        FaceBox bx;
+        bx.x0 = 1; bx.x1 = 0; bx.y0 = 1; bx.y1 = 0;
+        if (fn < f_end) {
+            bx = boxes_b[fn];
+            hit = (bx.x0 <= bx.x1) && (bx.x0 <= tx1) && (bx.x1 >= tx0) && (bx.y0 <= ty1) && (bx.y1 >= ty0);
+            if (hit) {
+                const int w = min((int)bx.x1, tx1) - max((int)bx.x0, tx0) + 1;
+                const int h = min((int)bx.y1, ty1) - max((int)bx.y0, ty0) + 1;
+                big = w * h > SMALL_MAX;
+            }
+        }
+        const unsigned long long m_small = __ballot(hit && !big);
+        unsigned long long m_big = __ballot(hit && big);
+        if (hit && !big) q[qn + __popcll(m_small & ((1ull << lane) - 1ull))] = fn;
+        qn += __popcll(m_small);
+        if (qn >= MR_WAVE) {
+            drain(MR_WAVE);
+            // move the tail of the queue to the front (wave-synchronous, <= 63 entries)
+            const int rest = qn - MR_WAVE;
+            int v = (lane < rest) ? q[MR_WAVE + lane] : 0;
+            if (lane < rest) q[lane] = v;
+            qn = rest;
+        }
+        // large faces: the whole wave walks the clipped bbox, one lane per pixel
+        while (m_big) {
+            const int src = __ffsll((long long)m_big) - 1;
+            m_big &= m_big - 1;
+            const int fb = base + src;
+            const int bx0 = max(__shfl((int)bx.x0, src), tx0), bx1 = min(__shfl((int)bx.x1, src), tx1);
+            const int by0 = max(__shfl((int)bx.y0, src), ty0), by1 = min(__shfl((int)bx.y1, src), ty1);
+            Face f;
+            load_face(faces_b + (int64_t)fb * 9, f, is);
+            const int bw = bx1 - bx0 + 1, n = bw * (by1 - by0 + 1);
+            for (int i = lane; i < n; i += MR_WAVE) {
+                const int xi = bx0 + i % bw, yi = by0 + i / bw;
+                float zp, w[3];
+                if (cover(f, xi, yi, is, p.near_, p.far_, zp, w))
+                    zbuf_min(zbuf, (yi - ty0) * TILE + (xi - tx0), zp, fb);
+            }
+        }
+    }
+    if (qn > 0) drain(qn);
+    if (p.keys) {
+#pragma unroll
+        for (int j = 0; j < PX_PER_THREAD; j++) {
+            const int ly = (tid >> 5) + j * (TPB / TILE), lx = tid & (TILE - 1);
+            if (tx0 + lx < is && ty0 + ly < is)
+                zbuf[ly * TILE + lx] = p.keys[((int64_t)b * is + ty0 + ly) * is + tx0 + lx];
+        }
+    }
+    __syncthreads();
+
+    // resolve: thread owns pixels (x = tid % 32, y = tid / 32 + 8 j)
+    const int px = tx0 + (tid & (TILE - 1));
+#pragma unroll
+    for (int j = 0; j < PX_PER_THREAD; j++) {
+        const int ly = (tid >> 5) + j * (TPB / TILE);
+        const int py = ty0 + ly;
+        if (px >= is || py >= is) continue;
+        const unsigned long long key = zbuf[ly * TILE + (tid & (TILE - 1))];
+        const bool hitpx = key != ~0ull;
+        const int64_t ri = ((int64_t)b * is + py) * is + px;            // raster orientation
+        const int64_t ii = ((int64_t)b * is + (is - 1 - py)) * is + px;  // image orientation
+        if (!hitpx) {
+            if (FUSED) {
+                p.fim[ri] = -1;
+                p.weight[ri * 3 + 0] = 0.0f; p.weight[ri * 3 + 1] = 0.0f; p.weight[ri * 3 + 2] = 0.0f;
+                if (p.depth) p.depth[ii] = p.far_;
+                if (p.alpha) p.alpha[ii] = 0.0f;
+                if (p.rgb) {
+                    const float* bg = p.background + (int64_t)b * p.bg_stride;
+                    const int64_t plane = (int64_t)is * is;
+                    const int64_t o = ((int64_t)b * 3 * is + (is - 1 - py)) * is + px;
+                    p.rgb[o] = bg[0]; p.rgb[o + plane] = bg[1]; p.rgb[o + 2 * plane] = bg[2];
+                }
+                if (p.face_inv_map)
+#pragma unroll
+                    for (int k = 0; k < 9; k++) p.face_inv_map[ri * 9 + k] = 0.0f;
+            }
+            continue;
+        }
+        const int fn = (int)(unsigned)(key & 0xffffffffull);
+        const float zp = ord2f((uint32_t)(key >> 32));
+        Face f;
+        load_face(faces_b + (int64_t)fn * 9, f, is);
+        // barycentrics of the winner, recomputed with the arithmetic of cover()
+        float w[3], zp2;
+        bary(f, px, py, zp2, w);
+        (void)zp2;
+        p.fim[ri] = fn;
+        p.weight[ri * 3 + 0] = w[0]; p.weight[ri * 3 + 1] = w[1]; p.weight[ri * 3 + 2] = w[2];
+        if (p.face_inv_map)
+#pragma unroll
+            for (int k = 0; k < 9; k++) p.face_inv_map[ri * 9 + k] = f.inv[k];
+        if (!FUSED) {
+            p.depth[ri] = zp;
+            continue;
+        }
+        if (p.depth) p.depth[ii] = zp;
+        if (p.alpha) p.alpha[ii] = 1.0f;
+        if (p.rgb) {
+            const int ts = p.ts;
+            const float* tex = p.textures + ((int64_t)b * p.F + fn) * ts * ts * ts * 3;
+            float tif[3];
+            tex_coords(w, zp, f.v, ts, p.eps, tif);
+            float c[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int pn = 0; pn < 8; pn++) {
+                float wg; int isc;
+                tex_tap(tif, pn, ts, wg, isc);
+#pragma unroll
+                for (int k = 0; k < 3; k++) c[k] += wg * tex[isc * 3 + k];
+            }
+            // rgb * mask + (1 - mask) * background with mask == 1 (rasterize.py:251-260)
+            const float* bg = p.background + (int64_t)b * p.bg_stride;
+            const int64_t plane = (int64_t)is * is;
+            const int64_t o = ((int64_t)b * 3 * is + (is - 1 - py)) * is + px;
+#pragma unroll
+            for (int k = 0; k < 3; k++) p.rgb[o + k * plane] = c[k] * 1.0f + 0.0f * bg[k];
+        }
+    }
+}
+
+// Validation-only variant (flags & MR_FLAG_REFERENCE_ALGO): upstream's structure, every pixel
+// tests every face in ascending order with a strict '<'.  Writes the z-buffer key per pixel
+// into `keys` (B*is*is u64), then the tile kernel's resolve is reused through a second launch.
+__global__ void __launch_bounds__(256) raster_brute_kernel(const float* __restrict__ faces, int B, int F,
+                                                           int is, float near_, float far_,
+                                                           unsigned long long* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * is * is) return;
+    const int b = (int)(i / ((int64_t)is * is));
+    const int pn = (int)(i % ((int64_t)is * is));
+    const int yi = pn / is, xi = pn % is;
+    float depth_min = far_;
+    int fmin_ = -1;
+    for (int fn = 0; fn < F; fn++) {
+        const float* g = faces + ((int64_t)b * F + fn) * 9;
+        float v[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) v[k] = g[k];
+        if (backfacing(v)) continue;
+        Face f;
+#pragma unroll
+        for (int k = 0; k < 9; k++) f.v[k] = v[k];
+        face_inverse(f.v, f.inv, is);
+        float zp, w[3];
+        if (!cover(f, xi, yi, is, near_, far_, zp, w)) continue;
+        if (zp < depth_min) { depth_min = zp; fmin_ = fn; }
+    }
+    keys[i] = (fmin_ >= 0) ? (((unsigned long long)f2ord(depth_min) << 32) | (unsigned)fmin_) : ~0ull;
+}
+
+// Upstream forward_texture_sampling on caller-provided maps (raster orientation, NHWC).
+__global__ void __launch_bounds__(256) texture_sampling_kernel(
+    const float* __restrict__ faces, const float* __restrict__ textures,
+    const int32_t* __restrict__ fim, const float* __restrict__ weight_map,
+    const float* __restrict__ depth_map, float* __restrict__ rgb_map,
+    int32_t* __restrict__ sidx_map, float* __restrict__ swgt_map, int64_t npx, int F, int is, int ts,
+    float eps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const int fn = fim[i];
+    if (fn < 0) return;
+    const int64_t bn = i / ((int64_t)is * is);
+    const float* face = faces + (bn * F + fn) * 9;
+    const float* tex = textures + (bn * F + fn) * ts * ts * ts * 3;
+    float v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = face[k];
+    float w[3] = {weight_map[i * 3], weight_map[i * 3 + 1], weight_map[i * 3 + 2]};
+    float tif[3];
+    tex_coords(w, depth_map[i], v, ts, eps, tif);
+    float c[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int pn = 0; pn < 8; pn++) {
+        float wg; int isc;
+        tex_tap(tif, pn, ts, wg, isc);
+#pragma unroll
+        for (int k = 0; k < 3; k++) c[k] += wg * tex[isc * 3 + k];
+        sidx_map[i * 8 + pn] = isc;
+        swgt_map[i * 8 + pn] = wg;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) rgb_map[i * 3 + k] = c[k];
+}
+
+__global__ void __launch_bounds__(256) face_inv_map_kernel(const float* __restrict__ faces,
+                                                           const int32_t* __restrict__ fim,
+                                                           float* __restrict__ out, int64_t npx, int F, int is) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const int fn = fim[i];
+    float inv[9];
+    if (fn >= 0) {
+        const int64_t b = i / ((int64_t)is * is);
+        float v[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) v[k] = faces[(b * F + fn) * 9 + k];
+        face_inverse(v, inv, is);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) inv[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) out[i * 9 + k] = inv[k];
+}
+
+static int launch_setup(const float* faces, FaceBox* boxes, float* faces_inv, int B, int F, int is,
+                        hipStream_t s) {
+    const int64_t total = (int64_t)B * F;
+    if (total == 0) return MR_OK;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(face_setup_kernel, dim3(blocks), dim3(256), 0, s, faces, boxes, faces_inv, total, is);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+template <bool FUSED>
+static int launch_tiles(FwdParams& p, hipStream_t s) {
+    p.tiles_x = (p.is + TILE - 1) / TILE;
+    const int64_t nblocks = (int64_t)p.B * p.tiles_x * p.tiles_x;
+    if (nblocks == 0) return MR_OK;
+    if (nblocks > 0x7fffffffLL) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(raster_tile_kernel<FUSED>, dim3((unsigned)nblocks), dim3(TPB), 0, s, p);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+extern "C" int64_t mr_render_workspace_bytes(int batch_size, int num_faces, int image_size) {
+    (void)image_size;
+    if (batch_size < 0 || num_faces < 0) return MR_ERR_BADARG;
+    return (((int64_t)batch_size * num_faces * (int64_t)sizeof(FaceBox)) + 255) & ~255LL;
+}
+
+extern "C" int mr_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
+                                         float* depth_map, float* face_inv_map, float* faces_inv,
+                                         int batch_size, int num_faces, int image_size, float near_,
+                                         float far_, int return_rgb, int return_alpha, int return_depth,
+                                         mr_stream_t stream) {
+    (void)return_rgb; (void)return_alpha;
+    if (!faces || !face_index_map || !weight_map || !depth_map || !faces_inv) return MR_ERR_BADARG;
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
+    if (return_depth && !face_inv_map) return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    FaceBox* boxes = nullptr;
+    const size_t bytes = (size_t)mr_render_workspace_bytes(batch_size, num_faces, image_size) + 256;
+    hipError_t e = hipMallocAsync((void**)&boxes, bytes, s);
+    if (e != hipSuccess) return (int)e;
+    int rc = launch_setup(faces, boxes, faces_inv, batch_size, num_faces, image_size, s);
+    if (rc == MR_OK) {
+        FwdParams p{};
+        p.faces = faces; p.boxes = boxes; p.depth = depth_map; p.fim = face_index_map;
+        p.weight = weight_map; p.face_inv_map = return_depth ? face_inv_map : nullptr;
+        p.B = batch_size; p.F = num_faces; p.is = image_size; p.ts = 1;
+        p.near_ = near_; p.far_ = far_; p.eps = 0.0f;
+        rc = launch_tiles<false>(p, s);
+    }
+    e = hipFreeAsync(boxes, s);
+    if (rc == MR_OK && e != hipSuccess) rc = (int)e;
+    return rc;
+}
+
+extern "C" int mr_forward_texture_sampling(const float* faces, const float* textures,
+                                           const int32_t* face_index_map, const float* weight_map,
+                                           const float* depth_map, float* rgb_map,
+                                           int32_t* sampling_index_map, float* sampling_weight_map,
+                                           int batch_size, int num_faces, int image_size,
+                                           int texture_size, float eps, mr_stream_t stream) {
+    if (!faces || !textures || !face_index_map || !weight_map || !depth_map || !rgb_map ||
+        !sampling_index_map || !sampling_weight_map)
+        return MR_ERR_BADARG;
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0 || texture_size < 2) return MR_ERR_BADARG;
+    const int64_t npx = (int64_t)batch_size * image_size * image_size;
+    if (npx == 0) return MR_OK;
+    hipLaunchKernelGGL(texture_sampling_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, faces, textures, face_index_map, weight_map, depth_map,
+                       rgb_map, sampling_index_map, sampling_weight_map, npx, num_faces, image_size,
+                       texture_size, eps);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_render_forward(const float* faces, const float* textures, const float* background,
+                                 int bg_stride, float* rgb_img, float* alpha_img, float* depth_img,
+                                 int32_t* face_index_map, float* weight_map, float* face_inv_map,
+                                 void* workspace, int64_t workspace_bytes, int batch_size,
+                                 int num_faces, int image_size, int texture_size, float near_,
+                                 float far_, float eps, int return_rgb, int return_alpha,
+                                 int return_depth, int flags, mr_stream_t stream) {
+    if ((!faces && num_faces > 0) || !face_index_map || !weight_map || !workspace) return MR_ERR_BADARG;
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
+    if (return_rgb && (!rgb_img || (!textures && num_faces > 0) || !background || texture_size < 2))
+        return MR_ERR_BADARG;
+    if (return_rgb && bg_stride != 0 && bg_stride != 3) return MR_ERR_BADARG;
+    if (return_alpha && !alpha_img) return MR_ERR_BADARG;
+    if (return_depth && !depth_img) return MR_ERR_BADARG;
+    if (workspace_bytes < mr_render_workspace_bytes(batch_size, num_faces, image_size)) return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    FaceBox* boxes = (FaceBox*)workspace;
+    int rc = launch_setup(faces, boxes, nullptr, batch_size, num_faces, image_size, s);
+    if (rc != MR_OK) return rc;
+    FwdParams p{};
+    p.faces = faces; p.boxes = boxes; p.textures = textures; p.background = background;
+    p.bg_stride = bg_stride;
+    p.rgb = return_rgb ? rgb_img : nullptr;
+    p.alpha = return_alpha ? alpha_img : nullptr;
+    p.depth = return_depth ? depth_img : nullptr;
+    p.fim = face_index_map; p.weight = weight_map;
+    p.face_inv_map = face_inv_map;
+    p.B = batch_size; p.F = num_faces; p.is = image_size; p.ts = return_rgb ? texture_size : 1;
+    p.near_ = near_; p.far_ = far_; p.eps = eps;
+    if (flags & MR_FLAG_REFERENCE_ALGO) {
+        const int64_t npx = (int64_t)batch_size * image_size * image_size;
+        unsigned long long* keys = nullptr;
+        hipError_t e = hipMallocAsync((void**)&keys, (size_t)npx * 8 + 256, s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(raster_brute_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, faces,
+                           batch_size, num_faces, image_size, near_, far_, keys);
+        rc = (int)hipGetLastError();
+        p.keys = keys;
+        if (rc == MR_OK) rc = launch_tiles<true>(p, s);
+        e = hipFreeAsync(keys, s);
+        if (rc == MR_OK && e != hipSuccess) rc = (int)e;
+        return rc;
+    }
+    return launch_tiles<true>(p, s);
+}
+
+extern "C" int mr_face_inv_map(const float* faces, const int32_t* face_index_map, float* face_inv_map,
+                               int batch_size, int num_faces, int image_size, mr_stream_t stream) {
+    if (!faces || !face_index_map || !face_inv_map) return MR_ERR_BADARG;
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0) return MR_ERR_BADARG;
+    const int64_t npx = (int64_t)batch_size * image_size * image_size;
+    if (npx == 0) return MR_OK;
+    hipLaunchKernelGGL(face_inv_map_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, faces, face_index_map, face_inv_map, npx, num_faces, image_size);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}

@@ -1,0 +1,581 @@
+// warp.hip -- photometric warp kernels for gfx950 (MI355X).
+//
+// Replaces the PyTorch op chains of /root/reference/meshreg/warping/imgflowarp.py:
+//   warp (:31-55)                  -> warp_forward_kernel / warp_backward_kernel
+//   get_occlusion_mask (:118-172)  -> occlusion_kernel (four chained nearest warps fused into
+//                                     two dependent gathers per pixel, no intermediates)
+//   pair_consist (:58-115) + PyramidCriterion('l1').compute (pyramidloss.py:56-62) +
+//   batch_masked_mean_loss (lossutils.py:1-8)
+//                                  -> pair_consist_forward_kernel (both directions, 8 grid
+//                                     samples, mask algebra and the masked L1 sums in ONE pass
+//                                     over the pixels) + finalize + backward w.r.t. the flows.
+// All are HBM-streaming kernels: one lane per pixel, channel planes read coalesced, the
+// bilinear taps hit L1/L2 (flows are a few pixels).  Reductions are two-stage and
+// deterministic (fixed-order block partials -> per-sample finalize), no float atomics.
+//
+// grid_sample semantics restated (torch, zeros padding, align_corners=False):
+//   vx = 2 (x + u) / max(W - 1, 1) - 1 ;  ix = ((vx + 1) W - 1) / 2        
+#include "mr_common.hpp"
+
+namespace mr {
+
+struct Taps {
+    int x0, y0;            // north-west tap
+    float nw, ne, sw, se;  // bilinear weights
+    float ix, iy;
+};
+
+__device__ __forceinline__ void sample_pos(float x, float y, float u, float v, int W, int H, float& ix,
+                                           float& iy) {
+    const float gx = x + u, gy = y + v;
+    const float vx = 2.0f * gx / (float)max(W - 1, 1) - 1.0f;
+    const float vy = 2.0f * gy / (float)max(H - 1, 1) - 1.0f;
+    ix = ((vx + 1.0f) * (float)W - 1.0f) / 2.0f;
+    iy = ((vy + 1.0f) * (float)H - 1.0f) / 2.0f;
+}
+
+__device__ __forceinline__ Taps make_taps(float ix, float iy) {
+    Taps t;
+    t.ix = ix; t.iy = iy;
+    const float fx = floorf(ix), fy = floorf(iy);
+    // clamp before the int conversion so that huge / non-finite positions are simply out of bounds
+    t.x0 = (int)fminf(fmaxf(fx, -4.0f), 1.0e9f);
+    t.y0 = (int)fminf(fmaxf(fy, -4.0f), 1.0e9f);
+    if (!(fx == fx)) t.x0 = -4;
+    if (!(fy == fy)) t.y0 = -4;
+    const float ix_se = fx + 1.0f, iy_se = fy + 1.0f;
+    t.nw = (ix_se - ix) * (iy_se - iy);
+    t.ne = (ix - fx) * (iy_se - iy);
+    t.sw = (ix_se - ix) * (iy - fy);
+    t.se = (ix - fx) * (iy - fy);
+    return t;
+}
+
+__device__ __forceinline__ bool inb(int x, int y, int W, int H) { return x >= 0 && x < W && y >= 0 && y < H; }
+
+// bilinear sample of one channel plane (zeros padding), accumulation order nw, ne, sw, se
+__device__ __forceinline__ float bilin(const float* __restrict__ plane, const Taps& t, int W, int H) {
+    float acc = 0.0f;
+    if (inb(t.x0, t.y0, W, H)) acc += plane[(int64_t)t.y0 * W + t.x0] * t.nw;
+    if (inb(t.x0 + 1, t.y0, W, H)) acc += plane[(int64_t)t.y0 * W + t.x0 + 1] * t.ne;
+    if (inb(t.x0, t.y0 + 1, W, H)) acc += plane[(int64_t)(t.y0 + 1) * W + t.x0] * t.sw;
+    if (inb(t.x0 + 1, t.y0 + 1, W, H)) acc += plane[(int64_t)(t.y0 + 1) * W + t.x0 + 1] * t.se;
+    return acc;
+}
+
+// bilinear sample of an all-ones image = sum of the in-bounds weights, binarised as
+// imgflowarp.py:52-53 (mask[mask < thresh] = 0; mask[mask > 0] = 1)
+__device__ __forceinline__ float valid_mask(const Taps& t, int W, int H, float thresh) {
+    float acc = 0.0f;
+    if (inb(t.x0, t.y0, W, H)) acc += t.nw;
+    if (inb(t.x0 + 1, t.y0, W, H)) acc += t.ne;
+    if (inb(t.x0, t.y0 + 1, W, H)) acc += t.sw;
+    if (inb(t.x0 + 1, t.y0 + 1, W, H)) acc += t.se;
+    if (acc < thresh) acc = 0.0f;
+    if (acc > 0.0f) acc = 1.0f;
+    return acc;
+}
+
+// d(sample)/d(ix), d(sample)/d(iy) of one channel plane
+__device__ __forceinline__ void bilin_grad(const float* __restrict__ plane, const Taps& t, int W, int H,
+                                           float& gix, float& giy) {
+    const float fx = (float)t.x0, fy = (float)t.y0;
+    const float ix_se = fx + 1.0f, iy_se = fy + 1.0f;
+    gix = 0.0f; giy = 0.0f;
+    if (inb(t.x0, t.y0, W, H)) {
+        const float v = plane[(int64_t)t.y0 * W + t.x0];
+        gix -= v * (iy_se - t.iy); giy -= v * (ix_se - t.ix);
+    }
+    if (inb(t.x0 + 1, t.y0, W, H)) {
+        const float v = plane[(int64_t)t.y0 * W + t.x0 + 1];
+        gix += v * (iy_se - t.iy); giy -= v * (t.ix - fx);
+    }
+    if (inb(t.x0, t.y0 + 1, W, H)) {
+        const float v = plane[(int64_t)(t.y0 + 1) * W + t.x0];
+        gix -= v * (t.iy - fy); giy += v * (ix_se - t.ix);
+    }
+    if (inb(t.x0 + 1, t.y0 + 1, W, H)) {
+        const float v = plane[(int64_t)(t.y0 + 1) * W + t.x0 + 1];
+        gix += v * (t.iy - fy); giy += v * (t.ix - fx);
+    }
+}
+
+__device__ __forceinline__ void nearest_idx(float ix, float iy, int& xn, int& yn) {
+    const float rx = rintf(ix), ry = rintf(iy);  // round half to even, as nearbyint
+    xn = (rx == rx) ? (int)fminf(fmaxf(rx, -4.0f), 1.0e9f) : -4;
+    yn = (ry == ry) ? (int)fminf(fmaxf(ry, -4.0f), 1.0e9f) : -4;
+}
+
+// ---------------------------------------------------------------------------------------
+// warp
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) warp_forward_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ flow,
+                                                           float* __restrict__ out, float* __restrict__ mask,
+                                                           int B, int C, int H, int W, float thresh, int mode) {
+    const int64_t hw = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * hw) return;
+    const int b = (int)(i / hw);
+    const int64_t pix = i % hw;
+    const int yy = (int)(pix / W), xx = (int)(pix % W);
+    const float u = flow[((int64_t)b * 2 + 0) * hw + pix], v = flow[((int64_t)b * 2 + 1) * hw + pix];
+    float ix, iy;
+    sample_pos((float)xx, (float)yy, u, v, W, H, ix, iy);
+    if (mode == 0) {
+        const Taps t = make_taps(ix, iy);
+        const float m = valid_mask(t, W, H, thresh);
+        for (int c = 0; c < C; c++) {
+            const int64_t o = ((int64_t)b * C + c) * hw;
+            out[o + pix] = bilin(x + o, t, W, H) * m;
+            mask[o + pix] = m;
+        }
+    } else {
+        int xn, yn;
+        nearest_idx(ix, iy, xn, yn);
+        const bool ok = inb(xn, yn, W, H);
+        float m = ok ? 1.0f : 0.0f;
+        if (m < thresh) m = 0.0f;
+        if (m > 0.0f) m = 1.0f;
+        for (int c = 0; c < C; c++) {
+            const int64_t o = ((int64_t)b * C + c) * hw;
+            const float s = ok ? x[o + (int64_t)yn * W + xn] : 0.0f;
+            out[o + pix] = s * m;
+            mask[o + pix] = m;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) warp_backward_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ flow,
+                                                            const float* __restrict__ grad_out,
+                                                            float* __restrict__ grad_x,
+                                                            float* __restrict__ grad_flow, int B, int C, int H,
+                                                            int W, float thresh, int mode) {
+    const int64_t hw = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * hw) return;
+    const int b = (int)(i / hw);
+    const int64_t pix = i % hw;
+    const int yy = (int)(pix / W), xx = (int)(pix % W);
+    const float u = flow[((int64_t)b * 2 + 0) * hw + pix], v = flow[((int64_t)b * 2 + 1) * hw + pix];
+    float ix, iy;
+    sample_pos((float)xx, (float)yy, u, v, W, H, ix, iy);
+    float gu = 0.0f, gv = 0.0f;
+    if (mode == 0) {
+        const Taps t = make_taps(ix, iy);
+        const float m = valid_mask(t, W, H, thresh);
+        for (int c = 0; c < C; c++) {
+            const int64_t o = ((int64_t)b * C + c) * hw;
+            const float g = grad_out[o + pix] * m;
+            if (grad_flow) {
+                float gix, giy;
+                bilin_grad(x + o, t, W, H, gix, giy);
+                gu += g * gix;
+                gv += g * giy;
+            }
+            if (grad_x && g != 0.0f) {
+                if (inb(t.x0, t.y0, W, H)) atomicAdd(&grad_x[o + (int64_t)t.y0 * W + t.x0], g * t.nw);
+                if (inb(t.x0 + 1, t.y0, W, H)) atomicAdd(&grad_x[o + (int64_t)t.y0 * W + t.x0 + 1], g * t.ne);
+                if (inb(t.x0, t.y0 + 1, W, H)) atomicAdd(&grad_x[o + (int64_t)(t.y0 + 1) * W + t.x0], g * t.sw);
+                if (inb(t.x0 + 1, t.y0 + 1, W, H))
+                    atomicAdd(&grad_x[o + (int64_t)(t.y0 + 1) * W + t.x0 + 1], g * t.se);
+            }
+        }
+        // d ix / d u = (W / 2) * (2 / max(W - 1, 1))
+        gu = gu * ((float)W / 2.0f) * (2.0f / (float)max(W - 1, 1));
+        gv = gv * ((float)H / 2.0f) * (2.0f / (float)max(H - 1, 1));
+    } else if (grad_x) {
+        int xn, yn;
+        nearest_idx(ix, iy, xn, yn);
+        if (inb(xn, yn, W, H)) {
+            float m = 1.0f;
+            if (m < thresh) m = 0.0f;
+            for (int c = 0; c < C; c++) {
+                const int64_t o = ((int64_t)b * C + c) * hw;
+                const float g = grad_out[o + pix] * m;
+                if (g != 0.0f) atomicAdd(&grad_x[o + (int64_t)yn * W + xn], g);
+            }
+        }
+    }
+    if (grad_flow) {
+        grad_flow[((int64_t)b * 2 + 0) * hw + pix] = gu;
+        grad_flow[((int64_t)b * 2 + 1) * hw + pix] = gv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward-backward occlusion check
+// ---------------------------------------------------------------------------------------
+// One direction: occl_a(p) from (mask_a, mask_b, flow_ab, flow_ba).
+//   grid_a = [x/W, y/H, mask_a, mask_a]
+//   warp_ab(q)  = nearest(grid_a; q + flow_ba(q)) * mask_b(q)            (imgflowarp.py:132,134)
+//   warp_aba(p) = nearest(warp_ab; p + flow_ab(p)) * mask_a(p)           (:136,138)
+//   occl_a = occlusion_mask_from_warped_grid(grid_a, warp_aba)           (:145)
+__device__ __forceinline__ float occl_one(const float* __restrict__ mask_a, const float* __restrict__ mask_b,
+                                          const float* __restrict__ flow_ab,
+                                          const float* __restrict__ flow_ba, int64_t hw, int H, int W,
+                                          int xx, int yy, float dist_thresh, float wthresh) {
+    const int64_t pix = (int64_t)yy * W + xx;
+    const float ma_p = mask_a[pix];
+    // second warp: sample warp_ab at p + flow_ab(p)
+    float ix, iy;
+    sample_pos((float)xx, (float)yy, flow_ab[pix], flow_ab[hw + pix], W, H, ix, iy);
+    int qx, qy;
+    nearest_idx(ix, iy, qx, qy);
+    float wg[3] = {0.0f, 0.0f, 0.0f};  // channels x, y, mask of warp_ab at q
+    float m2 = inb(qx, qy, W, H) ? 1.0f : 0.0f;
+    if (m2 < wthresh) m2 = 0.0f;
+    if (m2 > 0.0f) {
+        const int64_t qpix = (int64_t)qy * W + qx;
+        // first warp: sample grid_a at q + flow_ba(q)
+        float jx, jy;
+        sample_pos((float)qx, (float)qy, flow_ba[qpix], flow_ba[hw + qpix], W, H, jx, jy);
+        int rx, ry;
+        nearest_idx(jx, jy, rx, ry);
+        float m1 = inb(rx, ry, W, H) ? 1.0f : 0.0f;
+        if (m1 < wthresh) m1 = 0.0f;
+        if (m1 > 0.0f) {
+            const float mb_q = mask_b[qpix];
+            const float ma_r = mask_a[(int64_t)ry * W + rx];
+            wg[0] = ((float)rx / (float)W) * m1 * mb_q;
+            wg[1] = ((float)ry / (float)H) * m1 * mb_q;
+            wg[2] = ma_r * m1 * mb_q;
+        }
+    }
+    float w3[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) w3[k] = wg[k] * m2 * ma_p;
+    const float g0 = (float)xx / (float)W, g1 = (float)yy / (float)H;
+    const float mask = ma_p * w3[2];
+    const float dx = (w3[0] - g0) * mask, dy = (w3[1] - g1) * mask;
+    const float displ = sqrtf(dx * dx + dy * dy);
+    const float motion = (displ < dist_thresh) ? 1.0f : 0.0f;
+    return mask * motion;
+}
+
+__global__ void __launch_bounds__(256) occlusion_kernel(const float* __restrict__ mask1,
+                                                        const float* __restrict__ mask2,
+                                                        const float* __restrict__ flow12,
+                                                        const float* __restrict__ flow21, int64_t fbstride,
+                                                        float* __restrict__ occl1, float* __restrict__ occl2,
+                                                        int B, int H, int W, float dist_thresh, float wthresh) {
+    const int64_t hw = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * hw) return;
+    const int b = (int)(i / hw);
+    const int64_t pix = i % hw;
+    const int yy = (int)(pix / W), xx = (int)(pix % W);
+    const float* m1 = mask1 + (int64_t)b * hw;
+    const float* m2 = mask2 + (int64_t)b * hw;
+    const float* f12 = flow12 + (int64_t)b * fbstride;
+    const float* f21 = flow21 + (int64_t)b * fbstride;
+    occl1[i] = occl_one(m1, m2, f12, f21, hw, H, W, xx, yy, dist_thresh, wthresh);
+    occl2[i] = occl_one(m2, m1, f21, f12, hw, H, W, xx, yy, dist_thresh, wthresh);
+}
+
+// ---------------------------------------------------------------------------------------
+// pair_consist
+// ---------------------------------------------------------------------------------------
+struct PairParams {
+    const float* flow12;  // [B,H,W,2]
+    const float* flow21;
+    const float* image_ref;  // [B,3,H,W]
+    const float* image;
+    const float* jitter_ref;  // [B,Cj,H,W]
+    const float* jitter;
+    int Cj;
+    float* partial;  // [B, nblk, 4]
+    uint8_t* full_mask1;
+    uint8_t* full_mask2;
+    float* warp_mask1;  // [B,3,H,W]
+    float* warp_mask2;
+    float* warp1;
+    float* warp2;
+    float* diff1;
+    float* diff2;
+    int B, H, W, nblk;
+    float thresh;
+};
+
+// one direction at one pixel: warp `src` with `flow`, gate with the jitter mask `jwarp`
+// warped by the same flow and with `jdirect` at the pixel, compare with `tgt`.
+struct DirOut {
+    float s[3];      // warped source * warp mask
+    float m;         // warp mask (before the jitter gate)
+    float wm[3];     // warp mask after the jitter gate, per jitter channel
+    bool valid;
+};
+
+__device__ __forceinline__ DirOut pair_dir(const float* __restrict__ flow, const float* __restrict__ src,
+                                           const float* __restrict__ jwarp, const float* __restrict__ jdirect,
+                                           int Cj, int b, int xx, int yy, int H, int W, float thresh, Taps& t) {
+    const int64_t hw = (int64_t)H * W;
+    const int64_t pix = (int64_t)yy * W + xx;
+    const float2 uv = *reinterpret_cast<const float2*>(flow + ((int64_t)b * hw + pix) * 2);
+    float ix, iy;
+    sample_pos((float)xx, (float)yy, uv.x, uv.y, W, H, ix, iy);
+    t = make_taps(ix, iy);
+    DirOut o;
+    o.m = valid_mask(t, W, H, thresh);
+#pragma unroll
+    for (int c = 0; c < 3; c++) o.s[c] = bilin(src + ((int64_t)b * 3 + c) * hw, t, W, H) * o.m;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int cj = (Cj == 3) ? c : 0;
+        const float js = bilin(jwarp + ((int64_t)b * Cj + cj) * hw, t, W, H) * o.m;
+        o.wm[c] = o.m * ((js == 1.0f) ? 1.0f : 0.0f);
+    }
+    o.valid = (o.wm[0] != 0.0f) && (uv.x != 0.0f) && (jdirect[(int64_t)b * Cj * hw + pix] == 1.0f);
+    return o;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) pair_consist_forward_kernel(PairParams p) {
+    __shared__ float red[4];
+    const int64_t hw = (int64_t)p.H * p.W;
+    const int b = blockIdx.y;
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sum1 = 0.0f, cnt1 = 0.0f, sum2 = 0.0f, cnt2 = 0.0f;
+    if (pix < hw) {
+        const int yy = (int)(pix / p.W), xx = (int)(pix % p.W);
+        Taps t;
+        // forward term: image_ref warped by flow21 vs image (imgflowarp.py:80,85-87,93-102)
+        const DirOut d1 = pair_dir(p.flow21, p.image_ref, p.jitter, p.jitter, p.Cj, b, xx, yy, p.H, p.W, p.thresh, t);
+        // backward term: image warped by flow12 vs image_ref (:84,82,88,99-107)
+        const DirOut d2 = pair_dir(p.flow12, p.image, p.jitter_ref, p.jitter_ref, p.Cj, b, xx, yy, p.H, p.W, p.thresh, t);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int64_t o = ((int64_t)b * 3 + c) * hw + pix;
+            const float df = fabsf(d1.s[c] - p.image[o]);
+            const float db = fabsf(d2.s[c] - p.image_ref[o]);
+            if (d1.valid) sum1 += df;
+            if (d2.valid) sum2 += db;
+            if (p.warp1) p.warp1[o] = d1.s[c];
+            if (p.warp2) p.warp2[o] = d2.s[c];
+            if (p.diff1) p.diff1[o] = df;
+            if (p.diff2) p.diff2[o] = db;
+            if (p.warp_mask1) p.warp_mask1[o] = d1.wm[c];
+            if (p.warp_mask2) p.warp_mask2[o] = d2.wm[c];
+        }
+        if (d1.valid) cnt1 = 3.0f;
+        if (d2.valid) cnt2 = 3.0f;
+        if (p.full_mask1) p.full_mask1[(int64_t)b * hw + pix] = d1.valid ? 1 : 0;
+        if (p.full_mask2) p.full_mask2[(int64_t)b * hw + pix] = d2.valid ? 1 : 0;
+    }
+    const float s1 = block_sum(sum1, red), c1 = block_sum(cnt1, red);
+    const float s2 = block_sum(sum2, red), c2 = block_sum(cnt2, red);
+    if (threadIdx.x == 0) {
+        float* o = p.partial + ((int64_t)b * p.nblk + blockIdx.x) * 4;
+        o[0] = s1; o[1] = c1; o[2] = s2; o[3] = c2;
+    }
+}
+
+// per-sample fixed-order reduction of the block partials -> sums[B,4], loss_fwd/bwd[B]
+__global__ void __launch_bounds__(64) pair_consist_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                                   float* __restrict__ sums,
+                                                                   float* __restrict__ loss_fwd,
+                                                                   float* __restrict__ loss_bwd) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = lane; j < nblk; j += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(partial + ((int64_t)b * nblk + j) * 4);
+        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[k] += __shfl_xor(a[k], off);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) sums[b * 4 + k] = a[k];
+        const float n1 = (a[1] == 0.0f) ? 1.0f : a[1], n2 = (a[3] == 0.0f) ? 1.0f : a[3];
+        if (loss_fwd) loss_fwd[b] = a[0] / n1;
+        if (loss_bwd) loss_bwd[b] = a[2] / n2;
+    }
+}
+
+struct PairBwdParams {
+    const float* flow12;
+    const float* flow21;
+    const float* image_ref;
+    const float* image;
+    const float* jitter_ref;
+    const float* jitter;
+    int Cj;
+    const float* sums;  // [B,4]
+    const float* grad_loss_fwd;
+    const float* grad_loss_bwd;  // nullable
+    float* grad_flow12;
+    float* grad_flow21;
+    int B, H, W;
+    float thresh;
+};
+
+__device__ __forceinline__ float2 pair_dir_grad(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                const DirOut& d, const Taps& t, int b, int64_t pix, int H,
+                                                int W, float coef) {
+    float gu = 0.0f, gv = 0.0f;
+    if (d.valid && coef != 0.0f) {
+        const int64_t hw = (int64_t)H * W;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int64_t o = ((int64_t)b * 3 + c) * hw;
+            const float r = d.s[c] - tgt[o + pix];
+            const float sg = (r > 0.0f) ? 1.0f : ((r < 0.0f) ? -1.0f : 0.0f);
+            const float g = sg * coef * d.m;
+            float gix, giy;
+            bilin_grad(src + o, t, W, H, gix, giy);
+            gu += g * gix;
+            gv += g * giy;
+        }
+        gu = gu * ((float)W / 2.0f) * (2.0f / (float)max(W - 1, 1));
+        gv = gv * ((float)H / 2.0f) * (2.0f / (float)max(H - 1, 1));
+    }
+    return make_float2(gu, gv);
+}
+
+__global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParams p) {
+    const int64_t hw = (int64_t)p.H * p.W;
+    const int b = blockIdx.y;
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= hw) return;
+    const int yy = (int)(pix / p.W), xx = (int)(pix % p.W);
+    const float c1 = p.sums[b * 4 + 1], c2 = p.sums[b * 4 + 3];
+    const float coef1 = p.grad_loss_fwd[b] / ((c1 == 0.0f) ? 1.0f : c1);
+    const float coef2 = p.grad_loss_bwd ? p.grad_loss_bwd[b] / ((c2 == 0.0f) ? 1.0f : c2) : 0.0f;
+    Taps t1, t2;
+    const DirOut d1 = pair_dir(p.flow21, p.image_ref, p.jitter, p.jitter, p.Cj, b, xx, yy, p.H, p.W, p.thresh, t1);
+    const float2 g21 = pair_dir_grad(p.image_ref, p.image, d1, t1, b, pix, p.H, p.W, coef1);
+    *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = g21;
+    float2 g12 = make_float2(0.0f, 0.0f);
+    if (p.grad_loss_bwd) {
+        const DirOut d2 =
+            pair_dir(p.flow12, p.image, p.jitter_ref, p.jitter_ref, p.Cj, b, xx, yy, p.H, p.W, p.thresh, t2);
+        g12 = pair_dir_grad(p.image, p.image_ref, d2, t2, b, pix, p.H, p.W, coef2);
+    }
+    *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = g12;
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" int mr_warp_forward(const float* x, const float* flow, float* out, float* mask, int batch_size,
+                               int channels, int height, int width, float thresh, int mode,
+                               mr_stream_t stream) {
+    if (!x || !flow || !out || !mask) return MR_ERR_BADARG;
+    if (batch_size < 0 || channels < 0 || height <= 0 || width <= 0 || (mode != 0 && mode != 1))
+        return MR_ERR_BADARG;
+    const int64_t n = (int64_t)batch_size * height * width;
+    if (n == 0 || channels == 0) return MR_OK;
+    hipLaunchKernelGGL(warp_forward_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, flow,
+                       out, mask, batch_size, channels, height, width, thresh, mode);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_warp_backward(const float* x, const float* flow, const float* grad_out, float* grad_x,
+                                float* grad_flow, int batch_size, int channels, int height, int width,
+                                float thresh, int mode, mr_stream_t stream) {
+    if (!x || !flow || !grad_out) return MR_ERR_BADARG;
+    if (batch_size < 0 || channels < 0 || height <= 0 || width <= 0 || (mode != 0 && mode != 1))
+        return MR_ERR_BADARG;
+    const int64_t n = (int64_t)batch_size * height * width;
+    if (n == 0 || (!grad_x && !grad_flow)) return MR_OK;
+    hipLaunchKernelGGL(warp_backward_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, flow,
+                       grad_out, grad_x, grad_flow, batch_size, channels, height, width, thresh, mode);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_occlusion_mask(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                                 const float* flow21, int64_t flow_bstride, float* occl1, float* occl2,
+                                 int batch_size, int height, int width, float distance_thresh,
+                                 float warp_thresh, mr_stream_t stream) {
+    if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2) return MR_ERR_BADARG;
+    if (batch_size < 0 || height <= 0 || width <= 0 || flow_bstride < 2LL * height * width) return MR_ERR_BADARG;
+    const int64_t n = (int64_t)batch_size * height * width;
+    if (n == 0) return MR_OK;
+    hipLaunchKernelGGL(occlusion_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, mask_flow1,
+                       mask_flow2, flow12, flow21, flow_bstride, occl1, occl2, batch_size, height, width,
+                       distance_thresh, warp_thresh);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int64_t mr_pair_consist_workspace_bytes(int batch_size, int height, int width) {
+    if (batch_size < 0 || height <= 0 || width <= 0) return MR_ERR_BADARG;
+    const int64_t nblk = ((int64_t)height * width + 255) / 256;
+    return (int64_t)batch_size * nblk * 4 * (int64_t)sizeof(float);
+}
+
+extern "C" int mr_pair_consist_forward(const float* flow12, const float* flow21, const float* image_ref,
+                                       const float* image, const float* jitter_ref, const float* jitter,
+                                       int jitter_channels, void* workspace, int64_t workspace_bytes,
+                                       float* sums, float* loss_fwd, float* loss_bwd, uint8_t* full_mask1,
+                                       uint8_t* full_mask2, float* warp_mask1, float* warp_mask2,
+                                       float* warp1, float* warp2, float* diff1, float* diff2,
+                                       int batch_size, int height, int width, float thresh,
+                                       mr_stream_t stream) {
+    if (!flow12 || !flow21 || !image_ref || !image || !jitter_ref || !jitter || !workspace || !sums)
+        return MR_ERR_BADARG;
+    if (jitter_channels != 1 && jitter_channels != 3) return MR_ERR_BADARG;
+    if (batch_size < 0 || height <= 0 || width <= 0) return MR_ERR_BADARG;
+    if (workspace_bytes < mr_pair_consist_workspace_bytes(batch_size, height, width)) return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    const int nblk = (int)(((int64_t)height * width + 255) / 256);
+    PairParams p{flow12, flow21, image_ref, image, jitter_ref, jitter, jitter_channels, (float*)workspace,
+                 full_mask1, full_mask2, warp_mask1, warp_mask2, warp1, warp2, diff1, diff2,
+                 batch_size, height, width, nblk, thresh};
+    hipLaunchKernelGGL(pair_consist_forward_kernel, dim3(nblk, batch_size), dim3(256), 0, (hipStream_t)stream, p);
+    MR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pair_consist_finalize_kernel, dim3(batch_size), dim3(64), 0, (hipStream_t)stream,
+                       (const float*)workspace, nblk, sums, loss_fwd, loss_bwd);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_pair_consist_backward(const float* flow12, const float* flow21, const float* image_ref,
+                                        const float* image, const float* jitter_ref, const float* jitter,
+                                        int jitter_channels, const float* sums, const float* grad_loss_fwd,
+                                        const float* grad_loss_bwd, float* grad_flow12, float* grad_flow21,
+                                        int batch_size, int height, int width, float thresh,
+                                        mr_stream_t stream) {
+    if (!flow12 || !flow21 || !image_ref || !image || !jitter_ref || !jitter || !sums || !grad_loss_fwd ||
+        !grad_flow12 || !grad_flow21)
+        return MR_ERR_BADARG;
+    if (jitter_channels != 1 && jitter_channels != 3) return MR_ERR_BADARG;
+    if (batch_size < 0 || height <= 0 || width <= 0) return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    const int nblk = (int)(((int64_t)height * width + 255) / 256);
+    PairBwdParams p{flow12, flow21, image_ref, image, jitter_ref, jitter, jitter_channels, sums,
+                    grad_loss_fwd, grad_loss_bwd, grad_flow12, grad_flow21, batch_size, height, width, thresh};
+    hipLaunchKernelGGL(pair_consist_backward_kernel, dim3(nblk, batch_size), dim3(256), 0, (hipStream_t)stream, p);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_abi_version(void) { return 1; }
+
+extern "C" int mr_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+    const char* a = prop.gcnArchName;
+    return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+}

@@ -1,0 +1,130 @@
+"""PyTorch restatement of the neural_renderer python helpers renderer.py relies on.
+
+The reference imports them from the third-party ``neural_renderer`` package
+(/root/reference/meshreg/neurender/renderer.py:8, used at :124-282).  They are small
+differentiable tensor programs ([B,V,3]-sized), kept in stock PyTorch-ROCm so that autograd
+carries the gradient from the face coordinates back to the mesh vertices; the per-pixel
+work they feed lives in the HIP kernels.  Formulas: SURVEY.md appendix B.1-B.3.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def projection(vertices, K, R, t, dist_coeffs, orig_size, eps=1e-9):
+    """Pinhole + 5-coefficient distortion projection to NDC x,y in [-1,1] with metric z
+    (called at renderer.py:187).  K [B,3,3], R [B|1,3,3], t [B|1,(1,)3], dist_coeffs [B|1,5]."""
+    vertices = torch.matmul(vertices, R.transpose(2, 1)) + t
+    x, y, z = vertices[:, :, 0], vertices[:, :, 1], vertices[:, :, 2]
+    x_ = x / (z + eps)
+    y_ = y / (z + eps)
+    k1 = dist_coeffs[:, None, 0]
+    k2 = dist_coeffs[:, None, 1]
+    p1 = dist_coeffs[:, None, 2]
+    p2 = dist_coeffs[:, None, 3]
+    k3 = dist_coeffs[:, None, 4]
+    r = torch.sqrt(x_ ** 2 + y_ ** 2)
+    x__ = x_ * (1 + k1 * (r ** 2) + k2 * (r ** 4) + k3 * (r ** 6)) + 2 * p1 * x_ * y_ + p2 * (r ** 2 + 2 * x_ ** 2)
+    y__ = y_ * (1 + k1 * (r ** 2) + k2 * (r ** 4) + k3 * (r ** 6)) + p1 * (r ** 2 + 2 * y_ ** 2) + 2 * p2 * x_ * y_
+    vertices = torch.stack([x__, y__, torch.ones_like(z)], dim=-1)
+    vertices = torch.matmul(vertices, K.transpose(1, 2))
+    u, v = vertices[:, :, 0], vertices[:, :, 1]
+    v = orig_size - v
+    u = 2 * (u - orig_size / 2.0) / orig_size
+    v = 2 * (v - orig_size / 2.0) / orig_size
+    return torch.stack([u, v, z], dim=-1)
+
+
+def vertices_to_faces(vertices, faces):
+    """[B,V,3], [B,F,3] (int) -> [B,F,3,3] (renderer.py:282)."""
+    if vertices.ndimension() != 3 or faces.ndimension() != 3:
+        raise ValueError("vertices and faces must be 3-dimensional")
+    if vertices.shape[0] != faces.shape[0] or vertices.shape[2] != 3 or faces.shape[2] != 3:
+        raise ValueError("shape mismatch between vertices and faces")
+    bs, nv = vertices.shape[:2]
+    faces = faces.long() + (torch.arange(bs, device=vertices.device) * nv)[:, None, None]
+    return vertices.reshape(bs * nv, 3)[faces]
+
+
+def _vec(v, device, batch_size):
+    if not torch.is_tensor(v):
+        v = torch.tensor(v, dtype=torch.float32, device=device)
+    v = v.to(device=device, dtype=torch.float32)
+    if v.ndimension() == 1:
+        v = v[None, :].repeat(batch_size, 1)
+    return v
+
+
+def look_at(vertices, eye, at=(0, 0, 0), up=(0, 1, 0)):
+    """'Look at' transformation of vertices (renderer.py:124, :167)."""
+    if vertices.ndimension() != 3:
+        raise ValueError("vertices Tensor should have 3 dimensions")
+    bs, dev = vertices.shape[0], vertices.device
+    at, up, eye = _vec(at, dev, bs), _vec(up, dev, bs), _vec(eye, dev, bs)
+    z_axis = F.normalize(at - eye, eps=1e-5)
+    x_axis = F.normalize(torch.cross(up, z_axis, dim=1), eps=1e-5)
+    y_axis = F.normalize(torch.cross(z_axis, x_axis, dim=1), eps=1e-5)
+    r = torch.cat((x_axis[:, None, :], y_axis[:, None, :], z_axis[:, None, :]), dim=1)
+    if vertices.shape != eye.shape:
+        eye = eye[:, None, :]
+    vertices = vertices - eye
+    return torch.matmul(vertices, r.transpose(1, 2))
+
+
+def look(vertices, eye, direction=(0, 1, 0), up=None):
+    """'Look' transformation of vertices (renderer.py:129, :172)."""
+    if vertices.ndimension() != 3:
+        raise ValueError("vertices Tensor should have 3 dimensions")
+    bs, dev = vertices.shape[0], vertices.device
+    if up is None:
+        up = (0, 1, 0)
+    direction, up, eye = _vec(direction, dev, bs), _vec(up, dev, bs), _vec(eye, dev, bs)
+    z_axis = F.normalize(direction, eps=1e-5)
+    x_axis = F.normalize(torch.cross(up, z_axis, dim=1), eps=1e-5)
+    y_axis = F.normalize(torch.cross(z_axis, x_axis, dim=1), eps=1e-5)
+    r = torch.cat((x_axis[:, None, :], y_axis[:, None, :], z_axis[:, None, :]), dim=1)
+    if vertices.shape != eye.shape:
+        eye = eye[:, None, :]
+    vertices = vertices - eye
+    return torch.matmul(vertices, r.transpose(1, 2))
+
+
+def perspective(vertices, angle=30.0):
+    """Perspective distortion from a viewing angle in degrees (renderer.py:127, :132)."""
+    if vertices.ndimension() != 3:
+        raise ValueError("vertices Tensor should have 3 dimensions")
+    angle = torch.tensor(angle / 180 * math.pi, dtype=torch.float32, device=vertices.device)[None]
+    width = torch.tan(angle)[:, None]
+    z = vertices[:, :, 2]
+    x = vertices[:, :, 0] / z / width
+    y = vertices[:, :, 1] / z / width
+    return torch.stack((x, y, z), dim=2)
+
+
+def lighting(faces, textures, intensity_ambient=0.5, intensity_directional=0.5, color_ambient=(1, 1, 1),
+             color_directional=(1, 1, 1), direction=(0, 1, 0)):
+    """Ambient + directional Lambertian light baked into the face textures
+    (renderer.py:257-265).  Returns a new tensor (the upstream in-place ``*=`` would break
+    autograd on a leaf)."""
+    bs, nf = faces.shape[:2]
+    dev = faces.device
+
+    def col(c):
+        c = torch.as_tensor(c, dtype=torch.float32, device=dev)
+        return c[None, :] if c.ndimension() == 1 else c
+
+    color_ambient, color_directional, direction = col(color_ambient), col(color_directional), col(direction)
+    light = torch.zeros(bs, nf, 3, dtype=torch.float32, device=dev)
+    if intensity_ambient != 0:
+        light = light + intensity_ambient * color_ambient[:, None, :]
+    if intensity_directional != 0:
+        f = faces.reshape((bs * nf, 3, 3))
+        v10 = f[:, 0] - f[:, 1]
+        v12 = f[:, 2] - f[:, 1]
+        normals = F.normalize(torch.cross(v10, v12, dim=1), eps=1e-5).reshape((bs, nf, 3))
+        if direction.ndimension() == 2:
+            direction = direction[:, None, :]
+        cos = F.relu(torch.sum(normals * direction, dim=2))
+        light = light + intensity_directional * (color_directional[:, None, :] * cos[:, :, None])
+    return textures * light[:, :, None, None, None, :]

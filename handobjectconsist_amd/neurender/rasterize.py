@@ -1,0 +1,516 @@
+"""Differentiable rasterisation on MI355X -- drop-in for meshreg/neurender/rasterize.py.
+
+Same public names, argument order and return conventions as the reference module
+(/root/reference/meshreg/neurender/rasterize.py):
+
+* ``RasterizeFunction`` / ``Rasterize``     (rasterize.py:16, :318) -- built on the five
+  upstream-compatible C-ABI entry points (``mr_forward_face_index_map`` ...), with the
+  reference's buffer allocation / pre-fill / alpha / background logic (rasterize.py:60-103).
+* ``rasterize_rgbad`` / ``rasterize`` / ``rasterize_silhouettes`` / ``rasterize_depth``
+  (rasterize.py:362, :451, :483, :511) -- by default routed through the fused kernels
+  (``mr_render_forward`` / ``mr_render_backward``): one pass writes rgb/alpha/depth already
+  flipped + NCHW, the backward recomputes the sampling weights instead of storing them.
+  ``USE_FUSED = False`` selects the composed reference structure instead (same results).
+
+The native code lives in libmeshraster_hip.so (include/meshraster_hip.h); there is no CPU
+or PyTorch fallback.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from handobjectconsist_amd import _lib
+
+DEFAULT_IMAGE_SIZE = 256
+DEFAULT_ANTI_ALIASING = True
+DEFAULT_NEAR = 0.1
+DEFAULT_FAR = 100
+DEFAULT_EPS = 1e-4
+DEFAULT_BACKGROUND_COLOR = (0, 0, 0)
+
+# route rasterize_rgbad through the fused kernels (True) or through RasterizeFunction (False)
+USE_FUSED = True
+# validation / A-B profiling: run the upstream-structured algorithms inside the fused calls
+REFERENCE_ALGO = False
+
+
+def _dummy(device, dtype=torch.float32):
+    return torch.zeros(1, dtype=dtype, device=device)
+
+
+class RasterizeFunction(Function):
+    """
+    Definition of differentiable rasterize operation (reference rasterize.py:16-315).
+    Implemented only for cuda (ROCm) tensors.
+    """
+
+    @staticmethod
+    def forward(ctx, faces, textures, image_size, near, far, eps, background_color, return_rgb=False,
+                return_alpha=False, return_depth=False):
+        _lib.check_cuda(faces, textures if return_rgb else None)
+        ctx.image_size = image_size
+        ctx.near = near
+        ctx.far = far
+        ctx.eps = eps
+        ctx.background_color = background_color
+        ctx.return_rgb = return_rgb
+        ctx.return_alpha = return_alpha
+        ctx.return_depth = return_depth
+
+        faces = _lib.contig(faces).clone()
+        dev = faces.device
+        ctx.device = dev
+        ctx.batch_size, ctx.num_faces = faces.shape[:2]
+        B, is_ = ctx.batch_size, image_size
+
+        if return_rgb:
+            textures = _lib.contig(textures)
+        else:
+            textures = _dummy(dev)
+
+        # rasterize.py:60-85
+        face_index_map = torch.full((B, is_, is_), -1, dtype=torch.int32, device=dev)
+        weight_map = torch.zeros((B, is_, is_, 3), dtype=torch.float32, device=dev)
+        depth_map = torch.full((B, is_, is_), float(far), dtype=torch.float32, device=dev)
+        if return_rgb:
+            rgb_map = torch.zeros((B, is_, is_, 3), dtype=torch.float32, device=dev)
+            sampling_index_map = torch.zeros((B, is_, is_, 8), dtype=torch.int32, device=dev)
+            sampling_weight_map = torch.zeros((B, is_, is_, 8), dtype=torch.float32, device=dev)
+        else:
+            rgb_map = _dummy(dev)
+            sampling_index_map = _dummy(dev)
+            sampling_weight_map = _dummy(dev)
+        if return_alpha:
+            alpha_map = torch.zeros((B, is_, is_), dtype=torch.float32, device=dev)
+        else:
+            alpha_map = _dummy(dev)
+        if return_depth:
+            face_inv_map = torch.zeros((B, is_, is_, 3, 3), dtype=torch.float32, device=dev)
+        else:
+            face_inv_map = _dummy(dev)
+
+        face_index_map, weight_map, depth_map, face_inv_map = RasterizeFunction.forward_face_index_map(
+            ctx, faces, face_index_map, weight_map, depth_map, face_inv_map)
+        rgb_map, sampling_index_map, sampling_weight_map = RasterizeFunction.forward_texture_sampling(
+            ctx, faces, textures, face_index_map, weight_map, depth_map, rgb_map, sampling_index_map,
+            sampling_weight_map)
+        rgb_map = RasterizeFunction.forward_background(ctx, face_index_map, rgb_map)
+        alpha_map = RasterizeFunction.forward_alpha_map(ctx, alpha_map, face_index_map)
+
+        ctx.save_for_backward(faces, textures, face_index_map, weight_map, depth_map, rgb_map, alpha_map,
+                              face_inv_map, sampling_index_map, sampling_weight_map)
+
+        rgb_r, alpha_r, depth_r = torch.tensor([]), torch.tensor([]), torch.tensor([])
+        if return_rgb:
+            rgb_r = rgb_map
+        if return_alpha:
+            alpha_r = alpha_map.clone()
+        if return_depth:
+            depth_r = depth_map.clone()
+        ctx.mark_non_differentiable(face_index_map)
+        return rgb_r, alpha_r, depth_r, face_index_map, face_inv_map, weight_map
+
+    @staticmethod
+    def backward(ctx, grad_rgb_map, grad_alpha_map, grad_depth_map, grad_face_index_map, grad_face_inv_map,
+                 grad_weight_map):
+        (faces, textures, face_index_map, weight_map, depth_map, rgb_map, alpha_map, face_inv_map,
+         sampling_index_map, sampling_weight_map) = ctx.saved_tensors
+        dev = faces.device
+        grad_faces = torch.zeros_like(faces, dtype=torch.float32)
+        if ctx.return_rgb:
+            grad_textures = torch.zeros_like(textures, dtype=torch.float32)
+        else:
+            grad_textures = _dummy(dev)
+
+        if ctx.return_rgb:
+            grad_rgb_map = grad_rgb_map.contiguous() if grad_rgb_map is not None else torch.zeros_like(rgb_map)
+        else:
+            grad_rgb_map = _dummy(dev)
+        if ctx.return_alpha:
+            grad_alpha_map = (grad_alpha_map.contiguous() if grad_alpha_map is not None
+                              else torch.zeros_like(alpha_map))
+        else:
+            grad_alpha_map = _dummy(dev)
+        if ctx.return_depth:
+            # (the reference reads the never-set ctx.depth_map here, rasterize.py:179 -- Q9)
+            grad_depth_map = (grad_depth_map.contiguous() if grad_depth_map is not None
+                              else torch.zeros_like(depth_map))
+        else:
+            grad_depth_map = _dummy(dev)
+
+        grad_faces = RasterizeFunction.backward_pixel_map(
+            ctx, faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces)
+        grad_textures = RasterizeFunction.backward_textures(
+            ctx, face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures)
+        grad_faces = RasterizeFunction.backward_depth_map(
+            ctx, faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces)
+
+        if not ctx.needs_input_grad[1]:
+            grad_textures = None
+        return grad_faces, grad_textures, None, None, None, None, None, None, None, None
+
+    # -- the five native entry points (rasterize.py:199-315) ------------------------------
+    @staticmethod
+    def forward_face_index_map(ctx, faces, face_index_map, weight_map, depth_map, face_inv_map):
+        faces_inv = torch.zeros_like(faces)
+        _lib.call("mr_forward_face_index_map", _lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(weight_map),
+                  _lib.ptr(depth_map), _lib.ptr(face_inv_map), _lib.ptr(faces_inv), ctx.batch_size,
+                  ctx.num_faces, ctx.image_size, float(ctx.near), float(ctx.far), int(ctx.return_rgb),
+                  int(ctx.return_alpha), int(ctx.return_depth), _lib.stream_ptr(faces.device))
+        return face_index_map, weight_map, depth_map, face_inv_map
+
+    @staticmethod
+    def forward_texture_sampling(ctx, faces, textures, face_index_map, weight_map, depth_map, rgb_map,
+                                 sampling_index_map, sampling_weight_map):
+        if not ctx.return_rgb:
+            return rgb_map, sampling_index_map, sampling_weight_map
+        _lib.call("mr_forward_texture_sampling", _lib.ptr(faces), _lib.ptr(textures), _lib.ptr(face_index_map),
+                  _lib.ptr(weight_map), _lib.ptr(depth_map), _lib.ptr(rgb_map), _lib.ptr(sampling_index_map),
+                  _lib.ptr(sampling_weight_map), ctx.batch_size, ctx.num_faces, ctx.image_size,
+                  int(textures.shape[2]), float(ctx.eps), _lib.stream_ptr(faces.device))
+        return rgb_map, sampling_index_map, sampling_weight_map
+
+    @staticmethod
+    def forward_alpha_map(ctx, alpha_map, face_index_map):
+        if ctx.return_alpha:
+            alpha_map[face_index_map >= 0] = 1
+        return alpha_map
+
+    @staticmethod
+    def forward_background(ctx, face_index_map, rgb_map):
+        if ctx.return_rgb:
+            background_color = torch.as_tensor(ctx.background_color, dtype=torch.float32,
+                                               device=rgb_map.device)
+            mask = (face_index_map >= 0).float()[:, :, :, None]
+            if background_color.ndimension() == 1:
+                rgb_map = rgb_map * mask + (1 - mask) * background_color[None, None, None, :]
+            elif background_color.ndimension() == 2:
+                rgb_map = rgb_map * mask + (1 - mask) * background_color[:, None, None, :]
+        return rgb_map
+
+    @staticmethod
+    def backward_pixel_map(ctx, faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,
+                           grad_faces):
+        if (not ctx.return_rgb) and (not ctx.return_alpha):
+            return grad_faces
+        _lib.call("mr_backward_pixel_map", _lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(rgb_map),
+                  _lib.ptr(alpha_map), _lib.ptr(grad_rgb_map), _lib.ptr(grad_alpha_map), _lib.ptr(grad_faces),
+                  ctx.batch_size, ctx.num_faces, ctx.image_size, float(ctx.eps), int(ctx.return_rgb),
+                  int(ctx.return_alpha), _lib.stream_ptr(faces.device))
+        return grad_faces
+
+    @staticmethod
+    def backward_textures(ctx, face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map,
+                          grad_textures):
+        if not ctx.return_rgb:
+            return grad_textures
+        _lib.call("mr_backward_textures", _lib.ptr(face_index_map), _lib.ptr(sampling_weight_map),
+                  _lib.ptr(sampling_index_map), _lib.ptr(grad_rgb_map), _lib.ptr(grad_textures),
+                  ctx.batch_size, ctx.num_faces, ctx.image_size, int(grad_textures.shape[2]),
+                  _lib.stream_ptr(face_index_map.device))
+        return grad_textures
+
+    @staticmethod
+    def backward_depth_map(ctx, faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map,
+                           grad_faces):
+        if not ctx.return_depth:
+            return grad_faces
+        _lib.call("mr_backward_depth_map", _lib.ptr(faces), _lib.ptr(depth_map), _lib.ptr(face_index_map),
+                  _lib.ptr(face_inv_map), _lib.ptr(weight_map), _lib.ptr(grad_depth_map), _lib.ptr(grad_faces),
+                  ctx.batch_size, ctx.num_faces, ctx.image_size, _lib.stream_ptr(faces.device))
+        return grad_faces
+
+
+class Rasterize(nn.Module):
+    """
+    Wrapper around the autograd function RasterizeFunction (reference rasterize.py:318-359).
+    """
+
+    def __init__(self, image_size, near, far, eps, background_color, return_rgb=False, return_alpha=False,
+                 return_depth=False):
+        super(Rasterize, self).__init__()
+        self.image_size = image_size
+        self.near = near
+        self.far = far
+        self.eps = eps
+        self.background_color = background_color
+        self.return_rgb = return_rgb
+        self.return_alpha = return_alpha
+        self.return_depth = return_depth
+
+    def forward(self, faces, textures):
+        if faces.device.type == "cpu" or (textures is not None and textures.device.type == "cpu"):
+            raise TypeError("Rasterize module supports only cuda Tensors")
+        return RasterizeFunction.apply(faces, textures, self.image_size, self.near, self.far, self.eps,
+                                       self.background_color, self.return_rgb, self.return_alpha,
+                                       self.return_depth)
+
+
+# ---------------------------------------------------------------------------------------
+# fused path
+# ---------------------------------------------------------------------------------------
+
+_BG_CACHE = {}
+
+
+def _background_tensor(background_color, device, batch_size):
+    """Device copy of the background colour: [3] (stride 0) or [B,3] (stride 3)."""
+    if torch.is_tensor(background_color):
+        bg = background_color.to(device=device, dtype=torch.float32).contiguous()
+    else:
+        key = (tuple(map(float, background_color)) if not isinstance(background_color[0], (list, tuple))
+               else tuple(tuple(map(float, row)) for row in background_color), str(device))
+        bg = _BG_CACHE.get(key)
+        if bg is None:
+            bg = torch.tensor(background_color, dtype=torch.float32, device=device)
+            _BG_CACHE[key] = bg
+    if bg.ndimension() == 1:
+        if bg.numel() != 3:
+            raise ValueError("background_color must have 3 components")
+        return bg, 0
+    if bg.ndimension() == 2 and bg.shape == (batch_size, 3):
+        return bg, 3
+    raise ValueError("background_color must be [3] or [batch_size, 3]")
+
+
+class RasterizeFusedFunction(Function):
+    """(faces[B,F,3,3], textures[B,F,ts,ts,ts,3]) -> rgb[B,3,is,is], alpha[B,is,is],
+    depth[B,is,is] in IMAGE orientation + face_index_map / weight_map in raster orientation:
+    RasterizeFunction followed by the permute/flip of rasterize_rgbad, in one kernel."""
+
+    @staticmethod
+    def forward(ctx, faces, textures, image_size, near, far, eps, background_color, return_rgb, return_alpha,
+                return_depth):
+        _lib.check_cuda(faces, textures if return_rgb else None)
+        if faces.dim() != 4 or faces.shape[2:] != (3, 3):
+            raise ValueError("faces must be [batch size, number of faces, 3, 3]")
+        faces = _lib.contig(faces.detach())
+        dev = faces.device
+        B, Fn = faces.shape[:2]
+        is_ = int(image_size)
+        ts = 1
+        tex = None
+        bg, bg_stride = None, 0
+        if return_rgb:
+            tex = _lib.contig(textures.detach())
+            if tex.dim() != 6 or tex.shape[:2] != (B, Fn) or tex.shape[-1] != 3:
+                raise ValueError("textures must be [batch size, number of faces, ts, ts, ts, 3]")
+            ts = int(tex.shape[2])
+            bg, bg_stride = _background_tensor(background_color, dev, B)
+        empty = torch.empty
+        rgb = empty((B, 3, is_, is_), dtype=torch.float32, device=dev) if return_rgb else None
+        alpha = empty((B, is_, is_), dtype=torch.float32, device=dev) if return_alpha else None
+        depth = empty((B, is_, is_), dtype=torch.float32, device=dev) if return_depth else None
+        fim = empty((B, is_, is_), dtype=torch.int32, device=dev)
+        wmap = empty((B, is_, is_, 3), dtype=torch.float32, device=dev)
+        wbytes = _lib.load().mr_render_workspace_bytes(B, Fn, is_)
+        work = empty((max(int(wbytes), 8),), dtype=torch.uint8, device=dev)
+        flags = _lib.FLAG_REFERENCE_ALGO if REFERENCE_ALGO else 0
+        _lib.call("mr_render_forward", _lib.ptr(faces), _lib.ptr(tex), _lib.ptr(bg), bg_stride, _lib.ptr(rgb),
+                  _lib.ptr(alpha), _lib.ptr(depth), _lib.ptr(fim), _lib.ptr(wmap), None, _lib.ptr(work),
+                  int(wbytes), B, Fn, is_, ts, float(near), float(far), float(eps), int(return_rgb),
+                  int(return_alpha), int(return_depth), flags, _lib.stream_ptr(dev))
+        ctx.cfg = (is_, float(near), float(far), float(eps), bool(return_rgb), bool(return_alpha),
+                   bool(return_depth), ts, flags)
+        ctx.save_for_backward(faces, tex if tex is not None else _dummy(dev), fim,
+                              rgb if rgb is not None else _dummy(dev),
+                              alpha if alpha is not None else _dummy(dev))
+        ctx.mark_non_differentiable(fim, wmap)
+        e = torch.tensor([])
+        return (rgb if return_rgb else e, alpha if return_alpha else e, depth if return_depth else e, fim,
+                wmap)
+
+    @staticmethod
+    def backward(ctx, grad_rgb, grad_alpha, grad_depth, _gfim, _gw):
+        faces, tex, fim, rgb, alpha = ctx.saved_tensors
+        is_, near, far, eps, rr, ra, rd, ts, flags = ctx.cfg
+        dev = faces.device
+        B, Fn = faces.shape[:2]
+        want_faces, want_tex = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and rr
+        grad_faces = grad_textures = None
+        if not (want_faces or want_tex):
+            return (None,) * 10
+        g_rgb = _lib.contig(grad_rgb) if (rr and grad_rgb is not None) else None
+        g_alpha = _lib.contig(grad_alpha) if (ra and grad_alpha is not None) else None
+        g_depth = _lib.contig(grad_depth) if (rd and grad_depth is not None) else None
+        if want_faces:
+            grad_faces = torch.empty_like(faces)
+        if want_tex:
+            if g_rgb is None:
+                grad_textures = torch.zeros_like(tex)
+                want_tex = False
+            else:
+                grad_textures = torch.empty_like(tex)
+        if want_faces or want_tex:
+            _lib.call("mr_render_backward", _lib.ptr(faces), _lib.ptr(tex) if rr else None, _lib.ptr(fim),
+                      _lib.ptr(rgb) if rr else None, _lib.ptr(alpha) if ra else None, _lib.ptr(g_rgb),
+                      _lib.ptr(g_alpha), _lib.ptr(g_depth), _lib.ptr(grad_faces),
+                      _lib.ptr(grad_textures) if want_tex else None, None, 0, B, Fn, is_, ts, near, far, eps,
+                      int(rr), int(ra), int(rd), flags, _lib.stream_ptr(dev))
+        return grad_faces, grad_textures, None, None, None, None, None, None, None, None
+
+
+class _RenderOutput(dict):
+    """The dict rasterize_rgbad returns.  ``face_inv_map`` ([B,is,is,3,3], 36 B/pixel, only
+    ever consumed by the depth backward, which recomputes it) is materialised on first
+    access instead of being written by every forward pass."""
+
+    _LAZY = "face_inv_map"
+    _thunk = None
+
+    def _materialise(self):
+        if self._thunk is not None:
+            dict.__setitem__(self, self._LAZY, self._thunk())
+            self._thunk = None
+
+    def __getitem__(self, key):
+        if key == self._LAZY:
+            self._materialise()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        if key == self._LAZY:
+            self._materialise()
+        return dict.get(self, key, default)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+
+def face_inv_map_from(faces, face_index_map):
+    """[B,is,is,3,3] per-pixel inverse of the winning face (zeros on background)."""
+    faces = _lib.contig(faces.detach())
+    B, Fn = faces.shape[:2]
+    is_ = face_index_map.shape[1]
+    out = torch.empty((B, is_, is_, 3, 3), dtype=torch.float32, device=faces.device)
+    _lib.call("mr_face_inv_map", _lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(out), B, Fn, is_,
+              _lib.stream_ptr(faces.device))
+    return out
+
+
+def rasterize_rgbad(
+    faces,
+    textures=None,
+    image_size=DEFAULT_IMAGE_SIZE,
+    anti_aliasing=DEFAULT_ANTI_ALIASING,
+    near=DEFAULT_NEAR,
+    far=DEFAULT_FAR,
+    eps=DEFAULT_EPS,
+    background_color=DEFAULT_BACKGROUND_COLOR,
+    return_rgb=True,
+    return_alpha=True,
+    return_depth=True,
+):
+    """
+    Generate RGB, alpha channel, and depth images from faces and textures (for RGB).
+    Same contract as the reference (rasterize.py:362-448).
+
+    Args:
+        faces (torch.Tensor): [batch size, number of faces, 3 (vertices), 3 (XYZ)].
+        textures (torch.Tensor): [batch size, number of faces, ts, ts, ts, 3 (RGB)].
+        image_size (int): Width and height of rendered images.
+        anti_aliasing (bool): do anti-aliasing by 2x super-sampling.
+        near / far (float): z-range to draw.
+        eps (float): small epsilon for approximated differentiation.
+        background_color (tuple): background color of RGB images.
+        return_rgb / return_alpha / return_depth (bool): which images to generate.
+
+    Returns:
+        dict: 'rgb' [B,3,is,is], 'alpha' [B,is,is], 'depth' [B,is,is] (image orientation),
+        'face_index_map', 'weight_map', 'face_inv_map' (raster orientation, un-flipped).
+    """
+    if faces.device.type == "cpu" or (textures is not None and textures.device.type == "cpu"):
+        raise TypeError("Rasterize module supports only cuda Tensors")
+    ras_size = image_size * 2 if anti_aliasing else image_size
+    if background_color is None:
+        background_color = DEFAULT_BACKGROUND_COLOR
+
+    if USE_FUSED:
+        rgb, alpha, depth, face_index_map, weight_map = RasterizeFusedFunction.apply(
+            faces, textures, ras_size, near, far, eps, background_color, return_rgb, return_alpha, return_depth)
+        face_inv_map = None
+    else:
+        rgb, alpha, depth, face_index_map, face_inv_map, weight_map = Rasterize(
+            ras_size, near, far, eps, background_color, return_rgb, return_alpha, return_depth)(faces, textures)
+        # transpose & vertical flip (rasterize.py:413-428)
+        if return_rgb:
+            rgb = rgb.permute((0, 3, 1, 2)).flip(2)
+        if return_alpha:
+            alpha = alpha.flip(1)
+        if return_depth:
+            depth = depth.flip(1)
+
+    if anti_aliasing:
+        # 0.5x down-sampling
+        if return_rgb:
+            rgb = F.avg_pool2d(rgb, kernel_size=(2, 2))
+        if return_alpha:
+            alpha = F.avg_pool2d(alpha[:, None, :, :], kernel_size=(2, 2))[:, 0]
+        if return_depth:
+            depth = F.avg_pool2d(depth[:, None, :, :], kernel_size=(2, 2))[:, 0]
+
+    ret = _RenderOutput({
+        "rgb": rgb if return_rgb else None,
+        "alpha": alpha if return_alpha else None,
+        "depth": depth if return_depth else None,
+        "face_inv_map": face_inv_map,
+        "face_index_map": face_index_map,
+        "weight_map": weight_map,
+    })
+    if USE_FUSED:
+        if return_depth:
+            faces_d, fim_d = faces.detach(), face_index_map
+            ret._thunk = lambda: face_inv_map_from(faces_d, fim_d)
+        else:
+            dict.__setitem__(ret, "face_inv_map", _dummy(faces.device))
+    return ret
+
+
+def rasterize(
+    faces,
+    textures,
+    image_size=DEFAULT_IMAGE_SIZE,
+    anti_aliasing=DEFAULT_ANTI_ALIASING,
+    near=DEFAULT_NEAR,
+    far=DEFAULT_FAR,
+    eps=DEFAULT_EPS,
+    background_color=DEFAULT_BACKGROUND_COLOR,
+):
+    """Generate RGB images from faces and textures: [batch size, 3, image_size, image_size]."""
+    return rasterize_rgbad(
+        faces, textures, image_size, anti_aliasing, near, far, eps, background_color, True, False, False
+    )["rgb"]
+
+
+def rasterize_silhouettes(
+    faces,
+    image_size=DEFAULT_IMAGE_SIZE,
+    anti_aliasing=DEFAULT_ANTI_ALIASING,
+    near=DEFAULT_NEAR,
+    far=DEFAULT_FAR,
+    eps=DEFAULT_EPS,
+):
+    """Generate alpha channels from faces: [batch size, image_size, image_size]."""
+    return rasterize_rgbad(faces, None, image_size, anti_aliasing, near, far, eps, None, False, True, False)[
+        "alpha"
+    ]
+
+
+def rasterize_depth(
+    faces,
+    image_size=DEFAULT_IMAGE_SIZE,
+    anti_aliasing=DEFAULT_ANTI_ALIASING,
+    near=DEFAULT_NEAR,
+    far=DEFAULT_FAR,
+    eps=DEFAULT_EPS,
+):
+    """Generate depth images from faces: [batch size, image_size, image_size]."""
+    return rasterize_rgbad(faces, None, image_size, anti_aliasing, near, far, eps, None, False, False, True)[
+        "depth"
+    ]

@@ -33,12 +33,23 @@ extern "C" {
 #define MR_ERR_BADARG (-1)
 #define MR_ERR_NOTIMPL (-2)
 
+/* `flags` bit of the fused entry points: run the straightforward upstream-structured
+ * algorithm (every pixel loops over every face / per-pixel global atomics) instead of the
+ * tiled one.  Validation and A/B profiling only. */
+#define MR_FLAG_REFERENCE_ALGO 1
+
+#if defined(__GNUC__)
+#define MR_API __attribute__((visibility("default")))
+#else
+#define MR_API
+#endif
+
 typedef void* mr_stream_t;
 
 /* ABI version of this header (bumped on any signature change). */
-int mr_abi_version(void);
+MR_API int mr_abi_version(void);
 /* 1 if a gfx950-capable device is visible to the HIP runtime, else 0. */
-int mr_device_ok(void);
+MR_API int mr_device_ok(void);
 
 /* ------------------------------------------------------------------------------------
  * 1. Upstream-compatible entry points (neural_renderer.cuda.rasterize)
@@ -50,7 +61,7 @@ int mr_device_ok(void);
  * face_inv_map[B,is,is,3,3] (written iff return_depth; else may be a 1-element dummy),
  * faces_inv[B,F,3,3] caller scratch (receives the per-face pixel-space inverse; entries
  * of back-facing faces are left untouched).  Hard z-buffer, lowest face index wins ties. */
-int mr_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
+MR_API int mr_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
                               float* depth_map, float* face_inv_map, float* faces_inv,
                               int batch_size, int num_faces, int image_size, float near_,
                               float far_, int return_rgb, int return_alpha, int return_depth,
@@ -59,7 +70,7 @@ int mr_forward_face_index_map(const float* faces, int32_t* face_index_map, float
 /* Replaces rasterize_cuda.forward_texture_sampling (rasterize.py:232-243).
  * textures[B,F,ts,ts,ts,3]; writes rgb_map[B,is,is,3], sampling_index_map[B,is,is,8],
  * sampling_weight_map[B,is,is,8] at hit pixels only (caller pre-fills 0). */
-int mr_forward_texture_sampling(const float* faces, const float* textures,
+MR_API int mr_forward_texture_sampling(const float* faces, const float* textures,
                                 const int32_t* face_index_map, const float* weight_map,
                                 const float* depth_map, float* rgb_map,
                                 int32_t* sampling_index_map, float* sampling_weight_map,
@@ -69,7 +80,7 @@ int mr_forward_texture_sampling(const float* faces, const float* textures,
 /* Replaces rasterize_cuda.backward_pixel_map (rasterize.py:269-281): the NMR
  * edge-crossing pseudo-gradient.  Writes (does not accumulate) the x,y slots of
  * grad_faces[B,F,3,3] for front-facing faces; z slots and back-facing rows untouched. */
-int mr_backward_pixel_map(const float* faces, const int32_t* face_index_map,
+MR_API int mr_backward_pixel_map(const float* faces, const int32_t* face_index_map,
                           const float* rgb_map, const float* alpha_map,
                           const float* grad_rgb_map, const float* grad_alpha_map,
                           float* grad_faces, int batch_size, int num_faces, int image_size,
@@ -77,14 +88,14 @@ int mr_backward_pixel_map(const float* faces, const int32_t* face_index_map,
 
 /* Replaces rasterize_cuda.backward_textures (rasterize.py:290-297): exact adjoint of
  * the texture sampling; accumulates into grad_textures[B,F,ts,ts,ts,3] (pre-zeroed). */
-int mr_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
+MR_API int mr_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
                          const int32_t* sampling_index_map, const float* grad_rgb_map,
                          float* grad_textures, int batch_size, int num_faces, int image_size,
                          int texture_size, mr_stream_t stream);
 
 /* Replaces rasterize_cuda.backward_depth_map (rasterize.py:306-315): accumulates the
  * analytic d(depth)/d(vertex) into grad_faces[B,F,3,3]. */
-int mr_backward_depth_map(const float* faces, const float* depth_map,
+MR_API int mr_backward_depth_map(const float* faces, const float* depth_map,
                           const int32_t* face_index_map, const float* face_inv_map,
                           const float* weight_map, const float* grad_depth_map,
                           float* grad_faces, int batch_size, int num_faces, int image_size,
@@ -95,7 +106,7 @@ int mr_backward_depth_map(const float* faces, const float* depth_map,
  * ---------------------------------------------------------------------------------- */
 
 /* Bytes of device workspace mr_render_forward / mr_render_backward need. */
-int64_t mr_render_workspace_bytes(int batch_size, int num_faces, int image_size);
+MR_API int64_t mr_render_workspace_bytes(int batch_size, int num_faces, int image_size);
 
 /* Kernels A+B+C + background + alpha + vertical flip + NHWC->NCHW in one pass
  * (= RasterizeFunction.forward rasterize.py:23-125 followed by rasterize_rgbad's
@@ -106,13 +117,19 @@ int64_t mr_render_workspace_bytes(int batch_size, int num_faces, int image_size)
  *   face_index_map[B,is,is] i32  weight_map[B,is,is,3]  face_inv_map[B,is,is,3,3]
  *                                                                  (RASTER orientation)
  * background[3] (bg_stride 0) or [B,3] (bg_stride 3) is a device pointer. */
-int mr_render_forward(const float* faces, const float* textures, const float* background,
+MR_API int mr_render_forward(const float* faces, const float* textures, const float* background,
                       int bg_stride, float* rgb_img, float* alpha_img, float* depth_img,
                       int32_t* face_index_map, float* weight_map, float* face_inv_map,
                       void* workspace, int64_t workspace_bytes, int batch_size,
                       int num_faces, int image_size, int texture_size, float near_,
                       float far_, float eps, int return_rgb, int return_alpha,
-                      int return_depth, mr_stream_t stream);
+                      int return_depth, int flags, mr_stream_t stream);
+
+/* face_inv_map[B,is,is,3,3] (RASTER orientation) from (faces, face_index_map): the map
+ * upstream stores per pixel during the forward pass (rasterize.py:79-83), materialised on
+ * demand instead (zeros where no face was hit). */
+MR_API int mr_face_inv_map(const float* faces, const int32_t* face_index_map, float* face_inv_map,
+                           int batch_size, int num_faces, int image_size, mr_stream_t stream);
 
 /* Kernels E+F (and D when want_grad_faces and (return_rgb or return_alpha)) against the
  * IMAGE-orientation gradients produced by autograd for mr_render_forward's outputs.
@@ -120,14 +137,14 @@ int mr_render_forward(const float* faces, const float* textures, const float* ba
  * (faces, face_index_map) instead of being stored.  grad_faces[B,F,3,3] /
  * grad_textures[B,F,ts,ts,ts,3] are fully written (no pre-zeroing needed); either may
  * be NULL to skip it.  rgb_img / alpha_img are only read by the pixel-map term. */
-int mr_render_backward(const float* faces, const float* textures,
+MR_API int mr_render_backward(const float* faces, const float* textures,
                        const int32_t* face_index_map, const float* rgb_img,
                        const float* alpha_img, const float* grad_rgb_img,
                        const float* grad_alpha_img, const float* grad_depth_img,
                        float* grad_faces, float* grad_textures, void* workspace,
                        int64_t workspace_bytes, int batch_size, int num_faces,
                        int image_size, int texture_size, float near_, float far_, float eps,
-                       int return_rgb, int return_alpha, int return_depth,
+                       int return_rgb, int return_alpha, int return_depth, int flags,
                        mr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -138,50 +155,51 @@ int mr_render_backward(const float* faces, const float* textures,
  * out[B,C,H,W] = sample(x) * mask, mask[B,C,H,W] in {0,1}.  mode 0 = bilinear,
  * 1 = nearest; zeros padding; normalisation by (W-1),(H-1) sampled with
  * align_corners=False. */
-int mr_warp_forward(const float* x, const float* flow, float* out, float* mask,
+MR_API int mr_warp_forward(const float* x, const float* flow, float* out, float* mask,
                     int batch_size, int channels, int height, int width, float thresh,
                     int mode, mr_stream_t stream);
 
 /* Adjoint of mr_warp_forward w.r.t. x (grad_x, pre-zeroed, accumulated with atomics; may
  * be NULL) and w.r.t. flow (grad_flow[B,2,H,W], fully written; may be NULL; zero for
  * mode 1).  The mask carries no gradient (Q7). */
-int mr_warp_backward(const float* x, const float* flow, const float* grad_out,
+MR_API int mr_warp_backward(const float* x, const float* flow, const float* grad_out,
                      float* grad_x, float* grad_flow, int batch_size, int channels,
                      int height, int width, float thresh, int mode, mr_stream_t stream);
 
 /* imgflowarp.get_occlusion_mask (imgflowarp.py:118-172), the four chained nearest
  * warps fused: mask_flow{1,2}[B,H,W], flow{12,21}[B,>=2,H,W] with channel stride
  * flow_cstride = H*W and batch stride flow_bstride (elements) -> occl{1,2}[B,H,W]. */
-int mr_occlusion_mask(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+MR_API int mr_occlusion_mask(const float* mask_flow1, const float* mask_flow2, const float* flow12,
                       const float* flow21, int64_t flow_bstride, float* occl1, float* occl2,
                       int batch_size, int height, int width, float distance_thresh,
                       float warp_thresh, mr_stream_t stream);
 
+/* Bytes of device workspace mr_pair_consist_forward needs (per-block partial sums). */
+MR_API int64_t mr_pair_consist_workspace_bytes(int batch_size, int height, int width);
+
 /* imgflowarp.pair_consist (imgflowarp.py:58-115) with criterion l1 / level_nb 1
- * (pyramidloss.py:56-62, lossutils.py:1-8), both directions fused.
- *   flow12, flow21 [B,H,W,2]   image_ref, image [B,3,H,W]   jitter_ref, jitter [B,Cj,H,W]
- * Outputs (any of the optional ones may be NULL):
- *   loss_fwd[B], loss_bwd[B]          per-sample masked means (warp_loss = fwd (+ bwd))
- *   sums[B,4]                         workspace: {sum1, cnt1, sum2, cnt2} (must be zeroed)
- *   full_mask1/2[B,H,W] u8            valid_mask1/2
- *   warp_mask1/2[B,H,W] f32           channel 0 of the reference's [B,3,H,W] masks
- *   warp1/2[B,3,H,W]   diff1/2[B,3,H,W] */
-int mr_pair_consist_forward(const float* flow12, const float* flow21, const float* image_ref,
+ * (pyramidloss.py:56-62, lossutils.py:1-8), both directions fused into one pass.
+ *   flow12, flow21 [B,H,W,2]   image_ref, image [B,3,H,W]   jitter_ref, jitter [B,Cj,H,W],
+ *   Cj = jitter_channels in {1, 3}
+ * Outputs:
+ *   sums[B,4] = {sum1, cnt1, sum2, cnt2}  (masked L1 sums / 3*valid counts; kept for backward)
+ *   loss_fwd[B], loss_bwd[B]              sum / (cnt == 0 ? 1 : cnt); warp_loss = fwd (+ bwd)
+ * Optional debug outputs of the reference's `masks, warps, diffs` (any may be NULL):
+ *   full_mask1/2[B,H,W] u8    warp_mask1/2[B,3,H,W]    warp1/2[B,3,H,W]    diff1/2[B,3,H,W]
+ * The reduction is two-stage and deterministic (no float atomics). */
+MR_API int mr_pair_consist_forward(const float* flow12, const float* flow21, const float* image_ref,
                             const float* image, const float* jitter_ref, const float* jitter,
-                            int jitter_channels, float* sums, uint8_t* full_mask1,
+                            int jitter_channels, void* workspace, int64_t workspace_bytes,
+                            float* sums, float* loss_fwd, float* loss_bwd, uint8_t* full_mask1,
                             uint8_t* full_mask2, float* warp_mask1, float* warp_mask2,
                             float* warp1, float* warp2, float* diff1, float* diff2,
                             int batch_size, int height, int width, float thresh,
                             mr_stream_t stream);
 
-/* loss_fwd[b] = sums[b,0]/max(sums[b,1],1) (cnt==0 -> 1), loss_bwd likewise. */
-int mr_pair_consist_finalize(const float* sums, float* loss_fwd, float* loss_bwd,
-                             int batch_size, mr_stream_t stream);
-
 /* Adjoint of the pair loss w.r.t. the two flows (the only differentiable inputs on the
  * training path): grad_flow12/21[B,H,W,2] fully written.  grad_loss_fwd/bwd[B] are the
  * incoming gradients of loss_fwd / loss_bwd (grad_loss_bwd may be NULL). */
-int mr_pair_consist_backward(const float* flow12, const float* flow21, const float* image_ref,
+MR_API int mr_pair_consist_backward(const float* flow12, const float* flow21, const float* image_ref,
                              const float* image, const float* jitter_ref, const float* jitter,
                              int jitter_channels, const float* sums,
                              const float* grad_loss_fwd, const float* grad_loss_bwd,

@@ -1,0 +1,216 @@
+"""Parity of the HIP rasteriser (through the C-ABI) against the CPU oracle.
+
+face_index_map must match exactly; weight / depth / rgb are bit-identical by construction
+(same fp32 operation order, -ffp-contract=off on both sides) and are checked to 1e-6;
+gradients to 1e-4 relative (the north-star tolerance) where the summation order differs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from handobjectconsist_amd.utils import synth
+from oracle import raster_ref as R
+
+pytestmark = pytest.mark.gpu
+
+REN_KW = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
+              dist_coeffs=np.zeros((1, 5), np.float32), near=0.1, far=100, eps=1e-3)
+
+
+def projected_faces(B, image_size, seed, fill_back=True):
+    """NDC faces + vertex-colour textures of the synthetic hand+object scene."""
+    s = synth.random_scene(B, seed=seed, image_size=image_size)
+    rng = np.random.default_rng(seed)
+    colors = rng.uniform(-2, 2, (B, s["verts1"].shape[1], 3)).astype(np.float32)
+    tex = R.batch_vertex_textures(s["faces"], colors)
+    fidx, tex = R.fill_back(s["faces"], tex) if fill_back else (s["faces"], tex)
+    v = R.nr_projection(s["verts1"], s["K1"], REN_KW["R"], REN_KW["t"], REN_KW["dist_coeffs"], image_size)
+    return R.nr_vertices_to_faces(v, fidx), tex
+
+
+def big_faces(B, image_size, seed, n=24):
+    """A handful of large random triangles (exercise the wave-cooperative paths), both windings."""
+    rng = np.random.default_rng(seed)
+    f = rng.uniform(-1.3, 1.3, (B, n, 3, 3)).astype(np.float32)
+    f[..., 2] = rng.uniform(0.3, 3.0, (B, n, 3))
+    f = np.concatenate([f, f[:, :, ::-1]], 1)
+    tex = rng.uniform(-1, 1, (B, 2 * n, 2, 2, 2, 3)).astype(np.float32)
+    return np.ascontiguousarray(f), tex
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def assert_close(a, b, rtol, atol, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert (err <= tol).all(), f"{what}: max err {err.max():.3e} (|ref| max {np.abs(b).max():.3e}), {(err > tol).sum()} / {err.size} out of tol"
+
+
+CASES = [("scene", 2, 64, 0), ("scene", 3, 96, 1), ("scene", 2, 256, 2), ("big", 2, 64, 3), ("big", 1, 100, 4)]
+
+
+def make_case(kind, B, is_, seed):
+    return projected_faces(B, is_, seed) if kind == "scene" else big_faces(B, is_, seed)
+
+
+@pytest.mark.parametrize("kind,B,is_,seed", CASES)
+@pytest.mark.parametrize("reference_algo", [False, True])
+def test_fused_forward_matches_oracle(cuda, kind, B, is_, seed, reference_algo):
+    from handobjectconsist_amd.neurender import rasterize
+
+    if reference_algo and is_ > 100:
+        pytest.skip("brute-force validation kernel only at small sizes")
+    faces, tex = make_case(kind, B, is_, seed)
+    bg = (0.25, -0.5, 0.75)
+    ref = R.rasterize_rgbad(faces, tex, is_, False, 0.1, 100, 1e-3, bg, num_threads=8)
+    rasterize.REFERENCE_ALGO = reference_algo
+    try:
+        out = rasterize.rasterize_rgbad(t(faces, cuda), t(tex, cuda), is_, False, 0.1, 100, 1e-3, bg)
+    finally:
+        rasterize.REFERENCE_ALGO = False
+    fim = out["face_index_map"].cpu().numpy()
+    assert fim.dtype == np.int32
+    mism = (fim != ref["face_index_map"]).sum()
+    assert mism == 0, f"face_index_map differs at {mism} pixels"
+    assert (fim >= 0).sum() > 50
+    assert_close(out["weight_map"].cpu().numpy(), ref["weight_map"], 0, 1e-6, "weight_map")
+    assert_close(out["depth"].cpu().numpy(), ref["depth"], 1e-6, 0, "depth")
+    assert_close(out["alpha"].cpu().numpy(), ref["alpha"], 0, 0, "alpha")
+    assert_close(out["rgb"].cpu().numpy(), ref["rgb"], 1e-6, 1e-6, "rgb")
+    assert_close(out["face_inv_map"].cpu().numpy(), ref["face_inv_map"], 1e-6, 1e-7, "face_inv_map")
+    assert set(out.keys()) == {"rgb", "alpha", "depth", "face_inv_map", "face_index_map", "weight_map"}
+
+
+@pytest.mark.parametrize("kind,B,is_,seed", CASES[:2] + CASES[3:4])
+def test_compat_five_entry_points_match_oracle(cuda, kind, B, is_, seed):
+    """RasterizeFunction = the reference's structure on the 5 upstream-compatible entry points."""
+    from handobjectconsist_amd.neurender import rasterize
+
+    faces, tex = make_case(kind, B, is_, seed)
+    bg = (0.1, 0.2, 0.3)
+    saved = R.rasterize_forward(faces, tex, is_, 0.1, 100, 1e-3, bg, num_threads=8)
+    f_t = t(faces, cuda).requires_grad_(True)
+    x_t = t(tex, cuda).requires_grad_(True)
+    rgb, alpha, depth, fim, finv, wmap = rasterize.RasterizeFunction.apply(
+        f_t, x_t, is_, 0.1, 100, 1e-3, bg, True, True, True)
+    assert (fim.cpu().numpy() != saved["face_index_map"]).sum() == 0
+    assert_close(rgb.detach().cpu().numpy(), saved["rgb_map"], 1e-6, 1e-6, "rgb_map")
+    assert_close(alpha.detach().cpu().numpy(), saved["alpha_map"], 0, 0, "alpha_map")
+    assert_close(depth.detach().cpu().numpy(), saved["depth_map"], 1e-6, 0, "depth_map")
+    assert_close(wmap.detach().cpu().numpy(), saved["weight_map"], 0, 1e-6, "weight_map")
+    assert_close(finv.detach().cpu().numpy(), saved["face_inv_map"], 1e-6, 1e-7, "face_inv_map")
+    rng = np.random.default_rng(seed + 100)
+    g_rgb = rng.standard_normal(saved["rgb_map"].shape).astype(np.float32)
+    g_alpha = rng.standard_normal(saved["alpha_map"].shape).astype(np.float32)
+    g_depth = rng.standard_normal(saved["depth_map"].shape).astype(np.float32)
+    gf_ref, gt_ref = R.rasterize_backward(saved, g_rgb, g_alpha, g_depth, num_threads=8)
+    torch.autograd.backward([rgb, alpha, depth], [t(g_rgb, cuda), t(g_alpha, cuda), t(g_depth, cuda)])
+    scale_t = np.abs(gt_ref).max()
+    assert_close(x_t.grad.cpu().numpy(), gt_ref, 1e-4, 1e-5 * scale_t, "grad_textures")
+    scale_f = np.abs(gf_ref).max()
+    assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * scale_f, "grad_faces")
+
+
+def _img_grads(saved, seed):
+    rng = np.random.default_rng(seed + 100)
+    g_rgb = rng.standard_normal(saved["rgb_map"].shape).astype(np.float32)       # raster NHWC
+    g_alpha = rng.standard_normal(saved["alpha_map"].shape).astype(np.float32)
+    g_depth = rng.standard_normal(saved["depth_map"].shape).astype(np.float32)
+    img = (np.ascontiguousarray(g_rgb.transpose(0, 3, 1, 2)[:, :, ::-1]), np.ascontiguousarray(g_alpha[:, ::-1]),
+           np.ascontiguousarray(g_depth[:, ::-1]))
+    return (g_rgb, g_alpha, g_depth), img
+
+
+@pytest.mark.parametrize("kind,B,is_,seed", CASES)
+@pytest.mark.parametrize("reference_algo", [False, True])
+def test_fused_backward_matches_oracle(cuda, kind, B, is_, seed, reference_algo):
+    from handobjectconsist_amd.neurender import rasterize
+
+    faces, tex = make_case(kind, B, is_, seed)
+    bg = (0.0, 0.0, 0.0)
+    ref = R.rasterize_rgbad(faces, tex, is_, False, 0.1, 100, 1e-3, bg, num_threads=8, keep_saved=True)
+    saved = ref["_saved"]
+    raster_g, img_g = _img_grads(saved, seed)
+    gf_ref, gt_ref = R.rasterize_backward(saved, *raster_g, num_threads=8)
+    f_t = t(faces, cuda).requires_grad_(True)
+    x_t = t(tex, cuda).requires_grad_(True)
+    rasterize.REFERENCE_ALGO = reference_algo
+    try:
+        out = rasterize.rasterize_rgbad(f_t, x_t, is_, False, 0.1, 100, 1e-3, bg)
+        torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]], [t(g, cuda) for g in img_g])
+    finally:
+        rasterize.REFERENCE_ALGO = False
+    scale_t = np.abs(gt_ref).max()
+    assert_close(x_t.grad.cpu().numpy(), gt_ref, 1e-4, 1e-5 * scale_t, "grad_textures")
+    scale_f = np.abs(gf_ref).max()
+    assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * scale_f, "grad_faces")
+
+
+def test_training_mode_textures_only_bit_exact(cuda):
+    """detach_renders=True (warpbranch.py:65-66): only grad_textures is live; the one-lane gather
+    accumulates in the oracle's pixel order, so small-face scenes are bit-identical."""
+    from handobjectconsist_amd.neurender import rasterize
+
+    faces, tex = projected_faces(2, 128, 7)
+    ref = R.rasterize_rgbad(faces, tex, 128, False, 0.1, 100, 1e-3, (0, 0, 0), num_threads=8, keep_saved=True)
+    raster_g, img_g = _img_grads(ref["_saved"], 7)
+    _, gt_ref = R.rasterize_backward(ref["_saved"], raster_g[0], None, None, num_threads=8)
+    x_t = t(tex, cuda).requires_grad_(True)
+    out = rasterize.rasterize_rgbad(t(faces, cuda), x_t, 128, False, 0.1, 100, 1e-3, (0, 0, 0))
+    out["rgb"].backward(t(img_g[0], cuda))
+    got = x_t.grad.cpu().numpy()
+    assert np.abs(gt_ref).max() > 0
+    assert_close(got, gt_ref, 1e-6, 1e-7 * np.abs(gt_ref).max(), "grad_textures (training mode)")
+
+
+def test_edge_cases(cuda):
+    from handobjectconsist_amd.neurender import rasterize
+
+    # coplanar duplicates (tie -> lowest index), near/far rejection, degenerate + NaN faces, odd size
+    is_ = 37
+    tri = np.array([[-0.8, -0.7, 1.0], [0.9, -0.6, 1.0], [0.1, 0.85, 1.0]], np.float32)
+    faces = np.stack([tri, tri, tri * [1, 1, 0.05], tri * [1, 1, 500.0], tri[[0, 0, 1]], tri * np.nan,
+                      tri[::-1]])[None]
+    tex = np.random.default_rng(0).uniform(0, 1, (1, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    ref = R.rasterize_rgbad(faces, tex, is_, False, 0.1, 100, 1e-3, (0, 0, 0))
+    out = rasterize.rasterize_rgbad(t(faces, cuda), t(tex, cuda), is_, False, 0.1, 100, 1e-3, (0, 0, 0))
+    fim = out["face_index_map"].cpu().numpy()
+    assert (fim != ref["face_index_map"]).sum() == 0
+    assert set(np.unique(fim)) == {-1, 0}
+    assert_close(out["rgb"].cpu().numpy(), ref["rgb"], 1e-6, 1e-6, "rgb")
+    # empty batch / zero faces
+    e = rasterize.rasterize_rgbad(torch.zeros((1, 0, 3, 3), device=cuda), torch.zeros((1, 0, 2, 2, 2, 3), device=cuda),
+                                  16, False)
+    assert (e["face_index_map"] == -1).all() and (e["alpha"] == 0).all() and (e["depth"] == 100).all()
+    # anti-aliasing: 2x raster + average pool, maps stay at 2x
+    faces2, tex2 = projected_faces(1, 64, 5)
+    ref = R.rasterize_rgbad(faces2, tex2, 32, True, 0.1, 100, 1e-3, (0, 0, 0))
+    out = rasterize.rasterize_rgbad(t(faces2, cuda), t(tex2, cuda), 32, True, 0.1, 100, 1e-3, (0, 0, 0))
+    assert out["face_index_map"].shape == (1, 64, 64) and out["rgb"].shape == (1, 3, 32, 32)
+    assert_close(out["rgb"].cpu().numpy(), ref["rgb"], 1e-6, 1e-6, "aa rgb")
+    assert_close(out["alpha"].cpu().numpy(), ref["alpha"], 0, 1e-7, "aa alpha")
+    # CPU tensors are rejected like the reference (rasterize.py:346-347)
+    with pytest.raises(TypeError):
+        rasterize.rasterize_rgbad(torch.zeros((1, 1, 3, 3)), torch.zeros((1, 1, 2, 2, 2, 3)), 8, False)
+
+
+def test_silhouette_config1(cuda):
+    """BASELINE config 1: single 1538-face hand-like mesh, 64x64 AA silhouette + depth modes."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+
+    s = synth.random_scene(1, seed=11, image_size=64)
+    verts, fidx = s["hand_verts1"], s["hand_faces"][None, :1538]
+    ren = Renderer(image_size=64, anti_aliasing=True, fill_back=True, camera_mode="projection",
+                   K=t(s["K1"], cuda), R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   orig_size=64)
+    sil = ren(t(verts, cuda), t(fidx, cuda), mode="silhouettes").cpu().numpy()
+    dep = ren(t(verts, cuda), t(fidx, cuda), mode="depth").cpu().numpy()
+    f2, _ = R.fill_back(fidx)
+    v = R.nr_projection(verts, s["K1"], REN_KW["R"], REN_KW["t"], REN_KW["dist_coeffs"], 64)
+    ref = R.rasterize_rgbad(R.nr_vertices_to_faces(v, f2), None, 64, True, 0.1, 100, 1e-4, None, False, True, True)
+    assert sil.shape == (1, 64, 64) and sil.sum() > 20
+    assert_close(sil, ref["alpha"], 0, 1e-7, "silhouette")
+    assert_close(dep, ref["depth"], 1e-6, 0, "depth")

@@ -1,0 +1,175 @@
+"""Parity of the HIP warp kernels (through the C-ABI) against the numpy oracle AND against the
+golden vectors captured from the real reference (tests/golden/warp_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from handobjectconsist_amd.utils import synth
+from oracle import raster_ref as R
+from oracle import warp_ref as W
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def close(a, b, rtol, atol, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert (err <= tol).all(), f"{what}: max err {err.max():.3e}, {(err > tol).sum()} / {err.size} out of tol"
+
+
+def test_warp_golden(cuda):
+    from handobjectconsist_amd.warping import imgflowarp
+
+    g = np.load(os.path.join(GOLDEN, "warp_basic.npz"))
+    for mode in ("bilinear", "nearest"):
+        x = t(g["x"], cuda).requires_grad_(True)
+        flow = t(g["flow"], cuda).requires_grad_(True)
+        out, mask = imgflowarp.warp(x, flow, mode=mode)
+        assert (mask.cpu().numpy() != g[f"mask_{mode}"]).sum() == 0
+        close(out.detach().cpu().numpy(), g[f"out_{mode}"], 1e-5, 2e-6, f"warp {mode}")
+        if mode == "bilinear":
+            (out * t(g["grad_out"], cuda)).sum().backward()
+            close(x.grad.cpu().numpy(), g["grad_x"], 1e-4, 1e-5, "grad_x")
+            close(flow.grad.cpu().numpy(), g["grad_flow"], 1e-4, 1e-5, "grad_flow")
+    for scale in (False, True):
+        mg = imgflowarp.get_spatial_meshgrid(t(g["x"], cuda), scale=scale)
+        close(mg.cpu().numpy(), g[f"meshgrid_{int(scale)}"], 0, 0, "meshgrid")
+
+
+def test_occlusion_golden(cuda):
+    from handobjectconsist_amd.warping import imgflowarp
+
+    g = np.load(os.path.join(GOLDEN, "warp_occlusion.npz"))
+    o1, o2 = imgflowarp.get_occlusion_mask(t(g["mask_flow1"], cuda), t(g["mask_flow2"], cuda),
+                                           t(g["flow12"], cuda), t(g["flow21"], cuda))
+    close(o1.cpu().numpy(), g["occl1"], 0, 1e-7, "occl1")
+    close(o2.cpu().numpy(), g["occl2"], 0, 1e-7, "occl2")
+    assert g["occl1"].sum() > 10
+
+
+@pytest.mark.parametrize("use_backward", [False, True])
+@pytest.mark.parametrize("outputs", ["full", "loss"])
+def test_pair_consist_golden(cuda, use_backward, outputs):
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import imgflowarp
+
+    g = np.load(os.path.join(GOLDEN, "warp_pair_consist.npz"))
+    tag = f"ub{int(use_backward)}"
+    f12 = t(g["flow12"], cuda).requires_grad_(True)
+    f21 = t(g["flow21"], cuda).requires_grad_(True)
+    loss, masks, warps, diffs = imgflowarp.pair_consist(
+        [f12, f21], t(g["image_ref"], cuda), t(g["image"], cuda), t(g["jitter_ref"], cuda), t(g["jitter"], cuda),
+        PyramidCriterion("l1"), use_backward=use_backward, outputs=outputs)
+    close(loss.detach().cpu().numpy(), g[f"loss_{tag}"], 1e-5, 1e-7, "loss")
+    (loss * t(g["grad_loss"], cuda)).sum().backward()
+    g12 = f12.grad.cpu().numpy() if f12.grad is not None else np.zeros_like(g["flow12"])
+    close(g12, g[f"grad_flow12_{tag}"], 1e-4, 1e-7, "grad_flow12")
+    close(f21.grad.cpu().numpy(), g[f"grad_flow21_{tag}"], 1e-4, 1e-7, "grad_flow21")
+    if outputs == "loss":
+        assert masks is None and warps is None and diffs is None
+        return
+    for i in (0, 1):
+        assert (masks[i]["full_mask"].cpu().numpy() != g[f"full_mask{i + 1}"]).sum() == 0
+        assert (masks[i]["warp_mask"].cpu().numpy() != g[f"warp_mask{i + 1}"]).sum() == 0
+        assert (masks[i]["flow_mask"].cpu().numpy() != g[f"flow_mask{i + 1}"]).sum() == 0
+        close(warps[i].cpu().numpy(), g[f"warp{i + 1}"], 1e-5, 2e-6, "warp")
+        close(diffs[i].cpu().numpy(), g[f"diff{i + 1}"], 1e-5, 2e-6, "diff")
+
+
+def test_pair_consist_generic_criterion_matches_fused(cuda):
+    """l2 goes through the composed `warp` path (reference control flow); with l1 both paths agree."""
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import imgflowarp
+
+    g = np.load(os.path.join(GOLDEN, "warp_pair_consist.npz"))
+    args = [t(g[k], cuda) for k in ("image_ref", "image", "jitter_ref", "jitter")]
+    flows = [t(g["flow12"], cuda), t(g["flow21"], cuda)]
+    fused = imgflowarp.pair_consist(flows, *args, PyramidCriterion("l1"), use_backward=True)
+
+    class L1Composed(PyramidCriterion):  # not recognised by the fused fast path
+        level_nb = 1
+
+        def __init__(self):
+            self.criterion = lambda a, b: (a - b).abs()
+
+    comp = imgflowarp.pair_consist(flows, *args, L1Composed(), use_backward=True)
+    close(comp[0].cpu().numpy(), fused[0].cpu().numpy(), 1e-5, 1e-7, "loss composed vs fused")
+    for i in (0, 1):
+        assert (comp[1][i]["full_mask"] != fused[1][i]["full_mask"]).sum() == 0
+        assert (comp[1][i]["warp_mask"] != fused[1][i]["warp_mask"]).sum() == 0
+    l2 = imgflowarp.pair_consist(flows, *args, PyramidCriterion("l2"), use_backward=False)
+    assert torch.isfinite(l2[0]).all()
+
+
+def test_pair_consist_large_matches_oracle(cuda):
+    """Full-size (B=8, 256x256) loss + flow gradients vs the numpy oracle; non-multiple-of-256
+    pixel count as well (270x480 FPHAB frames, BASELINE config 3)."""
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import imgflowarp
+
+    for (B, H, Wd, seed) in ((4, 256, 256, 0), (2, 270, 480, 1)):
+        rng = np.random.default_rng(seed)
+        im_ref, im, jm_ref, jm = synth.random_images(B, H, Wd, seed)
+        flows = []
+        for _ in range(2):
+            f = (rng.standard_normal((B, H, Wd, 2)) * 2).astype(np.float32)
+            f[rng.random((B, H, Wd)) < 0.5] = 0
+            flows.append(f)
+        gl = rng.uniform(0.5, 1.5, (B,)).astype(np.float32)
+        ref_loss, ref_masks, _, _, _ = W.pair_consist(flows, im_ref, im, jm_ref, jm, True)
+        ref_g = W.pair_consist_grad(flows, im_ref, im, jm_ref, jm, gl, True)
+        f12 = t(flows[0], cuda).requires_grad_(True)
+        f21 = t(flows[1], cuda).requires_grad_(True)
+        loss, masks, _, _ = imgflowarp.pair_consist([f12, f21], t(im_ref, cuda), t(im, cuda), t(jm_ref, cuda),
+                                                   t(jm, cuda), PyramidCriterion("l1"), use_backward=True)
+        close(loss.detach().cpu().numpy(), ref_loss, 1e-5, 1e-7, "loss")
+        for i in (0, 1):
+            assert (masks[i]["full_mask"].cpu().numpy() != ref_masks[i]["full_mask"]).sum() == 0
+        (loss * t(gl, cuda)).sum().backward()
+        close(f12.grad.cpu().numpy(), ref_g[0], 1e-4, 1e-9, "grad_flow12")
+        close(f21.grad.cpu().numpy(), ref_g[1], 1e-4, 1e-9, "grad_flow21")
+
+
+def test_opticalflow_chain_matches_oracle(cuda):
+    """get_opticalflow (two renders + masks + occlusion + crop) and the pair loss on top of it,
+    HIP path vs oracle chain, on the synthetic hand+object scene (non-square crop)."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import imgflowarp, opticalflow
+
+    B, is_, H, Wd = 2, 128, 96, 128
+    s = synth.random_scene(B, seed=21, image_size=is_)
+    kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
+              dist_coeffs=np.zeros((1, 5), np.float32), orig_size=is_, image_size=is_, anti_aliasing=False,
+              near=0.1, far=100, eps=1e-3)
+    ref_flows = W.get_opticalflow(R, [s["verts1"], s["verts2"]], s["faces"], [s["K1"], s["K2"]], kw,
+                                  orig_img_size=(Wd, H), ignore_face_idxs=synth.HAND_IGNORE_FACES)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
+                   no_light=True, light_intensity_ambient=0.8)  # warpreg.py:40-51
+    v1 = t(s["verts1"], cuda).requires_grad_(True)
+    flows = opticalflow.get_opticalflow([v1, t(s["verts2"], cuda)], t(s["faces"], cuda),
+                                        [t(s["K1"], cuda), t(s["K2"], cuda)], ren, orig_img_size=(Wd, H),
+                                        detach_textures=False, detach_renders=True,
+                                        ignore_face_idxs=synth.HAND_IGNORE_FACES)
+    for i in (0, 1):
+        assert flows[i].shape == (B, H, Wd, 2)
+        got, ref = flows[i].detach().cpu().numpy(), ref_flows[i]
+        assert ((got != 0) != (ref != 0)).sum() == 0, "flow support differs"
+        close(got, ref, 1e-4, 1e-5, f"flow{i}")
+        assert (ref[..., 0] != 0).sum() > 100
+    im_ref, im, jm_ref, jm = synth.random_images(B, H, Wd, 3)
+    ref_loss = W.pair_consist(ref_flows, im_ref, im, jm_ref, jm, True)[0]
+    loss = imgflowarp.pair_consist(flows, t(im_ref, cuda), t(im, cuda), t(jm_ref, cuda), t(jm, cuda),
+                                   PyramidCriterion("l1"), use_backward=True, outputs="loss")[0]
+    close(loss.detach().cpu().numpy(), ref_loss, 1e-4, 1e-7, "pair loss on rendered flows")
+    loss.sum().backward()
+    assert v1.grad is not None and torch.isfinite(v1.grad).all() and v1.grad.abs().sum() > 0
