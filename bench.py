@@ -1,0 +1,303 @@
+#!/usr/bin/env python
+"""bench.py -- trainmeshwarp optimiser-steps/sec with render + warp in the loop.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimiser step of trainmeshwarp.py at B=64, 256x256 (BASELINE.json metric;
+SURVEY Q15): a supervised data batch (B frames) + a consistency batch (B frame pairs): 3B
+ResNet-18 forwards, MANO LBS, 2 differentiable renders (1780 verts / 7104 faces after
+fill-back), occlusion check, 2-direction photometric pair loss, ONE backward through all of
+it, Adam step.  Inputs are synthetic (seeded) and resident in HBM before the timed region.
+Per-GPU work is fixed as N grows (weak scaling, batch-sharded DP; the model's gradients are
+all-reduced by DDP over RCCL, the render/warp kernels need no collective).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  "roofline":     algorithmic bytes / live HIP-event duration of the dominant hot-path kernel,
+  "kernels":      the same for every hot-path kernel group (render fwd, render bwd, pair loss...),
+  "cpu_baseline": the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
+                  bounded sample of the same hot path (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=64, help="per-GPU batch size (frames / frame pairs)")
+    p.add_argument("--image-size", type=int, default=256)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-bench", action="store_true")
+    p.add_argument("--cpu-sample", type=int, default=2, help="images in the CPU-baseline sample")
+    p.add_argument("--kernel-iters", type=int, default=50)
+    return p.parse_args()
+
+
+def event_time_ms(fn, iters, warmup=5):
+    """Average duration of fn() in ms, HIP events on torch's current stream (the stream every
+    libmeshraster_hip launch of this process goes to)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_bench(dev, B, is_, iters):
+    """Each hot-path kernel group alone, on the bench workload's own tensors.  Algorithmic
+    bytes per launch follow SURVEY 8(d) / DESIGN.md."""
+    from handobjectconsist_amd import _lib
+    from handobjectconsist_amd.neurender import nr_ops
+    from handobjectconsist_amd.utils import synth, textutils
+    from handobjectconsist_amd.warping import imgflowarp
+
+    s = synth.random_scene(B, seed=0, image_size=is_)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    verts, faces_idx, K = t(s["verts1"]), t(s["faces"]), t(s["K1"])
+    colors = torch.randn(B, verts.shape[1], 3, device=dev)
+    tex = textutils.batch_vertex_textures(faces_idx, colors)
+    faces_idx2 = torch.cat((faces_idx, faces_idx.flip(-1)), 1)
+    tex2 = torch.cat((tex, tex.permute(0, 1, 4, 3, 2, 5)), 1).contiguous()
+    v = nr_ops.projection(verts, K, torch.eye(3, device=dev)[None], torch.zeros(1, 3, device=dev),
+                          torch.zeros(1, 5, device=dev), is_)
+    faces = nr_ops.vertices_to_faces(v, faces_idx2).contiguous()
+    F = faces.shape[1]
+    npx = B * is_ * is_
+    lib = _lib.load()
+    st = _lib.stream_ptr(dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    rgb, alpha, depth = torch.empty((B, 3, is_, is_), **f32), torch.empty((B, is_, is_), **f32), torch.empty((B, is_, is_), **f32)
+    fim = torch.empty((B, is_, is_), dtype=torch.int32, device=dev)
+    wmap = torch.empty((B, is_, is_, 3), **f32)
+    wbytes = int(lib.mr_render_workspace_bytes(B, F, is_))
+    work = torch.empty((wbytes,), dtype=torch.uint8, device=dev)
+    bg = torch.zeros(3, **f32)
+    P = _lib.ptr
+
+    def render_fwd():
+        _lib.call("mr_render_forward", P(faces), P(tex2), P(bg), 0, P(rgb), P(alpha), P(depth), P(fim), P(wmap),
+                  None, P(work), wbytes, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+
+    g_rgb, g_alpha, g_depth = torch.randn_like(rgb), torch.randn_like(alpha), torch.randn_like(depth)
+    grad_tex, grad_faces = torch.empty_like(tex2), torch.empty_like(faces)
+
+    def render_bwd_train():  # detach_renders=True: textures only (kernel E)
+        _lib.call("mr_render_backward", P(faces), P(tex2), P(fim), P(rgb), P(alpha), P(g_rgb), None, None, None,
+                  P(grad_tex), None, 0, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+
+    def render_bwd_full():  # kernels D + E + F
+        _lib.call("mr_render_backward", P(faces), P(tex2), P(fim), P(rgb), P(alpha), P(g_rgb), P(g_alpha),
+                  P(g_depth), P(grad_faces), P(grad_tex), None, 0, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+
+    im_ref, im, jm_ref, jm = [t(a) for a in synth.random_images(B, is_, is_, 0)]
+    flow12 = (torch.randn(B, is_, is_, 2, device=dev) * 2) * (torch.rand(B, is_, is_, 1, device=dev) < 0.1)
+    flow21 = (torch.randn(B, is_, is_, 2, device=dev) * 2) * (torch.rand(B, is_, is_, 1, device=dev) < 0.1)
+    pbytes = int(lib.mr_pair_consist_workspace_bytes(B, is_, is_))
+    pwork = torch.empty((pbytes,), dtype=torch.uint8, device=dev)
+    sums, lf, lb = torch.empty((B, 4), **f32), torch.empty((B,), **f32), torch.empty((B,), **f32)
+    g12, g21 = torch.empty_like(flow12), torch.empty_like(flow21)
+    gl = torch.full((B,), 1.0 / B, **f32)
+
+    def pair_fwd():
+        _lib.call("mr_pair_consist_forward", P(flow12), P(flow21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(pwork),
+                  pbytes, P(sums), P(lf), P(lb), *([None] * 8), B, is_, is_, 0.99999, st)
+
+    def pair_bwd():
+        _lib.call("mr_pair_consist_backward", P(flow12), P(flow21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(sums),
+                  P(gl), P(gl), P(g12), P(g21), B, is_, is_, 0.99999, st)
+
+    m1, m2 = alpha.unsqueeze(1).contiguous(), alpha.unsqueeze(1).contiguous()
+    o1, o2 = torch.empty((B, is_, is_), **f32), torch.empty((B, is_, is_), **f32)
+
+    def occlusion():
+        _lib.call("mr_occlusion_mask", P(m1), P(m2), P(rgb), P(rgb), 3 * is_ * is_, P(o1), P(o2), B, is_, is_, 0.03,
+                  0.99999, st)
+
+    render_fwd()
+    BF = B * F
+    groups = [
+        # name, fn, algorithmic bytes per launch
+        ("render_forward", render_fwd, 132 * BF + 36 * npx),
+        ("render_backward_train(E)", render_bwd_train, (12 + 4 + 12 + 4) * npx + (36 + 96) * BF),
+        ("render_backward_full(D+E+F)", render_bwd_full, 56 * npx + 168 * BF),
+        ("pair_consist_forward", pair_fwd, 48 * npx),
+        ("pair_consist_backward", pair_bwd, 64 * npx),
+        ("occlusion_mask", occlusion, (8 + 16 + 8) * npx),
+    ]
+    out = {}
+    for name, fn, nbytes in groups:
+        ms = event_time_ms(fn, iters)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {"ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1), "GBps": round(gbs, 1),
+                     "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def cpu_baseline(B_sample, is_, B_full):
+    """The CPU oracle (oracle/, a port -- the reference has no CPU render path) on a
+    bounded sample of the hot path: 2 renders + flow masks + occlusion + pair loss forward, and
+    the texture / flow backward; extrapolated linearly in the batch size (images are independent)."""
+    from handobjectconsist_amd.utils import synth
+    from oracle import raster_ref as R
+    from oracle import warp_ref as W
+
+    threads = os.cpu_count() or 1
+    s = synth.random_scene(B_sample, seed=0, image_size=is_)
+    kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
+              dist_coeffs=np.zeros((1, 5), np.float32), orig_size=is_, image_size=is_, anti_aliasing=False,
+              near=0.1, far=100, eps=1e-3, num_threads=threads)
+    im_ref, im, jm_ref, jm = synth.random_images(B_sample, is_, is_, 0)
+    R.lib()
+    kw["keep_saved"] = True
+    t0 = time.perf_counter()
+    flows, renders = W.get_opticalflow(R, [s["verts1"], s["verts2"]], s["faces"], [s["K1"], s["K2"]], kw,
+                                       orig_img_size=(is_, is_), ignore_face_idxs=synth.HAND_IGNORE_FACES,
+                                       return_renders=True)
+    W.pair_consist(flows, im_ref, im, jm_ref, jm, True)
+    gl = np.full((B_sample,), 1.0 / B_sample, np.float32)
+    gflows = W.pair_consist_grad(flows, im_ref, im, jm_ref, jm, gl, True)
+    # texture backward of the two renders (kernel E; training mode = detach_renders)
+    for ro, g in zip(renders, gflows):
+        sv = ro["_saved"]
+        g_rgb = np.zeros_like(sv["rgb_map"])
+        g_rgb[..., :2] = g[:, ::-1]
+        R.backward_textures(sv["face_index_map"], sv["sampling_weight_map"], sv["sampling_index_map"], g_rgb,
+                            sv["faces"].shape[1], 2)
+    dt = time.perf_counter() - t0
+    sec_per_iter = dt * (B_full / B_sample)
+    return {"value": round(1.0 / sec_per_iter, 6), "unit": "iters/s", "cores": threads, "kind": "port",
+            "sample": f"hot path only (2 renders fwd, flow masks, occlusion, pair loss fwd+bwd, texture bwd; encoder "
+                      f"and optimiser excluded), B={B_sample} of {B_full} at {is_}x{is_}, {dt:.1f} s measured on "
+                      f"{threads} threads, extrapolated x{B_full // B_sample}"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from handobjectconsist_amd import _lib
+    from handobjectconsist_amd.models.synthnet import SynthMeshRegNet
+    from handobjectconsist_amd.models.warpreg import WarpRegNet
+    from handobjectconsist_amd.netscripts.epochpassconsist import SyntheticConsistLoader, train_step
+
+    assert _lib.load().mr_device_ok() == 1, "libmeshraster_hip.so: no gfx950 device"
+    torch.manual_seed(rank)
+    B, is_ = args.batch, args.image_size
+    model = SynthMeshRegNet().to(dev)
+    model.eval()  # --freeze_batchnorm: BN statistics frozen, affine parameters trainable
+    net = model
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        net = DDP(model, device_ids=[local_rank], bucket_cap_mb=8, gradient_as_bucket_view=True)
+    premodel = WarpRegNet((is_, is_), net, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
+                          progressive_steps=1000, use_backward=True, mano_faces=model.mano_layer.th_faces,
+                          pair_outputs="loss").to(dev)
+    premodel.step_count = 1000  # past the lambda ramp: the consistency term carries its full weight
+    optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5)
+    loader = SyntheticConsistLoader(B, is_, seed=rank, device=dev, pool=2)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        train_step(loader.step_batches(i), premodel, optimizer)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = train_step(loader.step_batches(i), premodel, optimizer)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(loss).all(), "loss is not finite"
+
+    # hot path alone (2 renders, flows, occlusion, pair loss, backward to the vertices)
+    hot_ms = None
+    if rank == 0:
+        from handobjectconsist_amd.models import warpbranch
+
+        consist = loader.step_batches(0)[1]
+        fake_results = [{"recov_handverts3d": s_["_handverts3d"].clone().requires_grad_(True),
+                         "recov_objverts3d": s_["_objverts3d"].clone().requires_grad_(True)}
+                        for s_ in consist["data"]]
+
+        def hot():
+            l, _ = warpbranch.forward(consist["data"], fake_results, premodel.th_faces, premodel.renderer, (is_, is_),
+                                      premodel.criterion, gt_refs=True, hand_ignore_faces=premodel.hand_ignore_faces,
+                                      use_backward=True, pair_outputs="loss")
+            l.backward()
+
+        hot_ms = event_time_ms(hot, 10, 3)
+
+    kernels, roof, cpu = None, None, None
+    if rank == 0 and not args.no_kernel_bench:
+        kernels = kernel_bench(dev, B, is_, args.kernel_iters)
+        dom = "render_backward_train(E)"
+        k = kernels[dom]
+        roof = {"kernel": dom, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": k["frac_hbm_peak"], "traffic": None}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_sample, is_, B)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        line = {
+            "metric": "trainmeshwarp iters/sec (render+warp, B=64, 256x256)",
+            "value": round(world * args.steps / dt, 4),
+            "unit": "iters/s (each: 1 data batch + 1 consist batch of B per GPU, one optimizer step)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"trainmeshwarp.py consist step, per-GPU B={B}, {is_}x{is_}, hand 778v/1552f + "
+                                   f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 fp32 stock PyTorch, Adam",
+                       "global_batch": B * world, "image_size": is_, "parallelism": f"dp{world}"},
+            "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),
+            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

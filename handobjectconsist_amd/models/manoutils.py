@@ -1,0 +1,20 @@
+"""Closed-hand face list -- counterpart of meshreg/models/manoutils.py:6-35.
+
+The 14 wrist-closing faces and the ignore list are the reference's constants; the 1538 MANO
+faces themselves come from the (licence-gated, absent) MANO pickle in the reference and from
+the synthetic template here."""
+import torch
+
+CLOSE_FACES = [
+    [92, 38, 122], [234, 92, 122], [239, 234, 122], [279, 239, 122], [215, 279, 122], [215, 122, 118],
+    [215, 118, 117], [215, 117, 119], [215, 119, 120], [215, 120, 108], [215, 108, 79], [215, 79, 78],
+    [215, 78, 121], [214, 215, 121],
+]
+# Indices of faces added during closing --> ignored, they match the wrist (manoutils.py:33)
+HAND_IGNORE_FACES = [1538, 1539, 1540, 1541, 1542, 1543, 1544, 1545, 1546, 1547, 1548, 1549, 1550, 1551]
+
+
+def get_closed_faces(th_faces):
+    """th_faces [1538,3] (MANO faces) -> (closed_faces [1552,3], hand_ignore_faces)."""
+    close_faces = torch.tensor(CLOSE_FACES, dtype=torch.long, device=th_faces.device)
+    return torch.cat([th_faces.long(), close_faces]), list(HAND_IGNORE_FACES)

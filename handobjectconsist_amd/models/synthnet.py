@@ -1,0 +1,263 @@
+"""Stock PyTorch-ROCm counterpart of the network the hot path trains (bench / trainer only).
+
+BASELINE.json's north star keeps "the ResNet-18 encoder and regression heads on stock
+PyTorch-ROCm"; this module restates their ARCHITECTURE so that the timed optimiser step
+does the same work as the reference's (/root/reference/meshreg/models/meshregnet.py:54-384,
+resnet.py:92-175, absolutebranch.py, objbranch.py, manobranch.py:11-155, project.py:5-24):
+ResNet-18 trunk (features only, the unused `fc` dropped -- SURVEY 8e), two 512x512 MANO
+base layers, pose 512->18 (3 global + 15 PCA), shape 512->10, scale/trans branches
+512->256->{3,6}, MANO linear-blend skinning, object rotation + weak-perspective recovery,
+and the reference's default loss terms (trainmeshwarp.py defaults: recov_joints3d 0.5,
+obj recov_verts3d 0.5, pose_reg 5e-6, shape 5e-7).
+
+The MANO model files are licence-gated and absent, so `SynthManoLayer` carries seeded
+synthetic parameters of MANO's exact tensor shapes (template [778,3], shapedirs
+[778,3,10], posedirs [778,3,135], J_regressor [16,778], weights [778,16], 15 PCA comps)
+and performs manopth's `ManoLayer.forward` arithmetic: the batched
+contractions run on rocBLAS (MFMA), everything else is element-wise.  Weights are random
+(no checkpoints / no network): throughput, not accuracy, is what this model is for.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from handobjectconsist_amd.utils import project as camproject
+from handobjectconsist_amd.utils import synth
+
+
+# ----------------------------------------------------------------------------- ResNet-18
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        residual = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + residual)
+
+
+class ResNet18Features(nn.Module):
+    """resnet.py:92-167 with features=True: conv trunk, global average pool, [B,512]."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, 2)
+        self.layer2 = self._make_layer(128, 2, stride=2)
+        self.layer3 = self._make_layer(256, 2, stride=2)
+        self.layer4 = self._make_layer(512, 2, stride=2)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return x.mean(3).mean(2)
+
+
+class AbsoluteBranch(nn.Module):
+    """absolutebranch.py:4-19."""
+
+    def __init__(self, base_neurons=(512, 256), out_dim=3):
+        super().__init__()
+        layers = []
+        for i, o in zip(base_neurons[:-1], base_neurons[1:]):
+            layers += [nn.Linear(i, o), nn.ReLU()]
+        self.decoder = nn.Sequential(*layers)
+        self.final_layer = nn.Linear(base_neurons[-1], out_dim)
+
+    def forward(self, inp):
+        return self.final_layer(self.decoder(inp))
+
+
+# ----------------------------------------------------------------------------- MANO LBS
+def batch_rodrigues(rvec):
+    """[N,3] axis-angle -> [N,3,3] (manopth rodrigues_layer semantics, via quaternion)."""
+    angle = torch.norm(rvec + 1e-8, p=2, dim=1, keepdim=True)
+    axis = rvec / angle
+    half = angle * 0.5
+    q = torch.cat([torch.cos(half), torch.sin(half) * axis], 1)
+    q = q / q.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    w2, x2, y2, z2 = w * w, x * x, y * y, z * z
+    wx, wy, wz, xy, xz, yz = w * x, w * y, w * z, x * y, x * z, y * z
+    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz, 2 * wz + 2 * xy, w2 - x2 + y2 - z2,
+                        2 * yz - 2 * wx, 2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], 1).view(-1, 3, 3)
+
+
+MANO_PARENTS = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14]
+MANO_TIPS = [745, 317, 444, 556, 673]
+MANO_REORDER = [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]
+
+
+class SynthManoLayer(nn.Module):
+    """manopth ManoLayer.forward on synthetic MANO-shaped parameters."""
+
+    def __init__(self, ncomps=15, use_pca=True, flat_hand_mean=False, center_idx=9, seed=0):
+        super().__init__()
+        rng = np.random.default_rng(seed)
+        v, f = synth.hand_template()
+        self.use_pca, self.ncomps, self.center_idx = use_pca, ncomps, center_idx
+        # 16 synthetic joints spread through the template, soft skinning weights by distance
+        jpos = v[rng.choice(v.shape[0], 16, replace=False)] * 0.6
+        d = ((v[:, None] - jpos[None]) ** 2).sum(-1)
+        wts = np.exp(-d / (2 * 0.02 ** 2))
+        wts = wts / wts.sum(1, keepdims=True)
+        jreg = np.exp(-d.T / (2 * 0.01 ** 2))
+        jreg = jreg / jreg.sum(1, keepdims=True)
+        comps = np.linalg.qr(rng.standard_normal((45, 45)))[0]
+        buf = lambda name, a: self.register_buffer(name, torch.tensor(np.asarray(a), dtype=torch.float32))
+        buf("th_v_template", v[None])
+        buf("th_shapedirs", rng.standard_normal((778, 3, 10)) * 0.002)
+        buf("th_posedirs", rng.standard_normal((778, 3, 135)) * 0.0005)
+        buf("th_J_regressor", jreg)
+        buf("th_weights", wts)
+        buf("th_comps", comps)
+        buf("th_hands_mean", np.zeros((1, 45)) if flat_hand_mean else rng.standard_normal((1, 45)) * 0.1)
+        self.register_buffer("th_faces", torch.tensor(f[:1538], dtype=torch.long))
+
+    def forward(self, th_pose_coeffs, th_betas=None, th_trans=None):
+        B = th_pose_coeffs.shape[0]
+        hand = th_pose_coeffs[:, 3:3 + self.ncomps] if self.use_pca else th_pose_coeffs[:, 3:]
+        full_hand = hand.mm(self.th_comps[: self.ncomps]) if self.use_pca else hand
+        full_pose = torch.cat([th_pose_coeffs[:, :3], self.th_hands_mean + full_hand], 1)
+        rots = batch_rodrigues(full_pose.reshape(-1, 3)).view(B, 16, 3, 3)
+        root_rot = rots[:, 0]
+        pose_map = (rots[:, 1:] - torch.eye(3, device=rots.device)).reshape(B, 135)
+        if th_betas is None:
+            th_betas = th_pose_coeffs.new_zeros((B, 10))
+        v_shaped = torch.matmul(self.th_shapedirs, th_betas.t()).permute(2, 0, 1) + self.th_v_template
+        joints = torch.matmul(self.th_J_regressor, v_shaped)
+        v_posed = v_shaped + torch.matmul(self.th_posedirs, pose_map.t()).permute(2, 0, 1)
+
+        def with_zeros(rot, tr):
+            top = torch.cat([rot, tr.unsqueeze(-1)], -1)
+            bottom = top.new_tensor([0.0, 0.0, 0.0, 1.0]).expand(top.shape[0], 1, 4)
+            return torch.cat([top, bottom], 1)
+
+        results = [with_zeros(root_rot, joints[:, 0])]
+        for k in range(1, 16):
+            p = MANO_PARENTS[k]
+            rel = with_zeros(rots[:, k], joints[:, k] - joints[:, p])
+            results.append(torch.matmul(results[p], rel))
+        G = torch.stack(results, 1)  # [B,16,4,4]
+        j_h = torch.cat([joints, joints.new_zeros((B, 16, 1))], 2).unsqueeze(-1)
+        G2 = G - F.pad(torch.matmul(G, j_h), (3, 0))
+        T = torch.matmul(self.th_weights, G2.reshape(B, 16, 16)).view(B, 778, 4, 4)
+        v_h = torch.cat([v_posed, v_posed.new_ones((B, 778, 1))], 2).unsqueeze(-1)
+        verts = torch.matmul(T, v_h)[:, :, :3, 0]
+        jtr = torch.cat([G[:, :, :3, 3], verts[:, MANO_TIPS]], 1)[:, MANO_REORDER]
+        if th_trans is None or bool(torch.norm(th_trans) == 0):
+            if self.center_idx is not None:
+                center = jtr[:, self.center_idx].unsqueeze(1)
+                jtr, verts = jtr - center, verts - center
+        else:
+            jtr, verts = jtr + th_trans.unsqueeze(1), verts + th_trans.unsqueeze(1)
+        return verts * 1000, jtr * 1000
+
+
+# ----------------------------------------------------------------------------- the network
+def recover_3d_proj(objpoints3d, camintr, est_scale, est_trans, off_z=0.4, input_res=(128, 128)):
+    """meshreg/models/project.py:5-24 (pinned by tests/golden/warp_misc.npz)."""
+    focal = camintr[:, :1, :1]
+    batch_size = objpoints3d.shape[0]
+    focal = focal.view(batch_size, 1)
+    est_scale = est_scale.view(batch_size, 1)
+    est_trans = est_trans.view(batch_size, 2)
+    est_Z0 = focal * est_scale + off_z
+    cam_centers = camintr[:, :2, 2]
+    img_centers = (cam_centers.new_tensor(input_res) / 2).view(1, 2).repeat(batch_size, 1)
+    est_XY0 = (est_trans + img_centers - cam_centers) * est_Z0 / focal
+    est_c3d = torch.cat([est_XY0, est_Z0], -1).unsqueeze(1)
+    return est_c3d + objpoints3d, est_c3d
+
+
+class SynthMeshRegNet(nn.Module):
+    """MeshRegNet (meshregnet.py:54-384) with the trainmeshwarp.py default loss weights.
+
+    forward(sample) -> (total_loss [1], results, losses); sample is a dict of device tensors:
+    image [B,3,H,W], camintr [B,3,3], objcanverts [B,Vo,3], and (supervised frames only)
+    joints3d [B,21,3], objverts3d [B,Vo,3]."""
+
+    def __init__(self, obj_trans_factor=100, obj_scale_factor=0.0001, lambda_recov_joints3d=0.5,
+                 lambda_obj_recov_verts3d=0.5, lambda_pose_reg=5e-6, lambda_shape=5e-7, mano_comps=15):
+        super().__init__()
+        self.base_net = ResNet18Features()
+        self.scaletrans_branch = AbsoluteBranch((512, 256), 3)
+        self.scaletrans_branch_obj = AbsoluteBranch((512, 256), 6)
+        self.mano_base = nn.Sequential(nn.Linear(512, 512), nn.ReLU(), nn.Linear(512, 512), nn.ReLU())
+        self.pose_reg = nn.Linear(512, mano_comps + 3)
+        self.shape_reg = nn.Linear(512, 10)
+        self.mano_layer = SynthManoLayer(ncomps=mano_comps, use_pca=True, center_idx=9)
+        self.obj_trans_factor, self.obj_scale_factor = obj_trans_factor, obj_scale_factor
+        self.lam = (lambda_recov_joints3d, lambda_obj_recov_verts3d, lambda_pose_reg, lambda_shape)
+
+    def forward(self, sample, no_loss=False):
+        image = sample["image"]
+        features = self.base_net(image)
+        H, W = image.shape[2:]
+        camintr = sample["camintr"]
+        lam_j, lam_o, lam_pose, lam_shape = self.lam
+        losses, results = {}, {}
+        total_loss = image.new_zeros((1,))
+
+        # hand: MANO branch (manobranch.py:88-155) + camera recovery (meshregnet.py:206-245)
+        base = self.mano_base(features)
+        pose, shape = self.pose_reg(base), self.shape_reg(base)
+        verts, joints = self.mano_layer(pose, th_betas=shape)
+        verts3d, joints3d = verts / 1000, joints / 1000
+        reg_loss = lam_shape * F.mse_loss(shape, torch.zeros_like(shape)) \
+            + lam_pose * F.mse_loss(pose[:, 3:], torch.zeros_like(pose[:, 3:]))
+        losses["mano_reg_loss"] = reg_loss.view(1)
+        total_loss = total_loss + reg_loss
+        scaletrans = self.scaletrans_branch(features)
+        trans, scale = scaletrans[:, 1:], scaletrans[:, :1]
+        final_trans = trans.unsqueeze(1) * self.obj_trans_factor
+        final_scale = scale.view(-1, 1, 1) * self.obj_scale_factor
+        recov_joints3d, center3d = recover_3d_proj(joints3d, camintr, final_scale, final_trans, input_res=(W, H))
+        results["recov_handverts3d"] = verts3d + center3d
+        results["recov_joints3d"] = recov_joints3d
+        results["joints2d"] = camproject.batch_proj2d(recov_joints3d, camintr)
+        if not no_loss and "joints3d" in sample:
+            losses["recov_joint3d"] = F.mse_loss(recov_joints3d, sample["joints3d"])
+            total_loss = total_loss + lam_j * losses["recov_joint3d"]
+
+        # object: rotation + weak-perspective recovery (objbranch.py:28-84, meshregnet.py:274-323)
+        st_obj = self.scaletrans_branch_obj(features)
+        rotmat = batch_rodrigues(st_obj[:, 3:])
+        rotobjverts = rotmat.bmm(sample["objcanverts"].transpose(1, 2)).transpose(1, 2)
+        o_trans = st_obj[:, 1:3].unsqueeze(1) * self.obj_trans_factor
+        o_scale = st_obj[:, :1].view(-1, 1, 1) * self.obj_scale_factor
+        objverts3d, _ = recover_3d_proj(rotobjverts, camintr, o_scale, o_trans, input_res=(W, H))
+        results["recov_objverts3d"] = objverts3d
+        results["obj_verts2d"] = camproject.batch_proj2d(objverts3d, camintr)
+        if not no_loss and "objverts3d" in sample:
+            losses["recov_objverts3d"] = F.mse_loss(objverts3d, sample["objverts3d"])
+            total_loss = total_loss + lam_o * losses["recov_objverts3d"]
+        losses["total_loss"] = total_loss
+        return total_loss, results, losses

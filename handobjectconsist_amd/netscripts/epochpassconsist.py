@@ -1,0 +1,80 @@
+"""Training loop over alternating data / consist batches -- counterpart of the hot loop of
+meshreg/netscripts/epochpassconsist.py:56-68 (metric meters, evaluators and figure dumps are
+out of scope).  Loss is accumulated over ``loader_nb`` consecutive batches, then ONE
+``zero_grad / backward / step``: that is the "iteration" of the headline metric.
+"""
+import torch
+
+from handobjectconsist_amd.utils import synth
+
+
+def train_step(batches, premodel, optimizer):
+    """One optimiser step over `loader_nb = len(batches)` batches (epochpassconsist.py:57-68)."""
+    losses, logs = [], {}
+    for batch in batches:
+        loss, all_losses, _results, _pair_results = premodel.forward(batch)
+        losses.append(loss.flatten())
+        logs.update({k: v for k, v in all_losses.items() if v is not None})
+    optimizer.zero_grad(set_to_none=True)
+    loss = torch.stack(losses).sum()
+    if loss.requires_grad:
+        loss.backward()
+        optimizer.step()
+    return loss.detach(), logs
+
+
+def epoch_pass(loader, premodel, optimizer, loader_nb=2, check_nan=True):
+    """loader yields {"data": [sample, ...], "supervision": "data" | "consist"} dicts."""
+    pending, history = [], []
+    for batch in loader:
+        pending.append(batch)
+        if len(pending) == loader_nb:
+            loss, _ = train_step(pending, premodel, optimizer)
+            if check_nan and bool(torch.isnan(loss)):
+                raise ValueError("Loss became nan!")
+            history.append(loss)
+            pending = []
+    return history
+
+
+class SyntheticConsistLoader:
+    """Device-resident synthetic stand-in for ConcatLoader(strong loader, consist loader)
+    (concatloader.py:4-30; trainmeshwarp.py:97-156): alternates one "data" batch (one frame,
+    fully supervised) and one "consist" batch (a frame pair: unannotated frame first, annotated
+    reference second -- warpbranch compares everything to samples[0], GT replaces samples[1:])."""
+
+    def __init__(self, batch_size, image_size=256, steps=1, seed=0, device="cuda", pool=2):
+        self.steps, self.device = steps, torch.device(device)
+        self.batches = []
+        t = lambda a: torch.from_numpy(a).to(self.device)
+        ov, _ = synth.object_template()
+        for k in range(pool):
+            s = synth.random_scene(batch_size, seed=seed * 1000 + k, image_size=image_size)
+            im_ref, im, jm_ref, jm = synth.random_images(batch_size, image_size, image_size, seed * 1000 + k)
+            canverts = t(ov[None].repeat(batch_size, 0).copy())
+
+            def sample(img, jmask, hand, obj, K, supervised):
+                d = {"image": t(img), "jittermask": t(jmask), "camintr": t(K), "objcanverts": canverts,
+                     "objfaces": t(s["obj_faces"][None].repeat(batch_size, 0).copy()),
+                     # geometry of the frame, NOT read by the model (kernel-only benchmarks use it)
+                     "_handverts3d": t(hand), "_objverts3d": t(obj)}
+                if supervised:
+                    d.update({"handverts3d": t(hand), "objverts3d": t(obj),
+                              "joints3d": t(hand[:, :21].copy())})
+                return d
+
+            data = {"data": [sample(im_ref, jm_ref, s["hand_verts2"], s["obj_verts2"], s["K2"], True)],
+                    "supervision": "data"}
+            consist = {"data": [sample(im, jm, s["hand_verts1"], s["obj_verts1"], s["K1"], False),
+                                sample(im_ref, jm_ref, s["hand_verts2"], s["obj_verts2"], s["K2"], True)],
+                       "supervision": "consist"}
+            self.batches.append((data, consist))
+
+    def __iter__(self):
+        for i in range(self.steps):
+            data, consist = self.batches[i % len(self.batches)]
+            yield data
+            yield consist
+
+    def step_batches(self, i):
+        return list(self.batches[i % len(self.batches)])

@@ -240,7 +240,7 @@ def get_occlusion_mask(mask_flow1, mask_flow2, flow12, flow21, thresh=0.99999):
 
 
 def get_opticalflow(raster, verts_cam, faces_idx, camintrs, renderer_kw, orig_img_size=None,
-                    mask_occlusions=True, ignore_face_idxs=None):
+                    mask_occlusions=True, ignore_face_idxs=None, return_renders=False):
     """opticalflow.get_opticalflow (opticalflow.py:51-156) on top of the render oracle.
     `raster` is the oracle.raster_ref module; renderer_kw are the Renderer settings of
     warpreg.py:40-51 (image_size, R, t, dist_coeffs, orig_size, near, far, eps...)."""
@@ -271,4 +271,7 @@ def get_opticalflow(raster, verts_cam, faces_idx, camintrs, renderer_kw, orig_im
     if orig_img_size is not None:
         pred12 = pred12[:, : orig_img_size[1], : orig_img_size[0]]
         pred21 = pred21[:, : orig_img_size[1], : orig_img_size[0]]
-    return [np.ascontiguousarray(pred12, F32), np.ascontiguousarray(pred21, F32)]
+    flows = [np.ascontiguousarray(pred12, F32), np.ascontiguousarray(pred21, F32)]
+    if return_renders:
+        return flows, [ro1, ro2]
+    return flows
