@@ -45,6 +45,7 @@ def parse():
     p.add_argument("--no-kernel-bench", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=2, help="images in the CPU-baseline sample")
     p.add_argument("--kernel-iters", type=int, default=50)
+    p.add_argument("--kernels-only", action="store_true", help="only the per-kernel benchmark (profiling aid)")
     return p.parse_args()
 
 
@@ -213,6 +214,9 @@ def main():
     from handobjectconsist_amd.netscripts.epochpassconsist import SyntheticConsistLoader, train_step
 
     assert _lib.load().mr_device_ok() == 1, "libmeshraster_hip.so: no gfx950 device"
+    if args.kernels_only:
+        print(json.dumps(kernel_bench(dev, args.batch, args.image_size, args.kernel_iters), indent=1))
+        return
     torch.manual_seed(rank)
     B, is_ = args.batch, args.image_size
     model = SynthMeshRegNet().to(dev)

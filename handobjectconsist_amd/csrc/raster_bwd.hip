@@ -9,9 +9,9 @@
 //     pixel bounding box in the face_index_map and, for the pixels it won, recomputes the
 //     barycentrics / sampling weights from the vertices (nothing but face_index_map is read
 //     back from the forward pass) and accumulates the 24 texel and 9 vertex gradients in
-//     registers, in ascending pixel order -- the order of the serial CPU oracle, so the
-//     result is deterministic and, for one-lane faces, bit-identical to it.  Faces whose
-//     bbox is large are walked by the whole wave (lane per pixel) and tree-reduced.
+//     registers.  Four lanes share a face (one bbox row each, combined by two quad
+//     shuffles in a fixed order), so the result is deterministic run to run; faces whose
+//     bbox is very large are walked by the whole wave (lane per pixel) and tree-reduced.
 //     Every output element is written exactly once: no memset, no atomics.
 //   * the pixel-map pseudo-gradient (upstream kernel D) keeps upstream's per-face edge
 //     walks but spreads the six (edge, axis) walks of a face over six lanes.
@@ -21,7 +21,6 @@
 
 namespace mr {
 
-constexpr int GATHER_SMALL_MAX = 64;  // bbox area up to which one lane walks a face
 
 // ---------------------------------------------------------------------------------------
 // map accessors: IMG = image orientation (vertically flipped, NCHW rgb), else raster NHWC
@@ -51,13 +50,13 @@ struct GatherParams {
     int accumulate_faces;     // 1: grad_faces already holds the pixel-map term
 };
 
-template <bool IMG>
+template <bool IMG, bool TEX, bool DEPTH>
 __device__ __forceinline__ void gather_pixel(const GatherParams& p, const Face& f, int b, int xi, int yi,
                                              float* gt, float* gf) {
     float w[3], zp;
     bary(f, xi, yi, zp, w);
     const int is = p.is;
-    if (p.grad_textures) {
+    if (TEX) {
         float tif[3];
         tex_coords(w, zp, f.v, 2, p.eps, tif);
         float g[3];
@@ -74,7 +73,7 @@ __device__ __forceinline__ void gather_pixel(const GatherParams& p, const Face& 
             for (int c = 0; c < 3; c++) gt[isc * 3 + c] += wg * g[c];
         }
     }
-    if (p.grad_depth && p.grad_faces) {
+    if (DEPTH) {
         const float gd = p.grad_depth[idx1<IMG>(b, yi, xi, is)];
         const float d2 = zp * zp;
 #pragma unroll
@@ -94,89 +93,110 @@ __device__ __forceinline__ void gather_pixel(const GatherParams& p, const Face& 
     }
 }
 
-template <bool IMG>
+// GLPF lanes per face: lane `sub` walks bbox rows sub, sub + GLPF, ...; the four partial sums are
+// combined with two quad shuffles (fixed order: deterministic).  Faces whose bbox exceeds
+// GATHER_BIG pixels are walked by the whole wave instead.
+constexpr int GLPF = 4;
+constexpr int GATHER_BIG = 2048;
+
+template <bool TEX, bool DEPTH>
+__device__ __forceinline__ void gather_store(const GatherParams& p, int64_t i, const float* gt, const float* gf) {
+    if (TEX) {
+        float4* o = reinterpret_cast<float4*>(p.grad_textures + i * 24);
+#pragma unroll
+        for (int k = 0; k < 6; k++) o[k] = make_float4(gt[4 * k], gt[4 * k + 1], gt[4 * k + 2], gt[4 * k + 3]);
+    }
+    if (p.grad_faces) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const float v = DEPTH ? gf[k] : 0.0f;
+            p.grad_faces[i * 9 + k] = p.accumulate_faces ? p.grad_faces[i * 9 + k] + v : v;
+        }
+    }
+}
+
+template <bool IMG, bool TEX, bool DEPTH>
 __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
+    constexpr int NT = TEX ? 24 : 1, NF = DEPTH ? 9 : 1;
     const int64_t total = (int64_t)p.B * p.F;
-    const int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const int64_t gid = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const int64_t i = gid / GLPF;
+    const int sub = (int)(gid % GLPF);
     const int lane = threadIdx.x & 63;
     const bool valid = i < total;
     const int b = valid ? (int)(i / p.F) : 0;
     const int fn = valid ? (int)(i % p.F) : 0;
     const int is = p.is;
 
-    Face f;
     FaceBox bx;
     bx.x0 = 1; bx.x1 = 0; bx.y0 = 1; bx.y1 = 0;
-    float gt[24], gf[9];
-#pragma unroll
-    for (int k = 0; k < 24; k++) gt[k] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 9; k++) gf[k] = 0.0f;
     if (valid) {
-        load_face(p.faces + i * 9, f, is);
-        bx = face_box(f.v, is);
-        if (p.grad_faces && p.accumulate_faces)
+        float v[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) gf[k] = p.grad_faces[i * 9 + k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; k++) { f.v[k] = 0.0f; f.inv[k] = 0.0f; }
+        for (int k = 0; k < 9; k++) v[k] = p.faces[i * 9 + k];
+        bx = face_box(v, is);
     }
     const bool nonempty = valid && bx.x0 <= bx.x1;
     const int bw = bx.x1 - bx.x0 + 1, bh = bx.y1 - bx.y0 + 1;
-    const bool big = nonempty && bw * bh > GATHER_SMALL_MAX;
+    const bool big = nonempty && bw * bh > GATHER_BIG;
 
-    if (nonempty && !big) {
-        const int32_t* fim_b = p.fim + (int64_t)b * is * is;
-        for (int yi = bx.y0; yi <= bx.y1; yi++)
-            for (int xi = bx.x0; xi <= bx.x1; xi++)
-                if (fim_b[yi * is + xi] == fn) gather_pixel<IMG>(p, f, b, xi, yi, gt, gf);
-    }
+    float gt[NT], gf[NF];
 
-    unsigned long long m_big = __ballot(big);
+    // very large faces first: the whole wave walks the bbox, lane per pixel, butterfly-reduce,
+    // the owner lane stores the result straight away
+    unsigned long long m_big = __ballot(big && sub == 0);
     while (m_big) {
         const int src = __ffsll((long long)m_big) - 1;
         m_big &= m_big - 1;
-        Face fb;
-#pragma unroll
-        for (int k = 0; k < 9; k++) { fb.v[k] = __shfl(f.v[k], src); fb.inv[k] = __shfl(f.inv[k], src); }
         const int x0 = __shfl((int)bx.x0, src), y0 = __shfl((int)bx.y0, src);
         const int w_ = __shfl(bw, src), n = w_ * __shfl(bh, src);
         const int bb = __shfl(b, src), ff = __shfl(fn, src);
+        Face fb;
+        load_face(p.faces + ((int64_t)bb * p.F + ff) * 9, fb, is);
         const int32_t* fim_b = p.fim + (int64_t)bb * is * is;
-        float pt[24], pf[9];
 #pragma unroll
-        for (int k = 0; k < 24; k++) pt[k] = 0.0f;
+        for (int k = 0; k < NT; k++) gt[k] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 9; k++) pf[k] = 0.0f;
+        for (int k = 0; k < NF; k++) gf[k] = 0.0f;
         for (int j = lane; j < n; j += MR_WAVE) {
             const int xi = x0 + j % w_, yi = y0 + j / w_;
-            if (fim_b[yi * is + xi] == ff) gather_pixel<IMG>(p, fb, bb, xi, yi, pt, pf);
+            if (fim_b[yi * is + xi] == ff) gather_pixel<IMG, TEX, DEPTH>(p, fb, bb, xi, yi, gt, gf);
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
+            if (TEX)
 #pragma unroll
-            for (int k = 0; k < 24; k++) pt[k] += __shfl_xor(pt[k], off);
+                for (int k = 0; k < NT; k++) gt[k] += __shfl_xor(gt[k], off);
+            if (DEPTH)
 #pragma unroll
-            for (int k = 0; k < 9; k++) pf[k] += __shfl_xor(pf[k], off);
+                for (int k = 0; k < NF; k++) gf[k] += __shfl_xor(gf[k], off);
         }
-        if (lane == src) {
-#pragma unroll
-            for (int k = 0; k < 24; k++) gt[k] += pt[k];
-#pragma unroll
-            for (int k = 0; k < 9; k++) gf[k] += pf[k];
-        }
+        if (lane == src) gather_store<TEX, DEPTH>(p, (int64_t)bb * p.F + ff, gt, gf);
     }
 
-    if (!valid) return;
-    if (p.grad_textures) {
-        float4* o = reinterpret_cast<float4*>(p.grad_textures + i * 24);
 #pragma unroll
-        for (int k = 0; k < 6; k++) o[k] = make_float4(gt[4 * k], gt[4 * k + 1], gt[4 * k + 2], gt[4 * k + 3]);
+    for (int k = 0; k < NT; k++) gt[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NF; k++) gf[k] = 0.0f;
+    if (nonempty && !big) {
+        Face f;
+        load_face(p.faces + i * 9, f, is);
+        const int32_t* fim_b = p.fim + (int64_t)b * is * is;
+        for (int yi = bx.y0 + sub; yi <= bx.y1; yi += GLPF)
+            for (int xi = bx.x0; xi <= bx.x1; xi++)
+                if (fim_b[yi * is + xi] == fn) gather_pixel<IMG, TEX, DEPTH>(p, f, b, xi, yi, gt, gf);
     }
-    if (p.grad_faces)
+    // quad reduction: afterwards every lane of the quad holds the face's sums
 #pragma unroll
-        for (int k = 0; k < 9; k++) p.grad_faces[i * 9 + k] = gf[k];
+    for (int off = 1; off < GLPF; off <<= 1) {
+        if (TEX)
+#pragma unroll
+            for (int k = 0; k < NT; k++) gt[k] += __shfl_xor(gt[k], off);
+        if (DEPTH)
+#pragma unroll
+            for (int k = 0; k < NF; k++) gf[k] += __shfl_xor(gf[k], off);
+    }
+    if (valid && sub == 0 && !big) gather_store<TEX, DEPTH>(p, i, gt, gf);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -538,7 +558,13 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
         g.grad_textures = gather_tex ? grad_textures : nullptr;
         g.B = batch_size; g.F = num_faces; g.is = image_size; g.eps = eps;
         g.accumulate_faces = want_d ? 1 : 0;
-        if (gather_tex || want_f || !want_d) rc = launch1d(gather_kernel<true>, nfaces, s, g);
+        if (gather_tex || want_f || !want_d) {
+            const int64_t nthreads = nfaces * GLPF;
+            if (gather_tex && want_f) rc = launch1d(gather_kernel<true, true, true>, nthreads, s, g);
+            else if (gather_tex) rc = launch1d(gather_kernel<true, true, false>, nthreads, s, g);
+            else if (want_f) rc = launch1d(gather_kernel<true, false, true>, nthreads, s, g);
+            else rc = launch1d(gather_kernel<true, false, false>, nthreads, s, g);
+        }
     }
     return rc;
 }

@@ -5,24 +5,29 @@
 // (/root/reference/meshreg/neurender/rasterize.py:87-103, 413-428).
 //
 // Design (not the upstream "every pixel loops over every face" scheme):
-//   1. face_setup_kernel   one thread per face: back-face cull + conservative pixel bbox
-//                          (8 B record), optional faces_inv for the upstream-compatible API.
-//   2. raster_tile_kernel  one 256-thread workgroup per 32x32 screen tile.  Each of the 4
-//                          waves scans a quarter of the image's bbox records (coalesced 8-B
-//                          loads), ballots the faces that touch the tile and compacts them
-//                          (wave64 ballot + popcount prefix) into a wave-private LDS queue.
-//                          Small faces are drained 64 at a time, ONE LANE PER FACE walking
-//                          the face's few bbox pixels; large faces are walked by the whole
-//                          wave, one lane per pixel.  Depth test = ds_min_u64 on a per-tile
-//                          LDS z-buffer holding (ordered(zp) << 32 | face_index): a
-//                          lexicographic min, i.e. exactly upstream's "strict < in ascending
-//                          face order" (nearest face, lowest index on ties), independent of
-//                          processing order.
+//   1. face_setup_kernel   one thread per face: back-face cull + conservative pixel bbox.  Faces
+//                          that can touch the screen are appended (wave-aggregated atomic) to a
+//                          compact per-image record list {bbox, face index} (16 B) and folded
+//                          into the image's union bbox; optional faces_inv for the
+//                          upstream-compatible API.
+//   2. raster_tile_kernel  one 256-thread workgroup per 32x32 screen tile.  Tiles outside the
+//                          image's union bbox skip straight to the background fill.  Otherwise
+//                          each of the 4 waves scans a quarter of the record list -- 4
+//                          independent 16-B loads per lane in flight -- ballots the records
+//                          that touch the tile and compacts them (wave64 ballot + popcount
+//                          prefix) into a wave-private LDS ring.  The ring is drained 16 faces
+//                          at a time, FOUR LANES PER FACE (lane k walks bbox rows k, k+4, ...),
+//                          which keeps lanes busy for the 5x5..16x16-pixel triangles of these
+//                          meshes and bounds the walk of a tile-filling face to 256 pixels.
+//                          Depth test = ds_min_u64 on a per-tile LDS z-buffer holding
+//                          (ordered(zp) << 32 | face_index): a lexicographic min, i.e. exactly
+//                          upstream's "strict < in ascending face order" (nearest face, lowest
+//                          index on ties), independent of processing order.
 //   3. resolve (same kernel) each thread owns 4 pixels: decode winner, recompute its
 //                          barycentrics (bit-identical to the winning test), sample the
 //                          texture, blend background, write every output plane once,
 //                          already vertically flipped / NCHW for the image-space outputs.
-// HBM traffic: faces 36 B + 8 B record per face, outputs written exactly once; no
+// HBM traffic: faces 36 B + 16 B record per live face, outputs written exactly once; no
 // per-pixel memset, no sampling maps, no separate flip / permute / alpha / background pass.
 #include "mr_common.hpp"
 
@@ -31,30 +36,80 @@ namespace mr {
 constexpr int TILE = 32;              // tile edge in pixels
 constexpr int TPB = 256;              // threads per workgroup (4 waves)
 constexpr int PX_PER_THREAD = TILE * TILE / TPB;
-constexpr int SMALL_MAX = 32;         // bbox-in-tile area up to which one lane walks a face
-constexpr int QCAP = 128;             // wave-private queue capacity (>= 2 * 64)
+constexpr int LPF = 4;                // lanes per face in a drain
+constexpr int DRAIN_FACES = MR_WAVE / LPF;
+constexpr int QCAP = 128;             // wave-private ring capacity (>= DRAIN_FACES - 1 + 64, power of 2)
+constexpr int SCAN_UNROLL = 4;        // independent record loads in flight per lane
 
+// Per-image header of the compact face-record list (zero-initialised before face_setup_kernel).
+// The union bbox is kept as maxima so that all-zero means "no face": nx0 = max(is - x0), x1p =
+// max(x1 + 1), likewise for y.
+struct ImageHdr {
+    int count;
+    int nx0, x1p, ny0, y1p;
+    int pad[3];
+};
+
+// {x0 | x1 << 16, y0 | y1 << 16, face index, unused}
+typedef uint4 FaceRec;
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
+// grid = (ceil(F / 256), B): a workgroup never straddles two images.
 __global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict__ faces,
-                                                         FaceBox* __restrict__ boxes,
-                                                         float* __restrict__ faces_inv,
-                                                         int64_t total, int is) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+                                                         ImageHdr* __restrict__ hdrs,
+                                                         FaceRec* __restrict__ recs,
+                                                         float* __restrict__ faces_inv, int F, int is) {
+    const int b = blockIdx.y;
+    const int fn = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = fn < F;
+    const int64_t i = (int64_t)b * F + (valid ? fn : 0);
     float f[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) f[k] = faces[i * 9 + k];
-    if (boxes) boxes[i] = face_box(f, is);
-    if (faces_inv && !backfacing(f)) {
+    for (int k = 0; k < 9; k++) f[k] = valid ? faces[i * 9 + k] : __builtin_nanf("");
+    FaceBox bx = face_box(f, is);  // NaN -> empty
+    if (faces_inv && valid && !backfacing(f)) {
         float inv[9];
         face_inverse(f, inv, is);
 #pragma unroll
         for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = inv[k];
     }
+    if (!hdrs) return;
+    const bool live = valid && bx.x0 <= bx.x1;
+    const unsigned long long m = __ballot(live);
+    if (m == 0ull) return;  // wave-uniform
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&hdrs[b].count, __popcll(m));
+    base = __shfl(base, leader);
+    if (live) {
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        FaceRec r;
+        r.x = (unsigned)(unsigned short)bx.x0 | ((unsigned)(unsigned short)bx.x1 << 16);
+        r.y = (unsigned)(unsigned short)bx.y0 | ((unsigned)(unsigned short)bx.y1 << 16);
+        r.z = (unsigned)fn;
+        r.w = 0u;
+        recs[(int64_t)b * F + slot] = r;
+    }
+    const int nx0 = wave_max(live ? is - bx.x0 : 0), x1p = wave_max(live ? bx.x1 + 1 : 0);
+    const int ny0 = wave_max(live ? is - bx.y0 : 0), y1p = wave_max(live ? bx.y1 + 1 : 0);
+    if (lane == leader) {
+        atomicMax(&hdrs[b].nx0, nx0);
+        atomicMax(&hdrs[b].x1p, x1p);
+        atomicMax(&hdrs[b].ny0, ny0);
+        atomicMax(&hdrs[b].y1p, y1p);
+    }
 }
 
 struct FwdParams {
     const float* faces;
-    const FaceBox* boxes;
+    const ImageHdr* hdrs;
+    const FaceRec* recs;
     const float* textures;
     const float* background;
     int bg_stride;
@@ -68,6 +123,7 @@ struct FwdParams {
     float near_, far_, eps;
     int tiles_x;           // tiles per row (= per column)
     const unsigned long long* keys;  // validation only: precomputed z-buffer keys (skip the scan)
+    int dbg;                         // profiling experiments (flags >> 8)
 };
 
 __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float zp, int fn) {
@@ -97,73 +153,65 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     __syncthreads();
 
     const float* faces_b = p.faces + (int64_t)b * p.F * 9;
-    const FaceBox* boxes_b = p.boxes + (int64_t)b * p.F;
+    const FaceRec* recs_b = p.recs + (int64_t)b * p.F;
     int* q = queue[wave];
-    int qn = 0;  // wave-uniform
+    int qhead = 0, qn = 0;  // wave-uniform ring state
 
-    // one lane per small face: walk its bbox clipped to the tile
+    int n_rec = 0;
+    if (!p.keys) {
+        const ImageHdr h = p.hdrs[b];
+        // union bbox of the image's live faces: [is - nx0, x1p - 1] x [is - ny0, y1p - 1]
+        const bool touch = h.count > 0 && (is - h.nx0) <= tx1 && (h.x1p - 1) >= tx0 && (is - h.ny0) <= ty1 &&
+                           (h.y1p - 1) >= ty0;
+        n_rec = touch ? h.count : 0;
+        if (p.dbg & 1) n_rec = 0;
+    }
+
+    // DRAIN_FACES faces per call, LPF lanes per face: lane `sub` walks rows sub, sub + LPF, ...
     auto drain = [&](int count) {
-        if (lane < count) {
-            const int fn = q[lane];
-            const FaceBox bx = boxes_b[fn];
+        const int slot = lane / LPF, sub = lane % LPF;
+        if (slot < count && !(p.dbg & 4)) {
+            const FaceRec r = recs_b[q[(qhead + slot) & (QCAP - 1)]];
+            const int fn = (int)r.z;
             Face f;
             load_face(faces_b + (int64_t)fn * 9, f, is);
-            const int x0 = max((int)bx.x0, tx0), x1 = min((int)bx.x1, tx1);
-            const int y0 = max((int)bx.y0, ty0), y1 = min((int)bx.y1, ty1);
-            for (int yi = y0; yi <= y1; yi++)
+            const int x0 = max((int)(r.x & 0xffffu), tx0), x1 = min((int)(r.x >> 16), tx1);
+            const int y0 = max((int)(r.y & 0xffffu), ty0), y1 = min((int)(r.y >> 16), ty1);
+            for (int yi = y0 + sub; yi <= y1; yi += LPF)
                 for (int xi = x0; xi <= x1; xi++) {
                     float zp, w[3];
                     if (cover(f, xi, yi, is, p.near_, p.far_, zp, w))
                         zbuf_min(zbuf, (yi - ty0) * TILE + (xi - tx0), zp, fn);
                 }
         }
+        __builtin_amdgcn_wave_barrier();
     };
 
-    // each wave scans a contiguous quarter of the face records
-    const int per_wave = (p.F + 3) / 4;
-    const int f_begin = wave * per_wave;
-    const int f_end = p.keys ? f_begin : min(f_begin + per_wave, p.F);
-    for (int base = f_begin; base < f_end; base += MR_WAVE) {
-        const int fn = base + lane;
-        bool hit = false, big = false;
-        FaceBox bx;
-        bx.x0 = 1; bx.x1 = 0; bx.y0 = 1; bx.y1 = 0;
-        if (fn < f_end) {
-            bx = boxes_b[fn];
-            hit = (bx.x0 <= bx.x1) && (bx.x0 <= tx1) && (bx.x1 >= tx0) && (bx.y0 <= ty1) && (bx.y1 >= ty0);
-            if (hit) {
-                const int w = min((int)bx.x1, tx1) - max((int)bx.x0, tx0) + 1;
-                const int h = min((int)bx.y1, ty1) - max((int)bx.y0, ty0) + 1;
-                big = w * h > SMALL_MAX;
-            }
+    // each wave scans a contiguous quarter of the image's record list
+    const int per_wave = (n_rec + 3) / 4;
+    const int r_begin = wave * per_wave;
+    const int r_end = min(r_begin + per_wave, n_rec);
+    for (int base = r_begin; base < r_end; base += MR_WAVE * SCAN_UNROLL) {
+        FaceRec rr[SCAN_UNROLL];
+#pragma unroll
+        for (int j = 0; j < SCAN_UNROLL; j++) {
+            const int ri = base + j * MR_WAVE + lane;
+            rr[j] = recs_b[min(ri, r_end - 1)];
         }
-        const unsigned long long m_small = __ballot(hit && !big);
-        unsigned long long m_big = __ballot(hit && big);
-        if (hit && !big) q[qn + __popcll(m_small & ((1ull << lane) - 1ull))] = fn;
-        qn += __popcll(m_small);
-        if (qn >= MR_WAVE) {
-            drain(MR_WAVE);
-            // move the tail of the queue to the front (wave-synchronous, <= 63 entries)
-            const int rest = qn - MR_WAVE;
-            int v = (lane < rest) ? q[MR_WAVE + lane] : 0;
-            if (lane < rest) q[lane] = v;
-            qn = rest;
-        }
-        // large faces: the whole wave walks the clipped bbox, one lane per pixel
-        while (m_big) {
-            const int src = __ffsll((long long)m_big) - 1;
-            m_big &= m_big - 1;
-            const int fb = base + src;
-            const int bx0 = max(__shfl((int)bx.x0, src), tx0), bx1 = min(__shfl((int)bx.x1, src), tx1);
-            const int by0 = max(__shfl((int)bx.y0, src), ty0), by1 = min(__shfl((int)bx.y1, src), ty1);
-            Face f;
-            load_face(faces_b + (int64_t)fb * 9, f, is);
-            const int bw = bx1 - bx0 + 1, n = bw * (by1 - by0 + 1);
-            for (int i = lane; i < n; i += MR_WAVE) {
-                const int xi = bx0 + i % bw, yi = by0 + i / bw;
-                float zp, w[3];
-                if (cover(f, xi, yi, is, p.near_, p.far_, zp, w))
-                    zbuf_min(zbuf, (yi - ty0) * TILE + (xi - tx0), zp, fb);
+#pragma unroll
+        for (int j = 0; j < SCAN_UNROLL; j++) {
+            const int ri = base + j * MR_WAVE + lane;
+            const int bx0 = (int)(rr[j].x & 0xffffu), bx1 = (int)(rr[j].x >> 16);
+            const int by0 = (int)(rr[j].y & 0xffffu), by1 = (int)(rr[j].y >> 16);
+            const bool hit = ri < r_end && bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
+            const unsigned long long m = __ballot(hit);
+            if (hit) q[(qhead + qn + __popcll(m & ((1ull << lane) - 1ull))) & (QCAP - 1)] = ri;
+            qn += __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            while (qn >= DRAIN_FACES) {
+                drain(DRAIN_FACES);
+                qhead = (qhead + DRAIN_FACES) & (QCAP - 1);
+                qn -= DRAIN_FACES;
             }
         }
     }
@@ -178,6 +226,7 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     }
     __syncthreads();
 
+    if (p.dbg & 2) return;
     // resolve: thread owns pixels (x = tid % 32, y = tid / 32 + 8 j)
     const int px = tx0 + (tid & (TILE - 1));
 #pragma unroll
@@ -334,12 +383,20 @@ __global__ void __launch_bounds__(256) face_inv_map_kernel(const float* __restri
     for (int k = 0; k < 9; k++) out[i * 9 + k] = inv[k];
 }
 
-static int launch_setup(const float* faces, FaceBox* boxes, float* faces_inv, int B, int F, int is,
+// workspace layout: [B] ImageHdr (zeroed per call) | [B * F] FaceRec
+static inline size_t hdr_bytes(int B) { return (((size_t)B * sizeof(ImageHdr)) + 255) & ~(size_t)255; }
+
+static int launch_setup(const float* faces, void* workspace, float* faces_inv, int B, int F, int is,
                         hipStream_t s) {
-    const int64_t total = (int64_t)B * F;
-    if (total == 0) return MR_OK;
-    const unsigned blocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(face_setup_kernel, dim3(blocks), dim3(256), 0, s, faces, boxes, faces_inv, total, is);
+    if (B == 0) return MR_OK;
+    ImageHdr* hdrs = (ImageHdr*)workspace;
+    FaceRec* recs = (FaceRec*)((char*)workspace + hdr_bytes(B));
+    hipError_t e = hipMemsetAsync(hdrs, 0, hdr_bytes(B), s);
+    if (e != hipSuccess) return (int)e;
+    if (F == 0) return MR_OK;
+    if (B > 65535) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, faces,
+                       hdrs, recs, faces_inv, F, is);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -362,7 +419,8 @@ using namespace mr;
 extern "C" int64_t mr_render_workspace_bytes(int batch_size, int num_faces, int image_size) {
     (void)image_size;
     if (batch_size < 0 || num_faces < 0) return MR_ERR_BADARG;
-    return (((int64_t)batch_size * num_faces * (int64_t)sizeof(FaceBox)) + 255) & ~255LL;
+    return (int64_t)hdr_bytes(batch_size) +
+           ((((int64_t)batch_size * num_faces * (int64_t)sizeof(FaceRec)) + 255) & ~255LL);
 }
 
 extern "C" int mr_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
@@ -376,20 +434,22 @@ extern "C" int mr_forward_face_index_map(const float* faces, int32_t* face_index
     if (return_depth && !face_inv_map) return MR_ERR_BADARG;
     if (batch_size == 0) return MR_OK;
     hipStream_t s = (hipStream_t)stream;
-    FaceBox* boxes = nullptr;
+    void* work = nullptr;
     const size_t bytes = (size_t)mr_render_workspace_bytes(batch_size, num_faces, image_size) + 256;
-    hipError_t e = hipMallocAsync((void**)&boxes, bytes, s);
+    hipError_t e = hipMallocAsync(&work, bytes, s);
     if (e != hipSuccess) return (int)e;
-    int rc = launch_setup(faces, boxes, faces_inv, batch_size, num_faces, image_size, s);
+    int rc = launch_setup(faces, work, faces_inv, batch_size, num_faces, image_size, s);
     if (rc == MR_OK) {
         FwdParams p{};
-        p.faces = faces; p.boxes = boxes; p.depth = depth_map; p.fim = face_index_map;
+        p.faces = faces; p.hdrs = (const ImageHdr*)work;
+        p.recs = (const FaceRec*)((const char*)work + hdr_bytes(batch_size));
+        p.depth = depth_map; p.fim = face_index_map;
         p.weight = weight_map; p.face_inv_map = return_depth ? face_inv_map : nullptr;
         p.B = batch_size; p.F = num_faces; p.is = image_size; p.ts = 1;
         p.near_ = near_; p.far_ = far_; p.eps = 0.0f;
         rc = launch_tiles<false>(p, s);
     }
-    e = hipFreeAsync(boxes, s);
+    e = hipFreeAsync(work, s);
     if (rc == MR_OK && e != hipSuccess) rc = (int)e;
     return rc;
 }
@@ -431,11 +491,12 @@ extern "C" int mr_render_forward(const float* faces, const float* textures, cons
     if (workspace_bytes < mr_render_workspace_bytes(batch_size, num_faces, image_size)) return MR_ERR_BADARG;
     if (batch_size == 0) return MR_OK;
     hipStream_t s = (hipStream_t)stream;
-    FaceBox* boxes = (FaceBox*)workspace;
-    int rc = launch_setup(faces, boxes, nullptr, batch_size, num_faces, image_size, s);
+    int rc = launch_setup(faces, workspace, nullptr, batch_size, num_faces, image_size, s);
     if (rc != MR_OK) return rc;
     FwdParams p{};
-    p.faces = faces; p.boxes = boxes; p.textures = textures; p.background = background;
+    p.faces = faces; p.hdrs = (const ImageHdr*)workspace;
+    p.recs = (const FaceRec*)((const char*)workspace + hdr_bytes(batch_size));
+    p.textures = textures; p.background = background;
     p.bg_stride = bg_stride;
     p.rgb = return_rgb ? rgb_img : nullptr;
     p.alpha = return_alpha ? alpha_img : nullptr;
@@ -444,6 +505,7 @@ extern "C" int mr_render_forward(const float* faces, const float* textures, cons
     p.face_inv_map = face_inv_map;
     p.B = batch_size; p.F = num_faces; p.is = image_size; p.ts = return_rgb ? texture_size : 1;
     p.near_ = near_; p.far_ = far_; p.eps = eps;
+    p.dbg = flags >> 8;
     if (flags & MR_FLAG_REFERENCE_ALGO) {
         const int64_t npx = (int64_t)batch_size * image_size * image_size;
         unsigned long long* keys = nullptr;

@@ -53,14 +53,42 @@ __device__ __forceinline__ Taps make_taps(float ix, float iy) {
 
 __device__ __forceinline__ bool inb(int x, int y, int W, int H) { return x >= 0 && x < W && y >= 0 && y < H; }
 
-// bilinear sample of one channel plane (zeros padding), accumulation order nw, ne, sw, se
-__device__ __forceinline__ float bilin(const float* __restrict__ plane, const Taps& t, int W, int H) {
+// bilinear sample of one channel plane (zeros padding), accumulation order nw, ne, sw, se.
+// The four loads are unconditional (clamped addresses) so they issue back to back; a tap that
+// is out of bounds leaves the accumulator untouched, exactly like the skipped branch of the
+// reference implementation.
+struct TapAddr {
+    int64_t a_nw, a_ne, a_sw, a_se;
+    bool b_nw, b_ne, b_sw, b_se;
+};
+
+__device__ __forceinline__ TapAddr tap_addr(const Taps& t, int W, int H) {
+    TapAddr a;
+    a.b_nw = inb(t.x0, t.y0, W, H);
+    a.b_ne = inb(t.x0 + 1, t.y0, W, H);
+    a.b_sw = inb(t.x0, t.y0 + 1, W, H);
+    a.b_se = inb(t.x0 + 1, t.y0 + 1, W, H);
+    const int xc0 = min(max(t.x0, 0), W - 1), xc1 = min(max(t.x0 + 1, 0), W - 1);
+    const int yc0 = min(max(t.y0, 0), H - 1), yc1 = min(max(t.y0 + 1, 0), H - 1);
+    a.a_nw = (int64_t)yc0 * W + xc0;
+    a.a_ne = (int64_t)yc0 * W + xc1;
+    a.a_sw = (int64_t)yc1 * W + xc0;
+    a.a_se = (int64_t)yc1 * W + xc1;
+    return a;
+}
+
+__device__ __forceinline__ float bilin(const float* __restrict__ plane, const Taps& t, const TapAddr& a) {
+    const float v_nw = plane[a.a_nw], v_ne = plane[a.a_ne], v_sw = plane[a.a_sw], v_se = plane[a.a_se];
     float acc = 0.0f;
-    if (inb(t.x0, t.y0, W, H)) acc += plane[(int64_t)t.y0 * W + t.x0] * t.nw;
-    if (inb(t.x0 + 1, t.y0, W, H)) acc += plane[(int64_t)t.y0 * W + t.x0 + 1] * t.ne;
-    if (inb(t.x0, t.y0 + 1, W, H)) acc += plane[(int64_t)(t.y0 + 1) * W + t.x0] * t.sw;
-    if (inb(t.x0 + 1, t.y0 + 1, W, H)) acc += plane[(int64_t)(t.y0 + 1) * W + t.x0 + 1] * t.se;
+    acc = a.b_nw ? acc + v_nw * t.nw : acc;
+    acc = a.b_ne ? acc + v_ne * t.ne : acc;
+    acc = a.b_sw ? acc + v_sw * t.sw : acc;
+    acc = a.b_se ? acc + v_se * t.se : acc;
     return acc;
+}
+
+__device__ __forceinline__ float bilin(const float* __restrict__ plane, const Taps& t, int W, int H) {
+    return bilin(plane, t, tap_addr(t, W, H));
 }
 
 // bilinear sample of an all-ones image = sum of the in-bounds weights, binarised as
@@ -77,27 +105,21 @@ __device__ __forceinline__ float valid_mask(const Taps& t, int W, int H, float t
 }
 
 // d(sample)/d(ix), d(sample)/d(iy) of one channel plane
-__device__ __forceinline__ void bilin_grad(const float* __restrict__ plane, const Taps& t, int W, int H,
+__device__ __forceinline__ void bilin_grad(const float* __restrict__ plane, const Taps& t, const TapAddr& a,
                                            float& gix, float& giy) {
     const float fx = (float)t.x0, fy = (float)t.y0;
     const float ix_se = fx + 1.0f, iy_se = fy + 1.0f;
+    const float v_nw = plane[a.a_nw], v_ne = plane[a.a_ne], v_sw = plane[a.a_sw], v_se = plane[a.a_se];
     gix = 0.0f; giy = 0.0f;
-    if (inb(t.x0, t.y0, W, H)) {
-        const float v = plane[(int64_t)t.y0 * W + t.x0];
-        gix -= v * (iy_se - t.iy); giy -= v * (ix_se - t.ix);
-    }
-    if (inb(t.x0 + 1, t.y0, W, H)) {
-        const float v = plane[(int64_t)t.y0 * W + t.x0 + 1];
-        gix += v * (iy_se - t.iy); giy -= v * (t.ix - fx);
-    }
-    if (inb(t.x0, t.y0 + 1, W, H)) {
-        const float v = plane[(int64_t)(t.y0 + 1) * W + t.x0];
-        gix -= v * (t.iy - fy); giy += v * (ix_se - t.ix);
-    }
-    if (inb(t.x0 + 1, t.y0 + 1, W, H)) {
-        const float v = plane[(int64_t)(t.y0 + 1) * W + t.x0 + 1];
-        gix += v * (t.iy - fy); giy += v * (t.ix - fx);
-    }
+    if (a.b_nw) { gix -= v_nw * (iy_se - t.iy); giy -= v_nw * (ix_se - t.ix); }
+    if (a.b_ne) { gix += v_ne * (iy_se - t.iy); giy -= v_ne * (t.ix - fx); }
+    if (a.b_sw) { gix -= v_sw * (t.iy - fy); giy += v_sw * (ix_se - t.ix); }
+    if (a.b_se) { gix += v_se * (t.iy - fy); giy += v_se * (t.ix - fx); }
+}
+
+__device__ __forceinline__ void bilin_grad(const float* __restrict__ plane, const Taps& t, int W, int H,
+                                           float& gix, float& giy) {
+    bilin_grad(plane, t, tap_addr(t, W, H), gix, giy);
 }
 
 __device__ __forceinline__ void nearest_idx(float ix, float iy, int& xn, int& yn) {
@@ -294,7 +316,7 @@ struct PairParams {
     float* warp2;
     float* diff1;
     float* diff2;
-    int B, H, W, nblk;
+    int B, H, W, nblk, tiles_x;
     float thresh;
 };
 
@@ -309,25 +331,48 @@ struct DirOut {
 
 __device__ __forceinline__ DirOut pair_dir(const float* __restrict__ flow, const float* __restrict__ src,
                                            const float* __restrict__ jwarp, const float* __restrict__ jdirect,
-                                           int Cj, int b, int xx, int yy, int H, int W, float thresh, Taps& t) {
+                                           int Cj, bool all_jitter_channels, int b, int xx, int yy, int H, int W,
+                                           float thresh, Taps& t, TapAddr& a) {
     const int64_t hw = (int64_t)H * W;
     const int64_t pix = (int64_t)yy * W + xx;
     const float2 uv = *reinterpret_cast<const float2*>(flow + ((int64_t)b * hw + pix) * 2);
+    const float jd = jdirect[(int64_t)b * Cj * hw + pix];
     float ix, iy;
     sample_pos((float)xx, (float)yy, uv.x, uv.y, W, H, ix, iy);
     t = make_taps(ix, iy);
+    a = tap_addr(t, W, H);
     DirOut o;
     o.m = valid_mask(t, W, H, thresh);
+    float sv[3], jv[3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) o.s[c] = bilin(src + ((int64_t)b * 3 + c) * hw, t, W, H) * o.m;
+    for (int c = 0; c < 3; c++) sv[c] = bilin(src + ((int64_t)b * 3 + c) * hw, t, a);
+    jv[0] = bilin(jwarp + (int64_t)b * Cj * hw, t, a);
+    jv[1] = jv[0]; jv[2] = jv[0];
+    if (all_jitter_channels && Cj == 3) {
+        jv[1] = bilin(jwarp + ((int64_t)b * Cj + 1) * hw, t, a);
+        jv[2] = bilin(jwarp + ((int64_t)b * Cj + 2) * hw, t, a);
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const int cj = (Cj == 3) ? c : 0;
-        const float js = bilin(jwarp + ((int64_t)b * Cj + cj) * hw, t, W, H) * o.m;
+        o.s[c] = sv[c] * o.m;
+        const float js = jv[c] * o.m;
         o.wm[c] = o.m * ((js == 1.0f) ? 1.0f : 0.0f);
     }
-    o.valid = (o.wm[0] != 0.0f) && (uv.x != 0.0f) && (jdirect[(int64_t)b * Cj * hw + pix] == 1.0f);
+    o.valid = (o.wm[0] != 0.0f) && (uv.x != 0.0f) && (jd == 1.0f);
     return o;
+}
+
+// 32 x 8 pixel tiles; logical tile id -> (sample, tile) with the XCD-aware remap so that
+// vertically adjacent tiles (which share bilinear taps) run behind the same L2.
+constexpr int PT_W = 32, PT_H = 8;
+__device__ __forceinline__ bool pair_tile_pixel(int H, int W, int tiles_x, int ntiles, int& b, int& tile, int& xx,
+                                                int& yy) {
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    b = lid / ntiles;
+    tile = lid % ntiles;
+    xx = (tile % tiles_x) * PT_W + (threadIdx.x & (PT_W - 1));
+    yy = (tile / tiles_x) * PT_H + (threadIdx.x >> 5);
+    return xx < W && yy < H;
 }
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -343,16 +388,20 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 __global__ void __launch_bounds__(256) pair_consist_forward_kernel(PairParams p) {
     __shared__ float red[4];
     const int64_t hw = (int64_t)p.H * p.W;
-    const int b = blockIdx.y;
-    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int b, tile, xx, yy;
+    const bool in_img = pair_tile_pixel(p.H, p.W, p.tiles_x, p.nblk, b, tile, xx, yy);
     float sum1 = 0.0f, cnt1 = 0.0f, sum2 = 0.0f, cnt2 = 0.0f;
-    if (pix < hw) {
-        const int yy = (int)(pix / p.W), xx = (int)(pix % p.W);
+    if (in_img) {
+        const int64_t pix = (int64_t)yy * p.W + xx;
         Taps t;
+        TapAddr a;
+        const bool allj = p.warp_mask1 != nullptr || p.warp_mask2 != nullptr;
         // forward term: image_ref warped by flow21 vs image (imgflowarp.py:80,85-87,93-102)
-        const DirOut d1 = pair_dir(p.flow21, p.image_ref, p.jitter, p.jitter, p.Cj, b, xx, yy, p.H, p.W, p.thresh, t);
+        const DirOut d1 = pair_dir(p.flow21, p.image_ref, p.jitter, p.jitter, p.Cj, allj, b, xx, yy, p.H, p.W,
+                                   p.thresh, t, a);
         // backward term: image warped by flow12 vs image_ref (:84,82,88,99-107)
-        const DirOut d2 = pair_dir(p.flow12, p.image, p.jitter_ref, p.jitter_ref, p.Cj, b, xx, yy, p.H, p.W, p.thresh, t);
+        const DirOut d2 = pair_dir(p.flow12, p.image, p.jitter_ref, p.jitter_ref, p.Cj, allj, b, xx, yy, p.H, p.W,
+                                   p.thresh, t, a);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int64_t o = ((int64_t)b * 3 + c) * hw + pix;
@@ -375,7 +424,7 @@ __global__ void __launch_bounds__(256) pair_consist_forward_kernel(PairParams p)
     const float s1 = block_sum(sum1, red), c1 = block_sum(cnt1, red);
     const float s2 = block_sum(sum2, red), c2 = block_sum(cnt2, red);
     if (threadIdx.x == 0) {
-        float* o = p.partial + ((int64_t)b * p.nblk + blockIdx.x) * 4;
+        float* o = p.partial + ((int64_t)b * p.nblk + tile) * 4;
         o[0] = s1; o[1] = c1; o[2] = s2; o[3] = c2;
     }
 }
@@ -417,26 +466,30 @@ struct PairBwdParams {
     const float* grad_loss_bwd;  // nullable
     float* grad_flow12;
     float* grad_flow21;
-    int B, H, W;
+    int B, H, W, ntiles, tiles_x;
     float thresh;
 };
 
 __device__ __forceinline__ float2 pair_dir_grad(const float* __restrict__ src, const float* __restrict__ tgt,
-                                                const DirOut& d, const Taps& t, int b, int64_t pix, int H,
-                                                int W, float coef) {
+                                                const DirOut& d, const Taps& t, const TapAddr& a, int b,
+                                                int64_t pix, int H, int W, float coef) {
     float gu = 0.0f, gv = 0.0f;
+    const int64_t hw = (int64_t)H * W;
+    float tg[3], gix[3], giy[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int64_t o = ((int64_t)b * 3 + c) * hw;
+        tg[c] = tgt[o + pix];
+        bilin_grad(src + o, t, a, gix[c], giy[c]);
+    }
     if (d.valid && coef != 0.0f) {
-        const int64_t hw = (int64_t)H * W;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const int64_t o = ((int64_t)b * 3 + c) * hw;
-            const float r = d.s[c] - tgt[o + pix];
+            const float r = d.s[c] - tg[c];
             const float sg = (r > 0.0f) ? 1.0f : ((r < 0.0f) ? -1.0f : 0.0f);
             const float g = sg * coef * d.m;
-            float gix, giy;
-            bilin_grad(src + o, t, W, H, gix, giy);
-            gu += g * gix;
-            gv += g * giy;
+            gu += g * gix[c];
+            gv += g * giy[c];
         }
         gu = gu * ((float)W / 2.0f) * (2.0f / (float)max(W - 1, 1));
         gv = gv * ((float)H / 2.0f) * (2.0f / (float)max(H - 1, 1));
@@ -446,22 +499,23 @@ __device__ __forceinline__ float2 pair_dir_grad(const float* __restrict__ src, c
 
 __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParams p) {
     const int64_t hw = (int64_t)p.H * p.W;
-    const int b = blockIdx.y;
-    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= hw) return;
-    const int yy = (int)(pix / p.W), xx = (int)(pix % p.W);
+    int b, tile, xx, yy;
+    if (!pair_tile_pixel(p.H, p.W, p.tiles_x, p.ntiles, b, tile, xx, yy)) return;
+    const int64_t pix = (int64_t)yy * p.W + xx;
     const float c1 = p.sums[b * 4 + 1], c2 = p.sums[b * 4 + 3];
     const float coef1 = p.grad_loss_fwd[b] / ((c1 == 0.0f) ? 1.0f : c1);
     const float coef2 = p.grad_loss_bwd ? p.grad_loss_bwd[b] / ((c2 == 0.0f) ? 1.0f : c2) : 0.0f;
     Taps t1, t2;
-    const DirOut d1 = pair_dir(p.flow21, p.image_ref, p.jitter, p.jitter, p.Cj, b, xx, yy, p.H, p.W, p.thresh, t1);
-    const float2 g21 = pair_dir_grad(p.image_ref, p.image, d1, t1, b, pix, p.H, p.W, coef1);
+    TapAddr a1, a2;
+    const DirOut d1 = pair_dir(p.flow21, p.image_ref, p.jitter, p.jitter, p.Cj, false, b, xx, yy, p.H, p.W,
+                               p.thresh, t1, a1);
+    const float2 g21 = pair_dir_grad(p.image_ref, p.image, d1, t1, a1, b, pix, p.H, p.W, coef1);
     *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = g21;
     float2 g12 = make_float2(0.0f, 0.0f);
     if (p.grad_loss_bwd) {
-        const DirOut d2 =
-            pair_dir(p.flow12, p.image, p.jitter_ref, p.jitter_ref, p.Cj, b, xx, yy, p.H, p.W, p.thresh, t2);
-        g12 = pair_dir_grad(p.image, p.image_ref, d2, t2, b, pix, p.H, p.W, coef2);
+        const DirOut d2 = pair_dir(p.flow12, p.image, p.jitter_ref, p.jitter_ref, p.Cj, false, b, xx, yy, p.H, p.W,
+                                   p.thresh, t2, a2);
+        g12 = pair_dir_grad(p.image, p.image_ref, d2, t2, a2, b, pix, p.H, p.W, coef2);
     }
     *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = g12;
 }
@@ -517,7 +571,7 @@ extern "C" int mr_occlusion_mask(const float* mask_flow1, const float* mask_flow
 
 extern "C" int64_t mr_pair_consist_workspace_bytes(int batch_size, int height, int width) {
     if (batch_size < 0 || height <= 0 || width <= 0) return MR_ERR_BADARG;
-    const int64_t nblk = ((int64_t)height * width + 255) / 256;
+    const int64_t nblk = (int64_t)((width + PT_W - 1) / PT_W) * ((height + PT_H - 1) / PT_H);
     return (int64_t)batch_size * nblk * 4 * (int64_t)sizeof(float);
 }
 
@@ -535,12 +589,14 @@ extern "C" int mr_pair_consist_forward(const float* flow12, const float* flow21,
     if (batch_size < 0 || height <= 0 || width <= 0) return MR_ERR_BADARG;
     if (workspace_bytes < mr_pair_consist_workspace_bytes(batch_size, height, width)) return MR_ERR_BADARG;
     if (batch_size == 0) return MR_OK;
-    if (batch_size > 65535) return MR_ERR_BADARG;
-    const int nblk = (int)(((int64_t)height * width + 255) / 256);
+    const int tiles_x = (width + PT_W - 1) / PT_W;
+    const int nblk = tiles_x * ((height + PT_H - 1) / PT_H);
+    if ((int64_t)nblk * batch_size > 0x7fffffffLL) return MR_ERR_BADARG;
     PairParams p{flow12, flow21, image_ref, image, jitter_ref, jitter, jitter_channels, (float*)workspace,
                  full_mask1, full_mask2, warp_mask1, warp_mask2, warp1, warp2, diff1, diff2,
-                 batch_size, height, width, nblk, thresh};
-    hipLaunchKernelGGL(pair_consist_forward_kernel, dim3(nblk, batch_size), dim3(256), 0, (hipStream_t)stream, p);
+                 batch_size, height, width, nblk, tiles_x, thresh};
+    hipLaunchKernelGGL(pair_consist_forward_kernel, dim3((unsigned)(nblk * batch_size)), dim3(256), 0,
+                       (hipStream_t)stream, p);
     MR_CHECK_LAUNCH();
     hipLaunchKernelGGL(pair_consist_finalize_kernel, dim3(batch_size), dim3(64), 0, (hipStream_t)stream,
                        (const float*)workspace, nblk, sums, loss_fwd, loss_bwd);
@@ -560,11 +616,14 @@ extern "C" int mr_pair_consist_backward(const float* flow12, const float* flow21
     if (jitter_channels != 1 && jitter_channels != 3) return MR_ERR_BADARG;
     if (batch_size < 0 || height <= 0 || width <= 0) return MR_ERR_BADARG;
     if (batch_size == 0) return MR_OK;
-    if (batch_size > 65535) return MR_ERR_BADARG;
-    const int nblk = (int)(((int64_t)height * width + 255) / 256);
+    const int tiles_x = (width + PT_W - 1) / PT_W;
+    const int nblk = tiles_x * ((height + PT_H - 1) / PT_H);
+    if ((int64_t)nblk * batch_size > 0x7fffffffLL) return MR_ERR_BADARG;
     PairBwdParams p{flow12, flow21, image_ref, image, jitter_ref, jitter, jitter_channels, sums,
-                    grad_loss_fwd, grad_loss_bwd, grad_flow12, grad_flow21, batch_size, height, width, thresh};
-    hipLaunchKernelGGL(pair_consist_backward_kernel, dim3(nblk, batch_size), dim3(256), 0, (hipStream_t)stream, p);
+                    grad_loss_fwd, grad_loss_bwd, grad_flow12, grad_flow21, batch_size, height, width, nblk,
+                    tiles_x, thresh};
+    hipLaunchKernelGGL(pair_consist_backward_kernel, dim3((unsigned)(nblk * batch_size)), dim3(256), 0,
+                       (hipStream_t)stream, p);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

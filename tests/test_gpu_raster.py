@@ -149,9 +149,10 @@ def test_fused_backward_matches_oracle(cuda, kind, B, is_, seed, reference_algo)
     assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * scale_f, "grad_faces")
 
 
-def test_training_mode_textures_only_bit_exact(cuda):
-    """detach_renders=True (warpbranch.py:65-66): only grad_textures is live; the one-lane gather
-    accumulates in the oracle's pixel order, so small-face scenes are bit-identical."""
+def test_training_mode_textures_only(cuda):
+    """detach_renders=True (warpbranch.py:65-66): only grad_textures is live.  The gather sums a
+    face's pixels as four row-interleaved partial sums (fixed order), so it matches the serial
+    oracle to fp32 round-off and is bit-reproducible run to run."""
     from handobjectconsist_amd.neurender import rasterize
 
     faces, tex = projected_faces(2, 128, 7)
@@ -163,7 +164,11 @@ def test_training_mode_textures_only_bit_exact(cuda):
     out["rgb"].backward(t(img_g[0], cuda))
     got = x_t.grad.cpu().numpy()
     assert np.abs(gt_ref).max() > 0
-    assert_close(got, gt_ref, 1e-6, 1e-7 * np.abs(gt_ref).max(), "grad_textures (training mode)")
+    assert_close(got, gt_ref, 1e-5, 1e-6 * np.abs(gt_ref).max(), "grad_textures (training mode)")
+    x2 = t(tex, cuda).requires_grad_(True)
+    out2 = rasterize.rasterize_rgbad(t(faces, cuda), x2, 128, False, 0.1, 100, 1e-3, (0, 0, 0))
+    out2["rgb"].backward(t(img_g[0], cuda))
+    assert torch.equal(x2.grad, x_t.grad), "gather backward is not deterministic"
 
 
 def test_edge_cases(cuda):
