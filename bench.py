@@ -225,7 +225,8 @@ def main():
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
 
-        net = DDP(model, device_ids=[local_rank], bucket_cap_mb=8, gradient_as_bucket_view=True)
+        net = DDP(model, device_ids=[local_rank], bucket_cap_mb=8, gradient_as_bucket_view=True,
+                  broadcast_buffers=False)  # frozen BN stats; 3 forwards per step share the buffers
     premodel = WarpRegNet((is_, is_), net, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
                           progressive_steps=1000, use_backward=True, mano_faces=model.mano_layer.th_faces,
                           pair_outputs="loss").to(dev)

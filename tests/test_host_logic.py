@@ -1,0 +1,170 @@
+"""Host-side logic (no GPU): the PyTorch pieces around the kernels against the oracle's numpy
+restatements / golden vectors, the lambda schedule closed forms, the lazy render dict."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from handobjectconsist_amd.utils import synth
+from oracle import raster_ref as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_lambda_schedule_closed_forms():
+    """warpreg.py:103-110 with trainmeshwarp.py defaults."""
+    from handobjectconsist_amd.models.warpreg import consist_lambdas
+
+    assert consist_lambdas(0, 0.999, 0.001) == (0.999, 0.0)
+    ld, lc = consist_lambdas(500, 0.999, 0.001)
+    assert abs(lc - 0.0005) < 1e-12 and abs(ld - 0.9985) < 1e-12
+    for step in (1000, 5000):
+        ld, lc = consist_lambdas(step, 0.999, 0.001)
+        assert abs(lc - 0.001) < 1e-15 and abs(ld - 0.998) < 1e-12
+    assert consist_lambdas(3, 1, 1, progressive_consist=False) == (1, 1)
+
+
+def test_closed_faces_constants():
+    from handobjectconsist_amd.models import manoutils
+
+    closed, ignore = manoutils.get_closed_faces(torch.zeros(1538, 3, dtype=torch.long))
+    assert closed.shape == (1552, 3) and ignore == list(range(1538, 1552))
+    assert closed[1538].tolist() == [92, 38, 122] and closed[-1].tolist() == [214, 215, 121]
+
+
+def test_projection_and_gather_match_oracle():
+    from handobjectconsist_amd.neurender import nr_ops
+
+    s = synth.random_scene(3, seed=1, image_size=128)
+    dist = np.array([[0.1, -0.05, 0.001, 0.002, 0.01]], np.float32)
+    Rm = np.array([[[0.96, -0.28, 0], [0.28, 0.96, 0], [0, 0, 1]]], np.float32)
+    tv = np.array([[0.01, -0.02, 0.03]], np.float32)
+    ref = R.nr_projection(s["verts1"], s["K1"], Rm, tv, dist, 128)
+    got = nr_ops.projection(torch.from_numpy(s["verts1"]), torch.from_numpy(s["K1"]), torch.from_numpy(Rm),
+                            torch.from_numpy(tv), torch.from_numpy(dist), 128).numpy()
+    assert np.abs(got - ref).max() < 1e-5
+    f = nr_ops.vertices_to_faces(torch.from_numpy(ref), torch.from_numpy(s["faces"])).numpy()
+    assert np.array_equal(f, R.nr_vertices_to_faces(ref, s["faces"]))
+
+
+def test_vertex_textures_proj2d_catmesh_match_oracle():
+    from handobjectconsist_amd.utils import catmesh, project, textutils
+
+    rng = np.random.default_rng(0)
+    faces = rng.integers(0, 9, (2, 7, 3))
+    cols = rng.standard_normal((2, 9, 3)).astype(np.float32)
+    c_t = torch.from_numpy(cols).requires_grad_(True)
+    tex = textutils.batch_vertex_textures(torch.from_numpy(faces), c_t)
+    assert np.array_equal(tex.detach().numpy(), R.batch_vertex_textures(faces, cols))
+    tex.sum().backward()
+    assert c_t.grad.shape == cols.shape  # differentiable w.r.t. the vertex colours
+    v = rng.standard_normal((2, 9, 3)).astype(np.float32) + [0, 0, 3]
+    K = np.tile(np.array([[300.0, 0, 120], [0, 305.0, 130], [0, 0, 1]], np.float32), (2, 1, 1))
+    got = project.batch_proj2d(torch.from_numpy(v.astype(np.float32)), torch.from_numpy(K)).numpy()
+    assert np.abs(got - R.batch_proj2d(v, K)).max() < 1e-4
+    vs, fs, _ = catmesh.batch_cat_meshes([torch.zeros(2, 4, 3), torch.ones(2, 5, 3)],
+                                         [torch.zeros(2, 3, 3, dtype=torch.long), torch.ones(2, 2, 3, dtype=torch.long)])
+    assert vs.shape == (2, 9, 3) and fs[:, 3:].min() == 5 and fs[:, :3].max() == 0
+
+
+def test_fill_back_and_lighting_match_oracle():
+    from handobjectconsist_amd.neurender import nr_ops
+    from handobjectconsist_amd.neurender.renderer import Renderer
+
+    rng = np.random.default_rng(2)
+    fidx = rng.integers(0, 6, (2, 5, 3))
+    tex = rng.standard_normal((2, 5, 2, 2, 2, 3)).astype(np.float32)
+    f2, t2 = R.fill_back(fidx, tex)
+    assert np.array_equal(Renderer._fill_back_faces(torch.from_numpy(fidx)).numpy(), f2)
+    assert np.array_equal(Renderer._fill_back_textures(torch.from_numpy(tex)).numpy(), t2)
+    faces = rng.standard_normal((2, 5, 3, 3)).astype(np.float32)
+    lit = nr_ops.lighting(torch.from_numpy(faces), torch.from_numpy(tex), 0.8, 0.5, (1, 1, 1), (1, 0.9, 0.8), (0, 1, 0))
+    assert np.abs(lit.numpy() - R.nr_lighting(faces, tex, 0.8, 0.5, (1, 1, 1), (1, 0.9, 0.8), (0, 1, 0))).max() < 1e-6
+
+
+def test_look_at_and_perspective():
+    from handobjectconsist_amd.neurender import nr_ops
+
+    v = torch.tensor([[[0.0, 0.0, 0.0], [0.5, 0.25, 0.1]]])
+    eye = [0, 0, -(1.0 / np.tan(np.radians(30)) + 1)]
+    out = nr_ops.look_at(v, eye)
+    # looking from -z towards the origin: x, y unchanged, z shifted by the eye distance
+    assert torch.allclose(out[0, 0], torch.tensor([0.0, 0.0, float(-eye[2])], dtype=torch.float32), atol=1e-6)
+    assert torch.allclose(out[0, 1, :2], v[0, 1, :2], atol=1e-6)
+    out2 = nr_ops.look(v, eye, [0, 0, 1])
+    assert torch.allclose(out, out2, atol=1e-6)
+    p = nr_ops.perspective(out, angle=30)
+    w = np.tan(np.radians(30))
+    assert abs(float(p[0, 1, 0]) - float(out[0, 1, 0] / out[0, 1, 2]) / w) < 1e-6
+
+
+def test_golden_recover_3d_proj_and_masked_mean():
+    from handobjectconsist_amd.models.synthnet import recover_3d_proj
+    from handobjectconsist_amd.optim import lossutils, pyramidloss
+
+    g = np.load(os.path.join(GOLDEN, "warp_misc.npz"))
+    t = torch.from_numpy
+    r3d, c3d = recover_3d_proj(t(g["objpoints3d"]), t(g["camintr"]), t(g["est_scale"]), t(g["est_trans"]), off_z=0.4,
+                               input_res=(256, 256))
+    assert np.abs(r3d.numpy() - g["recons3d"]).max() < 1e-6 and np.abs(c3d.numpy() - g["est_c3d"]).max() < 1e-6
+    mm = lossutils.batch_masked_mean_loss(t(g["dists"]), t(g["mask"]))
+    assert np.abs(mm.numpy() - g["masked_mean"]).max() < 1e-6
+    crit = pyramidloss.PyramidCriterion("l1")
+    _, _, losses, diffs, _ = crit.compute(t(g["dists"]), torch.zeros_like(t(g["dists"])), mask=t(g["mask"]))
+    assert np.abs(losses.numpy() - g["masked_mean"]).max() < 1e-6 and diffs[0].shape == g["dists"].shape
+    with pytest.raises(ValueError):
+        pyramidloss.PyramidCriterion("huber")
+    with pytest.raises(NotImplementedError):
+        pyramidloss.PyramidCriterion("ssim")
+
+
+def test_renderer_argument_errors():
+    from handobjectconsist_amd.neurender.renderer import Renderer
+
+    with pytest.raises(ValueError):
+        Renderer(camera_mode="orthographic")
+    ren = Renderer(image_size=8, K=np.eye(3, dtype=np.float32)[None], R=np.eye(3, dtype=np.float32)[None],
+                   t=np.zeros((1, 3), np.float32))
+    assert ren.rasterizer_eps == 1e-3 and ren.dist_coeffs.shape == (1, 5)
+    with pytest.raises(ValueError):
+        ren(torch.zeros(1, 3, 3), torch.zeros(1, 1, 3, dtype=torch.long), mode="normals")
+
+
+def test_lazy_render_dict():
+    from handobjectconsist_amd.neurender.rasterize import _RenderOutput
+
+    calls = []
+    d = _RenderOutput({"rgb": 1, "face_inv_map": None})
+    d._thunk = lambda: calls.append(1) or "materialised"
+    assert set(d.keys()) == {"rgb", "face_inv_map"} and calls == []
+    assert d["rgb"] == 1 and calls == []
+    assert d["face_inv_map"] == "materialised" and d.get("face_inv_map") == "materialised" and calls == [1]
+
+
+def test_synthetic_meshes_have_the_reference_sizes():
+    hv, hf = synth.hand_template()
+    ov, of = synth.object_template()
+    assert hv.shape == (778, 3) and hf.shape == (1552, 3) and ov.shape == (1002, 3) and of.shape == (2000, 3)
+    s = synth.random_scene(2, seed=0)
+    assert s["verts1"].shape == (2, 1780, 3) and s["faces"].shape == (2, 3552, 3) and s["faces"].max() == 1779
+    # closed, consistently oriented: every directed edge appears exactly once
+    e = np.concatenate([hf[:, [0, 1]], hf[:, [1, 2]], hf[:, [2, 0]]])
+    assert len({tuple(x) for x in e}) == len(e) and {tuple(x[::-1]) for x in e} == {tuple(x) for x in e}
+
+
+def test_synthetic_network_matches_the_reference_parameter_count():
+    from handobjectconsist_amd.models.synthnet import SynthMeshRegNet
+
+    m = SynthMeshRegNet()
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 11981157
+    from handobjectconsist_amd.netscripts.epochpassconsist import SyntheticConsistLoader
+
+    ld = SyntheticConsistLoader(2, 64, device="cpu", pool=1)
+    data, consist = ld.step_batches(0)
+    assert data["supervision"] == "data" and consist["supervision"] == "consist" and len(consist["data"]) == 2
+    loss, res, losses = m(data["data"][0])
+    assert loss.shape == (1,) and res["recov_handverts3d"].shape == (2, 778, 3)
+    assert res["recov_objverts3d"].shape == (2, 1002, 3) and "mano_reg_loss" in losses
+    loss.backward()
+    assert all(p.grad is not None for p in m.parameters() if p.requires_grad)
