@@ -10,20 +10,27 @@
 //                          compact per-image record list {bbox, face index} (16 B) and folded
 //                          into the image's union bbox; optional faces_inv for the
 //                          upstream-compatible API.
-//   2. raster_tile_kernel  one 256-thread workgroup per 32x32 screen tile.  Tiles outside the
+//   2. raster_tile_kernel  one 256-thread workgroup per 32x8 screen tile (128-B output rows).  Tiles outside the
 //                          image's union bbox skip straight to the background fill.  Otherwise
 //                          each of the 4 waves scans a quarter of the record list -- 4
 //                          independent 16-B loads per lane in flight -- ballots the records
 //                          that touch the tile and compacts them (wave64 ballot + popcount
-//                          prefix) into a wave-private LDS ring.  The ring is drained 16 faces
-//                          at a time, FOUR LANES PER FACE (lane k walks bbox rows k, k+4, ...),
-//                          which keeps lanes busy for the 5x5..16x16-pixel triangles of these
-//                          meshes and bounds the walk of a tile-filling face to 256 pixels.
+//                          prefix) into a wave-private LDS ring.  The ring is consumed in
+//                          batches of 32 faces, in three lock-step stages that keep the lanes
+//                          full for the 5x5..16x16-pixel triangles of these meshes:
+//                            S1 lane per face: load the 9 floats, invert the pixel-space
+//                               matrix, park the face in an LDS face cache;
+//                            S2 8 faces x 8 tile rows per pass, one lane per (face, row),
+//                               walking the clipped x-range with ONLY the three cheap edge
+//                               tests; covered pixels are appended as fragments (face slot,
+//                               x, y) to an LDS queue by ballot + popcount;
+//                            S3 lane per fragment, 64 at a time: barycentrics (the 7 IEEE
+//                               divisions), near/far test, depth test.
 //                          Depth test = ds_min_u64 on a per-tile LDS z-buffer holding
 //                          (ordered(zp) << 32 | face_index): a lexicographic min, i.e. exactly
 //                          upstream's "strict < in ascending face order" (nearest face, lowest
 //                          index on ties), independent of processing order.
-//   3. resolve (same kernel) each thread owns 4 pixels: decode winner, recompute its
+//   3. resolve (same kernel) each thread owns one pixel: decode winner, recompute its
 //                          barycentrics (bit-identical to the winning test), sample the
 //                          texture, blend background, write every output plane once,
 //                          already vertically flipped / NCHW for the image-space outputs.
@@ -33,13 +40,14 @@
 
 namespace mr {
 
-constexpr int TILE = 32;              // tile edge in pixels
+constexpr int TILE_W = 32, TILE_H = 8;  // tile size in pixels (one pixel per thread)
 constexpr int TPB = 256;              // threads per workgroup (4 waves)
-constexpr int PX_PER_THREAD = TILE * TILE / TPB;
-constexpr int LPF = 4;                // lanes per face in a drain
-constexpr int DRAIN_FACES = MR_WAVE / LPF;
-constexpr int QCAP = 128;             // wave-private ring capacity (>= DRAIN_FACES - 1 + 64, power of 2)
+constexpr int NB = 32;                // faces per batch (stage S1: one lane per face)
+constexpr int FPP = MR_WAVE / TILE_H; // faces per S2 pass: one lane per (face, tile row)
+constexpr int FC_STRIDE = 25;         // dwords per face-cache slot (odd: conflict-free ds_read_b32)
+constexpr int FQCAP = 128;            // fragment queue capacity (>= 2 * 64)
 constexpr int SCAN_UNROLL = 4;        // independent record loads in flight per lane
+constexpr int QCAP = 512;             // wave-private ring capacity (>= NB - 1 + 64 * SCAN_UNROLL, power of 2)
 
 // Per-image header of the compact face-record list (zero-initialised before face_setup_kernel).
 // The union bbox is kept as maxima so that all-zero means "no face": nx0 = max(is - x0), x1p =
@@ -121,7 +129,7 @@ struct FwdParams {
     float* face_inv_map;   // [B,is,is,9] raster orientation (nullable)
     int B, F, is, ts;
     float near_, far_, eps;
-    int tiles_x;           // tiles per row (= per column)
+    int tiles_x, tiles_y;  // tiles per row / per column
     const unsigned long long* keys;  // validation only: precomputed z-buffer keys (skip the scan)
     int dbg;                         // profiling experiments (flags >> 8)
 };
@@ -135,27 +143,36 @@ __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float 
 // FUSED = false: upstream-compatible forward_face_index_map: touch hit pixels only.
 template <bool FUSED>
 __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
-    __shared__ unsigned long long zbuf[TILE * TILE];
+    __shared__ unsigned long long zbuf[TILE_W * TILE_H];
     __shared__ int queue[TPB / MR_WAVE][QCAP];
+    __shared__ float fcache[TPB / MR_WAVE][NB * FC_STRIDE];
+    __shared__ unsigned fragq[TPB / MR_WAVE][FQCAP];
+    __shared__ float xp_tab[TILE_W], yp_tab[TILE_H];
 
     const unsigned nblocks = gridDim.x;
     const unsigned lid = xcd_remap(blockIdx.x, nblocks);
-    const int tiles_per_img = p.tiles_x * p.tiles_x;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int b = lid / tiles_per_img;
     const int t = lid % tiles_per_img;
-    const int tx0 = (t % p.tiles_x) * TILE, ty0 = (t / p.tiles_x) * TILE;
-    const int tx1 = min(tx0 + TILE, p.is) - 1, ty1 = min(ty0 + TILE, p.is) - 1;
+    const int tx0 = (t % p.tiles_x) * TILE_W, ty0 = (t / p.tiles_x) * TILE_H;
+    const int tx1 = min(tx0 + TILE_W, p.is) - 1, ty1 = min(ty0 + TILE_H, p.is) - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int is = p.is;
+    const float fis = (float)is;
 
-#pragma unroll
-    for (int j = 0; j < PX_PER_THREAD; j++) zbuf[tid + j * TPB] = ~0ull;
+    zbuf[tid] = ~0ull;
+    // NDC coordinates of the tile's pixel centres (upstream: (2 * i + 1 - is) / is)
+    if (tid < TILE_W) xp_tab[tid] = (float)(2 * (tx0 + tid) + 1 - is) / fis;
+    else if (tid < TILE_W + TILE_H) yp_tab[tid - TILE_W] = (float)(2 * (ty0 + tid - TILE_W) + 1 - is) / fis;
     __syncthreads();
 
     const float* faces_b = p.faces + (int64_t)b * p.F * 9;
     const FaceRec* recs_b = p.recs + (int64_t)b * p.F;
     int* q = queue[wave];
+    float* fc = fcache[wave];
+    unsigned* fq = fragq[wave];
     int qhead = 0, qn = 0;  // wave-uniform ring state
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     int n_rec = 0;
     if (!p.keys) {
@@ -167,74 +184,129 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
         if (p.dbg & 1) n_rec = 0;
     }
 
-    // DRAIN_FACES faces per call, LPF lanes per face: lane `sub` walks rows sub, sub + LPF, ...
-    auto drain = [&](int count) {
-        const int slot = lane / LPF, sub = lane % LPF;
-        if (slot < count && !(p.dbg & 4)) {
-            const FaceRec r = recs_b[q[(qhead + slot) & (QCAP - 1)]];
+    // S3: one lane per fragment -- barycentrics, near/far, depth test
+    auto shade = [&](int n) {
+        if (lane < n && !(p.dbg & 16)) {
+            const unsigned fr = fq[lane];
+            const float* c = fc + (fr >> 16) * FC_STRIDE;
+            const int lx = (int)(fr & 0xffu), ly = (int)((fr >> 8) & 0xffu);
+            Face f;
+#pragma unroll
+            for (int k = 0; k < 9; k++) f.inv[k] = c[9 + k];
+            f.v[2] = c[2]; f.v[5] = c[5]; f.v[8] = c[8];
+            const int fn = __float_as_int(c[18]);
+            float zp, w[3];
+            bary(f, tx0 + lx, ty0 + ly, zp, w);
+            if (!(zp <= p.near_ || p.far_ <= zp)) zbuf_min(zbuf, ly * TILE_W + lx, zp, fn);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    auto process_batch = [&](int count) {
+        // S1: one lane per face
+        if (lane < count && !(p.dbg & 4)) {
+            const FaceRec r = recs_b[q[(qhead + lane) & (QCAP - 1)]];
             const int fn = (int)r.z;
             Face f;
             load_face(faces_b + (int64_t)fn * 9, f, is);
-            const int x0 = max((int)(r.x & 0xffffu), tx0), x1 = min((int)(r.x >> 16), tx1);
-            const int y0 = max((int)(r.y & 0xffffu), ty0), y1 = min((int)(r.y >> 16), ty1);
-            for (int yi = y0 + sub; yi <= y1; yi += LPF)
-                for (int xi = x0; xi <= x1; xi++) {
-                    float zp, w[3];
-                    if (cover(f, xi, yi, is, p.near_, p.far_, zp, w))
-                        zbuf_min(zbuf, (yi - ty0) * TILE + (xi - tx0), zp, fn);
-                }
+            float* c = fc + lane * FC_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 9; k++) { c[k] = f.v[k]; c[9 + k] = f.inv[k]; }
+            const int x0 = max((int)(r.x & 0xffffu), tx0) - tx0, x1 = min((int)(r.x >> 16), tx1) - tx0;
+            const int y0 = max((int)(r.y & 0xffffu), ty0) - ty0, y1 = min((int)(r.y >> 16), ty1) - ty0;
+            c[18] = __int_as_float(fn);
+            c[19] = __int_as_float(x0 | (x1 << 8) | (y0 << 16) | (y1 << 24));
         }
         __builtin_amdgcn_wave_barrier();
+        if (p.dbg & (4 | 8)) return;
+        // S2: FPP faces per pass, one lane per (face, tile row): walk the face's clipped x-range on
+        // that row with the edge tests only, all lanes in lock step
+        int fqn = 0;
+        for (int f0 = 0; f0 < count; f0 += FPP) {
+            const int slot = f0 + lane / TILE_H, row = lane % TILE_H;
+            bool act = slot < count;
+            float ax = 0, ay = 0, bx = 0, by = 0, cx_ = 0, cy_ = 0, yp = 0;
+            int px = 0, lx1 = -1;
+            if (act) {
+                const float* c = fc + slot * FC_STRIDE;
+                const int bb = __float_as_int(c[19]);
+                act = row >= ((bb >> 16) & 0xff) && row <= ((bb >> 24) & 0xff);
+                ax = c[0]; ay = c[1]; bx = c[3]; by = c[4]; cx_ = c[6]; cy_ = c[7];
+                px = bb & 0xff; lx1 = (bb >> 8) & 0xff;
+                yp = yp_tab[row];
+            }
+            const float dx01 = bx - ax, dy01 = by - ay, dx12 = cx_ - bx, dy12 = cy_ - by, dx20 = ax - cx_,
+                        dy20 = ay - cy_;
+            const float ey0 = (yp - ay) * dx01, ey1 = (yp - by) * dx12, ey2 = (yp - cy_) * dx20;
+            while (__ballot(act) != 0ull) {
+                bool cov = false;
+                if (act) {
+                    const float xp = xp_tab[px];
+                    cov = !((ey0 < (xp - ax) * dy01) || (ey1 < (xp - bx) * dy12) || (ey2 < (xp - cx_) * dy20));
+                }
+                const unsigned long long m = __ballot(cov);
+                if (cov) fq[fqn + __popcll(m & lt_mask)] = ((unsigned)slot << 16) | ((unsigned)row << 8) | (unsigned)px;
+                fqn += __popcll(m);
+                px++;
+                act = act && px <= lx1;
+                __builtin_amdgcn_wave_barrier();
+                if (fqn >= MR_WAVE) {
+                    shade(MR_WAVE);
+                    const int rest = fqn - MR_WAVE;
+                    const unsigned v = (lane < rest) ? fq[MR_WAVE + lane] : 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rest) fq[lane] = v;
+                    __builtin_amdgcn_wave_barrier();
+                    fqn = rest;
+                }
+            }
+        }
+        if (fqn > 0) shade(fqn);
     };
 
     // each wave scans a contiguous quarter of the image's record list
     const int per_wave = (n_rec + 3) / 4;
     const int r_begin = wave * per_wave;
     const int r_end = min(r_begin + per_wave, n_rec);
-    for (int base = r_begin; base < r_end; base += MR_WAVE * SCAN_UNROLL) {
-        FaceRec rr[SCAN_UNROLL];
+    for (int base = r_begin;; base += MR_WAVE * SCAN_UNROLL) {
+        const bool flush = base >= r_end;
+        if (!flush) {
+            FaceRec rr[SCAN_UNROLL];
 #pragma unroll
-        for (int j = 0; j < SCAN_UNROLL; j++) {
-            const int ri = base + j * MR_WAVE + lane;
-            rr[j] = recs_b[min(ri, r_end - 1)];
-        }
-#pragma unroll
-        for (int j = 0; j < SCAN_UNROLL; j++) {
-            const int ri = base + j * MR_WAVE + lane;
-            const int bx0 = (int)(rr[j].x & 0xffffu), bx1 = (int)(rr[j].x >> 16);
-            const int by0 = (int)(rr[j].y & 0xffffu), by1 = (int)(rr[j].y >> 16);
-            const bool hit = ri < r_end && bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
-            const unsigned long long m = __ballot(hit);
-            if (hit) q[(qhead + qn + __popcll(m & ((1ull << lane) - 1ull))) & (QCAP - 1)] = ri;
-            qn += __popcll(m);
-            __builtin_amdgcn_wave_barrier();
-            while (qn >= DRAIN_FACES) {
-                drain(DRAIN_FACES);
-                qhead = (qhead + DRAIN_FACES) & (QCAP - 1);
-                qn -= DRAIN_FACES;
+            for (int j = 0; j < SCAN_UNROLL; j++) {
+                const int ri = base + j * MR_WAVE + lane;
+                rr[j] = recs_b[min(ri, r_end - 1)];
             }
-        }
-    }
-    if (qn > 0) drain(qn);
-    if (p.keys) {
 #pragma unroll
-        for (int j = 0; j < PX_PER_THREAD; j++) {
-            const int ly = (tid >> 5) + j * (TPB / TILE), lx = tid & (TILE - 1);
-            if (tx0 + lx < is && ty0 + ly < is)
-                zbuf[ly * TILE + lx] = p.keys[((int64_t)b * is + ty0 + ly) * is + tx0 + lx];
+            for (int j = 0; j < SCAN_UNROLL; j++) {
+                const int ri = base + j * MR_WAVE + lane;
+                const int bx0 = (int)(rr[j].x & 0xffffu), bx1 = (int)(rr[j].x >> 16);
+                const int by0 = (int)(rr[j].y & 0xffffu), by1 = (int)(rr[j].y >> 16);
+                const bool hit = ri < r_end && bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
+                const unsigned long long m = __ballot(hit);
+                if (hit) q[(qhead + qn + __popcll(m & lt_mask)) & (QCAP - 1)] = ri;
+                qn += __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        while (qn >= (flush ? 1 : NB)) {
+            const int c = min(qn, NB);
+            process_batch(c);
+            qhead = (qhead + c) & (QCAP - 1);
+            qn -= c;
+        }
+        if (flush) break;
     }
+    const int lxr = tid & (TILE_W - 1), ly = tid >> 5;
+    const int px = tx0 + lxr, py = ty0 + ly;
+    if (p.keys && px < is && py < is) zbuf[tid] = p.keys[((int64_t)b * is + py) * is + px];
     __syncthreads();
 
     if (p.dbg & 2) return;
-    // resolve: thread owns pixels (x = tid % 32, y = tid / 32 + 8 j)
-    const int px = tx0 + (tid & (TILE - 1));
-#pragma unroll
-    for (int j = 0; j < PX_PER_THREAD; j++) {
-        const int ly = (tid >> 5) + j * (TPB / TILE);
-        const int py = ty0 + ly;
-        if (px >= is || py >= is) continue;
-        const unsigned long long key = zbuf[ly * TILE + (tid & (TILE - 1))];
+    // resolve: one pixel per thread (x = tid % 32, y = tid / 32)
+    {
+        if (px >= is || py >= is) return;
+        const unsigned long long key = zbuf[tid];
         const bool hitpx = key != ~0ull;
         const int64_t ri = ((int64_t)b * is + py) * is + px;            // raster orientation
         const int64_t ii = ((int64_t)b * is + (is - 1 - py)) * is + px;  // image orientation
@@ -254,7 +326,7 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
 #pragma unroll
                     for (int k = 0; k < 9; k++) p.face_inv_map[ri * 9 + k] = 0.0f;
             }
-            continue;
+            return;
         }
         const int fn = (int)(unsigned)(key & 0xffffffffull);
         const float zp = ord2f((uint32_t)(key >> 32));
@@ -271,7 +343,7 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
             for (int k = 0; k < 9; k++) p.face_inv_map[ri * 9 + k] = f.inv[k];
         if (!FUSED) {
             p.depth[ri] = zp;
-            continue;
+            return;
         }
         if (p.depth) p.depth[ii] = zp;
         if (p.alpha) p.alpha[ii] = 1.0f;
@@ -403,8 +475,9 @@ static int launch_setup(const float* faces, void* workspace, float* faces_inv, i
 
 template <bool FUSED>
 static int launch_tiles(FwdParams& p, hipStream_t s) {
-    p.tiles_x = (p.is + TILE - 1) / TILE;
-    const int64_t nblocks = (int64_t)p.B * p.tiles_x * p.tiles_x;
+    p.tiles_x = (p.is + TILE_W - 1) / TILE_W;
+    p.tiles_y = (p.is + TILE_H - 1) / TILE_H;
+    const int64_t nblocks = (int64_t)p.B * p.tiles_x * p.tiles_y;
     if (nblocks == 0) return MR_OK;
     if (nblocks > 0x7fffffffLL) return MR_ERR_BADARG;
     hipLaunchKernelGGL(raster_tile_kernel<FUSED>, dim3((unsigned)nblocks), dim3(TPB), 0, s, p);

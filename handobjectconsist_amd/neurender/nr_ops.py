@@ -44,7 +44,8 @@ def vertices_to_faces(vertices, faces):
         raise ValueError("shape mismatch between vertices and faces")
     bs, nv = vertices.shape[:2]
     faces = faces.long() + (torch.arange(bs, device=vertices.device) * nv)[:, None, None]
-    return vertices.reshape(bs * nv, 3)[faces]
+    # index_select: its backward is an atomic index_add (no per-call index sort)
+    return vertices.reshape(bs * nv, 3).index_select(0, faces.reshape(-1)).view(bs, faces.shape[1], 3, 3)
 
 
 def _vec(v, device, batch_size):

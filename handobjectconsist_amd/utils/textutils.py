@@ -14,7 +14,8 @@ def batch_vertex_textures(faces, vertex_colors):
     B, Fn = faces.shape[:2]
     V = vertex_colors.shape[1]
     idx = faces.long() + (torch.arange(B, device=faces.device) * V)[:, None, None]
-    cols = vertex_colors.reshape(B * V, 3)[idx]  # [B,F,3 (vertex),3 (rgb)]
+    # index_select: its backward is an atomic index_add (no per-call index sort)
+    cols = vertex_colors.reshape(B * V, 3).index_select(0, idx.reshape(-1)).view(B, Fn, 3, 3)
     tex = vertex_colors.new_zeros((B, Fn, 8, 3))
     # flat texel index = 4 * i0 + 2 * i1 + i2
     tex = torch.cat([tex[:, :, :1], cols[:, :, 2:3], cols[:, :, 1:2], tex[:, :, :1], cols[:, :, 0:1],

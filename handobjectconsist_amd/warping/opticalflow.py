@@ -47,10 +47,23 @@ def get_opticalflows(
 
 def _ignore_mask(face_index_map, ignore_face_idxs):
     """1 where the winning face is not in the ignore list, in IMAGE orientation
-    (opticalflow.py:110-116: |fim - ids|.min != 0, then the manual vertical flip)."""
-    ids = torch.as_tensor(ignore_face_idxs, dtype=face_index_map.dtype, device=face_index_map.device)
-    keep = ~torch.isin(face_index_map, ids)
-    return keep.flip(1).float().unsqueeze(1)
+    (opticalflow.py:110-116: |fim - ids|.min != 0, then the manual vertical flip).  Done as a
+    table lookup over face indices instead of materialising the [B, is, is, 14] difference."""
+    ids = torch.as_tensor(ignore_face_idxs, dtype=torch.long, device=face_index_map.device)
+    n = int(max(int(ids.max().item()) + 2, 2)) if ids.numel() else 2
+    key = (tuple(int(i) for i in ignore_face_idxs), str(face_index_map.device))
+    lut = _LUT_CACHE.get(key)
+    if lut is None:
+        lut = torch.ones(n, dtype=torch.float32, device=face_index_map.device)
+        lut[ids[ids >= 0] + 1] = 0.0  # slot 0 = background (-1)
+        _LUT_CACHE[key] = lut
+    idx = (face_index_map.long() + 1).clamp_(max=lut.numel() - 1)
+    hi = face_index_map >= (lut.numel() - 1)  # faces beyond the table are never ignored
+    keep = torch.where(hi, torch.ones((), device=lut.device), lut[idx])
+    return keep.flip(1).unsqueeze(1)
+
+
+_LUT_CACHE = {}
 
 
 def get_opticalflow(
