@@ -97,7 +97,7 @@ __device__ __forceinline__ void gather_pixel(const GatherParams& p, const Face& 
 // combined with two quad shuffles (fixed order: deterministic).  Faces whose bbox exceeds
 // GATHER_BIG pixels are walked by the whole wave instead.
 constexpr int GLPF = 4;
-constexpr int GATHER_BIG = 2048;
+constexpr int GATHER_BIG = 256;
 
 template <bool TEX, bool DEPTH>
 __device__ __forceinline__ void gather_store(const GatherParams& p, int64_t i, const float* gt, const float* gf) {
@@ -158,9 +158,20 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
         for (int k = 0; k < NT; k++) gt[k] = 0.0f;
 #pragma unroll
         for (int k = 0; k < NF; k++) gf[k] = 0.0f;
-        for (int j = lane; j < n; j += MR_WAVE) {
-            const int xi = x0 + j % w_, yi = y0 + j / w_;
-            if (fim_b[yi * is + xi] == ff) gather_pixel<IMG, TEX, DEPTH>(p, fb, bb, xi, yi, gt, gf);
+        // lane per column (chunks of 64 columns), rows in groups of 8 with the 8 index-map loads
+        // issued back to back (a degenerate face carries a full-screen bbox: 1024 probes per lane)
+        (void)n;
+        const int h_ = __shfl(bh, src);
+        for (int cx = lane; cx < w_; cx += MR_WAVE) {
+            const int xi = x0 + cx;
+            for (int r = 0; r < h_; r += 8) {
+                int hit[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) hit[u] = fim_b[min(y0 + r + u, y0 + h_ - 1) * is + xi];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (r + u < h_ && hit[u] == ff) gather_pixel<IMG, TEX, DEPTH>(p, fb, bb, xi, y0 + r + u, gt, gf);
+            }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -183,8 +194,14 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
         load_face(p.faces + i * 9, f, is);
         const int32_t* fim_b = p.fim + (int64_t)b * is * is;
         for (int yi = bx.y0 + sub; yi <= bx.y1; yi += GLPF)
-            for (int xi = bx.x0; xi <= bx.x1; xi++)
-                if (fim_b[yi * is + xi] == fn) gather_pixel<IMG, TEX, DEPTH>(p, f, b, xi, yi, gt, gf);
+            for (int xi = bx.x0; xi <= bx.x1; xi += 4) {
+                int hit[4];  // four probes in flight
+#pragma unroll
+                for (int u = 0; u < 4; u++) hit[u] = fim_b[yi * is + min(xi + u, (int)bx.x1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (xi + u <= bx.x1 && hit[u] == fn) gather_pixel<IMG, TEX, DEPTH>(p, f, b, xi + u, yi, gt, gf);
+            }
     }
     // quad reduction: afterwards every lane of the quad holds the face's sums
 #pragma unroll

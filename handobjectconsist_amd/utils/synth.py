@@ -41,13 +41,40 @@ def sphere_mesh(n_verts):
     return v.astype(np.float32), f
 
 
+# the 14 wrist-closing faces of meshreg/models/manoutils.py:10-28 and the 16 vertex ids they use
+MANO_CLOSE_FACES = [
+    [92, 38, 122], [234, 92, 122], [239, 234, 122], [279, 239, 122], [215, 279, 122], [215, 122, 118],
+    [215, 118, 117], [215, 117, 119], [215, 119, 120], [215, 120, 108], [215, 108, 79], [215, 79, 78],
+    [215, 78, 121], [214, 215, 121],
+]
+MANO_WRIST_IDS = sorted({v for f in MANO_CLOSE_FACES for v in f})
+
+
 @functools.lru_cache(maxsize=None)
 def hand_template():
-    """778 verts / 1552 faces, palm-like flattened ellipsoid, metres, centred."""
+    """778 verts / 1552 faces, palm-like flattened ellipsoid, metres, centred.
+
+    Vertices are relabelled so that the 16 ids MANO's wrist-closing faces refer to are the 16
+    vertices of the template's wrist-end cap: faces[:1538] play the role of MANO's open mesh and
+    faces[1538:] ARE manoutils' 14 closing faces (a fan of a few centimetres, like the real ones)."""
     v, f = sphere_mesh(HAND_VERTS)
     v = v * np.array([0.045, 0.09, 0.018], np.float32)
     # a few bumps so that the silhouette is not convex ("fingers")
     v = v * (1.0 + 0.25 * np.cos(5 * np.arctan2(v[:, 0], v[:, 1] + 1e-6)) * (v[:, 1] > 0))[:, None]
+    cap = np.argsort(v[:, 1])[: len(MANO_WRIST_IDS)]          # wrist end = smallest y
+    perm = np.arange(HAND_VERTS)                              # new id -> old id
+    free_new = [i for i in range(HAND_VERTS) if i not in set(MANO_WRIST_IDS)]
+    free_old = [i for i in range(HAND_VERTS) if i not in set(cap.tolist())]
+    perm[MANO_WRIST_IDS] = cap
+    perm[free_new] = free_old
+    inv = np.empty(HAND_VERTS, np.int64)
+    inv[perm] = np.arange(HAND_VERTS)
+    v, f = v[perm], inv[f]
+    # drop the 14 faces closest to the wrist end, append the closing fan
+    order = np.argsort(v[f].mean(1)[:, 1])
+    keep = np.sort(order[14:])
+    f = np.concatenate([f[keep], np.asarray(MANO_CLOSE_FACES, np.int64)], 0)
+    assert f.shape == (HAND_FACES, 3)
     return v.astype(np.float32), f
 
 

@@ -148,9 +148,13 @@ def test_synthetic_meshes_have_the_reference_sizes():
     assert hv.shape == (778, 3) and hf.shape == (1552, 3) and ov.shape == (1002, 3) and of.shape == (2000, 3)
     s = synth.random_scene(2, seed=0)
     assert s["verts1"].shape == (2, 1780, 3) and s["faces"].shape == (2, 3552, 3) and s["faces"].max() == 1779
-    # closed, consistently oriented: every directed edge appears exactly once
-    e = np.concatenate([hf[:, [0, 1]], hf[:, [1, 2]], hf[:, [2, 0]]])
+    # the object is closed and consistently oriented: every directed edge appears exactly once
+    e = np.concatenate([of[:, [0, 1]], of[:, [1, 2]], of[:, [2, 0]]])
     assert len({tuple(x) for x in e}) == len(e) and {tuple(x[::-1]) for x in e} == {tuple(x) for x in e}
+    # the hand's last 14 faces are manoutils' wrist-closing fan, a few centimetres across
+    from handobjectconsist_amd.models import manoutils
+    assert hf[1538:].tolist() == manoutils.CLOSE_FACES
+    assert np.ptp(hv[np.unique(hf[1538:])], axis=0).max() < 0.06
 
 
 def test_synthetic_network_matches_the_reference_parameter_count():
