@@ -217,6 +217,166 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// E for the vertex-colour mode: gradient w.r.t. the per-vertex colours, fill-back by index
+// ---------------------------------------------------------------------------------------
+struct GatherVCParams {
+    const float* verts;     // [B,V,3] projected
+    const int32_t* fidx;    // [B,F0,3]
+    const int32_t* fim;     // raster orientation, values in [0, 2 F0)
+    const float* grad_rgb;  // image orientation
+    float* grad_vcolors;    // [B,V,3], pre-zeroed, accumulated with fp32 atomics
+    int B, V, F0, fill_back, is;
+    float eps;
+};
+
+// contribution of one won pixel to the colours of the face's three vertices (its own order)
+__device__ __forceinline__ void gather_vc_pixel(const GatherVCParams& p, const Face& f, int b, int xi, int yi,
+                                                float (*acc)[3]) {
+    float w[3], zp, tif[3], g[3];
+    bary(f, xi, yi, zp, w);
+    tex_coords(w, zp, f.v, 2, p.eps, tif);
+#pragma unroll
+    for (int c = 0; c < 3; c++) g[c] = p.grad_rgb[idx3<true>(b, yi, xi, c, p.is)];
+    // taps pn = 1, 2, 4 are the texels holding the colours of vertices 0, 1, 2
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int pn = 1 << k;
+        float wg = 1.0f;
+#pragma unroll
+        for (int j = 0; j < 3; j++) wg *= ((pn >> j) & 1) ? (tif[j] - 0.0f) : (1.0f - (tif[j] - 0.0f));
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[k][c] += wg * g[c];
+    }
+}
+
+template <int DUMMY>
+__global__ void __launch_bounds__(256) gather_vc_kernel(GatherVCParams p) {
+    const int64_t total = (int64_t)p.B * p.F0;
+    const int64_t gid = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const int64_t i = gid / GLPF;
+    const int sub = (int)(gid % GLPF);
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < total;
+    const int b = valid ? (int)(i / p.F0) : 0;
+    const int f0 = valid ? (int)(i % p.F0) : 0;
+    const int is = p.is;
+
+    int vid[3] = {0, 0, 0};
+    float v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = __builtin_nanf("");
+    if (valid) {
+        const int32_t* ix = p.fidx + i * 3;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            vid[k] = ix[k];
+            const float* g = p.verts + ((int64_t)b * p.V + vid[k]) * 3;
+            v[3 * k] = g[0]; v[3 * k + 1] = g[1]; v[3 * k + 2] = g[2];
+        }
+    }
+    float acc[3][3];  // [real vertex][channel]
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[k][c] = 0.0f;
+
+    const int32_t* fim_b = p.fim + (int64_t)b * is * is;
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        if (o == 1 && !p.fill_back) break;
+        Face f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int s = o ? 2 - k : k;
+            f.v[3 * k] = v[3 * s]; f.v[3 * k + 1] = v[3 * s + 1]; f.v[3 * k + 2] = v[3 * s + 2];
+        }
+        const FaceBox bx = face_box(f.v, is);
+        const bool nonempty = valid && bx.x0 <= bx.x1;
+        const int bw = bx.x1 - bx.x0 + 1, bh = bx.y1 - bx.y0 + 1;
+        const bool big = nonempty && bw * bh > GATHER_BIG;
+        const int fn = o ? f0 + p.F0 : f0;
+        float part[3][3];  // [vertex in this orientation's order][channel]
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) part[k][c] = 0.0f;
+        if (nonempty && !big) {
+            face_inverse(f.v, f.inv, is);
+            for (int yi = bx.y0 + sub; yi <= bx.y1; yi += GLPF)
+                for (int xi = bx.x0; xi <= bx.x1; xi += 4) {
+                    int hit[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) hit[u] = fim_b[yi * is + min(xi + u, (int)bx.x1)];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (xi + u <= bx.x1 && hit[u] == fn) gather_vc_pixel(p, f, b, xi + u, yi, part);
+                }
+        }
+        // very large faces: whole wave, lane per column, rows in groups of 8
+        unsigned long long m_big = __ballot(big && sub == 0);
+        while (m_big) {
+            const int src = __ffsll((long long)m_big) - 1;
+            m_big &= m_big - 1;
+            Face fb;
+#pragma unroll
+            for (int k = 0; k < 9; k++) fb.v[k] = __shfl(f.v[k], src);
+            face_inverse(fb.v, fb.inv, is);
+            const int x0 = __shfl((int)bx.x0, src), y0 = __shfl((int)bx.y0, src);
+            const int w_ = __shfl(bw, src), h_ = __shfl(bh, src);
+            const int bb = __shfl(b, src), ff = __shfl(fn, src);
+            const int32_t* fim_s = p.fim + (int64_t)bb * is * is;
+            float pb[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) pb[k][c] = 0.0f;
+            for (int cx = lane; cx < w_; cx += MR_WAVE) {
+                const int xi = x0 + cx;
+                for (int r = 0; r < h_; r += 8) {
+                    int hit[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) hit[u] = fim_s[min(y0 + r + u, y0 + h_ - 1) * is + xi];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (r + u < h_ && hit[u] == ff) gather_vc_pixel(p, fb, bb, xi, y0 + r + u, pb);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) pb[k][c] += __shfl_xor(pb[k][c], off);
+            if (lane == src)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) part[k][c] += pb[k][c];
+        }
+        // map this orientation's vertex order back to the real vertices
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[o ? 2 - k : k][c] += part[k][c];
+    }
+#pragma unroll
+    for (int off = 1; off < GLPF; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[k][c] += __shfl_xor(acc[k][c], off);
+    if (valid && sub == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float* o = p.grad_vcolors + ((int64_t)b * p.V + vid[k]) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (acc[k][c] != 0.0f) atomicAdd(&o[c], acc[k][c]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // E, generic texture size: per-pixel atomics on recomputed sampling weights
 // ---------------------------------------------------------------------------------------
 template <bool IMG>
@@ -584,4 +744,22 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
         }
     }
     return rc;
+}
+
+extern "C" int mr_render_vc_backward(const float* verts, const int32_t* faces_idx, const int32_t* face_index_map,
+                                     const float* grad_rgb_img, float* grad_vcolors, int batch_size, int num_verts,
+                                     int num_faces, int fill_back, int image_size, float eps, int flags,
+                                     mr_stream_t stream) {
+    (void)flags;
+    if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0) return MR_ERR_BADARG;
+    if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
+    if (batch_size == 0 || num_verts == 0) return MR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_vcolors, 0, (size_t)batch_size * num_verts * 3 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    if (num_faces == 0) return MR_OK;
+    if (!verts || !faces_idx || !face_index_map || !grad_rgb_img || !(eps >= 1e-6f)) return MR_ERR_BADARG;
+    GatherVCParams g{verts, faces_idx, face_index_map, grad_rgb_img, grad_vcolors, batch_size, num_verts, num_faces,
+                     fill_back, image_size, eps};
+    return launch1d(gather_vc_kernel<0>, (int64_t)batch_size * num_faces * GLPF, s, g);
 }

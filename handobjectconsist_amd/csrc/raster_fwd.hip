@@ -114,6 +114,69 @@ __global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict
     }
 }
 
+// Vertex-colour mode: one thread per REAL face evaluates both orientations (fill-back) and
+// appends up to two records.  grid = (ceil(F0 / 256), B).
+__global__ void __launch_bounds__(256) face_setup_vc_kernel(const float* __restrict__ verts,
+                                                            const int32_t* __restrict__ fidx,
+                                                            ImageHdr* __restrict__ hdrs,
+                                                            FaceRec* __restrict__ recs, int V, int F0,
+                                                            int fill_back, int is) {
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = f0 < F0;
+    const int F = fill_back ? 2 * F0 : F0;
+    float f[9], r[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[k] = __builtin_nanf("");
+    if (valid) {
+        const int32_t* ix = fidx + ((int64_t)b * F0 + f0) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float* g = verts + ((int64_t)b * V + ix[k]) * 3;
+            f[3 * k] = g[0]; f[3 * k + 1] = g[1]; f[3 * k + 2] = g[2];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { r[k] = f[6 + k]; r[3 + k] = f[3 + k]; r[6 + k] = f[k]; }
+    const FaceBox ba = face_box(f, is);
+    FaceBox bb = face_box(r, is);
+    if (!fill_back) { bb.x0 = 1; bb.x1 = 0; }
+    int nx0 = 0, x1p = 0, ny0 = 0, y1p = 0;
+    unsigned long long any = 0ull;
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        const FaceBox bx = o ? bb : ba;
+        const bool live = valid && bx.x0 <= bx.x1;
+        const unsigned long long m = __ballot(live);
+        any |= m;
+        if (m != 0ull) {
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&hdrs[b].count, __popcll(m));
+            base = __shfl(base, leader);
+            if (live) {
+                FaceRec rec;
+                rec.x = (unsigned)(unsigned short)bx.x0 | ((unsigned)(unsigned short)bx.x1 << 16);
+                rec.y = (unsigned)(unsigned short)bx.y0 | ((unsigned)(unsigned short)bx.y1 << 16);
+                rec.z = (unsigned)(o ? f0 + F0 : f0);
+                rec.w = 0u;
+                recs[(int64_t)b * F + base + __popcll(m & ((1ull << lane) - 1ull))] = rec;
+                nx0 = max(nx0, is - bx.x0); x1p = max(x1p, bx.x1 + 1);
+                ny0 = max(ny0, is - bx.y0); y1p = max(y1p, bx.y1 + 1);
+            }
+        }
+    }
+    if (any == 0ull) return;
+    nx0 = wave_max(nx0); x1p = wave_max(x1p); ny0 = wave_max(ny0); y1p = wave_max(y1p);
+    if (lane == __ffsll((long long)any) - 1) {
+        atomicMax(&hdrs[b].nx0, nx0);
+        atomicMax(&hdrs[b].x1p, x1p);
+        atomicMax(&hdrs[b].ny0, ny0);
+        atomicMax(&hdrs[b].y1p, y1p);
+    }
+}
+
 struct FwdParams {
     const float* faces;
     const ImageHdr* hdrs;
@@ -132,7 +195,33 @@ struct FwdParams {
     int tiles_x, tiles_y;  // tiles per row / per column
     const unsigned long long* keys;  // validation only: precomputed z-buffer keys (skip the scan)
     int dbg;                         // profiling experiments (flags >> 8)
+    // vertex-colour mode (VC): indexed geometry + per-vertex colours, fill-back done by index
+    // arithmetic: virtual face fn >= F0 is face fn - F0 with its vertex order reversed
+    const float* verts;              // [B,V,3] projected vertices (x,y NDC, z metric)
+    const int32_t* fidx;             // [B,F0,3] vertex indices
+    const float* vcolors;            // [B,V,3]
+    int V, F0;
 };
+
+// the 9 floats of (virtual) face fn of image b
+template <bool VC>
+__device__ __forceinline__ void fetch_verts(const FwdParams& p, int b, int fn, float* v, int* vid) {
+    if (!VC) {
+        const float* g = p.faces + ((int64_t)b * p.F + fn) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) v[k] = g[k];
+    } else {
+        const bool rev = fn >= p.F0;
+        const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + (rev ? fn - p.F0 : fn)) * 3;
+        const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+        vid[0] = rev ? i2 : i0; vid[1] = i1; vid[2] = rev ? i0 : i2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float* g = p.verts + ((int64_t)b * p.V + vid[k]) * 3;
+            v[3 * k] = g[0]; v[3 * k + 1] = g[1]; v[3 * k + 2] = g[2];
+        }
+    }
+}
 
 __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float zp, int fn) {
     const unsigned long long key = ((unsigned long long)f2ord(zp) << 32) | (unsigned)fn;
@@ -141,7 +230,7 @@ __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float 
 
 // FUSED = true : write every pixel of every requested plane (fused epilogue).
 // FUSED = false: upstream-compatible forward_face_index_map: touch hit pixels only.
-template <bool FUSED>
+template <bool FUSED, bool VC>
 __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     __shared__ unsigned long long zbuf[TILE_W * TILE_H];
     __shared__ int queue[TPB / MR_WAVE][QCAP];
@@ -166,7 +255,6 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     else if (tid < TILE_W + TILE_H) yp_tab[tid - TILE_W] = (float)(2 * (ty0 + tid - TILE_W) + 1 - is) / fis;
     __syncthreads();
 
-    const float* faces_b = p.faces + (int64_t)b * p.F * 9;
     const FaceRec* recs_b = p.recs + (int64_t)b * p.F;
     int* q = queue[wave];
     float* fc = fcache[wave];
@@ -208,7 +296,9 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
             const FaceRec r = recs_b[q[(qhead + lane) & (QCAP - 1)]];
             const int fn = (int)r.z;
             Face f;
-            load_face(faces_b + (int64_t)fn * 9, f, is);
+            int vid[3];
+            fetch_verts<VC>(p, b, fn, f.v, vid);
+            face_inverse(f.v, f.inv, is);
             float* c = fc + lane * FC_STRIDE;
 #pragma unroll
             for (int k = 0; k < 9; k++) { c[k] = f.v[k]; c[9 + k] = f.inv[k]; }
@@ -331,7 +421,9 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
         const int fn = (int)(unsigned)(key & 0xffffffffull);
         const float zp = ord2f((uint32_t)(key >> 32));
         Face f;
-        load_face(faces_b + (int64_t)fn * 9, f, is);
+        int vid[3] = {0, 0, 0};
+        fetch_verts<VC>(p, b, fn, f.v, vid);
+        face_inverse(f.v, f.inv, is);
         // barycentrics of the winner, recomputed with the arithmetic of cover()
         float w[3], zp2;
         bary(f, px, py, zp2, w);
@@ -349,16 +441,38 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
         if (p.alpha) p.alpha[ii] = 1.0f;
         if (p.rgb) {
             const int ts = p.ts;
-            const float* tex = p.textures + ((int64_t)b * p.F + fn) * ts * ts * ts * 3;
             float tif[3];
             tex_coords(w, zp, f.v, ts, p.eps, tif);
             float c[3] = {0.0f, 0.0f, 0.0f};
+            if (!VC) {
+                const float* tex = p.textures + ((int64_t)b * p.F + fn) * ts * ts * ts * 3;
 #pragma unroll
-            for (int pn = 0; pn < 8; pn++) {
-                float wg; int isc;
-                tex_tap(tif, pn, ts, wg, isc);
+                for (int pn = 0; pn < 8; pn++) {
+                    float wg; int isc;
+                    tex_tap(tif, pn, ts, wg, isc);
 #pragma unroll
-                for (int k = 0; k < 3; k++) c[k] += wg * tex[isc * 3 + k];
+                    for (int k = 0; k < 3; k++) c[k] += wg * tex[isc * 3 + k];
+                }
+            } else {
+                // the 2x2x2 vertex-colour texture of batch_vertex_textures, never materialised:
+                // texel (1,0,0) = colour of vertex 0, (0,1,0) = vertex 1, (0,0,1) = vertex 2, else 0;
+                // same 8-tap accumulation order as the texture path (bit-identical)
+                float vc[3][3];
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) vc[k][ch] = p.vcolors[((int64_t)b * p.V + vid[k]) * 3 + ch];
+#pragma unroll
+                for (int pn = 0; pn < 8; pn++) {
+                    float wg = 1.0f;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) wg *= ((pn >> k) & 1) ? (tif[k] - 0.0f) : (1.0f - (tif[k] - 0.0f));
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float tv = (pn == 1) ? vc[0][ch] : (pn == 2) ? vc[1][ch] : (pn == 4) ? vc[2][ch] : 0.0f;
+                        c[ch] += wg * tv;
+                    }
+                }
             }
             // rgb * mask + (1 - mask) * background with mask == 1 (rasterize.py:251-260)
             const float* bg = p.background + (int64_t)b * p.bg_stride;
@@ -473,14 +587,14 @@ static int launch_setup(const float* faces, void* workspace, float* faces_inv, i
     return MR_OK;
 }
 
-template <bool FUSED>
+template <bool FUSED, bool VC>
 static int launch_tiles(FwdParams& p, hipStream_t s) {
     p.tiles_x = (p.is + TILE_W - 1) / TILE_W;
     p.tiles_y = (p.is + TILE_H - 1) / TILE_H;
     const int64_t nblocks = (int64_t)p.B * p.tiles_x * p.tiles_y;
     if (nblocks == 0) return MR_OK;
     if (nblocks > 0x7fffffffLL) return MR_ERR_BADARG;
-    hipLaunchKernelGGL(raster_tile_kernel<FUSED>, dim3((unsigned)nblocks), dim3(TPB), 0, s, p);
+    hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC>), dim3((unsigned)nblocks), dim3(TPB), 0, s, p);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -520,7 +634,7 @@ extern "C" int mr_forward_face_index_map(const float* faces, int32_t* face_index
         p.weight = weight_map; p.face_inv_map = return_depth ? face_inv_map : nullptr;
         p.B = batch_size; p.F = num_faces; p.is = image_size; p.ts = 1;
         p.near_ = near_; p.far_ = far_; p.eps = 0.0f;
-        rc = launch_tiles<false>(p, s);
+        rc = launch_tiles<false, false>(p, s);
     }
     e = hipFreeAsync(work, s);
     if (rc == MR_OK && e != hipSuccess) rc = (int)e;
@@ -588,12 +702,12 @@ extern "C" int mr_render_forward(const float* faces, const float* textures, cons
                            batch_size, num_faces, image_size, near_, far_, keys);
         rc = (int)hipGetLastError();
         p.keys = keys;
-        if (rc == MR_OK) rc = launch_tiles<true>(p, s);
+        if (rc == MR_OK) rc = launch_tiles<true, false>(p, s);
         e = hipFreeAsync(keys, s);
         if (rc == MR_OK && e != hipSuccess) rc = (int)e;
         return rc;
     }
-    return launch_tiles<true>(p, s);
+    return launch_tiles<true, false>(p, s);
 }
 
 extern "C" int mr_face_inv_map(const float* faces, const int32_t* face_index_map, float* face_inv_map,
@@ -606,4 +720,43 @@ extern "C" int mr_face_inv_map(const float* faces, const int32_t* face_index_map
                        (hipStream_t)stream, faces, face_index_map, face_inv_map, npx, num_faces, image_size);
     MR_CHECK_LAUNCH();
     return MR_OK;
+}
+
+extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
+                                    const float* background, int bg_stride, float* rgb_img, float* alpha_img,
+                                    float* depth_img, int32_t* face_index_map, float* weight_map,
+                                    void* workspace, int64_t workspace_bytes, int batch_size, int num_verts,
+                                    int num_faces, int fill_back, int image_size, float near_, float far_,
+                                    float eps, int return_rgb, int return_alpha, int return_depth, int flags,
+                                    mr_stream_t stream) {
+    (void)flags;
+    const int F = fill_back ? 2 * num_faces : num_faces;
+    if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
+    if (((!verts || !faces_idx) && num_faces > 0) || !face_index_map || !weight_map || !workspace) return MR_ERR_BADARG;
+    if (return_rgb && (!rgb_img || (!vcolors && num_faces > 0) || !background || !(eps >= 1e-6f))) return MR_ERR_BADARG;
+    if (return_rgb && bg_stride != 0 && bg_stride != 3) return MR_ERR_BADARG;
+    if ((return_alpha && !alpha_img) || (return_depth && !depth_img)) return MR_ERR_BADARG;
+    if (workspace_bytes < mr_render_workspace_bytes(batch_size, F, image_size)) return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ImageHdr* hdrs = (ImageHdr*)workspace;
+    FaceRec* recs = (FaceRec*)((char*)workspace + hdr_bytes(batch_size));
+    hipError_t e = hipMemsetAsync(hdrs, 0, hdr_bytes(batch_size), s);
+    if (e != hipSuccess) return (int)e;
+    if (num_faces > 0) {
+        hipLaunchKernelGGL(face_setup_vc_kernel, dim3((unsigned)((num_faces + 255) / 256), (unsigned)batch_size),
+                           dim3(256), 0, s, verts, faces_idx, hdrs, recs, num_verts, num_faces, fill_back, image_size);
+        MR_CHECK_LAUNCH();
+    }
+    FwdParams p{};
+    p.hdrs = hdrs; p.recs = recs; p.background = background; p.bg_stride = bg_stride;
+    p.rgb = return_rgb ? rgb_img : nullptr;
+    p.alpha = return_alpha ? alpha_img : nullptr;
+    p.depth = return_depth ? depth_img : nullptr;
+    p.fim = face_index_map; p.weight = weight_map;
+    p.B = batch_size; p.F = F; p.is = image_size; p.ts = 2;
+    p.near_ = near_; p.far_ = far_; p.eps = eps;
+    p.verts = verts; p.fidx = faces_idx; p.vcolors = vcolors; p.V = num_verts; p.F0 = num_faces;
+    return launch_tiles<true, true>(p, s);
 }

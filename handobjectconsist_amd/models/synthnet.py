@@ -142,37 +142,47 @@ class SynthManoLayer(nn.Module):
         self.register_buffer("th_faces", torch.tensor(f[:1538], dtype=torch.long))
 
     def forward(self, th_pose_coeffs, th_betas=None, th_trans=None):
+        """Same contractions as manopth, arranged as a few dense GEMMs (rocBLAS /
+        MFMA) instead of many tiny batched ones: blend shapes as ONE [B,145] x [145,2334] product,
+        joints from pre-multiplied regressors, the kinematic chain level by level (3 batched
+        products instead of 15 sequential ones), skinning as one [778,16] x [16,B*16] product
+        and the final per-vertex 4x4 transform as a broadcast multiply-sum."""
         B = th_pose_coeffs.shape[0]
+        dev = th_pose_coeffs.device
         hand = th_pose_coeffs[:, 3:3 + self.ncomps] if self.use_pca else th_pose_coeffs[:, 3:]
         full_hand = hand.mm(self.th_comps[: self.ncomps]) if self.use_pca else hand
         full_pose = torch.cat([th_pose_coeffs[:, :3], self.th_hands_mean + full_hand], 1)
         rots = batch_rodrigues(full_pose.reshape(-1, 3)).view(B, 16, 3, 3)
-        root_rot = rots[:, 0]
-        pose_map = (rots[:, 1:] - torch.eye(3, device=rots.device)).reshape(B, 135)
+        pose_map = (rots[:, 1:] - torch.eye(3, device=dev)).reshape(B, 135)
         if th_betas is None:
             th_betas = th_pose_coeffs.new_zeros((B, 10))
-        v_shaped = torch.matmul(self.th_shapedirs, th_betas.t()).permute(2, 0, 1) + self.th_v_template
-        joints = torch.matmul(self.th_J_regressor, v_shaped)
-        v_posed = v_shaped + torch.matmul(self.th_posedirs, pose_map.t()).permute(2, 0, 1)
+        blend = torch.cat([self.th_shapedirs.reshape(2334, 10), self.th_posedirs.reshape(2334, 135)], 1)  # [2334,145]
+        v_posed = (torch.cat([th_betas, pose_map], 1) @ blend.t()).view(B, 778, 3) + self.th_v_template
+        js = torch.matmul(self.th_J_regressor, self.th_shapedirs.reshape(778, 30)).view(48, 10)  # J_reg @ shapedirs
+        jt = torch.matmul(self.th_J_regressor, self.th_v_template[0])                             # [16,3]
+        joints = (th_betas @ js.t()).view(B, 16, 3) + jt
 
-        def with_zeros(rot, tr):
+        def with_zeros(rot, tr):  # [..,3,3], [..,3] -> [..,4,4]
             top = torch.cat([rot, tr.unsqueeze(-1)], -1)
-            bottom = top.new_tensor([0.0, 0.0, 0.0, 1.0]).expand(top.shape[0], 1, 4)
-            return torch.cat([top, bottom], 1)
+            bottom = top.new_tensor([0.0, 0.0, 0.0, 1.0]).expand(*top.shape[:-2], 1, 4)
+            return torch.cat([top, bottom], -2)
 
-        results = [with_zeros(root_rot, joints[:, 0])]
-        for k in range(1, 16):
-            p = MANO_PARENTS[k]
-            rel = with_zeros(rots[:, k], joints[:, k] - joints[:, p])
-            results.append(torch.matmul(results[p], rel))
-        G = torch.stack(results, 1)  # [B,16,4,4]
+        parents = torch.tensor(MANO_PARENTS[1:], device=dev)
+        rel = with_zeros(rots[:, 1:], joints[:, 1:] - joints[:, parents])          # [B,15,4,4]
+        root = with_zeros(rots[:, 0], joints[:, 0])                                # [B,4,4]
+        lvl1, lvl2, lvl3 = [0, 3, 6, 9, 12], [1, 4, 7, 10, 13], [2, 5, 8, 11, 14]  # indices into rel (joint - 1)
+        g1 = torch.matmul(root.unsqueeze(1), rel[:, lvl1])
+        g2 = torch.matmul(g1, rel[:, lvl2])
+        g3 = torch.matmul(g2, rel[:, lvl3])
+        G = torch.empty((B, 16, 4, 4), device=dev, dtype=root.dtype)
+        G = torch.cat([root.unsqueeze(1), torch.stack([g1, g2, g3], 2).reshape(B, 15, 4, 4)], 1)  # joints 1..15 in order
         j_h = torch.cat([joints, joints.new_zeros((B, 16, 1))], 2).unsqueeze(-1)
         G2 = G - F.pad(torch.matmul(G, j_h), (3, 0))
-        T = torch.matmul(self.th_weights, G2.reshape(B, 16, 16)).view(B, 778, 4, 4)
-        v_h = torch.cat([v_posed, v_posed.new_ones((B, 778, 1))], 2).unsqueeze(-1)
-        verts = torch.matmul(T, v_h)[:, :, :3, 0]
+        T = (self.th_weights @ G2.permute(1, 0, 2, 3).reshape(16, B * 16)).view(778, B, 4, 4).permute(1, 0, 2, 3)
+        v_h = torch.cat([v_posed, v_posed.new_ones((B, 778, 1))], 2)
+        verts = (T[:, :, :3, :] * v_h.unsqueeze(2)).sum(-1)
         jtr = torch.cat([G[:, :, :3, 3], verts[:, MANO_TIPS]], 1)[:, MANO_REORDER]
-        if th_trans is None or bool(torch.norm(th_trans) == 0):
+        if th_trans is None:
             if self.center_idx is not None:
                 center = jtr[:, self.center_idx].unsqueeze(1)
                 jtr, verts = jtr - center, verts - center

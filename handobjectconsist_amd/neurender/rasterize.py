@@ -351,6 +351,105 @@ class RasterizeFusedFunction(Function):
         return grad_faces, grad_textures, None, None, None, None, None, None, None, None
 
 
+class RasterizeVertexColorFunction(Function):
+    """Render of per-vertex colours straight from (projected vertices, vertex indices, colours):
+    = batch_vertex_textures -> fill-back -> vertices_to_faces -> RasterizeFusedFunction, without
+    materialising the face coordinates, the 2x2x2 textures or their fill-back copies
+    (mr_render_vc_forward / mr_render_vc_backward).  Differentiable w.r.t. the colours only --
+    the vertex positions must be detached (the reference's training setting, detach_renders=True,
+    warpbranch.py:65-66)."""
+
+    @staticmethod
+    def forward(ctx, verts_ndc, faces_idx, vcolors, fill_back, image_size, near, far, eps, background_color,
+                return_rgb, return_alpha, return_depth):
+        _lib.check_cuda(verts_ndc, faces_idx, vcolors)
+        if not (float(eps) >= 1e-6):
+            raise ValueError("vertex-colour rendering needs eps >= 1e-6")
+        verts = _lib.contig(verts_ndc.detach())
+        fidx = faces_idx.detach().to(torch.int32).contiguous()
+        cols = _lib.contig(vcolors.detach())
+        dev = verts.device
+        B, V = verts.shape[:2]
+        F0 = fidx.shape[1]
+        if fidx.shape != (B, F0, 3) or cols.shape != (B, V, 3) or verts.shape != (B, V, 3):
+            raise ValueError("expected vertices [B,V,3], faces [B,F,3], vertex colours [B,V,3]")
+        is_ = int(image_size)
+        bg, bg_stride = _background_tensor(background_color, dev, B) if return_rgb else (None, 0)
+        empty = torch.empty
+        rgb = empty((B, 3, is_, is_), dtype=torch.float32, device=dev) if return_rgb else None
+        alpha = empty((B, is_, is_), dtype=torch.float32, device=dev) if return_alpha else None
+        depth = empty((B, is_, is_), dtype=torch.float32, device=dev) if return_depth else None
+        fim = empty((B, is_, is_), dtype=torch.int32, device=dev)
+        wmap = empty((B, is_, is_, 3), dtype=torch.float32, device=dev)
+        F = 2 * F0 if fill_back else F0
+        wbytes = _lib.load().mr_render_workspace_bytes(B, F, is_)
+        work = empty((max(int(wbytes), 8),), dtype=torch.uint8, device=dev)
+        _lib.call("mr_render_vc_forward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(cols), _lib.ptr(bg), bg_stride,
+                  _lib.ptr(rgb), _lib.ptr(alpha), _lib.ptr(depth), _lib.ptr(fim), _lib.ptr(wmap), _lib.ptr(work),
+                  int(wbytes), B, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps),
+                  int(return_rgb), int(return_alpha), int(return_depth), 0, _lib.stream_ptr(dev))
+        ctx.cfg = (is_, float(eps), bool(fill_back), bool(return_rgb))
+        ctx.save_for_backward(verts, fidx, fim)
+        ctx.mark_non_differentiable(fim, wmap)
+        e = torch.tensor([])
+        return (rgb if return_rgb else e, alpha if return_alpha else e, depth if return_depth else e, fim, wmap)
+
+    @staticmethod
+    def backward(ctx, grad_rgb, _ga, _gd, _gf, _gw):
+        verts, fidx, fim = ctx.saved_tensors
+        is_, eps, fill_back, rr = ctx.cfg
+        if not ctx.needs_input_grad[2] or not rr:
+            return (None,) * 12
+        B, V = verts.shape[:2]
+        grad_cols = torch.empty((B, V, 3), dtype=torch.float32, device=verts.device)
+        if grad_rgb is None:
+            grad_cols.zero_()
+        else:
+            g = _lib.contig(grad_rgb)
+            _lib.call("mr_render_vc_backward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(fim), _lib.ptr(g),
+                      _lib.ptr(grad_cols), B, V, int(fidx.shape[1]), int(fill_back), is_, eps, 0,
+                      _lib.stream_ptr(verts.device))
+        return (None, None, grad_cols) + (None,) * 9
+
+
+def rasterize_vertex_colors(
+    vertices_ndc,
+    faces_idx,
+    vertex_colors,
+    fill_back=True,
+    image_size=DEFAULT_IMAGE_SIZE,
+    anti_aliasing=DEFAULT_ANTI_ALIASING,
+    near=DEFAULT_NEAR,
+    far=DEFAULT_FAR,
+    eps=DEFAULT_EPS,
+    background_color=DEFAULT_BACKGROUND_COLOR,
+):
+    """rasterize_rgbad for vertex-colour textures: same returned dict as
+    ``rasterize_rgbad(vertices_to_faces(v, fill_back(faces)), fill_back(batch_vertex_textures(faces,
+    colours)), ...)`` (bit-identical images and maps), computed by the fused vertex-colour kernels."""
+    ras_size = image_size * 2 if anti_aliasing else image_size
+    if background_color is None:
+        background_color = DEFAULT_BACKGROUND_COLOR
+    rgb, alpha, depth, face_index_map, weight_map = RasterizeVertexColorFunction.apply(
+        vertices_ndc, faces_idx, vertex_colors, fill_back, ras_size, near, far, eps, background_color, True, True, True)
+    if anti_aliasing:
+        rgb = F.avg_pool2d(rgb, kernel_size=(2, 2))
+        alpha = F.avg_pool2d(alpha[:, None, :, :], kernel_size=(2, 2))[:, 0]
+        depth = F.avg_pool2d(depth[:, None, :, :], kernel_size=(2, 2))[:, 0]
+    ret = _RenderOutput({"rgb": rgb, "alpha": alpha, "depth": depth, "face_inv_map": None,
+                         "face_index_map": face_index_map, "weight_map": weight_map})
+    v_d, f_d = vertices_ndc.detach(), faces_idx.detach()
+
+    def thunk():
+        from handobjectconsist_amd.neurender import nr_ops
+
+        f_all = torch.cat((f_d, f_d.flip(-1)), dim=1) if fill_back else f_d
+        return face_inv_map_from(nr_ops.vertices_to_faces(v_d, f_all), face_index_map)
+
+    ret._thunk = thunk
+    return ret
+
+
 class _RenderOutput(dict):
     """The dict rasterize_rgbad returns.  ``face_inv_map`` ([B,is,is,3,3], 36 B/pixel, only
     ever consumed by the depth backward, which recomputes it) is materialised on first

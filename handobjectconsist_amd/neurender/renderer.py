@@ -211,6 +211,20 @@ class Renderer(nn.Module):
         )
         return images
 
+    def render_vertex_colors(self, vertices, faces, vertex_colors, K=None, R=None, t=None, dist_coeffs=None,
+                             orig_size=None):
+        """``render(vertices, faces, batch_vertex_textures(faces, vertex_colors), ...,
+        detach_renders=True)`` through the fused vertex-colour kernels: same dict, same values,
+        gradient w.r.t. ``vertex_colors`` only.  Used by opticalflow.get_opticalflow (the training
+        path renders exactly this: opticalflow.py:101-108 with detach_renders=True).  Not available
+        with lighting (``no_light=False``)."""
+        if not self.no_light:
+            raise ValueError("render_vertex_colors requires no_light=True")
+        v = self.project(vertices, K=K, R=R, t=t, dist_coeffs=dist_coeffs, orig_size=orig_size).detach()
+        return rasterize.rasterize_vertex_colors(
+            v, faces, vertex_colors, self.fill_back, self.image_size, self.anti_aliasing, self.near, self.far,
+            self.rasterizer_eps, self.background_color)
+
     def render(
         self,
         vertices,

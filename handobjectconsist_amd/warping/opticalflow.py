@@ -45,6 +45,24 @@ def get_opticalflows(
     return all_flows
 
 
+# Use the renderer's fused vertex-colour path when it has one and the positions are detached
+# (False: always build the face textures and call neurenderer(...) like the reference).
+USE_VERTEX_COLOR_RENDER = True
+
+
+def _render_flow(neurenderer, verts, faces, sample_flows, camintr, detach_textures, detach_renders):
+    """neurenderer(verts, faces, batch_vertex_textures(faces, sample_flows), K=..., detach_renders=...)
+    (opticalflow.py:103-108)."""
+    if (USE_VERTEX_COLOR_RENDER and detach_renders and hasattr(neurenderer, "render_vertex_colors")
+            and getattr(neurenderer, "no_light", False) and getattr(neurenderer, "camera_mode", "") == "projection"):
+        cols = sample_flows.detach() if detach_textures else sample_flows
+        return neurenderer.render_vertex_colors(verts, faces, cols, K=camintr)
+    all_textures = textutils.batch_vertex_textures(faces, sample_flows)
+    if detach_textures:
+        all_textures = all_textures.detach()
+    return neurenderer(verts, faces, all_textures, K=camintr, detach_renders=detach_renders)
+
+
 def _ignore_mask(face_index_map, ignore_face_idxs):
     """1 where the winning face is not in the ignore list, in IMAGE orientation
     (opticalflow.py:110-116: |fim - ids|.min != 0, then the manual vertical flip).  Done as a
@@ -89,11 +107,8 @@ def get_opticalflow(
     # forward optical flow
     verts_displ2d_12 = gt_locs2d_2 - gt_locs2d_1
     sample_flows = torch.cat([verts_displ2d_12, torch.ones_like(verts_displ2d_12[:, :, :1])], -1)
-    all_textures = textutils.batch_vertex_textures(faces, sample_flows)
-    if detach_textures:
-        all_textures = all_textures.detach()
-
-    renderout = neurenderer(verts_cam[0], faces, all_textures, K=camintrs[0], detach_renders=detach_renders)
+    renderout = _render_flow(neurenderer, verts_cam[0], faces, sample_flows, camintrs[0], detach_textures,
+                             detach_renders)
     mask_flow1 = (renderout["alpha"].unsqueeze(1) > 0.99999).float()
     if ignore_face_idxs is not None:
         mask_flow1 = mask_flow1 * _ignore_mask(renderout["face_index_map"], ignore_face_idxs)
@@ -102,9 +117,8 @@ def get_opticalflow(
     # backward optical flow
     verts_displ2d_21 = gt_locs2d_1 - gt_locs2d_2
     sample_flows = torch.cat([verts_displ2d_21, torch.ones_like(verts_displ2d_21[:, :, :1])], -1)
-    all_textures = textutils.batch_vertex_textures(faces, sample_flows)
-
-    renderout = neurenderer(verts_cam[1], faces, all_textures, K=camintrs[1], detach_renders=detach_renders)
+    # (the reference never detaches the second texture set, opticalflow.py:123)
+    renderout = _render_flow(neurenderer, verts_cam[1], faces, sample_flows, camintrs[1], False, detach_renders)
     mask_flow2 = (renderout["alpha"].unsqueeze(1) > 0.99999).float()
     if ignore_face_idxs is not None:
         mask_flow2 = mask_flow2 * _ignore_mask(renderout["face_index_map"], ignore_face_idxs)

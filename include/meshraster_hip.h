@@ -147,6 +147,32 @@ MR_API int mr_render_backward(const float* faces, const float* textures,
                        int return_rgb, int return_alpha, int return_depth, int flags,
                        mr_stream_t stream);
 
+/* Vertex-colour mode (SURVEY 8f "f1"): the render of opticalflow.get_opticalflow, where the
+ * face textures are the 2x2x2 vertex-colour textures of batch_vertex_textures
+ * (opticalflow.py:101-105) and fill-back doubles the faces (renderer.py:250-252).  Takes the
+ * projected vertices verts[B,V,3] (x,y NDC, z metric), the vertex indices faces_idx[B,F0,3]
+ * (int32) and the per-vertex colours vcolors[B,V,3] directly: neither the [B,F,3,3] face
+ * coordinates, nor the [B,F,2,2,2,3] textures, nor their fill-back copies ever exist in HBM.
+ * With fill_back, face index fn >= F0 denotes face fn - F0 with reversed vertex order.
+ * Outputs as mr_render_forward (face_index_map values in [0, 2 F0)); bit-identical to rendering
+ * the materialised textures.  workspace: mr_render_workspace_bytes(B, fill_back ? 2 F0 : F0, is). */
+MR_API int mr_render_vc_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
+                                const float* background, int bg_stride, float* rgb_img,
+                                float* alpha_img, float* depth_img, int32_t* face_index_map,
+                                float* weight_map, void* workspace, int64_t workspace_bytes,
+                                int batch_size, int num_verts, int num_faces, int fill_back,
+                                int image_size, float near_, float far_, float eps, int return_rgb,
+                                int return_alpha, int return_depth, int flags, mr_stream_t stream);
+
+/* Adjoint of the above w.r.t. vcolors (kernel E composed with the adjoints of
+ * batch_vertex_textures and of the fill-back concatenation): grad_vcolors[B,V,3] is zeroed
+ * here and accumulated with fp32 atomics (9 per live face). */
+MR_API int mr_render_vc_backward(const float* verts, const int32_t* faces_idx,
+                                 const int32_t* face_index_map, const float* grad_rgb_img,
+                                 float* grad_vcolors, int batch_size, int num_verts, int num_faces,
+                                 int fill_back, int image_size, float eps, int flags,
+                                 mr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * 3. Warping (meshreg/warping/imgflowarp.py)
  * ---------------------------------------------------------------------------------- */

@@ -219,3 +219,40 @@ def test_silhouette_config1(cuda):
     assert sil.shape == (1, 64, 64) and sil.sum() > 20
     assert_close(sil, ref["alpha"], 0, 1e-7, "silhouette")
     assert_close(dep, ref["depth"], 1e-6, 0, "depth")
+
+
+@pytest.mark.parametrize("fill_back,aa", [(True, False), (False, False), (True, True)])
+def test_vertex_color_render_matches_generic_path_and_oracle(cuda, fill_back, aa):
+    """Renderer.render_vertex_colors == Renderer.render(batch_vertex_textures(...), detach_renders=True):
+    identical images / maps, same gradient w.r.t. the vertex colours; and == the oracle chain."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.utils import textutils
+
+    B, is_ = 3, 96
+    s = synth.random_scene(B, seed=31, image_size=is_)
+    rng = np.random.default_rng(5)
+    cols_np = rng.uniform(-3, 3, (B, s["verts1"].shape[1], 3)).astype(np.float32)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=aa, fill_back=fill_back, near=0.1,
+                   no_light=True)
+    verts, fidx, K = t(s["verts1"], cuda), t(s["faces"], cuda), t(s["K1"], cuda)
+    c1 = t(cols_np, cuda).requires_grad_(True)
+    out_vc = ren.render_vertex_colors(verts, fidx, c1, K=K)
+    c2 = t(cols_np, cuda).requires_grad_(True)
+    out_gen = ren(verts, fidx, textutils.batch_vertex_textures(fidx, c2), K=K, detach_renders=True)
+    for k in ("rgb", "alpha", "depth", "weight_map", "face_inv_map"):
+        assert torch.equal(out_vc[k], out_gen[k]), k
+    assert torch.equal(out_vc["face_index_map"], out_gen["face_index_map"])
+    g = torch.randn_like(out_vc["rgb"])
+    out_vc["rgb"].backward(g)
+    out_gen["rgb"].backward(g)
+    assert_close(c1.grad.cpu().numpy(), c2.grad.cpu().numpy(), 1e-4, 1e-5 * float(c2.grad.abs().max()), "grad colours")
+    assert c2.grad.abs().max() > 0
+    # oracle chain
+    tex = R.batch_vertex_textures(s["faces"], cols_np)
+    ref = R.render(s["verts1"], s["faces"], tex, s["K1"], REN_KW["R"], REN_KW["t"], REN_KW["dist_coeffs"], is_, is_,
+                   anti_aliasing=aa, fill_back_=fill_back, near=0.1, far=100, eps=1e-3, num_threads=8)
+    assert (out_vc["face_index_map"].cpu().numpy() != ref["face_index_map"]).sum() == 0
+    # (vertices are projected by torch on the GPU here and by numpy in the oracle chain: the face
+    # coordinates differ in the last bit, hence 1e-4 of the colour range instead of 1e-6)
+    assert_close(out_vc["rgb"].detach().cpu().numpy(), ref["rgb"], 1e-4, 3e-4, "rgb vs oracle")

@@ -138,13 +138,15 @@ def test_pair_consist_large_matches_oracle(cuda):
         close(f21.grad.cpu().numpy(), ref_g[1], 1e-4, 1e-9, "grad_flow21")
 
 
-def test_opticalflow_chain_matches_oracle(cuda):
+@pytest.mark.parametrize("vertex_color_render", [True, False])
+def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, monkeypatch):
     """get_opticalflow (two renders + masks + occlusion + crop) and the pair loss on top of it,
     HIP path vs oracle chain, on the synthetic hand+object scene (non-square crop)."""
     from handobjectconsist_amd.neurender.renderer import Renderer
     from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
     from handobjectconsist_amd.warping import imgflowarp, opticalflow
 
+    monkeypatch.setattr(opticalflow, "USE_VERTEX_COLOR_RENDER", vertex_color_render)
     B, is_, H, Wd = 2, 128, 96, 128
     s = synth.random_scene(B, seed=21, image_size=is_)
     kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
