@@ -97,7 +97,7 @@ __device__ __forceinline__ void gather_pixel(const GatherParams& p, const Face& 
 // combined with two quad shuffles (fixed order: deterministic).  Faces whose bbox exceeds
 // GATHER_BIG pixels are walked by the whole wave instead.
 constexpr int GLPF = 4;
-constexpr int GATHER_BIG = 256;
+constexpr int GATHER_BIG = 128;
 
 template <bool TEX, bool DEPTH>
 __device__ __forceinline__ void gather_store(const GatherParams& p, int64_t i, const float* gt, const float* gf) {
@@ -227,6 +227,7 @@ struct GatherVCParams {
     float* grad_vcolors;    // [B,V,3], pre-zeroed, accumulated with fp32 atomics
     int B, V, F0, fill_back, is;
     float eps;
+    int dbg;  // profiling experiments (flags >> 8)
 };
 
 // contribution of one won pixel to the colours of the face's three vertices (its own order)
@@ -249,17 +250,37 @@ __device__ __forceinline__ void gather_vc_pixel(const GatherVCParams& p, const F
     }
 }
 
+// One lane per REAL face, 64 faces per wave, two passes (one per orientation; normally exactly
+// one of the two is front-facing).  Per pass, three lock-step stages mirror the forward kernel:
+//   P1 lane per face: orientation's vertices + inverse into an LDS face cache;
+//   P2 lane per face probes its bbox in face_index_map, 4 probes in flight per iteration, and
+//      appends the pixels it WON as fragments (slot, dx, dy) to an LDS ring (ballot compaction);
+//   P3 lane per fragment, 64 at a time: barycentrics, sampling weights, gradient of the three
+//      vertex colours, accumulated per face in LDS (ds_add_f32).
+// The per-face sums go to grad_vcolors with 9 global fp32 atomics per live face.
+constexpr int GV_SLOTS = MR_WAVE / GLPF;  // faces per wave
+constexpr int GV_FCS = 23;    // dwords per face-cache slot (odd stride)
+constexpr int GV_FQ = 1024;   // fragment ring capacity (>= 63 + 8 * 64, power of 2)
+
 template <int DUMMY>
 __global__ void __launch_bounds__(256) gather_vc_kernel(GatherVCParams p) {
+    __shared__ float fcache[4][GV_SLOTS * GV_FCS];
+    __shared__ float facc[4][GV_SLOTS * 9];
+    __shared__ unsigned fragq[4][GV_FQ];
+
     const int64_t total = (int64_t)p.B * p.F0;
     const int64_t gid = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const int64_t i = gid / GLPF;
-    const int sub = (int)(gid % GLPF);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % GLPF, slot_own = lane / GLPF;
     const bool valid = i < total;
     const int b = valid ? (int)(i / p.F0) : 0;
     const int f0 = valid ? (int)(i % p.F0) : 0;
     const int is = p.is;
+    float* fc = fcache[wave];
+    float* fa = facc[wave];
+    unsigned* fq = fragq[wave];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     int vid[3] = {0, 0, 0};
     float v[9];
@@ -279,93 +300,170 @@ __global__ void __launch_bounds__(256) gather_vc_kernel(GatherVCParams p) {
     for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int c = 0; c < 3; c++) acc[k][c] = 0.0f;
-
     const int32_t* fim_b = p.fim + (int64_t)b * is * is;
+    if (p.dbg & 8) {
+        if (valid && v[0] == 12345.0f) p.grad_vcolors[0] = v[1] + v[5];
+        return;
+    }
+
+    // P3: one lane per fragment
+    int qhead = 0, qn = 0;
+    auto shade = [&](int n) {
+        if (lane < n && !(p.dbg & 2)) {
+            const unsigned fr = fq[(qhead + lane) & (GV_FQ - 1)];
+            const int slot = (int)(fr >> 26);
+            const float* c = fc + slot * GV_FCS;
+            Face f;
 #pragma unroll
-    for (int o = 0; o < 2; o++) {
-        if (o == 1 && !p.fill_back) break;
+            for (int k = 0; k < 9; k++) f.inv[k] = c[9 + k];
+            f.v[2] = c[2]; f.v[5] = c[5]; f.v[8] = c[8];
+            const int xi = __float_as_int(c[18]) + (int)(fr & 0x1fffu), yi = __float_as_int(c[19]) + (int)((fr >> 13) & 0x1fffu);
+            const int bb = __float_as_int(c[20]);
+            float w[3], zp, tif[3], g[3];
+            bary(f, xi, yi, zp, w);
+            tex_coords(w, zp, f.v, 2, p.eps, tif);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) g[ch] = p.grad_rgb[idx3<true>(bb, yi, xi, ch, is)];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int pn = 1 << k;
+                float wg = 1.0f;
+#pragma unroll
+                for (int j = 0; j < 3; j++) wg *= ((pn >> j) & 1) ? (tif[j] - 0.0f) : (1.0f - (tif[j] - 0.0f));
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) atomicAdd(&fa[slot * 9 + k * 3 + ch], wg * g[ch]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // which orientations can be visible (normally exactly one: the front-facing one)
+    bool live[2];
+    {
+        float r[9];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { r[k] = v[6 + k]; r[3 + k] = v[3 + k]; r[6 + k] = v[k]; }
+        const FaceBox ba = face_box(v, is), bb2 = face_box(r, is);
+        live[0] = valid && ba.x0 <= ba.x1;
+        live[1] = valid && p.fill_back && bb2.x0 <= bb2.x1;
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 0: every face's first live orientation; pass 1: the second one where BOTH are live
+        // (zero-area faces only)
+        const int o = pass == 0 ? (live[0] ? 0 : 1) : 1;
+        const bool mine = pass == 0 ? (live[0] || live[1]) : (live[0] && live[1]);
         Face f;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int s = o ? 2 - k : k;
             f.v[3 * k] = v[3 * s]; f.v[3 * k + 1] = v[3 * s + 1]; f.v[3 * k + 2] = v[3 * s + 2];
         }
-        const FaceBox bx = face_box(f.v, is);
-        const bool nonempty = valid && bx.x0 <= bx.x1;
+        FaceBox bx = face_box(f.v, is);
+        if (!mine) { bx.x0 = 1; bx.x1 = 0; bx.y0 = 1; bx.y1 = 0; }
+        const bool nonempty = mine && bx.x0 <= bx.x1;
         const int bw = bx.x1 - bx.x0 + 1, bh = bx.y1 - bx.y0 + 1;
         const bool big = nonempty && bw * bh > GATHER_BIG;
         const int fn = o ? f0 + p.F0 : f0;
-        float part[3][3];  // [vertex in this orientation's order][channel]
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) part[k][c] = 0.0f;
-        if (nonempty && !big) {
-            face_inverse(f.v, f.inv, is);
-            for (int yi = bx.y0 + sub; yi <= bx.y1; yi += GLPF)
-                for (int xi = bx.x0; xi <= bx.x1; xi += 4) {
-                    int hit[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) hit[u] = fim_b[yi * is + min(xi + u, (int)bx.x1)];
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (xi + u <= bx.x1 && hit[u] == fn) gather_vc_pixel(p, f, b, xi + u, yi, part);
-                }
+        if (__ballot(nonempty) == 0ull) continue;  // wave-uniform
+        if (p.dbg & 16) {
+            if (nonempty && bw == 12345) p.grad_vcolors[0] = 1.0f;
+            continue;
         }
-        // very large faces: whole wave, lane per column, rows in groups of 8
-        unsigned long long m_big = __ballot(big && sub == 0);
+
+        // P1: park the orientation's face in the cache, clear its accumulators
+        if (sub == 0) {
+            float* c = fc + slot_own * GV_FCS;
+            if (nonempty) {
+                face_inverse(f.v, f.inv, is);
+#pragma unroll
+                for (int k = 0; k < 9; k++) { c[k] = f.v[k]; c[9 + k] = f.inv[k]; }
+                c[18] = __int_as_float((int)bx.x0); c[19] = __int_as_float((int)bx.y0); c[20] = __int_as_float(b);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) fa[slot_own * 9 + k] = 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // P2 (large faces): the whole wave probes the bbox, lane per column, rows in groups of 8;
+        // won pixels join the same fragment ring
+        unsigned long long m_big = (p.dbg & 4) ? 0ull : __ballot(big && sub == 0);
         while (m_big) {
             const int src = __ffsll((long long)m_big) - 1;
             m_big &= m_big - 1;
-            Face fb;
-#pragma unroll
-            for (int k = 0; k < 9; k++) fb.v[k] = __shfl(f.v[k], src);
-            face_inverse(fb.v, fb.inv, is);
             const int x0 = __shfl((int)bx.x0, src), y0 = __shfl((int)bx.y0, src);
             const int w_ = __shfl(bw, src), h_ = __shfl(bh, src);
-            const int bb = __shfl(b, src), ff = __shfl(fn, src);
-            const int32_t* fim_s = p.fim + (int64_t)bb * is * is;
-            float pb[3][3];
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) pb[k][c] = 0.0f;
-            for (int cx = lane; cx < w_; cx += MR_WAVE) {
-                const int xi = x0 + cx;
+            const int ff = __shfl(fn, src);
+            const int32_t* fim_s = p.fim + (int64_t)__shfl(b, src) * is * is;  // the wave may straddle two images
+            for (int cx0 = 0; cx0 < w_; cx0 += MR_WAVE) {
+                const int cx = cx0 + lane;
+                const bool col = cx < w_;
                 for (int r = 0; r < h_; r += 8) {
                     int hit[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) hit[u] = fim_s[min(y0 + r + u, y0 + h_ - 1) * is + xi];
-#pragma unroll
                     for (int u = 0; u < 8; u++)
-                        if (r + u < h_ && hit[u] == ff) gather_vc_pixel(p, fb, bb, xi, y0 + r + u, pb);
+                        hit[u] = col ? fim_s[min(y0 + r + u, y0 + h_ - 1) * is + x0 + cx] : -2;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const bool won = col && r + u < h_ && hit[u] == ff;
+                        const unsigned long long m = __ballot(won);
+                        if (won)
+                            fq[(qhead + qn + __popcll(m & lt_mask)) & (GV_FQ - 1)] =
+                                ((unsigned)(src / GLPF) << 26) | ((unsigned)(r + u) << 13) | (unsigned)cx;
+                        qn += __popcll(m);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    while (qn >= MR_WAVE) {
+                        shade(MR_WAVE);
+                        qhead = (qhead + MR_WAVE) & (GV_FQ - 1);
+                        qn -= MR_WAVE;
+                    }
                 }
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1)
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) pb[k][c] += __shfl_xor(pb[k][c], off);
-            if (lane == src)
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) part[k][c] += pb[k][c];
         }
-        // map this orientation's vertex order back to the real vertices
+
+        // P2: GLPF lanes per face (rows sub, sub + GLPF, ...), 8 probes per iteration, lock step
+        bool act = nonempty && !big && !(p.dbg & 4);
+        int px = bx.x0, py = bx.y0 + sub;
+        act = act && py <= bx.y1;
+        while (__ballot(act) != 0ull) {
+            int hit[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) hit[u] = act ? fim_b[py * is + min(px + u, (int)bx.x1)] : -2;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool won = act && px + u <= bx.x1 && hit[u] == fn;
+                const unsigned long long m = __ballot(won);
+                if (won)
+                    fq[(qhead + qn + __popcll(m & lt_mask)) & (GV_FQ - 1)] =
+                        ((unsigned)slot_own << 26) | ((unsigned)(py - bx.y0) << 13) | (unsigned)(px + u - bx.x0);
+                qn += __popcll(m);
+            }
+            if (act) {
+                px += 8;
+                if (px > bx.x1) { px = bx.x0; py += GLPF; }
+                act = py <= bx.y1;
+            }
+            __builtin_amdgcn_wave_barrier();
+            while (qn >= MR_WAVE) {
+                shade(MR_WAVE);
+                qhead = (qhead + MR_WAVE) & (GV_FQ - 1);
+                qn -= MR_WAVE;
+            }
+        }
+        if (qn > 0) {
+            shade(qn);
+            qhead = (qhead + qn) & (GV_FQ - 1);
+            qn = 0;
+        }
+        // collect this orientation's sums, mapped back to the real vertex order
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) acc[o ? 2 - k : k][c] += part[k][c];
+            for (int c = 0; c < 3; c++) acc[o ? 2 - k : k][c] += fa[slot_own * 9 + k * 3 + c];
+        __builtin_amdgcn_wave_barrier();
     }
-#pragma unroll
-    for (int off = 1; off < GLPF; off <<= 1)
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) acc[k][c] += __shfl_xor(acc[k][c], off);
-    if (valid && sub == 0) {
+    if (valid && sub == 0 && !(p.dbg & 1)) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             float* o = p.grad_vcolors + ((int64_t)b * p.V + vid[k]) * 3;
@@ -759,7 +857,8 @@ extern "C" int mr_render_vc_backward(const float* verts, const int32_t* faces_id
     if (e != hipSuccess) return (int)e;
     if (num_faces == 0) return MR_OK;
     if (!verts || !faces_idx || !face_index_map || !grad_rgb_img || !(eps >= 1e-6f)) return MR_ERR_BADARG;
+    if (image_size > 8192) return MR_ERR_BADARG;  // fragment encoding: 13 bits per bbox offset
     GatherVCParams g{verts, faces_idx, face_index_map, grad_rgb_img, grad_vcolors, batch_size, num_verts, num_faces,
-                     fill_back, image_size, eps};
+                     fill_back, image_size, eps, flags >> 8};
     return launch1d(gather_vc_kernel<0>, (int64_t)batch_size * num_faces * GLPF, s, g);
 }

@@ -362,31 +362,37 @@ __device__ __forceinline__ DirOut pair_dir(const float* __restrict__ flow, const
     return o;
 }
 
-// 32 x 8 pixel tiles; logical tile id -> (sample, tile) with the XCD-aware remap so that
+// 64 x 4 pixel tiles (one 256-B row per wave); logical tile id -> (sample, tile) with the XCD-aware remap so that
 // vertically adjacent tiles (which share bilinear taps) run behind the same L2.
-constexpr int PT_W = 32, PT_H = 8;
+constexpr int PT_W = 64, PT_H = 4;
 __device__ __forceinline__ bool pair_tile_pixel(int H, int W, int tiles_x, int ntiles, int& b, int& tile, int& xx,
                                                 int& yy) {
     const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
     b = lid / ntiles;
     tile = lid % ntiles;
-    xx = (tile % tiles_x) * PT_W + (threadIdx.x & (PT_W - 1));
-    yy = (tile / tiles_x) * PT_H + (threadIdx.x >> 5);
+    xx = (tile % tiles_x) * PT_W + (threadIdx.x % PT_W);
+    yy = (tile / tiles_x) * PT_H + (threadIdx.x / PT_W);
     return xx < W && yy < H;
 }
 
-__device__ __forceinline__ float block_sum(float v, float* red) {
+// block-wide sums of four values with ONE barrier: wave butterflies, 4 x 4 partials in LDS,
+// every thread adds the four wave partials in wave order (fixed order: deterministic)
+__device__ __forceinline__ void block_sum4(float* v, float (*red)[4]) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] += __shfl_xor(v[k], off);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 4; k++) red[wave][k] = v[k];
     __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
 }
 
 __global__ void __launch_bounds__(256) pair_consist_forward_kernel(PairParams p) {
-    __shared__ float red[4];
+    __shared__ float red[4][4];
     const int64_t hw = (int64_t)p.H * p.W;
     int b, tile, xx, yy;
     const bool in_img = pair_tile_pixel(p.H, p.W, p.tiles_x, p.nblk, b, tile, xx, yy);
@@ -421,11 +427,11 @@ __global__ void __launch_bounds__(256) pair_consist_forward_kernel(PairParams p)
         if (p.full_mask1) p.full_mask1[(int64_t)b * hw + pix] = d1.valid ? 1 : 0;
         if (p.full_mask2) p.full_mask2[(int64_t)b * hw + pix] = d2.valid ? 1 : 0;
     }
-    const float s1 = block_sum(sum1, red), c1 = block_sum(cnt1, red);
-    const float s2 = block_sum(sum2, red), c2 = block_sum(cnt2, red);
+    float v[4] = {sum1, cnt1, sum2, cnt2};
+    block_sum4(v, red);
     if (threadIdx.x == 0) {
         float* o = p.partial + ((int64_t)b * p.nblk + tile) * 4;
-        o[0] = s1; o[1] = c1; o[2] = s2; o[3] = c2;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
     }
 }
 
