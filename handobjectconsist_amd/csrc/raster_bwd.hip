@@ -250,11 +250,13 @@ __device__ __forceinline__ void gather_vc_pixel(const GatherVCParams& p, const F
     }
 }
 
-// One lane per REAL face, 64 faces per wave, two passes (one per orientation; normally exactly
-// one of the two is front-facing).  Per pass, three lock-step stages mirror the forward kernel:
-//   P1 lane per face: orientation's vertices + inverse into an LDS face cache;
-//   P2 lane per face probes its bbox in face_index_map, 4 probes in flight per iteration, and
-//      appends the pixels it WON as fragments (slot, dx, dy) to an LDS ring (ballot compaction);
+// GLPF lanes per REAL face, 16 faces per wave.  Pass 0 handles every face's visible orientation
+// (normally exactly one of the two fill-back orientations is front-facing), pass 1 the second
+// orientation of zero-area faces.  Per pass, three lock-step stages mirror the forward kernel:
+//   P1 one lane of the quad: orientation's vertices + inverse into an LDS face cache;
+//   P2 the quad probes the face's bbox in face_index_map (lane k: rows k, k+4, ...; 8 probes in
+//      flight per iteration) and appends the pixels the face WON as fragments (slot, dx, dy) to
+//      an LDS ring (ballot compaction); faces with a large bbox are probed by the whole wave;
 //   P3 lane per fragment, 64 at a time: barycentrics, sampling weights, gradient of the three
 //      vertex colours, accumulated per face in LDS (ds_add_f32).
 // The per-face sums go to grad_vcolors with 9 global fp32 atomics per live face.
