@@ -159,8 +159,8 @@ def kernel_bench(dev, B, is_, iters):
     o1, o2 = torch.empty((B, is_, is_), **f32), torch.empty((B, is_, is_), **f32)
 
     def occlusion():
-        _lib.call("mr_occlusion_mask", P(m1), P(m2), P(rgb), P(rgb), 3 * is_ * is_, P(o1), P(o2), B, is_, is_, 0.03,
-                  0.99999, st)
+        _lib.call("mr_occlusion_mask", P(m1), P(m2), P(rgb), P(rgb), 3 * is_ * is_, None, None, P(o1), P(o2), B, is_,
+                  is_, 0.03, 0.99999, st)
 
     render_fwd()
     BF = B * F

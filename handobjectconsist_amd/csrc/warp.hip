@@ -236,13 +236,16 @@ __global__ void __launch_bounds__(256) warp_backward_kernel(const float* __restr
 //   occl_a = occlusion_mask_from_warped_grid(grid_a, warp_aba)           (:145)
 __device__ __forceinline__ float occl_one(const float* __restrict__ mask_a, const float* __restrict__ mask_b,
                                           const float* __restrict__ flow_ab,
-                                          const float* __restrict__ flow_ba, int64_t hw, int H, int W,
+                                          const float* __restrict__ flow_ba, const float* __restrict__ scale_ab,
+                                          const float* __restrict__ scale_ba, int64_t hw, int H, int W,
                                           int xx, int yy, float dist_thresh, float wthresh) {
     const int64_t pix = (int64_t)yy * W + xx;
     const float ma_p = mask_a[pix];
-    // second warp: sample warp_ab at p + flow_ab(p)
+    // second warp: sample warp_ab at p + flow_ab(p)   (flow = raw flow * scale when a scale map is given)
     float ix, iy;
-    sample_pos((float)xx, (float)yy, flow_ab[pix], flow_ab[hw + pix], W, H, ix, iy);
+    const float sa = scale_ab ? scale_ab[pix] : 1.0f;
+    sample_pos((float)xx, (float)yy, scale_ab ? flow_ab[pix] * sa : flow_ab[pix],
+               scale_ab ? flow_ab[hw + pix] * sa : flow_ab[hw + pix], W, H, ix, iy);
     int qx, qy;
     nearest_idx(ix, iy, qx, qy);
     float wg[3] = {0.0f, 0.0f, 0.0f};  // channels x, y, mask of warp_ab at q
@@ -252,7 +255,9 @@ __device__ __forceinline__ float occl_one(const float* __restrict__ mask_a, cons
         const int64_t qpix = (int64_t)qy * W + qx;
         // first warp: sample grid_a at q + flow_ba(q)
         float jx, jy;
-        sample_pos((float)qx, (float)qy, flow_ba[qpix], flow_ba[hw + qpix], W, H, jx, jy);
+        const float sb = scale_ba ? scale_ba[qpix] : 1.0f;
+        sample_pos((float)qx, (float)qy, scale_ba ? flow_ba[qpix] * sb : flow_ba[qpix],
+                   scale_ba ? flow_ba[hw + qpix] * sb : flow_ba[hw + qpix], W, H, jx, jy);
         int rx, ry;
         nearest_idx(jx, jy, rx, ry);
         float m1 = inb(rx, ry, W, H) ? 1.0f : 0.0f;
@@ -280,6 +285,8 @@ __global__ void __launch_bounds__(256) occlusion_kernel(const float* __restrict_
                                                         const float* __restrict__ mask2,
                                                         const float* __restrict__ flow12,
                                                         const float* __restrict__ flow21, int64_t fbstride,
+                                                        const float* __restrict__ scale12,
+                                                        const float* __restrict__ scale21,
                                                         float* __restrict__ occl1, float* __restrict__ occl2,
                                                         int B, int H, int W, float dist_thresh, float wthresh) {
     const int64_t hw = (int64_t)H * W;
@@ -292,8 +299,70 @@ __global__ void __launch_bounds__(256) occlusion_kernel(const float* __restrict_
     const float* m2 = mask2 + (int64_t)b * hw;
     const float* f12 = flow12 + (int64_t)b * fbstride;
     const float* f21 = flow21 + (int64_t)b * fbstride;
-    occl1[i] = occl_one(m1, m2, f12, f21, hw, H, W, xx, yy, dist_thresh, wthresh);
-    occl2[i] = occl_one(m2, m1, f21, f12, hw, H, W, xx, yy, dist_thresh, wthresh);
+    const float* s12 = scale12 ? scale12 + (int64_t)b * hw : nullptr;
+    const float* s21 = scale21 ? scale21 + (int64_t)b * hw : nullptr;
+    occl1[i] = occl_one(m1, m2, f12, f21, s12, s21, hw, H, W, xx, yy, dist_thresh, wthresh);
+    occl2[i] = occl_one(m2, m1, f21, f12, s21, s12, hw, H, W, xx, yy, dist_thresh, wthresh);
+}
+
+// ---------------------------------------------------------------------------------------
+// flow epilogue of opticalflow.get_opticalflow (opticalflow.py:109-154)
+// ---------------------------------------------------------------------------------------
+// mask[b, yi_img, x] = (alpha > thresh) * keep(face_index_map[b, is - 1 - yi_img, x])
+// keep(f) = lut[f + 1] for f + 1 < n_lut, else 1 (lut[0] is the background slot)
+__global__ void __launch_bounds__(256) flow_mask_kernel(const float* __restrict__ alpha,
+                                                        const int32_t* __restrict__ fim,
+                                                        const float* __restrict__ lut, int n_lut, float thresh,
+                                                        float* __restrict__ mask, int64_t npx, int is) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    float m = (alpha[i] > thresh) ? 1.0f : 0.0f;
+    if (lut) {
+        const int64_t plane = (int64_t)is * is;
+        const int64_t b = i / plane;
+        const int pix = (int)(i % plane);
+        const int yi = pix / is, xi = pix % is;
+        const int f = fim[b * plane + (int64_t)(is - 1 - yi) * is + xi] + 1;
+        m = m * ((f >= 0 && f < n_lut) ? lut[f] : 1.0f);
+    }
+    mask[i] = m;
+}
+
+// flow[b, y, x, c] = (rgb[b, c, y, x] * m_pre) * (m_x * occl), c = 0, 1, cropped to H x W
+__global__ void __launch_bounds__(256) flow_finalize_forward_kernel(
+    const float* __restrict__ rgb, const float* __restrict__ m_pre, const float* __restrict__ m_x,
+    const float* __restrict__ occl, float* __restrict__ flow, int B, int is, int H, int W) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * H * W) return;
+    const int b = (int)(i / ((int64_t)H * W));
+    const int pix = (int)(i % ((int64_t)H * W));
+    const int y = pix / W, x = pix % W;
+    const int64_t plane = (int64_t)is * is, o = (int64_t)b * plane + (int64_t)y * is + x;
+    const float a = m_pre[o], post = m_x[o] * occl[o];
+    const float r0 = rgb[(int64_t)b * 3 * plane + (int64_t)y * is + x], r1 = rgb[((int64_t)b * 3 + 1) * plane + (int64_t)y * is + x];
+    *reinterpret_cast<float2*>(flow + i * 2) = make_float2((r0 * a) * post, (r1 * a) * post);
+}
+
+// grad_rgb[b, c, y, x] = grad_flow[b, y, x, c] * post * m_pre inside the crop, 0 elsewhere / for c = 2
+__global__ void __launch_bounds__(256) flow_finalize_backward_kernel(
+    const float* __restrict__ grad_flow, const float* __restrict__ m_pre, const float* __restrict__ m_x,
+    const float* __restrict__ occl, float* __restrict__ grad_rgb, int B, int is, int H, int W) {
+    const int64_t plane = (int64_t)is * is;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * plane) return;
+    const int64_t b = i / plane;
+    const int pix = (int)(i % plane);
+    const int y = pix / is, x = pix % is;
+    float g0 = 0.0f, g1 = 0.0f;
+    if (y < H && x < W) {
+        const float a = m_pre[i], post = m_x[i] * occl[i];
+        const float2 g = *reinterpret_cast<const float2*>(grad_flow + ((b * H + y) * (int64_t)W + x) * 2);
+        g0 = (g.x * post) * a;
+        g1 = (g.y * post) * a;
+    }
+    grad_rgb[b * 3 * plane + pix] = g0;
+    grad_rgb[(b * 3 + 1) * plane + pix] = g1;
+    grad_rgb[(b * 3 + 2) * plane + pix] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -561,16 +630,17 @@ extern "C" int mr_warp_backward(const float* x, const float* flow, const float* 
 }
 
 extern "C" int mr_occlusion_mask(const float* mask_flow1, const float* mask_flow2, const float* flow12,
-                                 const float* flow21, int64_t flow_bstride, float* occl1, float* occl2,
-                                 int batch_size, int height, int width, float distance_thresh,
-                                 float warp_thresh, mr_stream_t stream) {
+                                 const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                                 const float* flow21_scale, float* occl1, float* occl2, int batch_size,
+                                 int height, int width, float distance_thresh, float warp_thresh,
+                                 mr_stream_t stream) {
     if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2) return MR_ERR_BADARG;
     if (batch_size < 0 || height <= 0 || width <= 0 || flow_bstride < 2LL * height * width) return MR_ERR_BADARG;
     const int64_t n = (int64_t)batch_size * height * width;
     if (n == 0) return MR_OK;
     hipLaunchKernelGGL(occlusion_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, mask_flow1,
-                       mask_flow2, flow12, flow21, flow_bstride, occl1, occl2, batch_size, height, width,
-                       distance_thresh, warp_thresh);
+                       mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2, batch_size,
+                       height, width, distance_thresh, warp_thresh);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -643,4 +713,44 @@ extern "C" int mr_device_ok(void) {
     if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
     const char* a = prop.gcnArchName;
     return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+}
+
+extern "C" int mr_flow_mask(const float* alpha_img, const int32_t* face_index_map, const float* keep_lut, int n_lut,
+                            float thresh, float* mask, int batch_size, int image_size, mr_stream_t stream) {
+    if (!alpha_img || !mask || batch_size < 0 || image_size <= 0) return MR_ERR_BADARG;
+    if (keep_lut && (!face_index_map || n_lut <= 0)) return MR_ERR_BADARG;
+    const int64_t n = (int64_t)batch_size * image_size * image_size;
+    if (n == 0) return MR_OK;
+    hipLaunchKernelGGL(flow_mask_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, alpha_img,
+                       face_index_map, keep_lut, n_lut, thresh, mask, n, image_size);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_flow_finalize_forward(const float* rgb_img, const float* mask_pre, const float* mask_x,
+                                        const float* occl, float* flow, int batch_size, int image_size, int height,
+                                        int width, mr_stream_t stream) {
+    if (!rgb_img || !mask_pre || !mask_x || !occl || !flow) return MR_ERR_BADARG;
+    if (batch_size < 0 || image_size <= 0 || height <= 0 || width <= 0 || height > image_size || width > image_size)
+        return MR_ERR_BADARG;
+    const int64_t n = (int64_t)batch_size * height * width;
+    if (n == 0) return MR_OK;
+    hipLaunchKernelGGL(flow_finalize_forward_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, rgb_img,
+                       mask_pre, mask_x, occl, flow, batch_size, image_size, height, width);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_flow_finalize_backward(const float* grad_flow, const float* mask_pre, const float* mask_x,
+                                         const float* occl, float* grad_rgb_img, int batch_size, int image_size,
+                                         int height, int width, mr_stream_t stream) {
+    if (!grad_flow || !mask_pre || !mask_x || !occl || !grad_rgb_img) return MR_ERR_BADARG;
+    if (batch_size < 0 || image_size <= 0 || height <= 0 || width <= 0 || height > image_size || width > image_size)
+        return MR_ERR_BADARG;
+    const int64_t n = (int64_t)batch_size * image_size * image_size;
+    if (n == 0) return MR_OK;
+    hipLaunchKernelGGL(flow_finalize_backward_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       grad_flow, mask_pre, mask_x, occl, grad_rgb_img, batch_size, image_size, height, width);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
 }

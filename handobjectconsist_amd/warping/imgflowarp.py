@@ -262,7 +262,7 @@ def get_occlusion_mask(mask_flow1, mask_flow2, flow12, flow21):
     occl1 = torch.empty((B, H, W), dtype=torch.float32, device=m1.device)
     occl2 = torch.empty((B, H, W), dtype=torch.float32, device=m1.device)
     _lib.call("mr_occlusion_mask", _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(f12), _lib.ptr(f21),
-              int(f12.shape[1]) * H * W, _lib.ptr(occl1), _lib.ptr(occl2), B, H, W, 0.03, 0.99999,
+              int(f12.shape[1]) * H * W, None, None, _lib.ptr(occl1), _lib.ptr(occl2), B, H, W, 0.03, 0.99999,
               _lib.stream_ptr(m1.device))
     return occl1, occl2
 

@@ -11,8 +11,14 @@ from typing import List
 
 import torch
 
+from handobjectconsist_amd import _lib
 from handobjectconsist_amd.utils import project, textutils
 from handobjectconsist_amd.warping import imgflowarp
+
+# Fuse the mask algebra / crop / permute that follows the two renders (opticalflow.py:109-154) into
+# three small kernels (mr_flow_mask, mr_occlusion_mask with on-the-fly masked flows,
+# mr_flow_finalize_*).  False: the reference's op-by-op structure on torch tensors (same values).
+USE_FUSED_EPILOGUE = True
 
 
 def get_opticalflows(
@@ -63,22 +69,87 @@ def _render_flow(neurenderer, verts, faces, sample_flows, camintr, detach_textur
     return neurenderer(verts, faces, all_textures, K=camintr, detach_renders=detach_renders)
 
 
+def _keep_lut(ignore_face_idxs, device):
+    """float table over face index + 1 (slot 0 = background): 0 for ignored faces, 1 otherwise."""
+    key = (tuple(int(i) for i in ignore_face_idxs), str(device))
+    lut = _LUT_CACHE.get(key)
+    if lut is None:
+        ids = torch.as_tensor(list(ignore_face_idxs), dtype=torch.long, device=device)
+        n = int(max(int(ids.max().item()) + 2, 2)) if ids.numel() else 2
+        lut = torch.ones(n, dtype=torch.float32, device=device)
+        if ids.numel():
+            lut[ids[ids >= 0] + 1] = 0.0
+        _LUT_CACHE[key] = lut
+    return lut
+
+
 def _ignore_mask(face_index_map, ignore_face_idxs):
     """1 where the winning face is not in the ignore list, in IMAGE orientation
     (opticalflow.py:110-116: |fim - ids|.min != 0, then the manual vertical flip).  Done as a
     table lookup over face indices instead of materialising the [B, is, is, 14] difference."""
-    ids = torch.as_tensor(ignore_face_idxs, dtype=torch.long, device=face_index_map.device)
-    n = int(max(int(ids.max().item()) + 2, 2)) if ids.numel() else 2
-    key = (tuple(int(i) for i in ignore_face_idxs), str(face_index_map.device))
-    lut = _LUT_CACHE.get(key)
-    if lut is None:
-        lut = torch.ones(n, dtype=torch.float32, device=face_index_map.device)
-        lut[ids[ids >= 0] + 1] = 0.0  # slot 0 = background (-1)
-        _LUT_CACHE[key] = lut
+    lut = _keep_lut(ignore_face_idxs, face_index_map.device)
     idx = (face_index_map.long() + 1).clamp_(max=lut.numel() - 1)
     hi = face_index_map >= (lut.numel() - 1)  # faces beyond the table are never ignored
     keep = torch.where(hi, torch.ones((), device=lut.device), lut[idx])
     return keep.flip(1).unsqueeze(1)
+
+
+def _flow_mask(renderout, ignore_face_idxs):
+    """(alpha > 0.99999) * ignore-mask as one kernel -> [B, is, is] (opticalflow.py:109-117)."""
+    alpha = _lib.contig(renderout["alpha"].detach())
+    fim = renderout["face_index_map"]
+    B, is_ = alpha.shape[0], alpha.shape[1]
+    lut = _keep_lut(ignore_face_idxs, alpha.device) if ignore_face_idxs is not None else None
+    mask = torch.empty_like(alpha)
+    _lib.call("mr_flow_mask", _lib.ptr(alpha), _lib.ptr(fim), _lib.ptr(lut), int(lut.numel()) if lut is not None else 0,
+              0.99999, _lib.ptr(mask), B, is_, _lib.stream_ptr(alpha.device))
+    return mask, alpha
+
+
+class _FlowFinalize(torch.autograd.Function):
+    """flow[B,H,W,2] = ((rgb * mask_pre) * (mask_x * occl))[:, :2] permuted + cropped
+    (opticalflow.py:118, 146-154); differentiable w.r.t. rgb only (the masks carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, rgb, mask_pre, mask_x, occl, height, width):
+        rgb_c = _lib.contig(rgb)
+        B, _, is_, _ = rgb_c.shape
+        flow = torch.empty((B, height, width, 2), dtype=torch.float32, device=rgb_c.device)
+        _lib.call("mr_flow_finalize_forward", _lib.ptr(rgb_c), _lib.ptr(mask_pre), _lib.ptr(mask_x), _lib.ptr(occl),
+                  _lib.ptr(flow), B, is_, height, width, _lib.stream_ptr(rgb_c.device))
+        ctx.save_for_backward(mask_pre, mask_x, occl)
+        ctx.dims = (B, is_, height, width)
+        return flow
+
+    @staticmethod
+    def backward(ctx, grad_flow):
+        mask_pre, mask_x, occl = ctx.saved_tensors
+        B, is_, height, width = ctx.dims
+        g = _lib.contig(grad_flow)
+        grad_rgb = torch.empty((B, 3, is_, is_), dtype=torch.float32, device=g.device)
+        _lib.call("mr_flow_finalize_backward", _lib.ptr(g), _lib.ptr(mask_pre), _lib.ptr(mask_x), _lib.ptr(occl),
+                  _lib.ptr(grad_rgb), B, is_, height, width, _lib.stream_ptr(g.device))
+        return grad_rgb, None, None, None, None, None
+
+
+def _fused_epilogue(ro1, ro2, orig_img_size, ignore_face_idxs):
+    """opticalflow.py:109-154 for mask_occlusions=True on the outputs of the two renders."""
+    with torch.no_grad():
+        m1, _alpha1 = _flow_mask(ro1, ignore_face_idxs)
+        m2, alpha2 = _flow_mask(ro2, ignore_face_idxs)
+        rgb1, rgb2 = _lib.contig(ro1["rgb"].detach()), _lib.contig(ro2["rgb"].detach())
+        B, _, is_, _ = rgb1.shape
+        occl1 = torch.empty((B, is_, is_), dtype=torch.float32, device=rgb1.device)
+        occl2 = torch.empty_like(occl1)
+        # mask_flow2 is the RAW alpha inside the occlusion block (Q4); flows are rgb * mask, on the fly
+        _lib.call("mr_occlusion_mask", _lib.ptr(m1), _lib.ptr(alpha2), _lib.ptr(rgb1), _lib.ptr(rgb2), 3 * is_ * is_,
+                  _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(occl1), _lib.ptr(occl2), B, is_, is_, 0.03, 0.99999,
+                  _lib.stream_ptr(rgb1.device))
+    W, H = (orig_img_size[0], orig_img_size[1]) if orig_img_size is not None else (is_, is_)
+    W, H = min(int(W), is_), min(int(H), is_)
+    flow12 = _FlowFinalize.apply(ro1["rgb"], m1, m1, occl1, H, W)
+    flow21 = _FlowFinalize.apply(ro2["rgb"], m2, alpha2, occl2, H, W)
+    return [flow12, flow21]
 
 
 _LUT_CACHE = {}
@@ -109,6 +180,13 @@ def get_opticalflow(
     sample_flows = torch.cat([verts_displ2d_12, torch.ones_like(verts_displ2d_12[:, :, :1])], -1)
     renderout = _render_flow(neurenderer, verts_cam[0], faces, sample_flows, camintrs[0], detach_textures,
                              detach_renders)
+    fuse = (USE_FUSED_EPILOGUE and mask_occlusions and renderout["rgb"].is_cuda and renderout["rgb"].dim() == 4
+            and renderout["rgb"].shape[2] == renderout["rgb"].shape[3] == renderout["face_index_map"].shape[1])
+    if fuse:
+        verts_displ2d_21 = gt_locs2d_1 - gt_locs2d_2
+        sample_flows = torch.cat([verts_displ2d_21, torch.ones_like(verts_displ2d_21[:, :, :1])], -1)
+        renderout2 = _render_flow(neurenderer, verts_cam[1], faces, sample_flows, camintrs[1], False, detach_renders)
+        return _fused_epilogue(renderout, renderout2, orig_img_size, ignore_face_idxs)
     mask_flow1 = (renderout["alpha"].unsqueeze(1) > 0.99999).float()
     if ignore_face_idxs is not None:
         mask_flow1 = mask_flow1 * _ignore_mask(renderout["face_index_map"], ignore_face_idxs)

@@ -194,11 +194,34 @@ MR_API int mr_warp_backward(const float* x, const float* flow, const float* grad
 
 /* imgflowarp.get_occlusion_mask (imgflowarp.py:118-172), the four chained nearest
  * warps fused: mask_flow{1,2}[B,H,W], flow{12,21}[B,>=2,H,W] with channel stride
- * flow_cstride = H*W and batch stride flow_bstride (elements) -> occl{1,2}[B,H,W]. */
+ * flow_cstride = H*W and batch stride flow_bstride (elements) -> occl{1,2}[B,H,W].
+ * flow12_scale / flow21_scale [B,H,W] (nullable): per-pixel factors applied to the flows on
+ * load, so that the masked flows rgb * mask of opticalflow.py:118,135 need not be
+ * materialised. */
 MR_API int mr_occlusion_mask(const float* mask_flow1, const float* mask_flow2, const float* flow12,
-                      const float* flow21, int64_t flow_bstride, float* occl1, float* occl2,
-                      int batch_size, int height, int width, float distance_thresh,
-                      float warp_thresh, mr_stream_t stream);
+                      const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                      const float* flow21_scale, float* occl1, float* occl2, int batch_size,
+                      int height, int width, float distance_thresh, float warp_thresh,
+                      mr_stream_t stream);
+
+/* Flow epilogue of opticalflow.get_opticalflow (opticalflow.py:109-154), fused.
+ * mr_flow_mask: mask[B,is,is] (IMAGE orientation) = (alpha_img > thresh) * keep, where keep
+ *   looks the un-flipped face_index_map up in keep_lut[n_lut] (entry f+1 for face f, entry 0 =
+ *   background; faces beyond the table are kept) -- the ignore-face mask of :110-116 incl. its
+ *   manual vertical flip.  keep_lut may be NULL (no ignore list).
+ * mr_flow_finalize_forward: flow[B,H,W,2] = (rgb_img[:, c] * mask_pre) * (mask_x * occl), c = 0,1,
+ *   cropped to the top-left H x W (:146-154); all maps [B,is,is] in IMAGE orientation.
+ * mr_flow_finalize_backward: its adjoint w.r.t. rgb_img; grad_rgb_img[B,3,is,is] fully written. */
+MR_API int mr_flow_mask(const float* alpha_img, const int32_t* face_index_map, const float* keep_lut,
+                        int n_lut, float thresh, float* mask, int batch_size, int image_size,
+                        mr_stream_t stream);
+MR_API int mr_flow_finalize_forward(const float* rgb_img, const float* mask_pre, const float* mask_x,
+                                    const float* occl, float* flow, int batch_size, int image_size,
+                                    int height, int width, mr_stream_t stream);
+MR_API int mr_flow_finalize_backward(const float* grad_flow, const float* mask_pre,
+                                     const float* mask_x, const float* occl, float* grad_rgb_img,
+                                     int batch_size, int image_size, int height, int width,
+                                     mr_stream_t stream);
 
 /* Bytes of device workspace mr_pair_consist_forward needs (per-block partial sums). */
 MR_API int64_t mr_pair_consist_workspace_bytes(int batch_size, int height, int width);

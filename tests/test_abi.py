@@ -60,7 +60,7 @@ def test_argument_validation_needs_no_device():
     assert lib.mr_backward_textures(null, null, null, null, null, 1, 1, 8, 2, null) == -1
     assert lib.mr_face_inv_map(null, null, null, 1, 1, 8, null) == -1
     with pytest.raises(RuntimeError, match="bad argument"):
-        _lib.call("mr_occlusion_mask", null, null, null, null, 0, null, null, 1, 8, 8, 0.03, 0.99999, null)
+        _lib.call("mr_occlusion_mask", null, null, null, null, 0, null, null, null, null, 1, 8, 8, 0.03, 0.99999, null)
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -138,8 +138,8 @@ def test_pair_consist_large_matches_oracle(cuda):
         close(f21.grad.cpu().numpy(), ref_g[1], 1e-4, 1e-9, "grad_flow21")
 
 
-@pytest.mark.parametrize("vertex_color_render", [True, False])
-def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, monkeypatch):
+@pytest.mark.parametrize("vertex_color_render,fused_epilogue", [(True, True), (False, True), (True, False), (False, False)])
+def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, fused_epilogue, monkeypatch):
     """get_opticalflow (two renders + masks + occlusion + crop) and the pair loss on top of it,
     HIP path vs oracle chain, on the synthetic hand+object scene (non-square crop)."""
     from handobjectconsist_amd.neurender.renderer import Renderer
@@ -147,6 +147,7 @@ def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, monkeypatch
     from handobjectconsist_amd.warping import imgflowarp, opticalflow
 
     monkeypatch.setattr(opticalflow, "USE_VERTEX_COLOR_RENDER", vertex_color_render)
+    monkeypatch.setattr(opticalflow, "USE_FUSED_EPILOGUE", fused_epilogue)
     B, is_, H, Wd = 2, 128, 96, 128
     s = synth.random_scene(B, seed=21, image_size=is_)
     kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
@@ -175,3 +176,10 @@ def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, monkeypatch
     close(loss.detach().cpu().numpy(), ref_loss, 1e-4, 1e-7, "pair loss on rendered flows")
     loss.sum().backward()
     assert v1.grad is not None and torch.isfinite(v1.grad).all() and v1.grad.abs().sum() > 0
+    # all four (render path x epilogue) combinations give the same vertex gradient
+    ref_key = "_vgrad_ref"
+    if not hasattr(test_opticalflow_chain_matches_oracle, ref_key):
+        setattr(test_opticalflow_chain_matches_oracle, ref_key, v1.grad.clone())
+    else:
+        ref_g = getattr(test_opticalflow_chain_matches_oracle, ref_key)
+        close(v1.grad.cpu().numpy(), ref_g.cpu().numpy(), 1e-3, 1e-5 * float(ref_g.abs().max()), "vertex grad across paths")
