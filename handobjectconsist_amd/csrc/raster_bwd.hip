@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(256) depth_atomic_stored_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// D: NMR pixel-map pseudo-gradient.  8 lanes per face, lanes 0..5 = (edge, axis) walks.
+// D: NMR pixel-map pseudo-gradient.
 // ---------------------------------------------------------------------------------------
 struct PixelMapParams {
     const float* faces;
@@ -596,31 +596,42 @@ __device__ __forceinline__ float diff_grad_at(const PixelMapParams& p, int b, in
     return d;
 }
 
+// One WAVE per face.  The edge / axis / column loops of upstream's per-face walk are wave-uniform
+// (every lane evaluates the same scalars); the pixel sweeps along d1 -- up to the image border for
+// the "out" sweep -- are spread over the 64 lanes, each lane accumulating partial sums for the six
+// (vertex, component) slots, combined by one butterfly reduction at the end.
 template <bool IMG>
 __global__ void __launch_bounds__(256) pixel_map_kernel(PixelMapParams p) {
     const int64_t total = (int64_t)p.B * p.F;
-    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i = gtid >> 3;
-    const int item = (int)(gtid & 7);
-    const bool valid = i < total;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // face of this wave
+    const int lane = threadIdx.x & 63;
+    if (i >= total) return;  // wave-uniform
     const int is = p.is;
     const float fis = (float)is;
-    float g0 = 0.0f, g1 = 0.0f;  // gradients of vertices pi[0], pi[1], component (1 - axis)
-    bool front = false;
-    const int edge_num = item >> 1, axis = item & 1;
-    const int b = valid ? (int)(i / p.F) : 0;
-    const int fn = valid ? (int)(i % p.F) : 0;
-    if (valid) {
-        float face[9];
+    const int b = (int)(i / p.F);
+    const int fn = (int)(i % p.F);
+    float face[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) face[k] = p.faces[i * 9 + k];
-        front = !backfacing(face);
-        if (front && item < 6) {
-            int pi[3];
-            float pp[3][2];
-            for (int num = 0; num < 3; num++) pi[num] = (edge_num + num) % 3;
-            for (int num = 0; num < 3; num++)
-                for (int dim = 0; dim < 2; dim++) pp[num][dim] = 0.5f * (face[3 * pi[num] + dim] * fis + fis - 1.0f);
+    for (int k = 0; k < 9; k++) face[k] = p.faces[i * 9 + k];
+    const bool front = !backfacing(face);
+    if (!front) {
+        if (p.write_backfacing && lane < 9) p.grad_faces[i * 9 + lane] = 0.0f;
+        return;
+    }
+    const int32_t* fim_b = p.fim + (int64_t)b * is * is;
+    float acc[3][2];  // [vertex][component] partial sums of this lane
+#pragma unroll
+    for (int k = 0; k < 3; k++) { acc[k][0] = 0.0f; acc[k][1] = 0.0f; }
+
+#pragma unroll 1
+    for (int edge_num = 0; edge_num < 3; edge_num++) {
+        int pi[3];
+        float pp[3][2];
+        for (int num = 0; num < 3; num++) pi[num] = (edge_num + num) % 3;
+        for (int num = 0; num < 3; num++)
+            for (int dim = 0; dim < 2; dim++) pp[num][dim] = 0.5f * (face[3 * pi[num] + dim] * fis + fis - 1.0f);
+#pragma unroll 1
+        for (int axis = 0; axis < 2; axis++) {
             float q[3][2];
             for (int num = 0; num < 3; num++)
                 for (int dim = 0; dim < 2; dim++) q[num][dim] = pp[num][(dim + axis) % 2];
@@ -631,6 +642,7 @@ __global__ void __launch_bounds__(256) pixel_map_kernel(PixelMapParams p) {
                 direction = (q[0][0] < q[1][0]) ? 1 : -1;
             const int d0_from = (int)fmaxf(ceilf(fminf(q[0][0], q[1][0])), 0.0f);
             const int d0_to = (int)fminf(fmaxf(q[0][0], q[1][0]), fis - 1.0f);
+            float g0 = 0.0f, g1 = 0.0f;  // this lane's share for vertices pi[0], pi[1], component 1 - axis
             for (int d0 = d0_from; d0 <= d0_to; d0++) {
                 const float fd0 = (float)d0;
                 const float d1_cross = (q[1][1] - q[0][1]) / (q[1][0] - q[0][0]) * (fd0 - q[0][0]) + q[0][1];
@@ -654,14 +666,13 @@ __global__ void __launch_bounds__(256) pixel_map_kernel(PixelMapParams p) {
                 const float c0 = (q[1][0] - q[0][0]) / (q[1][0] - fd0);
                 const float c1 = (q[1][0] - q[0][0]) / (fd0 - q[0][0]);
                 const bool use0 = q[1][0] != fd0, use1 = q[0][0] != fd0;
-                const int32_t* fim_b = p.fim + (int64_t)b * is * is;
 
-                // out sweep
+                // out sweep: pixels beyond the edge, away from the face, lanes over d1
                 if (fim_b[yin * is + xin] == fn) {
                     const int d1_limit = (0 < direction) ? is - 1 : 0;
                     const int d1_from = max(min(d1_out, d1_limit), 0);
                     const int d1_to = min(max(d1_out, d1_limit), is - 1);
-                    for (int d1 = d1_from; d1 <= d1_to; d1++) {
+                    for (int d1 = d1_from + lane; d1 <= d1_to; d1 += MR_WAVE) {
                         const int xi = axis == 0 ? d0 : d1, yi = axis == 0 ? d1 : d0;
                         const float dg = diff_grad_at<IMG>(p, b, yi, xi, a_in, rgb_in);
                         if (dg <= 0) continue;
@@ -677,7 +688,7 @@ __global__ void __launch_bounds__(256) pixel_map_kernel(PixelMapParams p) {
                         }
                     }
                 }
-                // in sweep
+                // in sweep: this face's pixels between the edge and the opposite boundary
                 {
                     float d0_cross2;
                     if ((fd0 - q[0][0]) * (fd0 - q[2][0]) < 0)
@@ -687,7 +698,7 @@ __global__ void __launch_bounds__(256) pixel_map_kernel(PixelMapParams p) {
                     const int d1_limit = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
                     const int d1_from = max(min(d1_in, d1_limit), 0);
                     const int d1_to = min(max(d1_in, d1_limit), is - 1);
-                    for (int d1 = d1_from; d1 <= d1_to; d1++) {
+                    for (int d1 = d1_from + lane; d1 <= d1_to; d1 += MR_WAVE) {
                         const int xi = axis == 0 ? d0 : d1, yi = axis == 0 ? d1 : d0;
                         if (fim_b[yi * is + xi] != fn) continue;
                         const float dg = diff_grad_at<IMG>(p, b, yi, xi, a_out, rgb_out);
@@ -705,29 +716,29 @@ __global__ void __launch_bounds__(256) pixel_map_kernel(PixelMapParams p) {
                     }
                 }
             }
+            // slot (vertex pi[0], comp 1 - axis) += g0 ; slot (vertex pi[1], comp 1 - axis) += g1
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (k == pi[0]) acc[k][1 - axis] += g0;
+                if (k == pi[1]) acc[k][1 - axis] += g1;
+            }
         }
     }
-    // combine inside the 8-lane group.  Slot (vertex v, component c) receives g0 of the walk
-    // (edge v, axis 1 - c) and g1 of the walk (edge (v + 2) % 3, axis 1 - c), added in
-    // upstream's edge order.
-    const int lane = threadIdx.x & 63;
-    const int gbase = lane & ~7;
-    float out[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) out[k] = 0.0f;
+    for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
-    for (int v = 0; v < 3; v++)
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const int ax = 1 - c;
-            const int ea = v, eb = (v + 2) % 3;
-            const float ga = __shfl(g0, gbase + ea * 2 + ax);
-            const float gb = __shfl(g1, gbase + eb * 2 + ax);
-            out[3 * v + c] = (ea < eb) ? (ga + gb) : (gb + ga);
+        for (int k = 0; k < 3; k++) {
+            acc[k][0] += __shfl_xor(acc[k][0], off);
+            acc[k][1] += __shfl_xor(acc[k][1], off);
         }
-    if (valid && item == 0 && (front || p.write_backfacing))
+    if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) p.grad_faces[i * 9 + k] = out[k];
+        for (int k = 0; k < 3; k++) {
+            p.grad_faces[i * 9 + 3 * k + 0] = acc[k][0];
+            p.grad_faces[i * 9 + 3 * k + 1] = acc[k][1];
+            p.grad_faces[i * 9 + 3 * k + 2] = 0.0f;
+        }
+    }
 }
 
 template <typename K, typename... A>
@@ -756,7 +767,7 @@ extern "C" int mr_backward_pixel_map(const float* faces, const int32_t* face_ind
     if (!return_rgb && !return_alpha) return MR_OK;
     PixelMapParams p{faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
                      batch_size, num_faces, image_size, eps, return_rgb, return_alpha, 0};
-    return launch1d(pixel_map_kernel<false>, (int64_t)batch_size * num_faces * 8, (hipStream_t)stream, p);
+    return launch1d(pixel_map_kernel<false>, (int64_t)batch_size * num_faces * MR_WAVE, (hipStream_t)stream, p);
 }
 
 extern "C" int mr_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
@@ -813,7 +824,7 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
         const int rr = return_rgb && grad_rgb_img && rgb_img, ra = return_alpha && grad_alpha_img && alpha_img;
         PixelMapParams p{faces, face_index_map, rgb_img, alpha_img, grad_rgb_img, grad_alpha_img,
                          grad_faces, batch_size, num_faces, image_size, eps, rr, ra, 1};
-        rc = launch1d(pixel_map_kernel<true>, nfaces * 8, s, p);
+        rc = launch1d(pixel_map_kernel<true>, nfaces * MR_WAVE, s, p);
         if (rc != MR_OK) return rc;
     }
     const bool want_f = grad_faces && return_depth && grad_depth_img;
