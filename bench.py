@@ -43,7 +43,7 @@ def parse():
     p.add_argument("--image-size", type=int, default=256)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-bench", action="store_true")
-    p.add_argument("--cpu-sample", type=int, default=2, help="images in the CPU-baseline sample")
+    p.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample")
     p.add_argument("--kernel-iters", type=int, default=50)
     p.add_argument("--kernels-only", action="store_true", help="only the per-kernel benchmark (profiling aid)")
     p.add_argument("--hot-only", action="store_true", help="only the render+warp hot path fwd+bwd (profiling aid)")

@@ -97,7 +97,8 @@ __device__ __forceinline__ void gather_pixel(const GatherParams& p, const Face& 
 // combined with two quad shuffles (fixed order: deterministic).  Faces whose bbox exceeds
 // GATHER_BIG pixels are walked by the whole wave instead.
 constexpr int GLPF = 4;
-constexpr int GATHER_BIG = 128;
+constexpr int GATHER_BIG = 128;          // vertex-colour gather: bbox area above which the whole wave probes
+constexpr int GATHER_BIG_GENERIC = 256;  // generic gather (direct accumulation on the wave-cooperative path)
 
 template <bool TEX, bool DEPTH>
 __device__ __forceinline__ void gather_store(const GatherParams& p, int64_t i, const float* gt, const float* gf) {
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
     }
     const bool nonempty = valid && bx.x0 <= bx.x1;
     const int bw = bx.x1 - bx.x0 + 1, bh = bx.y1 - bx.y0 + 1;
-    const bool big = nonempty && bw * bh > GATHER_BIG;
+    const bool big = nonempty && bw * bh > GATHER_BIG_GENERIC;
 
     float gt[NT], gf[NF];
 
