@@ -45,7 +45,7 @@ constexpr int TPB = 256;              // threads per workgroup (4 waves)
 constexpr int NB = 32;                // faces per batch (stage S1: one lane per face)
 constexpr int FPP = MR_WAVE / TILE_H; // faces per S2 pass: one lane per (face, tile row)
 constexpr int FC_STRIDE = 25;         // dwords per face-cache slot (odd: conflict-free ds_read_b32)
-constexpr int FQCAP = 128;            // fragment queue capacity (>= 2 * 64)
+constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 4 * 64, power of 2)
 constexpr int SCAN_UNROLL = 4;        // independent record loads in flight per lane
 constexpr int QCAP = 512;             // wave-private ring capacity (>= NB - 1 + 64 * SCAN_UNROLL, power of 2)
 
@@ -273,9 +273,10 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     }
 
     // S3: one lane per fragment -- barycentrics, near/far, depth test
+    int fqh = 0, fqn = 0;  // fragment ring (wave-uniform)
     auto shade = [&](int n) {
         if (lane < n && !(p.dbg & 16)) {
-            const unsigned fr = fq[lane];
+            const unsigned fr = fq[(fqh + lane) & (FQCAP - 1)];
             const float* c = fc + (fr >> 16) * FC_STRIDE;
             const int lx = (int)(fr & 0xffu), ly = (int)((fr >> 8) & 0xffu);
             Face f;
@@ -309,49 +310,79 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
         }
         __builtin_amdgcn_wave_barrier();
         if (p.dbg & (4 | 8)) return;
-        // S2: FPP faces per pass, one lane per (face, tile row): walk the face's clipped x-range on
-        // that row with the edge tests only, all lanes in lock step
-        int fqn = 0;
+        // S2: FPP faces per pass, one lane per (face, tile row).  Along a row each edge test
+        //   reject_k(x) = ey_k < (xp[x] - a_k) * dy_k
+        // is monotone in x even in floating point (xp[x] increases with x; IEEE subtraction and
+        // multiplication by a constant are monotone), so the pixels a face covers on a row form ONE
+        // span: three 6-step binary searches with the exact predicate find it -- the same pixels
+        // the per-pixel loop would accept, without visiting the others.
         for (int f0 = 0; f0 < count; f0 += FPP) {
             const int slot = f0 + lane / TILE_H, row = lane % TILE_H;
             bool act = slot < count;
-            float ax = 0, ay = 0, bx = 0, by = 0, cx_ = 0, cy_ = 0, yp = 0;
-            int px = 0, lx1 = -1;
+            float ea[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, ey[3] = {0, 0, 0};
+            int lx0 = 0, lx1 = -1;
             if (act) {
                 const float* c = fc + slot * FC_STRIDE;
                 const int bb = __float_as_int(c[19]);
                 act = row >= ((bb >> 16) & 0xff) && row <= ((bb >> 24) & 0xff);
-                ax = c[0]; ay = c[1]; bx = c[3]; by = c[4]; cx_ = c[6]; cy_ = c[7];
-                px = bb & 0xff; lx1 = (bb >> 8) & 0xff;
-                yp = yp_tab[row];
+                const float ax = c[0], ay = c[1], bx = c[3], by = c[4], cx_ = c[6], cy_ = c[7];
+                lx0 = bb & 0xff; lx1 = (bb >> 8) & 0xff;
+                const float yp = yp_tab[row];
+                ea[0] = ax; ea[1] = bx; ea[2] = cx_;
+                dy[0] = by - ay; dy[1] = cy_ - by; dy[2] = ay - cy_;
+                ey[0] = (yp - ay) * (bx - ax); ey[1] = (yp - by) * (cx_ - bx); ey[2] = (yp - cy_) * (ax - cx_);
             }
-            const float dx01 = bx - ax, dy01 = by - ay, dx12 = cx_ - bx, dy12 = cy_ - by, dx20 = ax - cx_,
-                        dy20 = ay - cy_;
-            const float ey0 = (yp - ay) * dx01, ey1 = (yp - by) * dx12, ey2 = (yp - cy_) * dx20;
-            while (__ballot(act) != 0ull) {
-                bool cov = false;
-                if (act) {
-                    const float xp = xp_tab[px];
-                    cov = !((ey0 < (xp - ax) * dy01) || (ey1 < (xp - bx) * dy12) || (ey2 < (xp - cx_) * dy20));
+            int lo = lx0, hi = lx1;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                // accepted set of edge k on this row: a prefix of [lx0, lx1] if dy > 0 (or dy == 0: all
+                // or nothing), a suffix if dy < 0.  T(x) = accepted(x) XOR (dy < 0) is prefix-true.
+                const bool dec = dy[k] < 0.0f;
+                int l = lx0 - 1, h = lx1 + 1;
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const int mid = (l + h) >> 1;
+                    const float xp = xp_tab[max(mid, 0) & (TILE_W - 1)];
+                    const bool acc = !(ey[k] < (xp - ea[k]) * dy[k]);
+                    const bool go = h - l > 1;
+                    const bool t = acc != dec;
+                    l = (go && t) ? mid : l;
+                    h = (go && !t) ? mid : h;
                 }
-                const unsigned long long m = __ballot(cov);
-                if (cov) fq[fqn + __popcll(m & lt_mask)] = ((unsigned)slot << 16) | ((unsigned)row << 8) | (unsigned)px;
-                fqn += __popcll(m);
-                px++;
-                act = act && px <= lx1;
+                // l = last x with T true (lx0 - 1 if none)
+                if (dec) lo = max(lo, l + 1); else hi = min(hi, l);
+            }
+            int len = act ? max(hi - lo + 1, 0) : 0;
+            int x = lo;
+            // emit the spans as fragments, at most 4 pixels per lane per round
+            while (__ballot(len > 0) != 0ull) {
+                const int c = min(len, 4);
+                int incl = c;
+#pragma unroll
+                for (int d = 1; d < MR_WAVE; d <<= 1) {
+                    const int t = __shfl_up(incl, d);
+                    if (lane >= d) incl += t;
+                }
+                const int off = incl - c, total = __shfl(incl, MR_WAVE - 1);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (i < c)
+                        fq[(fqh + fqn + off + i) & (FQCAP - 1)] =
+                            ((unsigned)slot << 16) | ((unsigned)row << 8) | (unsigned)(x + i);
+                x += c; len -= c; fqn += total;
                 __builtin_amdgcn_wave_barrier();
-                if (fqn >= MR_WAVE) {
+                while (fqn >= MR_WAVE) {
                     shade(MR_WAVE);
-                    const int rest = fqn - MR_WAVE;
-                    const unsigned v = (lane < rest) ? fq[MR_WAVE + lane] : 0u;
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < rest) fq[lane] = v;
-                    __builtin_amdgcn_wave_barrier();
-                    fqn = rest;
+                    fqh = (fqh + MR_WAVE) & (FQCAP - 1);
+                    fqn -= MR_WAVE;
                 }
             }
         }
-        if (fqn > 0) shade(fqn);
+        if (fqn > 0) {
+            shade(fqn);
+            fqh = (fqh + fqn) & (FQCAP - 1);
+            fqn = 0;
+        }
     };
 
     // each wave scans a contiguous quarter of the image's record list

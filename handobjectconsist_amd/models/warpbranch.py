@@ -1,14 +1,35 @@
-"""Photometric-consistency branch -- counterpart of meshreg/models/warpbranch.py:9-96.
+"""Photometric-consistency branch: meshes of a frame sequence -> rendered optical flows -> pair
+losses.  Counterpart of meshreg/models/warpbranch.py:9-96 (same ``forward`` argument list and
+return value) organised as three steps:
 
-Same argument list and control flow as the reference's ``forward``: GT-reference
-substitution (:38-47), hand + object mesh concatenation (:49-55), detach of frames > 0,
-``get_opticalflows(..., detach_textures=False, detach_renders=True)`` (:59-68) and one
-``pair_consist`` per frame pair (:73-88).  Samples are dicts of device-resident tensors
-keyed by plain strings (the dataset layer and its Queries enums are out of scope)."""
+1. ``_frame_meshes``  hand + object vertices per frame; with ``gt_refs`` every frame after the
+   first is replaced by its ground-truth geometry (warpbranch.py:38-47); frames after the first
+   are constants for autograd when ``first_only`` (:53-54); hand and object are concatenated into
+   one mesh with offset face indices (:49-55).
+2. ``get_opticalflows`` with the reference's training setting ``detach_textures=False,
+   detach_renders=True`` (:59-68): gradients reach the vertices only through the flow VALUES.
+3. one ``pair_consist`` per (frame 0, frame k) pair, averaged (:73-88).
+
+Samples are dicts of device-resident tensors keyed by plain strings: "image", "jittermask",
+"camintr", "objfaces" and, for annotated frames, "handverts3d" / "objverts3d" (the dataset layer
+with its Queries enums is out of scope)."""
 import torch
 
 from handobjectconsist_amd.utils import catmesh
 from handobjectconsist_amd.warping import imgflowarp, opticalflow
+
+
+def _frame_meshes(samples, all_results, hand_face, gt_refs, first_only):
+    batch = all_results[0]["recov_objverts3d"].shape[0]
+    hand_faces = hand_face.long().unsqueeze(0).expand(batch, -1, -1) if hand_face.dim() == 2 else hand_face.long()
+    frames, faces = [], None
+    for k, (sample, result) in enumerate(zip(samples, all_results)):
+        annotated = gt_refs and k > 0
+        hand = sample["handverts3d"].cuda() if annotated else result["recov_handverts3d"]
+        obj = sample["objverts3d"].cuda() if annotated else result["recov_objverts3d"]
+        verts, faces, _ = catmesh.batch_cat_meshes([hand, obj], [hand_faces, sample["objfaces"].long().cuda()])
+        frames.append(verts.detach() if (first_only and k > 0) else verts)
+    return frames, faces
 
 
 def forward(
@@ -26,66 +47,46 @@ def forward(
 ):
     """
     Args:
-        use_backward: also compare the warp from the unannotated to the annotated frame with
-            the annotated image
-        pair_outputs: "full" (masks / warps / diffs as the reference) or "loss"
+        samples / all_results: per-frame inputs and network outputs; frame 0 is the frame under
+            supervision-by-consistency, later frames are the references it is compared with
+        hand_face: closed hand faces [F,3] (or already batched [B,F,3])
+        use_backward: also compare the warp of the unannotated frame with the annotated image
+        pair_outputs: "full" (masks / warps / diffs as the reference returns them) or "loss"
+
+    Returns:
+        (mean pair loss, {"masks", "warps", "recons_flows", "diffs", "diff_losses"})
     """
-    images = [sample["image"].cuda() for sample in samples]
-    jitter_masks = [sample["jittermask"].cuda() for sample in samples]
-    camintrs = [sample["camintr"].cuda() for sample in samples]
-
-    obj_verts = [result["recov_objverts3d"] for result in all_results]
-    obj_faces = [sample["objfaces"].long().cuda() for sample in samples]
-    hand_verts = [result["recov_handverts3d"] for result in all_results]
-    hand_faces_b = hand_face.repeat(obj_verts[0].shape[0], 1, 1).long()
-    hand_faces = [hand_faces_b for _ in range(len(samples))]
-    if gt_refs:
-        # Replace reference vertices by ground truth vertices (warpbranch.py:38-47)
-        for sample_idx in range(1, len(samples)):
-            obj_verts[sample_idx] = samples[sample_idx]["objverts3d"].cuda()
-            hand_verts[sample_idx] = samples[sample_idx]["handverts3d"].cuda()
-    verts_world = []
-    for seq_idx in range(len(samples)):
-        all_verts, all_faces, _ = catmesh.batch_cat_meshes(
-            [hand_verts[seq_idx], obj_verts[seq_idx]], [hand_faces[seq_idx], obj_faces[seq_idx]]
-        )
-        if first_only and seq_idx > 0:
-            all_verts = all_verts.detach()
-        verts_world.append(all_verts)
-
+    verts_world, all_faces = _frame_meshes(samples, all_results, hand_face, gt_refs, first_only)
     recons_flows = opticalflow.get_opticalflows(
         verts_world,
         all_faces,
-        camintrs,
+        [sample["camintr"].cuda() for sample in samples],
         renderer,
         image_size,
         detach_textures=False,
         detach_renders=True,
         ignore_face_idxs=hand_ignore_faces,
     )
-    all_masks, all_warps, all_diffs, full_losses = [], [], [], []
-    for recons_flow, image, jitter_mask in zip(recons_flows, images[1:], jitter_masks[1:]):
-        warp_loss, masks, warps, diffs = imgflowarp.pair_consist(
-            recons_flow,
-            image_ref=images[0],
-            image=image,
-            jitter_mask_ref=jitter_masks[0],
-            jitter_mask=jitter_mask,
+    ref_image, ref_jitter = samples[0]["image"].cuda(), samples[0]["jittermask"].cuda()
+    per_pair = [
+        imgflowarp.pair_consist(
+            flow,
+            image_ref=ref_image,
+            image=sample["image"].cuda(),
+            jitter_mask_ref=ref_jitter,
+            jitter_mask=sample["jittermask"].cuda(),
             criterion=criterion,
             use_backward=use_backward,
             outputs=pair_outputs,
         )
-        all_masks.append(masks)
-        full_losses.append(warp_loss)
-        all_warps.append(warps)
-        all_diffs.append(diffs)
-    stack_losses = torch.stack(full_losses)
-    full_loss = stack_losses.mean()
+        for flow, sample in zip(recons_flows, samples[1:])
+    ]
+    diff_losses = torch.stack([res[0] for res in per_pair])
     pair_results = {
-        "masks": all_masks,
-        "warps": all_warps,
+        "masks": [res[1] for res in per_pair],
+        "warps": [res[2] for res in per_pair],
         "recons_flows": recons_flows,
-        "diffs": all_diffs,
-        "diff_losses": stack_losses,
+        "diffs": [res[3] for res in per_pair],
+        "diff_losses": diff_losses,
     }
-    return full_loss, pair_results
+    return diff_losses.mean(), pair_results

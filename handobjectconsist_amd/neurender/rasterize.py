@@ -40,186 +40,100 @@ def _dummy(device, dtype=torch.float32):
 
 
 class RasterizeFunction(Function):
-    """
-    Definition of differentiable rasterize operation (reference rasterize.py:16-315).
-    Implemented only for cuda (ROCm) tensors.
+    """The reference's autograd op (rasterize.py:16-315) on the five upstream-compatible C-ABI entry
+    points: ``apply(faces, textures, image_size, near, far, eps, background_color, return_rgb,
+    return_alpha, return_depth) -> (rgb [B,is,is,3], alpha [B,is,is], depth [B,is,is],
+    face_index_map, face_inv_map, weight_map)``, all in RASTER orientation (un-flipped, NHWC).
+
+    The caller-side contract of the native calls is the reference's: every output map is allocated
+    and pre-filled here (index -1, depth ``far``, the rest 0; 1-element dummies for the outputs
+    that were not requested -- rasterize.py:58-85), the callee only touches the pixels a face
+    covers.  Background colour and alpha are applied with tensor ops afterwards (:245-260).
     """
 
     @staticmethod
     def forward(ctx, faces, textures, image_size, near, far, eps, background_color, return_rgb=False,
                 return_alpha=False, return_depth=False):
         _lib.check_cuda(faces, textures if return_rgb else None)
-        ctx.image_size = image_size
-        ctx.near = near
-        ctx.far = far
-        ctx.eps = eps
-        ctx.background_color = background_color
-        ctx.return_rgb = return_rgb
-        ctx.return_alpha = return_alpha
-        ctx.return_depth = return_depth
-
         faces = _lib.contig(faces).clone()
         dev = faces.device
-        ctx.device = dev
-        ctx.batch_size, ctx.num_faces = faces.shape[:2]
-        B, is_ = ctx.batch_size, image_size
+        B, Fn = faces.shape[:2]
+        is_ = int(image_size)
+        st = _lib.stream_ptr(dev)
+        ctx.cfg = dict(B=B, F=Fn, is_=is_, near=float(near), far=float(far), eps=float(eps), rgb=bool(return_rgb),
+                       alpha=bool(return_alpha), depth=bool(return_depth))
 
-        if return_rgb:
-            textures = _lib.contig(textures)
-        else:
-            textures = _dummy(dev)
+        def maps(shape, fill=0.0, dtype=torch.float32, wanted=True):
+            return torch.full(shape, fill, dtype=dtype, device=dev) if wanted else _dummy(dev)
 
-        # rasterize.py:60-85
-        face_index_map = torch.full((B, is_, is_), -1, dtype=torch.int32, device=dev)
-        weight_map = torch.zeros((B, is_, is_, 3), dtype=torch.float32, device=dev)
-        depth_map = torch.full((B, is_, is_), float(far), dtype=torch.float32, device=dev)
+        textures = _lib.contig(textures) if return_rgb else _dummy(dev)
+        face_index_map = maps((B, is_, is_), -1, torch.int32)
+        weight_map = maps((B, is_, is_, 3))
+        depth_map = maps((B, is_, is_), float(far))
+        face_inv_map = maps((B, is_, is_, 3, 3), wanted=return_depth)
+        rgb_map = maps((B, is_, is_, 3), wanted=return_rgb)
+        sampling_index_map = maps((B, is_, is_, 8), 0, torch.int32, wanted=return_rgb)
+        sampling_weight_map = maps((B, is_, is_, 8), wanted=return_rgb)
+        alpha_map = maps((B, is_, is_), wanted=return_alpha)
+
+        faces_inv = torch.zeros_like(faces)  # scratch of the native call (rasterize.py:201)
+        _lib.call("mr_forward_face_index_map", _lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(weight_map),
+                  _lib.ptr(depth_map), _lib.ptr(face_inv_map), _lib.ptr(faces_inv), B, Fn, is_, float(near),
+                  float(far), int(return_rgb), int(return_alpha), int(return_depth), st)
+        hit = face_index_map >= 0
         if return_rgb:
-            rgb_map = torch.zeros((B, is_, is_, 3), dtype=torch.float32, device=dev)
-            sampling_index_map = torch.zeros((B, is_, is_, 8), dtype=torch.int32, device=dev)
-            sampling_weight_map = torch.zeros((B, is_, is_, 8), dtype=torch.float32, device=dev)
-        else:
-            rgb_map = _dummy(dev)
-            sampling_index_map = _dummy(dev)
-            sampling_weight_map = _dummy(dev)
+            _lib.call("mr_forward_texture_sampling", _lib.ptr(faces), _lib.ptr(textures), _lib.ptr(face_index_map),
+                      _lib.ptr(weight_map), _lib.ptr(depth_map), _lib.ptr(rgb_map), _lib.ptr(sampling_index_map),
+                      _lib.ptr(sampling_weight_map), B, Fn, is_, int(textures.shape[2]), float(eps), st)
+            bg = torch.as_tensor(background_color, dtype=torch.float32, device=dev)
+            bg = bg[None, None, None, :] if bg.ndimension() == 1 else bg[:, None, None, :]
+            mask = hit.float()[:, :, :, None]
+            rgb_map = rgb_map * mask + (1 - mask) * bg
         if return_alpha:
-            alpha_map = torch.zeros((B, is_, is_), dtype=torch.float32, device=dev)
-        else:
-            alpha_map = _dummy(dev)
-        if return_depth:
-            face_inv_map = torch.zeros((B, is_, is_, 3, 3), dtype=torch.float32, device=dev)
-        else:
-            face_inv_map = _dummy(dev)
-
-        face_index_map, weight_map, depth_map, face_inv_map = RasterizeFunction.forward_face_index_map(
-            ctx, faces, face_index_map, weight_map, depth_map, face_inv_map)
-        rgb_map, sampling_index_map, sampling_weight_map = RasterizeFunction.forward_texture_sampling(
-            ctx, faces, textures, face_index_map, weight_map, depth_map, rgb_map, sampling_index_map,
-            sampling_weight_map)
-        rgb_map = RasterizeFunction.forward_background(ctx, face_index_map, rgb_map)
-        alpha_map = RasterizeFunction.forward_alpha_map(ctx, alpha_map, face_index_map)
+            alpha_map[hit] = 1
 
         ctx.save_for_backward(faces, textures, face_index_map, weight_map, depth_map, rgb_map, alpha_map,
                               face_inv_map, sampling_index_map, sampling_weight_map)
-
-        rgb_r, alpha_r, depth_r = torch.tensor([]), torch.tensor([]), torch.tensor([])
-        if return_rgb:
-            rgb_r = rgb_map
-        if return_alpha:
-            alpha_r = alpha_map.clone()
-        if return_depth:
-            depth_r = depth_map.clone()
         ctx.mark_non_differentiable(face_index_map)
-        return rgb_r, alpha_r, depth_r, face_index_map, face_inv_map, weight_map
+        none = torch.tensor([])
+        return (rgb_map if return_rgb else none, alpha_map.clone() if return_alpha else none,
+                depth_map.clone() if return_depth else none, face_index_map, face_inv_map, weight_map)
 
     @staticmethod
-    def backward(ctx, grad_rgb_map, grad_alpha_map, grad_depth_map, grad_face_index_map, grad_face_inv_map,
-                 grad_weight_map):
+    def backward(ctx, grad_rgb_map, grad_alpha_map, grad_depth_map, _g_index, _g_inv, _g_weight):
         (faces, textures, face_index_map, weight_map, depth_map, rgb_map, alpha_map, face_inv_map,
          sampling_index_map, sampling_weight_map) = ctx.saved_tensors
+        c = ctx.cfg
         dev = faces.device
-        grad_faces = torch.zeros_like(faces, dtype=torch.float32)
-        if ctx.return_rgb:
-            grad_textures = torch.zeros_like(textures, dtype=torch.float32)
-        else:
-            grad_textures = _dummy(dev)
+        st = _lib.stream_ptr(dev)
 
-        if ctx.return_rgb:
-            grad_rgb_map = grad_rgb_map.contiguous() if grad_rgb_map is not None else torch.zeros_like(rgb_map)
-        else:
-            grad_rgb_map = _dummy(dev)
-        if ctx.return_alpha:
-            grad_alpha_map = (grad_alpha_map.contiguous() if grad_alpha_map is not None
-                              else torch.zeros_like(alpha_map))
-        else:
-            grad_alpha_map = _dummy(dev)
-        if ctx.return_depth:
-            # (the reference reads the never-set ctx.depth_map here, rasterize.py:179 -- Q9)
-            grad_depth_map = (grad_depth_map.contiguous() if grad_depth_map is not None
-                              else torch.zeros_like(depth_map))
-        else:
-            grad_depth_map = _dummy(dev)
+        def incoming(grad, like, wanted):
+            # a missing gradient of a requested output counts as zeros (the reference trips over an
+            # unset ctx attribute here for the depth map, rasterize.py:179 -- not reproduced)
+            if not wanted:
+                return _dummy(dev)
+            return grad.contiguous() if grad is not None else torch.zeros_like(like)
 
-        grad_faces = RasterizeFunction.backward_pixel_map(
-            ctx, faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces)
-        grad_textures = RasterizeFunction.backward_textures(
-            ctx, face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures)
-        grad_faces = RasterizeFunction.backward_depth_map(
-            ctx, faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces)
-
+        grad_rgb_map = incoming(grad_rgb_map, rgb_map, c["rgb"])
+        grad_alpha_map = incoming(grad_alpha_map, alpha_map, c["alpha"])
+        grad_depth_map = incoming(grad_depth_map, depth_map, c["depth"])
+        grad_faces = torch.zeros_like(faces)
+        grad_textures = torch.zeros_like(textures) if c["rgb"] else None
+        if c["rgb"] or c["alpha"]:
+            _lib.call("mr_backward_pixel_map", _lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(rgb_map),
+                      _lib.ptr(alpha_map), _lib.ptr(grad_rgb_map), _lib.ptr(grad_alpha_map), _lib.ptr(grad_faces),
+                      c["B"], c["F"], c["is_"], c["eps"], int(c["rgb"]), int(c["alpha"]), st)
+        if c["rgb"]:
+            _lib.call("mr_backward_textures", _lib.ptr(face_index_map), _lib.ptr(sampling_weight_map),
+                      _lib.ptr(sampling_index_map), _lib.ptr(grad_rgb_map), _lib.ptr(grad_textures), c["B"], c["F"],
+                      c["is_"], int(textures.shape[2]), st)
+        if c["depth"]:
+            _lib.call("mr_backward_depth_map", _lib.ptr(faces), _lib.ptr(depth_map), _lib.ptr(face_index_map),
+                      _lib.ptr(face_inv_map), _lib.ptr(weight_map), _lib.ptr(grad_depth_map), _lib.ptr(grad_faces),
+                      c["B"], c["F"], c["is_"], st)
         if not ctx.needs_input_grad[1]:
             grad_textures = None
         return grad_faces, grad_textures, None, None, None, None, None, None, None, None
-
-    # -- the five native entry points (rasterize.py:199-315) ------------------------------
-    @staticmethod
-    def forward_face_index_map(ctx, faces, face_index_map, weight_map, depth_map, face_inv_map):
-        faces_inv = torch.zeros_like(faces)
-        _lib.call("mr_forward_face_index_map", _lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(weight_map),
-                  _lib.ptr(depth_map), _lib.ptr(face_inv_map), _lib.ptr(faces_inv), ctx.batch_size,
-                  ctx.num_faces, ctx.image_size, float(ctx.near), float(ctx.far), int(ctx.return_rgb),
-                  int(ctx.return_alpha), int(ctx.return_depth), _lib.stream_ptr(faces.device))
-        return face_index_map, weight_map, depth_map, face_inv_map
-
-    @staticmethod
-    def forward_texture_sampling(ctx, faces, textures, face_index_map, weight_map, depth_map, rgb_map,
-                                 sampling_index_map, sampling_weight_map):
-        if not ctx.return_rgb:
-            return rgb_map, sampling_index_map, sampling_weight_map
-        _lib.call("mr_forward_texture_sampling", _lib.ptr(faces), _lib.ptr(textures), _lib.ptr(face_index_map),
-                  _lib.ptr(weight_map), _lib.ptr(depth_map), _lib.ptr(rgb_map), _lib.ptr(sampling_index_map),
-                  _lib.ptr(sampling_weight_map), ctx.batch_size, ctx.num_faces, ctx.image_size,
-                  int(textures.shape[2]), float(ctx.eps), _lib.stream_ptr(faces.device))
-        return rgb_map, sampling_index_map, sampling_weight_map
-
-    @staticmethod
-    def forward_alpha_map(ctx, alpha_map, face_index_map):
-        if ctx.return_alpha:
-            alpha_map[face_index_map >= 0] = 1
-        return alpha_map
-
-    @staticmethod
-    def forward_background(ctx, face_index_map, rgb_map):
-        if ctx.return_rgb:
-            background_color = torch.as_tensor(ctx.background_color, dtype=torch.float32,
-                                               device=rgb_map.device)
-            mask = (face_index_map >= 0).float()[:, :, :, None]
-            if background_color.ndimension() == 1:
-                rgb_map = rgb_map * mask + (1 - mask) * background_color[None, None, None, :]
-            elif background_color.ndimension() == 2:
-                rgb_map = rgb_map * mask + (1 - mask) * background_color[:, None, None, :]
-        return rgb_map
-
-    @staticmethod
-    def backward_pixel_map(ctx, faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,
-                           grad_faces):
-        if (not ctx.return_rgb) and (not ctx.return_alpha):
-            return grad_faces
-        _lib.call("mr_backward_pixel_map", _lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(rgb_map),
-                  _lib.ptr(alpha_map), _lib.ptr(grad_rgb_map), _lib.ptr(grad_alpha_map), _lib.ptr(grad_faces),
-                  ctx.batch_size, ctx.num_faces, ctx.image_size, float(ctx.eps), int(ctx.return_rgb),
-                  int(ctx.return_alpha), _lib.stream_ptr(faces.device))
-        return grad_faces
-
-    @staticmethod
-    def backward_textures(ctx, face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map,
-                          grad_textures):
-        if not ctx.return_rgb:
-            return grad_textures
-        _lib.call("mr_backward_textures", _lib.ptr(face_index_map), _lib.ptr(sampling_weight_map),
-                  _lib.ptr(sampling_index_map), _lib.ptr(grad_rgb_map), _lib.ptr(grad_textures),
-                  ctx.batch_size, ctx.num_faces, ctx.image_size, int(grad_textures.shape[2]),
-                  _lib.stream_ptr(face_index_map.device))
-        return grad_textures
-
-    @staticmethod
-    def backward_depth_map(ctx, faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map,
-                           grad_faces):
-        if not ctx.return_depth:
-            return grad_faces
-        _lib.call("mr_backward_depth_map", _lib.ptr(faces), _lib.ptr(depth_map), _lib.ptr(face_index_map),
-                  _lib.ptr(face_inv_map), _lib.ptr(weight_map), _lib.ptr(grad_depth_map), _lib.ptr(grad_faces),
-                  ctx.batch_size, ctx.num_faces, ctx.image_size, _lib.stream_ptr(faces.device))
-        return grad_faces
 
 
 class Rasterize(nn.Module):

@@ -1,11 +1,16 @@
-"""``Renderer`` -- drop-in for meshreg/neurender/renderer.py (reference renderer.py:12-295).
+"""``Renderer`` -- camera + fill-back + (optional) lighting in front of the HIP rasteriser.
 
-Same constructor arguments, same ``forward`` / ``render`` / ``render_rgb`` /
-``render_silhouettes`` / ``render_depth`` / ``project`` signatures and the same quirks
-(``rasterizer_eps = 1e-3`` is only passed by ``render`` / ``render_rgb``; silhouettes and
-depth use the module default 1e-4 -- SURVEY Q1).  The camera / fill-back / gather steps
-are small differentiable PyTorch programs (nr_ops.py); rasterisation goes to the HIP
-kernels through rasterize.py.
+Drop-in for the reference's wrapper (meshreg/neurender/renderer.py:12-295): same constructor
+arguments, same ``forward(vertices, faces, textures, mode, K, R, t, dist_coeffs, orig_size,
+detach_renders)`` dispatch and the same public methods ``render`` / ``render_rgb`` /
+``render_silhouettes`` / ``render_depth`` / ``project``.  All modes share one geometry pipeline
+(``_face_coordinates``); they differ only in which rasteriser entry they call and with which
+epsilon: the reference passes its ``rasterizer_eps = 1e-3`` and its own near / far only from
+``render`` / ``render_rgb``, while silhouettes and depth run with the rasteriser's module defaults
+ -- kept as is.
+
+The camera / fill-back / gather steps are small differentiable PyTorch programs (nr_ops.py);
+``render_vertex_colors`` is the fused entry the optical-flow path uses.
 """
 from __future__ import division
 
@@ -18,9 +23,15 @@ import torch.nn as nn
 from handobjectconsist_amd.neurender import nr_ops as nr
 from handobjectconsist_amd.neurender import rasterize
 
+_CAMERA_MODES = ("projection", "look", "look_at")
 
-def _device():
-    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+def _as_device_tensor(value):
+    """numpy camera parameters are moved to the current GPU, like the reference constructor does."""
+    if isinstance(value, numpy.ndarray):
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        return torch.tensor(value, dtype=torch.float32, device=dev)
+    return value
 
 
 class Renderer(nn.Module):
@@ -48,55 +59,77 @@ class Renderer(nn.Module):
         light_direction=[0, 1, 0],
         no_light=False,
     ):
-        """
-        Wrapper on top of the rasteriser (reference renderer.py:13-83)
-        """
         super(Renderer, self).__init__()
-        # rendering
+        if camera_mode not in _CAMERA_MODES:
+            raise ValueError("Camera mode has to be one of projection, look or look_at")
+        # raster
         self.image_size = image_size
         self.anti_aliasing = anti_aliasing
         self.background_color = background_color
         self.fill_back = fill_back
-        self.no_light = no_light
-
+        self.near, self.far = near, far
+        self.rasterizer_eps = 1e-3
         # camera
         self.camera_mode = camera_mode
-        if self.camera_mode == "projection":
-            self.K = K
-            self.R = R
-            self.t = t
-            dev = _device()
-            if isinstance(self.K, numpy.ndarray):
-                self.K = torch.tensor(self.K, dtype=torch.float32, device=dev)
-            if isinstance(self.R, numpy.ndarray):
-                self.R = torch.tensor(self.R, dtype=torch.float32, device=dev)
-            if isinstance(self.t, numpy.ndarray):
-                self.t = torch.tensor(self.t, dtype=torch.float32, device=dev)
+        if camera_mode == "projection":
+            self.K, self.R, self.t = _as_device_tensor(K), _as_device_tensor(R), _as_device_tensor(t)
             self.dist_coeffs = dist_coeffs
             if dist_coeffs is None:
-                self.dist_coeffs = torch.tensor([[0.0, 0.0, 0.0, 0.0, 0.0]], dtype=torch.float32, device=dev)
+                self.dist_coeffs = _as_device_tensor(numpy.zeros((1, 5), numpy.float32))
             self.orig_size = orig_size
-        elif self.camera_mode in ["look", "look_at"]:
+        else:
             self.perspective = perspective
             self.viewing_angle = viewing_angle
-            self.eye = [0, 0, -(1.0 / math.tan(math.radians(self.viewing_angle)) + 1)]
+            self.eye = [0, 0, -(1.0 / math.tan(math.radians(viewing_angle)) + 1)]
             self.camera_direction = [0, 0, 1]
-        else:
-            raise ValueError("Camera mode has to be one of projection, look or look_at")
-
-        self.near = near
-        self.far = far
-
         # light
+        self.no_light = no_light
         self.light_intensity_ambient = light_intensity_ambient
         self.light_intensity_directional = light_intensity_directional
         self.light_color_ambient = light_color_ambient
         self.light_color_directional = light_color_directional
         self.light_direction = light_direction
 
-        # rasterization
-        self.rasterizer_eps = 1e-3
+    # -- geometry --------------------------------------------------------------------------------
+    @staticmethod
+    def _fill_back_faces(faces):
+        """[B,F,3] -> [B,2F,3]: every face followed (in the second half) by its reversed copy."""
+        return torch.cat((faces, faces.flip(-1)), dim=1).detach()
 
+    @staticmethod
+    def _fill_back_textures(textures):
+        """Textures of the reversed copies: texel (i,j,k) of the copy is texel (k,j,i)."""
+        return torch.cat((textures, textures.permute((0, 1, 4, 3, 2, 5))), dim=1)
+
+    def project(self, vertices, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        """Camera transform of [B,V,3] vertices to rasteriser coordinates (x,y in [-1,1], z depth)."""
+        if self.camera_mode == "projection":
+            dev = vertices.device
+            pick = lambda given, default: (default if given is None else given)
+            return nr.projection(
+                vertices, pick(K, self.K).to(dev), pick(R, self.R).to(dev), pick(t, self.t).to(dev),
+                pick(dist_coeffs, self.dist_coeffs).to(dev), pick(orig_size, self.orig_size))
+        if self.camera_mode == "look_at":
+            vertices = nr.look_at(vertices, self.eye)
+        else:
+            vertices = nr.look(vertices, self.eye, self.camera_direction)
+        return nr.perspective(vertices, angle=self.viewing_angle) if self.perspective else vertices
+
+    def _face_coordinates(self, vertices, faces, textures=None, camera=(), light=False, detach=False):
+        """fill-back -> (lighting) -> projection -> gather: returns (faces [B,F,3,3], textures)."""
+        if self.fill_back:
+            faces = self._fill_back_faces(faces)
+            if textures is not None:
+                textures = self._fill_back_textures(textures)
+        if light and textures is not None:
+            textures = nr.lighting(
+                nr.vertices_to_faces(vertices, faces), textures, self.light_intensity_ambient,
+                self.light_intensity_directional, self.light_color_ambient, self.light_color_directional,
+                self.light_direction)
+        coords = nr.vertices_to_faces(self.project(vertices, *camera), faces)
+        return (coords.detach() if detach else coords), textures
+
+    # -- modes -----------------------------------------------------------------------------------
     def forward(
         self,
         vertices,
@@ -110,120 +143,31 @@ class Renderer(nn.Module):
         orig_size=None,
         detach_renders=False,
     ):
-        """
-        Implementation of forward rendering method (reference renderer.py:85-114)
-        """
+        camera = (K, R, t, dist_coeffs, orig_size)
         if mode is None:
-            return self.render(
-                vertices, faces, textures, K, R, t, dist_coeffs, orig_size, detach_renders=detach_renders
-            )
-        elif mode == "rgb":
-            return self.render_rgb(vertices, faces, textures, K, R, t, dist_coeffs, orig_size)
-        elif mode == "silhouettes":
-            return self.render_silhouettes(vertices, faces, K, R, t, dist_coeffs, orig_size)
-        elif mode == "depth":
-            return self.render_depth(vertices, faces, K, R, t, dist_coeffs, orig_size)
-        else:
-            raise ValueError("mode should be one of None, 'silhouettes' or 'depth'")
+            return self.render(vertices, faces, textures, *camera, detach_renders=detach_renders)
+        if mode == "rgb":
+            return self.render_rgb(vertices, faces, textures, *camera)
+        if mode == "silhouettes":
+            return self.render_silhouettes(vertices, faces, *camera)
+        if mode == "depth":
+            return self.render_depth(vertices, faces, *camera)
+        raise ValueError("mode should be one of None, 'silhouettes' or 'depth'")
 
-    # -- helpers ---------------------------------------------------------------------------
-    @staticmethod
-    def _fill_back_faces(faces):
-        # renderer.py:251: cat(faces, faces[:, :, ::-1])
-        return torch.cat((faces, faces.flip(-1)), dim=1).detach()
-
-    @staticmethod
-    def _fill_back_textures(textures):
-        # renderer.py:252
-        return torch.cat((textures, textures.permute((0, 1, 4, 3, 2, 5))), dim=1)
-
-    def _light(self, vertices, faces, textures):
-        faces_lighting = nr.vertices_to_faces(vertices, faces)
-        return nr.lighting(
-            faces_lighting,
-            textures,
-            self.light_intensity_ambient,
-            self.light_intensity_directional,
-            self.light_color_ambient,
-            self.light_color_directional,
-            self.light_direction,
-        )
-
-    # -- modes -----------------------------------------------------------------------------
     def render_silhouettes(self, vertices, faces, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        if self.fill_back:
-            faces = self._fill_back_faces(faces)
-        vertices = self.project(vertices, K=K, R=R, t=t, dist_coeffs=dist_coeffs, orig_size=orig_size)
-        faces = nr.vertices_to_faces(vertices, faces)
-        images = rasterize.rasterize_silhouettes(faces, self.image_size, self.anti_aliasing)
-        return images
+        coords, _ = self._face_coordinates(vertices, faces, camera=(K, R, t, dist_coeffs, orig_size))
+        return rasterize.rasterize_silhouettes(coords, self.image_size, self.anti_aliasing)
 
     def render_depth(self, vertices, faces, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        if self.fill_back:
-            faces = self._fill_back_faces(faces)
-        vertices = self.project(vertices, K=K, R=R, t=t, dist_coeffs=dist_coeffs, orig_size=orig_size)
-        faces = nr.vertices_to_faces(vertices, faces)
-        images = rasterize.rasterize_depth(faces, self.image_size, self.anti_aliasing)
-        return images
-
-    def project(self, vertices, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        # viewpoint transformation (reference renderer.py:164-188)
-        if self.camera_mode == "look_at":
-            vertices = nr.look_at(vertices, self.eye)
-            if self.perspective:
-                vertices = nr.perspective(vertices, angle=self.viewing_angle)
-        elif self.camera_mode == "look":
-            vertices = nr.look(vertices, self.eye, self.camera_direction)
-            if self.perspective:
-                vertices = nr.perspective(vertices, angle=self.viewing_angle)
-        elif self.camera_mode == "projection":
-            if K is None:
-                K = self.K
-            if R is None:
-                R = self.R
-            if t is None:
-                t = self.t
-            if dist_coeffs is None:
-                dist_coeffs = self.dist_coeffs
-            if orig_size is None:
-                orig_size = self.orig_size
-            dev = vertices.device
-            vertices = nr.projection(vertices, K.to(dev), R.to(dev), t.to(dev), dist_coeffs.to(dev), orig_size)
-        return vertices
+        coords, _ = self._face_coordinates(vertices, faces, camera=(K, R, t, dist_coeffs, orig_size))
+        return rasterize.rasterize_depth(coords, self.image_size, self.anti_aliasing)
 
     def render_rgb(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        if self.fill_back:
-            faces = self._fill_back_faces(faces)
-            textures = self._fill_back_textures(textures)
-        if not self.no_light:
-            textures = self._light(vertices, faces, textures)
-        vertices = self.project(vertices, K=K, R=R, t=t, dist_coeffs=dist_coeffs, orig_size=orig_size)
-        faces = nr.vertices_to_faces(vertices, faces)
-        images = rasterize.rasterize(
-            faces,
-            textures,
-            self.image_size,
-            self.anti_aliasing,
-            self.near,
-            self.far,
-            self.rasterizer_eps,
-            self.background_color,
-        )
-        return images
-
-    def render_vertex_colors(self, vertices, faces, vertex_colors, K=None, R=None, t=None, dist_coeffs=None,
-                             orig_size=None):
-        """``render(vertices, faces, batch_vertex_textures(faces, vertex_colors), ...,
-        detach_renders=True)`` through the fused vertex-colour kernels: same dict, same values,
-        gradient w.r.t. ``vertex_colors`` only.  Used by opticalflow.get_opticalflow (the training
-        path renders exactly this: opticalflow.py:101-108 with detach_renders=True).  Not available
-        with lighting (``no_light=False``)."""
-        if not self.no_light:
-            raise ValueError("render_vertex_colors requires no_light=True")
-        v = self.project(vertices, K=K, R=R, t=t, dist_coeffs=dist_coeffs, orig_size=orig_size).detach()
-        return rasterize.rasterize_vertex_colors(
-            v, faces, vertex_colors, self.fill_back, self.image_size, self.anti_aliasing, self.near, self.far,
-            self.rasterizer_eps, self.background_color)
+        coords, textures = self._face_coordinates(
+            vertices, faces, textures, camera=(K, R, t, dist_coeffs, orig_size), light=not self.no_light)
+        return rasterize.rasterize(
+            coords, textures, self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,
+            self.background_color)
 
     def render(
         self,
@@ -237,24 +181,24 @@ class Renderer(nn.Module):
         orig_size=None,
         detach_renders=False,
     ):
-        """rgb + alpha + depth + index/weight maps as a dict (reference renderer.py:237-295)."""
-        if self.fill_back:
-            faces = self._fill_back_faces(faces)
-            textures = self._fill_back_textures(textures)
+        """rgb + alpha + depth + index / weight / inverse maps as a dict; ``detach_renders`` cuts the
+        gradient to the face POSITIONS (the texture values stay differentiable)."""
+        coords, textures = self._face_coordinates(
+            vertices, faces, textures, camera=(K, R, t, dist_coeffs, orig_size), light=not self.no_light,
+            detach=detach_renders)
+        return rasterize.rasterize_rgbad(
+            coords, textures, self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,
+            self.background_color)
+
+    def render_vertex_colors(self, vertices, faces, vertex_colors, K=None, R=None, t=None, dist_coeffs=None,
+                             orig_size=None):
+        """``render(vertices, faces, batch_vertex_textures(faces, vertex_colors), ...,
+        detach_renders=True)`` through the fused vertex-colour kernels: same dict, same values,
+        gradient w.r.t. ``vertex_colors`` only.  This is what the optical-flow path renders.  Not
+        available with lighting (``no_light=False``)."""
         if not self.no_light:
-            textures = self._light(vertices, faces, textures)
-        vertices = self.project(vertices, K=K, R=R, t=t, dist_coeffs=dist_coeffs, orig_size=orig_size)
-        faces = nr.vertices_to_faces(vertices, faces)
-        if detach_renders:
-            faces = faces.detach()
-        out = rasterize.rasterize_rgbad(
-            faces,
-            textures,
-            self.image_size,
-            self.anti_aliasing,
-            self.near,
-            self.far,
-            self.rasterizer_eps,
-            self.background_color,
-        )
-        return out
+            raise ValueError("render_vertex_colors requires no_light=True")
+        v = self.project(vertices, K, R, t, dist_coeffs, orig_size).detach()
+        return rasterize.rasterize_vertex_colors(
+            v, faces, vertex_colors, self.fill_back, self.image_size, self.anti_aliasing, self.near, self.far,
+            self.rasterizer_eps, self.background_color)

@@ -1,11 +1,11 @@
-"""Drop-in for meshreg/optim/lossutils.py (reference lossutils.py:1-8)."""
+"""Per-sample masked mean -- same contract as meshreg/optim/lossutils.py:1-8 (pinned by
+tests/golden/warp_misc.npz): mean of `dists` over the elements where `mask` is set, computed
+separately for every batch entry; an entry whose mask is empty yields 0 (divides by 1)."""
+import torch
 
 
 def batch_masked_mean_loss(dists, mask):
-    mask = mask.float()
-    batch_sum = (mask * dists).sum(dim=list(range(1, dists.dim())))
-    batch_valid_vals = mask.sum(dim=list(range(1, dists.dim())))
-    # Don't divide by 0
-    batch_valid_vals = batch_valid_vals.masked_fill(batch_valid_vals == 0, 1)
-    batch_losses = batch_sum / batch_valid_vals
-    return batch_losses
+    weights = mask.to(dists.dtype).flatten(1)
+    numer = (weights * dists.flatten(1)).sum(1)
+    count = weights.sum(1)
+    return numer / torch.where(count == 0, torch.ones_like(count), count)
