@@ -258,8 +258,9 @@ def main():
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
 
-        net = DDP(model, device_ids=[local_rank], bucket_cap_mb=8, gradient_as_bucket_view=True,
-                  broadcast_buffers=False)  # frozen BN stats; 3 forwards per step share the buffers
+        # 8 MB buckets overlap the RCCL all-reduce with the encoder backward; frozen BN statistics
+        # -> no buffer broadcast (the three forwards of a step share the buffers)
+        net = DDP(model, device_ids=[local_rank], bucket_cap_mb=8, broadcast_buffers=False)
     premodel = WarpRegNet((is_, is_), net, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
                           progressive_steps=1000, use_backward=True, mano_faces=model.mano_layer.th_faces,
                           pair_outputs="loss").to(dev)
@@ -338,6 +339,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

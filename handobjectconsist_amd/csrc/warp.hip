@@ -122,6 +122,38 @@ __device__ __forceinline__ void bilin_grad(const float* __restrict__ plane, cons
     bilin_grad(plane, t, tap_addr(t, W, H), gix, giy);
 }
 
+// Raw values of the four taps of one channel plane.  Loading them into a Quad first and pinning
+// them with `pin()` keeps the loads UNCONDITIONAL and back to back: otherwise the compiler sinks
+// each load into the branch of its in-bounds select and waits for it there (one exposed HBM
+// round trip per tap instead of one per batch).
+struct Quad {
+    float nw, ne, sw, se;
+};
+__device__ __forceinline__ Quad load_quad(const float* __restrict__ plane, const TapAddr& a) {
+    Quad q;
+    q.nw = plane[a.a_nw]; q.ne = plane[a.a_ne]; q.sw = plane[a.a_sw]; q.se = plane[a.a_se];
+    return q;
+}
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(Quad& q) { pin(q.nw); pin(q.ne); pin(q.sw); pin(q.se); }
+__device__ __forceinline__ float bilin_q(const Quad& q, const Taps& t, const TapAddr& a) {
+    float acc = 0.0f;
+    acc = a.b_nw ? acc + q.nw * t.nw : acc;
+    acc = a.b_ne ? acc + q.ne * t.ne : acc;
+    acc = a.b_sw ? acc + q.sw * t.sw : acc;
+    acc = a.b_se ? acc + q.se * t.se : acc;
+    return acc;
+}
+__device__ __forceinline__ void bilin_grad_q(const Quad& q, const Taps& t, const TapAddr& a, float& gix, float& giy) {
+    const float fx = (float)t.x0, fy = (float)t.y0;
+    const float ix_se = fx + 1.0f, iy_se = fy + 1.0f;
+    gix = 0.0f; giy = 0.0f;
+    if (a.b_nw) { gix -= q.nw * (iy_se - t.iy); giy -= q.nw * (ix_se - t.ix); }
+    if (a.b_ne) { gix += q.ne * (iy_se - t.iy); giy -= q.ne * (t.ix - fx); }
+    if (a.b_sw) { gix -= q.sw * (t.iy - fy); giy += q.sw * (ix_se - t.ix); }
+    if (a.b_se) { gix += q.se * (t.iy - fy); giy += q.se * (t.ix - fx); }
+}
+
 __device__ __forceinline__ void nearest_idx(float ix, float iy, int& xn, int& yn) {
     const float rx = rintf(ix), ry = rintf(iy);  // round half to even, as nearbyint
     xn = (rx == rx) ? (int)fminf(fmaxf(rx, -4.0f), 1.0e9f) : -4;
@@ -398,36 +430,67 @@ struct DirOut {
     bool valid;
 };
 
-__device__ __forceinline__ DirOut pair_dir(const float* __restrict__ flow, const float* __restrict__ src,
-                                           const float* __restrict__ jwarp, const float* __restrict__ jdirect,
-                                           int Cj, bool all_jitter_channels, int b, int xx, int yy, int H, int W,
-                                           float thresh, Taps& t, TapAddr& a) {
+// One direction at one pixel, in three steps so that every global load of the pixel is in
+// flight before anything waits:  pair_taps (flow -> tap addresses),  pair_load (raw tap values of
+// the 3 source channels and of the jitter mask, the target pixel, the direct jitter value),
+// pair_eval (masks, warped values).
+struct DirTaps {
+    Taps t;
+    TapAddr a;
+    float2 uv;
+};
+struct DirRaw {
+    Quad src[3];
+    Quad jit[3];
+    float tgt[3];
+    float jd;
+};
+
+__device__ __forceinline__ DirTaps pair_taps(const float* __restrict__ flow, int b, int xx, int yy, int H, int W) {
     const int64_t hw = (int64_t)H * W;
-    const int64_t pix = (int64_t)yy * W + xx;
-    const float2 uv = *reinterpret_cast<const float2*>(flow + ((int64_t)b * hw + pix) * 2);
-    const float jd = jdirect[(int64_t)b * Cj * hw + pix];
+    DirTaps d;
+    d.uv = *reinterpret_cast<const float2*>(flow + ((int64_t)b * hw + (int64_t)yy * W + xx) * 2);
     float ix, iy;
-    sample_pos((float)xx, (float)yy, uv.x, uv.y, W, H, ix, iy);
-    t = make_taps(ix, iy);
-    a = tap_addr(t, W, H);
-    DirOut o;
-    o.m = valid_mask(t, W, H, thresh);
-    float sv[3], jv[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) sv[c] = bilin(src + ((int64_t)b * 3 + c) * hw, t, a);
-    jv[0] = bilin(jwarp + (int64_t)b * Cj * hw, t, a);
-    jv[1] = jv[0]; jv[2] = jv[0];
-    if (all_jitter_channels && Cj == 3) {
-        jv[1] = bilin(jwarp + ((int64_t)b * Cj + 1) * hw, t, a);
-        jv[2] = bilin(jwarp + ((int64_t)b * Cj + 2) * hw, t, a);
-    }
+    sample_pos((float)xx, (float)yy, d.uv.x, d.uv.y, W, H, ix, iy);
+    d.t = make_taps(ix, iy);
+    d.a = tap_addr(d.t, W, H);
+    return d;
+}
+
+__device__ __forceinline__ void pair_load(const DirTaps& d, const float* __restrict__ src,
+                                          const float* __restrict__ tgt, const float* __restrict__ jwarp,
+                                          const float* __restrict__ jdirect, int Cj, bool all_jitter_channels,
+                                          int b, int64_t pix, int64_t hw, DirRaw& r) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        o.s[c] = sv[c] * o.m;
-        const float js = jv[c] * o.m;
+        r.src[c] = load_quad(src + ((int64_t)b * 3 + c) * hw, d.a);
+        r.tgt[c] = tgt[((int64_t)b * 3 + c) * hw + pix];
+    }
+    r.jit[0] = load_quad(jwarp + (int64_t)b * Cj * hw, d.a);
+    r.jit[1] = r.jit[0]; r.jit[2] = r.jit[0];
+    if (all_jitter_channels && Cj == 3) {
+        r.jit[1] = load_quad(jwarp + ((int64_t)b * Cj + 1) * hw, d.a);
+        r.jit[2] = load_quad(jwarp + ((int64_t)b * Cj + 2) * hw, d.a);
+    }
+    r.jd = jdirect[(int64_t)b * Cj * hw + pix];
+}
+
+__device__ __forceinline__ void pin(DirRaw& r) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { pin(r.src[c]); pin(r.jit[c]); pin(r.tgt[c]); }
+    pin(r.jd);
+}
+
+__device__ __forceinline__ DirOut pair_eval(const DirTaps& d, const DirRaw& r, int H, int W, float thresh) {
+    DirOut o;
+    o.m = valid_mask(d.t, W, H, thresh);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        o.s[c] = bilin_q(r.src[c], d.t, d.a) * o.m;
+        const float js = bilin_q(r.jit[c], d.t, d.a) * o.m;
         o.wm[c] = o.m * ((js == 1.0f) ? 1.0f : 0.0f);
     }
-    o.valid = (o.wm[0] != 0.0f) && (uv.x != 0.0f) && (jd == 1.0f);
+    o.valid = (o.wm[0] != 0.0f) && (d.uv.x != 0.0f) && (r.jd == 1.0f);
     return o;
 }
 
@@ -468,20 +531,22 @@ __global__ void __launch_bounds__(256) pair_consist_forward_kernel(PairParams p)
     float sum1 = 0.0f, cnt1 = 0.0f, sum2 = 0.0f, cnt2 = 0.0f;
     if (in_img) {
         const int64_t pix = (int64_t)yy * p.W + xx;
-        Taps t;
-        TapAddr a;
         const bool allj = p.warp_mask1 != nullptr || p.warp_mask2 != nullptr;
         // forward term: image_ref warped by flow21 vs image (imgflowarp.py:80,85-87,93-102)
-        const DirOut d1 = pair_dir(p.flow21, p.image_ref, p.jitter, p.jitter, p.Cj, allj, b, xx, yy, p.H, p.W,
-                                   p.thresh, t, a);
         // backward term: image warped by flow12 vs image_ref (:84,82,88,99-107)
-        const DirOut d2 = pair_dir(p.flow12, p.image, p.jitter_ref, p.jitter_ref, p.Cj, allj, b, xx, yy, p.H, p.W,
-                                   p.thresh, t, a);
+        const DirTaps t1 = pair_taps(p.flow21, b, xx, yy, p.H, p.W);
+        const DirTaps t2 = pair_taps(p.flow12, b, xx, yy, p.H, p.W);
+        DirRaw r1, r2;
+        pair_load(t1, p.image_ref, p.image, p.jitter, p.jitter, p.Cj, allj, b, pix, hw, r1);
+        pair_load(t2, p.image, p.image_ref, p.jitter_ref, p.jitter_ref, p.Cj, allj, b, pix, hw, r2);
+        pin(r1); pin(r2);
+        const DirOut d1 = pair_eval(t1, r1, p.H, p.W, p.thresh);
+        const DirOut d2 = pair_eval(t2, r2, p.H, p.W, p.thresh);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int64_t o = ((int64_t)b * 3 + c) * hw + pix;
-            const float df = fabsf(d1.s[c] - p.image[o]);
-            const float db = fabsf(d2.s[c] - p.image_ref[o]);
+            const float df = fabsf(d1.s[c] - r1.tgt[c]);
+            const float db = fabsf(d2.s[c] - r2.tgt[c]);
             if (d1.valid) sum1 += df;
             if (d2.valid) sum2 += db;
             if (p.warp1) p.warp1[o] = d1.s[c];
@@ -545,26 +610,19 @@ struct PairBwdParams {
     float thresh;
 };
 
-__device__ __forceinline__ float2 pair_dir_grad(const float* __restrict__ src, const float* __restrict__ tgt,
-                                                const DirOut& d, const Taps& t, const TapAddr& a, int b,
-                                                int64_t pix, int H, int W, float coef) {
+__device__ __forceinline__ float2 pair_grad(const DirTaps& d, const DirRaw& r, const DirOut& o, int H, int W,
+                                             float coef) {
     float gu = 0.0f, gv = 0.0f;
-    const int64_t hw = (int64_t)H * W;
-    float tg[3], gix[3], giy[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const int64_t o = ((int64_t)b * 3 + c) * hw;
-        tg[c] = tgt[o + pix];
-        bilin_grad(src + o, t, a, gix[c], giy[c]);
-    }
-    if (d.valid && coef != 0.0f) {
+    if (o.valid && coef != 0.0f) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const float r = d.s[c] - tg[c];
-            const float sg = (r > 0.0f) ? 1.0f : ((r < 0.0f) ? -1.0f : 0.0f);
-            const float g = sg * coef * d.m;
-            gu += g * gix[c];
-            gv += g * giy[c];
+            float gix, giy;
+            bilin_grad_q(r.src[c], d.t, d.a, gix, giy);
+            const float res = o.s[c] - r.tgt[c];
+            const float sg = (res > 0.0f) ? 1.0f : ((res < 0.0f) ? -1.0f : 0.0f);
+            const float g = sg * coef * o.m;
+            gu += g * gix;
+            gv += g * giy;
         }
         gu = gu * ((float)W / 2.0f) * (2.0f / (float)max(W - 1, 1));
         gv = gv * ((float)H / 2.0f) * (2.0f / (float)max(H - 1, 1));
@@ -580,17 +638,20 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
     const float c1 = p.sums[b * 4 + 1], c2 = p.sums[b * 4 + 3];
     const float coef1 = p.grad_loss_fwd[b] / ((c1 == 0.0f) ? 1.0f : c1);
     const float coef2 = p.grad_loss_bwd ? p.grad_loss_bwd[b] / ((c2 == 0.0f) ? 1.0f : c2) : 0.0f;
-    Taps t1, t2;
-    TapAddr a1, a2;
-    const DirOut d1 = pair_dir(p.flow21, p.image_ref, p.jitter, p.jitter, p.Cj, false, b, xx, yy, p.H, p.W,
-                               p.thresh, t1, a1);
-    const float2 g21 = pair_dir_grad(p.image_ref, p.image, d1, t1, a1, b, pix, p.H, p.W, coef1);
-    *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = g21;
+    const bool both = p.grad_loss_bwd != nullptr;
+    const DirTaps t1 = pair_taps(p.flow21, b, xx, yy, p.H, p.W);
+    const DirTaps t2 = pair_taps(both ? p.flow12 : p.flow21, b, xx, yy, p.H, p.W);
+    DirRaw r1, r2;
+    pair_load(t1, p.image_ref, p.image, p.jitter, p.jitter, p.Cj, false, b, pix, hw, r1);
+    if (both) pair_load(t2, p.image, p.image_ref, p.jitter_ref, p.jitter_ref, p.Cj, false, b, pix, hw, r2);
+    else r2 = r1;
+    pin(r1); pin(r2);
+    const DirOut d1 = pair_eval(t1, r1, p.H, p.W, p.thresh);
+    *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = pair_grad(t1, r1, d1, p.H, p.W, coef1);
     float2 g12 = make_float2(0.0f, 0.0f);
-    if (p.grad_loss_bwd) {
-        const DirOut d2 = pair_dir(p.flow12, p.image, p.jitter_ref, p.jitter_ref, p.Cj, false, b, xx, yy, p.H, p.W,
-                                   p.thresh, t2, a2);
-        g12 = pair_dir_grad(p.image, p.image_ref, d2, t2, a2, b, pix, p.H, p.W, coef2);
+    if (both) {
+        const DirOut d2 = pair_eval(t2, r2, p.H, p.W, p.thresh);
+        g12 = pair_grad(t2, r2, d2, p.H, p.W, coef2);
     }
     *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = g12;
 }
