@@ -256,3 +256,26 @@ def test_vertex_color_render_matches_generic_path_and_oracle(cuda, fill_back, aa
     # (vertices are projected by torch on the GPU here and by numpy in the oracle chain: the face
     # coordinates differ in the last bit, hence 1e-4 of the colour range instead of 1e-6)
     assert_close(out_vc["rgb"].detach().cpu().numpy(), ref["rgb"], 1e-4, 3e-4, "rgb vs oracle")
+
+
+@pytest.mark.parametrize("ts", [3, 4])
+def test_generic_texture_size_and_per_sample_background(cuda, ts):
+    """Textures larger than 2x2x2 (per-pixel-atomics backward on recomputed sampling weights) and a
+    [B,3] background colour (rasterize.py:254-258)."""
+    from handobjectconsist_amd.neurender import rasterize
+
+    B, is_ = 2, 64
+    faces, _ = projected_faces(B, is_, 17)
+    rng = np.random.default_rng(ts)
+    tex = rng.uniform(-1, 1, (B, faces.shape[1], ts, ts, ts, 3)).astype(np.float32)
+    bg = [[0.1, 0.2, 0.3], [0.9, 0.8, 0.7]]
+    ref = R.rasterize_rgbad(faces, tex, is_, False, 0.1, 100, 1e-3, bg, num_threads=8, keep_saved=True)
+    x_t = t(tex, cuda).requires_grad_(True)
+    out = rasterize.rasterize_rgbad(t(faces, cuda), x_t, is_, False, 0.1, 100, 1e-3, bg)
+    assert (out["face_index_map"].cpu().numpy() != ref["face_index_map"]).sum() == 0
+    assert_close(out["rgb"].detach().cpu().numpy(), ref["rgb"], 1e-6, 1e-6, "rgb")
+    assert np.allclose(out["rgb"].detach().cpu().numpy()[1, :, 0, 0], bg[1])
+    raster_g, img_g = _img_grads(ref["_saved"], ts)
+    _, gt_ref = R.rasterize_backward(ref["_saved"], raster_g[0], None, None, num_threads=8)
+    out["rgb"].backward(t(img_g[0], cuda))
+    assert_close(x_t.grad.cpu().numpy(), gt_ref, 1e-4, 1e-5 * np.abs(gt_ref).max(), "grad_textures")
