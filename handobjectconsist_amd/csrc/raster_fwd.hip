@@ -60,6 +60,12 @@ struct ImageHdr {
 
 // {x0 | x1 << 16, y0 | y1 << 16, face index, unused}
 typedef uint4 FaceRec;
+// the 9 coordinates of a live face, stored next to its record (slot-parallel array, 48-B stride)
+// so that the tile kernel fetches a face with ONE load phase instead of chasing
+// record -> vertex indices -> vertices
+struct __attribute__((aligned(16))) RecVerts {
+    float v[12];
+};
 
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -71,6 +77,7 @@ __device__ __forceinline__ int wave_max(int v) {
 __global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict__ faces,
                                                          ImageHdr* __restrict__ hdrs,
                                                          FaceRec* __restrict__ recs,
+                                                         RecVerts* __restrict__ rverts,
                                                          float* __restrict__ faces_inv, int F, int is) {
     const int b = blockIdx.y;
     const int fn = blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,6 +110,10 @@ __global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict
         r.z = (unsigned)fn;
         r.w = 0u;
         recs[(int64_t)b * F + slot] = r;
+        float4* rv = reinterpret_cast<float4*>(rverts + (int64_t)b * F + slot);
+        rv[0] = make_float4(f[0], f[1], f[2], f[3]);
+        rv[1] = make_float4(f[4], f[5], f[6], f[7]);
+        rv[2] = make_float4(f[8], 0.0f, 0.0f, 0.0f);
     }
     const int nx0 = wave_max(live ? is - bx.x0 : 0), x1p = wave_max(live ? bx.x1 + 1 : 0);
     const int ny0 = wave_max(live ? is - bx.y0 : 0), y1p = wave_max(live ? bx.y1 + 1 : 0);
@@ -119,7 +130,8 @@ __global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) face_setup_vc_kernel(const float* __restrict__ verts,
                                                             const int32_t* __restrict__ fidx,
                                                             ImageHdr* __restrict__ hdrs,
-                                                            FaceRec* __restrict__ recs, int V, int F0,
+                                                            FaceRec* __restrict__ recs,
+                                                            RecVerts* __restrict__ rverts, int V, int F0,
                                                             int fill_back, int is) {
     const int b = blockIdx.y;
     const int f0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -161,7 +173,13 @@ __global__ void __launch_bounds__(256) face_setup_vc_kernel(const float* __restr
                 rec.y = (unsigned)(unsigned short)bx.y0 | ((unsigned)(unsigned short)bx.y1 << 16);
                 rec.z = (unsigned)(o ? f0 + F0 : f0);
                 rec.w = 0u;
-                recs[(int64_t)b * F + base + __popcll(m & ((1ull << lane) - 1ull))] = rec;
+                const int64_t slot = (int64_t)b * F + base + __popcll(m & ((1ull << lane) - 1ull));
+                recs[slot] = rec;
+                const float* fv = o ? r : f;
+                float4* rv = reinterpret_cast<float4*>(rverts + slot);
+                rv[0] = make_float4(fv[0], fv[1], fv[2], fv[3]);
+                rv[1] = make_float4(fv[4], fv[5], fv[6], fv[7]);
+                rv[2] = make_float4(fv[8], 0.0f, 0.0f, 0.0f);
                 nx0 = max(nx0, is - bx.x0); x1p = max(x1p, bx.x1 + 1);
                 ny0 = max(ny0, is - bx.y0); y1p = max(y1p, bx.y1 + 1);
             }
@@ -181,6 +199,7 @@ struct FwdParams {
     const float* faces;
     const ImageHdr* hdrs;
     const FaceRec* recs;
+    const RecVerts* rverts;
     const float* textures;
     const float* background;
     int bg_stride;
@@ -249,6 +268,44 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     const int is = p.is;
     const float fis = (float)is;
 
+    // Tiles the image's faces cannot touch (outside the union bbox of the live faces) are pure
+    // background: stream it with 16-byte stores and leave before any LDS set-up.
+    int n_rec = 0;
+    if (!p.keys) {
+        const ImageHdr h = p.hdrs[b];
+        const bool touch = h.count > 0 && (is - h.nx0) <= tx1 && (h.x1p - 1) >= tx0 && (is - h.ny0) <= ty1 &&
+                           (h.y1p - 1) >= ty0;
+        n_rec = touch ? h.count : 0;
+        if (p.dbg & 1) n_rec = 0;
+        if (FUSED && n_rec == 0 && (is & 3) == 0 && tx0 + TILE_W <= is && ty0 + TILE_H <= is && !p.face_inv_map) {
+            // one 128-B row segment = 8 float4 (scalar planes) / 24 float4 (weight_map, 3 floats per pixel)
+            const int64_t plane = (int64_t)is * is;
+            const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (tid < TILE_H * 8) {
+                const int row = tid >> 3, seg = tid & 7;
+                const int64_t ro = ((int64_t)b * is + ty0 + row) * is + tx0;            // raster orientation
+                const int64_t io = ((int64_t)b * is + (is - 1 - ty0 - row)) * is + tx0;  // image orientation
+                const int m1 = -1;
+                const float fm1 = __int_as_float(m1);
+                reinterpret_cast<float4*>(p.fim + ro)[seg] = make_float4(fm1, fm1, fm1, fm1);
+                if (p.depth) reinterpret_cast<float4*>(p.depth + io)[seg] = make_float4(p.far_, p.far_, p.far_, p.far_);
+                if (p.alpha) reinterpret_cast<float4*>(p.alpha + io)[seg] = zero4;
+                if (p.rgb) {
+                    const float* bg = p.background + (int64_t)b * p.bg_stride;
+                    const int64_t o = ((int64_t)b * 3 * is + (is - 1 - ty0 - row)) * is + tx0;
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        reinterpret_cast<float4*>(p.rgb + o + c * plane)[seg] = make_float4(bg[c], bg[c], bg[c], bg[c]);
+                }
+            }
+            if (tid < TILE_H * 24) {
+                const int row = tid / 24, seg = tid % 24;
+                reinterpret_cast<float4*>(p.weight + (((int64_t)b * is + ty0 + row) * is + tx0) * 3)[seg] = zero4;
+            }
+            return;
+        }
+    }
+
     zbuf[tid] = ~0ull;
     // NDC coordinates of the tile's pixel centres (upstream: (2 * i + 1 - is) / is)
     if (tid < TILE_W) xp_tab[tid] = (float)(2 * (tx0 + tid) + 1 - is) / fis;
@@ -256,21 +313,12 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     __syncthreads();
 
     const FaceRec* recs_b = p.recs + (int64_t)b * p.F;
+    const RecVerts* rv_b = p.rverts + (int64_t)b * p.F;
     int* q = queue[wave];
     float* fc = fcache[wave];
     unsigned* fq = fragq[wave];
     int qhead = 0, qn = 0;  // wave-uniform ring state
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-    int n_rec = 0;
-    if (!p.keys) {
-        const ImageHdr h = p.hdrs[b];
-        // union bbox of the image's live faces: [is - nx0, x1p - 1] x [is - ny0, y1p - 1]
-        const bool touch = h.count > 0 && (is - h.nx0) <= tx1 && (h.x1p - 1) >= tx0 && (is - h.ny0) <= ty1 &&
-                           (h.y1p - 1) >= ty0;
-        n_rec = touch ? h.count : 0;
-        if (p.dbg & 1) n_rec = 0;
-    }
 
     // S3: one lane per fragment -- barycentrics, near/far, depth test
     int fqh = 0, fqn = 0;  // fragment ring (wave-uniform)
@@ -294,11 +342,14 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     auto process_batch = [&](int count) {
         // S1: one lane per face
         if (lane < count && !(p.dbg & 4)) {
-            const FaceRec r = recs_b[q[(qhead + lane) & (QCAP - 1)]];
+            const int ri = q[(qhead + lane) & (QCAP - 1)];
+            const FaceRec r = recs_b[ri];
+            const float4* rv = reinterpret_cast<const float4*>(rv_b + ri);
+            const float4 v0 = rv[0], v1 = rv[1], v2 = rv[2];
             const int fn = (int)r.z;
             Face f;
-            int vid[3];
-            fetch_verts<VC>(p, b, fn, f.v, vid);
+            f.v[0] = v0.x; f.v[1] = v0.y; f.v[2] = v0.z; f.v[3] = v0.w; f.v[4] = v1.x; f.v[5] = v1.y;
+            f.v[6] = v1.z; f.v[7] = v1.w; f.v[8] = v2.x;
             face_inverse(f.v, f.inv, is);
             float* c = fc + lane * FC_STRIDE;
 #pragma unroll
@@ -333,42 +384,44 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
                 ey[0] = (yp - ay) * (bx - ax); ey[1] = (yp - by) * (cx_ - bx); ey[2] = (yp - cy_) * (ax - cx_);
             }
             int lo = lx0, hi = lx1;
+            // T_k(x) = accepted_k(x) XOR (dy_k < 0) is prefix-true on [lx0, lx1] (accepted set of edge k:
+            // a prefix if dy_k > 0 -- or dy_k == 0: all or nothing --, a suffix if dy_k < 0).  Bisection
+            // with the exact predicate finds l_k = last x with T_k true (lx0 - 1 if none); the three
+            // edges advance together, depth = ceil(log2(widest range of the wave)).
+            const int range = wave_max(act ? lx1 - lx0 + 2 : 0);
+            const int steps = (p.dbg & 32) ? 0 : 32 - __clz(max(range, 1));
+            int l[3] = {lx0 - 1, lx0 - 1, lx0 - 1}, h[3] = {lx1 + 1, lx1 + 1, lx1 + 1};
+            const bool dec[3] = {dy[0] < 0.0f, dy[1] < 0.0f, dy[2] < 0.0f};
+            for (int it = 0; it < steps; it++) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int mid = (l[k] + h[k]) >> 1;
+                    const float xp = xp_tab[max(mid, 0) & (TILE_W - 1)];
+                    const bool t = (!(ey[k] < (xp - ea[k]) * dy[k])) != dec[k];
+                    const bool go = h[k] - l[k] > 1;
+                    l[k] = (go && t) ? mid : l[k];
+                    h[k] = (go && !t) ? mid : h[k];
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                // accepted set of edge k on this row: a prefix of [lx0, lx1] if dy > 0 (or dy == 0: all
-                // or nothing), a suffix if dy < 0.  T(x) = accepted(x) XOR (dy < 0) is prefix-true.
-                const bool dec = dy[k] < 0.0f;
-                int l = lx0 - 1, h = lx1 + 1;
-#pragma unroll
-                for (int it = 0; it < 6; it++) {
-                    const int mid = (l + h) >> 1;
-                    const float xp = xp_tab[max(mid, 0) & (TILE_W - 1)];
-                    const bool acc = !(ey[k] < (xp - ea[k]) * dy[k]);
-                    const bool go = h - l > 1;
-                    const bool t = acc != dec;
-                    l = (go && t) ? mid : l;
-                    h = (go && !t) ? mid : h;
-                }
-                // l = last x with T true (lx0 - 1 if none)
-                if (dec) lo = max(lo, l + 1); else hi = min(hi, l);
+                if (dec[k]) lo = max(lo, l[k] + 1); else hi = min(hi, l[k]);
             }
-            int len = act ? max(hi - lo + 1, 0) : 0;
+            int len = (act && !(p.dbg & 64)) ? max(hi - lo + 1, 0) : 0;
             int x = lo;
             // emit the spans as fragments, at most 4 pixels per lane per round
             while (__ballot(len > 0) != 0ull) {
                 const int c = min(len, 4);
-                int incl = c;
+                int total = 0;
 #pragma unroll
-                for (int d = 1; d < MR_WAVE; d <<= 1) {
-                    const int t = __shfl_up(incl, d);
-                    if (lane >= d) incl += t;
-                }
-                const int off = incl - c, total = __shfl(incl, MR_WAVE - 1);
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (i < c)
-                        fq[(fqh + fqn + off + i) & (FQCAP - 1)] =
+                for (int i = 0; i < 4; i++) {
+                    const bool has = i < c;
+                    const unsigned long long m = __ballot(has);
+                    if (has)
+                        fq[(fqh + fqn + total + __popcll(m & lt_mask)) & (FQCAP - 1)] =
                             ((unsigned)slot << 16) | ((unsigned)row << 8) | (unsigned)(x + i);
+                    total += __popcll(m);
+                }
                 x += c; len -= c; fqn += total;
                 __builtin_amdgcn_wave_barrier();
                 while (fqn >= MR_WAVE) {
@@ -600,20 +653,22 @@ __global__ void __launch_bounds__(256) face_inv_map_kernel(const float* __restri
     for (int k = 0; k < 9; k++) out[i * 9 + k] = inv[k];
 }
 
-// workspace layout: [B] ImageHdr (zeroed per call) | [B * F] FaceRec
+// workspace layout: [B] ImageHdr (zeroed per call) | [B * F] FaceRec | [B * F] RecVerts
 static inline size_t hdr_bytes(int B) { return (((size_t)B * sizeof(ImageHdr)) + 255) & ~(size_t)255; }
+static inline size_t rec_bytes(int B, int F) { return (((size_t)B * F * sizeof(FaceRec)) + 255) & ~(size_t)255; }
 
 static int launch_setup(const float* faces, void* workspace, float* faces_inv, int B, int F, int is,
                         hipStream_t s) {
     if (B == 0) return MR_OK;
     ImageHdr* hdrs = (ImageHdr*)workspace;
     FaceRec* recs = (FaceRec*)((char*)workspace + hdr_bytes(B));
+    RecVerts* rverts = (RecVerts*)((char*)workspace + hdr_bytes(B) + rec_bytes(B, F));
     hipError_t e = hipMemsetAsync(hdrs, 0, hdr_bytes(B), s);
     if (e != hipSuccess) return (int)e;
     if (F == 0) return MR_OK;
     if (B > 65535) return MR_ERR_BADARG;
     hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, faces,
-                       hdrs, recs, faces_inv, F, is);
+                       hdrs, recs, rverts, faces_inv, F, is);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -637,8 +692,8 @@ using namespace mr;
 extern "C" int64_t mr_render_workspace_bytes(int batch_size, int num_faces, int image_size) {
     (void)image_size;
     if (batch_size < 0 || num_faces < 0) return MR_ERR_BADARG;
-    return (int64_t)hdr_bytes(batch_size) +
-           ((((int64_t)batch_size * num_faces * (int64_t)sizeof(FaceRec)) + 255) & ~255LL);
+    return (int64_t)hdr_bytes(batch_size) + (int64_t)rec_bytes(batch_size, num_faces) +
+           ((((int64_t)batch_size * num_faces * (int64_t)sizeof(RecVerts)) + 255) & ~255LL);
 }
 
 extern "C" int mr_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
@@ -661,6 +716,7 @@ extern "C" int mr_forward_face_index_map(const float* faces, int32_t* face_index
         FwdParams p{};
         p.faces = faces; p.hdrs = (const ImageHdr*)work;
         p.recs = (const FaceRec*)((const char*)work + hdr_bytes(batch_size));
+        p.rverts = (const RecVerts*)((const char*)work + hdr_bytes(batch_size) + rec_bytes(batch_size, num_faces));
         p.depth = depth_map; p.fim = face_index_map;
         p.weight = weight_map; p.face_inv_map = return_depth ? face_inv_map : nullptr;
         p.B = batch_size; p.F = num_faces; p.is = image_size; p.ts = 1;
@@ -714,6 +770,7 @@ extern "C" int mr_render_forward(const float* faces, const float* textures, cons
     FwdParams p{};
     p.faces = faces; p.hdrs = (const ImageHdr*)workspace;
     p.recs = (const FaceRec*)((const char*)workspace + hdr_bytes(batch_size));
+    p.rverts = (const RecVerts*)((const char*)workspace + hdr_bytes(batch_size) + rec_bytes(batch_size, num_faces));
     p.textures = textures; p.background = background;
     p.bg_stride = bg_stride;
     p.rgb = return_rgb ? rgb_img : nullptr;
@@ -773,15 +830,17 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
     hipStream_t s = (hipStream_t)stream;
     ImageHdr* hdrs = (ImageHdr*)workspace;
     FaceRec* recs = (FaceRec*)((char*)workspace + hdr_bytes(batch_size));
+    RecVerts* rverts = (RecVerts*)((char*)workspace + hdr_bytes(batch_size) + rec_bytes(batch_size, F));
     hipError_t e = hipMemsetAsync(hdrs, 0, hdr_bytes(batch_size), s);
     if (e != hipSuccess) return (int)e;
     if (num_faces > 0) {
         hipLaunchKernelGGL(face_setup_vc_kernel, dim3((unsigned)((num_faces + 255) / 256), (unsigned)batch_size),
-                           dim3(256), 0, s, verts, faces_idx, hdrs, recs, num_verts, num_faces, fill_back, image_size);
+                           dim3(256), 0, s, verts, faces_idx, hdrs, recs, rverts, num_verts, num_faces, fill_back,
+                           image_size);
         MR_CHECK_LAUNCH();
     }
     FwdParams p{};
-    p.hdrs = hdrs; p.recs = recs; p.background = background; p.bg_stride = bg_stride;
+    p.hdrs = hdrs; p.recs = recs; p.rverts = rverts; p.background = background; p.bg_stride = bg_stride;
     p.rgb = return_rgb ? rgb_img : nullptr;
     p.alpha = return_alpha ? alpha_img : nullptr;
     p.depth = return_depth ? depth_img : nullptr;

@@ -26,7 +26,8 @@ wbytes = int(lib.mr_render_workspace_bytes(B, F, is_)); work = torch.empty((wbyt
 bg = torch.zeros(3, **f32)
 for name, dbg in (("full", 0), ("no scan (background fill only)", 1), ("scan+drain, no resolve", 2), ("scan only (no drain), no resolve", 6),
                   ("scan only + resolve", 4), ("nothing (zbuf init only)", 3), ("scan + S1, no resolve", 10),
-                  ("scan + S1 + S2 (no shade), no resolve", 18)):
+                  ("scan + S1 + S2 (no shade), no resolve", 18), ("... S2 without search (bbox spans)", 18 + 32),
+                  ("... S2 without emission", 18 + 64), ("... S2 without search and emission", 18 + 96)):
     fn = lambda: _lib.call("mr_render_forward", P(faces), P(tex2), P(bg), 0, P(rgb), P(alpha), P(depth), P(fim), P(wmap),
                            None, P(work), wbytes, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, dbg << 8, st)
     print(f"{name:40s} {bench.event_time_ms(fn, 30) * 1e3:8.1f} us")

@@ -51,7 +51,7 @@ def test_argument_validation_needs_no_device():
 
     lib = _lib.load()
     assert lib.mr_render_workspace_bytes(-1, 10, 64) == -1
-    assert lib.mr_render_workspace_bytes(2, 100, 64) >= 2 * 100 * 16
+    assert lib.mr_render_workspace_bytes(2, 100, 64) >= 2 * 100 * (16 + 48)
     assert lib.mr_pair_consist_workspace_bytes(4, 256, 256) == 4 * 4 * 64 * 16
     assert lib.mr_pair_consist_workspace_bytes(1, 0, 5) == -1
     null = ctypes.c_void_p(None)
