@@ -478,6 +478,174 @@ __global__ void __launch_bounds__(256) gather_vc_kernel(GatherVCParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// E for the vertex-colour mode, pixel-parallel: the default when the per-image colour table fits LDS
+// ---------------------------------------------------------------------------------------
+// One block owns a SV_W x SV_H pixel region of one image.  face_index_map is read once, coalesced
+// (a wave = one 64-pixel row segment, 256 B); regions without geometry leave after that single load.
+// Covered pixels are compacted per wave (ballot + popcount) so that the shading stage runs with
+// full lanes: lane per fragment -- index triple, three projected vertices, inverse, barycentrics,
+// sampling weights, the pixel's rgb gradient -- and adds its 9 products into a block-private
+// [V,3] table in LDS.  The table is flushed with one global fp32 atomic per touched (vertex,
+// channel): a few thousand per image instead of 9 per visible face, and no probing of face
+// bounding boxes at all.
+//
+// The LDS table is 64-bit FIXED POINT, not fp32: ds_add_f32 is several times slower than the
+// integer LDS atomics on gfx950 (measured: the 9 float adds per fragment cost more than everything
+// else in this kernel together).  Every product w * g is bounded by the largest |g| of the region
+// (the sampling weights are in [0,1]), so with that maximum < 2^e the products are scaled by
+// 2^(SV_FIX_BITS - e), truncated to int64 and summed exactly; <= 3 * SV_W * SV_H terms of
+// magnitude < 2^SV_FIX_BITS cannot overflow.  The absolute error per term is 2^-50 of the region's
+// largest gradient -- far below fp32 rounding of the sum -- and the block's sums do not depend on
+// the order of the additions.  Regions whose gradient holds an Inf / NaN take a plain fp32
+// global-atomic path so that non-finite values propagate as they do in the gather kernel.
+constexpr int SV_WAVES = 8;                                     // waves per block
+constexpr int SV_RPW = 4, SV_W = 64, SV_H = SV_WAVES * SV_RPW;  // rows per wave, region
+constexpr int SV_MAX_TABLE_BYTES = 56 * 1024;
+constexpr int SV_FIX_BITS = 50;
+static_assert(3LL * SV_W * SV_H < (1LL << (62 - SV_FIX_BITS)), "fixed-point sums must not overflow");
+
+__global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(GatherVCParams p, int rx_n, int ry_n) {
+    extern __shared__ long long vtab[];  // [V * 3] rounded up to an even count
+    __shared__ unsigned frag[SV_WAVES][SV_RPW * MR_WAVE];  // fn << 8 | row << 6 | column
+    __shared__ unsigned wmax[SV_WAVES];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int rx = (int)(blk % (unsigned)rx_n), ry = (int)((blk / (unsigned)rx_n) % (unsigned)ry_n);
+    const int b = (int)(blk / (unsigned)(rx_n * ry_n));
+    const int is = p.is;
+    const int32_t* fim_b = p.fim + (int64_t)b * is * is;
+    const int xi0 = rx * SV_W, yi0 = ry * SV_H + wave * SV_RPW;
+
+    int fnv[SV_RPW];
+#pragma unroll
+    for (int r = 0; r < SV_RPW; r++)
+        fnv[r] = (xi0 + lane < is && yi0 + r < is) ? fim_b[(yi0 + r) * is + xi0 + lane] : -1;
+    bool cov = false;
+#pragma unroll
+    for (int r = 0; r < SV_RPW; r++) cov = cov || fnv[r] >= 0;
+    if (!__syncthreads_or(cov)) return;  // block-uniform
+
+    // largest |gradient| over the region's covered pixels (coalesced row reads), as float bits
+    unsigned mx = 0u;
+    {
+        float g[SV_RPW][3];
+#pragma unroll
+        for (int r = 0; r < SV_RPW; r++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                g[r][ch] = fnv[r] >= 0 ? p.grad_rgb[idx3<true>(b, yi0 + r, xi0 + lane, ch, is)] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < SV_RPW; r++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) mx = max(mx, __float_as_uint(g[r][ch]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    if (lane == 0) wmax[wave] = mx;
+
+    const int n2 = (p.V * 3 + 1) >> 1;
+    for (int k = threadIdx.x; k < n2; k += blockDim.x) reinterpret_cast<int4*>(vtab)[k] = make_int4(0, 0, 0, 0);
+
+    // compaction: fragments of this wave's rows, row-major
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < SV_RPW; r++) {
+        const bool won = fnv[r] >= 0;
+        const unsigned long long m = __ballot(won);
+        if (won) frag[wave][n + __popcll(m & lt_mask)] = ((unsigned)fnv[r] << 8) | (unsigned)(r << 6) | (unsigned)lane;
+        n += __popcll(m);
+    }
+    __syncthreads();  // table zeroed, fragment lists and maxima visible
+
+    unsigned bm = 0u;
+#pragma unroll
+    for (int k = 0; k < SV_WAVES; k++) bm = max(bm, wmax[k]);
+    if (bm == 0u) return;                   // every gradient of the region is +-0: nothing to add
+    const bool finite = bm < 0x7f800000u;   // else: fp32 global atomics, Inf / NaN propagate
+    const int shift = SV_FIX_BITS - ((int)(bm >> 23) - 126);  // largest |g| < 2^((bm >> 23) - 126)
+
+    const float* verts_b = p.verts + (int64_t)b * p.V * 3;
+    const int32_t* fidx_b = p.fidx + (int64_t)b * p.F0 * 3;
+    float* out = p.grad_vcolors + (int64_t)b * p.V * 3;
+    for (int base = 0; base < n && !(p.dbg & 2); base += MR_WAVE) {
+        if (base + lane < n) {
+            const unsigned fr = frag[wave][base + lane];
+            const int fn = (int)(fr >> 8);
+            const int xi = xi0 + (int)(fr & 63u), yi = yi0 + (int)((fr >> 6) & 3u);
+            const bool o = fn >= p.F0;  // reversed copy of face fn - F0
+            const int32_t* ix = fidx_b + (int64_t)(o ? fn - p.F0 : fn) * 3;
+            int vid[3];
+            float g[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) vid[k] = ix[o ? 2 - k : k];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) g[ch] = p.grad_rgb[idx3<true>(b, yi, xi, ch, is)];
+            Face f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float* q = verts_b + (int64_t)vid[k] * 3;
+                f.v[3 * k] = q[0]; f.v[3 * k + 1] = q[1]; f.v[3 * k + 2] = q[2];
+            }
+            face_inverse(f.v, f.inv, is);
+            float w[3], zp, tif[3];
+            bary(f, xi, yi, zp, w);
+            tex_coords(w, zp, f.v, 2, p.eps, tif);
+            // taps pn = 1, 2, 4 are the texels holding the colours of vertices 0, 1, 2
+            float val[9];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int pn = 1 << k;
+                float wg = 1.0f;
+#pragma unroll
+                for (int j = 0; j < 3; j++) wg *= ((pn >> j) & 1) ? (tif[j] - 0.0f) : (1.0f - (tif[j] - 0.0f));
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) val[k * 3 + ch] = wg * g[ch];
+            }
+            // Neighbouring lanes hold fragments of the same face or of faces sharing a vertex, and
+            // an LDS atomic serialises lanes that hit one address.  Lane l therefore issues its nine
+            // adds in the order (l % 9), (l % 9) + 1, ... so that the lanes of a run work on
+            // different (vertex, channel) cells in any one instruction.
+            const int rot = lane % 9;
+#pragma unroll
+            for (int bit = 1; bit < 16; bit <<= 1) {
+                float t[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) t[k] = val[(k + bit) % 9];
+                const bool on = (rot & bit) != 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) val[k] = on ? t[k] : val[k];
+            }
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                int sl = j + rot;
+                sl = sl >= 9 ? sl - 9 : sl;
+                const int k = (sl >= 3) + (sl >= 6), ch = sl - 3 * k;
+                const int cell = (k == 0 ? vid[0] : (k == 1 ? vid[1] : vid[2])) * 3 + ch;
+                if (p.dbg & 4) {
+                    if (val[j] == 12345.0f) vtab[0] = 1;
+                } else if (finite) {
+                    const long long q = (long long)ldexp((double)val[j], shift);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&vtab[cell]), (unsigned long long)q);
+                } else if (val[j] != 0.0f) {
+                    atomicAdd(&out[cell], val[j]);
+                }
+            }
+        }
+    }
+    if (!finite || (p.dbg & 1)) return;  // block-uniform
+    __syncthreads();
+    for (int k = threadIdx.x; k < p.V * 3; k += blockDim.x) {
+        const long long t = vtab[k];
+        if (t != 0) {
+            const float v = (float)ldexp((double)t, -shift);
+            if (v != 0.0f) atomicAdd(&out[k], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // E, generic texture size: per-pixel atomics on recomputed sampling weights
 // ---------------------------------------------------------------------------------------
 template <bool IMG>
@@ -871,8 +1039,19 @@ extern "C" int mr_render_vc_backward(const float* verts, const int32_t* faces_id
     if (e != hipSuccess) return (int)e;
     if (num_faces == 0) return MR_OK;
     if (!verts || !faces_idx || !face_index_map || !grad_rgb_img || !(eps >= 1e-6f)) return MR_ERR_BADARG;
-    if (image_size > 8192) return MR_ERR_BADARG;  // fragment encoding: 13 bits per bbox offset
     GatherVCParams g{verts, faces_idx, face_index_map, grad_rgb_img, grad_vcolors, batch_size, num_verts, num_faces,
                      fill_back, image_size, eps, flags >> 8};
+    // pixel-parallel scatter when the per-image colour table fits LDS (dbg bit 32 forces the gather)
+    const int64_t table_bytes = (((int64_t)num_verts * 3 + 1) / 2) * 16;
+    if (table_bytes <= SV_MAX_TABLE_BYTES && (int64_t)2 * num_faces < (1 << 24) && !(g.dbg & 32)) {
+        const int rx_n = (image_size + SV_W - 1) / SV_W, ry_n = (image_size + SV_H - 1) / SV_H;
+        const int64_t blocks = (int64_t)batch_size * rx_n * ry_n;
+        if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
+        hipLaunchKernelGGL(scatter_vc_kernel, dim3((unsigned)blocks), dim3(SV_WAVES * MR_WAVE), (size_t)table_bytes, s, g,
+                           rx_n, ry_n);
+        MR_CHECK_LAUNCH();
+        return MR_OK;
+    }
+    if (image_size > 8192) return MR_ERR_BADARG;  // gather fragment encoding: 13 bits per bbox offset
     return launch1d(gather_vc_kernel<0>, (int64_t)batch_size * num_faces * GLPF, s, g);
 }

@@ -24,6 +24,9 @@ bg = torch.zeros(3, **f32)
 _lib.call("mr_render_vc_forward", P(v), P(fidx), P(colors), P(bg), 0, P(rgb), P(alpha), P(depth), P(fim), P(wmap), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
 g_rgb = torch.randn_like(rgb); g_cols = torch.empty_like(colors)
 flush = torch.zeros(768 * 1024 * 1024 // 4, **f32)
-for name, dbg in (("full", 0), ("no global atomics", 1), ("no shade", 2), ("no shade, no atomics", 3), ("no probes (setup only)", 7), ("loads only", 8), ("loads + boxes", 16)):
+G = 32  # force the face-parallel gather kernel
+for name, dbg in (("scatter: full", 0), ("scatter: no flush", 1), ("scatter: no shade", 2), ("scatter: no shade, no flush", 3), ("scatter: no lds atomics", 4),
+                  ("gather: full", G), ("gather: no global atomics", G | 1), ("gather: no shade", G | 2),
+                  ("gather: no probes (setup only)", G | 7), ("gather: loads only", G | 8), ("gather: loads + boxes", G | 16)):
     fn = lambda: _lib.call("mr_render_vc_backward", P(v), P(fidx), P(fim), P(g_rgb), P(g_cols), B, V, F0, 1, is_, 1e-3, dbg << 8, st)
     print(f"{name:30s} cold {bench.event_time_ms(fn, 20, flush=flush) * 1e3:8.1f} us   warm {bench.event_time_ms(fn, 20) * 1e3:8.1f} us")
