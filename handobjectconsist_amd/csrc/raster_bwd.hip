@@ -502,7 +502,7 @@ constexpr int SV_WAVES = 8;                                     // waves per blo
 constexpr int SV_RPW = 4, SV_W = 64, SV_H = SV_WAVES * SV_RPW;  // rows per wave, region
 constexpr int SV_MAX_TABLE_BYTES = 56 * 1024;
 constexpr int SV_FIX_BITS = 50;
-static_assert(3LL * SV_W * SV_H < (1LL << (62 - SV_FIX_BITS)), "fixed-point sums must not overflow");
+static_assert(3LL * SV_W * SV_H < (1LL << (63 - SV_FIX_BITS)), "fixed-point sums must not overflow");
 
 __global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(GatherVCParams p, int rx_n, int ry_n) {
     extern __shared__ long long vtab[];  // [V * 3] rounded up to an even count
