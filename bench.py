@@ -135,7 +135,7 @@ def kernel_bench(dev, B, is_, iters):
                   P(wmap), P(work), wbytes, B, v_c.shape[1], F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
 
     def render_vc_bwd():
-        _lib.call("mr_render_vc_backward", P(v_c), P(fidx32), P(fim), P(g_rgb), P(g_cols), B, v_c.shape[1], F0, 1, is_,
+        _lib.call("mr_render_vc_backward", P(v_c), P(fidx32), P(fim), P(wmap), P(depth), P(g_rgb), P(g_cols), B, v_c.shape[1], F0, 1, is_,
                   1e-3, 0, st)
 
     im_ref, im, jm_ref, jm = [t(a) for a in synth.random_images(B, is_, is_, 0)]

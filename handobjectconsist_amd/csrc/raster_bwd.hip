@@ -480,17 +480,19 @@ __global__ void __launch_bounds__(256) gather_vc_kernel(GatherVCParams p) {
 // ---------------------------------------------------------------------------------------
 // E for the vertex-colour mode, pixel-parallel: the default when the per-image colour table fits LDS
 // ---------------------------------------------------------------------------------------
-// One block owns a SV_W x SV_H pixel region of one image.  face_index_map is read once, coalesced
-// (a wave = one 64-pixel row segment, 256 B); regions without geometry leave after that single load.
-// Covered pixels are compacted per wave (ballot + popcount) so that the shading stage runs with
-// full lanes: lane per fragment -- index triple, three projected vertices, inverse, barycentrics,
-// sampling weights, the pixel's rgb gradient -- and adds its 9 products into a block-private
-// [V,3] table in LDS.  The table is flushed with one global fp32 atomic per touched (vertex,
-// channel): a few thousand per image instead of 9 per visible face, and no probing of face
-// bounding boxes at all.
+// One block owns a SV_W x SV_H pixel region of one image, one lane per pixel (SV_RPW rows per
+// wave).  face_index_map is read once, coalesced (a wave = one 64-pixel row segment, 256 B);
+// regions without geometry leave after that single load.  A covered pixel needs its rgb gradient,
+// the winner's index triple and -- STORED: the barycentric weights and depth the forward pass
+// wrote for this very pixel plus the three vertex depths; else: the three projected vertices, from
+// which inverse, weights and depth are recomputed with the forward's arithmetic.  All of these
+// loads are issued before the first use (two round trips after face_index_map).  The 9 products
+// (sampling weight x gradient channel) are added into a block-private [V,3] table in LDS, which is
+// flushed with one global fp32 atomic per touched (vertex, channel): a few thousand per image
+// instead of 9 per visible face, and no probing of face bounding boxes at all.
 //
 // The LDS table is 64-bit FIXED POINT, not fp32: ds_add_f32 is several times slower than the
-// integer LDS atomics on gfx950 (measured: the 9 float adds per fragment cost more than everything
+// integer LDS atomics on gfx950 (measured: the 9 float adds per pixel cost more than everything
 // else in this kernel together).  Every product w * g is bounded by the largest |g| of the region
 // (the sampling weights are in [0,1]), so with that maximum < 2^e the products are scaled by
 // 2^(SV_FIX_BITS - e), truncated to int64 and summed exactly; <= 3 * SV_W * SV_H terms of
@@ -498,66 +500,88 @@ __global__ void __launch_bounds__(256) gather_vc_kernel(GatherVCParams p) {
 // largest gradient -- far below fp32 rounding of the sum -- and the block's sums do not depend on
 // the order of the additions.  Regions whose gradient holds an Inf / NaN take a plain fp32
 // global-atomic path so that non-finite values propagate as they do in the gather kernel.
-constexpr int SV_WAVES = 8;                                     // waves per block
-constexpr int SV_RPW = 4, SV_W = 64, SV_H = SV_WAVES * SV_RPW;  // rows per wave, region
-constexpr int SV_MAX_TABLE_BYTES = 56 * 1024;
+constexpr int SV_WAVES = 16;                                    // waves per block
+constexpr int SV_RPW = 2, SV_W = 64, SV_H = SV_WAVES * SV_RPW;  // rows per wave, region
+constexpr int SV_MAX_TABLE_BYTES = 60 * 1024;
 constexpr int SV_FIX_BITS = 50;
 static_assert(3LL * SV_W * SV_H < (1LL << (63 - SV_FIX_BITS)), "fixed-point sums must not overflow");
 
-__global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(GatherVCParams p, int rx_n, int ry_n) {
+struct ScatterVCParams {
+    GatherVCParams g;
+    const float* weight;  // STORED: [B,is,is,3] raster orientation
+    const float* depth;   // STORED: [B,is,is] image orientation
+    int rx_n, ry_n;
+};
+
+template <bool STORED>
+__global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(ScatterVCParams sp) {
     extern __shared__ long long vtab[];  // [V * 3] rounded up to an even count
-    __shared__ unsigned frag[SV_WAVES][SV_RPW * MR_WAVE];  // fn << 8 | row << 6 | column
     __shared__ unsigned wmax[SV_WAVES];
 
+    const GatherVCParams& p = sp.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned blk = xcd_remap(blockIdx.x, gridDim.x);
-    const int rx = (int)(blk % (unsigned)rx_n), ry = (int)((blk / (unsigned)rx_n) % (unsigned)ry_n);
-    const int b = (int)(blk / (unsigned)(rx_n * ry_n));
+    const int rx = (int)(blk % (unsigned)sp.rx_n), ry = (int)((blk / (unsigned)sp.rx_n) % (unsigned)sp.ry_n);
+    const int b = (int)(blk / (unsigned)(sp.rx_n * sp.ry_n));
     const int is = p.is;
     const int32_t* fim_b = p.fim + (int64_t)b * is * is;
-    const int xi0 = rx * SV_W, yi0 = ry * SV_H + wave * SV_RPW;
+    const int xi = rx * SV_W + lane, yi0 = ry * SV_H + wave * SV_RPW;
 
     int fnv[SV_RPW];
 #pragma unroll
-    for (int r = 0; r < SV_RPW; r++)
-        fnv[r] = (xi0 + lane < is && yi0 + r < is) ? fim_b[(yi0 + r) * is + xi0 + lane] : -1;
+    for (int r = 0; r < SV_RPW; r++) fnv[r] = (xi < is && yi0 + r < is) ? fim_b[(yi0 + r) * is + xi] : -1;
     bool cov = false;
 #pragma unroll
     for (int r = 0; r < SV_RPW; r++) cov = cov || fnv[r] >= 0;
-    if (!__syncthreads_or(cov)) return;  // block-uniform
+    if (!__syncthreads_or(cov) || (p.dbg & 8)) return;  // block-uniform
 
-    // largest |gradient| over the region's covered pixels (coalesced row reads), as float bits
-    unsigned mx = 0u;
-    {
-        float g[SV_RPW][3];
-#pragma unroll
-        for (int r = 0; r < SV_RPW; r++)
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-                g[r][ch] = fnv[r] >= 0 ? p.grad_rgb[idx3<true>(b, yi0 + r, xi0 + lane, ch, is)] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < SV_RPW; r++)
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) mx = max(mx, __float_as_uint(g[r][ch]) & 0x7fffffffu);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
-    if (lane == 0) wmax[wave] = mx;
-
-    const int n2 = (p.V * 3 + 1) >> 1;
-    for (int k = threadIdx.x; k < n2; k += blockDim.x) reinterpret_cast<int4*>(vtab)[k] = make_int4(0, 0, 0, 0);
-
-    // compaction: fragments of this wave's rows, row-major
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    int n = 0;
+    const float* verts_b = p.verts + (int64_t)b * p.V * 3;
+    const int32_t* fidx_b = p.fidx + (int64_t)b * p.F0 * 3;
+    float g[SV_RPW][3], w[SV_RPW][3], zp[SV_RPW];
+    int vid[SV_RPW][3];
 #pragma unroll
     for (int r = 0; r < SV_RPW; r++) {
         const bool won = fnv[r] >= 0;
-        const unsigned long long m = __ballot(won);
-        if (won) frag[wave][n + __popcll(m & lt_mask)] = ((unsigned)fnv[r] << 8) | (unsigned)(r << 6) | (unsigned)lane;
-        n += __popcll(m);
+        const bool o = fnv[r] >= p.F0;  // reversed copy of face fn - F0
+        const int32_t* ix = fidx_b + (int64_t)(won ? (o ? fnv[r] - p.F0 : fnv[r]) : 0) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; k++) vid[r][k] = won ? ix[o ? 2 - k : k] : 0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) g[r][ch] = won ? p.grad_rgb[idx3<true>(b, yi0 + r, xi, ch, is)] : 0.0f;
+        if (STORED) {
+            const float* wq = sp.weight + idx1<false>(b, yi0 + r, xi, is) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) w[r][k] = won ? wq[k] : 0.0f;
+            zp[r] = won ? sp.depth[idx1<true>(b, yi0 + r, xi, is)] : 1.0f;
+        }
     }
-    __syncthreads();  // table zeroed, fragment lists and maxima visible
+    Face f[SV_RPW];  // STORED: only the three depths v[2], v[5], v[8] are loaded
+#pragma unroll
+    for (int r = 0; r < SV_RPW; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float* q = verts_b + (int64_t)vid[r][k] * 3;
+            const bool won = fnv[r] >= 0;
+            if (!STORED) { f[r].v[3 * k] = won ? q[0] : 0.0f; f[r].v[3 * k + 1] = won ? q[1] : 0.0f; }
+            f[r].v[3 * k + 2] = won ? q[2] : 1.0f;
+        }
+
+    // largest |gradient| over the region's covered pixels, as float bits
+    unsigned mx = 0u;
+#pragma unroll
+    for (int r = 0; r < SV_RPW; r++)
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) mx = max(mx, __float_as_uint(g[r][ch]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    if (lane == 0) wmax[wave] = mx;
+    const int n2 = (p.V * 3 + 1) >> 1;
+    for (int k = threadIdx.x; k < n2; k += blockDim.x) reinterpret_cast<int4*>(vtab)[k] = make_int4(0, 0, 0, 0);
+    if (p.dbg & 16) {
+        if (f[0].v[2] + f[SV_RPW - 1].v[8] == 12345.0f) p.grad_vcolors[0] = 1.0f;
+        return;
+    }
+    __syncthreads();  // table zeroed, maxima visible
 
     unsigned bm = 0u;
 #pragma unroll
@@ -565,33 +589,17 @@ __global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(GatherVC
     if (bm == 0u) return;                   // every gradient of the region is +-0: nothing to add
     const bool finite = bm < 0x7f800000u;   // else: fp32 global atomics, Inf / NaN propagate
     const int shift = SV_FIX_BITS - ((int)(bm >> 23) - 126);  // largest |g| < 2^((bm >> 23) - 126)
-
-    const float* verts_b = p.verts + (int64_t)b * p.V * 3;
-    const int32_t* fidx_b = p.fidx + (int64_t)b * p.F0 * 3;
     float* out = p.grad_vcolors + (int64_t)b * p.V * 3;
-    for (int base = 0; base < n && !(p.dbg & 2); base += MR_WAVE) {
-        if (base + lane < n) {
-            const unsigned fr = frag[wave][base + lane];
-            const int fn = (int)(fr >> 8);
-            const int xi = xi0 + (int)(fr & 63u), yi = yi0 + (int)((fr >> 6) & 3u);
-            const bool o = fn >= p.F0;  // reversed copy of face fn - F0
-            const int32_t* ix = fidx_b + (int64_t)(o ? fn - p.F0 : fn) * 3;
-            int vid[3];
-            float g[3];
+
 #pragma unroll
-            for (int k = 0; k < 3; k++) vid[k] = ix[o ? 2 - k : k];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) g[ch] = p.grad_rgb[idx3<true>(b, yi, xi, ch, is)];
-            Face f;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float* q = verts_b + (int64_t)vid[k] * 3;
-                f.v[3 * k] = q[0]; f.v[3 * k + 1] = q[1]; f.v[3 * k + 2] = q[2];
+    for (int r = 0; r < SV_RPW; r++) {
+        if (fnv[r] >= 0 && !(p.dbg & 2)) {
+            float tif[3];
+            if (!STORED) {
+                face_inverse(f[r].v, f[r].inv, is);
+                bary(f[r], xi, yi0 + r, zp[r], w[r]);
             }
-            face_inverse(f.v, f.inv, is);
-            float w[3], zp, tif[3];
-            bary(f, xi, yi, zp, w);
-            tex_coords(w, zp, f.v, 2, p.eps, tif);
+            tex_coords(w[r], zp[r], f[r].v, 2, p.eps, tif);
             // taps pn = 1, 2, 4 are the texels holding the colours of vertices 0, 1, 2
             float val[9];
 #pragma unroll
@@ -601,10 +609,10 @@ __global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(GatherVC
 #pragma unroll
                 for (int j = 0; j < 3; j++) wg *= ((pn >> j) & 1) ? (tif[j] - 0.0f) : (1.0f - (tif[j] - 0.0f));
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) val[k * 3 + ch] = wg * g[ch];
+                for (int ch = 0; ch < 3; ch++) val[k * 3 + ch] = wg * g[r][ch];
             }
-            // Neighbouring lanes hold fragments of the same face or of faces sharing a vertex, and
-            // an LDS atomic serialises lanes that hit one address.  Lane l therefore issues its nine
+            // Neighbouring lanes hold pixels of the same face or of faces sharing a vertex, and an
+            // LDS atomic serialises lanes that hit one address.  Lane l therefore issues its nine
             // adds in the order (l % 9), (l % 9) + 1, ... so that the lanes of a run work on
             // different (vertex, channel) cells in any one instruction.
             const int rot = lane % 9;
@@ -622,7 +630,7 @@ __global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(GatherVC
                 int sl = j + rot;
                 sl = sl >= 9 ? sl - 9 : sl;
                 const int k = (sl >= 3) + (sl >= 6), ch = sl - 3 * k;
-                const int cell = (k == 0 ? vid[0] : (k == 1 ? vid[1] : vid[2])) * 3 + ch;
+                const int cell = (k == 0 ? vid[r][0] : (k == 1 ? vid[r][1] : vid[r][2])) * 3 + ch;
                 if (p.dbg & 4) {
                     if (val[j] == 12345.0f) vtab[0] = 1;
                 } else if (finite) {
@@ -1027,10 +1035,9 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
 }
 
 extern "C" int mr_render_vc_backward(const float* verts, const int32_t* faces_idx, const int32_t* face_index_map,
-                                     const float* grad_rgb_img, float* grad_vcolors, int batch_size, int num_verts,
-                                     int num_faces, int fill_back, int image_size, float eps, int flags,
-                                     mr_stream_t stream) {
-    (void)flags;
+                                     const float* weight_map, const float* depth_img, const float* grad_rgb_img,
+                                     float* grad_vcolors, int batch_size, int num_verts, int num_faces, int fill_back,
+                                     int image_size, float eps, int flags, mr_stream_t stream) {
     if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0) return MR_ERR_BADARG;
     if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
     if (batch_size == 0 || num_verts == 0) return MR_OK;
@@ -1043,12 +1050,13 @@ extern "C" int mr_render_vc_backward(const float* verts, const int32_t* faces_id
                      fill_back, image_size, eps, flags >> 8};
     // pixel-parallel scatter when the per-image colour table fits LDS (dbg bit 32 forces the gather)
     const int64_t table_bytes = (((int64_t)num_verts * 3 + 1) / 2) * 16;
-    if (table_bytes <= SV_MAX_TABLE_BYTES && (int64_t)2 * num_faces < (1 << 24) && !(g.dbg & 32)) {
-        const int rx_n = (image_size + SV_W - 1) / SV_W, ry_n = (image_size + SV_H - 1) / SV_H;
-        const int64_t blocks = (int64_t)batch_size * rx_n * ry_n;
+    if (table_bytes <= SV_MAX_TABLE_BYTES && !(g.dbg & 32)) {
+        ScatterVCParams sp{g, weight_map, depth_img, (image_size + SV_W - 1) / SV_W, (image_size + SV_H - 1) / SV_H};
+        const int64_t blocks = (int64_t)batch_size * sp.rx_n * sp.ry_n;
         if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
-        hipLaunchKernelGGL(scatter_vc_kernel, dim3((unsigned)blocks), dim3(SV_WAVES * MR_WAVE), (size_t)table_bytes, s, g,
-                           rx_n, ry_n);
+        const bool stored = weight_map && depth_img && !(g.dbg & 64);
+        hipLaunchKernelGGL(stored ? scatter_vc_kernel<true> : scatter_vc_kernel<false>, dim3((unsigned)blocks),
+                           dim3(SV_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
         MR_CHECK_LAUNCH();
         return MR_OK;
     }

@@ -302,16 +302,17 @@ class RasterizeVertexColorFunction(Function):
                   _lib.ptr(rgb), _lib.ptr(alpha), _lib.ptr(depth), _lib.ptr(fim), _lib.ptr(wmap), _lib.ptr(work),
                   int(wbytes), B, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps),
                   int(return_rgb), int(return_alpha), int(return_depth), 0, _lib.stream_ptr(dev))
-        ctx.cfg = (is_, float(eps), bool(fill_back), bool(return_rgb))
-        ctx.save_for_backward(verts, fidx, fim)
+        ctx.cfg = (is_, float(eps), bool(fill_back), bool(return_rgb), bool(return_depth))
+        # the forward's own weight / depth maps feed the backward (no extra memory: they are outputs)
+        ctx.save_for_backward(verts, fidx, fim, wmap, depth if return_depth else fim)
         ctx.mark_non_differentiable(fim, wmap)
         e = torch.tensor([])
         return (rgb if return_rgb else e, alpha if return_alpha else e, depth if return_depth else e, fim, wmap)
 
     @staticmethod
     def backward(ctx, grad_rgb, _ga, _gd, _gf, _gw):
-        verts, fidx, fim = ctx.saved_tensors
-        is_, eps, fill_back, rr = ctx.cfg
+        verts, fidx, fim, wmap, depth = ctx.saved_tensors
+        is_, eps, fill_back, rr, rd = ctx.cfg
         if not ctx.needs_input_grad[2] or not rr:
             return (None,) * 12
         B, V = verts.shape[:2]
@@ -320,8 +321,8 @@ class RasterizeVertexColorFunction(Function):
             grad_cols.zero_()
         else:
             g = _lib.contig(grad_rgb)
-            _lib.call("mr_render_vc_backward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(fim), _lib.ptr(g),
-                      _lib.ptr(grad_cols), B, V, int(fidx.shape[1]), int(fill_back), is_, eps, 0,
+            _lib.call("mr_render_vc_backward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(fim),
+                      _lib.ptr(wmap) if rd else None, _lib.ptr(depth) if rd else None, _lib.ptr(g), _lib.ptr(grad_cols), B, V, int(fidx.shape[1]), int(fill_back), is_, eps, 0,
                       _lib.stream_ptr(verts.device))
         return (None, None, grad_cols) + (None,) * 9
 

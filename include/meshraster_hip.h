@@ -166,9 +166,13 @@ MR_API int mr_render_vc_forward(const float* verts, const int32_t* faces_idx, co
 
 /* Adjoint of the above w.r.t. vcolors (kernel E composed with the adjoints of
  * batch_vertex_textures and of the fill-back concatenation): grad_vcolors[B,V,3] is zeroed
- * here and accumulated with fp32 atomics (9 per live face). */
+ * here and accumulated with fp32 atomics.  weight_map (raster orientation) and depth_img
+ * (image orientation) are the maps mr_render_vc_forward wrote for the same inputs; both may
+ * be NULL, in which case the barycentrics and depths are recomputed from the vertices (same
+ * values, more arithmetic). */
 MR_API int mr_render_vc_backward(const float* verts, const int32_t* faces_idx,
-                                 const int32_t* face_index_map, const float* grad_rgb_img,
+                                 const int32_t* face_index_map, const float* weight_map,
+                                 const float* depth_img, const float* grad_rgb_img,
                                  float* grad_vcolors, int batch_size, int num_verts, int num_faces,
                                  int fill_back, int image_size, float eps, int flags,
                                  mr_stream_t stream);
