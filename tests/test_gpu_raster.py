@@ -279,3 +279,117 @@ def test_generic_texture_size_and_per_sample_background(cuda, ts):
     _, gt_ref = R.rasterize_backward(ref["_saved"], raster_g[0], None, None, num_threads=8)
     out["rgb"].backward(t(img_g[0], cuda))
     assert_close(x_t.grad.cpu().numpy(), gt_ref, 1e-4, 1e-5 * np.abs(gt_ref).max(), "grad_textures")
+
+
+def _vc_abi_case(cuda, B, is_, seed, n_extra_verts=0):
+    """Forward of the vertex-colour path through the C-ABI; returns device buffers + oracle inputs."""
+    from handobjectconsist_amd import _lib
+
+    s = synth.random_scene(B, seed=seed, image_size=is_)
+    v = R.nr_projection(s["verts1"], s["K1"], REN_KW["R"], REN_KW["t"], REN_KW["dist_coeffs"], is_)
+    if n_extra_verts:  # unreferenced vertices: only the size of the colour table changes
+        v = np.concatenate([v, np.ones((B, n_extra_verts, 3), np.float32)], 1)
+    fidx = s["faces"].astype(np.int32)
+    rng = np.random.default_rng(seed)
+    cols = rng.uniform(-2, 2, (B, v.shape[1], 3)).astype(np.float32)
+    V, F0 = v.shape[1], fidx.shape[1]
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    f32 = dict(dtype=torch.float32, device=cuda)
+    d = dict(v=t(v, cuda), fidx=t(fidx, cuda), cols=t(cols, cuda), rgb=torch.empty((B, 3, is_, is_), **f32),
+             alpha=torch.empty((B, is_, is_), **f32), depth=torch.empty((B, is_, is_), **f32),
+             fim=torch.empty((B, is_, is_), dtype=torch.int32, device=cuda), wmap=torch.empty((B, is_, is_, 3), **f32))
+    wbytes = int(_lib.load().mr_render_workspace_bytes(B, 2 * F0, is_))
+    work = torch.empty((wbytes,), dtype=torch.uint8, device=cuda)
+    bg = torch.zeros(3, **f32)
+    _lib.call("mr_render_vc_forward", P(d["v"]), P(d["fidx"]), P(d["cols"]), P(bg), 0, P(d["rgb"]), P(d["alpha"]),
+              P(d["depth"]), P(d["fim"]), P(d["wmap"]), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+    d.update(B=B, V=V, F0=F0, is_=is_, v_np=v, fidx_np=fidx, cols_np=cols)
+    return d
+
+
+def _vc_backward(d, g_rgb_img, mode):
+    """mode: 'stored' (forward maps), 'recompute' (NULL maps), 'gather' (face-parallel kernel)."""
+    from handobjectconsist_amd import _lib
+
+    P = _lib.ptr
+    out = torch.full((d["B"], d["V"], 3), float("nan"), dtype=torch.float32, device=g_rgb_img.device)
+    stored = mode == "stored"
+    _lib.call("mr_render_vc_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), P(d["wmap"]) if stored else None,
+              P(d["depth"]) if stored else None, P(g_rgb_img), P(out), d["B"], d["V"], d["F0"], 1, d["is_"], 1e-3,
+              (32 << 8) if mode == "gather" else 0, _lib.stream_ptr(g_rgb_img.device))
+    return out.cpu().numpy()
+
+
+def _vc_backward_oracle(d, g_rgb_raster):
+    """oracle kernel E on the materialised textures, then the adjoints of the fill-back concatenation
+    and of batch_vertex_textures in numpy (float64 accumulation)."""
+    B, V, F0, is_ = d["B"], d["V"], d["F0"], d["is_"]
+    tex = R.batch_vertex_textures(d["fidx_np"], d["cols_np"])
+    f2, tex2 = R.fill_back(d["fidx_np"], tex)
+    saved = R.rasterize_forward(R.nr_vertices_to_faces(d["v_np"], f2), tex2, is_, 0.1, 100, 1e-3, (0, 0, 0),
+                                num_threads=8)
+    _, gt = R.rasterize_backward(saved, g_rgb_raster, None, None, num_threads=8)
+    gt = gt.astype(np.float64)
+    g_tex = gt[:, :F0] + gt[:, F0:].transpose(0, 1, 4, 3, 2, 5)  # texel (i,j,k) of the copy is (k,j,i)
+    g_cols = np.zeros((B, V, 3))
+    for b in range(B):
+        np.add.at(g_cols[b], d["fidx_np"][b, :, 0], g_tex[b, :, 1, 0, 0])
+        np.add.at(g_cols[b], d["fidx_np"][b, :, 1], g_tex[b, :, 0, 1, 0])
+        np.add.at(g_cols[b], d["fidx_np"][b, :, 2], g_tex[b, :, 0, 0, 1])
+    return g_cols, saved
+
+
+@pytest.mark.parametrize("B,is_,seed", [(2, 64, 0), (3, 100, 1), (2, 256, 2)])
+def test_vc_backward_kernels_match_oracle(cuda, B, is_, seed):
+    """All three implementations of the vertex-colour backward (pixel-parallel scatter on the stored
+    maps / on recomputed barycentrics, face-parallel gather) against oracle kernel E."""
+    d = _vc_abi_case(cuda, B, is_, seed)
+    rng = np.random.default_rng(seed + 7)
+    g_raster = rng.standard_normal((B, is_, is_, 3)).astype(np.float32)
+    # region-dependent magnitudes: the fixed-point scale of the scatter kernel is per region
+    g_raster *= np.exp2(rng.integers(-30, 30, (B, is_ // 16 + 1, 1, 1))).astype(np.float32).repeat(16, 1)[:, :is_]
+    g_img = t(g_raster.transpose(0, 3, 1, 2)[:, :, ::-1], cuda)
+    ref, saved = _vc_backward_oracle(d, g_raster)
+    assert (d["fim"].cpu().numpy() == saved["face_index_map"]).all()
+    assert np.abs(ref).max() > 0
+    # per-vertex tolerance: 1e-4 of the vertex's own absolute contributions would need the oracle's
+    # partial sums; use 1e-4 relative + 1e-6 of the largest gradient the vertex's image region saw
+    atol = 1e-6 * np.abs(ref).max()
+    for mode in ("stored", "recompute", "gather"):
+        got = _vc_backward(d, g_img, mode)
+        assert np.isfinite(got).all(), mode
+        assert_close(got, ref, 1e-4, atol, f"grad_vcolors[{mode}]")
+    a, b_ = _vc_backward(d, g_img, "stored"), _vc_backward(d, g_img, "recompute")
+    assert_close(a, b_, 1e-5, 1e-7 * np.abs(ref).max(), "stored vs recompute")
+
+
+def test_vc_backward_edge_cases(cuda):
+    d = _vc_abi_case(cuda, 2, 96, 5)
+    B, is_ = d["B"], d["is_"]
+    zero = torch.zeros((B, 3, is_, is_), dtype=torch.float32, device=cuda)
+    for mode in ("stored", "recompute", "gather"):
+        assert (_vc_backward(d, zero, mode) == 0).all(), mode  # also: the output is zeroed by the call
+    # a non-finite gradient on a covered pixel reaches exactly the three vertices of the winning face
+    fim = d["fim"].cpu().numpy()
+    ys, xs = np.nonzero(fim[0] >= 0)
+    y, x = int(ys[len(ys) // 2]), int(xs[len(xs) // 2])
+    fn = int(fim[0, y, x])
+    tri = d["fidx_np"][0, fn % d["F0"]]
+    g = torch.randn((B, 3, is_, is_), dtype=torch.float32, device=cuda)
+    g[0, 1, is_ - 1 - y, x] = float("inf")
+    for mode in ("stored", "recompute", "gather"):
+        got = _vc_backward(d, g, mode)
+        bad = np.argwhere(~np.isfinite(got))
+        assert len(bad) > 0 and set(bad[:, 0]) == {0} and set(bad[:, 1]) <= set(tri.tolist()) and set(bad[:, 2]) == {1}, mode
+    # denormal-sized and huge gradients keep their relative accuracy (per-region scale)
+    for scale in (1e-38, 1e30):
+        gs = torch.randn((B, 3, is_, is_), dtype=torch.float32, device=cuda) * scale
+        a, b_ = _vc_backward(d, gs, "stored"), _vc_backward(d, gs, "gather")
+        assert_close(a, b_, 1e-4, 1e-6 * np.abs(b_).max(), f"scale {scale}")
+        assert np.abs(b_).max() > 0
+    # a colour table too large for LDS falls back to the gather kernel
+    big = _vc_abi_case(cuda, 1, 64, 6, n_extra_verts=4000)
+    gb = torch.randn((1, 3, 64, 64), dtype=torch.float32, device=cuda)
+    a, b_ = _vc_backward(big, gb, "stored"), _vc_backward(big, gb, "gather")
+    assert_close(a, b_, 1e-6, 1e-7 * np.abs(b_).max(), "large V")
+    assert (a[:, -4000:] == 0).all()
