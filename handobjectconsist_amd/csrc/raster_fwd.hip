@@ -44,7 +44,7 @@ constexpr int TILE_W = 32, TILE_H = 8;  // tile size in pixels (one pixel per th
 constexpr int TPB = 256;              // threads per workgroup (4 waves)
 constexpr int NB = 32;                // faces per batch (stage S1: one lane per face)
 constexpr int FPP = MR_WAVE / TILE_H; // faces per S2 pass: one lane per (face, tile row)
-constexpr int FC_STRIDE = 25;         // dwords per face-cache slot (odd: conflict-free ds_read_b32)
+constexpr int FC_STRIDE = 21;         // dwords per face-cache slot (odd: conflict-free ds_read_b32)
 constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 4 * 64, power of 2)
 constexpr int SCAN_UNROLL = 4;        // independent record loads in flight per lane
 constexpr int QCAP = 512;             // wave-private ring capacity (>= NB - 1 + 64 * SCAN_UNROLL, power of 2)
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     __shared__ unsigned long long zbuf[TILE_W * TILE_H];
     __shared__ int queue[TPB / MR_WAVE][QCAP];
     __shared__ float fcache[TPB / MR_WAVE][NB * FC_STRIDE];
-    __shared__ unsigned fragq[TPB / MR_WAVE][FQCAP];
+    __shared__ unsigned short fragq[TPB / MR_WAVE][FQCAP];  // slot << 8 | row << 5 | x
     __shared__ float xp_tab[TILE_W], yp_tab[TILE_H];
 
     const unsigned nblocks = gridDim.x;
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     const RecVerts* rv_b = p.rverts + (int64_t)b * p.F;
     int* q = queue[wave];
     float* fc = fcache[wave];
-    unsigned* fq = fragq[wave];
+    unsigned short* fq = fragq[wave];
     int qhead = 0, qn = 0;  // wave-uniform ring state
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -325,8 +325,8 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
     auto shade = [&](int n) {
         if (lane < n && !(p.dbg & 16)) {
             const unsigned fr = fq[(fqh + lane) & (FQCAP - 1)];
-            const float* c = fc + (fr >> 16) * FC_STRIDE;
-            const int lx = (int)(fr & 0xffu), ly = (int)((fr >> 8) & 0xffu);
+            const float* c = fc + (fr >> 8) * FC_STRIDE;
+            const int lx = (int)(fr & 31u), ly = (int)((fr >> 5) & 7u);
             Face f;
 #pragma unroll
             for (int k = 0; k < 9; k++) f.inv[k] = c[9 + k];
@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
                     const unsigned long long m = __ballot(has);
                     if (has)
                         fq[(fqh + fqn + total + __popcll(m & lt_mask)) & (FQCAP - 1)] =
-                            ((unsigned)slot << 16) | ((unsigned)row << 8) | (unsigned)(x + i);
+                            (unsigned short)(((unsigned)slot << 8) | ((unsigned)row << 5) | (unsigned)(x + i));
                     total += __popcll(m);
                 }
                 x += c; len -= c; fqn += total;
