@@ -46,8 +46,8 @@ constexpr int NB = 32;                // faces per batch (stage S1: one lane per
 constexpr int FPP = MR_WAVE / TILE_H; // faces per S2 pass: one lane per (face, tile row)
 constexpr int FC_STRIDE = 21;         // dwords per face-cache slot (odd: conflict-free ds_read_b32)
 constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 4 * 64, power of 2)
-constexpr int SCAN_UNROLL = 4;        // independent record loads in flight per lane
-constexpr int QCAP = 512;             // wave-private ring capacity (>= NB - 1 + 64 * SCAN_UNROLL, power of 2)
+constexpr int SCAN_UNROLL = 3;        // independent record loads in flight per lane
+constexpr int QCAP = 256;             // wave-private ring capacity (>= NB - 1 + 64 * SCAN_UNROLL, power of 2)
 
 // Per-image header of the compact face-record list (zero-initialised before face_setup_kernel).
 // The union bbox is kept as maxima so that all-zero means "no face": nx0 = max(is - x0), x1p =
@@ -250,7 +250,7 @@ __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float 
 // FUSED = true : write every pixel of every requested plane (fused epilogue).
 // FUSED = false: upstream-compatible forward_face_index_map: touch hit pixels only.
 template <bool FUSED, bool VC>
-__global__ void __launch_bounds__(TPB) raster_tile_kernel(FwdParams p) {
+__global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
     __shared__ unsigned long long zbuf[TILE_W * TILE_H];
     __shared__ int queue[TPB / MR_WAVE][QCAP];
     __shared__ float fcache[TPB / MR_WAVE][NB * FC_STRIDE];
