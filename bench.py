@@ -225,6 +225,20 @@ def cpu_baseline(B_sample, is_, B_full):
                       f"{threads} threads, extrapolated x{B_full // B_sample}"}
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (PMC counters cannot be
+    collected from inside this process; scripts/pmc.sh runs them, profiles/r01_pmc_traffic.json
+    holds the corrected per-dispatch means).  None when the file or the kernel is missing."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)[kernel_name]
+        return {"traffic": rec["hbm_bytes"], "traffic_unit": "bytes/launch",
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"}
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -319,6 +333,7 @@ def main():
         k = kernels[dom]
         roof = {"kernel": dom, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": k["frac_hbm_peak"], "traffic": None}
+        roof.update(pmc_traffic("mr::scatter_vc_kernel<true>"))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_sample, is_, B)
 
