@@ -136,7 +136,8 @@ __device__ __forceinline__ Quad load_quad(const float* __restrict__ plane, const
 }
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(Quad& q) { pin(q.nw); pin(q.ne); pin(q.sw); pin(q.se); }
-__device__ __forceinline__ float bilin_q(const Quad& q, const Taps& t, const TapAddr& a) {
+template <typename A>
+__device__ __forceinline__ float bilin_q(const Quad& q, const Taps& t, const A& a) {
     float acc = 0.0f;
     acc = a.b_nw ? acc + q.nw * t.nw : acc;
     acc = a.b_ne ? acc + q.ne * t.ne : acc;
@@ -144,7 +145,8 @@ __device__ __forceinline__ float bilin_q(const Quad& q, const Taps& t, const Tap
     acc = a.b_se ? acc + q.se * t.se : acc;
     return acc;
 }
-__device__ __forceinline__ void bilin_grad_q(const Quad& q, const Taps& t, const TapAddr& a, float& gix, float& giy) {
+template <typename A>
+__device__ __forceinline__ void bilin_grad_q(const Quad& q, const Taps& t, const A& a, float& gix, float& giy) {
     const float fx = (float)t.x0, fy = (float)t.y0;
     const float ix_se = fx + 1.0f, iy_se = fy + 1.0f;
     gix = 0.0f; giy = 0.0f;
@@ -152,6 +154,55 @@ __device__ __forceinline__ void bilin_grad_q(const Quad& q, const Taps& t, const
     if (a.b_ne) { gix += q.ne * (iy_se - t.iy); giy -= q.ne * (t.ix - fx); }
     if (a.b_sw) { gix -= q.sw * (t.iy - fy); giy += q.sw * (ix_se - t.ix); }
     if (a.b_se) { gix += q.se * (t.iy - fy); giy += q.se * (t.ix - fx); }
+}
+
+// Row-pair addressing (W >= 2): the west / east taps of a row are adjacent in memory, so ONE
+// 8-byte load per row fetches both -- half the load instructions of four scalar taps, which is
+// what bounds the fused pair kernels.  The pair starts at column clamp(x0, 0, W - 2); when that
+// differs from x0 the in-bounds tap sits in the other half (x0 == -1: east tap = first element;
+// x0 == W - 1: west tap = second element); taps that are out of bounds are never used.
+// Offsets are 32-bit BYTE offsets from a wave-uniform plane pointer (global_load saddr form).
+struct PairAddr {
+    unsigned o_n, o_s;  // byte offsets of the pairs in rows y0 and y0 + 1 (both clamped)
+    bool shl, shr;      // pair shifted right of x0 (x0 < 0) / left of x0 (x0 > W - 2)
+    bool b_nw, b_ne, b_sw, b_se;
+};
+__device__ __forceinline__ PairAddr pair_addr(const Taps& t, int W, int H) {
+    PairAddr a;
+    a.b_nw = inb(t.x0, t.y0, W, H);
+    a.b_ne = inb(t.x0 + 1, t.y0, W, H);
+    a.b_sw = inb(t.x0, t.y0 + 1, W, H);
+    a.b_se = inb(t.x0 + 1, t.y0 + 1, W, H);
+    const int xs = min(max(t.x0, 0), W - 2);
+    const int yc0 = min(max(t.y0, 0), H - 1), yc1 = min(max(t.y0 + 1, 0), H - 1);
+    a.o_n = ((unsigned)yc0 * (unsigned)W + (unsigned)xs) * 4u;
+    a.o_s = ((unsigned)yc1 * (unsigned)W + (unsigned)xs) * 4u;
+    a.shl = t.x0 < 0;
+    a.shr = t.x0 > W - 2;
+    return a;
+}
+struct __attribute__((packed, aligned(4))) F2 {
+    float x, y;
+};
+struct Quad2 {
+    F2 n, s;
+};
+__device__ __forceinline__ Quad2 load_quad2(const float* __restrict__ plane, const PairAddr& a) {
+    const char* base = reinterpret_cast<const char*>(plane);
+    Quad2 q;
+    q.n = *reinterpret_cast<const F2*>(base + a.o_n);
+    q.s = *reinterpret_cast<const F2*>(base + a.o_s);
+    return q;
+}
+__device__ __forceinline__ void pin(Quad2& q) {
+    asm volatile("" : "+v"(q.n.x)); asm volatile("" : "+v"(q.n.y));
+    asm volatile("" : "+v"(q.s.x)); asm volatile("" : "+v"(q.s.y));
+}
+__device__ __forceinline__ Quad quad_of(const Quad2& q, const PairAddr& a) {
+    Quad r;
+    r.nw = a.shr ? q.n.y : q.n.x; r.ne = a.shl ? q.n.x : q.n.y;
+    r.sw = a.shr ? q.s.y : q.s.x; r.se = a.shl ? q.s.x : q.s.y;
+    return r;
 }
 
 __device__ __forceinline__ void nearest_idx(float ix, float iy, int& xn, int& yn) {
@@ -436,8 +487,14 @@ struct DirOut {
 // pair_eval (masks, warped values).
 struct DirTaps {
     Taps t;
-    TapAddr a;
+    PairAddr a;
     float2 uv;
+};
+struct DirRaw2 {  // as loaded: one 8-byte pair per tap row
+    Quad2 src[3];
+    Quad2 jit[3];
+    float tgt[3];
+    float jd;
 };
 struct DirRaw {
     Quad src[3];
@@ -453,41 +510,57 @@ __device__ __forceinline__ DirTaps pair_taps(const float* __restrict__ flow, int
     float ix, iy;
     sample_pos((float)xx, (float)yy, d.uv.x, d.uv.y, W, H, ix, iy);
     d.t = make_taps(ix, iy);
-    d.a = tap_addr(d.t, W, H);
+    d.a = pair_addr(d.t, W, H);
     return d;
 }
 
 __device__ __forceinline__ void pair_load(const DirTaps& d, const float* __restrict__ src,
                                           const float* __restrict__ tgt, const float* __restrict__ jwarp,
                                           const float* __restrict__ jdirect, int Cj, bool all_jitter_channels,
-                                          int b, int64_t pix, int64_t hw, DirRaw& r) {
+                                          int b, int64_t pix, int64_t hw, DirRaw2& r) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        r.src[c] = load_quad(src + ((int64_t)b * 3 + c) * hw, d.a);
+        r.src[c] = load_quad2(src + ((int64_t)b * 3 + c) * hw, d.a);
         r.tgt[c] = tgt[((int64_t)b * 3 + c) * hw + pix];
     }
-    r.jit[0] = load_quad(jwarp + (int64_t)b * Cj * hw, d.a);
-    r.jit[1] = r.jit[0]; r.jit[2] = r.jit[0];
+    // channels 1, 2 only when the per-channel masks are requested (pair_eval then reads them; otherwise it
+    // uses channel 0 three times -- no copies of loaded values here, they would wait for the loads)
+    r.jit[0] = load_quad2(jwarp + (int64_t)b * Cj * hw, d.a);
+    const F2 z{0.0f, 0.0f};
+    r.jit[1].n = z; r.jit[1].s = z; r.jit[2].n = z; r.jit[2].s = z;
     if (all_jitter_channels && Cj == 3) {
-        r.jit[1] = load_quad(jwarp + ((int64_t)b * Cj + 1) * hw, d.a);
-        r.jit[2] = load_quad(jwarp + ((int64_t)b * Cj + 2) * hw, d.a);
+        r.jit[1] = load_quad2(jwarp + ((int64_t)b * Cj + 1) * hw, d.a);
+        r.jit[2] = load_quad2(jwarp + ((int64_t)b * Cj + 2) * hw, d.a);
     }
     r.jd = jdirect[(int64_t)b * Cj * hw + pix];
 }
 
-__device__ __forceinline__ void pin(DirRaw& r) {
+__device__ __forceinline__ void pin(DirRaw2& r) {
 #pragma unroll
     for (int c = 0; c < 3; c++) { pin(r.src[c]); pin(r.jit[c]); pin(r.tgt[c]); }
     pin(r.jd);
 }
 
-__device__ __forceinline__ DirOut pair_eval(const DirTaps& d, const DirRaw& r, int H, int W, float thresh) {
+__device__ __forceinline__ DirRaw unpack(const DirRaw2& r2, const PairAddr& a) {
+    DirRaw r;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        r.src[c] = quad_of(r2.src[c], a);
+        r.jit[c] = quad_of(r2.jit[c], a);
+        r.tgt[c] = r2.tgt[c];
+    }
+    r.jd = r2.jd;
+    return r;
+}
+
+__device__ __forceinline__ DirOut pair_eval(const DirTaps& d, const DirRaw& r, int H, int W, float thresh,
+                                            bool three_jitter_channels) {
     DirOut o;
     o.m = valid_mask(d.t, W, H, thresh);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         o.s[c] = bilin_q(r.src[c], d.t, d.a) * o.m;
-        const float js = bilin_q(r.jit[c], d.t, d.a) * o.m;
+        const float js = bilin_q(three_jitter_channels ? r.jit[c] : r.jit[0], d.t, d.a) * o.m;
         o.wm[c] = o.m * ((js == 1.0f) ? 1.0f : 0.0f);
     }
     o.valid = (o.wm[0] != 0.0f) && (d.uv.x != 0.0f) && (r.jd == 1.0f);
@@ -536,12 +609,13 @@ __global__ void __launch_bounds__(256) pair_consist_forward_kernel(PairParams p)
         // backward term: image warped by flow12 vs image_ref (:84,82,88,99-107)
         const DirTaps t1 = pair_taps(p.flow21, b, xx, yy, p.H, p.W);
         const DirTaps t2 = pair_taps(p.flow12, b, xx, yy, p.H, p.W);
-        DirRaw r1, r2;
-        pair_load(t1, p.image_ref, p.image, p.jitter, p.jitter, p.Cj, allj, b, pix, hw, r1);
-        pair_load(t2, p.image, p.image_ref, p.jitter_ref, p.jitter_ref, p.Cj, allj, b, pix, hw, r2);
-        pin(r1); pin(r2);
-        const DirOut d1 = pair_eval(t1, r1, p.H, p.W, p.thresh);
-        const DirOut d2 = pair_eval(t2, r2, p.H, p.W, p.thresh);
+        DirRaw2 q1, q2;
+        pair_load(t1, p.image_ref, p.image, p.jitter, p.jitter, p.Cj, allj, b, pix, hw, q1);
+        pair_load(t2, p.image, p.image_ref, p.jitter_ref, p.jitter_ref, p.Cj, allj, b, pix, hw, q2);
+        pin(q1); pin(q2);
+        const DirRaw r1 = unpack(q1, t1.a), r2 = unpack(q2, t2.a);
+        const DirOut d1 = pair_eval(t1, r1, p.H, p.W, p.thresh, allj && p.Cj == 3);
+        const DirOut d2 = pair_eval(t2, r2, p.H, p.W, p.thresh, allj && p.Cj == 3);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int64_t o = ((int64_t)b * 3 + c) * hw + pix;
@@ -641,16 +715,17 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
     const bool both = p.grad_loss_bwd != nullptr;
     const DirTaps t1 = pair_taps(p.flow21, b, xx, yy, p.H, p.W);
     const DirTaps t2 = pair_taps(both ? p.flow12 : p.flow21, b, xx, yy, p.H, p.W);
-    DirRaw r1, r2;
-    pair_load(t1, p.image_ref, p.image, p.jitter, p.jitter, p.Cj, false, b, pix, hw, r1);
-    if (both) pair_load(t2, p.image, p.image_ref, p.jitter_ref, p.jitter_ref, p.Cj, false, b, pix, hw, r2);
-    else r2 = r1;
-    pin(r1); pin(r2);
-    const DirOut d1 = pair_eval(t1, r1, p.H, p.W, p.thresh);
+    DirRaw2 q1, q2;
+    pair_load(t1, p.image_ref, p.image, p.jitter, p.jitter, p.Cj, false, b, pix, hw, q1);
+    if (both) pair_load(t2, p.image, p.image_ref, p.jitter_ref, p.jitter_ref, p.Cj, false, b, pix, hw, q2);
+    else q2 = q1;
+    pin(q1); pin(q2);
+    const DirRaw r1 = unpack(q1, t1.a), r2 = unpack(q2, t2.a);
+    const DirOut d1 = pair_eval(t1, r1, p.H, p.W, p.thresh, false);
     *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = pair_grad(t1, r1, d1, p.H, p.W, coef1);
     float2 g12 = make_float2(0.0f, 0.0f);
     if (both) {
-        const DirOut d2 = pair_eval(t2, r2, p.H, p.W, p.thresh);
+        const DirOut d2 = pair_eval(t2, r2, p.H, p.W, p.thresh, false);
         g12 = pair_grad(t2, r2, d2, p.H, p.W, coef2);
     }
     *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = g12;
@@ -725,6 +800,7 @@ extern "C" int mr_pair_consist_forward(const float* flow12, const float* flow21,
     if (jitter_channels != 1 && jitter_channels != 3) return MR_ERR_BADARG;
     if (batch_size < 0 || height <= 0 || width <= 0) return MR_ERR_BADARG;
     if (workspace_bytes < mr_pair_consist_workspace_bytes(batch_size, height, width)) return MR_ERR_BADARG;
+    if (width < 2 || (int64_t)height * width > (1LL << 29)) return MR_ERR_BADARG;  // row-pair taps, 32-bit byte offsets
     if (batch_size == 0) return MR_OK;
     const int tiles_x = (width + PT_W - 1) / PT_W;
     const int nblk = tiles_x * ((height + PT_H - 1) / PT_H);
@@ -752,6 +828,7 @@ extern "C" int mr_pair_consist_backward(const float* flow12, const float* flow21
         return MR_ERR_BADARG;
     if (jitter_channels != 1 && jitter_channels != 3) return MR_ERR_BADARG;
     if (batch_size < 0 || height <= 0 || width <= 0) return MR_ERR_BADARG;
+    if (width < 2 || (int64_t)height * width > (1LL << 29)) return MR_ERR_BADARG;  // row-pair taps, 32-bit byte offsets
     if (batch_size == 0) return MR_OK;
     const int tiles_x = (width + PT_W - 1) / PT_W;
     const int nblk = tiles_x * ((height + PT_H - 1) / PT_H);
