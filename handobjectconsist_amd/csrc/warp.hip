@@ -596,7 +596,7 @@ __device__ __forceinline__ void block_sum4(float* v, float (*red)[4]) {
     for (int k = 0; k < 4; k++) v[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
 }
 
-__global__ void __launch_bounds__(256) pair_consist_forward_kernel(PairParams p) {
+__global__ void __launch_bounds__(256, 6) pair_consist_forward_kernel(PairParams p) {
     __shared__ float red[4][4];
     const int64_t hw = (int64_t)p.H * p.W;
     int b, tile, xx, yy;
