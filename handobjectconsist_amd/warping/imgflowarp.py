@@ -200,7 +200,8 @@ def pair_consist(
     outputs = outputs or DEFAULT_PAIR_OUTPUTS
     image_ref, image = image_ref.cuda(), image.cuda()
     jitter_mask_ref, jitter_mask = jitter_mask_ref.cuda(), jitter_mask.cuda()
-    if _is_fused_l1(criterion) and image.shape[1] == 3 and jitter_mask.shape[1] in (1, 3):
+    # (the fused kernels fetch the two taps of a row with one 8-byte load: images at least 2 wide)
+    if _is_fused_l1(criterion) and image.shape[1] == 3 and jitter_mask.shape[1] in (1, 3) and image.shape[-1] >= 2:
         want_debug = outputs == "full"
         res = _PairConsistFunction.apply(recons_flow[0], recons_flow[1], image_ref, image, jitter_mask_ref,
                                          jitter_mask, 0.99999, want_debug)

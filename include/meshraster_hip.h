@@ -239,7 +239,9 @@ MR_API int64_t mr_pair_consist_workspace_bytes(int batch_size, int height, int w
  *   loss_fwd[B], loss_bwd[B]              sum / (cnt == 0 ? 1 : cnt); warp_loss = fwd (+ bwd)
  * Optional debug outputs of the reference's `masks, warps, diffs` (any may be NULL):
  *   full_mask1/2[B,H,W] u8    warp_mask1/2[B,3,H,W]    warp1/2[B,3,H,W]    diff1/2[B,3,H,W]
- * The reduction is two-stage and deterministic (no float atomics). */
+ * The reduction is two-stage and deterministic (no float atomics).  Requires width >= 2 and
+ * height * width <= 2^29 (the two taps of a row are fetched with one 8-byte load at a 32-bit
+ * byte offset); smaller images go through mr_warp_forward. */
 MR_API int mr_pair_consist_forward(const float* flow12, const float* flow21, const float* image_ref,
                             const float* image, const float* jitter_ref, const float* jitter,
                             int jitter_channels, void* workspace, int64_t workspace_bytes,
