@@ -121,9 +121,13 @@ def kernel_bench(dev, B, is_, iters):
         _lib.call("mr_render_backward", P(faces), P(tex2), P(fim), P(rgb), P(alpha), P(g_rgb), None, None, None,
                   P(grad_tex), None, 0, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
 
+    bw_bytes = int(lib.mr_render_backward_workspace_bytes(B, F, is_))
+    bw_work = torch.empty((bw_bytes,), dtype=torch.uint8, device=dev)
+
     def render_bwd_full():  # kernels D + E + F
         _lib.call("mr_render_backward", P(faces), P(tex2), P(fim), P(rgb), P(alpha), P(g_rgb), P(g_alpha),
-                  P(g_depth), P(grad_faces), P(grad_tex), None, 0, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+                  P(g_depth), P(grad_faces), P(grad_tex), P(bw_work), bw_bytes, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1,
+                  0, st)
 
     # vertex-colour mode: what the training path actually launches (opticalflow -> render_vertex_colors)
     fidx32 = faces_idx.to(torch.int32).contiguous()

@@ -918,6 +918,294 @@ __global__ void __launch_bounds__(256) pixel_map_kernel(PixelMapParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// D, packed: the same walks on two packed copies of the maps
+// ---------------------------------------------------------------------------------------
+// The per-face walks of kernel D sweep whole image columns (axis 0) and rows (axis 1).  Reading
+// eight separate planes with a stride of one image row per lane costs 8 cache lines per lane and
+// sweep step (measured: 2.8 GB of fabric traffic per launch for 311 algorithmic MB).  A pre-pass
+// therefore packs the eight values a sweep step needs -- alpha, d alpha, rgb, d rgb -- into one
+// 32-byte record per pixel and writes the records twice, row-major and column-major, so that
+// BOTH kinds of sweep read 2 KB of contiguous records per wave and step.
+struct PixRec {
+    float4 a;  // alpha, grad_alpha, r, g
+    float4 b;  // b, grad_r, grad_g, grad_b
+};
+
+constexpr int PK_T = 32;  // transpose tile
+
+template <bool IMG>
+__global__ void __launch_bounds__(256) pixel_pack_kernel(PixelMapParams p, PixRec* __restrict__ rec_row,
+                                                         PixRec* __restrict__ rec_col, int tiles) {
+    __shared__ float tile[8][PK_T][PK_T + 1];
+    const int is = p.is;
+    const int b = blockIdx.x / (tiles * tiles);
+    const int t = blockIdx.x % (tiles * tiles);
+    const int x0 = (t % tiles) * PK_T, y0 = (t / tiles) * PK_T;
+    const int tx = threadIdx.x % PK_T, ty8 = threadIdx.x / PK_T;  // 32 x 8 threads, 4 rows each
+#pragma unroll
+    for (int r = 0; r < PK_T / 8; r++) {
+        const int ly = ty8 + r * 8;
+        const int x = x0 + tx, y = y0 + ly;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (x < is && y < is) {
+            if (p.return_alpha) {
+                const int64_t ia = idx1<IMG>(b, y, x, is);
+                v[0] = p.alpha[ia]; v[1] = p.grad_alpha[ia];
+            }
+            if (p.return_rgb) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int64_t ic = idx3<IMG>(b, y, x, k, is);
+                    v[2 + k] = p.rgb[ic]; v[5 + k] = p.grad_rgb[ic];
+                }
+            }
+            PixRec rr;
+            rr.a = make_float4(v[0], v[1], v[2], v[3]);
+            rr.b = make_float4(v[4], v[5], v[6], v[7]);
+            rec_row[((int64_t)b * is + y) * is + x] = rr;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) tile[k][ly][tx] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PK_T / 8; r++) {
+        const int lx = ty8 + r * 8;      // column of the tile this thread row writes
+        const int x = x0 + lx, y = y0 + tx;  // consecutive threads -> consecutive y
+        if (x < is && y < is) {
+            PixRec rr;
+            rr.a = make_float4(tile[0][tx][lx], tile[1][tx][lx], tile[2][tx][lx], tile[3][tx][lx]);
+            rr.b = make_float4(tile[4][tx][lx], tile[5][tx][lx], tile[6][tx][lx], tile[7][tx][lx]);
+            rec_col[((int64_t)b * is + x) * is + y] = rr;
+        }
+    }
+}
+
+__device__ __forceinline__ float rec_diff_grad(const PixRec& r, float a_ref, const float* rgb_ref, bool ra, bool rr) {
+    float d = 0.0f;
+    if (ra) d += (r.a.x - a_ref) * r.a.y;
+    if (rr) {
+        d += (r.a.z - rgb_ref[0]) * r.b.y;
+        d += (r.a.w - rgb_ref[1]) * r.b.z;
+        d += (r.b.x - rgb_ref[2]) * r.b.w;
+    }
+    return d;
+}
+
+// One WAVE per face.  The (edge, axis, column) crossings of the face are enumerated as items;
+// a lane takes an item: crossing, in / out pixels and their records (all items' header loads in
+// flight together instead of one dependent round trip per column), then walks the item's short
+// "in" sweep by itself.  The "out" sweeps (up to the image border) and unusually long "in"
+// sweeps are walked by the whole wave, one item after the other, 64 records per step from the
+// copy that is contiguous along the sweep.  Same arithmetic per term as pixel_map_kernel; only
+// the order of the fp32 additions differs.
+constexpr int PM_LONG = 12;  // "in" sweeps longer than this are walked by the wave
+
+__global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p, const PixRec* __restrict__ rec_row,
+                                                               const PixRec* __restrict__ rec_col) {
+    const int64_t total = (int64_t)p.B * p.F;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // face of this wave
+    const int lane = threadIdx.x & 63;
+    if (i >= total) return;  // wave-uniform
+    const int is = p.is;
+    const float fis = (float)is;
+    const int b = (int)(i / p.F);
+    const int fn = (int)(i % p.F);
+    float face[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) face[k] = p.faces[i * 9 + k];
+    if (backfacing(face)) {
+        if (p.write_backfacing && lane < 9) p.grad_faces[i * 9 + lane] = 0.0f;
+        return;
+    }
+    const bool ra = p.return_alpha != 0, rr = p.return_rgb != 0;
+    const int32_t* fim_b = p.fim + (int64_t)b * is * is;
+    const PixRec* row_b = rec_row + (int64_t)b * is * is;
+    const PixRec* col_b = rec_col + (int64_t)b * is * is;
+    float px[3], py[3];  // pixel coordinates of the vertices
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        px[k] = 0.5f * (face[3 * k] * fis + fis - 1.0f);
+        py[k] = 0.5f * (face[3 * k + 1] * fis + fis - 1.0f);
+    }
+    // item ranges: k = 2 * edge + axis, columns d0_from[k] .. d0_to[k] (wave-uniform)
+    int from[6], off[7];
+    off[0] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int e = k >> 1, axis = k & 1;
+        const float q00 = axis == 0 ? px[e] : py[e], q10 = axis == 0 ? px[(e + 1) % 3] : py[(e + 1) % 3];
+        const int d0_from = (int)fmaxf(ceilf(fminf(q00, q10)), 0.0f);
+        const int d0_to = (int)fminf(fmaxf(q00, q10), fis - 1.0f);
+        from[k] = d0_from;
+        off[k + 1] = off[k] + max(d0_to - d0_from + 1, 0);
+    }
+    float acc[3][2];  // [vertex][component] partial sums of this lane
+#pragma unroll
+    for (int k = 0; k < 3; k++) { acc[k][0] = 0.0f; acc[k][1] = 0.0f; }
+
+    // one sweep of the whole wave: pixels d1_from .. d1_to of column / row d0
+    auto sweep = [&](int axis, int d0, int d1_from, int d1_to, float d1_cross, float c0, float c1, bool use0, bool use1,
+                     float a_ref, const float* rgb_ref, bool own_only, float& g0, float& g1) {
+        const PixRec* base = (axis == 0 ? col_b : row_b) + (int64_t)d0 * is;
+        for (int d1 = d1_from + lane; d1 <= d1_to; d1 += MR_WAVE) {
+            const PixRec r = base[d1];
+            if (own_only) {
+                const int xi = axis == 0 ? d0 : d1, yi = axis == 0 ? d1 : d0;
+                if (fim_b[yi * is + xi] != fn) continue;
+            }
+            const float dg = rec_diff_grad(r, a_ref, rgb_ref, ra, rr);
+            if (dg <= 0) continue;
+            if (use0) {
+                float dist = c0 * ((float)d1 - d1_cross) * 2.0f / fis;
+                dist = (0 < dist) ? dist + p.eps : dist - p.eps;
+                g0 -= dg / dist;
+            }
+            if (use1) {
+                float dist = c1 * ((float)d1 - d1_cross) * 2.0f / fis;
+                dist = (0 < dist) ? dist + p.eps : dist - p.eps;
+                g1 -= dg / dist;
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int base_item = 0; base_item < off[6]; base_item += MR_WAVE) {
+        const int item = base_item + lane;
+        bool valid = item < off[6];
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < 6; j++) k += (item >= off[j]) ? 1 : 0;
+        const int e = k >> 1, axis = k & 1;
+        int fromk = from[0], offk = off[0];
+#pragma unroll
+        for (int j = 1; j < 6; j++) { fromk = (k == j) ? from[j] : fromk; offk = (k == j) ? off[j] : offk; }
+        const int d0 = fromk + item - offk;
+        // q[num][dim]: vertices e, e+1, e+2 with the coordinate pair swapped for axis 1
+        float qx[3], qy[3];
+#pragma unroll
+        for (int num = 0; num < 3; num++) {
+            const float vx = (e == 0) ? px[num] : ((e == 1) ? px[(num + 1) % 3] : px[(num + 2) % 3]);
+            const float vy = (e == 0) ? py[num] : ((e == 1) ? py[(num + 1) % 3] : py[(num + 2) % 3]);
+            qx[num] = axis == 0 ? vx : vy;
+            qy[num] = axis == 0 ? vy : vx;
+        }
+        const int direction = (axis == 0) ? ((qx[0] < qx[1]) ? -1 : 1) : ((qx[0] < qx[1]) ? 1 : -1);
+        const float fd0 = (float)d0;
+        const float d1_cross = (qy[1] - qy[0]) / (qx[1] - qx[0]) * (fd0 - qx[0]) + qy[0];
+        const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
+        const int d1_out = d1_in + direction;
+        valid = valid && !(d1_in < 0 || is <= d1_in) && !(d1_out < 0 || is <= d1_out);
+        const int d1_in_c = min(max(d1_in, 0), is - 1), d1_out_c = min(max(d1_out, 0), is - 1), d0_c = min(d0, is - 1);
+        const int xin = axis == 0 ? d0_c : d1_in_c, yin = axis == 0 ? d1_in_c : d0_c;
+        const int xout = axis == 0 ? d0_c : d1_out_c, yout = axis == 0 ? d1_out_c : d0_c;
+        // header: both records and the owner of the "in" pixel (unconditional, clamped)
+        const PixRec r_in = row_b[yin * is + xin], r_out = row_b[yout * is + xout];
+        const bool visible = valid && fim_b[yin * is + xin] == fn;
+        const float a_in = r_in.a.x, a_out = r_out.a.x;
+        const float rgb_in[3] = {r_in.a.z, r_in.a.w, r_in.b.x}, rgb_out[3] = {r_out.a.z, r_out.a.w, r_out.b.x};
+        const float c0 = (qx[1] - qx[0]) / (qx[1] - fd0);
+        const float c1 = (qx[1] - qx[0]) / (fd0 - qx[0]);
+        const bool use0 = qx[1] != fd0, use1 = qx[0] != fd0;
+        // "in" sweep limits
+        float d0_cross2;
+        if ((fd0 - qx[0]) * (fd0 - qx[2]) < 0)
+            d0_cross2 = (qy[2] - qy[0]) / (qx[2] - qx[0]) * (fd0 - qx[0]) + qy[0];
+        else
+            d0_cross2 = (qy[1] - qy[2]) / (qx[1] - qx[2]) * (fd0 - qx[2]) + qy[2];
+        // (the float -> int conversion saturates on the GPU and in C alike only inside the int range:
+        // clamp in float first, the limits are clamped to the image below anyway)
+        const float lim_f = (0 < direction) ? ceilf(d0_cross2) : floorf(d0_cross2);
+        const int d1_limit = (lim_f == lim_f) ? (int)fminf(fmaxf(lim_f, -2.0f), fis + 1.0f) : (int)0x80000000;
+        const int in_from = max(min(d1_in, d1_limit), 0), in_to = min(max(d1_in, d1_limit), is - 1);
+        const bool long_in = valid && (in_to - in_from) >= PM_LONG;
+
+        float g0 = 0.0f, g1 = 0.0f;  // this lane's sums for (pi[0], 1 - axis) and (pi[1], 1 - axis)
+        // short "in" sweeps: the lane walks its own item
+        if (valid && !long_in) {
+            const PixRec* base = (axis == 0 ? col_b : row_b) + (int64_t)d0 * is;
+            for (int d1 = in_from; d1 <= in_to; d1++) {
+                const int xi = axis == 0 ? d0 : d1, yi = axis == 0 ? d1 : d0;
+                if (fim_b[yi * is + xi] != fn) continue;
+                const PixRec r = base[d1];
+                const float dg = rec_diff_grad(r, a_out, rgb_out, ra, rr);
+                if (dg <= 0) continue;
+                if (use0) {
+                    float dist = c0 * ((float)d1 - d1_cross) * 2.0f / fis;
+                    dist = (0 < dist) ? dist + p.eps : dist - p.eps;
+                    g0 -= dg / dist;
+                }
+                if (use1) {
+                    float dist = c1 * ((float)d1 - d1_cross) * 2.0f / fis;
+                    dist = (0 < dist) ? dist + p.eps : dist - p.eps;
+                    g1 -= dg / dist;
+                }
+            }
+        }
+        // lane-private sums -> accumulator slots (vertex pi[0] = e, pi[1] = e + 1; component 1 - axis)
+#pragma unroll
+        for (int v = 0; v < 3; v++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const bool comp = c == 1 - axis;
+                acc[v][c] += (comp && v == e) ? g0 : 0.0f;
+                acc[v][c] += (comp && v == (e + 1) % 3) ? g1 : 0.0f;
+            }
+
+        // wave sweeps: "out" of every visible item, "in" of the long ones
+        unsigned long long m_out = __ballot(visible), m_in = __ballot(long_in);
+        while (m_out | m_in) {
+            const bool is_out = m_out != 0ull;
+            const int src = __ffsll((long long)(is_out ? m_out : m_in)) - 1;
+            if (is_out) m_out &= m_out - 1; else m_in &= m_in - 1;
+            const int s_axis = __shfl(axis, src), s_e = __shfl(e, src), s_d0 = __shfl(d0, src);
+            const float s_cross = __shfl(d1_cross, src), s_c0 = __shfl(c0, src), s_c1 = __shfl(c1, src);
+            const bool s_use0 = __shfl((int)use0, src) != 0, s_use1 = __shfl((int)use1, src) != 0;
+            int s_from, s_to;
+            float s_a, s_rgb[3];
+            if (is_out) {
+                const int s_dir = __shfl(direction, src), s_out = __shfl(d1_out, src);
+                const int lim = (0 < s_dir) ? is - 1 : 0;
+                s_from = max(min(s_out, lim), 0); s_to = min(max(s_out, lim), is - 1);
+                s_a = __shfl(a_in, src);
+#pragma unroll
+                for (int c = 0; c < 3; c++) s_rgb[c] = __shfl(rgb_in[c], src);
+            } else {
+                s_from = __shfl(in_from, src); s_to = __shfl(in_to, src);
+                s_a = __shfl(a_out, src);
+#pragma unroll
+                for (int c = 0; c < 3; c++) s_rgb[c] = __shfl(rgb_out[c], src);
+            }
+            float w0 = 0.0f, w1 = 0.0f;
+            sweep(s_axis, s_d0, s_from, s_to, s_cross, s_c0, s_c1, s_use0, s_use1, s_a, s_rgb, !is_out, w0, w1);
+#pragma unroll
+            for (int v = 0; v < 3; v++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const bool comp = c == 1 - s_axis;
+                    acc[v][c] += (comp && v == s_e) ? w0 : 0.0f;
+                    acc[v][c] += (comp && v == (s_e + 1) % 3) ? w1 : 0.0f;
+                }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            acc[k][0] += __shfl_xor(acc[k][0], o);
+            acc[k][1] += __shfl_xor(acc[k][1], o);
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            p.grad_faces[i * 9 + 3 * k + 0] = acc[k][0];
+            p.grad_faces[i * 9 + 3 * k + 1] = acc[k][1];
+            p.grad_faces[i * 9 + 3 * k + 2] = 0.0f;
+        }
+    }
+}
+
 template <typename K, typename... A>
 static int launch1d(K kernel, int64_t n, hipStream_t s, A... args) {
     if (n <= 0) return MR_OK;
@@ -928,9 +1216,38 @@ static int launch1d(K kernel, int64_t n, hipStream_t s, A... args) {
     return MR_OK;
 }
 
+static int64_t pixel_map_workspace_bytes(int B, int is) {
+    return 2LL * (int64_t)B * is * is * (int64_t)sizeof(PixRec);
+}
+
+// kernel D: packed walks when a workspace of pixel_map_workspace_bytes is available, else the
+// plane-reading kernel (same results up to the order of the fp32 additions)
+template <bool IMG>
+static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t workspace_bytes, int flags,
+                            hipStream_t s) {
+    const int64_t nfaces = (int64_t)p.B * p.F;
+    if (!workspace || workspace_bytes < pixel_map_workspace_bytes(p.B, p.is) || (flags & MR_FLAG_REFERENCE_ALGO) ||
+        (int64_t)p.is * p.is > (1LL << 26))
+        return launch1d(pixel_map_kernel<IMG>, nfaces * MR_WAVE, s, p);
+    PixRec* rec_row = (PixRec*)workspace;
+    PixRec* rec_col = rec_row + (int64_t)p.B * p.is * p.is;
+    const int tiles = (p.is + PK_T - 1) / PK_T;
+    const int64_t nblk = (int64_t)p.B * tiles * tiles;
+    if (nblk > 0x7fffffffLL) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(pixel_pack_kernel<IMG>, dim3((unsigned)nblk), dim3(256), 0, s, p, rec_row, rec_col, tiles);
+    MR_CHECK_LAUNCH();
+    return launch1d(pixel_map_packed_kernel, nfaces * MR_WAVE, s, p, (const PixRec*)rec_row, (const PixRec*)rec_col);
+}
+
 }  // namespace mr
 
 using namespace mr;
+
+extern "C" int64_t mr_render_backward_workspace_bytes(int batch_size, int num_faces, int image_size) {
+    (void)num_faces;
+    if (batch_size < 0 || image_size <= 0) return MR_ERR_BADARG;
+    return pixel_map_workspace_bytes(batch_size, image_size);
+}
 
 extern "C" int mr_backward_pixel_map(const float* faces, const int32_t* face_index_map,
                                      const float* rgb_map, const float* alpha_map,
@@ -944,7 +1261,19 @@ extern "C" int mr_backward_pixel_map(const float* faces, const int32_t* face_ind
     if (!return_rgb && !return_alpha) return MR_OK;
     PixelMapParams p{faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
                      batch_size, num_faces, image_size, eps, return_rgb, return_alpha, 0};
-    return launch1d(pixel_map_kernel<false>, (int64_t)batch_size * num_faces * MR_WAVE, (hipStream_t)stream, p);
+    if (batch_size == 0 || num_faces == 0) return MR_OK;
+    // scratch for the packed walks, stream-ordered like the forward entry point's record list;
+    // if it cannot be had the plane-reading kernel does the same job
+    hipStream_t s = (hipStream_t)stream;
+    void* work = nullptr;
+    const int64_t bytes = pixel_map_workspace_bytes(batch_size, image_size);
+    if (hipMallocAsync(&work, (size_t)bytes, s) != hipSuccess) {
+        (void)hipGetLastError();
+        work = nullptr;
+    }
+    const int rc = launch_pixel_map<false>(p, work, work ? bytes : 0, 0, s);
+    if (work) (void)hipFreeAsync(work, s);
+    return rc;
 }
 
 extern "C" int mr_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
@@ -983,7 +1312,7 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
                                   int image_size, int texture_size, float near_, float far_, float eps,
                                   int return_rgb, int return_alpha, int return_depth, int flags,
                                   mr_stream_t stream) {
-    (void)textures; (void)workspace; (void)workspace_bytes; (void)near_; (void)far_;
+    (void)textures; (void)near_; (void)far_;
     if (batch_size < 0 || num_faces < 0 || image_size <= 0) return MR_ERR_BADARG;
     if (batch_size == 0 || num_faces == 0) return MR_OK;
     if (!faces || !face_index_map) return MR_ERR_BADARG;
@@ -1001,7 +1330,7 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
         const int rr = return_rgb && grad_rgb_img && rgb_img, ra = return_alpha && grad_alpha_img && alpha_img;
         PixelMapParams p{faces, face_index_map, rgb_img, alpha_img, grad_rgb_img, grad_alpha_img,
                          grad_faces, batch_size, num_faces, image_size, eps, rr, ra, 1};
-        rc = launch1d(pixel_map_kernel<true>, nfaces * MR_WAVE, s, p);
+        rc = launch_pixel_map<true>(p, workspace, workspace_bytes, flags, s);
         if (rc != MR_OK) return rc;
     }
     const bool want_f = grad_faces && return_depth && grad_depth_img;

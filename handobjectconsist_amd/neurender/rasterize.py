@@ -257,10 +257,14 @@ class RasterizeFusedFunction(Function):
             else:
                 grad_textures = torch.empty_like(tex)
         if want_faces or want_tex:
+            work, wbytes = None, 0
+            if want_faces and (g_rgb is not None or g_alpha is not None):  # kernel D runs: packed-walk scratch
+                wbytes = int(_lib.load().mr_render_backward_workspace_bytes(B, Fn, is_))
+                work = torch.empty((max(wbytes, 8),), dtype=torch.uint8, device=dev)
             _lib.call("mr_render_backward", _lib.ptr(faces), _lib.ptr(tex) if rr else None, _lib.ptr(fim),
                       _lib.ptr(rgb) if rr else None, _lib.ptr(alpha) if ra else None, _lib.ptr(g_rgb),
                       _lib.ptr(g_alpha), _lib.ptr(g_depth), _lib.ptr(grad_faces),
-                      _lib.ptr(grad_textures) if want_tex else None, None, 0, B, Fn, is_, ts, near, far, eps,
+                      _lib.ptr(grad_textures) if want_tex else None, _lib.ptr(work), wbytes, B, Fn, is_, ts, near, far, eps,
                       int(rr), int(ra), int(rd), flags, _lib.stream_ptr(dev))
         return grad_faces, grad_textures, None, None, None, None, None, None, None, None
 

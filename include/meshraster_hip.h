@@ -136,7 +136,12 @@ MR_API int mr_face_inv_map(const float* faces, const int32_t* face_index_map, fl
  * Sampling indices/weights and the per-pixel inverse are recomputed from
  * (faces, face_index_map) instead of being stored.  grad_faces[B,F,3,3] /
  * grad_textures[B,F,ts,ts,ts,3] are fully written (no pre-zeroing needed); either may
- * be NULL to skip it.  rgb_img / alpha_img are only read by the pixel-map term. */
+ * be NULL to skip it.  rgb_img / alpha_img are only read by the pixel-map term.
+ * workspace: optional scratch of mr_render_backward_workspace_bytes() bytes; with it kernel D
+ * walks two packed copies of the maps (row- and column-major 32-byte records) instead of eight
+ * strided planes.  NULL / too small: the plane-reading kernel runs (same result up to fp32
+ * summation order). */
+MR_API int64_t mr_render_backward_workspace_bytes(int batch_size, int num_faces, int image_size);
 MR_API int mr_render_backward(const float* faces, const float* textures,
                        const int32_t* face_index_map, const float* rgb_img,
                        const float* alpha_img, const float* grad_rgb_img,
