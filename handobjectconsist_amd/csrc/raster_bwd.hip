@@ -999,8 +999,21 @@ __device__ __forceinline__ float rec_diff_grad(const PixRec& r, float a_ref, con
 // "in" sweep by itself.  The "out" sweeps (up to the image border) and unusually long "in"
 // sweeps are walked by the whole wave, one item after the other, 64 records per step from the
 // copy that is contiguous along the sweep.  Same arithmetic per term as pixel_map_kernel; only
-// the order of the fp32 additions differs.
+// the order of the fp32 additions differs (and the two divisions per term, see pm_term).
 constexpr int PM_LONG = 12;  // "in" sweeps longer than this are walked by the wave
+
+// one accepted term of a walk: -dg / (c * (d1 - d1_cross) * 2 / is +- eps), with the two divisions
+// done as multiplications by reciprocals (v_rcp_f32, 1 ulp): the walks evaluate > 10^8 of these per
+// launch and an IEEE division is ten instructions
+__device__ __forceinline__ float pm_term(float dg, float c, float fd1, float d1_cross, float two_over_is, float eps) {
+    float dist = c * (fd1 - d1_cross) * two_over_is;
+    dist = (0 < dist) ? dist + eps : dist - eps;
+    return dg * __builtin_amdgcn_rcpf(dist);
+}
+__device__ __forceinline__ float pm_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ int pm_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p, const PixRec* __restrict__ rec_row,
                                                                const PixRec* __restrict__ rec_col) {
@@ -1010,6 +1023,7 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
     if (i >= total) return;  // wave-uniform
     const int is = p.is;
     const float fis = (float)is;
+    const float two_over_is = 2.0f / fis;
     const int b = (int)(i / p.F);
     const int fn = (int)(i % p.F);
     float face[9];
@@ -1057,16 +1071,8 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
             }
             const float dg = rec_diff_grad(r, a_ref, rgb_ref, ra, rr);
             if (dg <= 0) continue;
-            if (use0) {
-                float dist = c0 * ((float)d1 - d1_cross) * 2.0f / fis;
-                dist = (0 < dist) ? dist + p.eps : dist - p.eps;
-                g0 -= dg / dist;
-            }
-            if (use1) {
-                float dist = c1 * ((float)d1 - d1_cross) * 2.0f / fis;
-                dist = (0 < dist) ? dist + p.eps : dist - p.eps;
-                g1 -= dg / dist;
-            }
+            if (use0) g0 -= pm_term(dg, c0, (float)d1, d1_cross, two_over_is, p.eps);
+            if (use1) g1 -= pm_term(dg, c1, (float)d1, d1_cross, two_over_is, p.eps);
         }
     };
 
@@ -1131,16 +1137,8 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
                 const PixRec r = base[d1];
                 const float dg = rec_diff_grad(r, a_out, rgb_out, ra, rr);
                 if (dg <= 0) continue;
-                if (use0) {
-                    float dist = c0 * ((float)d1 - d1_cross) * 2.0f / fis;
-                    dist = (0 < dist) ? dist + p.eps : dist - p.eps;
-                    g0 -= dg / dist;
-                }
-                if (use1) {
-                    float dist = c1 * ((float)d1 - d1_cross) * 2.0f / fis;
-                    dist = (0 < dist) ? dist + p.eps : dist - p.eps;
-                    g1 -= dg / dist;
-                }
+                if (use0) g0 -= pm_term(dg, c0, (float)d1, d1_cross, two_over_is, p.eps);
+                if (use1) g1 -= pm_term(dg, c1, (float)d1, d1_cross, two_over_is, p.eps);
             }
         }
         // lane-private sums -> accumulator slots (vertex pi[0] = e, pi[1] = e + 1; component 1 - axis)
@@ -1157,25 +1155,25 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
         unsigned long long m_out = __ballot(visible), m_in = __ballot(long_in);
         while (m_out | m_in) {
             const bool is_out = m_out != 0ull;
-            const int src = __ffsll((long long)(is_out ? m_out : m_in)) - 1;
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)(is_out ? m_out : m_in)) - 1);
             if (is_out) m_out &= m_out - 1; else m_in &= m_in - 1;
-            const int s_axis = __shfl(axis, src), s_e = __shfl(e, src), s_d0 = __shfl(d0, src);
-            const float s_cross = __shfl(d1_cross, src), s_c0 = __shfl(c0, src), s_c1 = __shfl(c1, src);
-            const bool s_use0 = __shfl((int)use0, src) != 0, s_use1 = __shfl((int)use1, src) != 0;
+            const int s_axis = pm_bcast(axis, src), s_e = pm_bcast(e, src), s_d0 = pm_bcast(d0, src);
+            const float s_cross = pm_bcast(d1_cross, src), s_c0 = pm_bcast(c0, src), s_c1 = pm_bcast(c1, src);
+            const bool s_use0 = pm_bcast((int)use0, src) != 0, s_use1 = pm_bcast((int)use1, src) != 0;
             int s_from, s_to;
             float s_a, s_rgb[3];
             if (is_out) {
-                const int s_dir = __shfl(direction, src), s_out = __shfl(d1_out, src);
+                const int s_dir = pm_bcast(direction, src), s_out = pm_bcast(d1_out, src);
                 const int lim = (0 < s_dir) ? is - 1 : 0;
                 s_from = max(min(s_out, lim), 0); s_to = min(max(s_out, lim), is - 1);
-                s_a = __shfl(a_in, src);
+                s_a = pm_bcast(a_in, src);
 #pragma unroll
-                for (int c = 0; c < 3; c++) s_rgb[c] = __shfl(rgb_in[c], src);
+                for (int c = 0; c < 3; c++) s_rgb[c] = pm_bcast(rgb_in[c], src);
             } else {
-                s_from = __shfl(in_from, src); s_to = __shfl(in_to, src);
-                s_a = __shfl(a_out, src);
+                s_from = pm_bcast(in_from, src); s_to = pm_bcast(in_to, src);
+                s_a = pm_bcast(a_out, src);
 #pragma unroll
-                for (int c = 0; c < 3; c++) s_rgb[c] = __shfl(rgb_out[c], src);
+                for (int c = 0; c < 3; c++) s_rgb[c] = pm_bcast(rgb_out[c], src);
             }
             float w0 = 0.0f, w1 = 0.0f;
             sweep(s_axis, s_d0, s_from, s_to, s_cross, s_c0, s_c1, s_use0, s_use1, s_a, s_rgb, !is_out, w0, w1);
