@@ -752,6 +752,7 @@ struct PixelMapParams {
     float eps;
     int return_rgb, return_alpha;
     int write_backfacing;  // fused path: also zero the rows of culled faces
+    int dbg;               // profiling experiments (flags >> 8)
 };
 
 template <bool IMG>
@@ -936,7 +937,8 @@ constexpr int PK_T = 32;  // transpose tile
 
 template <bool IMG>
 __global__ void __launch_bounds__(256) pixel_pack_kernel(PixelMapParams p, PixRec* __restrict__ rec_row,
-                                                         PixRec* __restrict__ rec_col, int tiles) {
+                                                         PixRec* __restrict__ rec_col, uint8_t* __restrict__ owns,
+                                                         int tiles) {
     __shared__ float tile[8][PK_T][PK_T + 1];
     const int is = p.is;
     const int b = blockIdx.x / (tiles * tiles);
@@ -964,6 +966,9 @@ __global__ void __launch_bounds__(256) pixel_pack_kernel(PixelMapParams p, PixRe
             rr.a = make_float4(v[0], v[1], v[2], v[3]);
             rr.b = make_float4(v[4], v[5], v[6], v[7]);
             rec_row[((int64_t)b * is + y) * is + x] = rr;
+            // a face that owns no pixel contributes nothing to D (both sweeps are gated on ownership)
+            const int fn = p.fim[((int64_t)b * is + y) * is + x];
+            if (fn >= 0) owns[(int64_t)b * p.F + fn] = 1;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) tile[k][ly][tx] = v[k];
@@ -1016,11 +1021,18 @@ __device__ __forceinline__ float pm_bcast(float v, int src) {
 __device__ __forceinline__ int pm_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p, const PixRec* __restrict__ rec_row,
-                                                               const PixRec* __restrict__ rec_col) {
+                                                               const PixRec* __restrict__ rec_col,
+                                                               const uint8_t* __restrict__ owns) {
     const int64_t total = (int64_t)p.B * p.F;
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // face of this wave
+    // XCD-aware: every XCD works through a contiguous range of faces, i.e. a few images at a time, whose
+    // packed records (4 MB per 256 x 256 image) then stay in that XCD's L2 across the sweeps
+    const int64_t i = ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;  // face of this wave
     const int lane = threadIdx.x & 63;
     if (i >= total) return;  // wave-uniform
+    if (!owns[i]) {
+        if (lane < 9 && (p.write_backfacing || !backfacing(p.faces + i * 9))) p.grad_faces[i * 9 + lane] = 0.0f;
+        return;
+    }
     const int is = p.is;
     const float fis = (float)is;
     const float two_over_is = 2.0f / fis;
@@ -1129,7 +1141,7 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
 
         float g0 = 0.0f, g1 = 0.0f;  // this lane's sums for (pi[0], 1 - axis) and (pi[1], 1 - axis)
         // short "in" sweeps: the lane walks its own item
-        if (valid && !long_in) {
+        if (valid && !long_in && !(p.dbg & 2)) {
             const PixRec* base = (axis == 0 ? col_b : row_b) + (int64_t)d0 * is;
             for (int d1 = in_from; d1 <= in_to; d1++) {
                 const int xi = axis == 0 ? d0 : d1, yi = axis == 0 ? d1 : d0;
@@ -1153,6 +1165,8 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
 
         // wave sweeps: "out" of every visible item, "in" of the long ones
         unsigned long long m_out = __ballot(visible), m_in = __ballot(long_in);
+        if (p.dbg & 1) { m_out = 0ull; m_in = 0ull; }
+        if (p.dbg & 4) { m_out &= 1ull; }
         while (m_out | m_in) {
             const bool is_out = m_out != 0ull;
             const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)(is_out ? m_out : m_in)) - 1);
@@ -1214,8 +1228,9 @@ static int launch1d(K kernel, int64_t n, hipStream_t s, A... args) {
     return MR_OK;
 }
 
-static int64_t pixel_map_workspace_bytes(int B, int is) {
-    return 2LL * (int64_t)B * is * is * (int64_t)sizeof(PixRec);
+static int64_t pixel_map_workspace_bytes(int B, int F, int is) {
+    // packed records (row- and column-major) | per-face "owns a pixel" flags
+    return 2LL * (int64_t)B * is * is * (int64_t)sizeof(PixRec) + (((int64_t)B * F + 255) & ~255LL);
 }
 
 // kernel D: packed walks when a workspace of pixel_map_workspace_bytes is available, else the
@@ -1224,17 +1239,21 @@ template <bool IMG>
 static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t workspace_bytes, int flags,
                             hipStream_t s) {
     const int64_t nfaces = (int64_t)p.B * p.F;
-    if (!workspace || workspace_bytes < pixel_map_workspace_bytes(p.B, p.is) || (flags & MR_FLAG_REFERENCE_ALGO) ||
+    if (!workspace || workspace_bytes < pixel_map_workspace_bytes(p.B, p.F, p.is) || (flags & MR_FLAG_REFERENCE_ALGO) ||
         (int64_t)p.is * p.is > (1LL << 26))
         return launch1d(pixel_map_kernel<IMG>, nfaces * MR_WAVE, s, p);
     PixRec* rec_row = (PixRec*)workspace;
     PixRec* rec_col = rec_row + (int64_t)p.B * p.is * p.is;
+    uint8_t* owns = (uint8_t*)(rec_col + (int64_t)p.B * p.is * p.is);
+    hipError_t e = hipMemsetAsync(owns, 0, (size_t)nfaces, s);
+    if (e != hipSuccess) return (int)e;
     const int tiles = (p.is + PK_T - 1) / PK_T;
     const int64_t nblk = (int64_t)p.B * tiles * tiles;
     if (nblk > 0x7fffffffLL) return MR_ERR_BADARG;
-    hipLaunchKernelGGL(pixel_pack_kernel<IMG>, dim3((unsigned)nblk), dim3(256), 0, s, p, rec_row, rec_col, tiles);
+    hipLaunchKernelGGL(pixel_pack_kernel<IMG>, dim3((unsigned)nblk), dim3(256), 0, s, p, rec_row, rec_col, owns, tiles);
     MR_CHECK_LAUNCH();
-    return launch1d(pixel_map_packed_kernel, nfaces * MR_WAVE, s, p, (const PixRec*)rec_row, (const PixRec*)rec_col);
+    return launch1d(pixel_map_packed_kernel, nfaces * MR_WAVE, s, p, (const PixRec*)rec_row, (const PixRec*)rec_col,
+                    (const uint8_t*)owns);
 }
 
 }  // namespace mr
@@ -1242,9 +1261,8 @@ static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t wo
 using namespace mr;
 
 extern "C" int64_t mr_render_backward_workspace_bytes(int batch_size, int num_faces, int image_size) {
-    (void)num_faces;
-    if (batch_size < 0 || image_size <= 0) return MR_ERR_BADARG;
-    return pixel_map_workspace_bytes(batch_size, image_size);
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0) return MR_ERR_BADARG;
+    return pixel_map_workspace_bytes(batch_size, num_faces, image_size);
 }
 
 extern "C" int mr_backward_pixel_map(const float* faces, const int32_t* face_index_map,
@@ -1258,13 +1276,13 @@ extern "C" int mr_backward_pixel_map(const float* faces, const int32_t* face_ind
     if (batch_size < 0 || num_faces < 0 || image_size <= 0) return MR_ERR_BADARG;
     if (!return_rgb && !return_alpha) return MR_OK;
     PixelMapParams p{faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
-                     batch_size, num_faces, image_size, eps, return_rgb, return_alpha, 0};
+                     batch_size, num_faces, image_size, eps, return_rgb, return_alpha, 0, 0};
     if (batch_size == 0 || num_faces == 0) return MR_OK;
     // scratch for the packed walks, stream-ordered like the forward entry point's record list;
     // if it cannot be had the plane-reading kernel does the same job
     hipStream_t s = (hipStream_t)stream;
     void* work = nullptr;
-    const int64_t bytes = pixel_map_workspace_bytes(batch_size, image_size);
+    const int64_t bytes = pixel_map_workspace_bytes(batch_size, num_faces, image_size);
     if (hipMallocAsync(&work, (size_t)bytes, s) != hipSuccess) {
         (void)hipGetLastError();
         work = nullptr;
@@ -1327,7 +1345,7 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
     if (want_d) {
         const int rr = return_rgb && grad_rgb_img && rgb_img, ra = return_alpha && grad_alpha_img && alpha_img;
         PixelMapParams p{faces, face_index_map, rgb_img, alpha_img, grad_rgb_img, grad_alpha_img,
-                         grad_faces, batch_size, num_faces, image_size, eps, rr, ra, 1};
+                         grad_faces, batch_size, num_faces, image_size, eps, rr, ra, 1, flags >> 8};
         rc = launch_pixel_map<true>(p, workspace, workspace_bytes, flags, s);
         if (rc != MR_OK) return rc;
     }
