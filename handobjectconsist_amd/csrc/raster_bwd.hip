@@ -988,6 +988,7 @@ __global__ void __launch_bounds__(256) pixel_pack_kernel(PixelMapParams p, PixRe
 }
 
 __device__ __forceinline__ float rec_diff_grad(const PixRec& r, float a_ref, const float* rgb_ref, bool ra, bool rr) {
+#pragma clang fp contract(fast)  // fused multiply-adds: D is compared to 1e-4, not bit for bit
     float d = 0.0f;
     if (ra) d += (r.a.x - a_ref) * r.a.y;
     if (rr) {
@@ -1011,7 +1012,7 @@ constexpr int PM_LONG = 12;  // "in" sweeps longer than this are walked by the w
 // done as multiplications by reciprocals (v_rcp_f32, 1 ulp): the walks evaluate > 10^8 of these per
 // launch and an IEEE division is ten instructions
 __device__ __forceinline__ float pm_term(float dg, float c, float fd1, float d1_cross, float two_over_is, float eps) {
-    float dist = c * (fd1 - d1_cross) * two_over_is;
+    float dist = (c * two_over_is) * (fd1 - d1_cross);  // c * two_over_is is loop-invariant
     dist = (0 < dist) ? dist + eps : dist - eps;
     return dg * __builtin_amdgcn_rcpf(dist);
 }
@@ -1191,13 +1192,14 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
             }
             float w0 = 0.0f, w1 = 0.0f;
             sweep(s_axis, s_d0, s_from, s_to, s_cross, s_c0, s_c1, s_use0, s_use1, s_a, s_rgb, !is_out, w0, w1);
+            // the slots are wave-uniform here: scalar branches instead of 12 selects
+            const int sc = 1 - s_axis, v0 = s_e, v1 = s_e == 2 ? 0 : s_e + 1;
 #pragma unroll
             for (int v = 0; v < 3; v++)
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    const bool comp = c == 1 - s_axis;
-                    acc[v][c] += (comp && v == s_e) ? w0 : 0.0f;
-                    acc[v][c] += (comp && v == (s_e + 1) % 3) ? w1 : 0.0f;
+                    if (v == v0 && c == sc) acc[v][c] += w0;
+                    if (v == v1 && c == sc) acc[v][c] += w1;
                 }
         }
     }
