@@ -227,9 +227,27 @@ class SynthMeshRegNet(nn.Module):
         self.obj_trans_factor, self.obj_scale_factor = obj_trans_factor, obj_scale_factor
         self.lam = (lambda_recov_joints3d, lambda_obj_recov_verts3d, lambda_pose_reg, lambda_shape)
 
-    def forward(self, sample, no_loss=False):
+    def encode_frames(self, samples):
+        """ONE encoder pass over the frames of several samples (same resolution): the reference runs
+        the ResNet once per frame (warpreg.py:86-90); with the BatchNorm statistics frozen
+        (--freeze_batchnorm) every layer acts per image, so the concatenated pass gives the same
+        features with a third of the launches.  The features are left in
+        ``sample["_features"]`` for the following ``forward(sample)`` calls."""
+        if self.base_net.training:
+            raise RuntimeError("encode_frames needs frozen BatchNorm statistics (model.eval())")
+        sizes = [s["image"].shape[0] for s in samples]
+        feats = self.base_net(torch.cat([s["image"] for s in samples]))
+        for s, f in zip(samples, feats.split(sizes)):
+            s["_features"] = f
+
+    def forward(self, sample, no_loss=False, encode_only=False):
+        if encode_only:  # (through forward so that a DistributedDataParallel wrapper sees the call)
+            self.encode_frames(sample)
+            return None
         image = sample["image"]
-        features = self.base_net(image)
+        features = sample.get("_features")
+        if features is None:
+            features = self.base_net(image)
         H, W = image.shape[2:]
         camintr = sample["camintr"]
         lam_j, lam_o, lam_pose, lam_shape = self.lam

@@ -84,6 +84,19 @@ class WarpRegNet(torch.nn.Module):
             first_only=self.first_only, hand_ignore_faces=self.hand_ignore_faces, use_backward=self.use_backward,
             pair_outputs=self.pair_outputs)
 
+    def preencode(self, batches):
+        """Run the image encoder ONCE over all frames of `batches` (the data batch and both frames of
+        the consist batch of one optimiser step) when the wrapped model offers it and its BatchNorm
+        statistics are frozen; the per-frame ``self.model(sample)`` calls then reuse the features."""
+        core = getattr(self.model, "module", self.model)
+        if not hasattr(core, "encode_frames") or core.training:
+            return False
+        samples = [s for batch in batches for s in batch["data"]]
+        if len({tuple(s["image"].shape[1:]) for s in samples}) != 1:
+            return False
+        self.model(samples, encode_only=True)
+        return True
+
     def forward(self, batch):
         samples, supervision = batch["data"], batch["supervision"]
         outputs = [self.model(sample) for sample in samples]  # (loss, results, losses) per frame

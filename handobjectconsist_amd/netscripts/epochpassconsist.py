@@ -3,18 +3,36 @@ meshreg/netscripts/epochpassconsist.py:56-68 (metric meters, evaluators and figu
 out of scope).  Loss is accumulated over ``loader_nb`` consecutive batches, then ONE
 ``zero_grad / backward / step``: that is the "iteration" of the headline metric.
 """
+import os
+
 import torch
 
 from handobjectconsist_amd.utils import synth
 
 
+# One encoder pass over all frames of a step instead of one per frame (WarpRegNet.preencode): same
+# features when the BatchNorm statistics are frozen, a third of the encoder's launches.  Measured on
+# MI355X (scripts/cpu_floor.py): the launch-bound floor of a step drops from 27 ms to 17 ms, but at
+# the headline size (B=64, 256x256) the step is GPU-bound and MIOpen's fp32 Winograd kernels are ~1.3x
+# slower per image at B=192 than at B=64 (52.7 ms -> 57.9 ms per step) -- so this is OFF by default
+# and meant for small batches (HOC_BATCH_ENCODER=1).
+BATCH_ENCODER = os.environ.get("HOC_BATCH_ENCODER", "0") == "1"
+
+
 def train_step(batches, premodel, optimizer):
     """One optimiser step over `loader_nb = len(batches)` batches (epochpassconsist.py:57-68)."""
     losses, logs = [], {}
-    for batch in batches:
-        loss, all_losses, _results, _pair_results = premodel.forward(batch)
-        losses.append(loss.flatten())
-        logs.update({k: v for k, v in all_losses.items() if v is not None})
+    if BATCH_ENCODER and hasattr(premodel, "preencode"):
+        premodel.preencode(batches)
+    try:
+        for batch in batches:
+            loss, all_losses, _results, _pair_results = premodel.forward(batch)
+            losses.append(loss.flatten())
+            logs.update({k: v for k, v in all_losses.items() if v is not None})
+    finally:
+        for batch in batches:  # the features belong to this step's autograd graph
+            for sample in batch["data"]:
+                sample.pop("_features", None)
     optimizer.zero_grad(set_to_none=True)
     loss = torch.stack(losses).sum()
     if loss.requires_grad:

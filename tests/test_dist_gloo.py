@@ -32,6 +32,9 @@ def _worker(rank, world, port, out):
     opt = torch.optim.SGD(model.parameters(), lr=1e-3)
     ld = SyntheticConsistLoader(2, 64, seed=rank, device="cpu", pool=1)  # distinct shard per rank
     data, consist = ld.step_batches(0)
+    # one encoder pass over the three frames of the step (WarpRegNet.preencode), through the DDP wrapper
+    net([data["data"][0]] + list(consist["data"]), encode_only=True)
+    assert all("_features" in s for s in consist["data"])
     # epochpassconsist.py:57-68 structure: three forwards through the SAME DDP module, one backward
     losses = [net(data["data"][0])[0]]
     for sample in consist["data"]:
@@ -72,7 +75,8 @@ def test_ddp_gloo_two_ranks(tmp_path):
     # replicas stay in sync after the step
     assert torch.equal(res["w"][0], res["w"][1])
     assert torch.equal(res["g"][0], res["g"][1])
-    # and the synchronised gradient is the mean of the per-shard gradients
+    # and the synchronised gradient is the mean of the per-shard gradients (computed with the
+    # reference's one-encoder-pass-per-frame structure: the batched pass gives the same result)
     torch.set_num_threads(4)
     expect = (_local_grad(0) + _local_grad(1)) / 2
     err = (res["g"][0] - expect).abs().max() / expect.abs().max()
