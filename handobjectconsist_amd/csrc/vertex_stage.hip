@@ -1,0 +1,167 @@
+// vertex_stage.hip -- the per-vertex front end of get_opticalflow for gfx950 (SURVEY 8f "f1").
+//
+// Replaces, for the training setting (vertex-colour render, detach_renders=True):
+//   libyana camutils.project.batch_proj2d on both frames           (opticalflow.py:98-99)
+//   the two displacement textures  (p2 - p1, 1) and (p1 - p2, 1)    (opticalflow.py:101-102, 121-122)
+//   Renderer.project -> nr.projection of both frames               (renderer.py:164-188, 278)
+// and their autograd, ~150 small element-wise / bmm launches over [B,V,3] tensors, by ONE kernel
+// per direction.  One thread per (image, vertex); the camera matrices of the image are wave-uniform.
+// Arithmetic follows the operation order of the PyTorch expressions it replaces; the 3-term products of
+// the matmuls are FMA chains in k order (what the BLAS kernels behind torch.bmm / numpy.matmul do), so the
+// projected vertices -- and with them every coverage / validity decision downstream -- agree with the
+// op-by-op path to the last bit in practice.
+#include "mr_common.hpp"
+
+namespace mr {
+
+struct VertexStageParams {
+    const float* verts1;  // [B,V,3] camera frame
+    const float* verts2;
+    const float* K1;      // [B,3,3]
+    const float* K2;
+    const float* R;       // [Bc,3,3]  (Bc = 1 or B)
+    const float* t;       // [Bc,3]
+    const float* dist;    // [Bc,5]
+    int cam_bstride;      // 0 (broadcast) or 1
+    float orig_size;
+    float* ndc1;          // [B,V,3]
+    float* ndc2;
+    float* cols12;        // [B,V,3] = (p2 - p1, 1)
+    float* cols21;        // [B,V,3] = (p1 - p2, 1)
+    int B, V;
+};
+
+__device__ __forceinline__ float dot3(const float* a, const float* b) {
+    return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]));
+}
+
+// batch_proj2d: (K v)[:2] / (K v)[2]
+__device__ __forceinline__ void proj2d(const float* K, const float* v, float* h, float& px, float& py) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) h[i] = dot3(K + 3 * i, v);
+    px = h[0] / h[2];
+    py = h[1] / h[2];
+}
+
+// nr.projection
+__device__ __forceinline__ void ndc_project(const float* K, const float* R, const float* t, const float* d, float os,
+                                            const float* v, float* out) {
+    float c[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) c[i] = dot3(R + 3 * i, v) + t[i];
+    const float z = c[2];
+    const float x_ = c[0] / (z + 1e-9f), y_ = c[1] / (z + 1e-9f);
+    const float k1 = d[0], k2 = d[1], p1 = d[2], p2 = d[3], k3 = d[4];
+    const float r = sqrtf(x_ * x_ + y_ * y_);
+    const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2;
+    const float rad = 1.0f + k1 * r2 + k2 * r4 + k3 * r6;
+    const float x__ = x_ * rad + 2.0f * p1 * x_ * y_ + p2 * (r2 + 2.0f * (x_ * x_));
+    const float y__ = y_ * rad + p1 * (r2 + 2.0f * (y_ * y_)) + 2.0f * p2 * x_ * y_;
+    const float xy1[3] = {x__, y__, 1.0f};
+    float u = dot3(K, xy1);
+    float w = dot3(K + 3, xy1);
+    w = os - w;
+    out[0] = 2.0f * (u - os / 2.0f) / os;
+    out[1] = 2.0f * (w - os / 2.0f) / os;
+    out[2] = z;
+}
+
+__global__ void __launch_bounds__(256) flow_vertices_forward_kernel(VertexStageParams p) {
+    const int b = blockIdx.y;
+    const int vi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vi >= p.V) return;
+    float K1[9], K2[9], R[9], t[3], d[5];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        K1[k] = p.K1[b * 9 + k]; K2[k] = p.K2[b * 9 + k];
+        R[k] = p.R[(int64_t)b * p.cam_bstride * 9 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = p.t[(int64_t)b * p.cam_bstride * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 5; k++) d[k] = p.dist[(int64_t)b * p.cam_bstride * 5 + k];
+    const int64_t o = ((int64_t)b * p.V + vi) * 3;
+    const float v1[3] = {p.verts1[o], p.verts1[o + 1], p.verts1[o + 2]};
+    const float v2[3] = {p.verts2[o], p.verts2[o + 1], p.verts2[o + 2]};
+    float h[3], a[2], c[2];
+    proj2d(K1, v1, h, a[0], a[1]);
+    proj2d(K2, v2, h, c[0], c[1]);
+    p.cols12[o] = c[0] - a[0]; p.cols12[o + 1] = c[1] - a[1]; p.cols12[o + 2] = 1.0f;
+    p.cols21[o] = a[0] - c[0]; p.cols21[o + 1] = a[1] - c[1]; p.cols21[o + 2] = 1.0f;
+    float n[3];
+    ndc_project(K1, R, t, d, p.orig_size, v1, n);
+    p.ndc1[o] = n[0]; p.ndc1[o + 1] = n[1]; p.ndc1[o + 2] = n[2];
+    ndc_project(K2, R, t, d, p.orig_size, v2, n);
+    p.ndc2[o] = n[0]; p.ndc2[o + 1] = n[1]; p.ndc2[o + 2] = n[2];
+}
+
+// adjoint of (verts1, verts2) -> (cols12, cols21); grad_verts* may be NULL
+__global__ void __launch_bounds__(256) flow_vertices_backward_kernel(const float* __restrict__ verts1,
+                                                                     const float* __restrict__ verts2,
+                                                                     const float* __restrict__ K1g,
+                                                                     const float* __restrict__ K2g,
+                                                                     const float* __restrict__ g12,
+                                                                     const float* __restrict__ g21,
+                                                                     float* __restrict__ grad_verts1,
+                                                                     float* __restrict__ grad_verts2, int B, int V) {
+    const int b = blockIdx.y;
+    const int vi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vi >= V) return;
+    const int64_t o = ((int64_t)b * V + vi) * 3;
+    // d loss / d p1 = g21 - g12,  d loss / d p2 = g12 - g21  (x, y components; the constant 1 has no gradient)
+    float ga[2] = {0.0f, 0.0f};
+    if (g12) { ga[0] += g12[o]; ga[1] += g12[o + 1]; }
+    if (g21) { ga[0] -= g21[o]; ga[1] -= g21[o + 1]; }
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+        float* out = f == 0 ? grad_verts1 : grad_verts2;
+        if (!out) continue;
+        const float* K = (f == 0 ? K1g : K2g) + b * 9;
+        const float* vp = (f == 0 ? verts1 : verts2) + o;
+        const float v[3] = {vp[0], vp[1], vp[2]};
+        const float sgn = f == 0 ? -1.0f : 1.0f;  // p1 enters cols12 with a minus sign
+        const float gp[2] = {sgn * ga[0], sgn * ga[1]};
+        float h[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) h[i] = K[3 * i] * v[0] + K[3 * i + 1] * v[1] + K[3 * i + 2] * v[2];
+        // p = (h0 / h2, h1 / h2)
+        const float gh[3] = {gp[0] / h[2], gp[1] / h[2], -(gp[0] * h[0] + gp[1] * h[1]) / (h[2] * h[2])};
+#pragma unroll
+        for (int j = 0; j < 3; j++) out[o + j] = K[j] * gh[0] + K[3 + j] * gh[1] + K[6 + j] * gh[2];
+    }
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+extern "C" int mr_flow_vertices_forward(const float* verts1, const float* verts2, const float* K1, const float* K2,
+                                        const float* R, const float* t, const float* dist_coeffs, int cam_batched,
+                                        float orig_size, float* ndc1, float* ndc2, float* cols12, float* cols21,
+                                        int batch_size, int num_verts, mr_stream_t stream) {
+    if (batch_size < 0 || num_verts < 0 || !(orig_size > 0.0f)) return MR_ERR_BADARG;
+    if (batch_size == 0 || num_verts == 0) return MR_OK;
+    if (!verts1 || !verts2 || !K1 || !K2 || !R || !t || !dist_coeffs || !ndc1 || !ndc2 || !cols12 || !cols21)
+        return MR_ERR_BADARG;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    VertexStageParams p{verts1, verts2, K1, K2, R, t, dist_coeffs, cam_batched ? 1 : 0, orig_size,
+                        ndc1, ndc2, cols12, cols21, batch_size, num_verts};
+    hipLaunchKernelGGL(flow_vertices_forward_kernel, dim3((unsigned)((num_verts + 255) / 256), (unsigned)batch_size),
+                       dim3(256), 0, (hipStream_t)stream, p);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_flow_vertices_backward(const float* verts1, const float* verts2, const float* K1, const float* K2,
+                                         const float* grad_cols12, const float* grad_cols21, float* grad_verts1,
+                                         float* grad_verts2, int batch_size, int num_verts, mr_stream_t stream) {
+    if (batch_size < 0 || num_verts < 0) return MR_ERR_BADARG;
+    if (batch_size == 0 || num_verts == 0 || (!grad_verts1 && !grad_verts2)) return MR_OK;
+    if (!verts1 || !verts2 || !K1 || !K2) return MR_ERR_BADARG;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(flow_vertices_backward_kernel, dim3((unsigned)((num_verts + 255) / 256), (unsigned)batch_size),
+                       dim3(256), 0, (hipStream_t)stream, verts1, verts2, K1, K2, grad_cols12, grad_cols21, grad_verts1,
+                       grad_verts2, batch_size, num_verts);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}

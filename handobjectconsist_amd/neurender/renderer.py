@@ -199,6 +199,13 @@ class Renderer(nn.Module):
         if not self.no_light:
             raise ValueError("render_vertex_colors requires no_light=True")
         v = self.project(vertices, K, R, t, dist_coeffs, orig_size).detach()
+        return self.render_projected_vertex_colors(v, faces, vertex_colors)
+
+    def render_projected_vertex_colors(self, vertices_ndc, faces, vertex_colors):
+        """``render_vertex_colors`` for vertices that already went through ``project`` (the fused
+        vertex stage of the optical-flow path projects both frames of a pair in one kernel)."""
+        if not self.no_light:
+            raise ValueError("render_vertex_colors requires no_light=True")
         return rasterize.rasterize_vertex_colors(
-            v, faces, vertex_colors, self.fill_back, self.image_size, self.anti_aliasing, self.near, self.far,
-            self.rasterizer_eps, self.background_color)
+            vertices_ndc.detach(), faces, vertex_colors, self.fill_back, self.image_size, self.anti_aliasing, self.near,
+            self.far, self.rasterizer_eps, self.background_color)

@@ -59,14 +59,64 @@ USE_VERTEX_COLOR_RENDER = True
 def _render_flow(neurenderer, verts, faces, sample_flows, camintr, detach_textures, detach_renders):
     """neurenderer(verts, faces, batch_vertex_textures(faces, sample_flows), K=..., detach_renders=...)
     (opticalflow.py:103-108)."""
-    if (USE_VERTEX_COLOR_RENDER and detach_renders and hasattr(neurenderer, "render_vertex_colors")
-            and getattr(neurenderer, "no_light", False) and getattr(neurenderer, "camera_mode", "") == "projection"):
+    if _vertex_color_path(neurenderer, detach_renders):
         cols = sample_flows.detach() if detach_textures else sample_flows
         return neurenderer.render_vertex_colors(verts, faces, cols, K=camintr)
     all_textures = textutils.batch_vertex_textures(faces, sample_flows)
     if detach_textures:
         all_textures = all_textures.detach()
     return neurenderer(verts, faces, all_textures, K=camintr, detach_renders=detach_renders)
+
+
+# One kernel for batch_proj2d of both frames, the two displacement textures and the renderer's
+# camera projection of both frames (mr_flow_vertices_forward / _backward) instead of ~150 small
+# PyTorch launches; used with the vertex-colour render + fused epilogue.  False: op-by-op as in the
+# reference (same values up to fp32 rounding of the 3x3 products).
+USE_FUSED_VERTEX_STAGE = True
+
+
+class _FlowVertexStage(torch.autograd.Function):
+    """(verts1, verts2, K1, K2; R, t, dist, orig_size) -> (ndc1, ndc2, cols12, cols21); differentiable
+    w.r.t. the vertices through the two displacement textures only (detach_renders=True)."""
+
+    @staticmethod
+    def forward(ctx, verts1, verts2, K1, K2, R, t, dist, orig_size):
+        v1, v2 = _lib.contig(verts1.detach()), _lib.contig(verts2.detach())
+        k1, k2 = _lib.contig(K1.detach()), _lib.contig(K2.detach())
+        B, V = v1.shape[:2]
+        Rc = _lib.contig(R.detach().reshape(-1, 3, 3))
+        tc = _lib.contig(t.detach().reshape(-1, 3))
+        dc = _lib.contig(dist.detach().reshape(-1, 5))
+        nb = Rc.shape[0]
+        if v2.shape != v1.shape or k1.shape != (B, 3, 3) or k2.shape != (B, 3, 3) or nb not in (1, B) \
+                or tc.shape[0] != nb or dc.shape[0] != nb:
+            raise ValueError("expected vertices [B,V,3], intrinsics [B,3,3] and R / t / dist_coeffs with batch 1 or B")
+        outs = [torch.empty_like(v1) for _ in range(4)]
+        _lib.call("mr_flow_vertices_forward", _lib.ptr(v1), _lib.ptr(v2), _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(Rc),
+                  _lib.ptr(tc), _lib.ptr(dc), int(nb == B and B > 1), float(orig_size), *[_lib.ptr(o) for o in outs],
+                  B, V, _lib.stream_ptr(v1.device))
+        ctx.save_for_backward(v1, v2, k1, k2)
+        ctx.mark_non_differentiable(outs[0], outs[1])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, _g1, _g2, g12, g21):
+        v1, v2, k1, k2 = ctx.saved_tensors
+        B, V = v1.shape[:2]
+        want1, want2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gv1 = torch.empty_like(v1) if want1 else None
+        gv2 = torch.empty_like(v2) if want2 else None
+        if want1 or want2:
+            g12c = _lib.contig(g12) if g12 is not None else None
+            g21c = _lib.contig(g21) if g21 is not None else None
+            _lib.call("mr_flow_vertices_backward", _lib.ptr(v1), _lib.ptr(v2), _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(g12c),
+                      _lib.ptr(g21c), _lib.ptr(gv1), _lib.ptr(gv2), B, V, _lib.stream_ptr(v1.device))
+        return gv1, gv2, None, None, None, None, None, None
+
+
+def _vertex_color_path(neurenderer, detach_renders):
+    return (USE_VERTEX_COLOR_RENDER and detach_renders and hasattr(neurenderer, "render_vertex_colors")
+            and getattr(neurenderer, "no_light", False) and getattr(neurenderer, "camera_mode", "") == "projection")
 
 
 def _keep_lut(ignore_face_idxs, device):
@@ -173,6 +223,16 @@ def get_opticalflow(
     Returns:
         [pred_flow12, pred_flow21], each [batch_size, H, W, 2] in pixel units.
     """
+    if (USE_FUSED_VERTEX_STAGE and USE_FUSED_EPILOGUE and mask_occlusions and _vertex_color_path(neurenderer, detach_renders)
+            and hasattr(neurenderer, "render_projected_vertex_colors") and verts_cam[0].is_cuda
+            and verts_cam[0].dtype == torch.float32 and verts_cam[1].shape == verts_cam[0].shape):
+        dev = verts_cam[0].device
+        ndc1, ndc2, cols12, cols21 = _FlowVertexStage.apply(
+            verts_cam[0], verts_cam[1], camintrs[0].to(dev), camintrs[1].to(dev), neurenderer.R.to(dev),
+            neurenderer.t.to(dev), neurenderer.dist_coeffs.to(dev), neurenderer.orig_size)
+        ro1 = neurenderer.render_projected_vertex_colors(ndc1, faces, cols12.detach() if detach_textures else cols12)
+        ro2 = neurenderer.render_projected_vertex_colors(ndc2, faces, cols21)
+        return _fused_epilogue(ro1, ro2, orig_img_size, ignore_face_idxs)
     gt_locs2d_1 = project.batch_proj2d(verts_cam[0], camintrs[0])
     gt_locs2d_2 = project.batch_proj2d(verts_cam[1], camintrs[1])
     # forward optical flow

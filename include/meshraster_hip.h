@@ -182,6 +182,27 @@ MR_API int mr_render_vc_backward(const float* verts, const int32_t* faces_idx,
                                  int fill_back, int image_size, float eps, int flags,
                                  mr_stream_t stream);
 
+/* Per-vertex front end of get_opticalflow in its training setting (SURVEY 8f "f1"): for the two
+ * frames of a pair, in one launch
+ *   p_k    = batch_proj2d(verts_k, K_k)                      (opticalflow.py:98-99)
+ *   cols12 = (p_2 - p_1, 1),  cols21 = (p_1 - p_2, 1)         (opticalflow.py:101-102, 121-122)
+ *   ndc_k  = nr.projection(verts_k, K_k, R, t, dist_coeffs, orig_size)   (renderer.py:164-188)
+ * verts_k[B,V,3], K_k[B,3,3]; R[Bc,3,3], t[Bc,3], dist_coeffs[Bc,5] with Bc = B if cam_batched
+ * else 1.  The outputs feed mr_render_vc_forward (vertices = ndc_k, vcolors = cols). */
+MR_API int mr_flow_vertices_forward(const float* verts1, const float* verts2, const float* K1,
+                                    const float* K2, const float* R, const float* t,
+                                    const float* dist_coeffs, int cam_batched, float orig_size,
+                                    float* ndc1, float* ndc2, float* cols12, float* cols21,
+                                    int batch_size, int num_verts, mr_stream_t stream);
+/* Adjoint of (verts1, verts2) -> (cols12, cols21) (the projected vertices are constants for
+ * autograd: detach_renders=True).  Any of grad_cols12 / grad_cols21 / grad_verts1 / grad_verts2
+ * may be NULL. */
+MR_API int mr_flow_vertices_backward(const float* verts1, const float* verts2, const float* K1,
+                                     const float* K2, const float* grad_cols12,
+                                     const float* grad_cols21, float* grad_verts1,
+                                     float* grad_verts2, int batch_size, int num_verts,
+                                     mr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * 3. Warping (meshreg/warping/imgflowarp.py)
  * ---------------------------------------------------------------------------------- */

@@ -138,8 +138,10 @@ def test_pair_consist_large_matches_oracle(cuda):
         close(f21.grad.cpu().numpy(), ref_g[1], 1e-4, 1e-9, "grad_flow21")
 
 
-@pytest.mark.parametrize("vertex_color_render,fused_epilogue", [(True, True), (False, True), (True, False), (False, False)])
-def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, fused_epilogue, monkeypatch):
+@pytest.mark.parametrize("vertex_color_render,fused_epilogue,fused_vertex_stage",
+                         [(True, True, False), (True, True, True), (False, True, False), (True, False, False),
+                          (False, False, False)])
+def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, fused_epilogue, fused_vertex_stage, monkeypatch):
     """get_opticalflow (two renders + masks + occlusion + crop) and the pair loss on top of it,
     HIP path vs oracle chain, on the synthetic hand+object scene (non-square crop)."""
     from handobjectconsist_amd.neurender.renderer import Renderer
@@ -148,6 +150,10 @@ def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, fused_epilo
 
     monkeypatch.setattr(opticalflow, "USE_VERTEX_COLOR_RENDER", vertex_color_render)
     monkeypatch.setattr(opticalflow, "USE_FUSED_EPILOGUE", fused_epilogue)
+    monkeypatch.setattr(opticalflow, "USE_FUSED_VERTEX_STAGE", fused_vertex_stage)
+    calls = []
+    real_call = opticalflow._lib.call
+    monkeypatch.setattr(opticalflow._lib, "call", lambda name, *a: (calls.append(name), real_call(name, *a))[1])
     B, is_, H, Wd = 2, 128, 96, 128
     s = synth.random_scene(B, seed=21, image_size=is_)
     kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
@@ -176,7 +182,9 @@ def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, fused_epilo
     close(loss.detach().cpu().numpy(), ref_loss, 1e-4, 1e-7, "pair loss on rendered flows")
     loss.sum().backward()
     assert v1.grad is not None and torch.isfinite(v1.grad).all() and v1.grad.abs().sum() > 0
-    # all four (render path x epilogue) combinations give the same vertex gradient
+    assert ("mr_flow_vertices_forward" in calls) == fused_vertex_stage
+    assert ("mr_flow_vertices_backward" in calls) == fused_vertex_stage
+    # all (render path x epilogue x vertex stage) combinations give the same vertex gradient
     ref_key = "_vgrad_ref"
     if not hasattr(test_opticalflow_chain_matches_oracle, ref_key):
         setattr(test_opticalflow_chain_matches_oracle, ref_key, v1.grad.clone())
@@ -232,3 +240,46 @@ def test_encode_frames_matches_per_frame_features(cuda):
     model.train()
     with pytest.raises(RuntimeError):
         model.encode_frames(samples)
+
+
+@pytest.mark.parametrize("cam_batched", [False, True])
+def test_flow_vertex_stage_matches_torch_ops(cuda, cam_batched):
+    """mr_flow_vertices_forward / _backward == batch_proj2d + displacement textures + nr.projection and
+    their autograd, with a rotated / translated / distorting camera."""
+    from handobjectconsist_amd.neurender import nr_ops
+    from handobjectconsist_amd.utils import project
+    from handobjectconsist_amd.warping.opticalflow import _FlowVertexStage
+
+    B, is_ = 3, 128
+    s = synth.random_scene(B, seed=4, image_size=is_)
+    g = torch.Generator().manual_seed(1)
+    nb = B if cam_batched else 1
+    ang = 0.05 * torch.randn(nb, generator=g)
+    Rm = torch.eye(3).repeat(nb, 1, 1)
+    Rm[:, 0, 0], Rm[:, 0, 1], Rm[:, 1, 0], Rm[:, 1, 1] = ang.cos(), -ang.sin(), ang.sin(), ang.cos()
+    tv = 0.01 * torch.randn(nb, 1, 3, generator=g)
+    dist = 0.05 * torch.randn(nb, 5, generator=g)
+    Rm, tv, dist = Rm.to(cuda), tv.to(cuda), dist.to(cuda)
+    v1 = t(s["verts1"], cuda).requires_grad_(True)
+    v2 = t(s["verts2"], cuda).requires_grad_(True)
+    K1, K2 = t(s["K1"], cuda), t(s["K2"], cuda)
+    ndc1, ndc2, c12, c21 = _FlowVertexStage.apply(v1, v2, K1, K2, Rm, tv, dist, is_)
+    a1, a2 = v1.detach().clone().requires_grad_(True), v2.detach().clone().requires_grad_(True)
+    p1, p2 = project.batch_proj2d(a1, K1), project.batch_proj2d(a2, K2)
+    r12 = torch.cat([p2 - p1, torch.ones_like(p1[..., :1])], -1)
+    r21 = torch.cat([p1 - p2, torch.ones_like(p1[..., :1])], -1)
+    rn1 = nr_ops.projection(a1, K1, Rm, tv, dist, is_)
+    rn2 = nr_ops.projection(a2, K2, Rm, tv, dist, is_)
+    assert not ndc1.requires_grad and not ndc2.requires_grad and c12.requires_grad
+    for got, ref, what in ((ndc1, rn1, "ndc1"), (ndc2, rn2, "ndc2"), (c12, r12, "cols12"), (c21, r21, "cols21")):
+        close(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), 1e-5, 1e-5, what)
+    w12, w21 = torch.randn(c12.shape, generator=g).to(cuda), torch.randn(c21.shape, generator=g).to(cuda)
+    ((c12 * w12).sum() + (c21 * w21).sum()).backward()
+    ((r12 * w12).sum() + (r21 * w21).sum()).backward()
+    for got, ref, what in ((v1.grad, a1.grad, "grad verts1"), (v2.grad, a2.grad, "grad verts2")):
+        close(got.cpu().numpy(), ref.cpu().numpy(), 1e-4, 1e-5 * float(ref.abs().max()), what)
+    # frame 2 detached (warpbranch first_only): no gradient buffer for it
+    v1.grad = None
+    _, _, c12b, c21b = _FlowVertexStage.apply(v1, v2.detach(), K1, K2, Rm, tv, dist, is_)
+    (c12b * w12).sum().backward()
+    assert v1.grad is not None and torch.isfinite(v1.grad).all()
