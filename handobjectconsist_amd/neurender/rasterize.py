@@ -54,6 +54,7 @@ class RasterizeFunction(Function):
     @staticmethod
     def forward(ctx, faces, textures, image_size, near, far, eps, background_color, return_rgb=False,
                 return_alpha=False, return_depth=False):
+        ctx.set_materialize_grads(False)  # unused outputs' gradients arrive as None, not as zero maps
         _lib.check_cuda(faces, textures if return_rgb else None)
         faces = _lib.contig(faces).clone()
         dev = faces.device
@@ -196,6 +197,7 @@ class RasterizeFusedFunction(Function):
     @staticmethod
     def forward(ctx, faces, textures, image_size, near, far, eps, background_color, return_rgb, return_alpha,
                 return_depth):
+        ctx.set_materialize_grads(False)  # unused outputs' gradients arrive as None, not as zero maps
         _lib.check_cuda(faces, textures if return_rgb else None)
         if faces.dim() != 4 or faces.shape[2:] != (3, 3):
             raise ValueError("faces must be [batch size, number of faces, 3, 3]")
@@ -280,6 +282,7 @@ class RasterizeVertexColorFunction(Function):
     @staticmethod
     def forward(ctx, verts_ndc, faces_idx, vcolors, fill_back, image_size, near, far, eps, background_color,
                 return_rgb, return_alpha, return_depth):
+        ctx.set_materialize_grads(False)  # unused outputs' gradients arrive as None, not as zero maps
         _lib.check_cuda(verts_ndc, faces_idx, vcolors)
         if not (float(eps) >= 1e-6):
             raise ValueError("vertex-colour rendering needs eps >= 1e-6")

@@ -51,6 +51,7 @@ def get_spatial_meshgrid(x: torch.Tensor, scale=False):
 class _WarpFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, flow, thresh, mode):
+        ctx.set_materialize_grads(False)
         _lib.check_cuda(x, flow)
         x_c, flow_c = _lib.contig(x), _lib.contig(flow)
         B, C, H, W = x_c.shape

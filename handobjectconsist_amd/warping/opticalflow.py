@@ -81,6 +81,7 @@ class _FlowVertexStage(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, verts1, verts2, K1, K2, R, t, dist, orig_size):
+        ctx.set_materialize_grads(False)
         v1, v2 = _lib.contig(verts1.detach()), _lib.contig(verts2.detach())
         k1, k2 = _lib.contig(K1.detach()), _lib.contig(K2.detach())
         B, V = v1.shape[:2]
