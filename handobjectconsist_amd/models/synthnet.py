@@ -140,6 +140,14 @@ class SynthManoLayer(nn.Module):
         buf("th_comps", comps)
         buf("th_hands_mean", np.zeros((1, 45)) if flat_hand_mean else rng.standard_normal((1, 45)) * 0.1)
         self.register_buffer("th_faces", torch.tensor(f[:1538], dtype=torch.long))
+        # constants of forward() as buffers: nothing is built from host data per call (hipGraph-capturable)
+        self.register_buffer("_parents", torch.tensor(MANO_PARENTS[1:], dtype=torch.long), persistent=False)
+        self.register_buffer("_eye3", torch.eye(3), persistent=False)
+        self.register_buffer("_row0001", torch.tensor([0.0, 0.0, 0.0, 1.0]), persistent=False)
+        self.register_buffer("_tips", torch.tensor(MANO_TIPS, dtype=torch.long), persistent=False)
+        self.register_buffer("_reorder", torch.tensor(MANO_REORDER, dtype=torch.long), persistent=False)
+        for name, idx in (("_lvl1", [0, 3, 6, 9, 12]), ("_lvl2", [1, 4, 7, 10, 13]), ("_lvl3", [2, 5, 8, 11, 14])):
+            self.register_buffer(name, torch.tensor(idx, dtype=torch.long), persistent=False)  # indices into rel (joint - 1)
 
     def forward(self, th_pose_coeffs, th_betas=None, th_trans=None):
         """Same contractions as manopth, arranged as a few dense GEMMs (rocBLAS /
@@ -148,12 +156,11 @@ class SynthManoLayer(nn.Module):
         products instead of 15 sequential ones), skinning as one [778,16] x [16,B*16] product
         and the final per-vertex 4x4 transform as a broadcast multiply-sum."""
         B = th_pose_coeffs.shape[0]
-        dev = th_pose_coeffs.device
         hand = th_pose_coeffs[:, 3:3 + self.ncomps] if self.use_pca else th_pose_coeffs[:, 3:]
         full_hand = hand.mm(self.th_comps[: self.ncomps]) if self.use_pca else hand
         full_pose = torch.cat([th_pose_coeffs[:, :3], self.th_hands_mean + full_hand], 1)
         rots = batch_rodrigues(full_pose.reshape(-1, 3)).view(B, 16, 3, 3)
-        pose_map = (rots[:, 1:] - torch.eye(3, device=dev)).reshape(B, 135)
+        pose_map = (rots[:, 1:] - self._eye3).reshape(B, 135)
         if th_betas is None:
             th_betas = th_pose_coeffs.new_zeros((B, 10))
         blend = torch.cat([self.th_shapedirs.reshape(2334, 10), self.th_posedirs.reshape(2334, 135)], 1)  # [2334,145]
@@ -164,24 +171,22 @@ class SynthManoLayer(nn.Module):
 
         def with_zeros(rot, tr):  # [..,3,3], [..,3] -> [..,4,4]
             top = torch.cat([rot, tr.unsqueeze(-1)], -1)
-            bottom = top.new_tensor([0.0, 0.0, 0.0, 1.0]).expand(*top.shape[:-2], 1, 4)
+            bottom = self._row0001.expand(*top.shape[:-2], 1, 4)
             return torch.cat([top, bottom], -2)
 
-        parents = torch.tensor(MANO_PARENTS[1:], device=dev)
-        rel = with_zeros(rots[:, 1:], joints[:, 1:] - joints[:, parents])          # [B,15,4,4]
+        parents = self._parents
+        rel = with_zeros(rots[:, 1:], joints[:, 1:] - joints.index_select(1, parents))          # [B,15,4,4]
         root = with_zeros(rots[:, 0], joints[:, 0])                                # [B,4,4]
-        lvl1, lvl2, lvl3 = [0, 3, 6, 9, 12], [1, 4, 7, 10, 13], [2, 5, 8, 11, 14]  # indices into rel (joint - 1)
-        g1 = torch.matmul(root.unsqueeze(1), rel[:, lvl1])
-        g2 = torch.matmul(g1, rel[:, lvl2])
-        g3 = torch.matmul(g2, rel[:, lvl3])
-        G = torch.empty((B, 16, 4, 4), device=dev, dtype=root.dtype)
+        g1 = torch.matmul(root.unsqueeze(1), rel.index_select(1, self._lvl1))
+        g2 = torch.matmul(g1, rel.index_select(1, self._lvl2))
+        g3 = torch.matmul(g2, rel.index_select(1, self._lvl3))
         G = torch.cat([root.unsqueeze(1), torch.stack([g1, g2, g3], 2).reshape(B, 15, 4, 4)], 1)  # joints 1..15 in order
         j_h = torch.cat([joints, joints.new_zeros((B, 16, 1))], 2).unsqueeze(-1)
         G2 = G - F.pad(torch.matmul(G, j_h), (3, 0))
         T = (self.th_weights @ G2.permute(1, 0, 2, 3).reshape(16, B * 16)).view(778, B, 4, 4).permute(1, 0, 2, 3)
         v_h = torch.cat([v_posed, v_posed.new_ones((B, 778, 1))], 2)
         verts = (T[:, :, :3, :] * v_h.unsqueeze(2)).sum(-1)
-        jtr = torch.cat([G[:, :, :3, 3], verts[:, MANO_TIPS]], 1)[:, MANO_REORDER]
+        jtr = torch.cat([G[:, :, :3, 3], verts.index_select(1, self._tips)], 1).index_select(1, self._reorder)
         if th_trans is None:
             if self.center_idx is not None:
                 center = jtr[:, self.center_idx].unsqueeze(1)
@@ -201,10 +206,24 @@ def recover_3d_proj(objpoints3d, camintr, est_scale, est_trans, off_z=0.4, input
     est_trans = est_trans.view(batch_size, 2)
     est_Z0 = focal * est_scale + off_z
     cam_centers = camintr[:, :2, 2]
-    img_centers = (cam_centers.new_tensor(input_res) / 2).view(1, 2).repeat(batch_size, 1)
+    # (input_res / 2 as two scalar fills: no host array -> device copy per call)
+    img_centers = torch.stack([cam_centers.new_full((batch_size,), input_res[0] / 2),
+                               cam_centers.new_full((batch_size,), input_res[1] / 2)], 1)
     est_XY0 = (est_trans + img_centers - cam_centers) * est_Z0 / focal
     est_c3d = torch.cat([est_XY0, est_Z0], -1).unsqueeze(1)
     return est_c3d + objpoints3d, est_c3d
+
+
+class _PostHeads(nn.Module):
+    """``net.post_heads`` with a fixed input resolution, as a parameter-free module for graph capture."""
+
+    def __init__(self, net, input_res):
+        super().__init__()
+        object.__setattr__(self, "_net", net)  # not registered: no parameters / buffers of its own
+        self.input_res = tuple(input_res)
+
+    def forward(self, *args):
+        return self._net.post_heads(*args, input_res=self.input_res)
 
 
 class SynthMeshRegNet(nn.Module):
@@ -240,6 +259,73 @@ class SynthMeshRegNet(nn.Module):
         for s, f in zip(samples, feats.split(sizes)):
             s["_features"] = f
 
+    def post_heads(self, pose, shape, scaletrans, st_obj, camintr, objcanverts, joints3d_gt=None, objverts3d_gt=None,
+                   input_res=(256, 256)):
+        """Head outputs -> meshes, projections and loss terms.  No trainable parameter is read here (MANO
+        and the camera recovery are fixed functions), which is what lets ``enable_post_graphs`` replay
+        it as one hipGraph per frame: ~100 small launches in forward and ~150 in backward otherwise sit
+        between the loss and the encoder's backward."""
+        _lam_j, _lam_o, lam_pose, lam_shape = self.lam
+        # hand: MANO branch (manobranch.py:88-155) + camera recovery (meshregnet.py:206-245)
+        verts, joints = self.mano_layer(pose, th_betas=shape)
+        verts3d, joints3d = verts / 1000, joints / 1000
+        reg_loss = lam_shape * F.mse_loss(shape, torch.zeros_like(shape)) \
+            + lam_pose * F.mse_loss(pose[:, 3:], torch.zeros_like(pose[:, 3:]))
+        trans, scale = scaletrans[:, 1:], scaletrans[:, :1]
+        final_trans = trans.unsqueeze(1) * self.obj_trans_factor
+        final_scale = scale.view(-1, 1, 1) * self.obj_scale_factor
+        recov_joints3d, center3d = recover_3d_proj(joints3d, camintr, final_scale, final_trans, input_res=input_res)
+        recov_handverts3d = verts3d + center3d
+        joints2d = camproject.batch_proj2d(recov_joints3d, camintr)
+        # object: rotation + weak-perspective recovery (objbranch.py:28-84, meshregnet.py:274-323)
+        rotmat = batch_rodrigues(st_obj[:, 3:])
+        rotobjverts = rotmat.bmm(objcanverts.transpose(1, 2)).transpose(1, 2)
+        o_trans = st_obj[:, 1:3].unsqueeze(1) * self.obj_trans_factor
+        o_scale = st_obj[:, :1].view(-1, 1, 1) * self.obj_scale_factor
+        objverts3d, _ = recover_3d_proj(rotobjverts, camintr, o_scale, o_trans, input_res=input_res)
+        obj_verts2d = camproject.batch_proj2d(objverts3d, camintr)
+        out = (recov_handverts3d, recov_joints3d, joints2d, objverts3d, obj_verts2d, reg_loss)
+        if joints3d_gt is not None:
+            out = out + (F.mse_loss(recov_joints3d, joints3d_gt), F.mse_loss(objverts3d, objverts3d_gt))
+        return out
+
+    # -- optional hipGraph replay of post_heads ------------------------------------------------
+    def enable_post_graphs(self, frames):
+        """Capture ``post_heads`` (forward and backward) once per frame slot of a step with
+        ``torch.cuda.make_graphed_callables``.  `frames`: the sample dicts of one optimiser step in the
+        order ``forward`` will see them (data frame, consist frame 0, consist frame 1, ...); the same
+        order must be kept in every step, and every slot is used exactly once per backward (the
+        outputs of a slot live in the graph's static memory until its next replay).  Nothing with
+        parameters is captured, so this is independent of DistributedDataParallel and the optimiser."""
+        calls, args_all, keys = [], [], []
+        with torch.no_grad():
+            for s in frames:
+                feats = self.base_net(s["image"][:1]).expand(s["image"].shape[0], -1)
+                base = self.mano_base(feats)
+                heads = [self.pose_reg(base), self.shape_reg(base), self.scaletrans_branch(feats),
+                         self.scaletrans_branch_obj(feats)]
+                supervised = "joints3d" in s and "objverts3d" in s
+                args = tuple(h.detach().clone().requires_grad_(True) for h in heads) + (s["camintr"], s["objcanverts"])
+                if supervised:
+                    args = args + (s["joints3d"], s["objverts3d"])
+                W, H = s["image"].shape[3], s["image"].shape[2]
+                calls.append(_PostHeads(self, (W, H)))
+                args_all.append(args)
+                keys.append((supervised, tuple(tuple(a.shape) for a in args), (W, H)))
+        graphed = torch.cuda.make_graphed_callables(tuple(calls), tuple(args_all))
+        self._post_graphs = list(zip(keys, graphed if isinstance(graphed, tuple) else (graphed,)))
+        self._post_cursor = 0
+
+    def _graphed_post(self, supervised, args, input_res):
+        graphs = getattr(self, "_post_graphs", None)
+        if not graphs or not torch.is_grad_enabled():
+            return None
+        key, fn = graphs[self._post_cursor % len(graphs)]
+        if key != (supervised, tuple(tuple(a.shape) for a in args), tuple(input_res)):
+            raise RuntimeError("enable_post_graphs: frames arrive in a different order / shape than captured")
+        self._post_cursor += 1
+        return fn
+
     def forward(self, sample, no_loss=False, encode_only=False):
         if encode_only:  # (through forward so that a DistributedDataParallel wrapper sees the call)
             self.encode_frames(sample)
@@ -249,43 +335,28 @@ class SynthMeshRegNet(nn.Module):
         if features is None:
             features = self.base_net(image)
         H, W = image.shape[2:]
-        camintr = sample["camintr"]
-        lam_j, lam_o, lam_pose, lam_shape = self.lam
-        losses, results = {}, {}
-        total_loss = image.new_zeros((1,))
+        supervised = not no_loss and "joints3d" in sample and "objverts3d" in sample
+        if not no_loss and not supervised and ("joints3d" in sample or "objverts3d" in sample):
+            raise ValueError("a supervised frame carries both joints3d and objverts3d")
 
-        # hand: MANO branch (manobranch.py:88-155) + camera recovery (meshregnet.py:206-245)
+        # the four regression heads (the only trainable part after the trunk) ...
         base = self.mano_base(features)
         pose, shape = self.pose_reg(base), self.shape_reg(base)
-        verts, joints = self.mano_layer(pose, th_betas=shape)
-        verts3d, joints3d = verts / 1000, joints / 1000
-        reg_loss = lam_shape * F.mse_loss(shape, torch.zeros_like(shape)) \
-            + lam_pose * F.mse_loss(pose[:, 3:], torch.zeros_like(pose[:, 3:]))
-        losses["mano_reg_loss"] = reg_loss.view(1)
-        total_loss = total_loss + reg_loss
         scaletrans = self.scaletrans_branch(features)
-        trans, scale = scaletrans[:, 1:], scaletrans[:, :1]
-        final_trans = trans.unsqueeze(1) * self.obj_trans_factor
-        final_scale = scale.view(-1, 1, 1) * self.obj_scale_factor
-        recov_joints3d, center3d = recover_3d_proj(joints3d, camintr, final_scale, final_trans, input_res=(W, H))
-        results["recov_handverts3d"] = verts3d + center3d
-        results["recov_joints3d"] = recov_joints3d
-        results["joints2d"] = camproject.batch_proj2d(recov_joints3d, camintr)
-        if not no_loss and "joints3d" in sample:
-            losses["recov_joint3d"] = F.mse_loss(recov_joints3d, sample["joints3d"])
-            total_loss = total_loss + lam_j * losses["recov_joint3d"]
-
-        # object: rotation + weak-perspective recovery (objbranch.py:28-84, meshregnet.py:274-323)
         st_obj = self.scaletrans_branch_obj(features)
-        rotmat = batch_rodrigues(st_obj[:, 3:])
-        rotobjverts = rotmat.bmm(sample["objcanverts"].transpose(1, 2)).transpose(1, 2)
-        o_trans = st_obj[:, 1:3].unsqueeze(1) * self.obj_trans_factor
-        o_scale = st_obj[:, :1].view(-1, 1, 1) * self.obj_scale_factor
-        objverts3d, _ = recover_3d_proj(rotobjverts, camintr, o_scale, o_trans, input_res=(W, H))
-        results["recov_objverts3d"] = objverts3d
-        results["obj_verts2d"] = camproject.batch_proj2d(objverts3d, camintr)
-        if not no_loss and "objverts3d" in sample:
-            losses["recov_objverts3d"] = F.mse_loss(objverts3d, sample["objverts3d"])
-            total_loss = total_loss + lam_o * losses["recov_objverts3d"]
+        # ... and everything after them: parameter-free tensor code (optionally one hipGraph replay)
+        args = (pose, shape, scaletrans, st_obj, sample["camintr"], sample["objcanverts"])
+        if supervised:
+            args = args + (sample["joints3d"], sample["objverts3d"])
+        post = self._graphed_post(supervised, args, (W, H))
+        out = post(*args) if post is not None else self.post_heads(*args, input_res=(W, H))
+        results = dict(zip(("recov_handverts3d", "recov_joints3d", "joints2d", "recov_objverts3d", "obj_verts2d"), out[:5]))
+        losses = {"mano_reg_loss": out[5].view(1)}
+        total_loss = image.new_zeros((1,)) + out[5]
+        if supervised:
+            lam_j, lam_o = self.lam[0], self.lam[1]
+            losses["recov_joint3d"], losses["recov_objverts3d"] = out[6], out[7]
+            total_loss = total_loss + lam_j * out[6]
+            total_loss = total_loss + lam_o * out[7]
         losses["total_loss"] = total_loss
         return total_loss, results, losses
