@@ -214,18 +214,6 @@ def recover_3d_proj(objpoints3d, camintr, est_scale, est_trans, off_z=0.4, input
     return est_c3d + objpoints3d, est_c3d
 
 
-class _PostHeads(nn.Module):
-    """``net.post_heads`` with a fixed input resolution, as a parameter-free module for graph capture."""
-
-    def __init__(self, net, input_res):
-        super().__init__()
-        object.__setattr__(self, "_net", net)  # not registered: no parameters / buffers of its own
-        self.input_res = tuple(input_res)
-
-    def forward(self, *args):
-        return self._net.post_heads(*args, input_res=self.input_res)
-
-
 class SynthMeshRegNet(nn.Module):
     """MeshRegNet (meshregnet.py:54-384) with the trainmeshwarp.py default loss weights.
 
@@ -262,9 +250,10 @@ class SynthMeshRegNet(nn.Module):
     def post_heads(self, pose, shape, scaletrans, st_obj, camintr, objcanverts, joints3d_gt=None, objverts3d_gt=None,
                    input_res=(256, 256)):
         """Head outputs -> meshes, projections and loss terms.  No trainable parameter is read here (MANO
-        and the camera recovery are fixed functions), which is what lets ``enable_post_graphs`` replay
-        it as one hipGraph per frame: ~100 small launches in forward and ~150 in backward otherwise sit
-        between the loss and the encoder's backward."""
+        and the camera recovery are fixed functions) and nothing is built from host data per call: a
+        host -> device copy of a constant is a hidden synchronisation (removing them was worth 10 % of
+        the step).  Replaying this function as a hipGraph per frame (torch.cuda.make_graphed_callables)
+        was tried and measured SLOWER than the eager launches (52.2 vs 47.3 ms per step)."""
         _lam_j, _lam_o, lam_pose, lam_shape = self.lam
         # hand: MANO branch (manobranch.py:88-155) + camera recovery (meshregnet.py:206-245)
         verts, joints = self.mano_layer(pose, th_betas=shape)
@@ -289,43 +278,6 @@ class SynthMeshRegNet(nn.Module):
             out = out + (F.mse_loss(recov_joints3d, joints3d_gt), F.mse_loss(objverts3d, objverts3d_gt))
         return out
 
-    # -- optional hipGraph replay of post_heads ------------------------------------------------
-    def enable_post_graphs(self, frames):
-        """Capture ``post_heads`` (forward and backward) once per frame slot of a step with
-        ``torch.cuda.make_graphed_callables``.  `frames`: the sample dicts of one optimiser step in the
-        order ``forward`` will see them (data frame, consist frame 0, consist frame 1, ...); the same
-        order must be kept in every step, and every slot is used exactly once per backward (the
-        outputs of a slot live in the graph's static memory until its next replay).  Nothing with
-        parameters is captured, so this is independent of DistributedDataParallel and the optimiser."""
-        calls, args_all, keys = [], [], []
-        with torch.no_grad():
-            for s in frames:
-                feats = self.base_net(s["image"][:1]).expand(s["image"].shape[0], -1)
-                base = self.mano_base(feats)
-                heads = [self.pose_reg(base), self.shape_reg(base), self.scaletrans_branch(feats),
-                         self.scaletrans_branch_obj(feats)]
-                supervised = "joints3d" in s and "objverts3d" in s
-                args = tuple(h.detach().clone().requires_grad_(True) for h in heads) + (s["camintr"], s["objcanverts"])
-                if supervised:
-                    args = args + (s["joints3d"], s["objverts3d"])
-                W, H = s["image"].shape[3], s["image"].shape[2]
-                calls.append(_PostHeads(self, (W, H)))
-                args_all.append(args)
-                keys.append((supervised, tuple(tuple(a.shape) for a in args), (W, H)))
-        graphed = torch.cuda.make_graphed_callables(tuple(calls), tuple(args_all))
-        self._post_graphs = list(zip(keys, graphed if isinstance(graphed, tuple) else (graphed,)))
-        self._post_cursor = 0
-
-    def _graphed_post(self, supervised, args, input_res):
-        graphs = getattr(self, "_post_graphs", None)
-        if not graphs or not torch.is_grad_enabled():
-            return None
-        key, fn = graphs[self._post_cursor % len(graphs)]
-        if key != (supervised, tuple(tuple(a.shape) for a in args), tuple(input_res)):
-            raise RuntimeError("enable_post_graphs: frames arrive in a different order / shape than captured")
-        self._post_cursor += 1
-        return fn
-
     def forward(self, sample, no_loss=False, encode_only=False):
         if encode_only:  # (through forward so that a DistributedDataParallel wrapper sees the call)
             self.encode_frames(sample)
@@ -344,12 +296,11 @@ class SynthMeshRegNet(nn.Module):
         pose, shape = self.pose_reg(base), self.shape_reg(base)
         scaletrans = self.scaletrans_branch(features)
         st_obj = self.scaletrans_branch_obj(features)
-        # ... and everything after them: parameter-free tensor code (optionally one hipGraph replay)
+        # ... and everything after them: parameter-free tensor code
         args = (pose, shape, scaletrans, st_obj, sample["camintr"], sample["objcanverts"])
         if supervised:
             args = args + (sample["joints3d"], sample["objverts3d"])
-        post = self._graphed_post(supervised, args, (W, H))
-        out = post(*args) if post is not None else self.post_heads(*args, input_res=(W, H))
+        out = self.post_heads(*args, input_res=(W, H))
         results = dict(zip(("recov_handverts3d", "recov_joints3d", "joints2d", "recov_objverts3d", "obj_verts2d"), out[:5]))
         losses = {"mano_reg_loss": out[5].view(1)}
         total_loss = image.new_zeros((1,)) + out[5]
