@@ -393,3 +393,45 @@ def test_vc_backward_edge_cases(cuda):
     a, b_ = _vc_backward(big, gb, "stored"), _vc_backward(big, gb, "gather")
     assert_close(a, b_, 1e-6, 1e-7 * np.abs(b_).max(), "large V")
     assert (a[:, -4000:] == 0).all()
+
+
+def test_vertex_colour_render_adjoint_at_metric_size(cuda):
+    """BASELINE metric config (B=64, 256x256, 7104 faces): no oracle run at this size, but the render
+    is LINEAR in the vertex colours for fixed geometry (background 0), so its backward must be the exact
+    transpose: <render(c), g> == <c, backward(g)>; plus linearity and coverage sanity."""
+    d = _vc_abi_case(cuda, 64, 256, 0)
+    from handobjectconsist_amd import _lib
+
+    B, V, F0, is_ = d["B"], d["V"], d["F0"], d["is_"]
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    f32 = dict(dtype=torch.float32, device=cuda)
+    wbytes = int(_lib.load().mr_render_workspace_bytes(B, 2 * F0, is_))
+    work = torch.empty((wbytes,), dtype=torch.uint8, device=cuda)
+    bg = torch.zeros(3, **f32)
+
+    def render(cols):
+        rgb = torch.empty((B, 3, is_, is_), **f32)
+        _lib.call("mr_render_vc_forward", P(d["v"]), P(d["fidx"]), P(cols), P(bg), 0, P(rgb), P(d["alpha"]), P(d["depth"]),
+                  P(d["fim"]), P(d["wmap"]), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+        return rgb
+
+    g = torch.Generator(device="cpu").manual_seed(0)
+    c1 = torch.randn((B, V, 3), generator=g).to(cuda)
+    c2 = torch.randn((B, V, 3), generator=g).to(cuda)
+    gr = torch.randn((B, 3, is_, is_), generator=g).to(cuda)
+    r1, r2, r12 = render(c1), render(c2), render(c1 + 2 * c2)
+    assert float((r12 - (r1 + 2 * r2)).abs().max()) <= 1e-4 * float(r12.abs().max())  # linearity
+    cov = (d["fim"] >= 0)
+    assert 0.05 < float(cov.float().mean()) < 0.5
+    assert float(r1[(~cov).unsqueeze(1).expand_as(r1).flip(2)].abs().max()) == 0.0  # background stays 0 (image is flipped)
+    back = torch.from_numpy(_vc_backward(d, gr, "stored")).to(cuda)
+    lhs = float((r1.double() * gr.double()).sum())
+    rhs = float((c1.double() * back.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), float(r1.abs().sum()) * 1e-3), (lhs, rhs)
+    # gradients only reach vertices of faces that own a pixel
+    owners = torch.zeros((B, V), dtype=torch.bool, device=cuda)
+    fim = d["fim"].long()
+    for b in range(0, B, 16):
+        fn = torch.unique(fim[b][fim[b] >= 0]) % F0
+        owners[b, d["fidx"][b, fn].long().flatten()] = True
+        assert (back[b][~owners[b]] == 0).all()

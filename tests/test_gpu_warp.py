@@ -283,3 +283,43 @@ def test_flow_vertex_stage_matches_torch_ops(cuda, cam_batched):
     _, _, c12b, c21b = _FlowVertexStage.apply(v1, v2.detach(), K1, K2, Rm, tv, dist, is_)
     (c12b * w12).sum().backward()
     assert v1.grad is not None and torch.isfinite(v1.grad).all()
+
+
+@pytest.mark.parametrize("B,is_,H,Wd", [(2, 480, 270, 480), (1, 640, 480, 640)])
+def test_opticalflow_chain_baseline_config_sizes(cuda, B, is_, H, Wd):
+    """BASELINE.json configs 3 (480x270 pairs) and 5 (640x480 renders): the default (fully fused) path --
+    vertex stage, two vertex-colour renders, epilogue, occlusion, pair loss and its backward -- against
+    the oracle chain at the full raster sizes (non-multiples of the 32 / 64-pixel tiles, non-square crop)."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import imgflowarp, opticalflow
+
+    s = synth.random_scene(B, seed=33, image_size=is_)
+    kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
+              dist_coeffs=np.zeros((1, 5), np.float32), orig_size=is_, image_size=is_, anti_aliasing=False,
+              near=0.1, far=100, eps=1e-3)
+    ref_flows = W.get_opticalflow(R, [s["verts1"], s["verts2"]], s["faces"], [s["K1"], s["K2"]], kw,
+                                  orig_img_size=(Wd, H), ignore_face_idxs=synth.HAND_IGNORE_FACES)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
+                   no_light=True, light_intensity_ambient=0.8)
+    v1 = t(s["verts1"], cuda).requires_grad_(True)
+    flows = opticalflow.get_opticalflow([v1, t(s["verts2"], cuda)], t(s["faces"], cuda),
+                                        [t(s["K1"], cuda), t(s["K2"], cuda)], ren, orig_img_size=(Wd, H),
+                                        detach_textures=False, detach_renders=True,
+                                        ignore_face_idxs=synth.HAND_IGNORE_FACES)
+    for i in (0, 1):
+        assert flows[i].shape == (B, H, Wd, 2)
+        got, ref = flows[i].detach().cpu().numpy(), ref_flows[i]
+        # a vertex projected with a last-bit difference may move one pixel across a face edge at these sizes
+        assert ((got != 0) != (ref != 0)).sum() <= 4, "flow support differs"
+        same = (got != 0) == (ref != 0)
+        close(np.where(same, got, 0), np.where(same, ref, 0), 1e-4, 1e-4, f"flow{i}")
+        assert (ref[..., 0] != 0).sum() > 1000
+    im_ref, im, jm_ref, jm = synth.random_images(B, H, Wd, 3)
+    ref_loss = W.pair_consist(ref_flows, im_ref, im, jm_ref, jm, True)[0]
+    loss = imgflowarp.pair_consist(flows, t(im_ref, cuda), t(im, cuda), t(jm_ref, cuda), t(jm, cuda),
+                                   PyramidCriterion("l1"), use_backward=True, outputs="loss")[0]
+    close(loss.detach().cpu().numpy(), ref_loss, 2e-3, 1e-6, "pair loss on rendered flows")
+    loss.sum().backward()
+    assert torch.isfinite(v1.grad).all() and v1.grad.abs().sum() > 0
