@@ -247,19 +247,22 @@ class SynthMeshRegNet(nn.Module):
         for s, f in zip(samples, feats.split(sizes)):
             s["_features"] = f
 
-    def post_heads(self, pose, shape, scaletrans, st_obj, camintr, objcanverts, joints3d_gt=None, objverts3d_gt=None,
-                   input_res=(256, 256)):
-        """Head outputs -> meshes, projections and loss terms.  No trainable parameter is read here (MANO
-        and the camera recovery are fixed functions) and nothing is built from host data per call: a
-        host -> device copy of a constant is a hidden synchronisation (removing them was worth 10 % of
-        the step).  Replaying this function as a hipGraph per frame (torch.cuda.make_graphed_callables)
-        was tried and measured SLOWER than the eager launches (52.2 vs 47.3 ms per step)."""
-        _lam_j, _lam_o, lam_pose, lam_shape = self.lam
+    def heads(self, features):
+        """The four regression heads: the only trainable part after the trunk."""
+        base = self.mano_base(features)
+        return self.pose_reg(base), self.shape_reg(base), self.scaletrans_branch(features), self.scaletrans_branch_obj(features)
+
+    def post_heads(self, pose, shape, scaletrans, st_obj, camintr, objcanverts, input_res=(256, 256)):
+        """Head outputs -> hand / object meshes in the camera frame and their projections.  No trainable
+        parameter is read here (MANO and the camera recovery are fixed functions), every operation acts
+        per sample, and nothing is built from host data per call: a host -> device copy of a constant is
+        a hidden synchronisation (removing them was worth 10 % of the step).  Replaying this function as a
+        hipGraph per frame (torch.cuda.make_graphed_callables) was tried and measured SLOWER than the
+        eager launches (52.2 vs 47.3 ms per step); what does pay is running it ONCE over all frames of
+        a step (``prepare_frames``)."""
         # hand: MANO branch (manobranch.py:88-155) + camera recovery (meshregnet.py:206-245)
         verts, joints = self.mano_layer(pose, th_betas=shape)
         verts3d, joints3d = verts / 1000, joints / 1000
-        reg_loss = lam_shape * F.mse_loss(shape, torch.zeros_like(shape)) \
-            + lam_pose * F.mse_loss(pose[:, 3:], torch.zeros_like(pose[:, 3:]))
         trans, scale = scaletrans[:, 1:], scaletrans[:, :1]
         final_trans = trans.unsqueeze(1) * self.obj_trans_factor
         final_scale = scale.view(-1, 1, 1) * self.obj_scale_factor
@@ -273,41 +276,56 @@ class SynthMeshRegNet(nn.Module):
         o_scale = st_obj[:, :1].view(-1, 1, 1) * self.obj_scale_factor
         objverts3d, _ = recover_3d_proj(rotobjverts, camintr, o_scale, o_trans, input_res=input_res)
         obj_verts2d = camproject.batch_proj2d(objverts3d, camintr)
-        out = (recov_handverts3d, recov_joints3d, joints2d, objverts3d, obj_verts2d, reg_loss)
-        if joints3d_gt is not None:
-            out = out + (F.mse_loss(recov_joints3d, joints3d_gt), F.mse_loss(objverts3d, objverts3d_gt))
-        return out
+        return recov_handverts3d, recov_joints3d, joints2d, objverts3d, obj_verts2d
 
-    def forward(self, sample, no_loss=False, encode_only=False):
+    def prepare_frames(self, samples, batch_encoder=False):
+        """Everything of ``forward`` that does not depend on the supervision, for ALL frames of an
+        optimiser step at once: the encoder (one pass per frame as in the reference, or one pass over
+        the concatenation), then ONE pass of the heads and of ``post_heads`` over the concatenated
+        features -- a third of their ~250 launches per frame (forward + backward).  Per-sample
+        operations only, so each frame's slice equals what its own ``forward`` would compute.  The
+        slices are left in ``sample["_post"]``; the loss terms stay per frame in ``forward``."""
+        if batch_encoder:
+            self.encode_frames(samples)
+        feats = [s["_features"] if "_features" in s else self.base_net(s["image"]) for s in samples]
+        sizes = [f.shape[0] for f in feats]
+        H, W = samples[0]["image"].shape[2:]
+        pose, shape, scaletrans, st_obj = self.heads(torch.cat(feats))
+        geo = self.post_heads(pose, shape, scaletrans, st_obj, torch.cat([s["camintr"] for s in samples]),
+                              torch.cat([s["objcanverts"] for s in samples]), input_res=(W, H))
+        per_frame = zip(*[t.split(sizes) for t in geo + (pose, shape)])
+        for s, chunk in zip(samples, per_frame):
+            s.pop("_features", None)
+            s["_post"] = chunk
+
+    def forward(self, sample, no_loss=False, encode_only=False, batch_encoder=False):
         if encode_only:  # (through forward so that a DistributedDataParallel wrapper sees the call)
-            self.encode_frames(sample)
+            self.prepare_frames(sample, batch_encoder=batch_encoder)
             return None
         image = sample["image"]
-        features = sample.get("_features")
-        if features is None:
-            features = self.base_net(image)
         H, W = image.shape[2:]
         supervised = not no_loss and "joints3d" in sample and "objverts3d" in sample
         if not no_loss and not supervised and ("joints3d" in sample or "objverts3d" in sample):
             raise ValueError("a supervised frame carries both joints3d and objverts3d")
-
-        # the four regression heads (the only trainable part after the trunk) ...
-        base = self.mano_base(features)
-        pose, shape = self.pose_reg(base), self.shape_reg(base)
-        scaletrans = self.scaletrans_branch(features)
-        st_obj = self.scaletrans_branch_obj(features)
-        # ... and everything after them: parameter-free tensor code
-        args = (pose, shape, scaletrans, st_obj, sample["camintr"], sample["objcanverts"])
+        post = sample.get("_post")
+        if post is None:
+            features = sample.get("_features")
+            if features is None:
+                features = self.base_net(image)
+            pose, shape, scaletrans, st_obj = self.heads(features)
+            post = self.post_heads(pose, shape, scaletrans, st_obj, sample["camintr"], sample["objcanverts"],
+                                   input_res=(W, H)) + (pose, shape)
+        results = dict(zip(("recov_handverts3d", "recov_joints3d", "joints2d", "recov_objverts3d", "obj_verts2d"), post[:5]))
+        pose, shape = post[5], post[6]
+        lam_j, lam_o, lam_pose, lam_shape = self.lam
+        reg_loss = lam_shape * F.mse_loss(shape, torch.zeros_like(shape)) \
+            + lam_pose * F.mse_loss(pose[:, 3:], torch.zeros_like(pose[:, 3:]))
+        losses = {"mano_reg_loss": reg_loss.view(1)}
+        total_loss = image.new_zeros((1,)) + reg_loss
         if supervised:
-            args = args + (sample["joints3d"], sample["objverts3d"])
-        out = self.post_heads(*args, input_res=(W, H))
-        results = dict(zip(("recov_handverts3d", "recov_joints3d", "joints2d", "recov_objverts3d", "obj_verts2d"), out[:5]))
-        losses = {"mano_reg_loss": out[5].view(1)}
-        total_loss = image.new_zeros((1,)) + out[5]
-        if supervised:
-            lam_j, lam_o = self.lam[0], self.lam[1]
-            losses["recov_joint3d"], losses["recov_objverts3d"] = out[6], out[7]
-            total_loss = total_loss + lam_j * out[6]
-            total_loss = total_loss + lam_o * out[7]
+            losses["recov_joint3d"] = F.mse_loss(results["recov_joints3d"], sample["joints3d"])
+            total_loss = total_loss + lam_j * losses["recov_joint3d"]
+            losses["recov_objverts3d"] = F.mse_loss(results["recov_objverts3d"], sample["objverts3d"])
+            total_loss = total_loss + lam_o * losses["recov_objverts3d"]
         losses["total_loss"] = total_loss
         return total_loss, results, losses

@@ -84,17 +84,19 @@ class WarpRegNet(torch.nn.Module):
             first_only=self.first_only, hand_ignore_faces=self.hand_ignore_faces, use_backward=self.use_backward,
             pair_outputs=self.pair_outputs)
 
-    def preencode(self, batches):
-        """Run the image encoder ONCE over all frames of `batches` (the data batch and both frames of
-        the consist batch of one optimiser step) when the wrapped model offers it and its BatchNorm
-        statistics are frozen; the per-frame ``self.model(sample)`` calls then reuse the features."""
+    def prepare(self, batches, batch_encoder=False):
+        """Run everything that does not depend on the supervision ONCE over all frames of `batches` (the
+        data batch and both frames of the consist batch of one optimiser step) when the wrapped model
+        offers it (``prepare_frames``): the heads and the parameter-free MANO / camera-recovery code run
+        on the concatenated features; with `batch_encoder` (frozen BatchNorm statistics only) the encoder
+        too.  The per-frame ``self.model(sample)`` calls then only add the loss terms."""
         core = getattr(self.model, "module", self.model)
-        if not hasattr(core, "encode_frames") or core.training:
+        if not hasattr(core, "prepare_frames"):
             return False
         samples = [s for batch in batches for s in batch["data"]]
         if len({tuple(s["image"].shape[1:]) for s in samples}) != 1:
             return False
-        self.model(samples, encode_only=True)
+        self.model(samples, encode_only=True, batch_encoder=bool(batch_encoder) and not core.training)
         return True
 
     def forward(self, batch):

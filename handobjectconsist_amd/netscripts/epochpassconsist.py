@@ -10,29 +10,33 @@ import torch
 from handobjectconsist_amd.utils import synth
 
 
-# One encoder pass over all frames of a step instead of one per frame (WarpRegNet.preencode): same
-# features when the BatchNorm statistics are frozen, a third of the encoder's launches.  Measured on
-# MI355X (scripts/cpu_floor.py): the launch-bound floor of a step drops from 27 ms to 17 ms, but at
-# the headline size (B=64, 256x256) the step is GPU-bound and MIOpen's fp32 Winograd kernels are ~1.3x
-# slower per image at B=192 than at B=64 (52.7 ms -> 57.9 ms per step) -- so this is OFF by default
-# and meant for small batches (HOC_BATCH_ENCODER=1).
+# BATCH_POST: the regression heads and the parameter-free code behind them (MANO LBS, camera recovery,
+# projections: ~100 small launches per frame in forward, ~150 in backward) run ONCE over the frames of a
+# step instead of once per frame (WarpRegNet.prepare).  Per-sample operations only: same values.
+# BATCH_ENCODER: also ONE encoder pass over all frames (same features when the BatchNorm statistics are
+# frozen).  Measured on MI355X (scripts/cpu_floor.py): the launch-bound floor of a step drops from 27 ms
+# to 17 ms, but at the headline size (B=64, 256x256) the step is GPU-bound and MIOpen's fp32 Winograd
+# kernels are ~1.3x slower per image at B=192 than at B=64 (52.7 ms -> 57.9 ms per step) -- so this one
+# is OFF by default and meant for small batches (HOC_BATCH_ENCODER=1).
+BATCH_POST = os.environ.get("HOC_BATCH_POST", "1") != "0"
 BATCH_ENCODER = os.environ.get("HOC_BATCH_ENCODER", "0") == "1"
 
 
 def train_step(batches, premodel, optimizer):
     """One optimiser step over `loader_nb = len(batches)` batches (epochpassconsist.py:57-68)."""
     losses, logs = [], {}
-    if BATCH_ENCODER and hasattr(premodel, "preencode"):
-        premodel.preencode(batches)
+    if (BATCH_POST or BATCH_ENCODER) and hasattr(premodel, "prepare"):
+        premodel.prepare(batches, batch_encoder=BATCH_ENCODER)
     try:
         for batch in batches:
             loss, all_losses, _results, _pair_results = premodel.forward(batch)
             losses.append(loss.flatten())
             logs.update({k: v for k, v in all_losses.items() if v is not None})
     finally:
-        for batch in batches:  # the features belong to this step's autograd graph
+        for batch in batches:  # the prepared tensors belong to this step's autograd graph
             for sample in batch["data"]:
                 sample.pop("_features", None)
+                sample.pop("_post", None)
     optimizer.zero_grad(set_to_none=True)
     loss = torch.stack(losses).sum()
     if loss.requires_grad:

@@ -32,9 +32,10 @@ def _worker(rank, world, port, out):
     opt = torch.optim.SGD(model.parameters(), lr=1e-3)
     ld = SyntheticConsistLoader(2, 64, seed=rank, device="cpu", pool=1)  # distinct shard per rank
     data, consist = ld.step_batches(0)
-    # one encoder pass over the three frames of the step (WarpRegNet.preencode), through the DDP wrapper
-    net([data["data"][0]] + list(consist["data"]), encode_only=True)
-    assert all("_features" in s for s in consist["data"])
+    # encoder + ONE pass of the heads / MANO over the three frames of the step (WarpRegNet.prepare), through
+    # the DDP wrapper; the three per-frame forwards below only add the loss terms
+    net([data["data"][0]] + list(consist["data"]), encode_only=True, batch_encoder=True)
+    assert all("_post" in s for s in consist["data"])
     # epochpassconsist.py:57-68 structure: three forwards through the SAME DDP module, one backward
     losses = [net(data["data"][0])[0]]
     for sample in consist["data"]:

@@ -193,15 +193,18 @@ def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, fused_epilo
         close(v1.grad.cpu().numpy(), ref_g.cpu().numpy(), 1e-3, 1e-5 * float(ref_g.abs().max()), "vertex grad across paths")
 
 
-def test_train_step_batched_encoder_matches_per_frame(cuda):
+@pytest.mark.parametrize("batch_post,batch_encoder", [(True, False), (True, True)])
+def test_train_step_batched_frames_match_per_frame(cuda, batch_post, batch_encoder):
     """One optimiser step (data batch + consist pair: encoder, MANO, 2 renders, occlusion, pair loss,
-    backward, SGD) with ONE encoder pass over the three frames == the reference's pass per frame."""
+    backward, SGD) with the heads / MANO (and optionally the encoder) run ONCE over the three frames
+    == the reference's structure of one pass per frame."""
     from handobjectconsist_amd.models.synthnet import SynthMeshRegNet
     from handobjectconsist_amd.models.warpreg import WarpRegNet
     from handobjectconsist_amd.netscripts import epochpassconsist as E
 
     res = {}
     for batched in (False, True):
+        E.BATCH_POST, E.BATCH_ENCODER = (batch_post, batch_encoder) if batched else (False, False)
         torch.manual_seed(0)
         model = SynthMeshRegNet().to(cuda).eval()
         pre = WarpRegNet((64, 64), model, lambda_consist=0.5, lambda_data=0.5, criterion="l1", gt_refs=True,
@@ -209,12 +212,11 @@ def test_train_step_batched_encoder_matches_per_frame(cuda):
         pre.step_count = 1000
         opt = torch.optim.SGD(model.parameters(), lr=1e-3)
         loader = E.SyntheticConsistLoader(3, 64, seed=0, device=cuda, pool=1)
-        E.BATCH_ENCODER = batched
         try:
             loss, logs = E.train_step(loader.step_batches(0), pre, opt)
         finally:
-            E.BATCH_ENCODER = False
-        assert all("_features" not in s for b in loader.step_batches(0) for s in b["data"])
+            E.BATCH_POST, E.BATCH_ENCODER = True, False
+        assert all("_features" not in s and "_post" not in s for b in loader.step_batches(0) for s in b["data"])
         assert "warp_consist" in logs and float(logs["warp_consist"].detach()) > 0
         res[batched] = {k: float(v.detach().flatten()[0]) for k, v in logs.items()}
     # the smooth terms agree to rounding (different MIOpen kernels for B and 3B images) ...
@@ -233,7 +235,7 @@ def test_encode_frames_matches_per_frame_features(cuda):
     samples = [{"image": torch.rand(4, 3, 64, 64, device=cuda) - 0.5} for _ in range(3)]
     with torch.no_grad():
         ref = [model.base_net(s["image"]) for s in samples]
-        model(samples, encode_only=True)
+        model.encode_frames(samples)
     for s, r in zip(samples, ref):
         assert s["_features"].shape == r.shape
         assert (s["_features"] - r).abs().max() <= 1e-5 * r.abs().max()
