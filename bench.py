@@ -41,6 +41,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--batch", type=int, default=64, help="per-GPU batch size (frames / frame pairs)")
     p.add_argument("--image-size", type=int, default=256)
+    p.add_argument("--encoder-dtype", choices=("f32", "bf16"), default="f32",
+                   help="f32 = the reference's precision (headline); bf16 = BASELINE config 5: trunk under bf16 "
+                        "autocast, heads / MANO / render / warp stay fp32 -- reported with dtype 'bf16+f32'")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-bench", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample")
@@ -272,6 +275,8 @@ def main():
     B, is_ = args.batch, args.image_size
     model = SynthMeshRegNet().to(dev)
     model.eval()  # --freeze_batchnorm: BN statistics frozen, affine parameters trainable
+    if args.encoder_dtype == "bf16":
+        model.encoder_dtype = torch.bfloat16
     net = model
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
@@ -351,10 +356,11 @@ def main():
             "value": round(world * args.steps / dt, 4),
             "unit": "iters/s (each: 1 data batch + 1 consist batch of B per GPU, one optimizer step)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
             "data": "synthetic",
             "config": {"workload": f"trainmeshwarp.py consist step, per-GPU B={B}, {is_}x{is_}, hand 778v/1552f + "
-                                   f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 fp32 stock PyTorch, Adam",
+                                   f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {'fp32' if args.encoder_dtype == 'f32' else 'bf16-autocast'} stock PyTorch, Adam",
                        "global_batch": B * world, "image_size": is_, "parallelism": f"dp{world}"},
             "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,

@@ -233,6 +233,16 @@ class SynthMeshRegNet(nn.Module):
         self.mano_layer = SynthManoLayer(ncomps=mano_comps, use_pca=True, center_idx=9)
         self.obj_trans_factor, self.obj_scale_factor = obj_trans_factor, obj_scale_factor
         self.lam = (lambda_recov_joints3d, lambda_obj_recov_verts3d, lambda_pose_reg, lambda_shape)
+        # BASELINE.json config 5 ("bf16"): the TRUNK under bf16 autocast; heads, MANO, render and warp stay fp32
+        self.encoder_dtype = torch.float32
+
+    def encode(self, images):
+        """ResNet-18 trunk -> [B,512] fp32 features (optionally computed under bf16 autocast)."""
+        if self.encoder_dtype == torch.float32:
+            return self.base_net(images)
+        with torch.autocast("cuda", dtype=self.encoder_dtype):
+            feats = self.base_net(images)
+        return feats.float()
 
     def encode_frames(self, samples):
         """ONE encoder pass over the frames of several samples (same resolution): the reference runs
@@ -243,7 +253,7 @@ class SynthMeshRegNet(nn.Module):
         if self.base_net.training:
             raise RuntimeError("encode_frames needs frozen BatchNorm statistics (model.eval())")
         sizes = [s["image"].shape[0] for s in samples]
-        feats = self.base_net(torch.cat([s["image"] for s in samples]))
+        feats = self.encode(torch.cat([s["image"] for s in samples]))
         for s, f in zip(samples, feats.split(sizes)):
             s["_features"] = f
 
@@ -287,7 +297,7 @@ class SynthMeshRegNet(nn.Module):
         slices are left in ``sample["_post"]``; the loss terms stay per frame in ``forward``."""
         if batch_encoder:
             self.encode_frames(samples)
-        feats = [s["_features"] if "_features" in s else self.base_net(s["image"]) for s in samples]
+        feats = [s["_features"] if "_features" in s else self.encode(s["image"]) for s in samples]
         sizes = [f.shape[0] for f in feats]
         H, W = samples[0]["image"].shape[2:]
         pose, shape, scaletrans, st_obj = self.heads(torch.cat(feats))
@@ -311,7 +321,7 @@ class SynthMeshRegNet(nn.Module):
         if post is None:
             features = sample.get("_features")
             if features is None:
-                features = self.base_net(image)
+                features = self.encode(image)
             pose, shape, scaletrans, st_obj = self.heads(features)
             post = self.post_heads(pose, shape, scaletrans, st_obj, sample["camintr"], sample["objcanverts"],
                                    input_res=(W, H)) + (pose, shape)
