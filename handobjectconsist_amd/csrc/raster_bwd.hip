@@ -3,20 +3,25 @@
 // Replaces upstream kernels backward_pixel_map / backward_textures / backward_depth_map
 // (/root/reference/meshreg/neurender/rasterize.py:269-315).
 //
-// Design:
-//   * texture + depth gradients (upstream kernels E, F) are computed by a FACE-PARALLEL
-//     GATHER instead of per-pixel global atomics: one lane owns one face, walks the face's
-//     pixel bounding box in the face_index_map and, for the pixels it won, recomputes the
-//     barycentrics / sampling weights from the vertices (nothing but face_index_map is read
-//     back from the forward pass) and accumulates the 24 texel and 9 vertex gradients in
-//     registers.  Four lanes share a face (one bbox row each, combined by two quad
-//     shuffles in a fixed order), so the result is deterministic run to run; faces whose
-//     bbox is very large are walked by the whole wave (lane per pixel) and tree-reduced.
-//     Every output element is written exactly once: no memset, no atomics.
-//   * the pixel-map pseudo-gradient (upstream kernel D) keeps upstream's per-face edge
-//     walks but spreads the six (edge, axis) walks of a face over six lanes.
-//   * generic-texture-size / upstream-compatible variants (per-pixel atomics on stored or
-//     recomputed sampling weights) back the five-entry-point API.
+// Kernels, in file order:
+//   * gather_kernel<IMG,TEX,DEPTH> -- E + F for generic 2x2x2 textures: FACE-PARALLEL GATHER instead of
+//     per-pixel global atomics.  Four lanes share a face (one bbox row each), walk its pixel bounding
+//     box in face_index_map and, for the pixels it won, recompute barycentrics / sampling weights from
+//     the vertices (nothing but face_index_map is read back from the forward) into register
+//     accumulators; faces with a very large bbox are walked by the whole wave.  Every output element
+//     is written exactly once: no memset, no atomics, deterministic.
+//   * gather_vc_kernel -- the same idea for the vertex-colour mode with an LDS fragment ring (probe,
+//     compact the won pixels, shade with full lanes); kept as the fallback for meshes whose colour
+//     table does not fit LDS.
+//   * scatter_vc_kernel<STORED> -- E for the vertex-colour mode, the training path: PIXEL-parallel,
+//     block-private [V,3] table in LDS in 64-bit fixed point, optionally on the forward's stored
+//     weight / depth maps (see the comment at the kernel).
+//   * textures_atomic_*, depth_atomic_stored_kernel -- generic texture size / upstream-compatible
+//     variants (per-pixel atomics on stored or recomputed sampling weights) behind the five-entry-point API.
+//   * pixel_map_kernel<IMG> -- kernel D as upstream walks it, one wave per face, reading the eight
+//     planes in place (reference algorithm; no workspace needed).
+//   * pixel_pack_kernel + pixel_map_packed_kernel -- kernel D on packed row- and column-major records
+//     with item-parallel headers (the default when a workspace is given; see the comment there).
 #include "mr_common.hpp"
 
 namespace mr {

@@ -20,10 +20,12 @@
 //                          full for the 5x5..16x16-pixel triangles of these meshes:
 //                            S1 lane per face: load the 9 floats, invert the pixel-space
 //                               matrix, park the face in an LDS face cache;
-//                            S2 8 faces x 8 tile rows per pass, one lane per (face, row),
-//                               walking the clipped x-range with ONLY the three cheap edge
-//                               tests; covered pixels are appended as fragments (face slot,
-//                               x, y) to an LDS queue by ballot + popcount;
+//                            S2 8 faces x 8 tile rows per pass, one lane per (face, row): the
+//                               pixels a face covers on a row form ONE span (each edge test is
+//                               monotone in x, also in floating point), found by three
+//                               interleaved bisections with the exact predicate; the span's
+//                               pixels are appended as fragments (face slot, x, y) to an LDS
+//                               ring by ballot + popcount;
 //                            S3 lane per fragment, 64 at a time: barycentrics (the 7 IEEE
 //                               divisions), near/far test, depth test.
 //                          Depth test = ds_min_u64 on a per-tile LDS z-buffer holding
@@ -34,7 +36,9 @@
 //                          barycentrics (bit-identical to the winning test), sample the
 //                          texture, blend background, write every output plane once,
 //                          already vertically flipped / NCHW for the image-space outputs.
-// HBM traffic: faces 36 B + 16 B record per live face, outputs written exactly once; no
+// Vertex-colour mode (face_setup_vc_kernel, raster_tile_kernel<FUSED, VC=true>): geometry through the vertex
+// indices, fill-back by index arithmetic, colours of the three vertices instead of a texture (bit-identical).
+// HBM traffic: faces 36 B + 16 + 48 B record per live face, outputs written exactly once; no
 // per-pixel memset, no sampling maps, no separate flip / permute / alpha / background pass.
 #include "mr_common.hpp"
 

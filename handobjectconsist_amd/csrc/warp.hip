@@ -9,9 +9,13 @@
 //                                  -> pair_consist_forward_kernel (both directions, 8 grid
 //                                     samples, mask algebra and the masked L1 sums in ONE pass
 //                                     over the pixels) + finalize + backward w.r.t. the flows.
+//   opticalflow.py:109-154 mask algebra / crop / permute
+//                                  -> flow_mask_kernel, flow_finalize_{forward,backward}_kernel
 // All are HBM-streaming kernels: one lane per pixel, channel planes read coalesced, the
-// bilinear taps hit L1/L2 (flows are a few pixels).  Reductions are two-stage and
-// deterministic (fixed-order block partials -> per-sample finalize), no float atomics.
+// bilinear taps hit L1/L2 (flows are a few pixels); in the pair kernels the two taps of a row
+// come from ONE 8-byte load at a 32-bit offset from a wave-uniform plane pointer (load-instruction
+// count is what bounds them).  Reductions are two-stage and deterministic (fixed-order block
+// partials -> per-sample finalize), no float atomics.
 //
 // grid_sample semantics restated (torch, zeros padding, align_corners=False):
 //   vx = 2 (x + u) / max(W - 1, 1) - 1 ;  ix = ((vx + 1) W - 1) / 2        
