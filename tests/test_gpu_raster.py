@@ -435,3 +435,55 @@ def test_vertex_colour_render_adjoint_at_metric_size(cuda):
         fn = torch.unique(fim[b][fim[b] >= 0]) % F0
         owners[b, d["fidx"][b, fn].long().flatten()] = True
         assert (back[b][~owners[b]] == 0).all()
+
+
+def test_integration_md_stub_runs_the_reference_call_sequence(cuda):
+    """The `neural_renderer.cuda.rasterize` replacement printed in INTEGRATION.md (section B), executed
+    verbatim and driven with the reference's own call sequence and buffer pre-fill (rasterize.py:60-90,
+    154-190): forward maps + rgb and the three backward kernels against the oracle."""
+    import os
+    import re
+    import types
+
+    from handobjectconsist_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = [b for b in re.findall(r"```python\n(.*?)```", md, re.S) if "def forward_face_index_map" in b]
+    assert len(code) == 1
+    src = code[0].replace("/path/to/handobjectconsist_amd/libmeshraster_hip.so", _lib.LIB_PATH)
+    stub = types.ModuleType("rasterize_stub")
+    exec(compile(src, "INTEGRATION.md", "exec"), stub.__dict__)
+
+    B, is_, eps = 2, 64, 1e-3
+    faces_np, tex_np = make_case("scene", B, is_, 0)
+    saved = R.rasterize_forward(faces_np, tex_np, is_, 0.1, 100, eps, (0, 0, 0), num_threads=8)
+    faces, tex = t(faces_np, cuda), t(tex_np, cuda)
+    F = faces.shape[1]
+    f32 = dict(dtype=torch.float32, device=cuda)
+    fim = torch.full((B, is_, is_), -1, dtype=torch.int32, device=cuda)       # rasterize.py:60-85
+    wmap = torch.zeros((B, is_, is_, 3), **f32)
+    dmap = torch.full((B, is_, is_), 100.0, **f32)
+    finv_map = torch.zeros((B, is_, is_, 3, 3), **f32)
+    faces_inv = torch.zeros_like(faces)
+    rgb = torch.zeros((B, is_, is_, 3), **f32)
+    sidx = torch.zeros((B, is_, is_, 8), dtype=torch.int32, device=cuda)
+    swgt = torch.zeros((B, is_, is_, 8), **f32)
+    out = stub.forward_face_index_map(faces, fim, wmap, dmap, finv_map, faces_inv, is_, 0.1, 100, True, True, True)
+    assert out[0] is fim and out[3] is finv_map
+    stub.forward_texture_sampling(faces, tex, fim, wmap, dmap, rgb, sidx, swgt, is_, eps)
+    assert (fim.cpu().numpy() == saved["face_index_map"]).all()
+    assert_close(rgb.cpu().numpy(), saved["rgb_map"] * (saved["face_index_map"] >= 0)[..., None], 1e-6, 1e-6, "rgb")
+    assert_close(dmap.cpu().numpy(), saved["depth_map"], 1e-6, 0, "depth")
+    alpha = (fim >= 0).float()
+    rng = np.random.default_rng(3)
+    g_rgb = rng.standard_normal((B, is_, is_, 3)).astype(np.float32)
+    g_alpha = rng.standard_normal((B, is_, is_)).astype(np.float32)
+    g_depth = rng.standard_normal((B, is_, is_)).astype(np.float32)
+    gf_ref, gt_ref = R.rasterize_backward(saved, g_rgb, g_alpha, g_depth, num_threads=8)
+    grad_faces, grad_tex = torch.zeros_like(faces), torch.zeros_like(tex)          # rasterize.py:154-158
+    stub.backward_pixel_map(faces, fim, rgb, alpha, t(g_rgb, cuda), t(g_alpha, cuda), grad_faces, is_, eps, True, True)
+    stub.backward_textures(fim, swgt, sidx, t(g_rgb, cuda), grad_tex, F)
+    stub.backward_depth_map(faces, dmap, fim, finv_map, wmap, t(g_depth, cuda), grad_faces, is_)
+    assert_close(grad_tex.cpu().numpy(), gt_ref, 1e-4, 1e-5 * np.abs(gt_ref).max(), "grad_textures")
+    assert_close(grad_faces.cpu().numpy(), gf_ref, 1e-4, 1e-5 * np.abs(gf_ref).max(), "grad_faces")
