@@ -34,6 +34,9 @@ SIGNATURES = {
     "mr_render_vc_backward": (_I, [_P] * 7 + [_I, _I, _I, _I, _I, _F, _I, _P]),
     "mr_flow_vertices_forward": (_I, [_P] * 7 + [_I, _F] + [_P] * 4 + [_I, _I, _P]),
     "mr_flow_vertices_backward": (_I, [_P] * 8 + [_I, _I, _P]),
+    "mr_mano_workspace_floats": (_L, [_I]),
+    "mr_mano_forward": (_I, [_P] * 12 + [_I, _I] + [_P] * 3 + [_I, _P]),
+    "mr_mano_backward": (_I, [_P] * 10 + [_I, _I] + [_P] * 5 + [_I, _P]),
     "mr_warp_forward": (_I, [_P] * 4 + [_I, _I, _I, _I, _F, _I, _P]),
     "mr_warp_backward": (_I, [_P] * 5 + [_I, _I, _I, _I, _F, _I, _P]),
     "mr_occlusion_mask": (_I, [_P] * 4 + [_L, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),

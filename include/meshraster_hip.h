@@ -203,6 +203,33 @@ MR_API int mr_flow_vertices_backward(const float* verts1, const float* verts2, c
                                      float* grad_verts2, int batch_size, int num_verts,
                                      mr_stream_t stream);
 
+/* MANO linear-blend skinning (manopth ManoLayer.forward as called at
+ * manobranch.py:130-136, PCA pose space, arithmetic of SURVEY appendix B.10) and its adjoint.
+ *   pose_coeffs[B, 3 + ncomps] (global axis-angle + PCA coefficients), betas[B,10]
+ *   -> verts_out[B,778,3], jtr_out[B,21,3]: millimetres, centred on joint `center` (or not: -1),
+ *      joints = cat(16 chain joints, 5 finger-tip vertices)[reorder].
+ * Model constants (device pointers, prepared once by the caller): comps[ncomps,45], hands_mean[45],
+ * js[48,10] = J_regressor x shapedirs, jt[48] = J_regressor x template, blend[146,2334] = the shape
+ * (rows 0-9) and pose (rows 10-144) blend shapes, coefficient-major, row 145 zero; v_template[2334];
+ * weights[778,16]; parents[16] (-1 for the root), tips[5], reorder[21] (int32).
+ * The blend-shape product -- the only GEMM-shaped step of the whole path -- runs on the matrix cores
+ * (v_mfma_f32_32x32x2_f32).  workspace: mr_mano_workspace_floats(B) floats; mr_mano_backward must get
+ * the workspace its forward call filled. */
+MR_API int64_t mr_mano_workspace_floats(int batch_size);
+MR_API int mr_mano_forward(const float* pose_coeffs, const float* betas, const float* comps,
+                           const float* hands_mean, const float* js, const float* jt,
+                           const float* blend, const float* v_template, const float* weights,
+                           const int32_t* parents, const int32_t* tips, const int32_t* reorder,
+                           int ncomps, int center, float* workspace, float* verts_out,
+                           float* jtr_out, int batch_size, mr_stream_t stream);
+MR_API int mr_mano_backward(const float* comps, const float* hands_mean, const float* js,
+                            const float* jt, const float* blend, const float* v_template,
+                            const float* weights, const int32_t* parents, const int32_t* tips,
+                            const int32_t* reorder, int ncomps, int center, float* workspace,
+                            const float* grad_verts, const float* grad_jtr,
+                            float* grad_pose_coeffs, float* grad_betas, int batch_size,
+                            mr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * 3. Warping (meshreg/warping/imgflowarp.py)
  * ---------------------------------------------------------------------------------- */
