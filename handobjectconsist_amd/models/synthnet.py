@@ -361,25 +361,28 @@ class SynthMeshRegNet(nn.Module):
         optimiser step at once: the encoder (one pass per frame as in the reference, or one pass over
         the concatenation), then ONE pass of the heads and of ``post_heads`` over the concatenated
         features -- a third of their ~250 launches per frame (forward + backward).  Per-sample
-        operations only, so each frame's slice equals what its own ``forward`` would compute.  The
-        slices are left in ``sample["_post"]``; the loss terms stay per frame in ``forward``."""
+        operations only, so each frame's slice equals what its own ``forward`` would compute.  Returns
+        one tuple per frame, to be passed back as ``sample["_post"]``; the loss terms stay per frame in
+        ``forward``."""
         if batch_encoder:
-            self.encode_frames(samples)
-        feats = [s["_features"] if "_features" in s else self.encode(s["image"]) for s in samples]
+            if self.base_net.training:
+                raise RuntimeError("a single encoder pass needs frozen BatchNorm statistics (model.eval())")
+            sizes_img = [s["image"].shape[0] for s in samples]
+            feats = list(self.encode(torch.cat([s["image"] for s in samples])).split(sizes_img))
+        else:
+            feats = [self.encode(s["image"]) for s in samples]
         sizes = [f.shape[0] for f in feats]
         H, W = samples[0]["image"].shape[2:]
         pose, shape, scaletrans, st_obj = self.heads(torch.cat(feats))
         geo = self.post_heads(pose, shape, scaletrans, st_obj, torch.cat([s["camintr"] for s in samples]),
                               torch.cat([s["objcanverts"] for s in samples]), input_res=(W, H))
-        per_frame = zip(*[t.split(sizes) for t in geo + (pose, shape)])
-        for s, chunk in zip(samples, per_frame):
-            s.pop("_features", None)
-            s["_post"] = chunk
+        # returned, not stored: behind a DistributedDataParallel wrapper `samples` may be re-built copies of
+        # the caller's containers (DDP moves inputs to its device recursively), so the caller stashes them
+        return list(zip(*[t.split(sizes) for t in geo + (pose, shape)]))
 
     def forward(self, sample, no_loss=False, encode_only=False, batch_encoder=False):
         if encode_only:  # (through forward so that a DistributedDataParallel wrapper sees the call)
-            self.prepare_frames(sample, batch_encoder=batch_encoder)
-            return None
+            return self.prepare_frames(sample, batch_encoder=batch_encoder)
         image = sample["image"]
         H, W = image.shape[2:]
         supervised = not no_loss and "joints3d" in sample and "objverts3d" in sample

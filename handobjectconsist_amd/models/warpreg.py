@@ -96,7 +96,9 @@ class WarpRegNet(torch.nn.Module):
         samples = [s for batch in batches for s in batch["data"]]
         if len({tuple(s["image"].shape[1:]) for s in samples}) != 1:
             return False
-        self.model(samples, encode_only=True, batch_encoder=bool(batch_encoder) and not core.training)
+        prepared = self.model(samples, encode_only=True, batch_encoder=bool(batch_encoder) and not core.training)
+        for sample, chunk in zip(samples, prepared):
+            sample["_post"] = chunk
         return True
 
     def forward(self, batch):

@@ -30,3 +30,10 @@ for s, e, n in seg:
           ("mr:: kernels" if "mr::" in n else ("elementwise" if "elementwise" in n else ("gemm" if "Cijk" in n else "other")))
     acc[key] += e - s
 print({k: round(v / 1e6, 2) for k, v in acc.items()})
+cnt = collections.Counter()
+for s, e, n in seg:
+    if not any(t in n for t in ("Conv", "igemm", "batch_norm", "BatchNorm", "max_pool", "transpose", "Im2", "Col2", "SubTensor")):
+        cnt[n[:90]] += 1
+print("non-encoder launches in the last step:", sum(cnt.values()))
+for k, v in cnt.most_common(25):
+    print(f"{v:4d}  {k}")

@@ -34,8 +34,9 @@ def _worker(rank, world, port, out):
     data, consist = ld.step_batches(0)
     # encoder + ONE pass of the heads / MANO over the three frames of the step (WarpRegNet.prepare), through
     # the DDP wrapper; the three per-frame forwards below only add the loss terms
-    net([data["data"][0]] + list(consist["data"]), encode_only=True, batch_encoder=True)
-    assert all("_post" in s for s in consist["data"])
+    frames = [data["data"][0]] + list(consist["data"])
+    for sample, chunk in zip(frames, net(frames, encode_only=True, batch_encoder=True)):
+        sample["_post"] = chunk
     # epochpassconsist.py:57-68 structure: three forwards through the SAME DDP module, one backward
     losses = [net(data["data"][0])[0]]
     for sample in consist["data"]:

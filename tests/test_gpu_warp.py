@@ -193,6 +193,23 @@ def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, fused_epilo
         close(v1.grad.cpu().numpy(), ref_g.cpu().numpy(), 1e-3, 1e-5 * float(ref_g.abs().max()), "vertex grad across paths")
 
 
+class _ContainerCopyingWrapper(torch.nn.Module):
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    @staticmethod
+    def _copy(obj):
+        if isinstance(obj, dict):
+            return {k: _ContainerCopyingWrapper._copy(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(_ContainerCopyingWrapper._copy(v) for v in obj)
+        return obj
+
+    def forward(self, *args, **kwargs):
+        return self.module(*self._copy(args), **self._copy(kwargs))
+
+
 @pytest.mark.parametrize("batch_post,batch_encoder", [(True, False), (True, True)])
 def test_train_step_batched_frames_match_per_frame(cuda, batch_post, batch_encoder):
     """One optimiser step (data batch + consist pair: encoder, MANO, 2 renders, occlusion, pair loss,
@@ -207,7 +224,10 @@ def test_train_step_batched_frames_match_per_frame(cuda, batch_post, batch_encod
         E.BATCH_POST, E.BATCH_ENCODER = (batch_post, batch_encoder) if batched else (False, False)
         torch.manual_seed(0)
         model = SynthMeshRegNet().to(cuda).eval()
-        pre = WarpRegNet((64, 64), model, lambda_consist=0.5, lambda_data=0.5, criterion="l1", gt_refs=True,
+        # like DistributedDataParallel with device_ids, the wrapper hands the module re-built COPIES of the
+        # input containers: whatever the prepare pass computes has to come back as a return value
+        wrapped = _ContainerCopyingWrapper(model) if batched else model
+        pre = WarpRegNet((64, 64), wrapped, lambda_consist=0.5, lambda_data=0.5, criterion="l1", gt_refs=True,
                          use_backward=True, mano_faces=model.mano_layer.th_faces, pair_outputs="loss").to(cuda)
         pre.step_count = 1000
         opt = torch.optim.SGD(model.parameters(), lr=1e-3)
