@@ -88,7 +88,6 @@ def kernel_bench(dev, B, is_, iters):
     from handobjectconsist_amd import _lib
     from handobjectconsist_amd.neurender import nr_ops
     from handobjectconsist_amd.utils import synth, textutils
-    from handobjectconsist_amd.warping import imgflowarp
 
     s = synth.random_scene(B, seed=0, image_size=is_)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)

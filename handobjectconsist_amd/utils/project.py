@@ -1,6 +1,5 @@
 """Camera projection helper -- stands in for ``libyana.camutils.project``
 (third-party, called at /root/reference/meshreg/warping/opticalflow.py:98-99)."""
-import torch
 
 
 def batch_proj2d(verts, camintr, camextr=None):

@@ -1,5 +1,5 @@
 """ResNet-18 trunk fwd+bwd, 3 passes of B=64 at 256x256: NCHW vs channels_last (GPU ms by events)."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from handobjectconsist_amd.models.synthnet import SynthMeshRegNet

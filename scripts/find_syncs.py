@@ -20,6 +20,6 @@ with warnings.catch_warnings(record=True) as w:
     E.train_step(loader.step_batches(0), pre, opt)
 torch.cuda.set_sync_debug_mode("default")
 print("synchronising calls in one step:", len(w))
-import traceback
+
 for x in w[:20]:
     print(" ", x.filename.replace(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "."), x.lineno, str(x.message)[:100])
