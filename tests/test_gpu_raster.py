@@ -512,3 +512,21 @@ def test_fastrender_lit_rgba_matches_oracle(cuda):
     assert_close(got[..., 3], alpha, 0, 0, "alpha")
     assert_close(got[..., :3], rgb.transpose(0, 2, 3, 1), 1e-4, 3e-4, "lit rgb")
     assert 0.02 < alpha.mean() < 0.6
+
+
+def test_cyclic_face_padding_is_invisible(cuda):
+    """the collate pads faces by cyclic repetition; duplicates tie in depth and the lower index
+    wins, so maps and images of the padded mesh equal those of the original, face indices included."""
+    from handobjectconsist_amd.neurender import rasterize
+    from handobjectconsist_amd.utils import collate
+
+    faces, tex = make_case("scene", 2, 96, 7)
+    F = faces.shape[1]
+    pad = F + 700
+    faces_p = np.stack([collate.pad_cyclic(f, pad) for f in faces])
+    tex_p = np.stack([collate.pad_cyclic(x, pad) for x in tex])
+    a = rasterize.rasterize_rgbad(t(faces, cuda), t(tex, cuda), 96, False, 0.1, 100, 1e-3, (0, 0, 0))
+    b = rasterize.rasterize_rgbad(t(faces_p, cuda), t(tex_p, cuda), 96, False, 0.1, 100, 1e-3, (0, 0, 0))
+    for k in ("rgb", "alpha", "depth", "weight_map", "face_index_map"):
+        assert torch.equal(a[k], b[k]), k
+    assert int(b["face_index_map"].max()) < F

@@ -172,3 +172,23 @@ def test_synthetic_network_matches_the_reference_parameter_count():
     assert res["recov_objverts3d"].shape == (2, 1002, 3) and "mano_reg_loss" in losses
     loss.backward()
     assert all(p.grad is not None for p in m.parameters() if p.requires_grad)
+
+
+def test_extend_collate_pads_by_cyclic_repetition():
+    """collate.py:15-36,77-83: per-mesh arrays padded to the batch maximum by repeating rows."""
+    from handobjectconsist_amd.utils import collate
+
+    a = {"objverts3d": np.arange(12, dtype=np.float32).reshape(4, 3), "objfaces": np.array([[0, 1, 2], [0, 2, 3]]),
+         "image": torch.zeros(3, 4, 4), "name": "a"}
+    b = {"objverts3d": np.arange(21, dtype=np.float32).reshape(7, 3) + 100, "objfaces": np.array([[0, 1, 2], [2, 3, 4], [4, 5, 6]]),
+         "image": torch.ones(3, 4, 4), "name": "b"}
+    out = collate.extend_collate([dict(a), dict(b)], ["objverts3d", "objfaces", "missing"])
+    assert out["objverts3d"].shape == (2, 7, 3) and out["objfaces"].shape == (2, 3, 3) and out["image"].shape == (2, 3, 4, 4)
+    assert torch.equal(out["objverts3d"][0, 4:], out["objverts3d"][0, :3])      # rows 0..2 again
+    assert torch.equal(out["objfaces"][0, 2], out["objfaces"][0, 0])
+    assert torch.equal(out["objverts3d"][1], torch.from_numpy(b["objverts3d"]))
+    assert out["name"] == ["a", "b"]
+    seq = collate.seq_extend_collate([[dict(a), dict(b)], [dict(b), dict(a)]], ["objverts3d", "objfaces"])
+    assert len(seq) == 2 and seq[0]["objverts3d"].shape == (2, 7, 3) and seq[1]["objfaces"].shape == (2, 3, 3)
+    with pytest.raises(ValueError):
+        collate.seq_extend_collate([[dict(a)], [dict(a), dict(b)]])
