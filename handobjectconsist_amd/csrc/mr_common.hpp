@@ -127,7 +127,8 @@ __device__ __forceinline__ bool cover(const Face& f, int xi, int yi, int is, flo
         ((yp - v[7]) * (v[0] - v[6]) < (xp - v[6]) * (v[1] - v[7])))
         return false;
     bary(f, xi, yi, zp, w);
-    if (zp <= near_ || far_ <= zp) return false;
+    // (a NaN depth passes upstream's near / far test and then loses `zp < depth`: not covered)
+    if (!(zp > near_ && zp < far_)) return false;
     return true;
 }
 

@@ -338,7 +338,10 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
             const int fn = __float_as_int(c[18]);
             float zp, w[3];
             bary(f, tx0 + lx, ty0 + ly, zp, w);
-            if (!(zp <= p.near_ || p.far_ <= zp)) zbuf_min(zbuf, ly * TILE_W + lx, zp, fn);
+            // upstream: `if (zp <= near || far <= zp) continue; if (zp < depth) win`.  A NaN depth (faces whose
+            // vertices coincide in x, y pass every edge test and have no inverse) survives the first test and
+            // loses the second, so it must not reach the z-buffer -- both comparisons below are false for NaN
+            if (zp > p.near_ && zp < p.far_) zbuf_min(zbuf, ly * TILE_W + lx, zp, fn);
         }
         __builtin_amdgcn_wave_barrier();
     };

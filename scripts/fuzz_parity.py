@@ -1,0 +1,79 @@
+"""Randomised parity sweep of the HIP path against the CPU oracle (not a test: a bug hunt).
+Usage: fuzz_parity.py [n_cases] [first_seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from handobjectconsist_amd.neurender import rasterize
+from handobjectconsist_amd.warping import imgflowarp
+from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+from handobjectconsist_amd.utils import synth
+from oracle import raster_ref as R, warp_ref as W
+
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+n_cases, seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 0
+KW = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32), dist_coeffs=np.zeros((1, 5), np.float32))
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    seed = seed0 + case
+    rng = np.random.default_rng(seed)
+    B, is_ = int(rng.integers(1, 4)), int(rng.integers(9, 161))
+    kind = ("scene", "big", "tiny", "degenerate")[int(rng.integers(0, 4))]
+    if kind == "scene":
+        s = synth.random_scene(B, seed=seed, image_size=is_)
+        cols = rng.uniform(-2, 2, (B, s["verts1"].shape[1], 3)).astype(np.float32)
+        f2, tex = R.fill_back(s["faces"], R.batch_vertex_textures(s["faces"], cols))
+        faces = R.nr_vertices_to_faces(R.nr_projection(s["verts1"], s["K1"], KW["R"], KW["t"], KW["dist_coeffs"], is_), f2)
+    else:
+        n = int(rng.integers(1, 60))
+        faces = rng.uniform(-1.4, 1.4, (B, n, 3, 3)).astype(np.float32)
+        if kind == "tiny":
+            faces[..., :2] = faces[:, :, :1, :2] + rng.uniform(-0.03, 0.03, (B, n, 3, 2)).astype(np.float32)
+        faces[..., 2] = rng.uniform(0.05, 3.0, (B, n, 3))
+        if kind == "degenerate":
+            faces[:, ::3, 2] = faces[:, ::3, 0]                       # zero area
+            faces[:, 1::5, 1, :2] = faces[:, 1::5, 0, :2]             # repeated vertex
+            faces[:, 2::7, :, 0] = faces[:, 2::7, :1, 0]              # vertical line
+            faces = np.round(faces * 8) / 8 if rng.random() < 0.5 else faces  # vertices on pixel-centre lattices
+        faces = np.ascontiguousarray(np.concatenate([faces, faces[:, :, ::-1]], 1))
+        tex = rng.uniform(-1, 1, (B, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    near, far, eps = 0.1, 100.0, 1e-3
+    ref = R.rasterize_rgbad(faces, tex, is_, False, near, far, eps, (0.1, 0.2, 0.3), num_threads=8, keep_saved=True)
+    f_t, x_t = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
+    out = rasterize.rasterize_rgbad(f_t, x_t, is_, False, near, far, eps, (0.1, 0.2, 0.3))
+    msg = []
+    nf = int((out["face_index_map"].cpu().numpy() != ref["face_index_map"]).sum())
+    if nf: msg.append(f"face_index_map differs at {nf} px")
+    for k, tol in (("rgb", 1e-5), ("depth", 1e-6), ("alpha", 0)):
+        e = np.abs(out[k].detach().cpu().numpy().astype(np.float64) - ref[k]).max()
+        if e > tol * max(1.0, np.abs(ref[k]).max()): msg.append(f"{k} err {e:.2e}")
+    saved = ref["_saved"]
+    g = [rng.standard_normal(saved[k].shape).astype(np.float32) for k in ("rgb_map", "alpha_map", "depth_map")]
+    gf_ref, gt_ref = R.rasterize_backward(saved, *g, num_threads=8)
+    img = [np.ascontiguousarray(g[0].transpose(0, 3, 1, 2)[:, :, ::-1]), np.ascontiguousarray(g[1][:, ::-1]), np.ascontiguousarray(g[2][:, ::-1])]
+    torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]], [t(a) for a in img])
+    for got, want, name in ((x_t.grad, gt_ref, "grad_textures"), (f_t.grad, gf_ref, "grad_faces")):
+        gotn = got.cpu().numpy().astype(np.float64)
+        if not np.isfinite(gotn).all() and np.isfinite(want).all(): msg.append(f"{name} non-finite")
+        sc = np.abs(want[np.isfinite(want)]).max() if np.isfinite(want).any() else 1.0
+        e = np.abs(np.nan_to_num(gotn - want)).max()
+        if e > 2e-4 * sc + 1e-6: msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
+    # warp half: random flows incl. out-of-range and exactly integer ones
+    H, Wd = int(rng.integers(2, 70)), int(rng.integers(2, 90))
+    fl = [rng.normal(0, 3, (B, H, Wd, 2)).astype(np.float32) for _ in range(2)]
+    for f in fl:
+        f[rng.random(f.shape[:3]) < 0.2] = 0
+        f[rng.random(f.shape[:3]) < 0.1] = np.round(f[rng.random(f.shape[:3]) < 0.1][: 0].sum() + 2.0)
+    im = [rng.uniform(-0.5, 0.5, (B, 3, H, Wd)).astype(np.float32) for _ in range(2)]
+    jm = [np.ones((B, 3, H, Wd), np.float32) for _ in range(2)]
+    for m in jm:
+        m[:, :, : int(rng.integers(0, 3))] = 0
+    ref_loss = W.pair_consist(fl, im[0], im[1], jm[0], jm[1], True)[0]
+    loss = imgflowarp.pair_consist([t(fl[0]), t(fl[1])], t(im[0]), t(im[1]), t(jm[0]), t(jm[1]), PyramidCriterion("l1"), use_backward=True, outputs="loss")[0]
+    e = np.abs(loss.cpu().numpy() - ref_loss).max()
+    if e > 1e-5 * max(1.0, np.abs(ref_loss).max()): msg.append(f"pair loss err {e:.2e}")
+    if msg:
+        bad += 1
+        print(f"seed {seed} {kind} B={B} is={is_} F={faces.shape[1]}: " + "; ".join(msg))
+print(f"{n_cases} cases, {bad} with mismatches, {time.time() - t0:.0f} s")

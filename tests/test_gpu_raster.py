@@ -177,8 +177,11 @@ def test_edge_cases(cuda):
     # coplanar duplicates (tie -> lowest index), near/far rejection, degenerate + NaN faces, odd size
     is_ = 37
     tri = np.array([[-0.8, -0.7, 1.0], [0.9, -0.6, 1.0], [0.1, 0.85, 1.0]], np.float32)
+    # (the point face -- three vertices on one pixel-centre-lattice point -- passes every edge test of
+    # upstream's inside test at every pixel and has a NaN depth: it must never win; found by scripts/fuzz_parity.py)
+    point = np.array([[-0.5, -0.5, 1.75], [-0.5, -0.5, 1.625], [-0.5, -0.5, 1.75]], np.float32)
     faces = np.stack([tri, tri, tri * [1, 1, 0.05], tri * [1, 1, 500.0], tri[[0, 0, 1]], tri * np.nan,
-                      tri[::-1]])[None]
+                      tri[::-1], point, point[::-1]])[None]
     tex = np.random.default_rng(0).uniform(0, 1, (1, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
     ref = R.rasterize_rgbad(faces, tex, is_, False, 0.1, 100, 1e-3, (0, 0, 0))
     out = rasterize.rasterize_rgbad(t(faces, cuda), t(tex, cuda), is_, False, 0.1, 100, 1e-3, (0, 0, 0))
