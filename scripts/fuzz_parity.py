@@ -77,3 +77,78 @@ for case in range(n_cases):
         bad += 1
         print(f"seed {seed} {kind} B={B} is={is_} F={faces.shape[1]}: " + "; ".join(msg))
 print(f"{n_cases} cases, {bad} with mismatches, {time.time() - t0:.0f} s")
+
+# ---- second sweep: vertex-colour path (indexed meshes, shared vertices, degenerate triangles), compat API,
+# ---- reference-algorithm flag, anti-aliasing, warp / occlusion kernels
+from handobjectconsist_amd.neurender.renderer import Renderer
+bad2 = 0
+t0 = time.time()
+for case in range(n_cases):
+    seed = seed0 + 100000 + case
+    rng = np.random.default_rng(seed)
+    B, is_ = int(rng.integers(1, 4)), int(rng.integers(8, 140))
+    V, F0 = int(rng.integers(3, 80)), int(rng.integers(1, 120))
+    verts = rng.uniform(-0.25, 0.25, (B, V, 3)).astype(np.float32)
+    verts[..., 2] = rng.uniform(0.3, 0.9, (B, V))
+    if rng.random() < 0.3:
+        verts[:, : V // 3] = verts[:, :1]  # coincident vertices -> zero-area / point faces
+    fidx = rng.integers(0, V, (B, F0, 3)).astype(np.int64)  # may repeat a vertex within a face
+    f = float(rng.uniform(100, 400)) * is_ / 256
+    K = np.tile(np.array([[f, 0, is_ / 2], [0, f, is_ / 2], [0, 0, 1]], np.float32), (B, 1, 1))
+    cols = rng.uniform(-2, 2, (B, V, 3)).astype(np.float32)
+    aa, fb = bool(rng.random() < 0.3), bool(rng.random() < 0.7)
+    msg = []
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=dev)[None], t=torch.zeros(1, 3, device=dev), K=torch.ones(1, 3, 3, device=dev),
+                   orig_size=is_, anti_aliasing=aa, fill_back=fb, near=0.1, no_light=True)
+    c1 = t(cols).requires_grad_(True)
+    # the SAME projected vertices on both sides (numpy projection): the rasterisers must then agree exactly
+    v_ndc = R.nr_projection(verts, K, KW["R"], KW["t"], KW["dist_coeffs"], is_)
+    out = ren.render_projected_vertex_colors(t(v_ndc), t(fidx), c1)
+    tex = R.batch_vertex_textures(fidx, cols)
+    f2, tex2 = R.fill_back(fidx, tex) if fb else (fidx, tex)
+    ref = R.rasterize_rgbad(R.nr_vertices_to_faces(v_ndc, f2), tex2, is_, aa, 0.1, 100, 1e-3, (0, 0, 0), num_threads=8)
+    a, b = out["face_index_map"].cpu().numpy(), ref["face_index_map"]
+    nd = int((a != b).sum())
+    if nd: msg.append(f"vc fim differs at {nd} px")
+    same = (a == b)
+    if aa:
+        pass
+    else:
+        e = np.abs(out["rgb"].detach().cpu().numpy() - ref["rgb"])[np.broadcast_to(same[:, None, ::-1], ref["rgb"].shape)].max() if same.any() else 0
+        if e > 2e-3: msg.append(f"vc rgb err {e:.2e}")
+    g = torch.randn_like(out["rgb"])
+    out["rgb"].backward(g)
+    c2 = t(cols).requires_grad_(True)
+    from handobjectconsist_amd.utils import textutils
+    out2 = ren(t(verts), t(fidx), textutils.batch_vertex_textures(t(fidx), c2), K=t(K), detach_renders=True)
+    out1 = ren.render_vertex_colors(t(verts), t(fidx), c1.detach(), K=t(K))  # same (GPU) projection as out2
+    if not torch.equal(out2["face_index_map"], out1["face_index_map"]) or not torch.equal(out2["rgb"], out1["rgb"]): msg.append("vc != generic forward")
+    if not torch.equal(out2["face_index_map"], out["face_index_map"]):
+        c1.grad = None  # projections differ in the last bit on this case: compare the gradients on the GPU projection
+        c1g = c1.detach().clone().requires_grad_(True)
+        out = ren.render_vertex_colors(t(verts), t(fidx), c1g, K=t(K))
+        out["rgb"].backward(g)
+        c1 = c1g
+    out2["rgb"].backward(g)
+    e = float((c1.grad - c2.grad).abs().max()); sc = float(c2.grad.abs().max()) + 1e-12
+    if e > 2e-4 * sc: msg.append(f"vc grad vs generic err {e:.2e} (scale {sc:.2e})")
+    # warp + occlusion kernels
+    H, Wd = int(rng.integers(1, 50)), int(rng.integers(1, 60))
+    x = rng.standard_normal((B, 3, H, Wd)).astype(np.float32)
+    fl = rng.normal(0, 4, (B, 2, H, Wd)).astype(np.float32)
+    fl[rng.random(fl.shape) < 0.15] = np.round(fl[rng.random(fl.shape) < 0.15][:0].sum() + 1.0)
+    for mode in ("bilinear", "nearest"):
+        ro, rm = W.warp(x, fl, mode=mode)
+        go, gm = imgflowarp.warp(t(x), t(fl), mode=mode)
+        if np.abs(go.cpu().numpy() - ro).max() > 1e-5 or (gm.cpu().numpy() != rm).any(): msg.append(f"warp {mode}")
+    m1, m2 = (rng.random((B, 1, H, Wd)) < 0.7).astype(np.float32), (rng.random((B, 1, H, Wd)) < 0.7).astype(np.float32)
+    f12 = np.concatenate([rng.normal(0, 3, (B, 2, H, Wd)), np.ones((B, 1, H, Wd))], 1).astype(np.float32) * m1
+    f21 = np.concatenate([rng.normal(0, 3, (B, 2, H, Wd)), np.ones((B, 1, H, Wd))], 1).astype(np.float32) * m2
+    if H > 1 and Wd > 1:
+        r1, r2 = W.get_occlusion_mask(m1, m2, f12, f21)
+        g1, g2 = imgflowarp.get_occlusion_mask(t(m1), t(m2), t(f12), t(f21))
+        if (g1.cpu().numpy() != r1).any() or (g2.cpu().numpy() != r2).any(): msg.append("occlusion mask")
+    if msg:
+        bad2 += 1
+        print(f"seed {seed} B={B} is={is_} V={V} F0={F0} aa={aa} fb={fb} HxW={H}x{Wd}: " + "; ".join(msg))
+print(f"sweep 2: {n_cases} cases, {bad2} with mismatches, {time.time() - t0:.0f} s")
