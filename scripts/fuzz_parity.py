@@ -152,3 +152,34 @@ for case in range(n_cases):
         bad2 += 1
         print(f"seed {seed} B={B} is={is_} V={V} F0={F0} aa={aa} fb={fb} HxW={H}x{Wd}: " + "; ".join(msg))
 print(f"sweep 2: {n_cases} cases, {bad2} with mismatches, {time.time() - t0:.0f} s")
+
+# ---- third sweep: MANO LBS kernels vs the PyTorch restatement (pose magnitudes from ~0 to several radians)
+from handobjectconsist_amd.models import synthnet
+layer = synthnet.SynthManoLayer(ncomps=15, use_pca=True, center_idx=9).to(dev)
+bad3 = 0
+for case in range(min(n_cases, 300)):
+    seed = seed0 + 200000 + case
+    g = torch.Generator().manual_seed(seed)
+    B = int(torch.randint(1, 70, (1,), generator=g))
+    scale = float(10 ** torch.empty(1).uniform_(-6, 0.7, generator=g))
+    pose = (scale * torch.randn(B, 18, generator=g)).to(dev)
+    beta = (3 * torch.randn(B, 10, generator=g)).to(dev)
+    p1, b1 = pose.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    p2, b2 = pose.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    v1, j1 = layer(p1, b1)
+    v2, j2 = layer.forward_torch(p2, b2)
+    wv, wj = torch.randn(v2.shape, generator=g).to(dev), torch.randn(j2.shape, generator=g).to(dev)
+    ((v1 * wv).sum() + (j1 * wj).sum()).backward()
+    ((v2 * wv).sum() + (j2 * wj).sum()).backward()
+    sc = float(v2.detach().abs().max())
+    msg = []
+    dv, dj = float((v1 - v2).detach().abs().max()), float((j1 - j2).detach().abs().max())
+    if dv > 2e-5 * sc: msg.append(f"verts err {dv:.2e}")
+    if dj > 2e-5 * sc: msg.append(f"joints err {dj:.2e}")
+    for a, b_, name in ((p1.grad, p2.grad, "grad pose"), (b1.grad, b2.grad, "grad betas")):
+        e, s_ = float((a - b_).abs().max()), float(b_.abs().max()) + 1e-12
+        if not torch.isfinite(a).all() or e > 3e-4 * s_: msg.append(f"{name} err {e:.2e} (scale {s_:.2e})")
+    if msg:
+        bad3 += 1
+        print(f"seed {seed} B={B} pose scale {scale:.1e}: " + "; ".join(msg))
+print(f"sweep 3 (MANO): {min(n_cases, 300)} cases, {bad3} with mismatches")
