@@ -59,6 +59,27 @@ for case in range(n_cases):
         sc = np.abs(want[np.isfinite(want)]).max() if np.isfinite(want).any() else 1.0
         e = np.abs(np.nan_to_num(gotn - want)).max()
         if e > 2e-4 * sc + 1e-6: msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
+    if case % 3 == 0:  # the upstream-compatible five-entry-point path and the reference-algorithm kernels
+        f3, x3 = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
+        rgb3, alpha3, depth3, fim3, finv3, wmap3 = rasterize.RasterizeFunction.apply(f3, x3, is_, near, far, eps, (0.1, 0.2, 0.3), True, True, True)
+        if (fim3.cpu().numpy() != saved["face_index_map"]).any(): msg.append("compat fim")
+        if np.abs(rgb3.detach().cpu().numpy() - saved["rgb_map"]).max() > 1e-5: msg.append("compat rgb")
+        torch.autograd.backward([rgb3, alpha3, depth3], [t(a) for a in g])
+        for got, want, name in ((x3.grad, gt_ref, "compat grad_textures"), (f3.grad, gf_ref, "compat grad_faces")):
+            sc = np.abs(want[np.isfinite(want)]).max() if np.isfinite(want).any() else 1.0
+            e = np.abs(np.nan_to_num(got.cpu().numpy().astype(np.float64) - want)).max()
+            if e > 2e-4 * sc + 1e-6: msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
+        rasterize.REFERENCE_ALGO = True
+        try:
+            f4, x4 = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
+            o4 = rasterize.rasterize_rgbad(f4, x4, is_, False, near, far, eps, (0.1, 0.2, 0.3))
+            if (o4["face_index_map"].cpu().numpy() != ref["face_index_map"]).any(): msg.append("reference-algo fim")
+            torch.autograd.backward([o4["rgb"], o4["alpha"], o4["depth"]], [t(a) for a in img])
+            sc = np.abs(gf_ref[np.isfinite(gf_ref)]).max() if np.isfinite(gf_ref).any() else 1.0
+            e = np.abs(np.nan_to_num(f4.grad.cpu().numpy().astype(np.float64) - gf_ref)).max()
+            if e > 2e-4 * sc + 1e-6: msg.append(f"reference-algo grad_faces err {e:.2e} (scale {sc:.2e})")
+        finally:
+            rasterize.REFERENCE_ALGO = False
     # warp half: random flows incl. out-of-range and exactly integer ones
     H, Wd = int(rng.integers(2, 70)), int(rng.integers(2, 90))
     fl = [rng.normal(0, 3, (B, H, Wd, 2)).astype(np.float32) for _ in range(2)]
