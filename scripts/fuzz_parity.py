@@ -14,6 +14,7 @@ t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 n_cases, seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 0
 KW = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32), dist_coeffs=np.zeros((1, 5), np.float32))
 bad = 0
+COVER = {}
 t0 = time.time()
 for case in range(n_cases):
     seed = seed0 + case
@@ -36,13 +37,20 @@ for case in range(n_cases):
             faces[:, 1::5, 1, :2] = faces[:, 1::5, 0, :2]             # repeated vertex
             faces[:, 2::7, :, 0] = faces[:, 2::7, :1, 0]              # vertical line
             faces = np.round(faces * 8) / 8 if rng.random() < 0.5 else faces  # vertices on pixel-centre lattices
+        if rng.random() < 0.15:
+            faces[..., :2] *= (5.0, 50.0, 1e4)[int(rng.integers(0, 3))]   # far off-screen vertices, huge bboxes
         faces = np.ascontiguousarray(np.concatenate([faces, faces[:, :, ::-1]], 1))
-        tex = rng.uniform(-1, 1, (B, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
-    near, far, eps = 0.1, 100.0, 1e-3
+        ts = (2, 2, 2, 3, 4)[int(rng.integers(0, 5))]
+        tex = rng.uniform(-1, 1, (B, faces.shape[1], ts, ts, ts, 3)).astype(np.float32)
+    if rng.random() < 0.1 and kind != "scene":
+        is_ = int(rng.integers(250, 330))
+    near, far = (0.1, 100.0) if rng.random() < 0.6 else (float(rng.uniform(0.05, 1.0)), float(rng.uniform(1.2, 3.5)))
+    eps = (1e-3, 1e-3, 1e-4, 1e-2)[int(rng.integers(0, 4))]
     ref = R.rasterize_rgbad(faces, tex, is_, False, near, far, eps, (0.1, 0.2, 0.3), num_threads=8, keep_saved=True)
     f_t, x_t = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
     out = rasterize.rasterize_rgbad(f_t, x_t, is_, False, near, far, eps, (0.1, 0.2, 0.3))
     msg = []
+    COVER.setdefault(kind, []).append(float((ref["face_index_map"] >= 0).mean()))
     nf = int((out["face_index_map"].cpu().numpy() != ref["face_index_map"]).sum())
     if nf: msg.append(f"face_index_map differs at {nf} px")
     for k, tol in (("rgb", 1e-5), ("depth", 1e-6), ("alpha", 0)):
@@ -97,7 +105,8 @@ for case in range(n_cases):
     if msg:
         bad += 1
         print(f"seed {seed} {kind} B={B} is={is_} F={faces.shape[1]}: " + "; ".join(msg))
-print(f"{n_cases} cases, {bad} with mismatches, {time.time() - t0:.0f} s")
+print(f"{n_cases} cases, {bad} with mismatches, {time.time() - t0:.0f} s; mean covered fraction by kind:",
+      {k: round(float(np.mean(v)), 3) for k, v in COVER.items()})
 
 # ---- second sweep: vertex-colour path (indexed meshes, shared vertices, degenerate triangles), compat API,
 # ---- reference-algorithm flag, anti-aliasing, warp / occlusion kernels
@@ -204,3 +213,40 @@ for case in range(min(n_cases, 300)):
         bad3 += 1
         print(f"seed {seed} B={B} pose scale {scale:.1e}: " + "; ".join(msg))
 print(f"sweep 3 (MANO): {min(n_cases, 300)} cases, {bad3} with mismatches")
+
+# ---- fourth sweep: get_opticalflow, fully fused path vs the op-by-op structure of the reference (both on the GPU)
+from handobjectconsist_amd.warping import opticalflow
+bad4 = 0
+for case in range(min(n_cases, 200)):
+    seed = seed0 + 300000 + case
+    rng = np.random.default_rng(seed)
+    B, is_ = int(rng.integers(1, 4)), int(rng.integers(24, 200))
+    H, Wd = int(rng.integers(8, is_ + 1)), int(rng.integers(8, is_ + 1))
+    s = synth.random_scene(B, seed=seed, image_size=is_)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=dev)[None], t=torch.zeros(1, 3, device=dev), K=torch.ones(1, 3, 3, device=dev),
+                   orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1, no_light=True)
+    res = {}
+    for fused in (True, False):
+        opticalflow.USE_VERTEX_COLOR_RENDER = opticalflow.USE_FUSED_EPILOGUE = opticalflow.USE_FUSED_VERTEX_STAGE = fused
+        v1 = t(s["verts1"]).requires_grad_(True)
+        flows = opticalflow.get_opticalflow([v1, t(s["verts2"])], t(s["faces"]), [t(s["K1"]), t(s["K2"])], ren, orig_img_size=(Wd, H),
+                                            detach_textures=False, detach_renders=True, ignore_face_idxs=synth.HAND_IGNORE_FACES)
+        w = [torch.from_numpy(np.random.default_rng(seed).standard_normal(f.shape).astype(np.float32)).to(dev) for f in flows]
+        (flows[0] * w[0]).sum().backward(retain_graph=True)
+        res[fused] = ([f.detach().cpu().numpy() for f in flows], v1.grad.cpu().numpy())
+    opticalflow.USE_VERTEX_COLOR_RENDER = opticalflow.USE_FUSED_EPILOGUE = opticalflow.USE_FUSED_VERTEX_STAGE = True
+    msg = []
+    for i in (0, 1):
+        a, b_ = res[True][0][i], res[False][0][i]
+        sup = int(((a != 0) != (b_ != 0)).sum())
+        if sup > 6: msg.append(f"flow{i} support differs at {sup} px")
+        same = (a != 0) == (b_ != 0)
+        e = np.abs(np.where(same, a - b_, 0)).max()
+        if e > 1e-3: msg.append(f"flow{i} err {e:.2e}")
+    ga, gb = res[True][1], res[False][1]
+    e, sc = np.abs(ga - gb).max(), np.abs(gb).max() + 1e-12
+    if e > 2e-2 * sc: msg.append(f"vertex grad err {e:.2e} (scale {sc:.2e})")   # (a flipped pixel moves the gradient of its face)
+    if msg:
+        bad4 += 1
+        print(f"seed {seed} B={B} is={is_} crop {H}x{Wd}: " + "; ".join(msg))
+print(f"sweep 4 (get_opticalflow fused vs op-by-op): {min(n_cases, 200)} cases, {bad4} with mismatches")
