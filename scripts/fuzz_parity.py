@@ -98,10 +98,19 @@ for case in range(n_cases):
     jm = [np.ones((B, 3, H, Wd), np.float32) for _ in range(2)]
     for m in jm:
         m[:, :, : int(rng.integers(0, 3))] = 0
-    ref_loss = W.pair_consist(fl, im[0], im[1], jm[0], jm[1], True)[0]
-    loss = imgflowarp.pair_consist([t(fl[0]), t(fl[1])], t(im[0]), t(im[1]), t(jm[0]), t(jm[1]), PyramidCriterion("l1"), use_backward=True, outputs="loss")[0]
-    e = np.abs(loss.cpu().numpy() - ref_loss).max()
+    ub = bool(rng.random() < 0.7)
+    ref_loss = W.pair_consist(fl, im[0], im[1], jm[0], jm[1], ub)[0]
+    fl_t = [t(fl[0]).requires_grad_(True), t(fl[1]).requires_grad_(True)]
+    loss = imgflowarp.pair_consist(fl_t, t(im[0]), t(im[1]), t(jm[0]), t(jm[1]), PyramidCriterion("l1"), use_backward=ub, outputs="loss")[0]
+    e = np.abs(loss.detach().cpu().numpy() - ref_loss).max()
     if e > 1e-5 * max(1.0, np.abs(ref_loss).max()): msg.append(f"pair loss err {e:.2e}")
+    gl = rng.standard_normal(B).astype(np.float32)
+    ref_gf = W.pair_consist_grad(fl, im[0], im[1], jm[0], jm[1], gl, ub)
+    (loss * t(gl)).sum().backward()
+    for i in (0, 1):
+        got = fl_t[i].grad.cpu().numpy() if fl_t[i].grad is not None else np.zeros_like(ref_gf[i])
+        e, sc = np.abs(got - ref_gf[i]).max(), np.abs(ref_gf[i]).max() + 1e-12
+        if e > 1e-4 * sc + 1e-9: msg.append(f"grad_flow{i} err {e:.2e} (scale {sc:.2e})")
     if msg:
         bad += 1
         print(f"seed {seed} {kind} B={B} is={is_} F={faces.shape[1]}: " + "; ".join(msg))
