@@ -188,8 +188,11 @@ class SynthManoLayer(nn.Module):
     def hip_constants(self):
         """Model constants in the layout of mr_mano_forward, built once per device."""
         dev = self.th_v_template.device
+        sources = (self.th_v_template, self.th_shapedirs, self.th_posedirs, self.th_J_regressor, self.th_weights,
+                   self.th_comps, self.th_hands_mean)
+        key = (dev, self.ncomps, self.center_idx) + tuple((b.data_ptr(), b._version) for b in sources)
         cached = getattr(self, "_hip_consts", None)
-        if cached is not None and cached["device"] == dev:
+        if cached is not None and cached["key"] == key:  # rebuilt if the buffers move or are overwritten
             return cached
         with torch.no_grad():
             blend = torch.zeros((146, 2334), dtype=torch.float32, device=dev)
@@ -202,7 +205,7 @@ class SynthManoLayer(nn.Module):
             tensors = [self.th_comps[: self.ncomps].contiguous(), self.th_hands_mean.reshape(45).contiguous(), js, jt,
                        blend, self.th_v_template.reshape(2334).contiguous(), self.th_weights.contiguous(),
                        i32(MANO_PARENTS), i32(MANO_TIPS), i32(MANO_REORDER)]
-        self._hip_consts = {"device": dev, "tensors": tensors, "ncomps": self.ncomps, "center": center}
+        self._hip_consts = {"key": key, "tensors": tensors, "ncomps": self.ncomps, "center": center}
         return self._hip_consts
 
     def _hip_path(self, th_pose_coeffs, th_betas, th_trans):
