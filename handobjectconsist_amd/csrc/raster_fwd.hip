@@ -20,7 +20,8 @@
 //                          full for the 5x5..16x16-pixel triangles of these meshes:
 //                            S1 lane per face: load the 9 floats, invert the pixel-space
 //                               matrix, park the face in an LDS face cache;
-//                            S2 8 faces x 8 tile rows per pass, one lane per (face, row): the
+//                            S2 one lane per (face, bbox row) item -- the items of the batch are
+//                               compacted with a prefix sum, 64 per pass --: the
 //                               pixels a face covers on a row form ONE span (each edge test is
 //                               monotone in x, also in floating point), found by three
 //                               interleaved bisections with the exact predicate; the span's
@@ -47,7 +48,6 @@ namespace mr {
 constexpr int TILE_W = 32, TILE_H = 8;  // tile size in pixels (one pixel per thread)
 constexpr int TPB = 256;              // threads per workgroup (4 waves)
 constexpr int NB = 32;                // faces per batch (stage S1: one lane per face)
-constexpr int FPP = MR_WAVE / TILE_H; // faces per S2 pass: one lane per (face, tile row)
 constexpr int FC_STRIDE = 21;         // dwords per face-cache slot (odd: conflict-free ds_read_b32)
 constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 4 * 64, power of 2)
 constexpr int SCAN_UNROLL = 3;        // independent record loads in flight per lane
@@ -260,6 +260,7 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
     __shared__ float fcache[TPB / MR_WAVE][NB * FC_STRIDE];
     __shared__ unsigned short fragq[TPB / MR_WAVE][FQCAP];  // slot << 8 | row << 5 | x
     __shared__ float xp_tab[TILE_W], yp_tab[TILE_H];
+    __shared__ int rowoff[TPB / MR_WAVE][NB + 1];  // prefix sums of the batch's per-face row counts
 
     const unsigned nblocks = gridDim.x;
     const unsigned lid = xcd_remap(blockIdx.x, nblocks);
@@ -321,6 +322,7 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
     int* q = queue[wave];
     float* fc = fcache[wave];
     unsigned short* fq = fragq[wave];
+    int* ro = rowoff[wave];
     int qhead = 0, qn = 0;  // wave-uniform ring state
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -348,6 +350,7 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
 
     auto process_batch = [&](int count) {
         // S1: one lane per face
+        int nrows = 0;  // rows of the face's bbox inside this tile
         if (lane < count && !(p.dbg & 4)) {
             const int ri = q[(qhead + lane) & (QCAP - 1)];
             const FaceRec r = recs_b[ri];
@@ -365,24 +368,43 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
             const int y0 = max((int)(r.y & 0xffffu), ty0) - ty0, y1 = min((int)(r.y >> 16), ty1) - ty0;
             c[18] = __int_as_float(fn);
             c[19] = __int_as_float(x0 | (x1 << 8) | (y0 << 16) | (y1 << 24));
+            nrows = y1 - y0 + 1;
         }
+        // (face, bbox row) items of the batch, compacted: exclusive prefix sum of the row counts -> the
+        // S2 lanes take consecutive items, so a pass works on 64 real rows whatever the face sizes
+        // (8 lanes per face would leave most of them idle for the 3 - 4-row faces of these meshes)
+        int incl = nrows;
+#pragma unroll
+        for (int off = 1; off < NB; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane < NB) ro[lane + 1] = incl;
+        if (lane == 0) ro[0] = 0;
+        const int n_items = __shfl(incl, NB - 1);
         __builtin_amdgcn_wave_barrier();
         if (p.dbg & (4 | 8)) return;
-        // S2: FPP faces per pass, one lane per (face, tile row).  Along a row each edge test
+        // S2: one lane per (face, bbox row) item, 64 items per pass.  Along a row each edge test
         //   reject_k(x) = ey_k < (xp[x] - a_k) * dy_k
         // is monotone in x even in floating point (xp[x] increases with x; IEEE subtraction and
         // multiplication by a constant are monotone), so the pixels a face covers on a row form ONE
         // span: three 6-step binary searches with the exact predicate find it -- the same pixels
         // the per-pixel loop would accept, without visiting the others.
-        for (int f0 = 0; f0 < count; f0 += FPP) {
-            const int slot = f0 + lane / TILE_H, row = lane % TILE_H;
-            bool act = slot < count;
+        for (int i0 = 0; i0 < n_items; i0 += MR_WAVE) {
+            const int item = i0 + lane;
+            bool act = item < n_items;
+            // slot = the face whose row range holds this item: largest k with ro[k] <= item (5 halvings of [0, NB))
+            int slot = 0;
+#pragma unroll
+            for (int step = NB / 2; step >= 1; step >>= 1)
+                slot += (ro[min(slot + step, NB)] <= item && slot + step < NB) ? step : 0;
+            int row = 0;
             float ea[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, ey[3] = {0, 0, 0};
             int lx0 = 0, lx1 = -1;
             if (act) {
                 const float* c = fc + slot * FC_STRIDE;
                 const int bb = __float_as_int(c[19]);
-                act = row >= ((bb >> 16) & 0xff) && row <= ((bb >> 24) & 0xff);
+                row = ((bb >> 16) & 0xff) + (item - ro[slot]);
                 const float ax = c[0], ay = c[1], bx = c[3], by = c[4], cx_ = c[6], cy_ = c[7];
                 lx0 = bb & 0xff; lx1 = (bb >> 8) & 0xff;
                 const float yp = yp_tab[row];
