@@ -59,8 +59,17 @@ __device__ __forceinline__ void load_face(const float* __restrict__ g, Face& f, 
 
 // Conservative pixel bounding box: every pixel the coverage test can accept is inside.
 // Back-facing faces and faces with a NaN coordinate can never win a pixel -> empty.
-// Degenerate (zero pixel-space determinant) or infinite faces get the whole screen so
-// that the exact per-pixel test decides, as in the brute-force upstream loop.
+// Degenerate or infinite faces get the whole screen so that the exact per-pixel test decides, as in
+// the brute-force upstream loop: for collinear vertices all three edge functions are the same line
+// function, and the pixels lying exactly on that line are accepted along its WHOLE length, also beyond
+// the vertices.  "Degenerate" cannot mean a zero pixel-space determinant only: with large coordinates
+// that determinant of a mathematically collinear triple rounds to a small non-zero value (found by
+// scripts/fuzz_parity.py).  The filter uses the two products of the back-face test instead (vertex
+// DIFFERENCES first, so a collinear triple gives equal products up to a few ulp): a pixel beyond the
+// apex of a sliver passes both long-edge tests only if it is within eps * r of both lines at distance r,
+// i.e. only for apex angles of ~1e-7 rad.  Faces whose smallest angle (area / product of the two longest
+// edges) is below 16 eps ~ 1e-6 rad are flagged: an order of magnitude of margin, and nothing but
+// numerically collinear faces (none of the 28416 front faces of the bench scene).
 __device__ __forceinline__ FaceBox face_box(const float* f, int is) {
     FaceBox b;
     b.x0 = 1; b.x1 = 0; b.y0 = 1; b.y1 = 0;
@@ -76,7 +85,14 @@ __device__ __forceinline__ FaceBox face_box(const float* f, int is) {
         py[n] = 0.5f * (f[3 * n + 1] * fis + fis - 1.0f);
     }
     const float den = (px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]));
-    bool full = !(den != 0.0f) || !(fabsf(den) <= 3.0e38f);
+    // twice the signed area from the back-face products (front-facing: !(pa < pb)) against the product of the
+    // two longest edges (max-norm): their ratio is the smallest angle of the triangle
+    const float pa = (f[7] - f[1]) * (f[3] - f[0]), pb = (f[4] - f[1]) * (f[6] - f[0]);
+    const float e01 = fmaxf(fabsf(f[3] - f[0]), fabsf(f[4] - f[1])), e12 = fmaxf(fabsf(f[6] - f[3]), fabsf(f[7] - f[4])),
+                e20 = fmaxf(fabsf(f[0] - f[6]), fabsf(f[1] - f[7]));
+    const float emin = fminf(e01, fminf(e12, e20));
+    const float two_longest = emin > 0.0f ? (e01 * e12 * e20) / emin : fmaxf(e01, fmaxf(e12, e20)) * fmaxf(e01, fmaxf(e12, e20));
+    bool full = !(den != 0.0f) || !(fabsf(den) <= 3.0e38f) || !(pa - pb > 16.0f * 5.9604645e-8f * two_longest);
 #pragma unroll
     for (int n = 0; n < 3; n++) full |= !(fabsf(px[n]) <= 3.0e38f) || !(fabsf(py[n]) <= 3.0e38f);
     if (full) {

@@ -20,7 +20,7 @@ for case in range(n_cases):
     seed = seed0 + case
     rng = np.random.default_rng(seed)
     B, is_ = int(rng.integers(1, 4)), int(rng.integers(9, 161))
-    kind = ("scene", "big", "tiny", "degenerate")[int(rng.integers(0, 4))]
+    kind = ("scene", "big", "tiny", "degenerate", "collinear")[int(rng.integers(0, 5))]
     if kind == "scene":
         s = synth.random_scene(B, seed=seed, image_size=is_)
         cols = rng.uniform(-2, 2, (B, s["verts1"].shape[1], 3)).astype(np.float32)
@@ -32,6 +32,13 @@ for case in range(n_cases):
         if kind == "tiny":
             faces[..., :2] = faces[:, :, :1, :2] + rng.uniform(-0.03, 0.03, (B, n, 3, 2)).astype(np.float32)
         faces[..., 2] = rng.uniform(0.05, 3.0, (B, n, 3))
+        if kind == "collinear":  # vertices p + k * d with exactly representable steps, optionally nudged by one ulp
+            p0 = np.round(rng.uniform(-1, 1, (B, n, 1, 2)) * 64) / 64
+            d = np.round(rng.uniform(-1, 1, (B, n, 1, 2)) * 32) / 32 * 2.0 ** rng.integers(-3, 6, (B, n, 1, 1))
+            k = rng.integers(-3, 4, (B, n, 3, 1)).astype(np.float32)
+            faces[..., :2] = (p0 + k * d).astype(np.float32)
+            nudge = rng.random((B, n, 3, 2)) < 0.15
+            faces[..., :2] = np.where(nudge, np.nextafter(faces[..., :2], np.float32(np.inf)), faces[..., :2])
         if kind == "degenerate":
             faces[:, ::3, 2] = faces[:, ::3, 0]                       # zero area
             faces[:, 1::5, 1, :2] = faces[:, 1::5, 0, :2]             # repeated vertex

@@ -180,14 +180,24 @@ def test_edge_cases(cuda):
     # (the point face -- three vertices on one pixel-centre-lattice point -- passes every edge test of
     # upstream's inside test at every pixel and has a NaN depth: it must never win; found by scripts/fuzz_parity.py)
     point = np.array([[-0.5, -0.5, 1.75], [-0.5, -0.5, 1.625], [-0.5, -0.5, 1.75]], np.float32)
+    # collinear vertices far off screen: the pixel-space determinant rounds to a non-zero value, yet upstream's
+    # edge tests accept the pixels exactly on the line, also BEYOND the vertices (bbox filter in face_box)
+    line = np.array([[-18.75, 31.25, 2.75], [0.0, 0.0, 0.5], [-37.5, 62.5, 1.625]], np.float32)
     faces = np.stack([tri, tri, tri * [1, 1, 0.05], tri * [1, 1, 500.0], tri[[0, 0, 1]], tri * np.nan,
-                      tri[::-1], point, point[::-1]])[None]
+                      tri[::-1], point, point[::-1], line, line[::-1]])[None]
     tex = np.random.default_rng(0).uniform(0, 1, (1, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
     ref = R.rasterize_rgbad(faces, tex, is_, False, 0.1, 100, 1e-3, (0, 0, 0))
     out = rasterize.rasterize_rgbad(t(faces, cuda), t(tex, cuda), is_, False, 0.1, 100, 1e-3, (0, 0, 0))
     fim = out["face_index_map"].cpu().numpy()
     assert (fim != ref["face_index_map"]).sum() == 0
     assert set(np.unique(fim)) == {-1, 0}
+    # the line face at the resolution where its line passes through pixel centres (also beyond its vertices)
+    lf = np.stack([line, line[::-1]])[None]
+    ltex = tex[:, :2]
+    ref = R.rasterize_rgbad(lf, ltex, 274, False, 0.1, 100, 1e-3, (0, 0, 0))
+    out = rasterize.rasterize_rgbad(t(lf, cuda), t(ltex, cuda), 274, False, 0.1, 100, 1e-3, (0, 0, 0))
+    assert (ref["face_index_map"] >= 0).sum() >= 20 and (ref["face_index_map"][0, :130] >= 0).any()
+    assert (out["face_index_map"].cpu().numpy() != ref["face_index_map"]).sum() == 0
     assert_close(out["rgb"].cpu().numpy(), ref["rgb"], 1e-6, 1e-6, "rgb")
     # empty batch / zero faces
     e = rasterize.rasterize_rgbad(torch.zeros((1, 0, 3, 3), device=cuda), torch.zeros((1, 0, 2, 2, 2, 3), device=cuda),
