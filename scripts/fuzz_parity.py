@@ -10,7 +10,7 @@ from handobjectconsist_amd.utils import synth
 from oracle import raster_ref as R, warp_ref as W
 
 dev = torch.device("cuda:0")
-t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+t = lambda a: torch.from_numpy(np.array(a, copy=True, order="C")).to(dev)
 n_cases, seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 0
 KW = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32), dist_coeffs=np.zeros((1, 5), np.float32))
 bad = 0
@@ -46,13 +46,19 @@ for case in range(n_cases):
             faces = np.round(faces * 8) / 8 if rng.random() < 0.5 else faces  # vertices on pixel-centre lattices
         if rng.random() < 0.15:
             faces[..., :2] *= (5.0, 50.0, 1e4)[int(rng.integers(0, 3))]   # far off-screen vertices, huge bboxes
+        if rng.random() < 0.2:  # vertices at / behind / absurdly far from the camera plane
+            special = np.array([0.0, -1.0, 1e-20, 1e20, np.inf, -0.0, 0.1, 100.0], np.float32)
+            hit = rng.random(faces.shape[:3]) < 0.15
+            faces[..., 2] = np.where(hit, special[rng.integers(0, len(special), faces.shape[:3])], faces[..., 2])
         faces = np.ascontiguousarray(np.concatenate([faces, faces[:, :, ::-1]], 1))
         ts = (2, 2, 2, 3, 4)[int(rng.integers(0, 5))]
         tex = rng.uniform(-1, 1, (B, faces.shape[1], ts, ts, ts, 3)).astype(np.float32)
     if rng.random() < 0.1 and kind != "scene":
         is_ = int(rng.integers(250, 330))
+    elif rng.random() < 0.08:
+        is_ = int(rng.integers(1, 9))
     near, far = (0.1, 100.0) if rng.random() < 0.6 else (float(rng.uniform(0.05, 1.0)), float(rng.uniform(1.2, 3.5)))
-    eps = (1e-3, 1e-3, 1e-4, 1e-2)[int(rng.integers(0, 4))]
+    eps = (1e-3, 1e-3, 1e-4, 1e-2, 1e-6, 0.3)[int(rng.integers(0, 6))]
     ref = R.rasterize_rgbad(faces, tex, is_, False, near, far, eps, (0.1, 0.2, 0.3), num_threads=8, keep_saved=True)
     f_t, x_t = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
     out = rasterize.rasterize_rgbad(f_t, x_t, is_, False, near, far, eps, (0.1, 0.2, 0.3))
@@ -74,6 +80,20 @@ for case in range(n_cases):
         sc = np.abs(want[np.isfinite(want)]).max() if np.isfinite(want).any() else 1.0
         e = np.abs(np.nan_to_num(gotn - want)).max()
         if e > 2e-4 * sc + 1e-6: msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
+    if case % 4 == 1:  # silhouette / depth entry points (module-default eps) and the anti-aliased render
+        aa = bool(rng.random() < 0.5)
+        sil = rasterize.rasterize_silhouettes(t(faces), is_, aa).cpu().numpy()
+        dep = rasterize.rasterize_depth(t(faces), is_, aa).cpu().numpy()
+        r2 = R.rasterize_rgbad(faces, None, is_, aa, 0.1, 100, 1e-4, None, False, True, True, num_threads=8)
+        if np.abs(sil - r2["alpha"]).max() > 1e-6: msg.append("silhouette mode")
+        dd = np.abs(dep - r2["depth"]); dd = dd[np.isfinite(dd)]
+        if dd.size and dd.max() > 1e-5 * max(1.0, float(np.abs(r2["depth"][np.isfinite(r2["depth"])]).max())): msg.append(f"depth mode err {dd.max():.2e}")
+        if ts == 2 or kind == "scene":
+            o5 = rasterize.rasterize_rgbad(t(faces), t(tex), is_, True, near, far, eps, (0.1, 0.2, 0.3))
+            r5 = R.rasterize_rgbad(faces, tex, is_, True, near, far, eps, (0.1, 0.2, 0.3), num_threads=8)
+            if (o5["face_index_map"].cpu().numpy() != r5["face_index_map"]).any(): msg.append("aa fim")
+            e5 = np.abs(o5["rgb"].cpu().numpy() - r5["rgb"]); e5 = e5[np.isfinite(e5)]
+            if e5.size and e5.max() > 1e-5 * max(1.0, float(np.abs(r5["rgb"][np.isfinite(r5["rgb"])]).max())): msg.append(f"aa rgb err {e5.max():.2e}")
     if case % 3 == 0:  # the upstream-compatible five-entry-point path and the reference-algorithm kernels
         f3, x3 = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
         rgb3, alpha3, depth3, fim3, finv3, wmap3 = rasterize.RasterizeFunction.apply(f3, x3, is_, near, far, eps, (0.1, 0.2, 0.3), True, True, True)
