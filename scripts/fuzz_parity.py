@@ -205,8 +205,16 @@ for case in range(n_cases):
     fl[rng.random(fl.shape) < 0.15] = np.round(fl[rng.random(fl.shape) < 0.15][:0].sum() + 1.0)
     for mode in ("bilinear", "nearest"):
         ro, rm = W.warp(x, fl, mode=mode)
-        go, gm = imgflowarp.warp(t(x), t(fl), mode=mode)
-        if np.abs(go.cpu().numpy() - ro).max() > 1e-5 or (gm.cpu().numpy() != rm).any(): msg.append(f"warp {mode}")
+        xt, ft = t(x).requires_grad_(True), t(fl).requires_grad_(True)
+        go, gm = imgflowarp.warp(xt, ft, mode=mode)
+        if np.abs(go.detach().cpu().numpy() - ro).max() > 1e-5 or (gm.cpu().numpy() != rm).any(): msg.append(f"warp {mode}")
+        if mode == "bilinear":
+            gout = rng.standard_normal(x.shape).astype(np.float32)
+            rgf, rgx = W.warp_backward(x, fl, gout)
+            go.backward(t(gout))
+            for got, want, name in ((ft.grad, rgf, "warp grad_flow"), (xt.grad, rgx, "warp grad_x")):
+                e, sc = np.abs(got.cpu().numpy() - want).max(), np.abs(want).max() + 1e-12
+                if e > 1e-4 * sc + 1e-6: msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
     m1, m2 = (rng.random((B, 1, H, Wd)) < 0.7).astype(np.float32), (rng.random((B, 1, H, Wd)) < 0.7).astype(np.float32)
     f12 = np.concatenate([rng.normal(0, 3, (B, 2, H, Wd)), np.ones((B, 1, H, Wd))], 1).astype(np.float32) * m1
     f21 = np.concatenate([rng.normal(0, 3, (B, 2, H, Wd)), np.ones((B, 1, H, Wd))], 1).astype(np.float32) * m2
