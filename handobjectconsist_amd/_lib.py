@@ -37,6 +37,8 @@ SIGNATURES = {
     "mr_mano_workspace_floats": (_L, [_I]),
     "mr_mano_forward": (_I, [_P] * 12 + [_I, _I] + [_P] * 3 + [_I, _P]),
     "mr_mano_backward": (_I, [_P] * 10 + [_I, _I] + [_P] * 5 + [_I, _P]),
+    "mr_meshreg_post_forward": (_I, [_P] * 6 + [_F] * 5 + [_P] * 5 + [_I, _I, _I, _I, _P]),
+    "mr_meshreg_post_backward": (_I, [_P] * 6 + [_F] * 5 + [_P] * 10 + [_I, _I, _I, _I, _P]),
     "mr_warp_forward": (_I, [_P] * 4 + [_I, _I, _I, _I, _F, _I, _P]),
     "mr_warp_backward": (_I, [_P] * 5 + [_I, _I, _I, _I, _F, _I, _P]),
     "mr_occlusion_mask": (_I, [_P] * 4 + [_L, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),

@@ -186,6 +186,62 @@ __device__ __forceinline__ void tex_tap(const float* tif, int pn, int ts, float&
     isc = ti[0] * ts * ts + ti[1] * ts + ti[2];
 }
 
+// axis-angle -> rotation through the normalised quaternion, the operation order of batch_rodrigues
+__device__ __forceinline__ void rodrigues(const float* r, float* R, float* q_out) {
+    const float a0 = r[0] + 1e-8f, a1 = r[1] + 1e-8f, a2 = r[2] + 1e-8f;
+    const float angle = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    const float half = angle * 0.5f;
+    const float c = cosf(half), s = sinf(half);
+    float q[4] = {c, s * (r[0] / angle), s * (r[1] / angle), s * (r[2] / angle)};
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = q[k] / n;
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+    const float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+    R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz;     R[2] = 2 * wy + 2 * xz;
+    R[3] = 2 * wz + 2 * xy;     R[4] = w2 - x2 + y2 - z2; R[5] = 2 * yz - 2 * wx;
+    R[6] = 2 * xz - 2 * wy;     R[7] = 2 * wx + 2 * yz;     R[8] = w2 - x2 - y2 + z2;
+    if (q_out) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) q_out[k] = q[k];
+    }
+}
+
+// adjoint of rodrigues: gR[9] -> gr[3]
+__device__ __forceinline__ void rodrigues_bwd(const float* r, const float* gR, float* gr) {
+    // recompute the forward intermediates
+    const float a0 = r[0] + 1e-8f, a1 = r[1] + 1e-8f, a2 = r[2] + 1e-8f;
+    const float angle = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    const float half = angle * 0.5f;
+    const float c = cosf(half), s = sinf(half);
+    const float ax[3] = {r[0] / angle, r[1] / angle, r[2] / angle};
+    const float p[4] = {c, s * ax[0], s * ax[1], s * ax[2]};  // un-normalised quaternion
+    const float n = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
+    const float q[4] = {p[0] / n, p[1] / n, p[2] / n, p[3] / n};
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    // R(q) -> gq
+    float gq[4];
+    gq[0] = 2 * (w * (gR[0] + gR[4] + gR[8]) + x * (gR[7] - gR[5]) + y * (gR[2] - gR[6]) + z * (gR[3] - gR[1]));
+    gq[1] = 2 * (x * (gR[0] - gR[4] - gR[8]) + y * (gR[1] + gR[3]) + z * (gR[2] + gR[6]) + w * (gR[7] - gR[5]));
+    gq[2] = 2 * (y * (gR[4] - gR[0] - gR[8]) + x * (gR[1] + gR[3]) + z * (gR[5] + gR[7]) + w * (gR[2] - gR[6]));
+    gq[3] = 2 * (z * (gR[8] - gR[0] - gR[4]) + x * (gR[2] + gR[6]) + y * (gR[5] + gR[7]) + w * (gR[3] - gR[1]));
+    // q = p / |p|
+    const float dot = gq[0] * q[0] + gq[1] * q[1] + gq[2] * q[2] + gq[3] * q[3];
+    float gp[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) gp[k] = (gq[k] - q[k] * dot) / n;
+    // p = (cos h, sin h * axis), h = angle / 2, axis = r / angle, angle = |r + 1e-8|
+    const float g_half = -s * gp[0] + c * (gp[1] * ax[0] + gp[2] * ax[1] + gp[3] * ax[2]);
+    const float g_ax[3] = {s * gp[1], s * gp[2], s * gp[3]};
+    float g_angle = 0.5f * g_half;
+#pragma unroll
+    for (int k = 0; k < 3; k++) g_angle -= g_ax[k] * r[k] / (angle * angle);
+    const float a[3] = {a0, a1, a2};
+#pragma unroll
+    for (int k = 0; k < 3; k++) gr[k] = g_ax[k] / angle + g_angle * a[k] / angle;
+}
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a
 // contiguous range of logical ids so the tiles / faces of one image share one L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {

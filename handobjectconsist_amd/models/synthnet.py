@@ -285,6 +285,42 @@ def recover_3d_proj(objpoints3d, camintr, est_scale, est_trans, off_z=0.4, input
     return est_c3d + objpoints3d, est_c3d
 
 
+# recover_3d_proj x2, unit conversion, object rotation and both projections through ONE HIP kernel each way
+# (mr_meshreg_post_forward / _backward) instead of ~280 small PyTorch launches per step.  False: op by op.
+USE_HIP_POST = True
+
+
+class _MeshRegPostFunction(torch.autograd.Function):
+    """(verts_mm, joints_mm, scaletrans, st_obj; camintr, objcanverts) -> (recov_handverts3d, recov_joints3d,
+    joints2d, recov_objverts3d, obj_verts2d)."""
+
+    @staticmethod
+    def forward(ctx, verts_mm, joints_mm, scaletrans, st_obj, camintr, canverts, trans_factor, scale_factor, input_res):
+        ctx.set_materialize_grads(False)
+        c = [_lib.contig(x.detach()) for x in (verts_mm, joints_mm, scaletrans, st_obj, camintr, canverts)]
+        B, Vh, J, Vo = c[0].shape[0], c[0].shape[1], c[1].shape[1], c[5].shape[1]
+        dev = c[0].device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        outs = [new(B, Vh, 3), new(B, J, 3), new(B, J, 2), new(B, Vo, 3), new(B, Vo, 2)]
+        ctx.consts = (float(trans_factor), float(scale_factor), 0.4, float(input_res[0]), float(input_res[1]))
+        _lib.call("mr_meshreg_post_forward", *[_lib.ptr(x) for x in c], *ctx.consts, *[_lib.ptr(o) for o in outs],
+                  B, Vh, J, Vo, _lib.stream_ptr(dev))
+        ctx.save_for_backward(*c)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        c = ctx.saved_tensors
+        B, Vh, J, Vo = c[0].shape[0], c[0].shape[1], c[1].shape[1], c[5].shape[1]
+        dev = c[0].device
+        g = [_lib.contig(x) if x is not None else None for x in grads]
+        work = torch.empty((B * 15,), dtype=torch.float32, device=dev)
+        outs = [torch.empty_like(c[0]), torch.empty_like(c[1]), torch.empty_like(c[2]), torch.empty_like(c[3])]
+        _lib.call("mr_meshreg_post_backward", *[_lib.ptr(x) for x in c], *ctx.consts, *[_lib.ptr(x) for x in g],
+                  _lib.ptr(work), *[_lib.ptr(o) for o in outs], B, Vh, J, Vo, _lib.stream_ptr(dev))
+        return outs[0], outs[1], outs[2], outs[3], None, None, None, None, None
+
+
 class SynthMeshRegNet(nn.Module):
     """MeshRegNet (meshregnet.py:54-384) with the trainmeshwarp.py default loss weights.
 
@@ -343,6 +379,10 @@ class SynthMeshRegNet(nn.Module):
         a step (``prepare_frames``)."""
         # hand: MANO branch (manobranch.py:88-155) + camera recovery (meshregnet.py:206-245)
         verts, joints = self.mano_layer(pose, th_betas=shape)
+        if (USE_HIP_POST and verts.is_cuda and verts.dtype == torch.float32 and camintr.shape[0] == verts.shape[0]
+                and objcanverts.shape[0] == verts.shape[0]):
+            return _MeshRegPostFunction.apply(verts, joints, scaletrans, st_obj, camintr, objcanverts,
+                                              self.obj_trans_factor, self.obj_scale_factor, input_res)
         verts3d, joints3d = verts / 1000, joints / 1000
         trans, scale = scaletrans[:, 1:], scaletrans[:, :1]
         final_trans = trans.unsqueeze(1) * self.obj_trans_factor

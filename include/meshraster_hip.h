@@ -230,6 +230,37 @@ MR_API int mr_mano_backward(const float* comps, const float* hands_mean, const f
                             float* grad_pose_coeffs, float* grad_betas, int batch_size,
                             mr_stream_t stream);
 
+/* The parameter-free geometry between MeshRegNet's regression heads and the render path
+ * (recover_3d_proj, project.py:5-24; meshregnet.py:206-245, 274-323; objbranch.py:28-84; libyana
+ * batch_proj2d), one launch:
+ *   c_h = centre(K, scaletrans)          handverts3d = verts_mm / 1000 + c_h
+ *                                        joints3d    = c_h + joints_mm / 1000,  joints2d = proj(K, joints3d)
+ *   c_o = centre(K, st_obj[:3]), R = rodrigues(st_obj[3:6])
+ *                                        objverts3d  = c_o + R canverts,        objverts2d = proj(K, objverts3d)
+ * with centre(K, (s, tx, ty)): Z0 = K00 * s * scale_factor + off_z,
+ *   XY0 = ((tx, ty) * trans_factor + (res_w, res_h) / 2 - (K02, K12)) * Z0 / K00.
+ * verts_mm[B,Vh,3], joints_mm[B,J,3], scaletrans[B,3], st_obj[B,6], K[B,3,3], canverts[B,Vo,3]. */
+MR_API int mr_meshreg_post_forward(const float* verts_mm, const float* joints_mm,
+                                   const float* scaletrans, const float* st_obj, const float* K,
+                                   const float* canverts, float trans_factor, float scale_factor,
+                                   float off_z, float res_w, float res_h, float* handverts3d,
+                                   float* joints3d, float* joints2d, float* objverts3d,
+                                   float* objverts2d, int batch_size, int num_hand_verts,
+                                   int num_joints, int num_obj_verts, mr_stream_t stream);
+/* Adjoint w.r.t. verts_mm, joints_mm, scaletrans, st_obj (any output gradient may be NULL);
+ * workspace: 15 * batch_size floats. */
+MR_API int mr_meshreg_post_backward(const float* verts_mm, const float* joints_mm,
+                                    const float* scaletrans, const float* st_obj, const float* K,
+                                    const float* canverts, float trans_factor, float scale_factor,
+                                    float off_z, float res_w, float res_h,
+                                    const float* grad_handverts3d, const float* grad_joints3d,
+                                    const float* grad_joints2d, const float* grad_objverts3d,
+                                    const float* grad_objverts2d, float* workspace,
+                                    float* grad_verts_mm, float* grad_joints_mm,
+                                    float* grad_scaletrans, float* grad_st_obj, int batch_size,
+                                    int num_hand_verts, int num_joints, int num_obj_verts,
+                                    mr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * 3. Warping (meshreg/warping/imgflowarp.py)
  * ---------------------------------------------------------------------------------- */

@@ -395,3 +395,40 @@ def test_mano_constants_follow_the_buffers(cuda):
     v_ref = layer.forward_torch(pose, beta)[0]
     assert float((v1 - v0).abs().max()) > 1e-3
     close(v1.cpu().numpy(), v_ref.cpu().numpy(), 1e-5, 1e-5 * float(v_ref.abs().max()), "verts after load_state_dict")
+
+
+@pytest.mark.parametrize("B,Vo", [(3, 1002), (64, 257)])
+def test_meshreg_post_hip_matches_torch_ops(cuda, B, Vo, monkeypatch):
+    """mr_meshreg_post_forward / _backward == recover_3d_proj x2 + unit conversion + object rotation + both
+    projections in PyTorch, values and gradients (any subset of the outputs used)."""
+    from handobjectconsist_amd.models import synthnet
+
+    model = synthnet.SynthMeshRegNet().to(cuda).eval()
+    g = torch.Generator().manual_seed(B)
+    mk = lambda *shape, s=1.0: (s * torch.randn(*shape, generator=g)).to(cuda)
+    pose, shape = mk(B, 18, s=0.3), mk(B, 10)
+    st, so = mk(B, 3), mk(B, 6)
+    so[0, 3:] = 0  # zero rotation: the 1e-8 guard
+    K = torch.tensor([[350.0, 0.0, 120.0], [0.0, 350.0, 131.0], [0.0, 0.0, 1.0]]).repeat(B, 1, 1).to(cuda)
+    K[:, 0, 0] += mk(B, s=20.0); K[:, 1, 1] = K[:, 0, 0]
+    can = mk(B, Vo, 3, s=0.05)
+    outs = {}
+    for hip in (True, False):
+        monkeypatch.setattr(synthnet, "USE_HIP_POST", hip)
+        leaves = [t_.clone().requires_grad_(True) for t_ in (pose, shape, st, so)]
+        o = model.post_heads(*leaves, K, can, input_res=(256, 240))
+        outs[hip] = (o, leaves)
+    gg = torch.Generator().manual_seed(1)
+    ws = [torch.randn(x.shape, generator=gg).to(cuda) for x in outs[False][0]]
+    for a, b_, name in zip(outs[True][0], outs[False][0], ("handverts3d", "joints3d", "joints2d", "objverts3d", "objverts2d")):
+        close(a.detach().cpu().numpy(), b_.detach().cpu().numpy(), 1e-5, 1e-5 * float(b_.detach().abs().max()), name)
+    for subset in ((0, 1, 2, 3, 4), (0,), (2, 4), (3,)):
+        for hip in (True, False):
+            o, leaves = outs[hip]
+            for l in leaves:
+                l.grad = None
+            sum((o[k] * ws[k]).sum() for k in subset).backward(retain_graph=True)
+        for a, b_, name in zip(outs[True][1], outs[False][1], ("pose", "shape", "scaletrans", "st_obj")):
+            ga = a.grad if a.grad is not None else torch.zeros_like(a)
+            gb = b_.grad if b_.grad is not None else torch.zeros_like(b_)
+            close(ga.cpu().numpy(), gb.cpu().numpy(), 2e-4, 2e-5 * float(gb.abs().max()) + 1e-12, f"grad {name} {subset}")
