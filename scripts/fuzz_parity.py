@@ -301,3 +301,39 @@ for case in range(min(n_cases, 200)):
         bad4 += 1
         print(f"seed {seed} B={B} is={is_} crop {H}x{Wd}: " + "; ".join(msg))
 print(f"sweep 4 (get_opticalflow fused vs op-by-op): {min(n_cases, 200)} cases, {bad4} with mismatches")
+
+# ---- fifth sweep: head post-processing kernels vs the op-by-op PyTorch code
+model5 = synthnet.SynthMeshRegNet().to(dev).eval()
+bad5 = 0
+for case in range(min(n_cases, 300)):
+    seed = seed0 + 400000 + case
+    g = torch.Generator().manual_seed(seed)
+    B, Vo = int(torch.randint(1, 40, (1,), generator=g)), int(torch.randint(1, 1500, (1,), generator=g))
+    mk = lambda *shape, s=1.0: (s * torch.randn(*shape, generator=g)).to(dev)
+    rs = float(10 ** torch.empty(1).uniform_(-5, 0.8, generator=g))
+    pose, shape, st, so = mk(B, 18, s=0.3), mk(B, 10), mk(B, 3), mk(B, 6)
+    so[:, 3:] *= rs
+    K = torch.tensor([[350.0, 0.0, 120.0], [0.0, 350.0, 131.0], [0.0, 0.0, 1.0]]).repeat(B, 1, 1).to(dev)
+    K[:, 0, 0] += mk(B, s=40.0); K[:, 1, 1] = K[:, 0, 0]; K[:, :2, 2] += mk(B, 2, s=10.0)
+    can = mk(B, Vo, 3, s=0.05)
+    res_wh = (int(torch.randint(32, 640, (1,), generator=g)), int(torch.randint(32, 640, (1,), generator=g)))
+    outs = {}
+    for hip in (True, False):
+        synthnet.USE_HIP_POST = hip
+        leaves = [x.clone().requires_grad_(True) for x in (pose, shape, st, so)]
+        o = model5.post_heads(*leaves, K, can, input_res=res_wh)
+        ws = [torch.randn(x.shape, generator=torch.Generator().manual_seed(seed)).to(dev) for x in o]
+        sum((a * w).sum() for a, w in zip(o, ws)).backward()
+        outs[hip] = ([a.detach() for a in o], [l.grad for l in leaves])
+    synthnet.USE_HIP_POST = True
+    msg = []
+    for a, b_, name in zip(outs[True][0], outs[False][0], ("handverts3d", "joints3d", "joints2d", "objverts3d", "objverts2d")):
+        e, sc = float((a - b_).abs().max()), float(b_.abs().max()) + 1e-12
+        if e > 2e-5 * sc: msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
+    for a, b_, name in zip(outs[True][1], outs[False][1], ("pose", "shape", "scaletrans", "st_obj")):
+        e, sc = float((a - b_).abs().max()), float(b_.abs().max()) + 1e-12
+        if not torch.isfinite(a).all() or e > 5e-4 * sc: msg.append(f"grad {name} err {e:.2e} (scale {sc:.2e})")
+    if msg:
+        bad5 += 1
+        print(f"seed {seed} B={B} Vo={Vo} rot scale {rs:.1e}: " + "; ".join(msg))
+print(f"sweep 5 (head post-processing): {min(n_cases, 300)} cases, {bad5} with mismatches")
