@@ -11,15 +11,18 @@ from handobjectconsist_amd.utils import synth
 
 
 # BATCH_POST: the regression heads and the parameter-free code behind them (MANO LBS, camera recovery,
-# projections: ~100 small launches per frame in forward, ~150 in backward) run ONCE over the frames of a
-# step instead of once per frame (WarpRegNet.prepare).  Per-sample operations only: same values.
-# BATCH_ENCODER: also ONE encoder pass over all frames (same features when the BatchNorm statistics are
-# frozen).  Measured on MI355X (scripts/cpu_floor.py): the launch-bound floor of a step drops from 27 ms
-# to 17 ms, but at the headline size (B=64, 256x256) the step is GPU-bound and MIOpen's fp32 Winograd
-# kernels are ~1.3x slower per image at B=192 than at B=64 (52.7 ms -> 57.9 ms per step) -- so this one
-# is OFF by default and meant for small batches (HOC_BATCH_ENCODER=1).
+# projections) run ONCE over the frames of a step instead of once per frame (WarpRegNet.prepare).
+# Per-sample operations only: same values.
+# BATCH_ENCODER: also ONE encoder pass over all frames of the step (SURVEY Q16 / 8f "f2": legal because the
+# BatchNorm statistics are frozen -- every layer then acts per image; WarpRegNet.prepare falls back to one
+# pass per frame for a model in training mode).  Measured on MI355X at B=64, 256x256: ResNet-18 forward +
+# backward over 3 x 64 images 41.8 ms, over 1 x 192 images 40.2 ms, and 124 gradient-accumulation launches
+# fewer; whole step 43.45 -> 42.0 ms.  (An earlier measurement had shown the opposite -- 52.7 -> 57.9 ms --
+# while the step still contained hidden host->device synchronisations; scripts/cpu_floor.py: the launch-bound
+# floor of a step drops from 27 ms to 17 ms.)  HOC_BATCH_ENCODER=0 / HOC_BATCH_POST=0 select the reference's
+# per-frame structure.
 BATCH_POST = os.environ.get("HOC_BATCH_POST", "1") != "0"
-BATCH_ENCODER = os.environ.get("HOC_BATCH_ENCODER", "0") == "1"
+BATCH_ENCODER = os.environ.get("HOC_BATCH_ENCODER", "1") != "0"
 
 
 def train_step(batches, premodel, optimizer):

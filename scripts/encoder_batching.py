@@ -13,7 +13,10 @@ def three():
     loss.backward()
 def one():
     net(xc).sum().backward()
-for name, fn in (("3 x B=64", three), ("1 x B=192", one), ("3 x B=64", three), ("1 x B=192", one)):
+x128 = torch.cat(x[1:])
+def two():
+    (net(x[0]).sum() + net(x128).sum()).backward()
+for name, fn in (("3 x B=64", three), ("64 + 128", two), ("1 x B=192", one), ("3 x B=64", three), ("64 + 128", two), ("1 x B=192", one)):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

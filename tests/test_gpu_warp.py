@@ -235,7 +235,7 @@ def test_train_step_batched_frames_match_per_frame(cuda, batch_post, batch_encod
         try:
             loss, logs = E.train_step(loader.step_batches(0), pre, opt)
         finally:
-            E.BATCH_POST, E.BATCH_ENCODER = True, False
+            E.BATCH_POST, E.BATCH_ENCODER = True, True
         assert all("_features" not in s and "_post" not in s for b in loader.step_batches(0) for s in b["data"])
         assert "warp_consist" in logs and float(logs["warp_consist"].detach()) > 0
         res[batched] = {k: float(v.detach().flatten()[0]) for k, v in logs.items()}
