@@ -40,7 +40,8 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--batch", type=int, default=64, help="per-GPU batch size (frames / frame pairs)")
-    p.add_argument("--image-size", type=int, default=256)
+    p.add_argument("--image-size", type=int, default=256, help="frame width (= side of the square raster)")
+    p.add_argument("--image-height", type=int, default=None, help="frame height if not square (BASELINE config 3: 480 x 270)")
     p.add_argument("--encoder-dtype", choices=("f32", "bf16"), default="f32",
                    help="f32 = the reference's precision (headline); bf16 = BASELINE config 5: trunk under bf16 "
                         "autocast, heads / MANO / render / warp stay fp32 -- reported with dtype 'bf16+f32'")
@@ -283,7 +284,9 @@ def main():
         # 8 MB buckets overlap the RCCL all-reduce with the encoder backward; frozen BN statistics
         # -> no buffer broadcast (the three forwards of a step share the buffers)
         net = DDP(model, device_ids=[local_rank], bucket_cap_mb=8, broadcast_buffers=False)
-    premodel = WarpRegNet((is_, is_), net, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
+    ih_ = args.image_height or is_
+    assert ih_ <= is_, "--image-height must not exceed --image-size (the raster is the square of the longer side)"
+    premodel = WarpRegNet((is_, ih_), net, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
                           progressive_steps=1000, use_backward=True, mano_faces=model.mano_layer.th_faces,
                           pair_outputs="loss").to(dev)
     premodel.step_count = 1000  # past the lambda ramp: the consistency term carries its full weight
@@ -291,7 +294,7 @@ def main():
     # same update (A/B on one MI355X: 46.05 -> 45.10 ms per step); HOC_FUSED_ADAM=0 selects the foreach default
     params = [p for p in model.parameters() if p.requires_grad]
     optimizer = torch.optim.Adam(params, lr=5e-5, fused=os.environ.get("HOC_FUSED_ADAM", "1") == "1")
-    loader = SyntheticConsistLoader(B, is_, seed=rank, device=dev, pool=2)
+    loader = SyntheticConsistLoader(B, is_, seed=rank, device=dev, pool=2, image_height=ih_)
 
     def barrier():
         if dist is not None:
@@ -327,7 +330,7 @@ def main():
                         for s_ in consist["data"]]
 
         def hot():
-            l, _ = warpbranch.forward(consist["data"], fake_results, premodel.th_faces, premodel.renderer, (is_, is_),
+            l, _ = warpbranch.forward(consist["data"], fake_results, premodel.th_faces, premodel.renderer, (is_, ih_),
                                       premodel.criterion, gt_refs=True, hand_ignore_faces=premodel.hand_ignore_faces,
                                       use_backward=True, pair_outputs="loss")
             l.backward()
@@ -358,7 +361,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
             "data": "synthetic",
-            "config": {"workload": f"trainmeshwarp.py consist step, per-GPU B={B}, {is_}x{is_}, hand 778v/1552f + "
+            "config": {"workload": f"trainmeshwarp.py consist step, per-GPU B={B}, {is_}x{ih_}, hand 778v/1552f + "
                                    f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {'fp32' if args.encoder_dtype == 'f32' else 'bf16-autocast'} stock PyTorch, Adam",
                        "global_batch": B * world, "image_size": is_, "parallelism": f"dp{world}"},
             "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),

@@ -68,14 +68,16 @@ class SyntheticConsistLoader:
     fully supervised) and one "consist" batch (a frame pair: unannotated frame first, annotated
     reference second -- warpbranch compares everything to samples[0], GT replaces samples[1:])."""
 
-    def __init__(self, batch_size, image_size=256, steps=1, seed=0, device="cuda", pool=2):
+    def __init__(self, batch_size, image_size=256, steps=1, seed=0, device="cuda", pool=2, image_height=None):
         self.steps, self.device = steps, torch.device(device)
         self.batches = []
         t = lambda a: torch.from_numpy(a).to(self.device)
         ov, _ = synth.object_template()
         for k in range(pool):
             s = synth.random_scene(batch_size, seed=seed * 1000 + k, image_size=image_size)
-            im_ref, im, jm_ref, jm = synth.random_images(batch_size, image_size, image_size, seed * 1000 + k)
+            # non-square frames (image_height < image_size): the scene is laid out for the square raster of the
+            # longer side, the images are its top rows (SURVEY Q12: the render is cropped to the top-left H x W)
+            im_ref, im, jm_ref, jm = synth.random_images(batch_size, image_height or image_size, image_size, seed * 1000 + k)
             canverts = t(ov[None].repeat(batch_size, 0).copy())
 
             def sample(img, jmask, hand, obj, K, supervised):
