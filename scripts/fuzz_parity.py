@@ -89,10 +89,23 @@ for case in range(n_cases):
         dd = np.abs(dep - r2["depth"]); dd = dd[np.isfinite(dd)]
         if dd.size and dd.max() > 1e-5 * max(1.0, float(np.abs(r2["depth"][np.isfinite(r2["depth"])]).max())): msg.append(f"depth mode err {dd.max():.2e}")
         if ts == 2 or kind == "scene":
-            o5 = rasterize.rasterize_rgbad(t(faces), t(tex), is_, True, near, far, eps, (0.1, 0.2, 0.3))
-            r5 = R.rasterize_rgbad(faces, tex, is_, True, near, far, eps, (0.1, 0.2, 0.3), num_threads=8)
+            f5, x5 = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
+            o5 = rasterize.rasterize_rgbad(f5, x5, is_, True, near, far, eps, (0.1, 0.2, 0.3))
+            r5 = R.rasterize_rgbad(faces, tex, is_, True, near, far, eps, (0.1, 0.2, 0.3), num_threads=8, keep_saved=True)
+            # backward through the 2 x 2 average pooling: image gradients spread over the 2x raster, / 4
+            gi = [rng.standard_normal((B, 3, is_, is_)).astype(np.float32), rng.standard_normal((B, is_, is_)).astype(np.float32),
+                  rng.standard_normal((B, is_, is_)).astype(np.float32)]
+            torch.autograd.backward([o5["rgb"], o5["alpha"], o5["depth"]], [t(a) for a in gi])
+            up = lambda a: np.repeat(np.repeat(a, 2, -1), 2, -2) / np.float32(4)
+            g2 = [np.ascontiguousarray(up(gi[0])[:, :, ::-1].transpose(0, 2, 3, 1)), np.ascontiguousarray(up(gi[1])[:, ::-1]),
+                  np.ascontiguousarray(up(gi[2])[:, ::-1])]
+            gf5, gt5 = R.rasterize_backward(r5["_saved"], *g2, num_threads=8)
+            for got, want, name in ((x5.grad, gt5, "aa grad_textures"), (f5.grad, gf5, "aa grad_faces")):
+                sc = np.abs(want[np.isfinite(want)]).max() if np.isfinite(want).any() else 1.0
+                e = np.abs(np.nan_to_num(got.cpu().numpy().astype(np.float64) - want)).max()
+                if e > 2e-4 * sc + 1e-6: msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
             if (o5["face_index_map"].cpu().numpy() != r5["face_index_map"]).any(): msg.append("aa fim")
-            e5 = np.abs(o5["rgb"].cpu().numpy() - r5["rgb"]); e5 = e5[np.isfinite(e5)]
+            e5 = np.abs(o5["rgb"].detach().cpu().numpy() - r5["rgb"]); e5 = e5[np.isfinite(e5)]
             if e5.size and e5.max() > 1e-5 * max(1.0, float(np.abs(r5["rgb"][np.isfinite(r5["rgb"])]).max())): msg.append(f"aa rgb err {e5.max():.2e}")
     if case % 3 == 0:  # the upstream-compatible five-entry-point path and the reference-algorithm kernels
         f3, x3 = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
