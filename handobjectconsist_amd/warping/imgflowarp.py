@@ -103,8 +103,15 @@ class _PairConsistFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, flow12, flow21, image_ref, image, jitter_ref, jitter, thresh, want_debug):
         _lib.check_cuda(flow12, flow21, image_ref, image, jitter_ref, jitter)
-        f12, f21 = _lib.contig(flow12), _lib.contig(flow21)
         im_ref, im = _lib.contig(image_ref), _lib.contig(image)
+        ctx.stacked = flow21 is None  # flow12 = [2B,H,W,2]: both flows in one tensor (get_opticalflow's fused path)
+        if ctx.stacked:
+            both = _lib.contig(flow12)
+            if both.shape[0] != 2 * im.shape[0]:
+                raise ValueError("stacked flows must be [2B, H, W, 2]")
+            f12, f21 = both[: im.shape[0]], both[im.shape[0]:]
+        else:
+            f12, f21 = _lib.contig(flow12), _lib.contig(flow21)
         jm_ref, jm = _lib.contig(jitter_ref), _lib.contig(jitter)
         B, C, H, W = im.shape
         if C != 3 or im_ref.shape != im.shape:
@@ -150,12 +157,31 @@ class _PairConsistFunction(torch.autograd.Function):
             g_fwd = torch.zeros((B,), dtype=torch.float32, device=dev)
         g_fwd = _lib.contig(g_fwd)
         g_bwd = _lib.contig(g_bwd) if g_bwd is not None else None
-        grad12 = torch.empty_like(f12)
-        grad21 = torch.empty_like(f21)
+        if ctx.stacked:  # one gradient tensor for the stacked flows: no slice / cat nodes in autograd
+            grad_both = torch.empty((2 * B, H, W, 2), dtype=torch.float32, device=dev)
+            grad12, grad21 = grad_both[:B], grad_both[B:]
+        else:
+            grad12 = torch.empty_like(f12)
+            grad21 = torch.empty_like(f21)
         _lib.call("mr_pair_consist_backward", _lib.ptr(f12), _lib.ptr(f21), _lib.ptr(im_ref), _lib.ptr(im),
                   _lib.ptr(jm_ref), _lib.ptr(jm), int(jm.shape[1]), _lib.ptr(sums), _lib.ptr(g_fwd),
                   _lib.ptr(g_bwd), _lib.ptr(grad12), _lib.ptr(grad21), B, H, W, ctx.thresh, _lib.stream_ptr(dev))
+        if ctx.stacked:
+            return grad_both, None, None, None, None, None, None, None
         return grad12, grad21, None, None, None, None, None, None
+
+
+def _stacked_base(flow12, flow21):
+    """The [2B,H,W,2] tensor the two flows are the halves of, if they are (get_opticalflow's fused path returns
+    them that way): the pair function then differentiates that tensor directly and autograd needs neither
+    slice nor cat nodes (each would copy a [2B]-sized gradient)."""
+    base = getattr(flow12, "_base", None)
+    if (base is None or base is not getattr(flow21, "_base", None) or not base.is_contiguous() or base.dim() != 4
+            or flow12.shape != flow21.shape or base.shape[0] != 2 * flow12.shape[0] or base.shape[1:] != flow12.shape[1:]
+            or not flow12.is_contiguous() or not flow21.is_contiguous() or flow12.data_ptr() != base.data_ptr()
+            or flow21.data_ptr() != base.data_ptr() + flow12.numel() * flow12.element_size()):
+        return None
+    return base
 
 
 def _is_fused_l1(criterion):
@@ -204,8 +230,10 @@ def pair_consist(
     # (the fused kernels fetch the two taps of a row with one 8-byte load: images at least 2 wide)
     if _is_fused_l1(criterion) and image.shape[1] == 3 and jitter_mask.shape[1] in (1, 3) and image.shape[-1] >= 2:
         want_debug = outputs == "full"
-        res = _PairConsistFunction.apply(recons_flow[0], recons_flow[1], image_ref, image, jitter_mask_ref,
-                                         jitter_mask, 0.99999, want_debug)
+        stacked = _stacked_base(recons_flow[0], recons_flow[1])
+        res = _PairConsistFunction.apply(stacked if stacked is not None else recons_flow[0],
+                                         None if stacked is not None else recons_flow[1], image_ref, image,
+                                         jitter_mask_ref, jitter_mask, 0.99999, want_debug)
         losses_fwd, losses_bwd = res[0], res[1]
         warp_loss = losses_bwd + losses_fwd if use_backward else losses_fwd
         if not want_debug:

@@ -76,8 +76,9 @@ USE_FUSED_VERTEX_STAGE = True
 
 
 class _FlowVertexStage(torch.autograd.Function):
-    """(verts1, verts2, K1, K2; R, t, dist, orig_size) -> (ndc1, ndc2, cols12, cols21); differentiable
-    w.r.t. the vertices through the two displacement textures only (detach_renders=True)."""
+    """(verts1, verts2, K1, K2; R, t, dist, orig_size) -> (ndc[2B,V,3], cols[2B,V,3]): frame 1 then frame 2
+    of every pair, stacked so that both renders of a pair can go out as ONE launch over 2B meshes;
+    differentiable w.r.t. the vertices through the two displacement textures only (detach_renders=True)."""
 
     @staticmethod
     def forward(ctx, verts1, verts2, K1, K2, R, t, dist, orig_size):
@@ -92,26 +93,27 @@ class _FlowVertexStage(torch.autograd.Function):
         if v2.shape != v1.shape or k1.shape != (B, 3, 3) or k2.shape != (B, 3, 3) or nb not in (1, B) \
                 or tc.shape[0] != nb or dc.shape[0] != nb:
             raise ValueError("expected vertices [B,V,3], intrinsics [B,3,3] and R / t / dist_coeffs with batch 1 or B")
-        outs = [torch.empty_like(v1) for _ in range(4)]
+        ndc = torch.empty((2 * B, V, 3), dtype=torch.float32, device=v1.device)
+        cols = torch.empty_like(ndc)
         _lib.call("mr_flow_vertices_forward", _lib.ptr(v1), _lib.ptr(v2), _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(Rc),
-                  _lib.ptr(tc), _lib.ptr(dc), int(nb == B and B > 1), float(orig_size), *[_lib.ptr(o) for o in outs],
-                  B, V, _lib.stream_ptr(v1.device))
+                  _lib.ptr(tc), _lib.ptr(dc), int(nb == B and B > 1), float(orig_size), _lib.ptr(ndc[:B]),
+                  _lib.ptr(ndc[B:]), _lib.ptr(cols[:B]), _lib.ptr(cols[B:]), B, V, _lib.stream_ptr(v1.device))
         ctx.save_for_backward(v1, v2, k1, k2)
-        ctx.mark_non_differentiable(outs[0], outs[1])
-        return tuple(outs)
+        ctx.mark_non_differentiable(ndc)
+        return ndc, cols
 
     @staticmethod
-    def backward(ctx, _g1, _g2, g12, g21):
+    def backward(ctx, _g_ndc, g_cols):
         v1, v2, k1, k2 = ctx.saved_tensors
         B, V = v1.shape[:2]
         want1, want2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if g_cols is None or not (want1 or want2):
+            return (None,) * 8
         gv1 = torch.empty_like(v1) if want1 else None
         gv2 = torch.empty_like(v2) if want2 else None
-        if want1 or want2:
-            g12c = _lib.contig(g12) if g12 is not None else None
-            g21c = _lib.contig(g21) if g21 is not None else None
-            _lib.call("mr_flow_vertices_backward", _lib.ptr(v1), _lib.ptr(v2), _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(g12c),
-                      _lib.ptr(g21c), _lib.ptr(gv1), _lib.ptr(gv2), B, V, _lib.stream_ptr(v1.device))
+        g = _lib.contig(g_cols)
+        _lib.call("mr_flow_vertices_backward", _lib.ptr(v1), _lib.ptr(v2), _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(g[:B]),
+                  _lib.ptr(g[B:]), _lib.ptr(gv1), _lib.ptr(gv2), B, V, _lib.stream_ptr(v1.device))
         return gv1, gv2, None, None, None, None, None, None
 
 
@@ -203,6 +205,71 @@ def _fused_epilogue(ro1, ro2, orig_img_size, ignore_face_idxs):
     return [flow12, flow21]
 
 
+class _FlowFinalizeStacked(torch.autograd.Function):
+    """``_FlowFinalize`` of both directions of a pair on the stacked render: rgb[2B,3,is,is] ->
+    flow[2B,H,W,2] (first half flow12, second half flow21), one gradient tensor back."""
+
+    @staticmethod
+    def forward(ctx, rgb, mask_pre, mask_x1, mask_x2, occl, height, width):
+        rgb_c = _lib.contig(rgb)
+        B2, _, is_, _ = rgb_c.shape
+        B = B2 // 2
+        flow = torch.empty((B2, height, width, 2), dtype=torch.float32, device=rgb_c.device)
+        for lo, mask_x in ((0, mask_x1), (B, mask_x2)):
+            _lib.call("mr_flow_finalize_forward", _lib.ptr(rgb_c[lo:lo + B]), _lib.ptr(mask_pre[lo:lo + B]),
+                      _lib.ptr(mask_x), _lib.ptr(occl[lo:lo + B]), _lib.ptr(flow[lo:lo + B]), B, is_, height, width,
+                      _lib.stream_ptr(rgb_c.device))
+        ctx.save_for_backward(mask_pre, mask_x1, mask_x2, occl)
+        ctx.dims = (B, is_, height, width)
+        return flow
+
+    @staticmethod
+    def backward(ctx, grad_flow):
+        mask_pre, mask_x1, mask_x2, occl = ctx.saved_tensors
+        B, is_, height, width = ctx.dims
+        if grad_flow is None:
+            return (None,) * 7
+        g = _lib.contig(grad_flow)
+        grad_rgb = torch.empty((2 * B, 3, is_, is_), dtype=torch.float32, device=g.device)
+        for lo, mask_x in ((0, mask_x1), (B, mask_x2)):
+            _lib.call("mr_flow_finalize_backward", _lib.ptr(g[lo:lo + B]), _lib.ptr(mask_pre[lo:lo + B]), _lib.ptr(mask_x),
+                      _lib.ptr(occl[lo:lo + B]), _lib.ptr(grad_rgb[lo:lo + B]), B, is_, height, width,
+                      _lib.stream_ptr(g.device))
+        return grad_rgb, None, None, None, None, None, None
+
+
+def _fused_epilogue_stacked(ro, orig_img_size, ignore_face_idxs):
+    """``_fused_epilogue`` on ONE render of the 2B stacked meshes (frame 1 of every pair, then frame 2)."""
+    with torch.no_grad():
+        m, alpha = _flow_mask(ro, ignore_face_idxs)
+        rgb = _lib.contig(ro["rgb"].detach())
+        B2, _, is_, _ = rgb.shape
+        B = B2 // 2
+        occl = torch.empty((B2, is_, is_), dtype=torch.float32, device=rgb.device)
+        _lib.call("mr_occlusion_mask", _lib.ptr(m[:B]), _lib.ptr(alpha[B:]), _lib.ptr(rgb[:B]), _lib.ptr(rgb[B:]),
+                  3 * is_ * is_, _lib.ptr(m[:B]), _lib.ptr(m[B:]), _lib.ptr(occl[:B]), _lib.ptr(occl[B:]), B, is_, is_,
+                  0.03, 0.99999, _lib.stream_ptr(rgb.device))
+    W, H = (orig_img_size[0], orig_img_size[1]) if orig_img_size is not None else (is_, is_)
+    W, H = min(int(W), is_), min(int(H), is_)
+    flows = _FlowFinalizeStacked.apply(ro["rgb"], m, m[:B], alpha[B:], occl, H, W)
+    # two views of one tensor: imgflowarp.pair_consist recognises them and differentiates the stack
+    return [flows[:B], flows[B:]]
+
+
+_FACES2_CACHE = {}
+
+
+def _stacked_faces(faces):
+    """int32 ``cat([faces, faces])`` for the 2B stacked render, cached on the tensor's identity/version."""
+    key = (faces.data_ptr(), faces._version, tuple(faces.shape), faces.dtype, str(faces.device))
+    hit = _FACES2_CACHE.get("f")
+    if hit is None or hit[0] != key:
+        f32 = faces.detach().to(torch.int32)
+        hit = (key, torch.cat([f32, f32], 0).contiguous(), faces)  # keeps `faces` alive: data_ptr stays unique
+        _FACES2_CACHE["f"] = hit
+    return hit[1]
+
+
 _LUT_CACHE = {}
 
 
@@ -228,12 +295,17 @@ def get_opticalflow(
             and hasattr(neurenderer, "render_projected_vertex_colors") and verts_cam[0].is_cuda
             and verts_cam[0].dtype == torch.float32 and verts_cam[1].shape == verts_cam[0].shape):
         dev = verts_cam[0].device
-        ndc1, ndc2, cols12, cols21 = _FlowVertexStage.apply(
+        ndc, cols = _FlowVertexStage.apply(
             verts_cam[0], verts_cam[1], camintrs[0].to(dev), camintrs[1].to(dev), neurenderer.R.to(dev),
             neurenderer.t.to(dev), neurenderer.dist_coeffs.to(dev), neurenderer.orig_size)
-        ro1 = neurenderer.render_projected_vertex_colors(ndc1, faces, cols12.detach() if detach_textures else cols12)
-        ro2 = neurenderer.render_projected_vertex_colors(ndc2, faces, cols21)
-        return _fused_epilogue(ro1, ro2, orig_img_size, ignore_face_idxs)
+        B = verts_cam[0].shape[0]
+        if detach_textures:  # only the first texture set is detached (opticalflow.py:100-102 vs :123)
+            ro1 = neurenderer.render_projected_vertex_colors(ndc[:B], faces, cols[:B].detach())
+            ro2 = neurenderer.render_projected_vertex_colors(ndc[B:], faces, cols[B:])
+            return _fused_epilogue(ro1, ro2, orig_img_size, ignore_face_idxs)
+        # both renders of the pair as one launch over 2B meshes
+        ro = neurenderer.render_projected_vertex_colors(ndc, _stacked_faces(faces), cols)
+        return _fused_epilogue_stacked(ro, orig_img_size, ignore_face_idxs)
     gt_locs2d_1 = project.batch_proj2d(verts_cam[0], camintrs[0])
     gt_locs2d_2 = project.batch_proj2d(verts_cam[1], camintrs[1])
     # forward optical flow

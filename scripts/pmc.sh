@@ -19,4 +19,5 @@ for grp in \
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_$i -o p -- python $ROOT/bench.py --kernels-only --kernel-iters 3 "$@" > "$ROOT/$OUT/pass$i.log" 2>&1
   cp /tmp/pmc_$i/p_counter_collection.csv "$ROOT/$OUT/pass${i}_counters.csv" 2>/dev/null || echo "pass $i: no counter csv"
 done
-python $ROOT/scripts/pmc_summary.py "$ROOT/$OUT" | tee "$ROOT/$OUT/summary.txt"
+python $ROOT/scripts/pmc_summary.py "$ROOT/$OUT" --json "$ROOT/$OUT/traffic.json" > "$ROOT/$OUT/summary.txt"
+tail -5 "$ROOT/$OUT/summary.txt"

@@ -184,6 +184,20 @@ def test_opticalflow_chain_matches_oracle(cuda, vertex_color_render, fused_epilo
     assert v1.grad is not None and torch.isfinite(v1.grad).all() and v1.grad.abs().sum() > 0
     assert ("mr_flow_vertices_forward" in calls) == fused_vertex_stage
     assert ("mr_flow_vertices_backward" in calls) == fused_vertex_stage
+    if fused_vertex_stage:  # both renders of the pair go out as one launch over 2B meshes, forward and backward
+        assert calls.count("mr_render_vc_forward") == 1 and calls.count("mr_render_vc_backward") == 1
+        assert calls.count("mr_pair_consist_forward") == 1 and calls.count("mr_pair_consist_backward") == 1
+        # detach_textures=True: two separate renders (only the first texture set is detached), same values
+        v1d = v1.detach().clone().requires_grad_(True)
+        flows_d = opticalflow.get_opticalflow([v1d, t(s["verts2"], cuda)], t(s["faces"], cuda),
+                                              [t(s["K1"], cuda), t(s["K2"], cuda)], ren, orig_img_size=(Wd, H),
+                                              detach_textures=True, detach_renders=True,
+                                              ignore_face_idxs=synth.HAND_IGNORE_FACES)
+        for i in (0, 1):
+            assert torch.equal(flows_d[i].detach(), flows[i].detach())
+        assert not flows_d[0].requires_grad and flows_d[1].requires_grad
+        flows_d[1].sum().backward()
+        assert torch.isfinite(v1d.grad).all() and v1d.grad.abs().sum() > 0
     # all (render path x epilogue x vertex stage) combinations give the same vertex gradient
     ref_key = "_vgrad_ref"
     if not hasattr(test_opticalflow_chain_matches_oracle, ref_key):
@@ -285,7 +299,9 @@ def test_flow_vertex_stage_matches_torch_ops(cuda, cam_batched):
     v1 = t(s["verts1"], cuda).requires_grad_(True)
     v2 = t(s["verts2"], cuda).requires_grad_(True)
     K1, K2 = t(s["K1"], cuda), t(s["K2"], cuda)
-    ndc1, ndc2, c12, c21 = _FlowVertexStage.apply(v1, v2, K1, K2, Rm, tv, dist, is_)
+    ndc, cols = _FlowVertexStage.apply(v1, v2, K1, K2, Rm, tv, dist, is_)  # frame 1 then frame 2, stacked
+    assert ndc.shape == cols.shape == (2 * B,) + tuple(v1.shape[1:])
+    (ndc1, ndc2), (c12, c21) = (ndc[:B], ndc[B:]), (cols[:B], cols[B:])
     a1, a2 = v1.detach().clone().requires_grad_(True), v2.detach().clone().requires_grad_(True)
     p1, p2 = project.batch_proj2d(a1, K1), project.batch_proj2d(a2, K2)
     r12 = torch.cat([p2 - p1, torch.ones_like(p1[..., :1])], -1)
@@ -302,8 +318,8 @@ def test_flow_vertex_stage_matches_torch_ops(cuda, cam_batched):
         close(got.cpu().numpy(), ref.cpu().numpy(), 1e-4, 1e-5 * float(ref.abs().max()), what)
     # frame 2 detached (warpbranch first_only): no gradient buffer for it
     v1.grad = None
-    _, _, c12b, c21b = _FlowVertexStage.apply(v1, v2.detach(), K1, K2, Rm, tv, dist, is_)
-    (c12b * w12).sum().backward()
+    _, colsb = _FlowVertexStage.apply(v1, v2.detach(), K1, K2, Rm, tv, dist, is_)
+    (colsb[:B] * w12).sum().backward()
     assert v1.grad is not None and torch.isfinite(v1.grad).all()
 
 
