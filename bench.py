@@ -280,10 +280,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # HOC_FORCE_DDP=1: take the multi-GPU code path (RCCL process group, DDP wrapper, barriers, max-over-ranks
+    # all-reduce) with a single rank too -- how the path is exercised on a one-GPU box (tests/test_gpu_bench.py)
+    use_dist = world > 1 or os.environ.get("HOC_FORCE_DDP", "0") == "1"
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -303,7 +307,7 @@ def main():
     if args.encoder_dtype == "bf16":
         model.encoder_dtype = torch.bfloat16
     net = model
-    if world > 1:
+    if use_dist:
         from torch.nn.parallel import DistributedDataParallel as DDP
 
         # 8 MB buckets overlap the RCCL all-reduce with the encoder backward; frozen BN statistics
