@@ -48,6 +48,8 @@ SIGNATURES = {
     "mr_pair_consist_workspace_bytes": (_L, [_I, _I, _I]),
     "mr_pair_consist_forward": (_I, [_P] * 6 + [_I, _P, _L] + [_P] * 11 + [_I, _I, _I, _F, _P]),
     "mr_pair_consist_backward": (_I, [_P] * 6 + [_I] + [_P] * 5 + [_I, _I, _I, _F, _P]),
+    "mr_frames_to_batch_workspace_bytes": (_L, [_I, _I, _I]),
+    "mr_frames_to_batch": (_I, [_P] * 3 + [_F] * 6 + [_P, _L, _P, _P] + [_I] * 6 + [_P]),
 }
 
 _lib = None

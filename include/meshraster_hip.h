@@ -345,6 +345,26 @@ MR_API int mr_pair_consist_backward(const float* flow12, const float* flow21, co
                              float* grad_flow12, float* grad_flow21, int batch_size,
                              int height, int width, float thresh, mr_stream_t stream);
 
+/* ---- dataset pipeline: decoded frames -> network-input batch ------------------------------
+ * One launch for a whole batch of what meshreg/datasets/handobjset.py:361-379 does per sample on the
+ * host: transform_img (libyana -> PIL Image.transform(size, AFFINE, coeffs), NEAREST, zero fill), crop to
+ * (width, height), torchvision to_tensor (u8 / 255) and normalize ((x - mean) / std; the reference uses
+ * mean 0.5, std 1), and the jitter mask = the same transform of an all-white image (:361-362, :376-378),
+ * after the optional left-right flip of handobjset.py:124-125.
+ *   frames[N, src_height, src_width, 3] u8 (HWC, as decoded); coeffs[N,6] f64 = Pillow's (a,b,c,d,e,f):
+ *   output pixel (x, y) <- input pixel (a x + b y + c, d x + e y + f); flip[N] u8 or NULL.
+ *   image[N,3,height,width] f32; jittermask[N,mask_channels,height,width] f32 in {0,1} or NULL
+ *   (mask_channels 3 = the reference's batch format, 1 = one plane).
+ * Source pixels are selected exactly as Pillow's Geometry.c does (scale / 16.16 fixed-point / double
+ * regimes): bit-exact with the reference's host path.  Non-finite coefficients: the frame is empty.
+ * workspace: mr_frames_to_batch_workspace_bytes(N, height, width) bytes, 16-byte aligned. */
+MR_API int64_t mr_frames_to_batch_workspace_bytes(int num_frames, int height, int width);
+MR_API int mr_frames_to_batch(const uint8_t* frames, const double* coeffs, const uint8_t* flip,
+                              float mean0, float mean1, float mean2, float std0, float std1,
+                              float std2, void* workspace, int64_t workspace_bytes, float* image,
+                              float* jittermask, int mask_channels, int num_frames, int src_height,
+                              int src_width, int height, int width, mr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
