@@ -192,6 +192,22 @@ def kernel_bench(dev, B, is_, iters):
         _lib.call("mr_occlusion_mask", P(m1), P(m2), P(rgb), P(rgb), 3 * is_ * is_, None, None, P(o1), P(o2), B, is_,
                   is_, 0.03, 0.99999, st)
 
+    # dataset side: the 3B frames of a step, 640x480 decoded frames -> is x is inputs + jitter masks
+    from handobjectconsist_amd.datasets import handutils
+
+    NF, Hs_, Ws_ = 3 * B, 480, 640
+    rngf = np.random.default_rng(0)
+    fr_u8 = torch.randint(0, 256, (NF, Hs_, Ws_, 3), dtype=torch.uint8, device=dev)
+    fr_coeffs = torch.from_numpy(np.stack([handutils.pil_coeffs(handutils.get_affine_transform(
+        rngf.uniform((250, 180), (390, 300)), rngf.uniform(250, 420), (is_, is_))[0]) for _ in range(NF)])).to(dev)
+    fr_img, fr_mask = torch.empty((NF, 3, is_, is_), **f32), torch.empty((NF, 3, is_, is_), **f32)
+    fr_wb = int(lib.mr_frames_to_batch_workspace_bytes(NF, is_, is_))
+    fr_work = torch.empty((fr_wb,), dtype=torch.uint8, device=dev)
+
+    def frames_to_batch():
+        _lib.call("mr_frames_to_batch", P(fr_u8), P(fr_coeffs), None, 0.5, 0.5, 0.5, 1.0, 1.0, 1.0, P(fr_work), fr_wb,
+                  P(fr_img), P(fr_mask), 3, NF, Hs_, Ws_, is_, is_, st)
+
     render_fwd()
     BF = B * F
     groups = [
@@ -206,6 +222,8 @@ def kernel_bench(dev, B, is_, iters):
         ("pair_consist_forward", pair_fwd, 48 * npx),
         ("pair_consist_backward", pair_bwd, 64 * npx),
         ("occlusion_mask", occlusion, (8 + 16 + 8) * npx),
+        # 3 source bytes in, 12 B image + 12 B three-channel jitter mask out, per output pixel of the 3B frames
+        ("frames_to_batch(3B frames,640x480->crop)", frames_to_batch, (3 + 12 + 12) * NF * is_ * is_),
     ]
     out = {}
     flush = torch.zeros(768 * 1024 * 1024 // 4, **f32)  # 768 MB > Infinity Cache (256 MB)
