@@ -64,7 +64,7 @@ __device__ __forceinline__ void load_face(const float* __restrict__ g, Face& f, 
 // function, and the pixels lying exactly on that line are accepted along its WHOLE length, also beyond
 // the vertices.  "Degenerate" cannot mean a zero pixel-space determinant only: with large coordinates
 // that determinant of a mathematically collinear triple rounds to a small non-zero value (found by
-// scripts/fuzz_parity.py).  The filter uses the two products of the back-face test instead (vertex
+// tests/fuzz_parity.py).  The filter uses the two products of the back-face test instead (vertex
 // DIFFERENCES first, so a collinear triple gives equal products up to a few ulp): a pixel beyond the
 // apex of a sliver passes both long-edge tests only if it is within eps * r of both lines at distance r,
 // i.e. only for apex angles of ~1e-7 rad.  Faces whose smallest angle (area / product of the two longest

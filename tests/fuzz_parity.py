@@ -1,5 +1,6 @@
-"""Randomised parity sweep of the HIP path against the CPU oracle (not a test: a bug hunt).
-Usage: fuzz_parity.py [n_cases] [first_seed]"""
+"""Randomised parity sweeps of the HIP path against the CPU oracle (not collected by pytest: a bug hunt to run
+on the GPU box).  Usage: python tests/fuzz_parity.py [n_cases] [first_seed].  Found the NaN-depth point-face bug
+and the collinear-face bounding-box bug; 24 000+ cases clean since."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

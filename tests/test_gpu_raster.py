@@ -178,7 +178,7 @@ def test_edge_cases(cuda):
     is_ = 37
     tri = np.array([[-0.8, -0.7, 1.0], [0.9, -0.6, 1.0], [0.1, 0.85, 1.0]], np.float32)
     # (the point face -- three vertices on one pixel-centre-lattice point -- passes every edge test of
-    # upstream's inside test at every pixel and has a NaN depth: it must never win; found by scripts/fuzz_parity.py)
+    # upstream's inside test at every pixel and has a NaN depth: it must never win; found by tests/fuzz_parity.py)
     point = np.array([[-0.5, -0.5, 1.75], [-0.5, -0.5, 1.625], [-0.5, -0.5, 1.75]], np.float32)
     # collinear vertices far off screen: the pixel-space determinant rounds to a non-zero value, yet upstream's
     # edge tests accept the pixels exactly on the line, also BEYOND the vertices (bbox filter in face_box)
