@@ -365,6 +365,27 @@ MR_API int mr_frames_to_batch(const uint8_t* frames, const double* coeffs, const
                               float* jittermask, int mask_channels, int num_frames, int src_height,
                               int src_width, int height, int width, mr_stream_t stream);
 
+/* ---- trainer side: BatchNorm with frozen statistics + residual add + ReLU -----------------
+ * The reference trains with --freeze_batchnorm (trainmeshwarp.py:205-206, 237-240): every BatchNorm2d of the
+ * ResNet-18 trunk runs in eval mode with trainable affine parameters, followed by ReLU, by "+ identity, ReLU"
+ * or by nothing (resnet.py:46-58, 31-43).  One pass each way instead of 2-3 element-wise kernels forward and
+ * batch_norm_backward + threshold_backward:
+ *   z = (x - running_mean) * (weight / sqrt(running_var + eps)) + bias [+ residual];  y = relu ? max(z, 0) : z
+ * x, residual, y, grad_*: [batch_size, channels, plane] fp32 contiguous (NCHW, plane = H * W); the channel
+ * arrays are [channels].  Backward: g = relu && !(z > 0) ? 0 : grad_y;  grad_x = g * weight / sqrt(var + eps);
+ * grad_residual = g (NULL if not wanted); grad_bias = sum g; grad_weight = sum g * (x - mean) / sqrt(var + eps)
+ * (either may be NULL; two-stage deterministic reduction through the workspace). */
+MR_API int mr_bn_act_forward(const float* x, const float* residual, const float* weight, const float* bias,
+                             const float* running_mean, const float* running_var, float eps, int relu,
+                             float* y, int batch_size, int channels, int plane, mr_stream_t stream);
+MR_API int64_t mr_bn_act_backward_workspace_bytes(int batch_size, int channels);
+MR_API int mr_bn_act_backward(const float* grad_y, const float* x, const float* residual,
+                              const float* weight, const float* bias, const float* running_mean,
+                              const float* running_var, float eps, int relu, float* grad_x,
+                              float* grad_residual, float* grad_weight, float* grad_bias,
+                              void* workspace, int64_t workspace_bytes, int batch_size, int channels,
+                              int plane, mr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,97 @@
+"""Fused frozen-BatchNorm + residual + ReLU (mr_bn_act_*) against the stock PyTorch modules it replaces in the
+ResNet-18 trunk (floating point: forward 1e-6, gradients 1e-5 relative to the gradient's scale)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rel, what):
+    scale = float(b.abs().max()) + 1e-30
+    err = float((a - b).abs().max())
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("shape", [(6, 64, 32, 32), (5, 16, 17, 30), (3, 512, 8, 8), (192, 8, 4, 4), (1, 3, 1, 1),
+                                   (7, 5, 3, 5)])
+@pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False), (False, True)])
+def test_bn_act_matches_stock_modules(cuda, shape, relu, with_res):
+    from handobjectconsist_amd.nn import frozen_bn
+
+    g = torch.Generator().manual_seed(hash((shape, relu, with_res)) % 2**31)
+    N, C = shape[:2]
+    bn = torch.nn.BatchNorm2d(C).to(cuda).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.4)
+        bn.running_var.copy_(torch.rand(C, generator=g) * 2 + 0.05)
+    x = torch.randn(shape, generator=g).to(cuda).requires_grad_(True)
+    res = torch.randn(shape, generator=g).to(cuda).requires_grad_(True) if with_res else None
+    gy = torch.randn(shape, generator=g).to(cuda)
+    y = frozen_bn.bn_act(x, bn, residual=res, relu=relu)
+    y.backward(gy)
+    got = [y.detach(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), None if res is None else res.grad.clone()]
+    x.grad = None
+    bn.weight.grad = bn.bias.grad = None
+    if res is not None:
+        res.grad = None
+    z = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+    if res is not None:
+        z = z + res
+    ref = F.relu(z) if relu else z
+    ref.backward(gy)
+    _close(got[0], ref.detach(), 2e-6, "forward")
+    # a ReLU mask may differ where z rounds to the other side of 0 in the two formulations: compare off those pixels
+    ambiguous = (z.detach().abs() < 1e-5) if relu else torch.zeros_like(z, dtype=torch.bool)
+    _close(got[1].masked_fill(ambiguous, 0), x.grad.masked_fill(ambiguous, 0), 1e-5, "grad x")
+    assert int(ambiguous.sum()) <= max(4, z.numel() // 20000)
+    tol = 1e-4 if ambiguous.any() else 2e-5
+    _close(got[2], bn.weight.grad, tol, "grad weight")
+    _close(got[3], bn.bias.grad, tol, "grad bias")
+    if res is not None:
+        _close(got[4].masked_fill(ambiguous, 0), res.grad.masked_fill(ambiguous, 0), 1e-6, "grad residual")
+
+
+def test_bn_act_rejects_training_mode_and_half(cuda):
+    from handobjectconsist_amd.nn import frozen_bn
+
+    bn = torch.nn.BatchNorm2d(4).to(cuda)
+    x = torch.randn(2, 4, 8, 8, device=cuda)
+    with pytest.raises(RuntimeError):
+        frozen_bn.bn_act(x, bn)
+    bn.eval()
+    with pytest.raises(ValueError):
+        frozen_bn.bn_act(x.half(), bn)
+    with pytest.raises(TypeError):
+        frozen_bn.bn_act(x.cpu(), bn)
+    assert frozen_bn.bn_act(x[:0], bn).shape == (0, 4, 8, 8)
+
+
+def test_resnet_trunk_fused_equals_stock(cuda, monkeypatch):
+    """The whole ResNet-18 trunk, forward features and every parameter gradient, fused BN path vs stock modules."""
+    from handobjectconsist_amd.models import synthnet
+
+    torch.manual_seed(0)
+    net = synthnet.ResNet18Features().to(cuda).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    x = torch.randn(6, 3, 96, 64, device=cuda)
+    w = torch.randn(6, 512, device=cuda)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(synthnet, "USE_HIP_BN", fused)
+        net.zero_grad(set_to_none=True)
+        feats = net(x)
+        (feats * w).sum().backward()
+        out[fused] = (feats.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()})
+    _close(out[True][0], out[False][0], 1e-4, "features")
+    for n, gref in out[False][1].items():
+        _close(out[True][1][n], gref, 2e-3, f"grad {n}")
