@@ -1,0 +1,256 @@
+// stem_pool.hip -- the ResNet stem after its 7x7 convolution, fused: BatchNorm with frozen statistics -> ReLU ->
+// MaxPool2d(kernel 3, stride 2, padding 1) (resnet.py:140-147 with --freeze_batchnorm), forward and backward.
+//
+// Stock PyTorch writes relu(bn(x)) (805 MB at B = 3 x 64, 256 x 256 inputs), reads it back to pool it, keeps it and a
+// 64-bit index map for the backward, and runs max_pool_backward (1.46 ms) + batch_norm_backward on top: 3.0 ms of a
+// 34 ms step.  Here the full-resolution activation after the BN never exists: the forward reads the convolution
+// output once and writes the pooled map (1/4 of the pixels); the backward recomputes z = bn(x) per tile in LDS,
+// re-derives every window's arg-max (PyTorch's rule: scan kh, kw ascending, strictly-greater wins, padding ignored)
+// and GATHERS the pooled gradient per input pixel -- no atomics, no zero-fill of the 805 MB gradient.
+#include "mr_common.hpp"
+
+namespace mr {
+
+struct StemParams {
+    const float* x;       // [N,C,H,W] convolution output
+    const float* weight;  // [C]
+    const float* bias;
+    const float* mean;
+    const float* var;
+    float eps;
+    int N, C, H, W, OH, OW;   // OH = (H - 1) / 2 + 1
+    int tiles_x, tiles_y;
+    float* y;             // forward: [N,C,OH,OW]
+    const float* grad_y;  // backward
+    float* grad_x;        // [N,C,H,W]
+    float* partial;       // [2][C][N * tiles]: sum g, sum g * (x - mean)
+};
+
+constexpr int SP_TX = 32, SP_TY = 8;               // windows (= pooled pixels) per tile
+constexpr int SP_IW = 2 * SP_TX + 3, SP_IH = 2 * SP_TY + 3;  // input region incl. halo: rows 2 oy0 - 1 .. 2 (oy0 + TY) + 1
+constexpr int SP_LDW = SP_IW + 1;
+
+__device__ __forceinline__ void stem_consts(const StemParams& p, int c, float& mean, float& a, float& b) {
+    mean = p.mean[c];
+    a = p.weight[c] * (1.0f / sqrtf(p.var[c] + p.eps));
+    b = p.bias[c];
+}
+
+// z = bn(x) of the tile's input region into LDS (-inf outside the image); returns through zt
+template <bool KEEP_D>
+__device__ __forceinline__ void load_tile(const StemParams& p, const float* xp, int iy0, int ix0, float mean, float a,
+                                          float b, float (*zt)[SP_LDW], float (*dt)[SP_LDW]) {
+    for (int e = threadIdx.x; e < SP_IH * SP_IW; e += 256) {
+        const int r = e / SP_IW, c = e - r * SP_IW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        float z = -__builtin_inff(), d = 0.0f;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            d = xp[(int64_t)iy * p.W + ix] - mean;
+            z = d * a + b;
+        }
+        zt[r][c] = z;
+        if (KEEP_D) dt[r][c] = d;
+    }
+}
+
+// grid = N * C * tiles workgroups of 256 threads (one pooled pixel per thread)
+__global__ __launch_bounds__(256) void stem_pool_forward_kernel(StemParams p) {
+    __shared__ float zt[SP_IH][SP_LDW];
+    const int tiles = p.tiles_x * p.tiles_y;
+    const int plane = blockIdx.x / tiles, t = blockIdx.x % tiles;
+    const int c = plane % p.C;
+    const int oy0 = (t / p.tiles_x) * SP_TY, ox0 = (t % p.tiles_x) * SP_TX;
+    float mean, a, b;
+    stem_consts(p, c, mean, a, b);
+    load_tile<false>(p, p.x + (int64_t)plane * p.H * p.W, 2 * oy0 - 1, 2 * ox0 - 1, mean, a, b, zt, nullptr);
+    __syncthreads();
+    const int wy = threadIdx.x / SP_TX, wx = threadIdx.x % SP_TX;
+    const int oy = oy0 + wy, ox = ox0 + wx;
+    if (oy >= p.OH || ox >= p.OW) return;
+    float m = 0.0f;  // relu: max(0, max z); every window holds at least one pixel of the image
+#pragma unroll
+    for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) m = fmaxf(m, zt[2 * wy + kh][2 * wx + kw]);
+    p.y[((int64_t)plane * p.OH + oy) * p.OW + ox] = m;
+}
+
+__global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
+    __shared__ float zt[SP_IH][SP_LDW];
+    __shared__ float dt[SP_IH][SP_LDW];                 // x - mean of the same region (for grad_weight)
+    __shared__ float gw[SP_TY + 1][SP_TX + 1];          // pooled gradient of the tile's windows (+1 row / column)
+    __shared__ unsigned char am[SP_TY + 1][SP_TX + 1];  // arg-max position kh * 3 + kw of every window
+    __shared__ float red[2][4];
+    const int tiles = p.tiles_x * p.tiles_y;
+    const int plane = blockIdx.x / tiles, t = blockIdx.x % tiles;
+    const int c = plane % p.C;
+    const int oy0 = (t / p.tiles_x) * SP_TY, ox0 = (t % p.tiles_x) * SP_TX;
+    float mean, a, b;
+    stem_consts(p, c, mean, a, b);
+    const float* xp = p.x + (int64_t)plane * p.H * p.W;
+    load_tile<true>(p, xp, 2 * oy0 - 1, 2 * ox0 - 1, mean, a, b, zt, dt);
+    __syncthreads();
+    // windows oy0 .. oy0 + TY, ox0 .. ox0 + TX: the owned input rows 2 oy0 .. 2 (oy0 + TY) - 1 touch one window more
+    for (int e = threadIdx.x; e < (SP_TY + 1) * (SP_TX + 1); e += 256) {
+        const int wy = e / (SP_TX + 1), wx = e - wy * (SP_TX + 1);
+        const int oy = oy0 + wy, ox = ox0 + wx;
+        float g = 0.0f;
+        int best = 0;
+        if (oy < p.OH && ox < p.OW) {
+            g = p.grad_y[((int64_t)plane * p.OH + oy) * p.OW + ox];
+            float mv = -__builtin_inff();  // PyTorch: first strictly greater value of relu(z) in (kh, kw) order, padding skipped
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const float z = zt[2 * wy + k / 3][2 * wx + k % 3];
+                const float v = fmaxf(z, 0.0f);
+                if (z != -__builtin_inff() && v > mv) { mv = v; best = k; }
+            }
+        }
+        gw[wy][wx] = g;
+        am[wy][wx] = (unsigned char)best;
+    }
+    __syncthreads();
+    // gather: owned input pixels rows 2 oy0 + [0, 2 TY), columns 2 ox0 + [0, 2 TX); LDS row = input row - (2 oy0 - 1)
+    float sum_g = 0.0f, sum_gx = 0.0f;
+    float* gx = p.grad_x + (int64_t)plane * p.H * p.W;
+    for (int e = threadIdx.x; e < 2 * SP_TY * 2 * SP_TX; e += 256) {
+        const int ry = e / (2 * SP_TX), rx = e - ry * (2 * SP_TX);
+        const int iy = 2 * oy0 + ry, ix = 2 * ox0 + rx;
+        if (iy >= p.H || ix >= p.W) continue;
+        const int ly = ry + 1, lx = rx + 1;  // position in zt
+        // windows containing the pixel: wy with 2 wy <= ly <= 2 wy + 2
+        float g = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++) {
+            const int wy = (ly >> 1) - dy;
+            const int kh = ly - 2 * wy;
+            if (wy < 0 || kh > 2) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                const int wx = (lx >> 1) - dx;
+                const int kw = lx - 2 * wx;
+                if (wx < 0 || kw > 2) continue;
+                if (am[wy][wx] == kh * 3 + kw) g += gw[wy][wx];
+            }
+        }
+        const float z = zt[ly][lx];
+        const float gm = z > 0.0f ? g : 0.0f;  // ReLU
+        gx[(int64_t)iy * p.W + ix] = gm * a;
+        const float d = dt[ly][lx];
+        sum_g += gm;
+        sum_gx += gm * d;
+    }
+    if (p.partial) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            sum_g += __shfl_down(sum_g, off);
+            sum_gx += __shfl_down(sum_gx, off);
+        }
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[0][wave] = sum_g; red[1][wave] = sum_gx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n = plane / p.C;
+            const int64_t per_c = (int64_t)p.N * tiles;
+            const int64_t slot = (int64_t)n * tiles + t;
+            p.partial[(int64_t)c * per_c + slot] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            p.partial[((int64_t)p.C + c) * per_c + slot] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        }
+    }
+}
+
+// grad_bias[c] = sum partial[0][c][:];  grad_weight[c] = invstd[c] * sum partial[1][c][:]   (one workgroup per channel)
+__global__ __launch_bounds__(256) void stem_finish_kernel(const float* __restrict__ partial, const float* __restrict__ var,
+                                                          float eps, float* grad_weight, float* grad_bias, int C,
+                                                          int64_t per_c) {
+    __shared__ float red[2][4];
+    const int c = blockIdx.x;
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int64_t k = threadIdx.x; k < per_c; k += 256) {
+        s0 += partial[(int64_t)c * per_c + k];
+        s1 += partial[((int64_t)C + c) * per_c + k];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s0 += __shfl_down(s0, off);
+        s1 += __shfl_down(s1, off);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (grad_bias) grad_bias[c] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        if (grad_weight) grad_weight[c] = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * (1.0f / sqrtf(var[c] + eps));
+    }
+}
+
+static int stem_fill(StemParams& p, const float* x, const float* weight, const float* bias, const float* mean,
+                     const float* var, float eps, int N, int C, int H, int W) {
+    if (N < 0 || C < 0 || H < 0 || W < 0) return MR_ERR_BADARG;
+    p.x = x; p.weight = weight; p.bias = bias; p.mean = mean; p.var = var; p.eps = eps;
+    p.N = N; p.C = C; p.H = H; p.W = W;
+    p.OH = H > 0 ? (H - 1) / 2 + 1 : 0;
+    p.OW = W > 0 ? (W - 1) / 2 + 1 : 0;
+    p.tiles_x = (p.OW + SP_TX - 1) / SP_TX;
+    p.tiles_y = (p.OH + SP_TY - 1) / SP_TY;
+    if ((int64_t)N * C * p.tiles_x * p.tiles_y > 0x7fffffff) return MR_ERR_BADARG;
+    return MR_OK;
+}
+
+}  // namespace mr
+
+extern "C" int mr_stem_pool_forward(const float* x, const float* weight, const float* bias, const float* running_mean,
+                                    const float* running_var, float eps, float* y, int batch_size, int channels,
+                                    int height, int width, mr_stream_t stream) {
+    using namespace mr;
+    StemParams p{};
+    const int rc = stem_fill(p, x, weight, bias, running_mean, running_var, eps, batch_size, channels, height, width);
+    if (rc != MR_OK) return rc;
+    if (batch_size == 0 || channels == 0 || height == 0 || width == 0) return MR_OK;
+    if (!x || !weight || !bias || !running_mean || !running_var || !y) return MR_ERR_BADARG;
+    p.y = y;
+    hipLaunchKernelGGL(stem_pool_forward_kernel, dim3((unsigned)((int64_t)batch_size * channels * p.tiles_x * p.tiles_y)),
+                       dim3(256), 0, (hipStream_t)stream, p);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int64_t mr_stem_pool_backward_workspace_bytes(int batch_size, int channels, int height, int width) {
+    using namespace mr;
+    StemParams p{};
+    if (stem_fill(p, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, batch_size, channels, height, width) != MR_OK) return -1;
+    return (int64_t)2 * channels * batch_size * p.tiles_x * p.tiles_y * 4 + 16;
+}
+
+extern "C" int mr_stem_pool_backward(const float* grad_y, const float* x, const float* weight, const float* bias,
+                                     const float* running_mean, const float* running_var, float eps, float* grad_x,
+                                     float* grad_weight, float* grad_bias, void* workspace, int64_t workspace_bytes,
+                                     int batch_size, int channels, int height, int width, mr_stream_t stream) {
+    using namespace mr;
+    StemParams p{};
+    const int rc = stem_fill(p, x, weight, bias, running_mean, running_var, eps, batch_size, channels, height, width);
+    if (rc != MR_OK) return rc;
+    if (channels == 0) return MR_OK;
+    const bool want_params = grad_weight || grad_bias;
+    if (batch_size == 0 || height == 0 || width == 0) {
+        hipError_t e = hipSuccess;
+        if (grad_weight) e = hipMemsetAsync(grad_weight, 0, (size_t)channels * 4, (hipStream_t)stream);
+        if (e == hipSuccess && grad_bias) e = hipMemsetAsync(grad_bias, 0, (size_t)channels * 4, (hipStream_t)stream);
+        return e == hipSuccess ? MR_OK : (int)e;
+    }
+    if (!grad_y || !x || !weight || !bias || !running_mean || !running_var || !grad_x) return MR_ERR_BADARG;
+    if (want_params &&
+        (!workspace || workspace_bytes < mr_stem_pool_backward_workspace_bytes(batch_size, channels, height, width)))
+        return MR_ERR_BADARG;
+    p.grad_y = grad_y; p.grad_x = grad_x;
+    p.partial = want_params ? static_cast<float*>(workspace) : nullptr;
+    const int tiles = p.tiles_x * p.tiles_y;
+    hipLaunchKernelGGL(stem_pool_backward_kernel, dim3((unsigned)((int64_t)batch_size * channels * tiles)), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    MR_CHECK_LAUNCH();
+    if (want_params) {
+        hipLaunchKernelGGL(stem_finish_kernel, dim3((unsigned)channels), dim3(256), 0, (hipStream_t)stream, p.partial,
+                           running_var, eps, grad_weight, grad_bias, channels, (int64_t)batch_size * tiles);
+        MR_CHECK_LAUNCH();
+    }
+    return MR_OK;
+}

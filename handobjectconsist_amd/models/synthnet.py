@@ -97,7 +97,7 @@ class ResNet18Features(nn.Module):
 
     def forward(self, x):
         if _fused_bn(self.bn1, x):
-            x = self.maxpool(frozen_bn.bn_act(self.conv1(x), self.bn1))
+            x = frozen_bn.stem_pool(self.conv1(x), self.bn1)  # bn1 + relu + maxpool(3, 2, 1)
         else:
             x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))

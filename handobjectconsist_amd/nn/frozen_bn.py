@@ -54,3 +54,45 @@ def bn_act(x, bn, residual=None, relu=True):
     if bn.training or not bn.track_running_stats:
         raise RuntimeError("bn_act needs frozen BatchNorm statistics (module.eval())")
     return _BnActFunction.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
+
+
+class _StemPoolFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps):
+        _lib.check_cuda(x, weight, bias, running_mean, running_var)
+        if x.dim() != 4 or x.dtype != torch.float32:
+            raise ValueError("expected an fp32 [N, C, H, W] tensor")
+        xc = x.contiguous()
+        N, C, H, W = xc.shape
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        m, v = running_mean.contiguous(), running_var.contiguous()
+        y = torch.empty((N, C, (H - 1) // 2 + 1 if H else 0, (W - 1) // 2 + 1 if W else 0), dtype=torch.float32,
+                        device=xc.device)
+        _lib.call("mr_stem_pool_forward", _lib.ptr(xc), _lib.ptr(w), _lib.ptr(b), _lib.ptr(m), _lib.ptr(v), float(eps),
+                  _lib.ptr(y), N, C, H, W, _lib.stream_ptr(xc.device))
+        ctx.save_for_backward(xc, w, b, m, v)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        xc, w, b, m, v = ctx.saved_tensors
+        N, C, H, W = xc.shape
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        g = grad_y.contiguous()
+        grad_x = torch.empty_like(xc)
+        grad_w = torch.empty_like(w) if need_w else None
+        grad_b = torch.empty_like(b) if need_b else None
+        wbytes = int(_lib.load().mr_stem_pool_backward_workspace_bytes(N, C, H, W))
+        work = torch.empty((wbytes,), dtype=torch.uint8, device=xc.device) if (need_w or need_b) else None
+        _lib.call("mr_stem_pool_backward", _lib.ptr(g), _lib.ptr(xc), _lib.ptr(w), _lib.ptr(b), _lib.ptr(m), _lib.ptr(v),
+                  ctx.eps, _lib.ptr(grad_x), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(work), wbytes, N, C, H, W,
+                  _lib.stream_ptr(xc.device))
+        return (grad_x if need_x else None), grad_w, grad_b, None, None, None
+
+
+def stem_pool(x, bn):
+    """``MaxPool2d(3, 2, 1)(relu(bn(x)))`` for an ``nn.BatchNorm2d`` in eval mode: the ResNet stem, one kernel."""
+    if bn.training or not bn.track_running_stats:
+        raise RuntimeError("stem_pool needs frozen BatchNorm statistics (module.eval())")
+    return _StemPoolFunction.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)

@@ -386,6 +386,21 @@ MR_API int mr_bn_act_backward(const float* grad_y, const float* x, const float* 
                               void* workspace, int64_t workspace_bytes, int batch_size, int channels,
                               int plane, mr_stream_t stream);
 
+/* The ResNet stem after its 7x7 convolution as one kernel each way (resnet.py:140-147 with frozen statistics):
+ *   y = MaxPool2d(kernel 3, stride 2, padding 1)(relu(bn(x)))     x[N,C,H,W] -> y[N,C,(H-1)/2+1,(W-1)/2+1]
+ * The full-resolution activation is never written; the backward recomputes it per tile, re-derives every
+ * window's arg-max with PyTorch's rule (kh, kw ascending, strictly greater wins, padding skipped) and gathers the
+ * pooled gradient per input pixel (no atomics).  grad_weight / grad_bias may be NULL. */
+MR_API int mr_stem_pool_forward(const float* x, const float* weight, const float* bias,
+                                const float* running_mean, const float* running_var, float eps, float* y,
+                                int batch_size, int channels, int height, int width, mr_stream_t stream);
+MR_API int64_t mr_stem_pool_backward_workspace_bytes(int batch_size, int channels, int height, int width);
+MR_API int mr_stem_pool_backward(const float* grad_y, const float* x, const float* weight, const float* bias,
+                                 const float* running_mean, const float* running_var, float eps,
+                                 float* grad_x, float* grad_weight, float* grad_bias, void* workspace,
+                                 int64_t workspace_bytes, int batch_size, int channels, int height,
+                                 int width, mr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,3 +95,42 @@ def test_resnet_trunk_fused_equals_stock(cuda, monkeypatch):
     _close(out[True][0], out[False][0], 1e-4, "features")
     for n, gref in out[False][1].items():
         _close(out[True][1][n], gref, 2e-3, f"grad {n}")
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 32, 32), (3, 5, 17, 31), (2, 3, 1, 1), (2, 4, 135, 240), (6, 64, 64, 66),
+                                   (1, 2, 2, 3)])
+def test_stem_pool_matches_stock_modules(cuda, shape):
+    """bn (frozen) -> relu -> MaxPool2d(3, 2, 1) as one kernel each way vs the three stock modules, incl. image
+    sizes that are not multiples of the tile, 1-pixel images and a negative BatchNorm weight."""
+    from handobjectconsist_amd.nn import frozen_bn
+
+    g = torch.Generator().manual_seed(sum(shape))
+    N, C = shape[:2]
+    bn = torch.nn.BatchNorm2d(C).to(cuda).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        bn.weight[0] = -0.7
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.4)
+        bn.running_var.copy_(torch.rand(C, generator=g) * 2 + 0.05)
+    x = torch.randn(shape, generator=g).to(cuda).requires_grad_(True)
+    y = frozen_bn.stem_pool(x, bn)
+    gy = torch.randn(y.shape, generator=g).to(cuda)
+    y.backward(gy)
+    got = (y.detach(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+    x.grad = None
+    bn.weight.grad = bn.bias.grad = None
+    z = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+    ref = F.max_pool2d(F.relu(z), kernel_size=3, stride=2, padding=1)
+    ref.backward(gy)
+    assert got[0].shape == ref.shape
+    _close(got[0], ref.detach(), 2e-6, "forward")
+    # the arg-max of a window can differ where two candidates are within rounding of each other (different but
+    # equivalent BN formulas): allow a handful of such windows, compare everything else tightly
+    diff = (got[1] - x.grad).abs() > 1e-5 * float(x.grad.abs().max() + 1e-30)
+    assert int(diff.sum()) <= max(2, x.numel() // 5000), int(diff.sum())
+    tol = 2e-5 if not diff.any() else 5e-3
+    _close(got[2], bn.weight.grad, tol, "grad weight")
+    _close(got[3], bn.bias.grad, tol, "grad bias")
+    # exact structural property: every pooled gradient lands on exactly one input pixel (or on none if relu is off there)
+    assert float(got[1].abs().sum()) > 0 or float(gy.abs().sum()) == 0
