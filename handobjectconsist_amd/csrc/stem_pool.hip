@@ -26,8 +26,11 @@ struct StemParams {
     float* partial;       // [2][C][N * tiles]: sum g, sum g * (x - mean)
 };
 
-constexpr int SP_TX = 32, SP_TY = 8;               // windows (= pooled pixels) per tile
-constexpr int SP_IW = 2 * SP_TX + 3, SP_IH = 2 * SP_TY + 3;  // input region incl. halo: rows 2 oy0 - 1 .. 2 (oy0 + TY) + 1
+constexpr int SP_TX = 32, SP_TY = 16;  // windows (= pooled pixels) per tile
+// Input region of a tile in LDS: rows 2 oy0 - 1 .. 2 (oy0 + TY) + 1, columns 2 ox0 - 4 .. 2 (ox0 + TX) + 3 -- the
+// column range starts 3 pixels early so that it begins on a 16-byte boundary (2 ox0 is a multiple of 64) and can be
+// fetched with aligned float4 loads.  LDS row = input row - (2 oy0 - 1), LDS column = input column - (2 ox0 - 4).
+constexpr int SP_IH = 2 * SP_TY + 3, SP_IW = 2 * SP_TX + 8, SP_C0 = 4;
 constexpr int SP_LDW = SP_IW + 1;
 
 __device__ __forceinline__ void stem_consts(const StemParams& p, int c, float& mean, float& a, float& b) {
@@ -36,14 +39,35 @@ __device__ __forceinline__ void stem_consts(const StemParams& p, int c, float& m
     b = p.bias[c];
 }
 
-// z = bn(x) of the tile's input region into LDS (-inf outside the image); returns through zt
+// z = bn(x) (and d = x - mean) of the tile's input region into LDS; -inf / 0 outside the image
 template <bool KEEP_D>
-__device__ __forceinline__ void load_tile(const StemParams& p, const float* xp, int iy0, int ix0, float mean, float a,
+__device__ __forceinline__ void load_tile(const StemParams& p, const float* xp, int oy0, int ox0, float mean, float a,
                                           float b, float (*zt)[SP_LDW], float (*dt)[SP_LDW]) {
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - SP_C0;
+    const float ninf = -__builtin_inff();
+    if ((p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 15) == 0) {
+        for (int e = threadIdx.x; e < SP_IH * (SP_IW / 4); e += 256) {
+            const int r = e / (SP_IW / 4), q = e - r * (SP_IW / 4);
+            const int iy = iy0 + r, ix = ix0 + 4 * q;  // a float4 is entirely inside or entirely outside the row
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            if (in) {
+                const float4 t = *reinterpret_cast<const float4*>(xp + (int64_t)iy * p.W + ix);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float d = v[i] - mean;
+                zt[r][4 * q + i] = in ? d * a + b : ninf;
+                if (KEEP_D) dt[r][4 * q + i] = in ? d : 0.0f;
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < SP_IH * SP_IW; e += 256) {
         const int r = e / SP_IW, c = e - r * SP_IW;
         const int iy = iy0 + r, ix = ix0 + c;
-        float z = -__builtin_inff(), d = 0.0f;
+        float z = ninf, d = 0.0f;
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
             d = xp[(int64_t)iy * p.W + ix] - mean;
             z = d * a + b;
@@ -53,7 +77,7 @@ __device__ __forceinline__ void load_tile(const StemParams& p, const float* xp, 
     }
 }
 
-// grid = N * C * tiles workgroups of 256 threads (one pooled pixel per thread)
+// grid = N * C * tiles workgroups of 256 threads
 __global__ __launch_bounds__(256) void stem_pool_forward_kernel(StemParams p) {
     __shared__ float zt[SP_IH][SP_LDW];
     const int tiles = p.tiles_x * p.tiles_y;
@@ -62,17 +86,19 @@ __global__ __launch_bounds__(256) void stem_pool_forward_kernel(StemParams p) {
     const int oy0 = (t / p.tiles_x) * SP_TY, ox0 = (t % p.tiles_x) * SP_TX;
     float mean, a, b;
     stem_consts(p, c, mean, a, b);
-    load_tile<false>(p, p.x + (int64_t)plane * p.H * p.W, 2 * oy0 - 1, 2 * ox0 - 1, mean, a, b, zt, nullptr);
+    load_tile<false>(p, p.x + (int64_t)plane * p.H * p.W, oy0, ox0, mean, a, b, zt, nullptr);
     __syncthreads();
-    const int wy = threadIdx.x / SP_TX, wx = threadIdx.x % SP_TX;
-    const int oy = oy0 + wy, ox = ox0 + wx;
-    if (oy >= p.OH || ox >= p.OW) return;
-    float m = 0.0f;  // relu: max(0, max z); every window holds at least one pixel of the image
+    for (int e = threadIdx.x; e < SP_TY * SP_TX; e += 256) {
+        const int wy = e / SP_TX, wx = e % SP_TX;
+        const int oy = oy0 + wy, ox = ox0 + wx;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        float m = 0.0f;  // relu: max(0, max z); every window holds at least one pixel of the image
 #pragma unroll
-    for (int kh = 0; kh < 3; kh++)
+        for (int kh = 0; kh < 3; kh++)
 #pragma unroll
-        for (int kw = 0; kw < 3; kw++) m = fmaxf(m, zt[2 * wy + kh][2 * wx + kw]);
-    p.y[((int64_t)plane * p.OH + oy) * p.OW + ox] = m;
+            for (int kw = 0; kw < 3; kw++) m = fmaxf(m, zt[2 * wy + kh][2 * wx + kw + SP_C0 - 1]);
+        p.y[((int64_t)plane * p.OH + oy) * p.OW + ox] = m;
+    }
 }
 
 __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
@@ -88,7 +114,7 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
     float mean, a, b;
     stem_consts(p, c, mean, a, b);
     const float* xp = p.x + (int64_t)plane * p.H * p.W;
-    load_tile<true>(p, xp, 2 * oy0 - 1, 2 * ox0 - 1, mean, a, b, zt, dt);
+    load_tile<true>(p, xp, oy0, ox0, mean, a, b, zt, dt);
     __syncthreads();
     // windows oy0 .. oy0 + TY, ox0 .. ox0 + TX: the owned input rows 2 oy0 .. 2 (oy0 + TY) - 1 touch one window more
     for (int e = threadIdx.x; e < (SP_TY + 1) * (SP_TX + 1); e += 256) {
@@ -101,7 +127,7 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
             float mv = -__builtin_inff();  // PyTorch: first strictly greater value of relu(z) in (kh, kw) order, padding skipped
 #pragma unroll
             for (int k = 0; k < 9; k++) {
-                const float z = zt[2 * wy + k / 3][2 * wx + k % 3];
+                const float z = zt[2 * wy + k / 3][2 * wx + k % 3 + SP_C0 - 1];
                 const float v = fmaxf(z, 0.0f);
                 if (z != -__builtin_inff() && v > mv) { mv = v; best = k; }
             }
@@ -113,32 +139,45 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
     // gather: owned input pixels rows 2 oy0 + [0, 2 TY), columns 2 ox0 + [0, 2 TX); LDS row = input row - (2 oy0 - 1)
     float sum_g = 0.0f, sum_gx = 0.0f;
     float* gx = p.grad_x + (int64_t)plane * p.H * p.W;
-    for (int e = threadIdx.x; e < 2 * SP_TY * 2 * SP_TX; e += 256) {
-        const int ry = e / (2 * SP_TX), rx = e - ry * (2 * SP_TX);
-        const int iy = 2 * oy0 + ry, ix = 2 * ox0 + rx;
-        if (iy >= p.H || ix >= p.W) continue;
-        const int ly = ry + 1, lx = rx + 1;  // position in zt
-        // windows containing the pixel: wy with 2 wy <= ly <= 2 wy + 2
-        float g = 0.0f;
+    const bool vec = (p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0;
+    for (int e = threadIdx.x; e < 2 * SP_TY * (2 * SP_TX / 4); e += 256) {  // four consecutive owned pixels per item
+        const int ry = e / (2 * SP_TX / 4), rx0 = 4 * (e - ry * (2 * SP_TX / 4));
+        const int iy = 2 * oy0 + ry, ix0 = 2 * ox0 + rx0;
+        if (iy >= p.H || ix0 >= p.W) continue;
+        const int ly = ry + 1;  // position relative to the first window's first row
+        float out[4];
 #pragma unroll
-        for (int dy = 0; dy < 2; dy++) {
-            const int wy = (ly >> 1) - dy;
-            const int kh = ly - 2 * wy;
-            if (wy < 0 || kh > 2) continue;
+        for (int i = 0; i < 4; i++) {
+            const int lx = rx0 + i + 1;
+            // windows containing the pixel: wy with 2 wy <= ly <= 2 wy + 2, likewise wx
+            float g = 0.0f;
 #pragma unroll
-            for (int dx = 0; dx < 2; dx++) {
-                const int wx = (lx >> 1) - dx;
-                const int kw = lx - 2 * wx;
-                if (wx < 0 || kw > 2) continue;
-                if (am[wy][wx] == kh * 3 + kw) g += gw[wy][wx];
+            for (int dy = 0; dy < 2; dy++) {
+                const int wy = (ly >> 1) - dy;
+                const int kh = ly - 2 * wy;
+                if (wy < 0 || kh > 2) continue;
+#pragma unroll
+                for (int dx = 0; dx < 2; dx++) {
+                    const int wx = (lx >> 1) - dx;
+                    const int kw = lx - 2 * wx;
+                    if (wx < 0 || kw > 2) continue;
+                    if (am[wy][wx] == kh * 3 + kw) g += gw[wy][wx];
+                }
             }
+            const float z = zt[ly][lx + SP_C0 - 1];
+            const float gm = (z > 0.0f && ix0 + i < p.W) ? g : 0.0f;  // ReLU
+            out[i] = gm * a;
+            sum_g += gm;
+            sum_gx += gm * dt[ly][lx + SP_C0 - 1];
         }
-        const float z = zt[ly][lx];
-        const float gm = z > 0.0f ? g : 0.0f;  // ReLU
-        gx[(int64_t)iy * p.W + ix] = gm * a;
-        const float d = dt[ly][lx];
-        sum_g += gm;
-        sum_gx += gm * d;
+        float* dst = gx + (int64_t)iy * p.W + ix0;
+        if (vec) {
+            *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (ix0 + i < p.W) dst[i] = out[i];
+        }
     }
     if (p.partial) {
 #pragma unroll
