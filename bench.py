@@ -208,6 +208,37 @@ def kernel_bench(dev, B, is_, iters):
         _lib.call("mr_frames_to_batch", P(fr_u8), P(fr_coeffs), None, 0.5, 0.5, 0.5, 1.0, 1.0, 1.0, P(fr_work), fr_wb,
                   P(fr_img), P(fr_mask), 3, NF, Hs_, Ws_, is_, is_, st)
 
+    # trainer side: what sits between MIOpen's convolutions in the ResNet-18 trunk, at the shapes of a
+    # step (3B frames): the stem (bn + relu + max-pool on [3B,64,is/2,is/2]) and a layer-1 bn + identity + relu
+    hs = is_ // 2
+    st_x = torch.randn(NF, 64, hs, hs, **f32)
+    st_y, st_gx = torch.empty(NF, 64, hs // 2, hs // 2, **f32), torch.empty_like(st_x)
+    st_gy = torch.randn_like(st_y)
+    bnp = [torch.rand(64, **f32) + 0.5, torch.randn(64, **f32), torch.randn(64, **f32), torch.rand(64, **f32) + 0.5]
+    bn_gw, bn_gb = torch.empty(64, **f32), torch.empty(64, **f32)
+    st_wb = int(lib.mr_stem_pool_backward_workspace_bytes(NF, 64, hs, hs))
+    st_work = torch.empty((st_wb,), dtype=torch.uint8, device=dev)
+    l1_x, l1_res, l1_gy = st_gx[:, :, :hs // 2, :hs // 2].contiguous(), torch.randn_like(st_y), torch.randn_like(st_y)
+    l1_y, l1_gx, l1_gr = torch.empty_like(st_y), torch.empty_like(st_y), torch.empty_like(st_y)
+    l1_wb = int(lib.mr_bn_act_backward_workspace_bytes(NF, 64))
+    l1_work = torch.empty((l1_wb,), dtype=torch.uint8, device=dev)
+    l1_x.normal_()
+
+    def stem_fwd():
+        _lib.call("mr_stem_pool_forward", P(st_x), *[P(t_) for t_ in bnp], 1e-5, P(st_y), NF, 64, hs, hs, st)
+
+    def stem_bwd():
+        _lib.call("mr_stem_pool_backward", P(st_gy), P(st_x), *[P(t_) for t_ in bnp], 1e-5, P(st_gx), P(bn_gw), P(bn_gb),
+                  P(st_work), st_wb, NF, 64, hs, hs, st)
+
+    def bn_fwd():
+        _lib.call("mr_bn_act_forward", P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, P(l1_y), NF, 64,
+                  (hs // 2) ** 2, st)
+
+    def bn_bwd():
+        _lib.call("mr_bn_act_backward", P(l1_gy), P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, P(l1_gx), P(l1_gr),
+                  P(bn_gw), P(bn_gb), P(l1_work), l1_wb, NF, 64, (hs // 2) ** 2, st)
+
     render_fwd()
     BF = B * F
     groups = [
@@ -224,6 +255,11 @@ def kernel_bench(dev, B, is_, iters):
         ("occlusion_mask", occlusion, (8 + 16 + 8) * npx),
         # 3 source bytes in, 12 B image + 12 B three-channel jitter mask out, per output pixel of the 3B frames
         ("frames_to_batch(3B frames,640x480->crop)", frames_to_batch, (3 + 12 + 12) * NF * is_ * is_),
+        # encoder glue: bytes = tensors read + written once
+        ("stem_bn_relu_maxpool_forward[3B,64]", stem_fwd, 4 * (st_x.numel() + st_y.numel())),
+        ("stem_bn_relu_maxpool_backward[3B,64]", stem_bwd, 4 * (2 * st_x.numel() + st_y.numel())),
+        ("bn_add_relu_forward(layer1)[3B,64]", bn_fwd, 4 * 3 * l1_x.numel()),
+        ("bn_add_relu_backward(layer1)[3B,64]", bn_bwd, 4 * 5 * l1_x.numel()),
     ]
     out = {}
     flush = torch.zeros(768 * 1024 * 1024 // 4, **f32)  # 768 MB > Infinity Cache (256 MB)
@@ -411,7 +447,7 @@ def main():
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
             "data": "synthetic",
             "config": {"workload": f"trainmeshwarp.py consist step, per-GPU B={B}, {is_}x{ih_}, hand 778v/1552f + "
-                                   f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {'fp32' if args.encoder_dtype == 'f32' else 'bf16-autocast'} stock PyTorch, Adam",
+                                   f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {'fp32 (MIOpen convolutions + fused HIP BatchNorm/ReLU/residual/max-pool kernels)' if args.encoder_dtype == 'f32' else 'bf16-autocast stock PyTorch'}, Adam",
                        "global_batch": B * world, "image_size": is_, "parallelism": f"dp{world}"},
             "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
