@@ -1,4 +1,6 @@
-"""Stock PyTorch-ROCm counterpart of the network the hot path trains (bench / trainer only).
+"""PyTorch-ROCm counterpart of the network the hot path trains (bench / trainer only): stock convolutions /
+linears (MIOpen, rocBLAS), this build's kernels for what sits between them (frozen BatchNorm + residual + ReLU,
+the stem's max-pool, MANO, the head post-processing).
 
 BASELINE.json's north star keeps "the ResNet-18 encoder and regression heads on stock
 PyTorch-ROCm"; this module restates their ARCHITECTURE so that the timed optimiser step
