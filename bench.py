@@ -225,18 +225,18 @@ def kernel_bench(dev, B, is_, iters):
     l1_x.normal_()
 
     def stem_fwd():
-        _lib.call("mr_stem_pool_forward", P(st_x), *[P(t_) for t_ in bnp], 1e-5, P(st_y), NF, 64, hs, hs, st)
+        _lib.call("mr_stem_pool_forward", P(st_x), *[P(t_) for t_ in bnp], 1e-5, 0, P(st_y), NF, 64, hs, hs, st)
 
     def stem_bwd():
-        _lib.call("mr_stem_pool_backward", P(st_gy), P(st_x), *[P(t_) for t_ in bnp], 1e-5, P(st_gx), P(bn_gw), P(bn_gb),
+        _lib.call("mr_stem_pool_backward", P(st_gy), P(st_x), *[P(t_) for t_ in bnp], 1e-5, 0, P(st_gx), P(bn_gw), P(bn_gb),
                   P(st_work), st_wb, NF, 64, hs, hs, st)
 
     def bn_fwd():
-        _lib.call("mr_bn_act_forward", P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, P(l1_y), NF, 64,
+        _lib.call("mr_bn_act_forward", P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, 0, P(l1_y), NF, 64,
                   (hs // 2) ** 2, st)
 
     def bn_bwd():
-        _lib.call("mr_bn_act_backward", P(l1_gy), P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, P(l1_gx), P(l1_gr),
+        _lib.call("mr_bn_act_backward", P(l1_gy), P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, 0, P(l1_gx), P(l1_gr),
                   P(bn_gw), P(bn_gb), P(l1_work), l1_wb, NF, 64, (hs // 2) ** 2, st)
 
     render_fwd()
@@ -447,7 +447,7 @@ def main():
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
             "data": "synthetic",
             "config": {"workload": f"trainmeshwarp.py consist step, per-GPU B={B}, {is_}x{ih_}, hand 778v/1552f + "
-                                   f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {'fp32 (MIOpen convolutions + fused HIP BatchNorm/ReLU/residual/max-pool kernels)' if args.encoder_dtype == 'f32' else 'bf16-autocast stock PyTorch'}, Adam",
+                                   f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {('fp32' if args.encoder_dtype == 'f32' else 'bf16-autocast') + ' (MIOpen convolutions + fused HIP BatchNorm/ReLU/residual/max-pool kernels)'}, Adam",
                        "global_batch": B * world, "image_size": is_, "parallelism": f"dp{world}"},
             "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,

@@ -19,8 +19,8 @@
 namespace mr {
 
 struct BnParams {
-    const float* x;         // [N,C,HW]
-    const float* residual;  // [N,C,HW] or NULL
+    const void* x;          // [N,C,HW]  fp32 or bf16 (the activation type T of the kernel)
+    const void* residual;   // [N,C,HW] or NULL
     const float* weight;    // [C]
     const float* bias;
     const float* mean;
@@ -29,13 +29,41 @@ struct BnParams {
     int relu;
     int N, C, HW, split;    // split = sample ranges per channel
     // forward
-    float* y;
+    void* y;
     // backward
-    const float* grad_y;
-    float* grad_x;
-    float* grad_residual;   // NULL or [N,C,HW]
+    const void* grad_y;
+    void* grad_x;
+    void* grad_residual;    // NULL or [N,C,HW]
     float* partial;         // [2][C][split]: sum g, sum g * (x - mean)
 };
+
+// activations: fp32, or bf16 (the trunk under bf16 autocast) converted on load / rounded to nearest-even on store
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { typedef float4 type; };
+template <> struct Vec4<bf16_t> { typedef ushort4 type; };
+
+template <typename T>
+__device__ __forceinline__ void load4(const void* base, int64_t o, float* v) {
+    const typename Vec4<T>::type t = *reinterpret_cast<const typename Vec4<T>::type*>(static_cast<const T*>(base) + o);
+    v[0] = to_f32(t.x); v[1] = to_f32(t.y); v[2] = to_f32(t.z); v[3] = to_f32(t.w);
+}
+template <typename T>
+__device__ __forceinline__ void store4(void* base, int64_t o, const float* v) {
+    typename Vec4<T>::type t;
+    t.x = from_f32<T>(v[0]); t.y = from_f32<T>(v[1]); t.z = from_f32<T>(v[2]); t.w = from_f32<T>(v[3]);
+    *reinterpret_cast<typename Vec4<T>::type*>(static_cast<T*>(base) + o) = t;
+}
 
 __device__ __forceinline__ void channel_consts(const BnParams& p, int c, float& mean, float& a, float& b, float& invstd) {
     mean = p.mean[c];
@@ -45,7 +73,7 @@ __device__ __forceinline__ void channel_consts(const BnParams& p, int c, float& 
 }
 
 // grid = C * split workgroups of 256 threads; workgroup (c, k) covers samples [k * N / split, (k + 1) * N / split)
-template <bool VEC, bool BACKWARD>
+template <typename T, bool VEC, bool BACKWARD>
 __global__ __launch_bounds__(256) void bn_act_kernel(BnParams p) {
     const int c = blockIdx.x / p.split, k = blockIdx.x % p.split;
     const int n0 = (int)((int64_t)k * p.N / p.split), n1 = (int)((int64_t)(k + 1) * p.N / p.split);
@@ -62,20 +90,13 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnParams p) {
         const int64_t o = ((int64_t)n * p.C + c) * p.HW + (int64_t)j * W;
         float xv[W], rv[W], gv[W];
         if (VEC) {
-            const float4 t = *reinterpret_cast<const float4*>(p.x + o);
-            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-            if (p.residual) {
-                const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
-                rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
-            }
-            if (BACKWARD) {
-                const float4 g = *reinterpret_cast<const float4*>(p.grad_y + o);
-                gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
-            }
+            load4<T>(p.x, o, xv);
+            if (p.residual) load4<T>(p.residual, o, rv);
+            if (BACKWARD) load4<T>(p.grad_y, o, gv);
         } else {
-            xv[0] = p.x[o];
-            if (p.residual) rv[0] = p.residual[o];
-            if (BACKWARD) gv[0] = p.grad_y[o];
+            xv[0] = to_f32(static_cast<const T*>(p.x)[o]);
+            if (p.residual) rv[0] = to_f32(static_cast<const T*>(p.residual)[o]);
+            if (BACKWARD) gv[0] = to_f32(static_cast<const T*>(p.grad_y)[o]);
         }
         float out[W], gres[W];
 #pragma unroll
@@ -93,14 +114,13 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnParams p) {
                 sum_gx += g * d;
             }
         }
-        float* dst = BACKWARD ? p.grad_x : p.y;
+        void* dst = BACKWARD ? p.grad_x : p.y;
         if (VEC) {
-            *reinterpret_cast<float4*>(dst + o) = make_float4(out[0], out[1], out[2], out[3]);
-            if (BACKWARD && p.grad_residual)
-                *reinterpret_cast<float4*>(p.grad_residual + o) = make_float4(gres[0], gres[1], gres[2], gres[3]);
+            store4<T>(dst, o, out);
+            if (BACKWARD && p.grad_residual) store4<T>(p.grad_residual, o, gres);
         } else {
-            dst[o] = out[0];
-            if (BACKWARD && p.grad_residual) p.grad_residual[o] = gres[0];
+            static_cast<T*>(dst)[o] = from_f32<T>(out[0]);
+            if (BACKWARD && p.grad_residual) static_cast<T*>(p.grad_residual)[o] = from_f32<T>(gres[0]);
         }
     }
     if (BACKWARD && p.partial) {
@@ -148,15 +168,27 @@ static inline int bn_split(int N, int C) {
     return s;
 }
 
-static inline bool bn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline bool bn_aligned(const void* p, int bytes) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(bytes - 1)) == 0; }
+
+template <bool BACKWARD>
+static void bn_launch(const BnParams& p, int act_dtype, bool vec, hipStream_t s) {
+    const dim3 grid((unsigned)(p.C * p.split));
+    if (act_dtype == 0) {
+        if (vec) hipLaunchKernelGGL((bn_act_kernel<float, true, BACKWARD>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((bn_act_kernel<float, false, BACKWARD>), grid, dim3(256), 0, s, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((bn_act_kernel<bf16_t, true, BACKWARD>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((bn_act_kernel<bf16_t, false, BACKWARD>), grid, dim3(256), 0, s, p);
+    }
+}
 
 }  // namespace mr
 
-extern "C" int mr_bn_act_forward(const float* x, const float* residual, const float* weight, const float* bias,
-                                 const float* running_mean, const float* running_var, float eps, int relu, float* y,
-                                 int batch_size, int channels, int plane, mr_stream_t stream) {
+extern "C" int mr_bn_act_forward(const void* x, const void* residual, const float* weight, const float* bias,
+                                 const float* running_mean, const float* running_var, float eps, int relu, int act_dtype,
+                                 void* y, int batch_size, int channels, int plane, mr_stream_t stream) {
     using namespace mr;
-    if (batch_size < 0 || channels < 0 || plane < 0) return MR_ERR_BADARG;
+    if (batch_size < 0 || channels < 0 || plane < 0 || (act_dtype != 0 && act_dtype != 1)) return MR_ERR_BADARG;
     if (batch_size == 0 || channels == 0 || plane == 0) return MR_OK;
     if (!x || !weight || !bias || !running_mean || !running_var || !y) return MR_ERR_BADARG;
     BnParams p{};
@@ -164,10 +196,9 @@ extern "C" int mr_bn_act_forward(const float* x, const float* residual, const fl
     p.eps = eps; p.relu = relu; p.N = batch_size; p.C = channels; p.HW = plane; p.split = bn_split(batch_size, channels);
     p.y = y;
     if ((int64_t)channels * p.split > 0x7fffffff || ((int64_t)batch_size / p.split + 1) * plane > 0x7fffffff) return MR_ERR_BADARG;
-    const bool vec = plane % 4 == 0 && bn_aligned16(x) && bn_aligned16(y) && bn_aligned16(residual);
-    const dim3 grid((unsigned)(channels * p.split));
-    if (vec) hipLaunchKernelGGL((bn_act_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((bn_act_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    const int vb = act_dtype == 0 ? 16 : 8;  // bytes of a 4-element access
+    const bool vec = plane % 4 == 0 && bn_aligned(x, vb) && bn_aligned(y, vb) && bn_aligned(residual, vb);
+    bn_launch<false>(p, act_dtype, vec, (hipStream_t)stream);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -177,13 +208,13 @@ extern "C" int64_t mr_bn_act_backward_workspace_bytes(int batch_size, int channe
     return (int64_t)2 * channels * mr::bn_split(batch_size > 0 ? batch_size : 1, channels > 0 ? channels : 1) * 4 + 16;
 }
 
-extern "C" int mr_bn_act_backward(const float* grad_y, const float* x, const float* residual, const float* weight,
+extern "C" int mr_bn_act_backward(const void* grad_y, const void* x, const void* residual, const float* weight,
                                   const float* bias, const float* running_mean, const float* running_var, float eps,
-                                  int relu, float* grad_x, float* grad_residual, float* grad_weight, float* grad_bias,
-                                  void* workspace, int64_t workspace_bytes, int batch_size, int channels, int plane,
-                                  mr_stream_t stream) {
+                                  int relu, int act_dtype, void* grad_x, void* grad_residual, float* grad_weight,
+                                  float* grad_bias, void* workspace, int64_t workspace_bytes, int batch_size,
+                                  int channels, int plane, mr_stream_t stream) {
     using namespace mr;
-    if (batch_size < 0 || channels < 0 || plane < 0) return MR_ERR_BADARG;
+    if (batch_size < 0 || channels < 0 || plane < 0 || (act_dtype != 0 && act_dtype != 1)) return MR_ERR_BADARG;
     if (channels == 0) return MR_OK;
     if (!weight || !bias || !running_mean || !running_var) return MR_ERR_BADARG;
     const bool want_params = grad_weight || grad_bias;
@@ -203,11 +234,10 @@ extern "C" int mr_bn_act_backward(const float* grad_y, const float* x, const flo
     p.grad_y = grad_y; p.grad_x = grad_x; p.grad_residual = grad_residual;
     p.partial = want_params ? static_cast<float*>(workspace) : nullptr;
     if ((int64_t)channels * p.split > 0x7fffffff || ((int64_t)batch_size / p.split + 1) * plane > 0x7fffffff) return MR_ERR_BADARG;
-    const bool vec = plane % 4 == 0 && bn_aligned16(x) && bn_aligned16(grad_y) && bn_aligned16(grad_x) &&
-                     bn_aligned16(residual) && bn_aligned16(grad_residual);
-    const dim3 grid((unsigned)(channels * p.split));
-    if (vec) hipLaunchKernelGGL((bn_act_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((bn_act_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    const int vb = act_dtype == 0 ? 16 : 8;
+    const bool vec = plane % 4 == 0 && bn_aligned(x, vb) && bn_aligned(grad_y, vb) && bn_aligned(grad_x, vb) &&
+                     bn_aligned(residual, vb) && bn_aligned(grad_residual, vb);
+    bn_launch<true>(p, act_dtype, vec, (hipStream_t)stream);
     MR_CHECK_LAUNCH();
     if (want_params) {
         hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)channels), dim3(64), 0, (hipStream_t)stream, p.partial,

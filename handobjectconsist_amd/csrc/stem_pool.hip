@@ -12,7 +12,7 @@
 namespace mr {
 
 struct StemParams {
-    const float* x;       // [N,C,H,W] convolution output
+    const void* x;        // [N,C,H,W] convolution output, fp32 or bf16 (the activation type T of the kernels)
     const float* weight;  // [C]
     const float* bias;
     const float* mean;
@@ -20,9 +20,9 @@ struct StemParams {
     float eps;
     int N, C, H, W, OH, OW;   // OH = (H - 1) / 2 + 1
     int tiles_x, tiles_y;
-    float* y;             // forward: [N,C,OH,OW]
-    const float* grad_y;  // backward
-    float* grad_x;        // [N,C,H,W]
+    void* y;              // forward: [N,C,OH,OW]
+    const void* grad_y;   // backward
+    void* grad_x;         // [N,C,H,W]
     float* partial;       // [2][C][N * tiles]: sum g, sum g * (x - mean)
 };
 
@@ -33,6 +33,21 @@ constexpr int SP_TX = 32, SP_TY = 16;  // windows (= pooled pixels) per tile
 constexpr int SP_IH = 2 * SP_TY + 3, SP_IW = 2 * SP_TX + 8, SP_C0 = 4;
 constexpr int SP_LDW = SP_IW + 1;
 
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float sp_f32(float v) { return v; }
+__device__ __forceinline__ float sp_f32(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+template <typename T> __device__ __forceinline__ T sp_from(float v);
+template <> __device__ __forceinline__ float sp_from<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t sp_from<bf16_t>(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+template <typename T> struct SpVec4;
+template <> struct SpVec4<float> { typedef float4 type; };
+template <> struct SpVec4<bf16_t> { typedef ushort4 type; };
+
 __device__ __forceinline__ void stem_consts(const StemParams& p, int c, float& mean, float& a, float& b) {
     mean = p.mean[c];
     a = p.weight[c] * (1.0f / sqrtf(p.var[c] + p.eps));
@@ -40,20 +55,20 @@ __device__ __forceinline__ void stem_consts(const StemParams& p, int c, float& m
 }
 
 // z = bn(x) (and d = x - mean) of the tile's input region into LDS; -inf / 0 outside the image
-template <bool KEEP_D>
-__device__ __forceinline__ void load_tile(const StemParams& p, const float* xp, int oy0, int ox0, float mean, float a,
+template <typename T, bool KEEP_D>
+__device__ __forceinline__ void load_tile(const StemParams& p, const T* xp, int oy0, int ox0, float mean, float a,
                                           float b, float (*zt)[SP_LDW], float (*dt)[SP_LDW]) {
     const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - SP_C0;
     const float ninf = -__builtin_inff();
-    if ((p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 15) == 0) {
+    if ((p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & (4 * sizeof(T) - 1)) == 0) {
         for (int e = threadIdx.x; e < SP_IH * (SP_IW / 4); e += 256) {
             const int r = e / (SP_IW / 4), q = e - r * (SP_IW / 4);
             const int iy = iy0 + r, ix = ix0 + 4 * q;  // a float4 is entirely inside or entirely outside the row
             float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             if (in) {
-                const float4 t = *reinterpret_cast<const float4*>(xp + (int64_t)iy * p.W + ix);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                const typename SpVec4<T>::type t = *reinterpret_cast<const typename SpVec4<T>::type*>(xp + (int64_t)iy * p.W + ix);
+                v[0] = sp_f32(t.x); v[1] = sp_f32(t.y); v[2] = sp_f32(t.z); v[3] = sp_f32(t.w);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -69,7 +84,7 @@ __device__ __forceinline__ void load_tile(const StemParams& p, const float* xp, 
         const int iy = iy0 + r, ix = ix0 + c;
         float z = ninf, d = 0.0f;
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-            d = xp[(int64_t)iy * p.W + ix] - mean;
+            d = sp_f32(xp[(int64_t)iy * p.W + ix]) - mean;
             z = d * a + b;
         }
         zt[r][c] = z;
@@ -78,6 +93,7 @@ __device__ __forceinline__ void load_tile(const StemParams& p, const float* xp, 
 }
 
 // grid = N * C * tiles workgroups of 256 threads
+template <typename T>
 __global__ __launch_bounds__(256) void stem_pool_forward_kernel(StemParams p) {
     __shared__ float zt[SP_IH][SP_LDW];
     const int tiles = p.tiles_x * p.tiles_y;
@@ -86,7 +102,7 @@ __global__ __launch_bounds__(256) void stem_pool_forward_kernel(StemParams p) {
     const int oy0 = (t / p.tiles_x) * SP_TY, ox0 = (t % p.tiles_x) * SP_TX;
     float mean, a, b;
     stem_consts(p, c, mean, a, b);
-    load_tile<false>(p, p.x + (int64_t)plane * p.H * p.W, oy0, ox0, mean, a, b, zt, nullptr);
+    load_tile<T, false>(p, static_cast<const T*>(p.x) + (int64_t)plane * p.H * p.W, oy0, ox0, mean, a, b, zt, nullptr);
     __syncthreads();
     for (int e = threadIdx.x; e < SP_TY * SP_TX; e += 256) {
         const int wy = e / SP_TX, wx = e % SP_TX;
@@ -97,10 +113,11 @@ __global__ __launch_bounds__(256) void stem_pool_forward_kernel(StemParams p) {
         for (int kh = 0; kh < 3; kh++)
 #pragma unroll
             for (int kw = 0; kw < 3; kw++) m = fmaxf(m, zt[2 * wy + kh][2 * wx + kw + SP_C0 - 1]);
-        p.y[((int64_t)plane * p.OH + oy) * p.OW + ox] = m;
+        static_cast<T*>(p.y)[((int64_t)plane * p.OH + oy) * p.OW + ox] = sp_from<T>(m);
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
     __shared__ float zt[SP_IH][SP_LDW];
     __shared__ float dt[SP_IH][SP_LDW];                 // x - mean of the same region (for grad_weight)
@@ -113,8 +130,8 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
     const int oy0 = (t / p.tiles_x) * SP_TY, ox0 = (t % p.tiles_x) * SP_TX;
     float mean, a, b;
     stem_consts(p, c, mean, a, b);
-    const float* xp = p.x + (int64_t)plane * p.H * p.W;
-    load_tile<true>(p, xp, oy0, ox0, mean, a, b, zt, dt);
+    const T* xp = static_cast<const T*>(p.x) + (int64_t)plane * p.H * p.W;
+    load_tile<T, true>(p, xp, oy0, ox0, mean, a, b, zt, dt);
     __syncthreads();
     // windows oy0 .. oy0 + TY, ox0 .. ox0 + TX: the owned input rows 2 oy0 .. 2 (oy0 + TY) - 1 touch one window more
     for (int e = threadIdx.x; e < (SP_TY + 1) * (SP_TX + 1); e += 256) {
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
         float g = 0.0f;
         int best = 0;
         if (oy < p.OH && ox < p.OW) {
-            g = p.grad_y[((int64_t)plane * p.OH + oy) * p.OW + ox];
+            g = sp_f32(static_cast<const T*>(p.grad_y)[((int64_t)plane * p.OH + oy) * p.OW + ox]);
             float mv = -__builtin_inff();  // PyTorch: first strictly greater value of relu(z) in (kh, kw) order, padding skipped
 #pragma unroll
             for (int k = 0; k < 9; k++) {
@@ -138,8 +155,8 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
     __syncthreads();
     // gather: owned input pixels rows 2 oy0 + [0, 2 TY), columns 2 ox0 + [0, 2 TX); LDS row = input row - (2 oy0 - 1)
     float sum_g = 0.0f, sum_gx = 0.0f;
-    float* gx = p.grad_x + (int64_t)plane * p.H * p.W;
-    const bool vec = (p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0;
+    T* gx = static_cast<T*>(p.grad_x) + (int64_t)plane * p.H * p.W;
+    const bool vec = (p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(gx) & (4 * sizeof(T) - 1)) == 0;
     for (int e = threadIdx.x; e < 2 * SP_TY * (2 * SP_TX / 4); e += 256) {  // four consecutive owned pixels per item
         const int ry = e / (2 * SP_TX / 4), rx0 = 4 * (e - ry * (2 * SP_TX / 4));
         const int iy = 2 * oy0 + ry, ix0 = 2 * ox0 + rx0;
@@ -170,13 +187,15 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
             sum_g += gm;
             sum_gx += gm * dt[ly][lx + SP_C0 - 1];
         }
-        float* dst = gx + (int64_t)iy * p.W + ix0;
+        T* dst = gx + (int64_t)iy * p.W + ix0;
         if (vec) {
-            *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+            typename SpVec4<T>::type t;
+            t.x = sp_from<T>(out[0]); t.y = sp_from<T>(out[1]); t.z = sp_from<T>(out[2]); t.w = sp_from<T>(out[3]);
+            *reinterpret_cast<typename SpVec4<T>::type*>(dst) = t;
         } else {
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (ix0 + i < p.W) dst[i] = out[i];
+                if (ix0 + i < p.W) dst[i] = sp_from<T>(out[i]);
         }
     }
     if (p.partial) {
@@ -222,7 +241,7 @@ __global__ __launch_bounds__(256) void stem_finish_kernel(const float* __restric
     }
 }
 
-static int stem_fill(StemParams& p, const float* x, const float* weight, const float* bias, const float* mean,
+static int stem_fill(StemParams& p, const void* x, const float* weight, const float* bias, const float* mean,
                      const float* var, float eps, int N, int C, int H, int W) {
     if (N < 0 || C < 0 || H < 0 || W < 0) return MR_ERR_BADARG;
     p.x = x; p.weight = weight; p.bias = bias; p.mean = mean; p.var = var; p.eps = eps;
@@ -237,18 +256,20 @@ static int stem_fill(StemParams& p, const float* x, const float* weight, const f
 
 }  // namespace mr
 
-extern "C" int mr_stem_pool_forward(const float* x, const float* weight, const float* bias, const float* running_mean,
-                                    const float* running_var, float eps, float* y, int batch_size, int channels,
-                                    int height, int width, mr_stream_t stream) {
+extern "C" int mr_stem_pool_forward(const void* x, const float* weight, const float* bias, const float* running_mean,
+                                    const float* running_var, float eps, int act_dtype, void* y, int batch_size,
+                                    int channels, int height, int width, mr_stream_t stream) {
     using namespace mr;
+    if (act_dtype != 0 && act_dtype != 1) return MR_ERR_BADARG;
     StemParams p{};
     const int rc = stem_fill(p, x, weight, bias, running_mean, running_var, eps, batch_size, channels, height, width);
     if (rc != MR_OK) return rc;
     if (batch_size == 0 || channels == 0 || height == 0 || width == 0) return MR_OK;
     if (!x || !weight || !bias || !running_mean || !running_var || !y) return MR_ERR_BADARG;
     p.y = y;
-    hipLaunchKernelGGL(stem_pool_forward_kernel, dim3((unsigned)((int64_t)batch_size * channels * p.tiles_x * p.tiles_y)),
-                       dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)((int64_t)batch_size * channels * p.tiles_x * p.tiles_y));
+    if (act_dtype == 0) hipLaunchKernelGGL(stem_pool_forward_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(stem_pool_forward_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -260,11 +281,13 @@ extern "C" int64_t mr_stem_pool_backward_workspace_bytes(int batch_size, int cha
     return (int64_t)2 * channels * batch_size * p.tiles_x * p.tiles_y * 4 + 16;
 }
 
-extern "C" int mr_stem_pool_backward(const float* grad_y, const float* x, const float* weight, const float* bias,
-                                     const float* running_mean, const float* running_var, float eps, float* grad_x,
-                                     float* grad_weight, float* grad_bias, void* workspace, int64_t workspace_bytes,
-                                     int batch_size, int channels, int height, int width, mr_stream_t stream) {
+extern "C" int mr_stem_pool_backward(const void* grad_y, const void* x, const float* weight, const float* bias,
+                                     const float* running_mean, const float* running_var, float eps, int act_dtype,
+                                     void* grad_x, float* grad_weight, float* grad_bias, void* workspace,
+                                     int64_t workspace_bytes, int batch_size, int channels, int height, int width,
+                                     mr_stream_t stream) {
     using namespace mr;
+    if (act_dtype != 0 && act_dtype != 1) return MR_ERR_BADARG;
     StemParams p{};
     const int rc = stem_fill(p, x, weight, bias, running_mean, running_var, eps, batch_size, channels, height, width);
     if (rc != MR_OK) return rc;
@@ -283,8 +306,9 @@ extern "C" int mr_stem_pool_backward(const float* grad_y, const float* x, const 
     p.grad_y = grad_y; p.grad_x = grad_x;
     p.partial = want_params ? static_cast<float*>(workspace) : nullptr;
     const int tiles = p.tiles_x * p.tiles_y;
-    hipLaunchKernelGGL(stem_pool_backward_kernel, dim3((unsigned)((int64_t)batch_size * channels * tiles)), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    const dim3 grid((unsigned)((int64_t)batch_size * channels * tiles));
+    if (act_dtype == 0) hipLaunchKernelGGL(stem_pool_backward_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(stem_pool_backward_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
     MR_CHECK_LAUNCH();
     if (want_params) {
         hipLaunchKernelGGL(stem_finish_kernel, dim3((unsigned)channels), dim3(256), 0, (hipStream_t)stream, p.partial,

@@ -35,14 +35,15 @@ from handobjectconsist_amd.utils import synth
 # ----------------------------------------------------------------------------- ResNet-18
 # BatchNorm (frozen statistics, --freeze_batchnorm) + residual add + ReLU as one HIP kernel each way instead of
 # stock PyTorch's 2-3 element-wise kernels forward and batch_norm_backward + threshold_backward (10.7 of the
-# 42 ms of a step).  HOC_HIP_BN=0 / USE_HIP_BN=False: the stock modules.  Only for fp32 CUDA activations of a
-# module in eval mode; anything else (bf16 autocast, BatchNorm in training mode, CPU) takes the stock path.
+# 42 ms of a step).  HOC_HIP_BN=0 / USE_HIP_BN=False: the stock modules.  For fp32 or bf16 (autocast) CUDA
+# activations of a module in eval mode; anything else (BatchNorm in training mode, CPU) takes the stock path.
 USE_HIP_BN = os.environ.get("HOC_HIP_BN", "1") == "1"
 
 
 def _fused_bn(bn, x):
-    return (USE_HIP_BN and not bn.training and x.is_cuda and x.dtype == torch.float32
-            and not torch.is_autocast_enabled())
+    # x is the convolution's input here; under bf16 autocast the convolution outputs (the BN inputs) are bf16,
+    # which the kernels take as well
+    return USE_HIP_BN and not bn.training and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
 
 
 class BasicBlock(nn.Module):

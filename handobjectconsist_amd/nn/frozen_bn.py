@@ -7,25 +7,28 @@ import torch
 from handobjectconsist_amd import _lib
 
 
+_ACT_DTYPES = {torch.float32: 0, torch.bfloat16: 1}  # act_dtype of the C-ABI
+
+
 class _BnActFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, relu):
         _lib.check_cuda(x, residual, weight, bias, running_mean, running_var)
-        if x.dim() < 2 or x.dtype != torch.float32:
-            raise ValueError("expected an fp32 [N, C, ...] tensor")
+        if x.dim() < 2 or x.dtype not in _ACT_DTYPES:
+            raise ValueError("expected an fp32 or bf16 [N, C, ...] tensor")
         xc = x.contiguous()
         rc = residual.contiguous() if residual is not None else None
-        if rc is not None and (rc.shape != xc.shape or rc.dtype != torch.float32):
+        if rc is not None and (rc.shape != xc.shape or rc.dtype != xc.dtype):
             raise ValueError("residual must match x")
         N, C = xc.shape[:2]
         plane = xc[0, 0].numel() if N and C else 0
-        w, b = weight.detach().contiguous(), bias.detach().contiguous()
-        m, v = running_mean.contiguous(), running_var.contiguous()
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        m, v = running_mean.float().contiguous(), running_var.float().contiguous()
         if not (w.shape == b.shape == m.shape == v.shape == (C,)):
             raise ValueError("channel arrays must be [C]")
         y = torch.empty_like(xc)
         _lib.call("mr_bn_act_forward", _lib.ptr(xc), _lib.ptr(rc), _lib.ptr(w), _lib.ptr(b), _lib.ptr(m), _lib.ptr(v),
-                  float(eps), int(bool(relu)), _lib.ptr(y), N, C, plane, _lib.stream_ptr(xc.device))
+                  float(eps), int(bool(relu)), _ACT_DTYPES[xc.dtype], _lib.ptr(y), N, C, plane, _lib.stream_ptr(xc.device))
         ctx.save_for_backward(xc, rc, w, b, m, v)
         ctx.cfg = (float(eps), bool(relu), N, C, plane)
         return y
@@ -35,7 +38,7 @@ class _BnActFunction(torch.autograd.Function):
         xc, rc, w, b, m, v = ctx.saved_tensors
         eps, relu, N, C, plane = ctx.cfg
         need_x, need_r, need_w, need_b = ctx.needs_input_grad[:4]
-        g = grad_y.contiguous()
+        g = grad_y.to(xc.dtype).contiguous()
         dev = xc.device
         grad_x = torch.empty_like(xc)
         grad_r = torch.empty_like(xc) if (rc is not None and need_r) else None
@@ -44,7 +47,8 @@ class _BnActFunction(torch.autograd.Function):
         wbytes = int(_lib.load().mr_bn_act_backward_workspace_bytes(N, C))
         work = torch.empty((wbytes,), dtype=torch.uint8, device=dev) if (need_w or need_b) else None
         _lib.call("mr_bn_act_backward", _lib.ptr(g), _lib.ptr(xc), _lib.ptr(rc), _lib.ptr(w), _lib.ptr(b), _lib.ptr(m),
-                  _lib.ptr(v), eps, int(relu), _lib.ptr(grad_x), _lib.ptr(grad_r), _lib.ptr(grad_w), _lib.ptr(grad_b),
+                  _lib.ptr(v), eps, int(relu), _ACT_DTYPES[xc.dtype], _lib.ptr(grad_x), _lib.ptr(grad_r), _lib.ptr(grad_w),
+                  _lib.ptr(grad_b),
                   _lib.ptr(work), wbytes, N, C, plane, _lib.stream_ptr(dev))
         return (grad_x if need_x else None), grad_r, grad_w, grad_b, None, None, None, None
 
@@ -60,16 +64,16 @@ class _StemPoolFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps):
         _lib.check_cuda(x, weight, bias, running_mean, running_var)
-        if x.dim() != 4 or x.dtype != torch.float32:
-            raise ValueError("expected an fp32 [N, C, H, W] tensor")
+        if x.dim() != 4 or x.dtype not in _ACT_DTYPES:
+            raise ValueError("expected an fp32 or bf16 [N, C, H, W] tensor")
         xc = x.contiguous()
         N, C, H, W = xc.shape
-        w, b = weight.detach().contiguous(), bias.detach().contiguous()
-        m, v = running_mean.contiguous(), running_var.contiguous()
-        y = torch.empty((N, C, (H - 1) // 2 + 1 if H else 0, (W - 1) // 2 + 1 if W else 0), dtype=torch.float32,
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        m, v = running_mean.float().contiguous(), running_var.float().contiguous()
+        y = torch.empty((N, C, (H - 1) // 2 + 1 if H else 0, (W - 1) // 2 + 1 if W else 0), dtype=xc.dtype,
                         device=xc.device)
         _lib.call("mr_stem_pool_forward", _lib.ptr(xc), _lib.ptr(w), _lib.ptr(b), _lib.ptr(m), _lib.ptr(v), float(eps),
-                  _lib.ptr(y), N, C, H, W, _lib.stream_ptr(xc.device))
+                  _ACT_DTYPES[xc.dtype], _lib.ptr(y), N, C, H, W, _lib.stream_ptr(xc.device))
         ctx.save_for_backward(xc, w, b, m, v)
         ctx.eps = float(eps)
         return y
@@ -79,14 +83,15 @@ class _StemPoolFunction(torch.autograd.Function):
         xc, w, b, m, v = ctx.saved_tensors
         N, C, H, W = xc.shape
         need_x, need_w, need_b = ctx.needs_input_grad[:3]
-        g = grad_y.contiguous()
+        g = grad_y.to(xc.dtype).contiguous()
         grad_x = torch.empty_like(xc)
         grad_w = torch.empty_like(w) if need_w else None
         grad_b = torch.empty_like(b) if need_b else None
         wbytes = int(_lib.load().mr_stem_pool_backward_workspace_bytes(N, C, H, W))
         work = torch.empty((wbytes,), dtype=torch.uint8, device=xc.device) if (need_w or need_b) else None
         _lib.call("mr_stem_pool_backward", _lib.ptr(g), _lib.ptr(xc), _lib.ptr(w), _lib.ptr(b), _lib.ptr(m), _lib.ptr(v),
-                  ctx.eps, _lib.ptr(grad_x), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(work), wbytes, N, C, H, W,
+                  ctx.eps, _ACT_DTYPES[xc.dtype], _lib.ptr(grad_x), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(work), wbytes,
+                  N, C, H, W,
                   _lib.stream_ptr(xc.device))
         return (grad_x if need_x else None), grad_w, grad_b, None, None, None
 

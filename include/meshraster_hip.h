@@ -371,18 +371,20 @@ MR_API int mr_frames_to_batch(const uint8_t* frames, const double* coeffs, const
  * or by nothing (resnet.py:46-58, 31-43).  One pass each way instead of 2-3 element-wise kernels forward and
  * batch_norm_backward + threshold_backward:
  *   z = (x - running_mean) * (weight / sqrt(running_var + eps)) + bias [+ residual];  y = relu ? max(z, 0) : z
- * x, residual, y, grad_*: [batch_size, channels, plane] fp32 contiguous (NCHW, plane = H * W); the channel
- * arrays are [channels].  Backward: g = relu && !(z > 0) ? 0 : grad_y;  grad_x = g * weight / sqrt(var + eps);
+ * x, residual, y, grad_x, grad_y, grad_residual: [batch_size, channels, plane] contiguous (NCHW, plane = H * W)
+ * of the activation type act_dtype: 0 = fp32, 1 = bf16 (the trunk under bf16 autocast: converted on load, fp32
+ * arithmetic, rounded to nearest-even on store); the channel arrays and their gradients are fp32 [channels].  Backward: g = relu && !(z > 0) ? 0 : grad_y;  grad_x = g * weight / sqrt(var + eps);
  * grad_residual = g (NULL if not wanted); grad_bias = sum g; grad_weight = sum g * (x - mean) / sqrt(var + eps)
  * (either may be NULL; two-stage deterministic reduction through the workspace). */
-MR_API int mr_bn_act_forward(const float* x, const float* residual, const float* weight, const float* bias,
+MR_API int mr_bn_act_forward(const void* x, const void* residual, const float* weight, const float* bias,
                              const float* running_mean, const float* running_var, float eps, int relu,
-                             float* y, int batch_size, int channels, int plane, mr_stream_t stream);
+                             int act_dtype, void* y, int batch_size, int channels, int plane,
+                             mr_stream_t stream);
 MR_API int64_t mr_bn_act_backward_workspace_bytes(int batch_size, int channels);
-MR_API int mr_bn_act_backward(const float* grad_y, const float* x, const float* residual,
+MR_API int mr_bn_act_backward(const void* grad_y, const void* x, const void* residual,
                               const float* weight, const float* bias, const float* running_mean,
-                              const float* running_var, float eps, int relu, float* grad_x,
-                              float* grad_residual, float* grad_weight, float* grad_bias,
+                              const float* running_var, float eps, int relu, int act_dtype, void* grad_x,
+                              void* grad_residual, float* grad_weight, float* grad_bias,
                               void* workspace, int64_t workspace_bytes, int batch_size, int channels,
                               int plane, mr_stream_t stream);
 
@@ -390,16 +392,18 @@ MR_API int mr_bn_act_backward(const float* grad_y, const float* x, const float* 
  *   y = MaxPool2d(kernel 3, stride 2, padding 1)(relu(bn(x)))     x[N,C,H,W] -> y[N,C,(H-1)/2+1,(W-1)/2+1]
  * The full-resolution activation is never written; the backward recomputes it per tile, re-derives every
  * window's arg-max with PyTorch's rule (kh, kw ascending, strictly greater wins, padding skipped) and gathers the
- * pooled gradient per input pixel (no atomics).  grad_weight / grad_bias may be NULL. */
-MR_API int mr_stem_pool_forward(const float* x, const float* weight, const float* bias,
-                                const float* running_mean, const float* running_var, float eps, float* y,
-                                int batch_size, int channels, int height, int width, mr_stream_t stream);
+ * pooled gradient per input pixel (no atomics).  x, y, grad_x, grad_y are of act_dtype (0 = fp32, 1 = bf16);
+ * grad_weight / grad_bias (fp32) may be NULL. */
+MR_API int mr_stem_pool_forward(const void* x, const float* weight, const float* bias,
+                                const float* running_mean, const float* running_var, float eps,
+                                int act_dtype, void* y, int batch_size, int channels, int height, int width,
+                                mr_stream_t stream);
 MR_API int64_t mr_stem_pool_backward_workspace_bytes(int batch_size, int channels, int height, int width);
-MR_API int mr_stem_pool_backward(const float* grad_y, const float* x, const float* weight, const float* bias,
+MR_API int mr_stem_pool_backward(const void* grad_y, const void* x, const float* weight, const float* bias,
                                  const float* running_mean, const float* running_var, float eps,
-                                 float* grad_x, float* grad_weight, float* grad_bias, void* workspace,
-                                 int64_t workspace_bytes, int batch_size, int channels, int height,
-                                 int width, mr_stream_t stream);
+                                 int act_dtype, void* grad_x, float* grad_weight, float* grad_bias,
+                                 void* workspace, int64_t workspace_bytes, int batch_size, int channels,
+                                 int height, int width, mr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -64,7 +64,7 @@ def test_bn_act_rejects_training_mode_and_half(cuda):
         frozen_bn.bn_act(x, bn)
     bn.eval()
     with pytest.raises(ValueError):
-        frozen_bn.bn_act(x.half(), bn)
+        frozen_bn.bn_act(x.half(), bn)  # fp16 is not an activation type of the kernels (fp32 and bf16 are)
     with pytest.raises(TypeError):
         frozen_bn.bn_act(x.cpu(), bn)
     assert frozen_bn.bn_act(x[:0], bn).shape == (0, 4, 8, 8)
@@ -134,3 +134,93 @@ def test_stem_pool_matches_stock_modules(cuda, shape):
     _close(got[3], bn.bias.grad, tol, "grad bias")
     # exact structural property: every pooled gradient lands on exactly one input pixel (or on none if relu is off there)
     assert float(got[1].abs().sum()) > 0 or float(gy.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("shape,with_res", [((6, 64, 32, 32), True), ((5, 16, 17, 30), False), ((3, 512, 8, 8), True),
+                                            ((7, 5, 3, 5), True)])
+def test_bn_act_bf16_activations(cuda, shape, with_res):
+    """bf16 activations (the trunk under autocast): fp32 arithmetic on the converted values, one rounding on store --
+    compared with the same computation in fp32 on the bf16-representable inputs."""
+    from handobjectconsist_amd.nn import frozen_bn
+
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C).to(cuda).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.4)
+        bn.running_var.copy_(torch.rand(C, generator=g) * 2 + 0.05)
+    x = torch.randn(shape, generator=g).to(cuda).bfloat16().requires_grad_(True)
+    res = torch.randn(shape, generator=g).to(cuda).bfloat16().requires_grad_(True) if with_res else None
+    gy = torch.randn(shape, generator=g).to(cuda).bfloat16()
+    y = frozen_bn.bn_act(x, bn, residual=res, relu=True)
+    assert y.dtype == torch.bfloat16
+    y.backward(gy)
+    xf = x.detach().float().requires_grad_(True)
+    rf = res.detach().float().requires_grad_(True) if with_res else None
+    gw, gb = bn.weight.grad.clone(), bn.bias.grad.clone()
+    bn.weight.grad = bn.bias.grad = None
+    ref = frozen_bn.bn_act(xf, bn, residual=rf, relu=True)   # the fp32 kernel (itself checked against stock PyTorch)
+    ref.backward(gy.float())
+    assert torch.equal(y, ref.detach().bfloat16())           # same arithmetic, one rounding to nearest-even
+    assert torch.equal(x.grad, xf.grad.bfloat16()) and x.grad.dtype == torch.bfloat16
+    if with_res:
+        assert torch.equal(res.grad, rf.grad.bfloat16())
+    _close(gw, bn.weight.grad, 1e-5, "grad weight")
+    _close(gb, bn.bias.grad, 1e-5, "grad bias")
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 32, 32), (3, 5, 17, 31), (2, 4, 135, 240)])
+def test_stem_pool_bf16_activations(cuda, shape):
+    from handobjectconsist_amd.nn import frozen_bn
+
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C).to(cuda).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.4)
+        bn.running_var.copy_(torch.rand(C, generator=g) * 2 + 0.05)
+    x = torch.randn(shape, generator=g).to(cuda).bfloat16().requires_grad_(True)
+    y = frozen_bn.stem_pool(x, bn)
+    gy = torch.randn(y.shape, generator=g).to(cuda).bfloat16()
+    y.backward(gy)
+    gw, gb = bn.weight.grad.clone(), bn.bias.grad.clone()
+    bn.weight.grad = bn.bias.grad = None
+    xf = x.detach().float().requires_grad_(True)
+    ref = frozen_bn.stem_pool(xf, bn)
+    ref.backward(gy.float())
+    assert y.dtype == torch.bfloat16 and torch.equal(y, ref.detach().bfloat16())
+    assert torch.equal(x.grad, xf.grad.bfloat16())
+    _close(gw, bn.weight.grad, 1e-5, "grad weight")
+    _close(gb, bn.bias.grad, 1e-5, "grad bias")
+
+
+def test_resnet_trunk_bf16_autocast_fused_no_worse_than_stock(cuda, monkeypatch):
+    """Whole trunk under bf16 autocast: rounding noise is amplified through 17 random-weight layers, so the fused and
+    the stock bf16 runs are each compared with the fp32 run -- the fused path (which rounds once per group instead of
+    after every element-wise module) must not be further from it than the stock bf16 path is."""
+    from handobjectconsist_amd.models import synthnet
+
+    torch.manual_seed(0)
+    net = synthnet.ResNet18Features().to(cuda).eval()
+    x = torch.randn(4, 3, 64, 64, device=cuda)
+
+    def run(fused, autocast):
+        monkeypatch.setattr(synthnet, "USE_HIP_BN", fused)
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            feats = net(x)
+        feats.float().sum().backward()
+        return feats.detach().float(), net.conv1.weight.grad.clone()
+
+    ref = run(False, False)
+    stock, fused = run(False, True), run(True, True)
+    for i, what in enumerate(("features", "stem weight gradient")):
+        e_stock = float((stock[i] - ref[i]).abs().max())
+        e_fused = float((fused[i] - ref[i]).abs().max())
+        scale = float(ref[i].abs().max())
+        assert e_fused <= 1.5 * e_stock + 1e-3 * scale, (what, e_fused, e_stock, scale)
+        assert e_fused <= 0.2 * scale, (what, e_fused, scale)
