@@ -362,3 +362,83 @@ for case in range(min(n_cases, 300)):
         bad5 += 1
         print(f"seed {seed} B={B} Vo={Vo} rot scale {rs:.1e}: " + "; ".join(msg))
 print(f"sweep 5 (head post-processing): {min(n_cases, 300)} cases, {bad5} with mismatches")
+
+# ---- sixth sweep: trunk glue kernels (frozen BN + identity + ReLU; stem BN + ReLU + max-pool) vs the stock modules
+import torch.nn.functional as TF
+from handobjectconsist_amd.nn import frozen_bn
+bad6 = 0
+for case in range(min(n_cases, 300)):
+    seed = seed0 + 500000 + case
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi, (1,), generator=g))
+    N, C, H, Wd = ri(1, 9), ri(1, 70), ri(1, 70), ri(1, 70)
+    if case % 7 == 0: H, Wd = 4 * ri(1, 20), 4 * ri(1, 20)
+    stem = case % 3 == 0
+    relu, with_res = bool(ri(0, 2)), bool(ri(0, 2)) and not stem
+    bn = torch.nn.BatchNorm2d(C).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g) * 0.7 + 0.8); bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.4); bn.running_var.copy_(torch.rand(C, generator=g) * 2 + 0.02)
+    x = torch.randn(N, C, H, Wd, generator=g).to(dev)
+    res = torch.randn(N, C, H, Wd, generator=g).to(dev) if with_res else None
+    outs = {}
+    for hip in (True, False):
+        xs = x.clone().requires_grad_(True)
+        rs_ = res.clone().requires_grad_(True) if with_res else None
+        bn.zero_grad(set_to_none=True)
+        if hip:
+            y = frozen_bn.stem_pool(xs, bn) if stem else frozen_bn.bn_act(xs, bn, residual=rs_, relu=relu)
+        else:
+            z = TF.batch_norm(xs, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+            zz = z if rs_ is None else z + rs_
+            y = TF.max_pool2d(TF.relu(z), 3, 2, 1) if stem else (TF.relu(zz) if relu else zz)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed)).to(dev)
+        y.backward(gy)
+        outs[hip] = (y.detach(), xs.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), None if rs_ is None else rs_.grad)
+    msg = []
+    a, b_ = outs[True], outs[False]
+    sc = lambda t_: float(t_.abs().max()) + 1e-20
+    if a[0].shape != b_[0].shape or float((a[0] - b_[0]).abs().max()) > 3e-6 * sc(b_[0]): msg.append("forward")
+    nbad = int(((a[1] - b_[1]).abs() > 1e-5 * sc(b_[1])).sum())      # a ReLU mask / arg-max may flip where z rounds across a tie
+    if nbad > max(3, x.numel() // 3000): msg.append(f"grad x differs at {nbad} of {x.numel()} elements")
+    tol = 3e-5 if nbad == 0 else 2e-2
+    for k, name in ((2, "grad weight"), (3, "grad bias")):
+        if float((a[k] - b_[k]).abs().max()) > tol * sc(b_[k]): msg.append(f"{name} err {float((a[k] - b_[k]).abs().max()):.2e} (scale {sc(b_[k]):.2e})")
+    if with_res and int(((a[4] - b_[4]).abs() > 1e-6 * sc(b_[4])).sum()) > max(3, x.numel() // 3000): msg.append("grad residual")
+    if msg:
+        bad6 += 1
+        print(f"seed {seed} {'stem' if stem else 'bn_act'} shape {(N, C, H, Wd)} relu={relu} res={with_res}: " + "; ".join(msg))
+print(f"sweep 6 (trunk glue kernels): {min(n_cases, 300)} cases, {bad6} with mismatches")
+
+# ---- seventh sweep: frames -> batch (Pillow's nearest affine transform, bit-exact) vs the oracle
+from handobjectconsist_amd.datasets import frames as frames_mod
+from oracle import augment_ref as AR
+bad7 = 0
+for case in range(min(n_cases, 200)):
+    seed = seed0 + 600000 + case
+    rng = np.random.default_rng(seed)
+    N, Hs, Ws = int(rng.integers(1, 5)), int(rng.integers(1, 90)), int(rng.integers(1, 90))
+    Wo, Ho = int(rng.integers(1, 100)), int(rng.integers(1, 70))
+    frames = rng.integers(0, 256, (N, Hs, Ws, 3), dtype=np.uint8)
+    coeffs = []
+    for n in range(N):
+        kind = int(rng.integers(0, 4))
+        if kind == 0: a = [rng.uniform(0.1, 4) * rng.choice([-1, 1]), 0, rng.uniform(-30, 60), 0, rng.uniform(0.1, 4) * rng.choice([-1, 1]), rng.uniform(-30, 60)]
+        elif kind == 1:
+            th, s_ = rng.uniform(-3.2, 3.2), rng.uniform(0.2, 3)
+            a = [s_ * np.cos(th), -s_ * np.sin(th), rng.uniform(-30, 60), s_ * np.sin(th), s_ * np.cos(th), rng.uniform(-30, 60)]
+        elif kind == 2: a = [float(rng.integers(-2, 3)), float(rng.integers(-1, 2)), float(rng.integers(-5, 40)), float(rng.integers(-1, 2)), float(rng.integers(-2, 3)), float(rng.integers(-5, 40))]
+        else: a = [rng.uniform(-2, 2) * 10.0 ** rng.integers(0, 5), rng.uniform(-1, 1), rng.uniform(-50000, 50000), rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-40, 40)]
+        coeffs.append([float(v) for v in a])
+    flip = rng.random(N) < 0.3
+    img, mask = frames_mod.frames_to_batch(t(frames), np.array(coeffs), (Wo, Ho), flip=flip)
+    img, mask = img.cpu().numpy(), mask.cpu().numpy()
+    ok = True
+    for n in range(N):
+        ref_u8, inside = AR.pil_affine_nearest(frames[n][:, ::-1] if flip[n] else frames[n], coeffs[n], (Wo, Ho))
+        ref = (ref_u8.astype(np.float32) / np.float32(255.0) - np.float32(0.5)).transpose(2, 0, 1)
+        ok = ok and np.array_equal(img[n], ref) and np.array_equal(mask[n, 0] == 1, inside)
+    if not ok:
+        bad7 += 1
+        print(f"seed {seed} N={N} src {Hs}x{Ws} -> {Ho}x{Wo}: mismatch")
+print(f"sweep 7 (frames -> batch): {min(n_cases, 200)} cases, {bad7} with mismatches")
