@@ -331,8 +331,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HOC_SHARE_GPU=1 (tests only): ranks beyond the device count share GPUs, with HOC_DIST_BACKEND=gloo -- RCCL
+    # refuses two ranks on one device; this is how a world_size-2 job is exercised on the one-GPU test box
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("HOC_SHARE_GPU", "0") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     # HOC_FORCE_DDP=1: take the multi-GPU code path (RCCL process group, DDP wrapper, barriers, max-over-ranks
     # all-reduce) with a single rank too -- how the path is exercised on a one-GPU box (tests/test_gpu_bench.py)
@@ -342,7 +345,11 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("HOC_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from handobjectconsist_amd import _lib
@@ -366,7 +373,7 @@ def main():
 
         # 8 MB buckets overlap the RCCL all-reduce with the encoder backward; frozen BN statistics
         # -> no buffer broadcast (the three forwards of a step share the buffers)
-        net = DDP(model, device_ids=[local_rank], bucket_cap_mb=8, broadcast_buffers=False)
+        net = DDP(model, device_ids=[dev_index], bucket_cap_mb=8, broadcast_buffers=False)
     ih_ = args.image_height or is_
     assert ih_ <= is_, "--image-height must not exceed --image-size (the raster is the square of the longer side)"
     premodel = WarpRegNet((is_, ih_), net, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
@@ -401,6 +408,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(loss).all(), "loss is not finite"
+    if dist is not None and os.environ.get("HOC_CHECK_REPLICAS", "0") == "1":
+        # data-parallel replicas must stay bit-identical: same averaged gradients, same Adam update on every rank
+        chk = torch.stack([p_.detach().double().sum() for p_ in model.parameters()]).sum().reshape(1)
+        allchk = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allchk, chk)
+        assert all(torch.equal(c_, allchk[0]) for c_ in allchk), f"replicas diverged: {[float(c_) for c_ in allchk]}"
 
     # hot path alone (2 renders, flows, occlusion, pair loss, backward to the vertices)
     hot_ms = None

@@ -40,7 +40,7 @@ def test_bench_single_process_line(cuda):
 
 @pytest.mark.gpu
 def test_bench_under_torchrun_rccl_ddp(cuda):
-    env = dict(os.environ, HOC_FORCE_DDP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HOC_FORCE_DDP="1", HOC_CHECK_REPLICAS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline",
            "--no-kernel-bench"] + SMALL
@@ -48,3 +48,20 @@ def test_bench_under_torchrun_rccl_ddp(cuda):
     assert res.returncode == 0, res.stderr[-2000:]
     line = _json_line(res.stdout)
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "dp1"
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_gpu_over_gloo(cuda):
+    """world_size 2 on the one-GPU box: both ranks on cuda:0, gradient all-reduce of DistributedDataParallel over gloo
+    (RCCL refuses two ranks per device).  Exercises what N > 1 adds -- per-rank seeds and loaders, DDP's bucketed
+    all-reduce through this build's autograd functions, the barrier + max-over-ranks timing, rank-0-only output;
+    HOC_CHECK_REPLICAS makes bench.py assert that the replicas' parameters are bit-identical after the steps."""
+    env = dict(os.environ, HOC_SHARE_GPU="1", HOC_DIST_BACKEND="gloo", HOC_CHECK_REPLICAS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline",
+           "--no-kernel-bench"] + SMALL
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _json_line(res.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["parallelism"] == "dp2"
+    assert line["config"]["global_batch"] == 8 and line["cpu_baseline"] is None
