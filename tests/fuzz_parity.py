@@ -80,7 +80,10 @@ for case in range(n_cases):
         if not np.isfinite(gotn).all() and np.isfinite(want).all(): msg.append(f"{name} non-finite")
         sc = np.abs(want[np.isfinite(want)]).max() if np.isfinite(want).any() else 1.0
         e = np.abs(np.nan_to_num(gotn - want)).max()
-        if e > 2e-4 * sc + 1e-6: msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
+        # absolute floor: a face covering the whole image sums is^2 unit-variance terms that largely cancel; the fp32
+        # rounding of that sum (sequential in the oracle, tree / atomic order on the GPU) is ~1e-6 * sqrt(is^2) whatever
+        # the size of the result (seed 201795: depth backward of a 1e4-NDC face over 62 x 62 px, 3.7e-5 on 0.063)
+        if e > 2e-4 * sc + 1e-6 * max(is_, 1): msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
     if case % 4 == 1:  # silhouette / depth entry points (module-default eps) and the anti-aliased render
         aa = bool(rng.random() < 0.5)
         sil = rasterize.rasterize_silhouettes(t(faces), is_, aa).cpu().numpy()
@@ -118,7 +121,7 @@ for case in range(n_cases):
         for got, want, name in ((x3.grad, gt_ref, "compat grad_textures"), (f3.grad, gf_ref, "compat grad_faces")):
             sc = np.abs(want[np.isfinite(want)]).max() if np.isfinite(want).any() else 1.0
             e = np.abs(np.nan_to_num(got.cpu().numpy().astype(np.float64) - want)).max()
-            if e > 2e-4 * sc + 1e-6: msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
+            if e > 2e-4 * sc + 1e-6 * max(is_, 1): msg.append(f"{name} err {e:.2e} (scale {sc:.2e})")
         rasterize.REFERENCE_ALGO = True
         try:
             f4, x4 = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
@@ -127,7 +130,7 @@ for case in range(n_cases):
             torch.autograd.backward([o4["rgb"], o4["alpha"], o4["depth"]], [t(a) for a in img])
             sc = np.abs(gf_ref[np.isfinite(gf_ref)]).max() if np.isfinite(gf_ref).any() else 1.0
             e = np.abs(np.nan_to_num(f4.grad.cpu().numpy().astype(np.float64) - gf_ref)).max()
-            if e > 2e-4 * sc + 1e-6: msg.append(f"reference-algo grad_faces err {e:.2e} (scale {sc:.2e})")
+            if e > 2e-4 * sc + 1e-6 * max(is_, 1): msg.append(f"reference-algo grad_faces err {e:.2e} (scale {sc:.2e})")
         finally:
             rasterize.REFERENCE_ALGO = False
     # warp half: random flows incl. out-of-range and exactly integer ones
