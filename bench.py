@@ -208,12 +208,14 @@ def kernel_bench(dev, B, is_, iters):
         _lib.call("mr_frames_to_batch", P(fr_u8), P(fr_coeffs), None, 0.5, 0.5, 0.5, 1.0, 1.0, 1.0, P(fr_work), fr_wb,
                   P(fr_img), P(fr_mask), 3, NF, Hs_, Ws_, is_, is_, st)
 
-    # trainer side: what sits between MIOpen's convolutions in the ResNet-18 trunk, at the shapes of a
+    # trainer side: what sits between MIOpen's convolutions in the ResNet-18 trunk (channels-last
+    # kernels, the layout the trunk runs in; the buffers are plain memory of the right size), at the shapes of a
     # step (3B frames): the stem (bn + relu + max-pool on [3B,64,is/2,is/2]) and a layer-1 bn + identity + relu
     hs = is_ // 2
     st_x = torch.randn(NF, 64, hs, hs, **f32)
     st_y, st_gx = torch.empty(NF, 64, hs // 2, hs // 2, **f32), torch.empty_like(st_x)
     st_gy = torch.randn_like(st_y)
+    st_am = torch.empty(st_y.shape, dtype=torch.uint8, device=dev)  # arg-max positions (channels-last kernels)
     bnp = [torch.rand(64, **f32) + 0.5, torch.randn(64, **f32), torch.randn(64, **f32), torch.rand(64, **f32) + 0.5]
     bn_gw, bn_gb = torch.empty(64, **f32), torch.empty(64, **f32)
     st_wb = int(lib.mr_stem_pool_backward_workspace_bytes(NF, 64, hs, hs))
@@ -225,18 +227,19 @@ def kernel_bench(dev, B, is_, iters):
     l1_x.normal_()
 
     def stem_fwd():
-        _lib.call("mr_stem_pool_forward", P(st_x), *[P(t_) for t_ in bnp], 1e-5, 0, P(st_y), NF, 64, hs, hs, st)
+        _lib.call("mr_stem_pool_forward", P(st_x), *[P(t_) for t_ in bnp], 1e-5, 0, 1, P(st_y), P(st_am), NF, 64, hs, hs, st)
 
     def stem_bwd():
-        _lib.call("mr_stem_pool_backward", P(st_gy), P(st_x), *[P(t_) for t_ in bnp], 1e-5, 0, P(st_gx), P(bn_gw), P(bn_gb),
+        _lib.call("mr_stem_pool_backward", P(st_gy), P(st_x), P(st_am), *[P(t_) for t_ in bnp], 1e-5, 0, 1, P(st_gx), P(bn_gw),
+                  P(bn_gb),
                   P(st_work), st_wb, NF, 64, hs, hs, st)
 
     def bn_fwd():
-        _lib.call("mr_bn_act_forward", P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, 0, P(l1_y), NF, 64,
+        _lib.call("mr_bn_act_forward", P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, 0, 1, P(l1_y), NF, 64,
                   (hs // 2) ** 2, st)
 
     def bn_bwd():
-        _lib.call("mr_bn_act_backward", P(l1_gy), P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, 0, P(l1_gx), P(l1_gr),
+        _lib.call("mr_bn_act_backward", P(l1_gy), P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, 0, 1, P(l1_gx), P(l1_gr),
                   P(bn_gw), P(bn_gb), P(l1_work), l1_wb, NF, 64, (hs // 2) ** 2, st)
 
     render_fwd()

@@ -160,6 +160,81 @@ __global__ __launch_bounds__(64) void bn_finish_kernel(const float* __restrict__
     }
 }
 
+// ---- channels-last (NHWC) activations: memory order [N, H*W, C] --------------------------------------------
+// MIOpen's convolutions are faster on channels-last tensors (no NCHW<->NHWC transposes around its implicit-GEMM
+// kernels: 23.5 instead of 26.9 ms per step for the trunk's convolutions, scripts/conv_layout.py), so the glue
+// kernels come in that layout too.  A thread owns FOUR consecutive channels (one 16-byte access) and walks pixels:
+// with 1024 % C == 0 its channel group never changes, so the channel constants live in registers and the backward's
+// reductions are per-thread partial sums combined once per workgroup; workgroup partials [blocks][C] are summed by
+// bn_finish_kernel in a fixed order.
+constexpr int BN_NHWC_BLOCKS = 2048;
+
+template <typename T, bool BACKWARD>
+__global__ __launch_bounds__(256) void bn_act_nhwc_kernel(BnParams p) {
+    __shared__ float red[256][9];
+    const int groups = p.C >> 2;                       // float4 groups per pixel; 256 % groups == 0
+    const int cg = threadIdx.x % groups, prow = threadIdx.x / groups, rows = 256 / groups;
+    const int c0 = 4 * cg;
+    float mean[4], a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float invstd;
+        channel_consts(p, c0 + i, mean[i], a[i], b[i], invstd);
+    }
+    const int64_t pixels = (int64_t)p.N * p.HW;
+    const bool relu = p.relu != 0;
+    float sg[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sgx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int64_t px = (int64_t)blockIdx.x * rows + prow; px < pixels; px += (int64_t)gridDim.x * rows) {
+        const int64_t o = px * p.C + c0;
+        float xv[4], rv[4], gv[4], out[4], gres[4];
+        load4<T>(p.x, o, xv);
+        if (p.residual) load4<T>(p.residual, o, rv);
+        if (BACKWARD) load4<T>(p.grad_y, o, gv);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float d = xv[i] - mean[i];
+            float z = d * a[i] + b[i];
+            if (p.residual) z = z + rv[i];
+            if (!BACKWARD) {
+                out[i] = relu ? fmaxf(z, 0.0f) : z;
+            } else {
+                const float g = (relu && !(z > 0.0f)) ? 0.0f : gv[i];
+                gres[i] = g;
+                out[i] = g * a[i];
+                sg[i] += g;
+                sgx[i] += g * d;
+            }
+        }
+        store4<T>(BACKWARD ? p.grad_x : p.y, o, out);
+        if (BACKWARD && p.grad_residual) store4<T>(p.grad_residual, o, gres);
+    }
+    if (BACKWARD && p.partial) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { red[threadIdx.x][i] = sg[i]; red[threadIdx.x][4 + i] = sgx[i]; }
+        __syncthreads();
+        if (threadIdx.x < groups) {
+            float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < rows; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) t[i] += red[r * groups + threadIdx.x][i];
+            // partial layout [2][C][blocks] (the finish kernel's), slot = this workgroup
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                p.partial[(int64_t)(c0 + i) * gridDim.x + blockIdx.x] = t[i];
+                p.partial[(int64_t)(p.C + c0 + i) * gridDim.x + blockIdx.x] = t[4 + i];
+            }
+        }
+    }
+}
+
+static inline bool bn_nhwc_ok(int C) { return C >= 4 && C <= 1024 && (1024 % C) == 0; }
+
+static inline int bn_nhwc_blocks(int64_t pixels, int C) {
+    const int rows = 256 / (C / 4);
+    const int64_t need = (pixels + rows - 1) / rows;
+    return (int)(need < BN_NHWC_BLOCKS ? (need < 1 ? 1 : need) : BN_NHWC_BLOCKS);
+}
+
 // sample ranges per channel: enough workgroups to fill the chip (>= ~4096), never more than N
 static inline int bn_split(int N, int C) {
     int s = (4096 + C - 1) / C;
@@ -186,9 +261,11 @@ static void bn_launch(const BnParams& p, int act_dtype, bool vec, hipStream_t s)
 
 extern "C" int mr_bn_act_forward(const void* x, const void* residual, const float* weight, const float* bias,
                                  const float* running_mean, const float* running_var, float eps, int relu, int act_dtype,
-                                 void* y, int batch_size, int channels, int plane, mr_stream_t stream) {
+                                 int channels_last, void* y, int batch_size, int channels, int plane,
+                                 mr_stream_t stream) {
     using namespace mr;
     if (batch_size < 0 || channels < 0 || plane < 0 || (act_dtype != 0 && act_dtype != 1)) return MR_ERR_BADARG;
+    if (channels_last && channels > 0 && !bn_nhwc_ok(channels)) return MR_ERR_BADARG;
     if (batch_size == 0 || channels == 0 || plane == 0) return MR_OK;
     if (!x || !weight || !bias || !running_mean || !running_var || !y) return MR_ERR_BADARG;
     BnParams p{};
@@ -197,6 +274,14 @@ extern "C" int mr_bn_act_forward(const void* x, const void* residual, const floa
     p.y = y;
     if ((int64_t)channels * p.split > 0x7fffffff || ((int64_t)batch_size / p.split + 1) * plane > 0x7fffffff) return MR_ERR_BADARG;
     const int vb = act_dtype == 0 ? 16 : 8;  // bytes of a 4-element access
+    if (channels_last) {
+        if (!bn_aligned(x, vb) || !bn_aligned(y, vb) || !bn_aligned(residual, vb)) return MR_ERR_BADARG;
+        const dim3 grid((unsigned)bn_nhwc_blocks((int64_t)batch_size * plane, channels));
+        if (act_dtype == 0) hipLaunchKernelGGL((bn_act_nhwc_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((bn_act_nhwc_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        MR_CHECK_LAUNCH();
+        return MR_OK;
+    }
     const bool vec = plane % 4 == 0 && bn_aligned(x, vb) && bn_aligned(y, vb) && bn_aligned(residual, vb);
     bn_launch<false>(p, act_dtype, vec, (hipStream_t)stream);
     MR_CHECK_LAUNCH();
@@ -205,16 +290,18 @@ extern "C" int mr_bn_act_forward(const void* x, const void* residual, const floa
 
 extern "C" int64_t mr_bn_act_backward_workspace_bytes(int batch_size, int channels) {
     if (batch_size < 0 || channels < 0) return -1;
-    return (int64_t)2 * channels * mr::bn_split(batch_size > 0 ? batch_size : 1, channels > 0 ? channels : 1) * 4 + 16;
+    const int64_t split = mr::bn_split(batch_size > 0 ? batch_size : 1, channels > 0 ? channels : 1);
+    return (int64_t)2 * channels * (split > mr::BN_NHWC_BLOCKS ? split : mr::BN_NHWC_BLOCKS) * 4 + 16;
 }
 
 extern "C" int mr_bn_act_backward(const void* grad_y, const void* x, const void* residual, const float* weight,
                                   const float* bias, const float* running_mean, const float* running_var, float eps,
-                                  int relu, int act_dtype, void* grad_x, void* grad_residual, float* grad_weight,
-                                  float* grad_bias, void* workspace, int64_t workspace_bytes, int batch_size,
-                                  int channels, int plane, mr_stream_t stream) {
+                                  int relu, int act_dtype, int channels_last, void* grad_x, void* grad_residual,
+                                  float* grad_weight, float* grad_bias, void* workspace, int64_t workspace_bytes,
+                                  int batch_size, int channels, int plane, mr_stream_t stream) {
     using namespace mr;
     if (batch_size < 0 || channels < 0 || plane < 0 || (act_dtype != 0 && act_dtype != 1)) return MR_ERR_BADARG;
+    if (channels_last && channels > 0 && !bn_nhwc_ok(channels)) return MR_ERR_BADARG;
     if (channels == 0) return MR_OK;
     if (!weight || !bias || !running_mean || !running_var) return MR_ERR_BADARG;
     const bool want_params = grad_weight || grad_bias;
@@ -235,13 +322,24 @@ extern "C" int mr_bn_act_backward(const void* grad_y, const void* x, const void*
     p.partial = want_params ? static_cast<float*>(workspace) : nullptr;
     if ((int64_t)channels * p.split > 0x7fffffff || ((int64_t)batch_size / p.split + 1) * plane > 0x7fffffff) return MR_ERR_BADARG;
     const int vb = act_dtype == 0 ? 16 : 8;
-    const bool vec = plane % 4 == 0 && bn_aligned(x, vb) && bn_aligned(grad_y, vb) && bn_aligned(grad_x, vb) &&
-                     bn_aligned(residual, vb) && bn_aligned(grad_residual, vb);
-    bn_launch<true>(p, act_dtype, vec, (hipStream_t)stream);
+    int slots = p.split;  // partial sums per channel
+    if (channels_last) {
+        if (!bn_aligned(x, vb) || !bn_aligned(grad_y, vb) || !bn_aligned(grad_x, vb) || !bn_aligned(residual, vb) ||
+            !bn_aligned(grad_residual, vb))
+            return MR_ERR_BADARG;
+        slots = bn_nhwc_blocks((int64_t)batch_size * plane, channels);
+        const dim3 grid((unsigned)slots);
+        if (act_dtype == 0) hipLaunchKernelGGL((bn_act_nhwc_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((bn_act_nhwc_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        const bool vec = plane % 4 == 0 && bn_aligned(x, vb) && bn_aligned(grad_y, vb) && bn_aligned(grad_x, vb) &&
+                         bn_aligned(residual, vb) && bn_aligned(grad_residual, vb);
+        bn_launch<true>(p, act_dtype, vec, (hipStream_t)stream);
+    }
     MR_CHECK_LAUNCH();
     if (want_params) {
         hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)channels), dim3(64), 0, (hipStream_t)stream, p.partial,
-                           running_var, eps, grad_weight, grad_bias, channels, p.split);
+                           running_var, eps, grad_weight, grad_bias, channels, slots);
         MR_CHECK_LAUNCH();
     }
     return MR_OK;

@@ -23,7 +23,8 @@ struct StemParams {
     void* y;              // forward: [N,C,OH,OW]
     const void* grad_y;   // backward
     void* grad_x;         // [N,C,H,W]
-    float* partial;       // [2][C][N * tiles]: sum g, sum g * (x - mean)
+    float* partial;       // [2][C][N * tiles]: sum g, sum g * (x - mean)   (channels-last: [2][C][workgroups])
+    unsigned char* argmax;  // channels-last only: [N,OH,OW,C] arg-max position kh * 3 + kw, written by the forward
 };
 
 constexpr int SP_TX = 32, SP_TY = 16;  // windows (= pooled pixels) per tile
@@ -241,6 +242,131 @@ __global__ __launch_bounds__(256) void stem_finish_kernel(const float* __restric
     }
 }
 
+// ---- channels-last (NHWC) activations ---------------------------------------------------------------------
+// A thread owns four consecutive channels of one pixel (one 16-byte access; the C / 4 threads of a pixel read a
+// contiguous 4 C-byte segment), so no LDS staging is needed: the forward reads the <= 9 pixels of its window directly
+// and also writes each channel's arg-max position (1 byte per pooled value); the backward walks INPUT pixels and
+// gathers from the <= 4 windows that contain them by comparing the stored positions -- same arithmetic and tie rule
+// as the NCHW kernels.
+constexpr int SP_NHWC_BLOCKS = 4096;
+
+template <typename T>
+__device__ __forceinline__ void sp_load4(const T* base, int64_t o, float* v) {
+    const typename SpVec4<T>::type t = *reinterpret_cast<const typename SpVec4<T>::type*>(base + o);
+    v[0] = sp_f32(t.x); v[1] = sp_f32(t.y); v[2] = sp_f32(t.z); v[3] = sp_f32(t.w);
+}
+template <typename T>
+__device__ __forceinline__ void sp_store4(T* base, int64_t o, const float* v) {
+    typename SpVec4<T>::type t;
+    t.x = sp_from<T>(v[0]); t.y = sp_from<T>(v[1]); t.z = sp_from<T>(v[2]); t.w = sp_from<T>(v[3]);
+    *reinterpret_cast<typename SpVec4<T>::type*>(base + o) = t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_nhwc_forward_kernel(StemParams p) {
+    const int groups = p.C >> 2, cg = threadIdx.x % groups, prow = threadIdx.x / groups, rows = 256 / groups;
+    const int c0 = 4 * cg;
+    float mean[4], a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) stem_consts(p, c0 + i, mean[i], a[i], b[i]);
+    const T* x = static_cast<const T*>(p.x);
+    const int64_t total = (int64_t)p.N * p.OH * p.OW;
+    for (int64_t op = (int64_t)blockIdx.x * rows + prow; op < total; op += (int64_t)gridDim.x * rows) {
+        const int ox = (int)(op % p.OW), oy = (int)((op / p.OW) % p.OH), n = (int)(op / ((int64_t)p.OW * p.OH));
+        float best[4];
+        unsigned bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; i++) best[i] = -__builtin_inff();
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int iy = 2 * oy - 1 + k / 3, ix = 2 * ox - 1 + k % 3;
+            if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
+            float xv[4];
+            sp_load4<T>(x, (((int64_t)n * p.H + iy) * p.W + ix) * p.C + c0, xv);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float v = fmaxf((xv[i] - mean[i]) * a[i] + b[i], 0.0f);
+                if (v > best[i]) { best[i] = v; bi[i] = (unsigned)k; }
+            }
+        }
+        const int64_t o = op * p.C + c0;
+        sp_store4<T>(static_cast<T*>(p.y), o, best);
+        *reinterpret_cast<uchar4*>(p.argmax + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1],
+                                                               (unsigned char)bi[2], (unsigned char)bi[3]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_nhwc_backward_kernel(StemParams p) {
+    __shared__ float red[256][9];
+    const int groups = p.C >> 2, cg = threadIdx.x % groups, prow = threadIdx.x / groups, rows = 256 / groups;
+    const int c0 = 4 * cg;
+    float mean[4], a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) stem_consts(p, c0 + i, mean[i], a[i], b[i]);
+    const T* x = static_cast<const T*>(p.x);
+    const T* gy = static_cast<const T*>(p.grad_y);
+    const int64_t total = (int64_t)p.N * p.H * p.W;
+    float sg[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sgx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int64_t ip = (int64_t)blockIdx.x * rows + prow; ip < total; ip += (int64_t)gridDim.x * rows) {
+        const int ix = (int)(ip % p.W), iy = (int)((ip / p.W) % p.H), n = (int)(ip / ((int64_t)p.W * p.H));
+        float xv[4], g[4] = {0.0f, 0.0f, 0.0f, 0.0f}, out[4];
+        sp_load4<T>(x, ip * p.C + c0, xv);
+        const int ly = iy + 1, lx = ix + 1;  // window w covers l = 2 w .. 2 w + 2
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++) {
+            const int wy = (ly >> 1) - dy, kh = ly - 2 * wy;
+            if (wy < 0 || wy >= p.OH || kh > 2) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                const int wx = (lx >> 1) - dx, kw = lx - 2 * wx;
+                if (wx < 0 || wx >= p.OW || kw > 2) continue;
+                const int64_t o = (((int64_t)n * p.OH + wy) * p.OW + wx) * p.C + c0;
+                const uchar4 id = *reinterpret_cast<const uchar4*>(p.argmax + o);
+                float gv[4];
+                sp_load4<T>(gy, o, gv);
+                const unsigned code = (unsigned)(kh * 3 + kw);
+                g[0] += id.x == code ? gv[0] : 0.0f;
+                g[1] += id.y == code ? gv[1] : 0.0f;
+                g[2] += id.z == code ? gv[2] : 0.0f;
+                g[3] += id.w == code ? gv[3] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float d = xv[i] - mean[i];
+            const float gm = (d * a[i] + b[i] > 0.0f) ? g[i] : 0.0f;  // ReLU
+            out[i] = gm * a[i];
+            sg[i] += gm;
+            sgx[i] += gm * d;
+        }
+        sp_store4<T>(static_cast<T*>(p.grad_x), ip * p.C + c0, out);
+    }
+    if (p.partial) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { red[threadIdx.x][i] = sg[i]; red[threadIdx.x][4 + i] = sgx[i]; }
+        __syncthreads();
+        if (threadIdx.x < groups) {
+            float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < rows; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) t[i] += red[r * groups + threadIdx.x][i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                p.partial[(int64_t)(c0 + i) * gridDim.x + blockIdx.x] = t[i];
+                p.partial[(int64_t)(p.C + c0 + i) * gridDim.x + blockIdx.x] = t[4 + i];
+            }
+        }
+    }
+}
+
+static inline bool sp_nhwc_ok(int C) { return C >= 4 && C <= 1024 && (1024 % C) == 0; }
+static inline int sp_nhwc_blocks(int64_t pixels, int C) {
+    const int rows = 256 / (C / 4);
+    const int64_t need = (pixels + rows - 1) / rows;
+    return (int)(need < SP_NHWC_BLOCKS ? (need < 1 ? 1 : need) : SP_NHWC_BLOCKS);
+}
+
 static int stem_fill(StemParams& p, const void* x, const float* weight, const float* bias, const float* mean,
                      const float* var, float eps, int N, int C, int H, int W) {
     if (N < 0 || C < 0 || H < 0 || W < 0) return MR_ERR_BADARG;
@@ -257,16 +383,30 @@ static int stem_fill(StemParams& p, const void* x, const float* weight, const fl
 }  // namespace mr
 
 extern "C" int mr_stem_pool_forward(const void* x, const float* weight, const float* bias, const float* running_mean,
-                                    const float* running_var, float eps, int act_dtype, void* y, int batch_size,
-                                    int channels, int height, int width, mr_stream_t stream) {
+                                    const float* running_var, float eps, int act_dtype, int channels_last, void* y,
+                                    unsigned char* argmax, int batch_size, int channels, int height, int width,
+                                    mr_stream_t stream) {
     using namespace mr;
     if (act_dtype != 0 && act_dtype != 1) return MR_ERR_BADARG;
+    if (channels_last && channels > 0 && !sp_nhwc_ok(channels)) return MR_ERR_BADARG;
     StemParams p{};
     const int rc = stem_fill(p, x, weight, bias, running_mean, running_var, eps, batch_size, channels, height, width);
     if (rc != MR_OK) return rc;
     if (batch_size == 0 || channels == 0 || height == 0 || width == 0) return MR_OK;
     if (!x || !weight || !bias || !running_mean || !running_var || !y) return MR_ERR_BADARG;
     p.y = y;
+    if (channels_last) {
+        const uintptr_t am = (uintptr_t)(act_dtype == 0 ? 15 : 7);
+        if (!argmax || (reinterpret_cast<uintptr_t>(x) & am) || (reinterpret_cast<uintptr_t>(y) & am) ||
+            (reinterpret_cast<uintptr_t>(argmax) & 3))
+            return MR_ERR_BADARG;
+        p.argmax = argmax;
+        const dim3 g((unsigned)sp_nhwc_blocks((int64_t)batch_size * p.OH * p.OW, channels));
+        if (act_dtype == 0) hipLaunchKernelGGL(stem_pool_nhwc_forward_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(stem_pool_nhwc_forward_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, p);
+        MR_CHECK_LAUNCH();
+        return MR_OK;
+    }
     const dim3 grid((unsigned)((int64_t)batch_size * channels * p.tiles_x * p.tiles_y));
     if (act_dtype == 0) hipLaunchKernelGGL(stem_pool_forward_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(stem_pool_forward_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -278,16 +418,18 @@ extern "C" int64_t mr_stem_pool_backward_workspace_bytes(int batch_size, int cha
     using namespace mr;
     StemParams p{};
     if (stem_fill(p, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, batch_size, channels, height, width) != MR_OK) return -1;
-    return (int64_t)2 * channels * batch_size * p.tiles_x * p.tiles_y * 4 + 16;
+    const int64_t nchw = (int64_t)batch_size * p.tiles_x * p.tiles_y;
+    return (int64_t)2 * channels * (nchw > SP_NHWC_BLOCKS ? nchw : SP_NHWC_BLOCKS) * 4 + 16;
 }
 
-extern "C" int mr_stem_pool_backward(const void* grad_y, const void* x, const float* weight, const float* bias,
-                                     const float* running_mean, const float* running_var, float eps, int act_dtype,
-                                     void* grad_x, float* grad_weight, float* grad_bias, void* workspace,
-                                     int64_t workspace_bytes, int batch_size, int channels, int height, int width,
-                                     mr_stream_t stream) {
+extern "C" int mr_stem_pool_backward(const void* grad_y, const void* x, const unsigned char* argmax, const float* weight,
+                                     const float* bias, const float* running_mean, const float* running_var, float eps,
+                                     int act_dtype, int channels_last, void* grad_x, float* grad_weight,
+                                     float* grad_bias, void* workspace, int64_t workspace_bytes, int batch_size,
+                                     int channels, int height, int width, mr_stream_t stream) {
     using namespace mr;
     if (act_dtype != 0 && act_dtype != 1) return MR_ERR_BADARG;
+    if (channels_last && channels > 0 && !sp_nhwc_ok(channels)) return MR_ERR_BADARG;
     StemParams p{};
     const int rc = stem_fill(p, x, weight, bias, running_mean, running_var, eps, batch_size, channels, height, width);
     if (rc != MR_OK) return rc;
@@ -306,13 +448,26 @@ extern "C" int mr_stem_pool_backward(const void* grad_y, const void* x, const fl
     p.grad_y = grad_y; p.grad_x = grad_x;
     p.partial = want_params ? static_cast<float*>(workspace) : nullptr;
     const int tiles = p.tiles_x * p.tiles_y;
-    const dim3 grid((unsigned)((int64_t)batch_size * channels * tiles));
-    if (act_dtype == 0) hipLaunchKernelGGL(stem_pool_backward_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(stem_pool_backward_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    int64_t slots = (int64_t)batch_size * tiles;
+    if (channels_last) {
+        const uintptr_t am = (uintptr_t)(act_dtype == 0 ? 15 : 7);
+        if (!argmax || (reinterpret_cast<uintptr_t>(x) & am) || (reinterpret_cast<uintptr_t>(grad_y) & am) ||
+            (reinterpret_cast<uintptr_t>(grad_x) & am) || (reinterpret_cast<uintptr_t>(argmax) & 3))
+            return MR_ERR_BADARG;
+        p.argmax = const_cast<unsigned char*>(argmax);
+        slots = sp_nhwc_blocks((int64_t)batch_size * height * width, channels);
+        const dim3 g((unsigned)slots);
+        if (act_dtype == 0) hipLaunchKernelGGL(stem_pool_nhwc_backward_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(stem_pool_nhwc_backward_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        const dim3 grid((unsigned)((int64_t)batch_size * channels * tiles));
+        if (act_dtype == 0) hipLaunchKernelGGL(stem_pool_backward_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(stem_pool_backward_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     MR_CHECK_LAUNCH();
     if (want_params) {
         hipLaunchKernelGGL(stem_finish_kernel, dim3((unsigned)channels), dim3(256), 0, (hipStream_t)stream, p.partial,
-                           running_var, eps, grad_weight, grad_bias, channels, (int64_t)batch_size * tiles);
+                           running_var, eps, grad_weight, grad_bias, channels, slots);
         MR_CHECK_LAUNCH();
     }
     return MR_OK;

@@ -40,6 +40,12 @@ from handobjectconsist_amd.utils import synth
 USE_HIP_BN = os.environ.get("HOC_HIP_BN", "1") == "1"
 
 
+# The trunk's activations and convolution weights in channels-last (NHWC) memory order: MIOpen's fp32 convolutions
+# of a step take 23.5 ms there instead of 26.9 ms (no NCHW<->NHWC transposes around its implicit-GEMM kernels,
+# scripts/conv_layout.py); the glue kernels above have channels-last variants.  HOC_CHANNELS_LAST=0: NCHW.
+USE_CHANNELS_LAST = os.environ.get("HOC_CHANNELS_LAST", "1") == "1"
+
+
 def _fused_bn(bn, x):
     # x is the convolution's input here; under bf16 autocast the convolution outputs (the BN inputs) are bf16,
     # which the kernels take as well
@@ -99,6 +105,10 @@ class ResNet18Features(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
+        if USE_CHANNELS_LAST and x.is_cuda:
+            if not self.conv1.weight.is_contiguous(memory_format=torch.channels_last):
+                self.to(memory_format=torch.channels_last)  # once: convolution weights (the Parameter objects stay)
+            x = x.contiguous(memory_format=torch.channels_last)
         if _fused_bn(self.bn1, x):
             x = frozen_bn.stem_pool(self.conv1(x), self.bn1)  # bn1 + relu + maxpool(3, 2, 1)
         else:

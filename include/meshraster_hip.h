@@ -373,18 +373,21 @@ MR_API int mr_frames_to_batch(const uint8_t* frames, const double* coeffs, const
  *   z = (x - running_mean) * (weight / sqrt(running_var + eps)) + bias [+ residual];  y = relu ? max(z, 0) : z
  * x, residual, y, grad_x, grad_y, grad_residual: [batch_size, channels, plane] contiguous (NCHW, plane = H * W)
  * of the activation type act_dtype: 0 = fp32, 1 = bf16 (the trunk under bf16 autocast: converted on load, fp32
- * arithmetic, rounded to nearest-even on store); the channel arrays and their gradients are fp32 [channels].  Backward: g = relu && !(z > 0) ? 0 : grad_y;  grad_x = g * weight / sqrt(var + eps);
+ * arithmetic, rounded to nearest-even on store); the channel arrays and their gradients are fp32 [channels].
+ * channels_last = 1: the activations are in NHWC memory order [batch_size, plane, channels] (what MIOpen's
+ * convolutions prefer); requires channels to be a power of two in [4, 1024] and 16-byte (bf16: 8-byte) alignment.  Backward: g = relu && !(z > 0) ? 0 : grad_y;  grad_x = g * weight / sqrt(var + eps);
  * grad_residual = g (NULL if not wanted); grad_bias = sum g; grad_weight = sum g * (x - mean) / sqrt(var + eps)
  * (either may be NULL; two-stage deterministic reduction through the workspace). */
 MR_API int mr_bn_act_forward(const void* x, const void* residual, const float* weight, const float* bias,
                              const float* running_mean, const float* running_var, float eps, int relu,
-                             int act_dtype, void* y, int batch_size, int channels, int plane,
-                             mr_stream_t stream);
+                             int act_dtype, int channels_last, void* y, int batch_size, int channels,
+                             int plane, mr_stream_t stream);
 MR_API int64_t mr_bn_act_backward_workspace_bytes(int batch_size, int channels);
 MR_API int mr_bn_act_backward(const void* grad_y, const void* x, const void* residual,
                               const float* weight, const float* bias, const float* running_mean,
-                              const float* running_var, float eps, int relu, int act_dtype, void* grad_x,
-                              void* grad_residual, float* grad_weight, float* grad_bias,
+                              const float* running_var, float eps, int relu, int act_dtype,
+                              int channels_last, void* grad_x, void* grad_residual, float* grad_weight,
+                              float* grad_bias,
                               void* workspace, int64_t workspace_bytes, int batch_size, int channels,
                               int plane, mr_stream_t stream);
 
@@ -393,17 +396,20 @@ MR_API int mr_bn_act_backward(const void* grad_y, const void* x, const void* res
  * The full-resolution activation is never written; the backward recomputes it per tile, re-derives every
  * window's arg-max with PyTorch's rule (kh, kw ascending, strictly greater wins, padding skipped) and gathers the
  * pooled gradient per input pixel (no atomics).  x, y, grad_x, grad_y are of act_dtype (0 = fp32, 1 = bf16);
- * grad_weight / grad_bias (fp32) may be NULL. */
+ * grad_weight / grad_bias (fp32) may be NULL.  channels_last = 1: NHWC memory order; the forward then also writes
+ * argmax[N,OH,OW,C] (u8, position kh * 3 + kw of every pooled value) which the backward reads instead of
+ * re-deriving it (argmax is unused and may be NULL for NCHW); channels must be a power of two in [4, 1024]. */
 MR_API int mr_stem_pool_forward(const void* x, const float* weight, const float* bias,
                                 const float* running_mean, const float* running_var, float eps,
-                                int act_dtype, void* y, int batch_size, int channels, int height, int width,
-                                mr_stream_t stream);
+                                int act_dtype, int channels_last, void* y, unsigned char* argmax,
+                                int batch_size, int channels, int height, int width, mr_stream_t stream);
 MR_API int64_t mr_stem_pool_backward_workspace_bytes(int batch_size, int channels, int height, int width);
-MR_API int mr_stem_pool_backward(const void* grad_y, const void* x, const float* weight, const float* bias,
-                                 const float* running_mean, const float* running_var, float eps,
-                                 int act_dtype, void* grad_x, float* grad_weight, float* grad_bias,
-                                 void* workspace, int64_t workspace_bytes, int batch_size, int channels,
-                                 int height, int width, mr_stream_t stream);
+MR_API int mr_stem_pool_backward(const void* grad_y, const void* x, const unsigned char* argmax,
+                                 const float* weight, const float* bias, const float* running_mean,
+                                 const float* running_var, float eps, int act_dtype, int channels_last,
+                                 void* grad_x, float* grad_weight, float* grad_bias, void* workspace,
+                                 int64_t workspace_bytes, int batch_size, int channels, int height,
+                                 int width, mr_stream_t stream);
 
 #ifdef __cplusplus
 }

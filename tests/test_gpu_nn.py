@@ -224,3 +224,90 @@ def test_resnet_trunk_bf16_autocast_fused_no_worse_than_stock(cuda, monkeypatch)
         scale = float(ref[i].abs().max())
         assert e_fused <= 1.5 * e_stock + 1e-3 * scale, (what, e_fused, e_stock, scale)
         assert e_fused <= 0.2 * scale, (what, e_fused, scale)
+
+
+def _bn(cuda, C, g):
+    bn = torch.nn.BatchNorm2d(C).to(cuda).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.4)
+        bn.running_var.copy_(torch.rand(C, generator=g) * 2 + 0.05)
+    return bn
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,relu,with_res", [((6, 64, 32, 32), True, True), ((5, 16, 17, 30), True, False),
+                                                 ((3, 512, 8, 8), True, True), ((7, 4, 3, 5), False, True),
+                                                 ((2, 256, 1, 3), True, False), ((192, 8, 4, 4), False, False)])
+def test_bn_act_channels_last_equals_nchw_kernel(cuda, shape, relu, with_res, dtype):
+    """The channels-last kernels against the NCHW kernels (themselves checked against stock PyTorch): same arithmetic
+    per element -> outputs and activation gradients bit-identical; the channel sums in a different order."""
+    from handobjectconsist_amd.nn import frozen_bn
+
+    g = torch.Generator().manual_seed(sum(shape))
+    bn = _bn(cuda, shape[1], g)
+    x0 = torch.randn(shape, generator=g).to(cuda).to(dtype)
+    r0 = torch.randn(shape, generator=g).to(cuda).to(dtype) if with_res else None
+    gy = torch.randn(shape, generator=g).to(cuda).to(dtype)
+    outs = {}
+    for cl in (False, True):
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        x = x0.clone().contiguous(memory_format=fmt).requires_grad_(True)
+        r = r0.clone().contiguous(memory_format=fmt).requires_grad_(True) if with_res else None
+        bn.zero_grad(set_to_none=True)
+        y = frozen_bn.bn_act(x, bn, residual=r, relu=relu)
+        assert y.is_contiguous(memory_format=fmt) and y.dtype == dtype
+        y.backward(gy.contiguous(memory_format=fmt))
+        assert x.grad.is_contiguous(memory_format=fmt)
+        outs[cl] = (y.detach(), x.grad, None if r is None else r.grad, bn.weight.grad.clone(), bn.bias.grad.clone())
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    if with_res:
+        assert torch.equal(outs[True][2], outs[False][2])
+    _close(outs[True][3], outs[False][3], 2e-5, "grad weight")
+    _close(outs[True][4], outs[False][4], 2e-5, "grad bias")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(4, 8, 32, 32), (3, 64, 17, 31), (2, 4, 1, 1), (2, 16, 135, 240), (1, 128, 2, 3)])
+def test_stem_pool_channels_last_equals_nchw_kernel(cuda, shape, dtype):
+    from handobjectconsist_amd.nn import frozen_bn
+
+    g = torch.Generator().manual_seed(sum(shape))
+    bn = _bn(cuda, shape[1], g)
+    with torch.no_grad():
+        bn.weight[0] = -0.6
+    x0 = torch.randn(shape, generator=g).to(cuda).to(dtype)
+    outs = {}
+    for cl in (False, True):
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        x = x0.clone().contiguous(memory_format=fmt).requires_grad_(True)
+        bn.zero_grad(set_to_none=True)
+        y = frozen_bn.stem_pool(x, bn)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(cuda).to(dtype)
+        y.backward(gy.contiguous(memory_format=fmt))
+        outs[cl] = (y.detach(), x.grad, bn.weight.grad.clone(), bn.bias.grad.clone())
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    _close(outs[True][2], outs[False][2], 2e-5, "grad weight")
+    _close(outs[True][3], outs[False][3], 2e-5, "grad bias")
+
+
+def test_resnet_trunk_channels_last_equals_nchw(cuda, monkeypatch):
+    """Whole trunk: channels-last (the default) vs NCHW activations, fused glue kernels in both -- MIOpen picks other
+    convolution kernels per layout, so features / gradients agree to fp32 rounding, not bit for bit."""
+    from handobjectconsist_amd.models import synthnet
+
+    x = torch.randn(6, 3, 96, 64, device=cuda)
+    w = torch.randn(6, 512, device=cuda)
+    out = {}
+    for cl in (True, False):
+        monkeypatch.setattr(synthnet, "USE_CHANNELS_LAST", cl)
+        torch.manual_seed(0)
+        net = synthnet.ResNet18Features().to(cuda).eval()
+        feats = net(x)
+        (feats * w).sum().backward()
+        assert net.conv1.weight.is_contiguous(memory_format=torch.channels_last) == cl or not cl
+        out[cl] = (feats.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()})
+    _close(out[True][0], out[False][0], 1e-4, "features")
+    for n, gref in out[False][1].items():
+        _close(out[True][1][n], gref, 2e-3, f"grad {n}")
