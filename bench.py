@@ -463,7 +463,7 @@ def main():
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
             "data": "synthetic",
             "config": {"workload": f"trainmeshwarp.py consist step, per-GPU B={B}, {is_}x{ih_}, hand 778v/1552f + "
-                                   f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {('fp32' if args.encoder_dtype == 'f32' else 'bf16-autocast') + ' (MIOpen convolutions + fused HIP BatchNorm/ReLU/residual/max-pool kernels)'}, Adam",
+                                   f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {('fp32' if args.encoder_dtype == 'f32' else 'bf16-autocast') + ' (MIOpen convolutions, channels-last, + fused HIP BatchNorm/ReLU/residual/max-pool kernels)'}, Adam",
                        "global_batch": B * world, "image_size": is_, "parallelism": f"dp{world}"},
             "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,

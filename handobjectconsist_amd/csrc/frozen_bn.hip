@@ -140,12 +140,14 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnParams p) {
     }
 }
 
-// grad_bias[c] = sum_k partial[0][c][k];  grad_weight[c] = invstd[c] * sum_k partial[1][c][k]   (one wave per channel)
-__global__ __launch_bounds__(64) void bn_finish_kernel(const float* __restrict__ partial, const float* __restrict__ var,
-                                                       float eps, float* grad_weight, float* grad_bias, int C, int split) {
+// grad_bias[c] = sum_k partial[0][c][k];  grad_weight[c] = invstd[c] * sum_k partial[1][c][k]   (one workgroup per channel,
+// fixed summation order)
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ partial, const float* __restrict__ var,
+                                                        float eps, float* grad_weight, float* grad_bias, int C, int split) {
+    __shared__ float red[2][4];
     const int c = blockIdx.x;
     float s0 = 0.0f, s1 = 0.0f;
-    for (int k = threadIdx.x; k < split; k += 64) {
+    for (int k = threadIdx.x; k < split; k += 256) {
         s0 += partial[(int64_t)c * split + k];
         s1 += partial[(int64_t)(C + c) * split + k];
     }
@@ -154,9 +156,11 @@ __global__ __launch_bounds__(64) void bn_finish_kernel(const float* __restrict__
         s0 += __shfl_down(s0, off);
         s1 += __shfl_down(s1, off);
     }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        if (grad_bias) grad_bias[c] = s0;
-        if (grad_weight) grad_weight[c] = s1 * (1.0f / sqrtf(var[c] + eps));
+        if (grad_bias) grad_bias[c] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        if (grad_weight) grad_weight[c] = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * (1.0f / sqrtf(var[c] + eps));
     }
 }
 
@@ -338,7 +342,7 @@ extern "C" int mr_bn_act_backward(const void* grad_y, const void* x, const void*
     }
     MR_CHECK_LAUNCH();
     if (want_params) {
-        hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)channels), dim3(64), 0, (hipStream_t)stream, p.partial,
+        hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)channels), dim3(256), 0, (hipStream_t)stream, p.partial,
                            running_var, eps, grad_weight, grad_bias, channels, slots);
         MR_CHECK_LAUNCH();
     }
