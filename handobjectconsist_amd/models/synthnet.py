@@ -378,6 +378,10 @@ class SynthMeshRegNet(nn.Module):
         self.lam = (lambda_recov_joints3d, lambda_obj_recov_verts3d, lambda_pose_reg, lambda_shape)
         # BASELINE.json config 5 ("bf16"): the TRUNK under bf16 autocast; heads, MANO, render and warp stay fp32
         self.encoder_dtype = torch.float32
+        if USE_CHANNELS_LAST:
+            # convolution weights in channels-last from the start, i.e. before a DistributedDataParallel wrapper
+            # builds its gradient buckets from the parameters' strides
+            self.base_net.to(memory_format=torch.channels_last)
 
     def encode(self, images):
         """ResNet-18 trunk -> [B,512] fp32 features (optionally computed under bf16 autocast)."""
