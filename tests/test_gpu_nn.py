@@ -311,3 +311,53 @@ def test_resnet_trunk_channels_last_equals_nchw(cuda, monkeypatch):
     _close(out[True][0], out[False][0], 1e-4, "features")
     for n, gref in out[False][1].items():
         _close(out[True][1][n], gref, 2e-3, f"grad {n}")
+
+
+def test_trunk_glue_at_the_metric_shapes(cuda):
+    """The shapes of a step at the metric configuration (3 x 64 frames of 256 x 256): stem [192,64,128,128] and a
+    layer-1 group [192,64,64,64] -- channels-last against NCHW kernels bit for bit, plus size-independent properties
+    (ReLU support, every pooled gradient lands on at most one input pixel, linearity of the backward in grad_y)."""
+    from handobjectconsist_amd.nn import frozen_bn
+
+    g = torch.Generator().manual_seed(0)
+    bn = _bn(cuda, 64, g)
+    x0 = torch.randn(192, 64, 128, 128, generator=g).to(cuda)
+    outs = {}
+    for cl in (False, True):
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        x = x0.detach().clone(memory_format=fmt).requires_grad_(True)
+        bn.zero_grad(set_to_none=True)
+        y = frozen_bn.stem_pool(x, bn)
+        gy = torch.ones_like(y)
+        y.backward(gy)
+        outs[cl] = (y.detach(), x.grad, bn.weight.grad.clone(), bn.bias.grad.clone())
+    y, gx = outs[True][0], outs[True][1]
+    assert torch.equal(y, outs[False][0]) and torch.equal(gx, outs[False][1])
+    _close(outs[True][2], outs[False][2], 5e-5, "stem grad weight")
+    assert y.shape == (192, 64, 64, 64) and float(y.min()) >= 0.0
+    a = (bn.weight / torch.sqrt(bn.running_var + bn.eps))[None, :, None, None]
+    # with grad_y = 1 every pooled value sends a * 1 to exactly one input pixel, unless the window is all <= 0
+    routed = (gx / a).sum((2, 3))
+    active = (y > 0).float().sum((2, 3))
+    assert torch.allclose(routed, active, rtol=1e-5, atol=1e-2)
+    del x0, outs, y, gx
+    x1 = torch.randn(192, 64, 64, 64, generator=g).to(cuda)
+    r1 = torch.randn(192, 64, 64, 64, generator=g).to(cuda)
+    g1, g2 = torch.randn(192, 64, 64, 64, generator=g).to(cuda), torch.randn(192, 64, 64, 64, generator=g).to(cuda)
+    res = {}
+    for cl in (False, True):
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        grads = []
+        for gy in (g1, g2, g1 + g2):
+            x = x1.detach().clone(memory_format=fmt).requires_grad_(True)
+            r = r1.detach().clone(memory_format=fmt).requires_grad_(True)
+            y = frozen_bn.bn_act(x, bn, residual=r, relu=True)
+            y.backward(gy.contiguous(memory_format=fmt))
+            grads.append((x.grad, r.grad))
+        res[cl] = (y.detach(), grads)
+    assert torch.equal(res[True][0], res[False][0])
+    for k in range(3):
+        assert torch.equal(res[True][1][k][0], res[False][1][k][0]) and torch.equal(res[True][1][k][1], res[False][1][k][1])
+    # the backward is linear in grad_y; its identity branch passes grad_y through the ReLU mask unchanged
+    _close(res[True][1][0][0] + res[True][1][1][0], res[True][1][2][0], 1e-6, "linearity of grad x")
+    assert torch.equal(res[True][1][0][1], torch.where(res[True][0] > 0, g1, torch.zeros_like(g1)).contiguous(memory_format=torch.channels_last))
