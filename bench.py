@@ -230,7 +230,7 @@ def kernel_bench(dev, B, is_, iters):
         _lib.call("mr_stem_pool_forward", P(st_x), *[P(t_) for t_ in bnp], 1e-5, 0, 1, P(st_y), P(st_am), NF, 64, hs, hs, st)
 
     def stem_bwd():
-        _lib.call("mr_stem_pool_backward", P(st_gy), P(st_x), P(st_am), *[P(t_) for t_ in bnp], 1e-5, 0, 1, P(st_gx), P(bn_gw),
+        _lib.call("mr_stem_pool_backward", P(st_gy), None, P(st_x), P(st_am), *[P(t_) for t_ in bnp], 1e-5, 0, 1, P(st_gx), P(bn_gw),
                   P(bn_gb),
                   P(st_work), st_wb, NF, 64, hs, hs, st)
 
@@ -239,7 +239,7 @@ def kernel_bench(dev, B, is_, iters):
                   (hs // 2) ** 2, st)
 
     def bn_bwd():
-        _lib.call("mr_bn_act_backward", P(l1_gy), P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, 0, 1, P(l1_gx), P(l1_gr),
+        _lib.call("mr_bn_act_backward", P(l1_gy), None, P(l1_x), P(l1_res), *[P(t_) for t_ in bnp], 1e-5, 1, 0, 1, P(l1_gx), P(l1_gr),
                   P(bn_gw), P(bn_gb), P(l1_work), l1_wb, NF, 64, (hs // 2) ** 2, st)
 
     render_fwd()

@@ -52,10 +52,10 @@ SIGNATURES = {
     "mr_frames_to_batch": (_I, [_P] * 3 + [_F] * 6 + [_P, _L, _P, _P] + [_I] * 6 + [_P]),
     "mr_bn_act_forward": (_I, [_P] * 6 + [_F, _I, _I, _I, _P, _I, _I, _I, _P]),
     "mr_bn_act_backward_workspace_bytes": (_L, [_I, _I]),
-    "mr_bn_act_backward": (_I, [_P] * 7 + [_F, _I, _I, _I] + [_P] * 5 + [_L, _I, _I, _I, _P]),
+    "mr_bn_act_backward": (_I, [_P] * 8 + [_F, _I, _I, _I] + [_P] * 5 + [_L, _I, _I, _I, _P]),
     "mr_stem_pool_forward": (_I, [_P] * 5 + [_F, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "mr_stem_pool_backward_workspace_bytes": (_L, [_I, _I, _I, _I]),
-    "mr_stem_pool_backward": (_I, [_P] * 7 + [_F, _I, _I] + [_P] * 4 + [_L, _I, _I, _I, _I, _P]),
+    "mr_stem_pool_backward": (_I, [_P] * 8 + [_F, _I, _I] + [_P] * 4 + [_L, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

@@ -32,6 +32,7 @@ struct BnParams {
     void* y;
     // backward
     const void* grad_y;
+    const void* grad_y2;    // optional second gradient of y (y feeds two consumers): summed on load
     void* grad_x;
     void* grad_residual;    // NULL or [N,C,HW]
     float* partial;         // [2][C][split]: sum g, sum g * (x - mean)
@@ -92,11 +93,22 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnParams p) {
         if (VEC) {
             load4<T>(p.x, o, xv);
             if (p.residual) load4<T>(p.residual, o, rv);
-            if (BACKWARD) load4<T>(p.grad_y, o, gv);
+            if (BACKWARD) {
+                load4<T>(p.grad_y, o, gv);
+                if (p.grad_y2) {
+                    float g2[4];
+                    load4<T>(p.grad_y2, o, g2);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) gv[i] += g2[i];
+                }
+            }
         } else {
             xv[0] = to_f32(static_cast<const T*>(p.x)[o]);
             if (p.residual) rv[0] = to_f32(static_cast<const T*>(p.residual)[o]);
-            if (BACKWARD) gv[0] = to_f32(static_cast<const T*>(p.grad_y)[o]);
+            if (BACKWARD) {
+                gv[0] = to_f32(static_cast<const T*>(p.grad_y)[o]);
+                if (p.grad_y2) gv[0] += to_f32(static_cast<const T*>(p.grad_y2)[o]);
+            }
         }
         float out[W], gres[W];
 #pragma unroll
@@ -193,7 +205,15 @@ __global__ __launch_bounds__(256) void bn_act_nhwc_kernel(BnParams p) {
         float xv[4], rv[4], gv[4], out[4], gres[4];
         load4<T>(p.x, o, xv);
         if (p.residual) load4<T>(p.residual, o, rv);
-        if (BACKWARD) load4<T>(p.grad_y, o, gv);
+        if (BACKWARD) {
+            load4<T>(p.grad_y, o, gv);
+            if (p.grad_y2) {
+                float g2[4];
+                load4<T>(p.grad_y2, o, g2);
+#pragma unroll
+                for (int i = 0; i < 4; i++) gv[i] += g2[i];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const float d = xv[i] - mean[i];
@@ -298,7 +318,8 @@ extern "C" int64_t mr_bn_act_backward_workspace_bytes(int batch_size, int channe
     return (int64_t)2 * channels * (split > mr::BN_NHWC_BLOCKS ? split : mr::BN_NHWC_BLOCKS) * 4 + 16;
 }
 
-extern "C" int mr_bn_act_backward(const void* grad_y, const void* x, const void* residual, const float* weight,
+extern "C" int mr_bn_act_backward(const void* grad_y, const void* grad_y2, const void* x, const void* residual,
+                                  const float* weight,
                                   const float* bias, const float* running_mean, const float* running_var, float eps,
                                   int relu, int act_dtype, int channels_last, void* grad_x, void* grad_residual,
                                   float* grad_weight, float* grad_bias, void* workspace, int64_t workspace_bytes,
@@ -322,13 +343,14 @@ extern "C" int mr_bn_act_backward(const void* grad_y, const void* x, const void*
     BnParams p{};
     p.x = x; p.residual = residual; p.weight = weight; p.bias = bias; p.mean = running_mean; p.var = running_var;
     p.eps = eps; p.relu = relu; p.N = batch_size; p.C = channels; p.HW = plane; p.split = bn_split(batch_size, channels);
-    p.grad_y = grad_y; p.grad_x = grad_x; p.grad_residual = grad_residual;
+    p.grad_y = grad_y; p.grad_y2 = grad_y2; p.grad_x = grad_x; p.grad_residual = grad_residual;
     p.partial = want_params ? static_cast<float*>(workspace) : nullptr;
     if ((int64_t)channels * p.split > 0x7fffffff || ((int64_t)batch_size / p.split + 1) * plane > 0x7fffffff) return MR_ERR_BADARG;
     const int vb = act_dtype == 0 ? 16 : 8;
     int slots = p.split;  // partial sums per channel
     if (channels_last) {
-        if (!bn_aligned(x, vb) || !bn_aligned(grad_y, vb) || !bn_aligned(grad_x, vb) || !bn_aligned(residual, vb) ||
+        if (!bn_aligned(x, vb) || !bn_aligned(grad_y, vb) || !bn_aligned(grad_y2, vb) || !bn_aligned(grad_x, vb) ||
+            !bn_aligned(residual, vb) ||
             !bn_aligned(grad_residual, vb))
             return MR_ERR_BADARG;
         slots = bn_nhwc_blocks((int64_t)batch_size * plane, channels);
@@ -336,7 +358,8 @@ extern "C" int mr_bn_act_backward(const void* grad_y, const void* x, const void*
         if (act_dtype == 0) hipLaunchKernelGGL((bn_act_nhwc_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((bn_act_nhwc_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
-        const bool vec = plane % 4 == 0 && bn_aligned(x, vb) && bn_aligned(grad_y, vb) && bn_aligned(grad_x, vb) &&
+        const bool vec = plane % 4 == 0 && bn_aligned(x, vb) && bn_aligned(grad_y, vb) && bn_aligned(grad_y2, vb) &&
+                         bn_aligned(grad_x, vb) &&
                          bn_aligned(residual, vb) && bn_aligned(grad_residual, vb);
         bn_launch<true>(p, act_dtype, vec, (hipStream_t)stream);
     }

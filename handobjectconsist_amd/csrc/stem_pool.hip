@@ -22,6 +22,7 @@ struct StemParams {
     int tiles_x, tiles_y;
     void* y;              // forward: [N,C,OH,OW]
     const void* grad_y;   // backward
+    const void* grad_y2;  // optional second gradient of y (y feeds two consumers): summed on load
     void* grad_x;         // [N,C,H,W]
     float* partial;       // [2][C][N * tiles]: sum g, sum g * (x - mean)   (channels-last: [2][C][workgroups])
     unsigned char* argmax;  // channels-last only: [N,OH,OW,C] arg-max position kh * 3 + kw, written by the forward
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
         int best = 0;
         if (oy < p.OH && ox < p.OW) {
             g = sp_f32(static_cast<const T*>(p.grad_y)[((int64_t)plane * p.OH + oy) * p.OW + ox]);
+            if (p.grad_y2) g += sp_f32(static_cast<const T*>(p.grad_y2)[((int64_t)plane * p.OH + oy) * p.OW + ox]);
             float mv = -__builtin_inff();  // PyTorch: first strictly greater value of relu(z) in (kh, kw) order, padding skipped
 #pragma unroll
             for (int k = 0; k < 9; k++) {
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(256) void stem_pool_nhwc_backward_kernel(StemParams
     for (int i = 0; i < 4; i++) stem_consts(p, c0 + i, mean[i], a[i], b[i]);
     const T* x = static_cast<const T*>(p.x);
     const T* gy = static_cast<const T*>(p.grad_y);
+    const T* gy2 = static_cast<const T*>(p.grad_y2);
     const int64_t total = (int64_t)p.N * p.H * p.W;
     float sg[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sgx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int64_t ip = (int64_t)blockIdx.x * rows + prow; ip < total; ip += (int64_t)gridDim.x * rows) {
@@ -325,6 +328,12 @@ __global__ __launch_bounds__(256) void stem_pool_nhwc_backward_kernel(StemParams
                 const uchar4 id = *reinterpret_cast<const uchar4*>(p.argmax + o);
                 float gv[4];
                 sp_load4<T>(gy, o, gv);
+                if (gy2) {
+                    float g2[4];
+                    sp_load4<T>(gy2, o, g2);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) gv[i] += g2[i];
+                }
                 const unsigned code = (unsigned)(kh * 3 + kw);
                 g[0] += id.x == code ? gv[0] : 0.0f;
                 g[1] += id.y == code ? gv[1] : 0.0f;
@@ -422,8 +431,8 @@ extern "C" int64_t mr_stem_pool_backward_workspace_bytes(int batch_size, int cha
     return (int64_t)2 * channels * (nchw > SP_NHWC_BLOCKS ? nchw : SP_NHWC_BLOCKS) * 4 + 16;
 }
 
-extern "C" int mr_stem_pool_backward(const void* grad_y, const void* x, const unsigned char* argmax, const float* weight,
-                                     const float* bias, const float* running_mean, const float* running_var, float eps,
+extern "C" int mr_stem_pool_backward(const void* grad_y, const void* grad_y2, const void* x, const unsigned char* argmax,
+                                     const float* weight, const float* bias, const float* running_mean, const float* running_var, float eps,
                                      int act_dtype, int channels_last, void* grad_x, float* grad_weight,
                                      float* grad_bias, void* workspace, int64_t workspace_bytes, int batch_size,
                                      int channels, int height, int width, mr_stream_t stream) {
@@ -445,13 +454,14 @@ extern "C" int mr_stem_pool_backward(const void* grad_y, const void* x, const un
     if (want_params &&
         (!workspace || workspace_bytes < mr_stem_pool_backward_workspace_bytes(batch_size, channels, height, width)))
         return MR_ERR_BADARG;
-    p.grad_y = grad_y; p.grad_x = grad_x;
+    p.grad_y = grad_y; p.grad_y2 = grad_y2; p.grad_x = grad_x;
     p.partial = want_params ? static_cast<float*>(workspace) : nullptr;
     const int tiles = p.tiles_x * p.tiles_y;
     int64_t slots = (int64_t)batch_size * tiles;
     if (channels_last) {
         const uintptr_t am = (uintptr_t)(act_dtype == 0 ? 15 : 7);
         if (!argmax || (reinterpret_cast<uintptr_t>(x) & am) || (reinterpret_cast<uintptr_t>(grad_y) & am) ||
+            (reinterpret_cast<uintptr_t>(grad_y2) & am) ||
             (reinterpret_cast<uintptr_t>(grad_x) & am) || (reinterpret_cast<uintptr_t>(argmax) & 3))
             return MR_ERR_BADARG;
         p.argmax = const_cast<unsigned char*>(argmax);

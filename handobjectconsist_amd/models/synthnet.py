@@ -64,12 +64,17 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
+    def forward_fused(self, x, x_identity, dup=False):
+        """The block on this build's kernels.  x / x_identity: the block input as the two autograd outputs of its
+        producer (one for the convolution, one for the identity branch; the same tensor twice is fine too)."""
+        residual = x_identity if self.downsample is None else frozen_bn.bn_act(
+            self.downsample[0](x_identity), self.downsample[1], relu=False)
+        out = frozen_bn.bn_act(self.conv1(x), self.bn1)
+        return frozen_bn.bn_act(self.conv2(out), self.bn2, residual=residual, dup=dup)
+
     def forward(self, x):
         if _fused_bn(self.bn1, x):
-            residual = x if self.downsample is None else frozen_bn.bn_act(self.downsample[0](x), self.downsample[1],
-                                                                         relu=False)
-            out = frozen_bn.bn_act(self.conv1(x), self.bn1)
-            return frozen_bn.bn_act(self.conv2(out), self.bn2, residual=residual)
+            return self.forward_fused(x, x)
         residual = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
@@ -110,10 +115,16 @@ class ResNet18Features(nn.Module):
                 self.to(memory_format=torch.channels_last)  # once: convolution weights (the Parameter objects stay)
             x = x.contiguous(memory_format=torch.channels_last)
         if _fused_bn(self.bn1, x):
-            x = frozen_bn.stem_pool(self.conv1(x), self.bn1)  # bn1 + relu + maxpool(3, 2, 1)
+            # every activation with two consumers (the next block's convolution and its identity branch) leaves its
+            # producer as two autograd outputs, so that the producer's backward kernel sums the two gradients on load
+            blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
+            pair = frozen_bn.stem_pool(self.conv1(x), self.bn1, dup=True)  # bn1 + relu + maxpool(3, 2, 1)
+            for block in blocks[:-1]:
+                pair = block.forward_fused(pair[0], pair[1], dup=True)
+            x = blocks[-1].forward_fused(pair[0], pair[1])
         else:
             x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return x.mean(3).mean(2)
 
 

@@ -377,13 +377,15 @@ MR_API int mr_frames_to_batch(const uint8_t* frames, const double* coeffs, const
  * channels_last = 1: the activations are in NHWC memory order [batch_size, plane, channels] (what MIOpen's
  * convolutions prefer); requires channels to be a power of two in [4, 1024] and 16-byte (bf16: 8-byte) alignment.  Backward: g = relu && !(z > 0) ? 0 : grad_y;  grad_x = g * weight / sqrt(var + eps);
  * grad_residual = g (NULL if not wanted); grad_bias = sum g; grad_weight = sum g * (x - mean) / sqrt(var + eps)
- * (either may be NULL; two-stage deterministic reduction through the workspace). */
+ * (either may be NULL; two-stage deterministic reduction through the workspace).  grad_y2 (nullable): a second
+ * gradient of y, added to grad_y on load -- y usually feeds two consumers (the next block's convolution and its
+ * identity branch), and summing the two gradients here saves autograd's separate add pass. */
 MR_API int mr_bn_act_forward(const void* x, const void* residual, const float* weight, const float* bias,
                              const float* running_mean, const float* running_var, float eps, int relu,
                              int act_dtype, int channels_last, void* y, int batch_size, int channels,
                              int plane, mr_stream_t stream);
 MR_API int64_t mr_bn_act_backward_workspace_bytes(int batch_size, int channels);
-MR_API int mr_bn_act_backward(const void* grad_y, const void* x, const void* residual,
+MR_API int mr_bn_act_backward(const void* grad_y, const void* grad_y2, const void* x, const void* residual,
                               const float* weight, const float* bias, const float* running_mean,
                               const float* running_var, float eps, int relu, int act_dtype,
                               int channels_last, void* grad_x, void* grad_residual, float* grad_weight,
@@ -404,7 +406,8 @@ MR_API int mr_stem_pool_forward(const void* x, const float* weight, const float*
                                 int act_dtype, int channels_last, void* y, unsigned char* argmax,
                                 int batch_size, int channels, int height, int width, mr_stream_t stream);
 MR_API int64_t mr_stem_pool_backward_workspace_bytes(int batch_size, int channels, int height, int width);
-MR_API int mr_stem_pool_backward(const void* grad_y, const void* x, const unsigned char* argmax,
+MR_API int mr_stem_pool_backward(const void* grad_y, const void* grad_y2, const void* x,
+                                 const unsigned char* argmax,
                                  const float* weight, const float* bias, const float* running_mean,
                                  const float* running_var, float eps, int act_dtype, int channels_last,
                                  void* grad_x, float* grad_weight, float* grad_bias, void* workspace,
