@@ -361,3 +361,32 @@ def test_trunk_glue_at_the_metric_shapes(cuda):
     # the backward is linear in grad_y; its identity branch passes grad_y through the ReLU mask unchanged
     _close(res[True][1][0][0] + res[True][1][1][0], res[True][1][2][0], 1e-6, "linearity of grad x")
     assert torch.equal(res[True][1][0][1], torch.where(res[True][0] > 0, g1, torch.zeros_like(g1)).contiguous(memory_format=torch.channels_last))
+
+
+def test_training_trajectory_fused_trunk_vs_stock_modules(cuda, monkeypatch):
+    """Ten optimiser steps of the whole trainer (data + consistency batches) with everything this build adds to the
+    trunk (channels-last, fused BatchNorm / ReLU / identity / max-pool kernels, dual-output activations) against the
+    stock NCHW modules: the loss trajectories stay together.  SGD and a zero weight on the photometric term: that
+    term is piecewise constant in the network's outputs (pixel coverage, validity masks) and Adam normalises
+    gradient magnitudes, so with either of them last-bit differences grow into different trajectories within a few
+    steps -- in both builds alike; the smooth part of the objective is what can be compared step by step."""
+    from handobjectconsist_amd.models import synthnet
+    from handobjectconsist_amd.models.warpreg import WarpRegNet
+    from handobjectconsist_amd.netscripts import epochpassconsist as E
+
+    traj = {}
+    for fused in (True, False):
+        monkeypatch.setattr(synthnet, "USE_HIP_BN", fused)
+        monkeypatch.setattr(synthnet, "USE_CHANNELS_LAST", fused)
+        torch.manual_seed(0)
+        model = synthnet.SynthMeshRegNet().to(cuda).eval()
+        pre = WarpRegNet((64, 64), model, lambda_consist=0.0, lambda_data=1.0, criterion="l1", gt_refs=True,
+                         use_backward=True, mano_faces=model.mano_layer.th_faces, pair_outputs="loss").to(cuda)
+        pre.step_count = 1000
+        opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+        loader = E.SyntheticConsistLoader(4, 64, seed=0, device=cuda, pool=2)
+        traj[fused] = [float(E.train_step(loader.step_batches(i), pre, opt)[0]) for i in range(10)]
+    a, b = np.array(traj[True]), np.array(traj[False])
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
+    assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max(), (a, b)
+    assert abs(b[-1] - b[0]) > 1e-6 * abs(b[0])  # the parameters do move
