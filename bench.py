@@ -47,6 +47,7 @@ def parse():
                         "autocast, heads / MANO / render / warp stay fp32 -- reported with dtype 'bf16+f32'")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-bench", action="store_true")
+    p.add_argument("--no-stock-trunk", action="store_true", help="skip the informational run with the stock trunk modules")
     p.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample")
     p.add_argument("--kernel-iters", type=int, default=50)
     p.add_argument("--kernels-only", action="store_true", help="only the per-kernel benchmark (profiling aid)")
@@ -442,6 +443,42 @@ def main():
             print(json.dumps({"hot_path_ms": hot_ms}))
             return
 
+    # the same step with the trunk exactly as stock PyTorch-ROCm runs it (nn.BatchNorm2d / ReLU / MaxPool2d modules,
+    # NCHW, MIOpen's default solver choice): what this build's trunk glue kernels + channels-last layout are worth.
+    # Informational (single GPU only); `value` above is the default configuration.
+    stock = None
+    if rank == 0 and world == 1 and not use_dist and not args.hot_only and not args.no_stock_trunk \
+            and args.encoder_dtype == "f32":
+        from handobjectconsist_amd.models import synthnet as _sn
+
+        saved = (_sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark)
+        _sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark = False, False, False
+        try:
+            torch.manual_seed(rank)
+            model_s = SynthMeshRegNet().to(dev)
+            model_s.eval()
+            pre_s = WarpRegNet((is_, ih_), model_s, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
+                               progressive_steps=1000, use_backward=True, mano_faces=model_s.mano_layer.th_faces,
+                               pair_outputs="loss").to(dev)
+            pre_s.step_count = 1000
+            opt_s = torch.optim.Adam([p for p in model_s.parameters() if p.requires_grad], lr=5e-5,
+                                     fused=os.environ.get("HOC_FUSED_ADAM", "1") == "1")
+            for i in range(max(args.warmup, 2)):
+                train_step(loader.step_batches(i), pre_s, opt_s)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                train_step(loader.step_batches(i), pre_s, opt_s)
+            torch.cuda.synchronize()
+            dt_s = time.perf_counter() - t1
+            stock = {"what": "same step, trunk on stock PyTorch-ROCm modules (BatchNorm2d / ReLU / MaxPool2d, NCHW, "
+                             "cudnn.benchmark off); render + warp + MANO + heads unchanged",
+                     "ms_per_step": round(dt_s / args.steps * 1e3, 3), "value": round(args.steps / dt_s, 4)}
+            del model_s, pre_s, opt_s
+        finally:
+            _sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark = saved
+        torch.cuda.empty_cache()
+
     kernels, roof, cpu = None, None, None
     if rank == 0 and not args.no_kernel_bench:
         kernels = kernel_bench(dev, B, is_, args.kernel_iters)
@@ -469,7 +506,7 @@ def main():
                                    f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {('fp32' if args.encoder_dtype == 'f32' else 'bf16-autocast') + ' (MIOpen convolutions, channels-last, + fused HIP BatchNorm/ReLU/residual/max-pool kernels)'}, Adam",
                        "global_batch": B * world, "image_size": is_, "parallelism": f"dp{world}"},
             "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),
-            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "stock_trunk": stock, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -36,6 +36,8 @@ def test_bench_single_process_line(cuda):
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert abs(roof["achieved"] - roof["algorithmic_bytes"] / (roof["launch_ms"] * 1e-3) / 1e9) <= 0.02 * roof["achieved"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    # the informational run of the same step with the stock trunk modules
+    assert line["stock_trunk"]["value"] > 0 and line["stock_trunk"]["ms_per_step"] > 0
 
 
 @pytest.mark.gpu
