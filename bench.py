@@ -331,6 +331,11 @@ def pmc_traffic(kernel_name):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 (RCCL prints its
+    # version banner there, buffered until exit) is sent to stderr for the duration of the run
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -366,7 +371,7 @@ def main():
 
     assert _lib.load().mr_device_ok() == 1, "libmeshraster_hip.so: no gfx950 device"
     if args.kernels_only:
-        print(json.dumps(kernel_bench(dev, args.batch, args.image_size, args.kernel_iters), indent=1))
+        os.write(real_stdout, (json.dumps(kernel_bench(dev, args.batch, args.image_size, args.kernel_iters), indent=1) + "\n").encode())
         return
     torch.manual_seed(rank)
     B, is_ = args.batch, args.image_size
@@ -380,7 +385,8 @@ def main():
 
         # 8 MB buckets overlap the RCCL all-reduce with the encoder backward; frozen BN statistics
         # -> no buffer broadcast (the three forwards of a step share the buffers)
-        net = DDP(model, device_ids=[dev_index], bucket_cap_mb=8, broadcast_buffers=False)
+        net = DDP(model, device_ids=[dev_index], bucket_cap_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "8")),
+                  broadcast_buffers=False, gradient_as_bucket_view=os.environ.get("HOC_DDP_BUCKET_VIEW", "1") == "1")
     ih_ = args.image_height or is_
     assert ih_ <= is_, "--image-height must not exceed --image-size (the raster is the square of the longer side)"
     premodel = WarpRegNet((is_, ih_), net, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
@@ -440,7 +446,7 @@ def main():
 
         hot_ms = event_time_ms(hot, 10, 3)
         if args.hot_only:
-            print(json.dumps({"hot_path_ms": hot_ms}))
+            os.write(real_stdout, (json.dumps({"hot_path_ms": hot_ms}) + "\n").encode())
             return
 
     # the same step with the trunk exactly as stock PyTorch-ROCm runs it (nn.BatchNorm2d / ReLU / MaxPool2d modules,
@@ -508,7 +514,8 @@ def main():
             "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),
             "stock_trunk": stock, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
