@@ -93,8 +93,21 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+class _StreamArg(ctypes.c_void_p):
+    """hipStream_t argument that remembers which device it belongs to (see ``call``)."""
+
+    device_index = None
+
+
 def stream_ptr(device=None):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """The torch current stream of ``device`` as the C-ABI's stream argument.  Every entry point takes the
+    stream of the device its tensors live on; ``call`` switches the thread's current HIP device to that
+    device for the duration of the launch when it differs (tensors on cuda:1 while cuda:0 is current)."""
+    arg = _StreamArg(torch.cuda.current_stream(device).cuda_stream)
+    if device is not None:
+        device = torch.device(device)
+        arg.device_index = device.index if device.index is not None else torch.cuda.current_device()
+    return arg
 
 
 def check_cuda(*tensors):
@@ -106,7 +119,14 @@ def check_cuda(*tensors):
 def call(name, *args):
     """Invoke an entry point; non-zero status -> RuntimeError (the reference's C++ asserts
     surface as RuntimeError too)."""
-    rc = getattr(load(), name)(*args)
+    fn = getattr(load(), name)
+    dev = getattr(args[-1], "device_index", None) if args else None
+    if dev is not None and dev != torch.cuda.current_device():
+        # HIP launches go to the calling thread's CURRENT device: make it the tensors' device
+        with torch.cuda.device(dev):
+            rc = fn(*args)
+    else:
+        rc = fn(*args)
     if rc != 0:
         kind = {-1: "bad argument", -2: "not implemented"}.get(rc, f"hipError_t {rc}")
         raise RuntimeError(f"{name} failed: {kind}")

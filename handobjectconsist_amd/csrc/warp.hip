@@ -849,10 +849,12 @@ extern "C" int mr_pair_consist_backward(const float* flow12, const float* flow21
 extern "C" int mr_abi_version(void) { return 1; }
 
 extern "C" int mr_device_ok(void) {
-    int n = 0;
+    // the calling thread's CURRENT device: that is where every entry point of this library launches
+    int n = 0, dev = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     const char* a = prop.gcnArchName;
     return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
 }

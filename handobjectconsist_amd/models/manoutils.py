@@ -14,7 +14,14 @@ CLOSE_FACES = [
 HAND_IGNORE_FACES = [1538, 1539, 1540, 1541, 1542, 1543, 1544, 1545, 1546, 1547, 1548, 1549, 1550, 1551]
 
 
-def get_closed_faces(th_faces):
-    """th_faces [1538,3] (MANO faces) -> (closed_faces [1552,3], hand_ignore_faces)."""
+def get_closed_faces(th_faces=None):
+    """-> (closed_faces [1552,3], hand_ignore_faces).  Called without arguments, like the reference
+    (manoutils.py:6, call site warpreg.py:61), the open faces are those of this package's MANO-layer
+    counterpart (the reference instantiates manopth's ManoLayer for its ``th_faces``); a caller holding
+    another layer passes its ``th_faces`` [1538,3]."""
+    if th_faces is None:
+        from handobjectconsist_amd.utils import synth
+
+        th_faces = torch.as_tensor(synth.hand_template()[1][:1538], dtype=torch.long)
     close_faces = torch.tensor(CLOSE_FACES, dtype=torch.long, device=th_faces.device)
     return torch.cat([th_faces.long(), close_faces]), list(HAND_IGNORE_FACES)

@@ -10,11 +10,13 @@ return value) organised as three steps:
    detach_renders=True`` (:59-68): gradients reach the vertices only through the flow VALUES.
 3. one ``pair_consist`` per (frame 0, frame k) pair, averaged (:73-88).
 
-Samples are dicts of device-resident tensors keyed by plain strings: "image", "jittermask",
-"camintr", "objfaces" and, for annotated frames, "handverts3d" / "objverts3d" (the dataset layer
-with its Queries enums is out of scope)."""
+Samples are dicts of tensors keyed like the reference's (``TransQueries.IMAGE / JITTERMASK / CAMINTR``,
+``BaseQueries.OBJFACES`` and, for annotated frames, ``BaseQueries.HANDVERTS3D / OBJVERTS3D``:
+datasets/queries.py) or by the plain strings "image", "jittermask", "camintr", "objfaces",
+"handverts3d", "objverts3d" the synthetic loaders of this package use."""
 import torch
 
+from handobjectconsist_amd.datasets.queries import lookup as _q
 from handobjectconsist_amd.warping import imgflowarp, opticalflow
 
 
@@ -29,7 +31,9 @@ def _cat_faces(hand_face, obj_faces, batch, hand_verts):
         + (batch, hand_verts)
     hit = _FACES_CACHE.get("last")
     if hit is None or hit[0] != key:
-        hand_faces = hand_face.long().unsqueeze(0).expand(batch, -1, -1) if hand_face.dim() == 2 else hand_face.long()
+        hand_faces = hand_face.long().unsqueeze(0) if hand_face.dim() == 2 else hand_face.long()
+        if hand_faces.shape[0] == 1:  # warpbranch.py:36: hand_face.repeat(batch, 1, 1)
+            hand_faces = hand_faces.expand(batch, -1, -1)
         faces = torch.cat([hand_faces, obj_faces.long().cuda() + hand_verts], 1)
         hit = (key, faces, hand_face, obj_faces)  # holds the inputs: their addresses stay unique while cached
         _FACES_CACHE["last"] = hit
@@ -41,12 +45,12 @@ def _frame_meshes(samples, all_results, hand_face, gt_refs, first_only):
     frames = []
     for k, (sample, result) in enumerate(zip(samples, all_results)):
         annotated = gt_refs and k > 0
-        hand = sample["handverts3d"].cuda() if annotated else result["recov_handverts3d"]
-        obj = sample["objverts3d"].cuda() if annotated else result["recov_objverts3d"]
+        hand = _q(sample, "handverts3d").cuda() if annotated else result["recov_handverts3d"]
+        obj = _q(sample, "objverts3d").cuda() if annotated else result["recov_objverts3d"]
         verts = torch.cat([hand, obj], 1)
         frames.append(verts.detach() if (first_only and k > 0) else verts)
     # the reference concatenates the faces of every frame and keeps the LAST frame's (warpbranch.py:49-55)
-    faces = _cat_faces(hand_face, samples[-1]["objfaces"], batch, hand.shape[1])
+    faces = _cat_faces(hand_face, _q(samples[-1], "objfaces"), batch, hand.shape[1])
     return frames, faces
 
 
@@ -78,21 +82,21 @@ def forward(
     recons_flows = opticalflow.get_opticalflows(
         verts_world,
         all_faces,
-        [sample["camintr"].cuda() for sample in samples],
+        [_q(sample, "camintr").cuda() for sample in samples],
         renderer,
         image_size,
         detach_textures=False,
         detach_renders=True,
         ignore_face_idxs=hand_ignore_faces,
     )
-    ref_image, ref_jitter = samples[0]["image"].cuda(), samples[0]["jittermask"].cuda()
+    ref_image, ref_jitter = _q(samples[0], "image").cuda(), _q(samples[0], "jittermask").cuda()
     per_pair = [
         imgflowarp.pair_consist(
             flow,
             image_ref=ref_image,
-            image=sample["image"].cuda(),
+            image=_q(sample, "image").cuda(),
             jitter_mask_ref=ref_jitter,
-            jitter_mask=sample["jittermask"].cuda(),
+            jitter_mask=_q(sample, "jittermask").cuda(),
             criterion=criterion,
             use_backward=use_backward,
             outputs=pair_outputs,

@@ -48,7 +48,11 @@ typedef void* mr_stream_t;
 
 /* ABI version of this header (bumped on any signature change). */
 MR_API int mr_abi_version(void);
-/* 1 if a gfx950-capable device is visible to the HIP runtime, else 0. */
+/* 1 if the calling thread's CURRENT HIP device is a gfx950, else 0.
+ * Device contract of every entry point below: kernels are launched on the calling thread's current HIP
+ * device, on `stream`, which must belong to that device, as must every pointer.  A host with several GPUs
+ * selects the device (hipSetDevice) before calling; the Python binding does so from the device of the
+ * tensors it passes (handobjectconsist_amd/_lib.py: call). */
 MR_API int mr_device_ok(void);
 
 /* ------------------------------------------------------------------------------------

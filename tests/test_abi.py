@@ -95,3 +95,46 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
                 assert "liboracle" not in txt, f
+
+
+def test_call_switches_to_the_device_of_its_stream(monkeypatch):
+    """``_lib.call`` launches on the device its stream argument was taken from, not on whatever device
+    happens to be current (tensors on cuda:1 while cuda:0 is current)."""
+    import contextlib
+
+    import torch
+
+    from handobjectconsist_amd import _lib
+
+    events = []
+
+    class FakeLib:
+        @staticmethod
+        def mr_fake(*args):
+            events.append(("launch", torch.cuda.current_device()))
+            return 0
+
+    state = {"current": 0}
+
+    @contextlib.contextmanager
+    def fake_device(idx):
+        prev, state["current"] = state["current"], idx
+        events.append(("enter", idx))
+        try:
+            yield
+        finally:
+            state["current"] = prev
+            events.append(("exit", idx))
+
+    monkeypatch.setattr(_lib, "load", lambda: FakeLib)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: state["current"])
+    monkeypatch.setattr(torch.cuda, "device", fake_device)
+    s1 = _lib._StreamArg(0)
+    s1.device_index = 1
+    _lib.call("mr_fake", None, 3, s1)
+    assert events == [("enter", 1), ("launch", 1), ("exit", 1)]
+    events.clear()
+    s0 = _lib._StreamArg(0)
+    s0.device_index = 0
+    _lib.call("mr_fake", None, 3, s0)
+    assert events == [("launch", 0)]
