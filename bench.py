@@ -403,23 +403,36 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # the reference raises on a NaN loss before backward / step (epochpassconsist.py:61-63): one host sync per step,
+    # kept inside the timed region (HOC_CHECK_NAN=0 measures the step without it)
+    check_nan = os.environ.get("HOC_CHECK_NAN", "1") == "1"
     for i in range(0 if args.hot_only else args.warmup):
-        train_step(loader.step_batches(i), premodel, optimizer)
+        train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = torch.zeros(1)
     for i in range(0 if args.hot_only else args.steps):
-        loss, _ = train_step(loader.step_batches(i), premodel, optimizer)
+        loss, _ = train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan)
     torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0  # this rank's own K steps, before it waits for the others
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ranks = None
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # evidence that N ranks ran: every rank's device, its own step time and the collective backend
+        mine = torch.tensor([float(rank), float(dev_index), t_local / max(args.steps, 1) * 1e3], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ranks = {"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "world_size": world,
+                 "per_rank": [{"rank": int(r_[0]), "device": int(r_[1]), "ms_per_step": round(float(r_[2]), 3)} for r_ in allr],
+                 "grad_allreduce_MB": round(sum(p_.numel() for p_ in model.parameters() if p_.requires_grad) * 4 / 1e6, 1),
+                 "ddp_bucket_MB": int(os.environ.get("HOC_DDP_BUCKET_MB", "8"))}
     assert torch.isfinite(loss).all(), "loss is not finite"
     if dist is not None and os.environ.get("HOC_CHECK_REPLICAS", "0") == "1":
         # data-parallel replicas must stay bit-identical: same averaged gradients, same Adam update on every rank
@@ -470,11 +483,11 @@ def main():
             opt_s = torch.optim.Adam([p for p in model_s.parameters() if p.requires_grad], lr=5e-5,
                                      fused=os.environ.get("HOC_FUSED_ADAM", "1") == "1")
             for i in range(max(args.warmup, 2)):
-                train_step(loader.step_batches(i), pre_s, opt_s)
+                train_step(loader.step_batches(i), pre_s, opt_s, check_nan=check_nan)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(args.steps):
-                train_step(loader.step_batches(i), pre_s, opt_s)
+                train_step(loader.step_batches(i), pre_s, opt_s, check_nan=check_nan)
             torch.cuda.synchronize()
             dt_s = time.perf_counter() - t1
             stock = {"what": "same step, trunk on stock PyTorch-ROCm modules (BatchNorm2d / ReLU / MaxPool2d, NCHW, "
@@ -512,7 +525,7 @@ def main():
                                    f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {('fp32' if args.encoder_dtype == 'f32' else 'bf16-autocast') + ' (MIOpen convolutions, channels-last, + fused HIP BatchNorm/ReLU/residual/max-pool kernels)'}, Adam",
                        "global_batch": B * world, "image_size": is_, "parallelism": f"dp{world}"},
             "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),
-            "stock_trunk": stock, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "ranks": ranks, "stock_trunk": stock, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

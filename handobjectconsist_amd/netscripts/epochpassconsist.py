@@ -25,8 +25,10 @@ BATCH_POST = os.environ.get("HOC_BATCH_POST", "1") != "0"
 BATCH_ENCODER = os.environ.get("HOC_BATCH_ENCODER", "1") != "0"
 
 
-def train_step(batches, premodel, optimizer):
-    """One optimiser step over `loader_nb = len(batches)` batches (epochpassconsist.py:57-68)."""
+def train_step(batches, premodel, optimizer, check_nan=True):
+    """One optimiser step over `loader_nb = len(batches)` batches (epochpassconsist.py:57-68).  With
+    ``check_nan`` a NaN loss raises BEFORE zero_grad / backward / step, as the reference does (:61-63): the
+    parameters and the Adam state are not touched by a diverged step (one host synchronisation per step)."""
     losses, logs = [], {}
     if (BATCH_POST or BATCH_ENCODER) and hasattr(premodel, "prepare"):
         premodel.prepare(batches, batch_encoder=BATCH_ENCODER)
@@ -40,8 +42,10 @@ def train_step(batches, premodel, optimizer):
             for sample in batch["data"]:
                 sample.pop("_features", None)
                 sample.pop("_post", None)
-    optimizer.zero_grad(set_to_none=True)
     loss = torch.stack(losses).sum()
+    if check_nan and bool(torch.isnan(loss)):
+        raise ValueError("Loss became nan!")
+    optimizer.zero_grad(set_to_none=True)
     if loss.requires_grad:
         loss.backward()
         optimizer.step()
@@ -54,9 +58,7 @@ def epoch_pass(loader, premodel, optimizer, loader_nb=2, check_nan=True):
     for batch in loader:
         pending.append(batch)
         if len(pending) == loader_nb:
-            loss, _ = train_step(pending, premodel, optimizer)
-            if check_nan and bool(torch.isnan(loss)):
-                raise ValueError("Loss became nan!")
+            loss, _ = train_step(pending, premodel, optimizer, check_nan=check_nan)
             history.append(loss)
             pending = []
     return history
