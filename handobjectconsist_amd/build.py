@@ -46,25 +46,55 @@ def needs_build():
         return fh.read().strip() != source_hash()
 
 
+OBJ_DIR = os.path.join(_HERE, "build")  # git-ignored object cache (one .o per source, keyed by content hash)
+COMPILE_FLAGS = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+
+def _object_for(src, headers_hash):
+    with open(os.path.join(CSRC, src), "rb") as fh:
+        key = hashlib.sha256(" ".join(COMPILE_FLAGS).encode() + headers_hash + fh.read()).hexdigest()[:16]
+    return os.path.join(OBJ_DIR, f"{os.path.splitext(src)[0]}.{key}.o")
+
+
 def build_library(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 ... -> handobjectconsist_amd/libmeshraster_hip.so.  Prints whether the
-    library was compiled or an up-to-date one (same source hash) was reused."""
+    """hipcc --offload-arch=gfx950 ... -> handobjectconsist_amd/libmeshraster_hip.so.  Sources are compiled
+    to objects in parallel (cached by content hash under build/) and linked; prints whether the library was
+    compiled or an up-to-date one (same source hash) was reused."""
     if not force and not needs_build():
         if verbose:
             print("libmeshraster_hip.so: reused (source hash %s)" % source_hash()[:12])
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hh = hashlib.sha256()
+    for hdr in sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))) + [os.path.join("..", "..", "include", "meshraster_hip.h")]:
+        with open(os.path.join(CSRC, hdr), "rb") as fh:
+            hh.update(fh.read())
+    objs = [_object_for(src, hh.digest()) for src in SOURCES]
+    procs = []
+    for src, obj in zip(SOURCES, objs):
+        if os.path.exists(obj):
+            continue
+        cmd = [_hipcc()] + COMPILE_FLAGS + ["-c", "-o", obj + ".tmp.o", os.path.join(CSRC, src)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((obj, cmd, subprocess.Popen(cmd)))
+    for obj, cmd, proc in procs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        os.replace(obj + ".tmp.o", obj)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    for junk in os.listdir(_HERE):  # clang-offload-bundler leftovers of an interrupted link
-        if junk.startswith("libmeshraster_hip.so.tmp") or junk.startswith("libmeshraster_hip.so.tmp."):
-            os.remove(os.path.join(_HERE, junk))
+    keep = set(objs)
+    for junk in os.listdir(OBJ_DIR):  # objects of older source versions
+        if os.path.join(OBJ_DIR, junk) not in keep:
+            os.remove(os.path.join(OBJ_DIR, junk))
     with open(STAMP_PATH, "w") as fh:
         fh.write(source_hash() + "\n")
     if verbose:
-        print("libmeshraster_hip.so: compiled (source hash %s)" % source_hash()[:12])
+        print("libmeshraster_hip.so: compiled %d of %d sources (source hash %s)" % (len(procs), len(SOURCES), source_hash()[:12]))
     return LIB_PATH
 
 

@@ -70,46 +70,75 @@ __device__ __forceinline__ void load_face(const float* __restrict__ g, Face& f, 
 // i.e. only for apex angles of ~1e-7 rad.  Faces whose smallest angle (area / product of the two longest
 // edges) is below 16 eps ~ 1e-6 rad are flagged: an order of magnitude of margin, and nothing but
 // numerically collinear faces (none of the 28416 front faces of the bench scene).
-__device__ __forceinline__ FaceBox face_box(const float* f, int is) {
-    FaceBox b;
-    b.x0 = 1; b.x1 = 0; b.y0 = 1; b.y1 = 0;
-    bool anynan = false;
-#pragma unroll
-    for (int k = 0; k < 9; k++) anynan |= (f[k] != f[k]);
-    if (anynan || backfacing(f)) return b;
-    const float fis = (float)is;
+// The part of face_box that does not depend on the ORDER of the three vertices (a face and its
+// fill-back copy -- the same vertices in reverse order -- share it): NaN check, pixel coordinates,
+// their finiteness, the clipped bounding box and the product of the two longest edges.  Every value is
+// a min / max / |difference| / commutative product of the same operands in both orders, hence
+// bit-identical.
+struct BoxShared {
     float px[3], py[3];
+    float two_longest;
+    FaceBox box;      // clipped bbox (empty if off screen)
+    bool anynan;
+    bool nonfinite;   // a pixel coordinate is Inf (or NaN)
+};
+
+__device__ __forceinline__ void face_box_shared(const float* f, int is, BoxShared& s) {
+    s.anynan = false;
+#pragma unroll
+    for (int k = 0; k < 9; k++) s.anynan |= (f[k] != f[k]);
+    const float fis = (float)is;
 #pragma unroll
     for (int n = 0; n < 3; n++) {
-        px[n] = 0.5f * (f[3 * n + 0] * fis + fis - 1.0f);
-        py[n] = 0.5f * (f[3 * n + 1] * fis + fis - 1.0f);
+        s.px[n] = 0.5f * (f[3 * n + 0] * fis + fis - 1.0f);
+        s.py[n] = 0.5f * (f[3 * n + 1] * fis + fis - 1.0f);
     }
-    const float den = (px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]));
-    // twice the signed area from the back-face products (front-facing: !(pa < pb)) against the product of the
-    // two longest edges (max-norm): their ratio is the smallest angle of the triangle
-    const float pa = (f[7] - f[1]) * (f[3] - f[0]), pb = (f[4] - f[1]) * (f[6] - f[0]);
     const float e01 = fmaxf(fabsf(f[3] - f[0]), fabsf(f[4] - f[1])), e12 = fmaxf(fabsf(f[6] - f[3]), fabsf(f[7] - f[4])),
                 e20 = fmaxf(fabsf(f[0] - f[6]), fabsf(f[1] - f[7]));
     const float emin = fminf(e01, fminf(e12, e20));
-    const float two_longest = emin > 0.0f ? (e01 * e12 * e20) / emin : fmaxf(e01, fmaxf(e12, e20)) * fmaxf(e01, fmaxf(e12, e20));
-    bool full = !(den != 0.0f) || !(fabsf(den) <= 3.0e38f) || !(pa - pb > 16.0f * 5.9604645e-8f * two_longest);
+    const float emax = fmaxf(e01, fmaxf(e12, e20));
+    s.two_longest = emin > 0.0f ? (e01 * e12 * e20) / emin : emax * emax;
+    s.nonfinite = false;
 #pragma unroll
-    for (int n = 0; n < 3; n++) full |= !(fabsf(px[n]) <= 3.0e38f) || !(fabsf(py[n]) <= 3.0e38f);
+    for (int n = 0; n < 3; n++) s.nonfinite |= !(fabsf(s.px[n]) <= 3.0e38f) || !(fabsf(s.py[n]) <= 3.0e38f);
+    s.box.x0 = 1; s.box.x1 = 0; s.box.y0 = 1; s.box.y1 = 0;
+    const float lim = fis - 1.0f;
+    const float xlo = floorf(fminf(s.px[0], fminf(s.px[1], s.px[2])));
+    const float xhi = ceilf(fmaxf(s.px[0], fmaxf(s.px[1], s.px[2])));
+    const float ylo = floorf(fminf(s.py[0], fminf(s.py[1], s.py[2])));
+    const float yhi = ceilf(fmaxf(s.py[0], fmaxf(s.py[1], s.py[2])));
+    if (!(xhi < 0.0f || yhi < 0.0f || xlo > lim || ylo > lim)) {
+        s.box.x0 = (int16_t)fmaxf(xlo, 0.0f);
+        s.box.x1 = (int16_t)fminf(xhi, lim);
+        s.box.y0 = (int16_t)fmaxf(ylo, 0.0f);
+        s.box.y1 = (int16_t)fminf(yhi, lim);
+    }
+}
+
+// The order-dependent part, for the vertex order (a, b, c) = (0, 1, 2) or, REV, (2, 1, 0).
+template <bool REV>
+__device__ __forceinline__ FaceBox face_box_orient(const float* f, int is, const BoxShared& s) {
+    constexpr int A = REV ? 2 : 0, B = 1, C = REV ? 0 : 2;
+    FaceBox b;
+    b.x0 = 1; b.x1 = 0; b.y0 = 1; b.y1 = 0;
+    const float xa = f[3 * A], ya = f[3 * A + 1], xb = f[3 * B], yb = f[3 * B + 1], xc = f[3 * C], yc = f[3 * C + 1];
+    // backfacing(): (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0])
+    const float pa = (yc - ya) * (xb - xa), pb = (yb - ya) * (xc - xa);
+    if (s.anynan || pa < pb) return b;
+    const float den = (s.px[C] * (s.py[A] - s.py[B]) + s.px[A] * (s.py[B] - s.py[C]) + s.px[B] * (s.py[C] - s.py[A]));
+    const bool full = !(den != 0.0f) || !(fabsf(den) <= 3.0e38f) || !(pa - pb > 16.0f * 5.9604645e-8f * s.two_longest) ||
+                      s.nonfinite;
     if (full) {
         b.x0 = 0; b.x1 = (int16_t)(is - 1); b.y0 = 0; b.y1 = (int16_t)(is - 1);
         return b;
     }
-    const float lim = fis - 1.0f;
-    float xlo = floorf(fminf(px[0], fminf(px[1], px[2])));
-    float xhi = ceilf(fmaxf(px[0], fmaxf(px[1], px[2])));
-    float ylo = floorf(fminf(py[0], fminf(py[1], py[2])));
-    float yhi = ceilf(fmaxf(py[0], fmaxf(py[1], py[2])));
-    if (xhi < 0.0f || yhi < 0.0f || xlo > lim || ylo > lim) return b;
-    b.x0 = (int16_t)fmaxf(xlo, 0.0f);
-    b.x1 = (int16_t)fminf(xhi, lim);
-    b.y0 = (int16_t)fmaxf(ylo, 0.0f);
-    b.y1 = (int16_t)fminf(yhi, lim);
-    return b;
+    return s.box;
+}
+
+__device__ __forceinline__ FaceBox face_box(const float* f, int is) {
+    BoxShared s;
+    face_box_shared(f, is, s);
+    return face_box_orient<false>(f, is, s);
 }
 
 // Barycentric weights (clamped, normalised) and perspective-correct depth of pixel (xi, yi)

@@ -5,17 +5,22 @@
 // (/root/reference/meshreg/neurender/rasterize.py:87-103, 413-428).
 //
 // Design (not the upstream "every pixel loops over every face" scheme):
-//   1. face_setup_kernel   one thread per face: back-face cull + conservative pixel bbox.  Faces
-//                          that can touch the screen are appended (wave-aggregated atomic) to a
-//                          compact per-image record list {bbox, face index} (16 B) and folded
-//                          into the image's union bbox; optional faces_inv for the
-//                          upstream-compatible API.
-//   2. raster_tile_kernel  one 256-thread workgroup per 32x8 screen tile (128-B output rows).  Tiles outside the
-//                          image's union bbox skip straight to the background fill.  Otherwise
-//                          each of the 4 waves scans a quarter of the record list -- 4
-//                          independent 16-B loads per lane in flight -- ballots the records
-//                          that touch the tile and compacts them (wave64 ballot + popcount
-//                          prefix) into a wave-private LDS ring.  The ring is consumed in
+//   1a. face_records_kernel one thread per face: back-face cull + conservative pixel bbox (8 B) and, for live
+//                          faces, a 96-B record {9 coordinates, pixel-space inverse, face index, vertex ids}
+//                          at the face's own index.
+//   1b. bin_boxes_kernel   ONE 1024-thread workgroup per image bins the image's boxes to screen tiles
+//                          entirely in LDS (no global atomics, no memset): a counting pass (LDS integer
+//                          atomics per bin), an exclusive scan over the bins and a fill pass produce per bin
+//                          a contiguous list of 16-B records {bbox, face index}.  A bin
+//                          is one 32x8 tile (a column of 2^s tiles for rasters beyond ~1400 pixels, so
+//                          that the counters fit LDS).  Faces overlapping more than 8 bins go to a
+//                          per-image "large" list instead, which every tile of the image scans.
+//   2. raster_tile_kernel  one 256-thread workgroup per 32x8 screen tile (128-B output rows).  Tiles whose bin
+//                          list and the image's large list are empty skip straight to the background
+//                          fill.  Otherwise each of the 4 waves takes a quarter of (bin list + large
+//                          list) -- independent 16-B loads per lane in flight --, ballots the records
+//                          that touch the tile (all of them, for a one-tile bin) and compacts them (wave64
+//                          ballot + popcount prefix) into a wave-private LDS ring.  The ring is consumed in
 //                          batches of 32 faces, in three lock-step stages that keep the lanes
 //                          full for the 5x5..16x16-pixel triangles of these meshes:
 //                            S1 lane per face: load the 9 floats, invert the pixel-space
@@ -37,9 +42,11 @@
 //                          barycentrics (bit-identical to the winning test), sample the
 //                          texture, blend background, write every output plane once,
 //                          already vertically flipped / NCHW for the image-space outputs.
-// Vertex-colour mode (face_setup_vc_kernel, raster_tile_kernel<FUSED, VC=true>): geometry through the vertex
+// Vertex-colour mode (face_records_kernel<VC=true>, raster_tile_kernel<FUSED, VC=true>): geometry through the vertex
 // indices, fill-back by index arithmetic, colours of the three vertices instead of a texture (bit-identical).
-// HBM traffic: faces 36 B + 16 + 48 B record per live face, outputs written exactly once; no
+// The order of the records inside a bin list depends on the order of the LDS atomics; the image does not: the
+// z-buffer key (depth, face index) makes the depth test a commutative minimum.
+// HBM traffic: faces 36 B + 48 B + ~3 x 16 B records per live face, outputs written exactly once; no
 // per-pixel memset, no sampling maps, no separate flip / permute / alpha / background pass.
 #include "mr_common.hpp"
 
@@ -48,28 +55,32 @@ namespace mr {
 constexpr int TILE_W = 32, TILE_H = 8;  // tile size in pixels (one pixel per thread)
 constexpr int TPB = 256;              // threads per workgroup (4 waves)
 constexpr int NB = 32;                // faces per batch (stage S1: one lane per face)
-constexpr int FC_STRIDE = 21;         // dwords per face-cache slot (odd: conflict-free ds_read_b32)
-constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 4 * 64, power of 2)
+constexpr int FC_STRIDE = 21;         // dwords per face-cache slot (odd: conflict-free ds_read_b32): v 9, inv 9, slot, box
+constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 8 * 64, power of 2)
 constexpr int SCAN_UNROLL = 3;        // independent record loads in flight per lane
 constexpr int QCAP = 256;             // wave-private ring capacity (>= NB - 1 + 64 * SCAN_UNROLL, power of 2)
 
-// Per-image header of the compact face-record list (zero-initialised before face_setup_kernel).
-// The union bbox is kept as maxima so that all-zero means "no face": nx0 = max(is - x0), x1p =
-// max(x1 + 1), likewise for y.
+// Per-image header written by bin_faces_kernel.
 struct ImageHdr {
-    int count;
-    int nx0, x1p, ny0, y1p;
-    int pad[3];
+    int n_live;   // live (front-facing, on-screen) faces = entries of the image's RecVerts array
+    int n_large;  // faces overlapping more than SMALL_MAX_BINS bins: the image's large list
+    int pad[6];
+};
+struct BinHdr {
+    unsigned off, cnt;  // the bin's records: recs[image base + off .. + cnt)
 };
 
-// {x0 | x1 << 16, y0 | y1 << 16, face index, unused}
+// {x0 | x1 << 16, y0 | y1 << 16, (virtual) face index, unused}
 typedef uint4 FaceRec;
-// the 9 coordinates of a live face, stored next to its record (slot-parallel array, 48-B stride)
-// so that the tile kernel fetches a face with ONE load phase instead of chasing
-// record -> vertex indices -> vertices
+// Vertex-colour mode: the 9 coordinates of REAL face f0 (its own vertex order), dense array with a 48-B stride,
+// so that the tile kernel fetches a face with ONE load phase instead of chasing record -> vertex indices ->
+// vertices.  The reversed copy f0 + F0 is the same record read back to front.  (A 96-B record per live virtual
+// face that also carried the pixel-space inverse and the vertex ids was measured: its scattered partial-line
+// stores cost 12 us per launch and neither S1 nor the resolve step got faster -- they are latency-bound.)
 struct __attribute__((aligned(16))) RecVerts {
     float v[12];
 };
+static_assert(sizeof(RecVerts) == 48, "RecVerts is read as three float4");
 
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -77,133 +88,176 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
-// grid = (ceil(F / 256), B): a workgroup never straddles two images.
-__global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict__ faces,
-                                                         ImageHdr* __restrict__ hdrs,
-                                                         FaceRec* __restrict__ recs,
-                                                         RecVerts* __restrict__ rverts,
-                                                         float* __restrict__ faces_inv, int F, int is) {
+constexpr int BIN_TPB = 1024;         // bin_boxes_kernel: one workgroup per image
+constexpr int MAX_BINS = 8192;        // LDS counters (32 KB)
+constexpr int SMALL_MAX_BINS = 8;     // a face overlapping more bins goes to the image's large list
+constexpr int REC_CAP = SMALL_MAX_BINS + 1;  // record capacity per image, in units of F: 8 F binned + F large
+
+struct BinParams {
+    const float* faces;      // !VC: [B,F,3,3]
+    const float* verts;      // VC: [B,V,3]
+    const int32_t* fidx;     // VC: [B,F0,3]
+    ImageHdr* hdrs;          // [B]
+    BinHdr* bins;            // [B, nbins]
+    FaceRec* recs;           // [B, REC_CAP * F]
+    RecVerts* rverts;        // VC: [B, F0] coordinates of the real faces (entries of dead faces stay unwritten)
+    FaceBox* boxes;          // [B, F] pixel bbox per (virtual) face, empty = dead
+    float* faces_inv;        // !VC, nullable: upstream's per-face inverse for the compatible API
+    int V, F0, F, fill_back, is;
+    int nbx, nby, ysh;       // bins per row / column; a bin is TILE_W x (TILE_H << ysh) pixels
+    int lds_boxes;           // bin_boxes_kernel keeps the image's boxes in LDS between its two passes
+    int dbg;                 // profiling experiments (scripts/fwd_vc_variants.py)
+};
+
+// Pass A, one thread per REAL face, grid = (ceil(F0 / 256), B): back-face cull + conservative pixel bbox of the
+// face in its own orientation and -- vertex-colour mode with fill-back -- of its reversed copy (virtual face
+// f0 + F0).  The order-independent part of face_box (pixel coordinates, bbox, sliver measure) is evaluated once
+// for both.  Writes the box of every virtual face (8 B, empty = dead) and, vertex-colour mode, the gathered
+// coordinates of the real face (dense, coalesced).  Nothing here depends on another face: the whole chip works on it.
+template <bool VC>
+__global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
     const int b = blockIdx.y;
-    const int fn = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool valid = fn < F;
-    const int64_t i = (int64_t)b * F + (valid ? fn : 0);
+    const int f0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f0 >= p.F0) return;
+    const int is = p.is;
     float f[9];
+    if (!VC) {
+        const float* g = p.faces + ((int64_t)b * p.F + f0) * 9;
 #pragma unroll
-    for (int k = 0; k < 9; k++) f[k] = valid ? faces[i * 9 + k] : __builtin_nanf("");
-    FaceBox bx = face_box(f, is);  // NaN -> empty
-    if (faces_inv && valid && !backfacing(f)) {
-        float inv[9];
-        face_inverse(f, inv, is);
+        for (int k = 0; k < 9; k++) f[k] = g[k];
+        if (p.faces_inv && !backfacing(f)) {
+            float inv[9];
+            face_inverse(f, inv, is);
 #pragma unroll
-        for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = inv[k];
+            for (int k = 0; k < 9; k++) p.faces_inv[((int64_t)b * p.F + f0) * 9 + k] = inv[k];
+        }
+    } else {
+        const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + f0) * 3;
+        const int id[3] = {ix[0], ix[1], ix[2]};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float* g = p.verts + ((int64_t)b * p.V + id[k]) * 3;
+            f[3 * k] = g[0]; f[3 * k + 1] = g[1]; f[3 * k + 2] = g[2];
+        }
     }
-    if (!hdrs) return;
-    const bool live = valid && bx.x0 <= bx.x1;
-    const unsigned long long m = __ballot(live);
-    if (m == 0ull) return;  // wave-uniform
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&hdrs[b].count, __popcll(m));
-    base = __shfl(base, leader);
-    if (live) {
-        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-        FaceRec r;
-        r.x = (unsigned)(unsigned short)bx.x0 | ((unsigned)(unsigned short)bx.x1 << 16);
-        r.y = (unsigned)(unsigned short)bx.y0 | ((unsigned)(unsigned short)bx.y1 << 16);
-        r.z = (unsigned)fn;
-        r.w = 0u;
-        recs[(int64_t)b * F + slot] = r;
-        float4* rv = reinterpret_cast<float4*>(rverts + (int64_t)b * F + slot);
+    const bool two = VC && p.fill_back;
+    BoxShared sh;
+    face_box_shared(f, is, sh);
+    const FaceBox b0 = face_box_orient<false>(f, is, sh);  // NaN / back-facing / off-screen -> empty
+    FaceBox* box_b = p.boxes + (int64_t)b * p.F;
+    box_b[f0] = b0;
+    bool live = b0.x0 <= b0.x1;
+    if (two) {
+        const FaceBox b1 = face_box_orient<true>(f, is, sh);
+        box_b[f0 + p.F0] = b1;
+        live = live || b1.x0 <= b1.x1;
+    }
+    if (VC && live && !(p.dbg & 16)) {
+        float4* rv = reinterpret_cast<float4*>(p.rverts + (int64_t)b * p.F0 + f0);
         rv[0] = make_float4(f[0], f[1], f[2], f[3]);
         rv[1] = make_float4(f[4], f[5], f[6], f[7]);
         rv[2] = make_float4(f[8], 0.0f, 0.0f, 0.0f);
     }
-    const int nx0 = wave_max(live ? is - bx.x0 : 0), x1p = wave_max(live ? bx.x1 + 1 : 0);
-    const int ny0 = wave_max(live ? is - bx.y0 : 0), y1p = wave_max(live ? bx.y1 + 1 : 0);
-    if (lane == leader) {
-        atomicMax(&hdrs[b].nx0, nx0);
-        atomicMax(&hdrs[b].x1p, x1p);
-        atomicMax(&hdrs[b].ny0, ny0);
-        atomicMax(&hdrs[b].y1p, y1p);
-    }
 }
 
-// Vertex-colour mode: one thread per REAL face evaluates both orientations (fill-back) and
-// appends up to two records.  grid = (ceil(F0 / 256), B).
-__global__ void __launch_bounds__(256) face_setup_vc_kernel(const float* __restrict__ verts,
-                                                            const int32_t* __restrict__ fidx,
-                                                            ImageHdr* __restrict__ hdrs,
-                                                            FaceRec* __restrict__ recs,
-                                                            RecVerts* __restrict__ rverts, int V, int F0,
-                                                            int fill_back, int is) {
-    const int b = blockIdx.y;
-    const int f0 = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool valid = f0 < F0;
-    const int F = fill_back ? 2 * F0 : F0;
-    float f[9], r[9];
+// Pass B, grid = B, block = BIN_TPB: ONE workgroup bins the boxes of an image to screen tiles entirely in LDS (no
+// global atomics, no memset): a counting pass (LDS integer atomics per bin), an exclusive scan over the bins and
+// a fill pass.  Dynamic LDS: int cnt[nbins] | FaceBox boxes[F] (p.lds_boxes).
+// (Measured and dropped, each SLOWER than the plain per-lane LDS atomics below -- the kernel is bound by the
+// length of each wave's dependent instruction chain, not by LDS conflicts: combining the lanes that hit one bin
+// with a ballot loop, folding runs of equal neighbours into one atomic, prefetching 8 iterations of boxes.)
+__global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
+    extern __shared__ int bin_smem[];
+    __shared__ int s_large;
+    __shared__ int wsum[BIN_TPB / MR_WAVE];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbins = p.nbx * p.nby;
+    int* cnt = bin_smem;
+    FaceBox* sbox = reinterpret_cast<FaceBox*>(bin_smem + ((nbins + 3) & ~3));
+    const FaceBox* box_b = p.boxes + (int64_t)b * p.F;
+
+    for (int i = tid; i < nbins; i += BIN_TPB) cnt[i] = 0;
+    if (tid == 0) s_large = 0;
+    __syncthreads();
+
+    // pass 1: records per bin
+    for (int fn = tid; fn < p.F; fn += BIN_TPB) {
+        const FaceBox bx = box_b[fn];
+        if (p.lds_boxes) sbox[fn] = bx;
+        if (bx.x0 > bx.x1) continue;
+        const int bx0 = bx.x0 / TILE_W, bx1 = bx.x1 / TILE_W;
+        const int by0 = bx.y0 >> (3 + p.ysh), by1 = bx.y1 >> (3 + p.ysh);
+        if ((bx1 - bx0 + 1) * (by1 - by0 + 1) > SMALL_MAX_BINS) continue;  // large list (counted in pass 2)
+        for (int y = by0; y <= by1; y++)
+            for (int x = bx0; x <= bx1; x++) atomicAdd(&cnt[y * p.nbx + x], 1);
+    }
+    __syncthreads();
+
+    // exclusive scan of the bin counts (each thread owns a run of consecutive bins); headers out, counters
+    // become fill cursors
+    const int per = (nbins + BIN_TPB - 1) / BIN_TPB;
+    const int i0 = min(tid * per, nbins), i1 = min(i0 + per, nbins);
+    int local = 0;
+    for (int i = i0; i < i1; i++) local += cnt[i];
+    int incl = local;
 #pragma unroll
-    for (int k = 0; k < 9; k++) f[k] = __builtin_nanf("");
-    if (valid) {
-        const int32_t* ix = fidx + ((int64_t)b * F0 + f0) * 3;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float* g = verts + ((int64_t)b * V + ix[k]) * 3;
-            f[3 * k] = g[0]; f[3 * k + 1] = g[1]; f[3 * k + 2] = g[2];
+    for (int off = 1; off < MR_WAVE; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == MR_WAVE - 1) wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - local;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    BinHdr* bh = p.bins + (int64_t)b * nbins;
+    for (int i = i0; i < i1; i++) {
+        const int c = cnt[i];
+        BinHdr h;
+        h.off = (unsigned)base; h.cnt = (unsigned)c;
+        bh[i] = h;
+        cnt[i] = base;
+        base += c;
+    }
+    __syncthreads();
+    if (p.dbg & 2) return;
+
+    // pass 2: fill
+    FaceRec* recs_b = p.recs + (int64_t)b * REC_CAP * p.F;
+    FaceRec* large_b = recs_b + (int64_t)SMALL_MAX_BINS * p.F;
+    for (int fn = tid; fn < p.F; fn += BIN_TPB) {
+        const FaceBox bx = p.lds_boxes ? sbox[fn] : box_b[fn];
+        if (bx.x0 > bx.x1) continue;
+        FaceRec rec;
+        rec.x = (unsigned)(unsigned short)bx.x0 | ((unsigned)(unsigned short)bx.x1 << 16);
+        rec.y = (unsigned)(unsigned short)bx.y0 | ((unsigned)(unsigned short)bx.y1 << 16);
+        rec.z = (unsigned)fn;
+        rec.w = 0u;
+        const int bx0 = bx.x0 / TILE_W, bx1 = bx.x1 / TILE_W;
+        const int by0 = bx.y0 >> (3 + p.ysh), by1 = bx.y1 >> (3 + p.ysh);
+        if ((bx1 - bx0 + 1) * (by1 - by0 + 1) > SMALL_MAX_BINS) {
+            large_b[atomicAdd(&s_large, 1)] = rec;
+        } else {
+            for (int y = by0; y <= by1; y++)
+                for (int x = bx0; x <= bx1; x++) recs_b[atomicAdd(&cnt[y * p.nbx + x], 1)] = rec;
         }
     }
+    __syncthreads();
+    if (tid == 0) {
+        ImageHdr h;
+        h.n_live = 0; h.n_large = s_large;
 #pragma unroll
-    for (int k = 0; k < 3; k++) { r[k] = f[6 + k]; r[3 + k] = f[3 + k]; r[6 + k] = f[k]; }
-    const FaceBox ba = face_box(f, is);
-    FaceBox bb = face_box(r, is);
-    if (!fill_back) { bb.x0 = 1; bb.x1 = 0; }
-    int nx0 = 0, x1p = 0, ny0 = 0, y1p = 0;
-    unsigned long long any = 0ull;
-#pragma unroll
-    for (int o = 0; o < 2; o++) {
-        const FaceBox bx = o ? bb : ba;
-        const bool live = valid && bx.x0 <= bx.x1;
-        const unsigned long long m = __ballot(live);
-        any |= m;
-        if (m != 0ull) {
-            const int leader = __ffsll((long long)m) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&hdrs[b].count, __popcll(m));
-            base = __shfl(base, leader);
-            if (live) {
-                FaceRec rec;
-                rec.x = (unsigned)(unsigned short)bx.x0 | ((unsigned)(unsigned short)bx.x1 << 16);
-                rec.y = (unsigned)(unsigned short)bx.y0 | ((unsigned)(unsigned short)bx.y1 << 16);
-                rec.z = (unsigned)(o ? f0 + F0 : f0);
-                rec.w = 0u;
-                const int64_t slot = (int64_t)b * F + base + __popcll(m & ((1ull << lane) - 1ull));
-                recs[slot] = rec;
-                const float* fv = o ? r : f;
-                float4* rv = reinterpret_cast<float4*>(rverts + slot);
-                rv[0] = make_float4(fv[0], fv[1], fv[2], fv[3]);
-                rv[1] = make_float4(fv[4], fv[5], fv[6], fv[7]);
-                rv[2] = make_float4(fv[8], 0.0f, 0.0f, 0.0f);
-                nx0 = max(nx0, is - bx.x0); x1p = max(x1p, bx.x1 + 1);
-                ny0 = max(ny0, is - bx.y0); y1p = max(y1p, bx.y1 + 1);
-            }
-        }
-    }
-    if (any == 0ull) return;
-    nx0 = wave_max(nx0); x1p = wave_max(x1p); ny0 = wave_max(ny0); y1p = wave_max(y1p);
-    if (lane == __ffsll((long long)any) - 1) {
-        atomicMax(&hdrs[b].nx0, nx0);
-        atomicMax(&hdrs[b].x1p, x1p);
-        atomicMax(&hdrs[b].ny0, ny0);
-        atomicMax(&hdrs[b].y1p, y1p);
+        for (int k = 0; k < 6; k++) h.pad[k] = 0;
+        p.hdrs[b] = h;
     }
 }
 
 struct FwdParams {
     const float* faces;
     const ImageHdr* hdrs;
+    const BinHdr* bins;
     const FaceRec* recs;
     const RecVerts* rverts;
+    int nbx, nby, ysh;
     const float* textures;
     const float* background;
     int bg_stride;
@@ -225,6 +279,24 @@ struct FwdParams {
     const float* vcolors;            // [B,V,3]
     int V, F0;
 };
+
+// the 9 coordinates of (virtual) face fn in ONE load phase: from the faces tensor, or (VC) from the gathered
+// coordinates of real face fn mod F0, read back to front for the reversed copy
+template <bool VC>
+__device__ __forceinline__ void load_face_coords(const FwdParams& p, const RecVerts* rv_b, int b, int fn, float* v) {
+    if (!VC) {
+        const float* g = p.faces + ((int64_t)b * p.F + fn) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) v[k] = g[k];
+    } else {
+        const bool rev = fn >= p.F0;
+        const float4* rv = reinterpret_cast<const float4*>(rv_b + (rev ? fn - p.F0 : fn));
+        const float4 v0 = rv[0], v1 = rv[1], v2 = rv[2];
+        v[0] = rev ? v1.z : v0.x; v[1] = rev ? v1.w : v0.y; v[2] = rev ? v2.x : v0.z;
+        v[3] = v0.w; v[4] = v1.x; v[5] = v1.y;
+        v[6] = rev ? v0.x : v1.z; v[7] = rev ? v0.y : v1.w; v[8] = rev ? v0.z : v2.x;
+    }
+}
 
 // the 9 floats of (virtual) face fn of image b
 template <bool VC>
@@ -254,7 +326,7 @@ __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float 
 // FUSED = true : write every pixel of every requested plane (fused epilogue).
 // FUSED = false: upstream-compatible forward_face_index_map: touch hit pixels only.
 template <bool FUSED, bool VC>
-__global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))) raster_tile_kernel(FwdParams p) {
     __shared__ unsigned long long zbuf[TILE_W * TILE_H];
     __shared__ int queue[TPB / MR_WAVE][QCAP];
     __shared__ float fcache[TPB / MR_WAVE][NB * FC_STRIDE];
@@ -275,13 +347,16 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
 
     // Tiles the image's faces cannot touch (outside the union bbox of the live faces) are pure
     // background: stream it with 16-byte stores and leave before any LDS set-up.
-    int n_rec = 0;
+    int n_rec = 0, n_bin = 0;
+    int64_t off_bin = 0, off_large = 0;  // record indices relative to the image's record base
     if (!p.keys) {
-        const ImageHdr h = p.hdrs[b];
-        const bool touch = h.count > 0 && (is - h.nx0) <= tx1 && (h.x1p - 1) >= tx0 && (is - h.ny0) <= ty1 &&
-                           (h.y1p - 1) >= ty0;
-        n_rec = touch ? h.count : 0;
+        const BinHdr bh = p.bins[(int64_t)b * (p.nbx * p.nby) + ((t / p.tiles_x) >> p.ysh) * p.nbx + (t % p.tiles_x)];
+        n_bin = (int)bh.cnt;
+        off_bin = (int64_t)bh.off;
+        off_large = (int64_t)SMALL_MAX_BINS * p.F - n_bin;  // so that record i >= n_bin sits at off_large + i
+        n_rec = n_bin + p.hdrs[b].n_large;
         if (p.dbg & 1) n_rec = 0;
+        if (n_rec == 0 && (p.dbg & 256)) return;
         if (FUSED && n_rec == 0 && (is & 3) == 0 && tx0 + TILE_W <= is && ty0 + TILE_H <= is && !p.face_inv_map) {
             // one 128-B row segment = 8 float4 (scalar planes) / 24 float4 (weight_map, 3 floats per pixel)
             const int64_t plane = (int64_t)is * is;
@@ -317,8 +392,10 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
     else if (tid < TILE_W + TILE_H) yp_tab[tid - TILE_W] = (float)(2 * (ty0 + tid - TILE_W) + 1 - is) / fis;
     __syncthreads();
 
-    const FaceRec* recs_b = p.recs + (int64_t)b * p.F;
-    const RecVerts* rv_b = p.rverts + (int64_t)b * p.F;
+    const FaceRec* recs_b = p.recs + (int64_t)b * REC_CAP * p.F;
+    const RecVerts* rv_b = p.rverts + (int64_t)b * p.F0;
+    // record i of this tile: the bin's list first, then the image's large list
+    auto rec_at = [&](int i) -> const FaceRec* { return recs_b + (i < n_bin ? off_bin : off_large) + i; };
     int* q = queue[wave];
     float* fc = fcache[wave];
     unsigned short* fq = fragq[wave];
@@ -337,13 +414,13 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
 #pragma unroll
             for (int k = 0; k < 9; k++) f.inv[k] = c[9 + k];
             f.v[2] = c[2]; f.v[5] = c[5]; f.v[8] = c[8];
-            const int fn = __float_as_int(c[18]);
+            const int fslot = __float_as_int(c[18]);  // the face index
             float zp, w[3];
             bary(f, tx0 + lx, ty0 + ly, zp, w);
             // upstream: `if (zp <= near || far <= zp) continue; if (zp < depth) win`.  A NaN depth (faces whose
             // vertices coincide in x, y pass every edge test and have no inverse) survives the first test and
             // loses the second, so it must not reach the z-buffer -- both comparisons below are false for NaN
-            if (zp > p.near_ && zp < p.far_) zbuf_min(zbuf, ly * TILE_W + lx, zp, fn);
+            if (zp > p.near_ && zp < p.far_) zbuf_min(zbuf, ly * TILE_W + lx, zp, fslot);
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -353,13 +430,10 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
         int nrows = 0;  // rows of the face's bbox inside this tile
         if (lane < count && !(p.dbg & 4)) {
             const int ri = q[(qhead + lane) & (QCAP - 1)];
-            const FaceRec r = recs_b[ri];
-            const float4* rv = reinterpret_cast<const float4*>(rv_b + ri);
-            const float4 v0 = rv[0], v1 = rv[1], v2 = rv[2];
+            const FaceRec r = *rec_at(ri);
             const int fn = (int)r.z;
             Face f;
-            f.v[0] = v0.x; f.v[1] = v0.y; f.v[2] = v0.z; f.v[3] = v0.w; f.v[4] = v1.x; f.v[5] = v1.y;
-            f.v[6] = v1.z; f.v[7] = v1.w; f.v[8] = v2.x;
+            load_face_coords<VC>(p, rv_b, b, fn, f.v);
             face_inverse(f.v, f.inv, is);
             float* c = fc + lane * FC_STRIDE;
 #pragma unroll
@@ -414,22 +488,38 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
             }
             int lo = lx0, hi = lx1;
             // T_k(x) = accepted_k(x) XOR (dy_k < 0) is prefix-true on [lx0, lx1] (accepted set of edge k:
-            // a prefix if dy_k > 0 -- or dy_k == 0: all or nothing --, a suffix if dy_k < 0).  Bisection
-            // with the exact predicate finds l_k = last x with T_k true (lx0 - 1 if none); the three
-            // edges advance together, depth = ceil(log2(widest range of the wave)).
-            const int range = wave_max(act ? lx1 - lx0 + 2 : 0);
-            const int steps = (p.dbg & 32) ? 0 : 32 - __clz(max(range, 1));
+            // a prefix if dy_k > 0 -- or dy_k == 0: all or nothing --, a suffix if dy_k < 0).  l_k = last x with
+            // T_k true (lx0 - 1 if none) is bracketed by l < l_k + 1 <= h with the EXACT predicate only; where to
+            // probe is free.  The first probe is the closed-form crossing of the edge with the row (approximate
+            // reciprocal: it only has to land within a pixel), the next ones step to the neighbour of the bound
+            // that just moved -- two or three probes settle almost every item -- and whatever is still open after
+            // three probes is bisected.  The three edges advance together.
             int l[3] = {lx0 - 1, lx0 - 1, lx0 - 1}, h[3] = {lx1 + 1, lx1 + 1, lx1 + 1};
             const bool dec[3] = {dy[0] < 0.0f, dy[1] < 0.0f, dy[2] < 0.0f};
-            for (int it = 0; it < steps; it++) {
+            int probe[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const int mid = (l[k] + h[k]) >> 1;
-                    const float xp = xp_tab[max(mid, 0) & (TILE_W - 1)];
-                    const bool t = (!(ey[k] < (xp - ea[k]) * dy[k])) != dec[k];
-                    const bool go = h[k] - l[k] > 1;
-                    l[k] = (go && t) ? mid : l[k];
-                    h[k] = (go && !t) ? mid : h[k];
+            for (int k = 0; k < 3; k++) {
+                // (xp - a) dy = ey  ->  xp = a + ey / dy;  pixel index = (xp is + is - 1) / 2, tile-local
+                const float xs = ((ea[k] + ey[k] * __builtin_amdgcn_rcpf(dy[k])) * fis + fis - 1.0f) * 0.5f - (float)tx0;
+                // NaN (dy == 0) -> lx1: T is constant along the row then, one probe at the far end settles it
+                probe[k] = (int)fminf(fmaxf(floorf(xs), (float)lx0), (float)lx1);
+                if (!(xs == xs)) probe[k] = lx1;
+            }
+            if (!(p.dbg & 32)) {
+                for (int it = 0;; it++) {
+                    bool open_any = false;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const bool go = h[k] - l[k] > 1;
+                        const int mid = it < 3 ? min(max(probe[k], l[k] + 1), h[k] - 1) : (l[k] + h[k]) >> 1;
+                        const float xp = xp_tab[max(mid, 0) & (TILE_W - 1)];
+                        const bool t = (!(ey[k] < (xp - ea[k]) * dy[k])) != dec[k];
+                        l[k] = (go && t) ? mid : l[k];
+                        h[k] = (go && !t) ? mid : h[k];
+                        probe[k] = t ? mid + 1 : mid - 1;
+                        open_any = open_any || (h[k] - l[k] > 1);
+                    }
+                    if (__ballot(act && open_any) == 0ull) break;
                 }
             }
 #pragma unroll
@@ -438,19 +528,23 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
             }
             int len = (act && !(p.dbg & 64)) ? max(hi - lo + 1, 0) : 0;
             int x = lo;
-            // emit the spans as fragments, at most 4 pixels per lane per round
+            // emit the spans as fragments, at most EMIT pixels per lane per round: a wave prefix sum gives every
+            // lane its place in the ring
+            constexpr int EMIT = 4;
             while (__ballot(len > 0) != 0ull) {
-                const int c = min(len, 4);
-                int total = 0;
+                const int c = min(len, EMIT);
+                int incl = c;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const bool has = i < c;
-                    const unsigned long long m = __ballot(has);
-                    if (has)
-                        fq[(fqh + fqn + total + __popcll(m & lt_mask)) & (FQCAP - 1)] =
-                            (unsigned short)(((unsigned)slot << 8) | ((unsigned)row << 5) | (unsigned)(x + i));
-                    total += __popcll(m);
+                for (int off = 1; off < MR_WAVE; off <<= 1) {
+                    const int up = __shfl_up(incl, off);
+                    if (lane >= off) incl += up;
                 }
+                const int total = __shfl(incl, MR_WAVE - 1);
+                const int at = fqh + fqn + incl - c;
+                const unsigned tag = ((unsigned)slot << 8) | ((unsigned)row << 5);
+#pragma unroll
+                for (int i = 0; i < EMIT; i++)
+                    if (i < c) fq[(at + i) & (FQCAP - 1)] = (unsigned short)(tag | (unsigned)(x + i));
                 x += c; len -= c; fqn += total;
                 __builtin_amdgcn_wave_barrier();
                 while (fqn >= MR_WAVE) {
@@ -478,7 +572,7 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
 #pragma unroll
             for (int j = 0; j < SCAN_UNROLL; j++) {
                 const int ri = base + j * MR_WAVE + lane;
-                rr[j] = recs_b[min(ri, r_end - 1)];
+                rr[j] = *rec_at(min(ri, r_end - 1));
             }
 #pragma unroll
             for (int j = 0; j < SCAN_UNROLL; j++) {
@@ -531,12 +625,23 @@ __global__ void __launch_bounds__(TPB, 7) raster_tile_kernel(FwdParams p) {
             }
             return;
         }
-        const int fn = (int)(unsigned)(key & 0xffffffffull);
+        int fn = (int)(unsigned)(key & 0xffffffffull);
         const float zp = ord2f((uint32_t)(key >> 32));
         Face f;
         int vid[3] = {0, 0, 0};
-        fetch_verts<VC>(p, b, fn, f.v, vid);
-        face_inverse(f.v, f.inv, is);
+        if (p.keys) {  // validation path: keys carry face indices, no binning pass ran
+            fetch_verts<VC>(p, b, fn, f.v, vid);
+            face_inverse(f.v, f.inv, is);
+        } else {
+            load_face_coords<VC>(p, rv_b, b, fn, f.v);
+            if (VC) {
+                const bool rev = fn >= p.F0;
+                const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + (rev ? fn - p.F0 : fn)) * 3;
+                const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+                vid[0] = rev ? i2 : i0; vid[1] = i1; vid[2] = rev ? i0 : i2;
+            }
+            face_inverse(f.v, f.inv, is);
+        }
         // barycentrics of the winner, recomputed with the arithmetic of cover()
         float w[3], zp2;
         bary(f, px, py, zp2, w);
@@ -682,22 +787,64 @@ __global__ void __launch_bounds__(256) face_inv_map_kernel(const float* __restri
     for (int k = 0; k < 9; k++) out[i * 9 + k] = inv[k];
 }
 
-// workspace layout: [B] ImageHdr (zeroed per call) | [B * F] FaceRec | [B * F] RecVerts
-static inline size_t hdr_bytes(int B) { return (((size_t)B * sizeof(ImageHdr)) + 255) & ~(size_t)255; }
-static inline size_t rec_bytes(int B, int F) { return (((size_t)B * F * sizeof(FaceRec)) + 255) & ~(size_t)255; }
+// workspace layout: [B] ImageHdr | [B * nbins] BinHdr | [B * F] FaceBox | [B * REC_CAP * F] FaceRec | [B * F] RecVerts
+// (every byte the tile kernel reads is written by the two setup kernels: no memset)
+struct WorkLayout {
+    int nbx, nby, ysh;
+    size_t off_bins, off_boxes, off_recs, off_rverts, total;
+};
 
-static int launch_setup(const float* faces, void* workspace, float* faces_inv, int B, int F, int is,
-                        hipStream_t s) {
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static WorkLayout work_layout(int B, int F, int is) {
+    WorkLayout w;
+    const int tiles_x = (is + TILE_W - 1) / TILE_W, tiles_y = (is + TILE_H - 1) / TILE_H;
+    w.nbx = tiles_x;
+    w.ysh = 0;
+    while ((int64_t)tiles_x * ((tiles_y + (1 << w.ysh) - 1) >> w.ysh) > MAX_BINS) w.ysh++;
+    w.nby = (tiles_y + (1 << w.ysh) - 1) >> w.ysh;
+    w.off_bins = align256((size_t)B * sizeof(ImageHdr));
+    w.off_boxes = w.off_bins + align256((size_t)B * w.nbx * w.nby * sizeof(BinHdr));
+    w.off_recs = w.off_boxes + align256((size_t)B * F * sizeof(FaceBox));
+    w.off_rverts = w.off_recs + align256((size_t)B * REC_CAP * F * sizeof(FaceRec));
+    w.total = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (VC needs F / 2 of it with fill-back)
+    return w;
+}
+
+// per-face records + boxes (pass A), bin lists (pass B); fills the record-source fields of `fp`
+template <bool VC>
+static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int F, int is, hipStream_t s) {
+    const WorkLayout w = work_layout(B, F, is);
+    if (w.nbx > MAX_BINS) return MR_ERR_BADARG;  // (image_size <= 16384 keeps a row of bins within the counters)
+    char* base = (char*)workspace;
+    bp.hdrs = (ImageHdr*)base;
+    bp.bins = (BinHdr*)(base + w.off_bins);
+    bp.boxes = (FaceBox*)(base + w.off_boxes);
+    bp.recs = (FaceRec*)(base + w.off_recs);
+    bp.rverts = (RecVerts*)(base + w.off_rverts);
+    bp.F = F; bp.is = is; bp.nbx = w.nbx; bp.nby = w.nby; bp.ysh = w.ysh;
+    const int nbins = w.nbx * w.nby;
+    size_t lds = (size_t)((nbins + 3) & ~3) * sizeof(int);
+    const size_t box_lds = (size_t)F * sizeof(FaceBox);
+    bp.lds_boxes = (lds + box_lds <= 152 * 1024) ? 1 : 0;
+    if (bp.lds_boxes) lds += box_lds;
+    fp.hdrs = bp.hdrs; fp.bins = bp.bins; fp.recs = bp.recs; fp.rverts = bp.rverts;
+    fp.nbx = w.nbx; fp.nby = w.nby; fp.ysh = w.ysh;
     if (B == 0) return MR_OK;
-    ImageHdr* hdrs = (ImageHdr*)workspace;
-    FaceRec* recs = (FaceRec*)((char*)workspace + hdr_bytes(B));
-    RecVerts* rverts = (RecVerts*)((char*)workspace + hdr_bytes(B) + rec_bytes(B, F));
-    hipError_t e = hipMemsetAsync(hdrs, 0, hdr_bytes(B), s);
-    if (e != hipSuccess) return (int)e;
-    if (F == 0) return MR_OK;
     if (B > 65535) return MR_ERR_BADARG;
-    hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, faces,
-                       hdrs, recs, rverts, faces_inv, F, is);
+    if (bp.F0 > 0) {
+        hipLaunchKernelGGL((face_records_kernel<VC>), dim3((unsigned)((bp.F0 + 255) / 256), (unsigned)B), dim3(256), 0, s,
+                           bp);
+        MR_CHECK_LAUNCH();
+    }
+    static size_t allowed = 48 * 1024;  // dynamic LDS beyond the default limit is an opt-in, raised on demand
+    if (lds > allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_boxes_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e != hipSuccess) return (int)e;
+        allowed = 152 * 1024;
+    }
+    hipLaunchKernelGGL(bin_boxes_kernel, dim3((unsigned)B), dim3(BIN_TPB), lds, s, bp);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -719,10 +866,8 @@ static int launch_tiles(FwdParams& p, hipStream_t s) {
 using namespace mr;
 
 extern "C" int64_t mr_render_workspace_bytes(int batch_size, int num_faces, int image_size) {
-    (void)image_size;
-    if (batch_size < 0 || num_faces < 0) return MR_ERR_BADARG;
-    return (int64_t)hdr_bytes(batch_size) + (int64_t)rec_bytes(batch_size, num_faces) +
-           ((((int64_t)batch_size * num_faces * (int64_t)sizeof(RecVerts)) + 255) & ~255LL);
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
+    return (int64_t)work_layout(batch_size, num_faces, image_size).total;
 }
 
 extern "C" int mr_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
@@ -740,12 +885,12 @@ extern "C" int mr_forward_face_index_map(const float* faces, int32_t* face_index
     const size_t bytes = (size_t)mr_render_workspace_bytes(batch_size, num_faces, image_size) + 256;
     hipError_t e = hipMallocAsync(&work, bytes, s);
     if (e != hipSuccess) return (int)e;
-    int rc = launch_setup(faces, work, faces_inv, batch_size, num_faces, image_size, s);
+    FwdParams p{};
+    BinParams bp{};
+    bp.faces = faces; bp.faces_inv = faces_inv; bp.F0 = num_faces;
+    int rc = launch_bins<false>(bp, p, work, batch_size, num_faces, image_size, s);
     if (rc == MR_OK) {
-        FwdParams p{};
-        p.faces = faces; p.hdrs = (const ImageHdr*)work;
-        p.recs = (const FaceRec*)((const char*)work + hdr_bytes(batch_size));
-        p.rverts = (const RecVerts*)((const char*)work + hdr_bytes(batch_size) + rec_bytes(batch_size, num_faces));
+        p.faces = faces;
         p.depth = depth_map; p.fim = face_index_map;
         p.weight = weight_map; p.face_inv_map = return_depth ? face_inv_map : nullptr;
         p.B = batch_size; p.F = num_faces; p.is = image_size; p.ts = 1;
@@ -794,12 +939,13 @@ extern "C" int mr_render_forward(const float* faces, const float* textures, cons
     if (workspace_bytes < mr_render_workspace_bytes(batch_size, num_faces, image_size)) return MR_ERR_BADARG;
     if (batch_size == 0) return MR_OK;
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_setup(faces, workspace, nullptr, batch_size, num_faces, image_size, s);
-    if (rc != MR_OK) return rc;
     FwdParams p{};
-    p.faces = faces; p.hdrs = (const ImageHdr*)workspace;
-    p.recs = (const FaceRec*)((const char*)workspace + hdr_bytes(batch_size));
-    p.rverts = (const RecVerts*)((const char*)workspace + hdr_bytes(batch_size) + rec_bytes(batch_size, num_faces));
+    BinParams bp{};
+    bp.faces = faces; bp.F0 = num_faces;
+    int rc = (flags & MR_FLAG_REFERENCE_ALGO) ? MR_OK
+                                              : launch_bins<false>(bp, p, workspace, batch_size, num_faces, image_size, s);
+    if (rc != MR_OK) return rc;
+    p.faces = faces;
     p.textures = textures; p.background = background;
     p.bg_stride = bg_stride;
     p.rgb = return_rgb ? rgb_img : nullptr;
@@ -846,7 +992,6 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
                                     int num_faces, int fill_back, int image_size, float near_, float far_,
                                     float eps, int return_rgb, int return_alpha, int return_depth, int flags,
                                     mr_stream_t stream) {
-    (void)flags;
     const int F = fill_back ? 2 * num_faces : num_faces;
     if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
     if (((!verts || !faces_idx) && num_faces > 0) || !face_index_map || !weight_map || !workspace) return MR_ERR_BADARG;
@@ -857,19 +1002,14 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
     if (batch_size == 0) return MR_OK;
     if (batch_size > 65535) return MR_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    ImageHdr* hdrs = (ImageHdr*)workspace;
-    FaceRec* recs = (FaceRec*)((char*)workspace + hdr_bytes(batch_size));
-    RecVerts* rverts = (RecVerts*)((char*)workspace + hdr_bytes(batch_size) + rec_bytes(batch_size, F));
-    hipError_t e = hipMemsetAsync(hdrs, 0, hdr_bytes(batch_size), s);
-    if (e != hipSuccess) return (int)e;
-    if (num_faces > 0) {
-        hipLaunchKernelGGL(face_setup_vc_kernel, dim3((unsigned)((num_faces + 255) / 256), (unsigned)batch_size),
-                           dim3(256), 0, s, verts, faces_idx, hdrs, recs, rverts, num_verts, num_faces, fill_back,
-                           image_size);
-        MR_CHECK_LAUNCH();
-    }
     FwdParams p{};
-    p.hdrs = hdrs; p.recs = recs; p.rverts = rverts; p.background = background; p.bg_stride = bg_stride;
+    BinParams bp{};
+    bp.verts = verts; bp.fidx = faces_idx; bp.V = num_verts; bp.F0 = num_faces; bp.fill_back = fill_back;
+    bp.dbg = flags >> 24;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    const int rc = launch_bins<true>(bp, p, workspace, batch_size, F, image_size, s);
+    if (rc != MR_OK) return rc;
+    p.background = background; p.bg_stride = bg_stride;
     p.rgb = return_rgb ? rgb_img : nullptr;
     p.alpha = return_alpha ? alpha_img : nullptr;
     p.depth = return_depth ? depth_img : nullptr;
@@ -877,5 +1017,7 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
     p.B = batch_size; p.F = F; p.is = image_size; p.ts = 2;
     p.near_ = near_; p.far_ = far_; p.eps = eps;
     p.verts = verts; p.fidx = faces_idx; p.vcolors = vcolors; p.V = num_verts; p.F0 = num_faces;
+    p.dbg = (flags >> 8) & 0xffff;  // profiling experiments (scripts/fwd_vc_variants.py)
+    if (p.dbg & 128) return MR_OK;  // ... binning pass alone
     return launch_tiles<true, true>(p, s);
 }
