@@ -265,7 +265,15 @@ struct FwdParams {
     float* alpha;          // FUSED: [B,is,is] image orientation
     float* depth;          // FUSED: image orientation; COMPAT: raster orientation
     int32_t* fim;          // raster orientation
-    float* weight;         // [B,is,is,3] raster orientation
+    float* weight;         // [B,is,is,3] raster orientation (nullable in flow mode)
+    // flow mode (mr_render_flow_forward): the training path's output set
+    float* mask;           // FUSED: [B,is,is] image orientation: (alpha > thresh) * keep_lut[face + 1]; nullable
+    const float* keep_lut; // nullable: 0 for ignored faces, 1 otherwise, indexed by face index + 1
+    int n_lut;
+    float alpha_thresh;
+    int rgb_channels;      // 3, or 2: the third colour plane is left untouched
+    int sparse_wd;         // weight / depth are written at covered pixels only (their only reader, the colour
+                           // backward, looks at nothing else)
     float* face_inv_map;   // [B,is,is,9] raster orientation (nullable)
     int B, F, is, ts;
     float near_, far_, eps;
@@ -368,17 +376,19 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
                 const int m1 = -1;
                 const float fm1 = __int_as_float(m1);
                 reinterpret_cast<float4*>(p.fim + ro)[seg] = make_float4(fm1, fm1, fm1, fm1);
-                if (p.depth) reinterpret_cast<float4*>(p.depth + io)[seg] = make_float4(p.far_, p.far_, p.far_, p.far_);
+                if (p.depth && !p.sparse_wd) reinterpret_cast<float4*>(p.depth + io)[seg] = make_float4(p.far_, p.far_, p.far_, p.far_);
                 if (p.alpha) reinterpret_cast<float4*>(p.alpha + io)[seg] = zero4;
+                if (p.mask) reinterpret_cast<float4*>(p.mask + io)[seg] = zero4;
                 if (p.rgb) {
                     const float* bg = p.background + (int64_t)b * p.bg_stride;
                     const int64_t o = ((int64_t)b * 3 * is + (is - 1 - ty0 - row)) * is + tx0;
 #pragma unroll
                     for (int c = 0; c < 3; c++)
-                        reinterpret_cast<float4*>(p.rgb + o + c * plane)[seg] = make_float4(bg[c], bg[c], bg[c], bg[c]);
+                        if (c < p.rgb_channels)
+                            reinterpret_cast<float4*>(p.rgb + o + c * plane)[seg] = make_float4(bg[c], bg[c], bg[c], bg[c]);
                 }
             }
-            if (tid < TILE_H * 24) {
+            if (p.weight && !p.sparse_wd && tid < TILE_H * 24) {
                 const int row = tid / 24, seg = tid % 24;
                 reinterpret_cast<float4*>(p.weight + (((int64_t)b * is + ty0 + row) * is + tx0) * 3)[seg] = zero4;
             }
@@ -610,14 +620,16 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
         if (!hitpx) {
             if (FUSED) {
                 p.fim[ri] = -1;
-                p.weight[ri * 3 + 0] = 0.0f; p.weight[ri * 3 + 1] = 0.0f; p.weight[ri * 3 + 2] = 0.0f;
-                if (p.depth) p.depth[ii] = p.far_;
+                if (p.weight && !p.sparse_wd) { p.weight[ri * 3 + 0] = 0.0f; p.weight[ri * 3 + 1] = 0.0f; p.weight[ri * 3 + 2] = 0.0f; }
+                if (p.depth && !p.sparse_wd) p.depth[ii] = p.far_;
                 if (p.alpha) p.alpha[ii] = 0.0f;
+                if (p.mask) p.mask[ii] = 0.0f;
                 if (p.rgb) {
                     const float* bg = p.background + (int64_t)b * p.bg_stride;
                     const int64_t plane = (int64_t)is * is;
                     const int64_t o = ((int64_t)b * 3 * is + (is - 1 - py)) * is + px;
-                    p.rgb[o] = bg[0]; p.rgb[o + plane] = bg[1]; p.rgb[o + 2 * plane] = bg[2];
+                    p.rgb[o] = bg[0]; p.rgb[o + plane] = bg[1];
+                    if (p.rgb_channels > 2) p.rgb[o + 2 * plane] = bg[2];
                 }
                 if (p.face_inv_map)
 #pragma unroll
@@ -647,7 +659,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
         bary(f, px, py, zp2, w);
         (void)zp2;
         p.fim[ri] = fn;
-        p.weight[ri * 3 + 0] = w[0]; p.weight[ri * 3 + 1] = w[1]; p.weight[ri * 3 + 2] = w[2];
+        if (p.weight) { p.weight[ri * 3 + 0] = w[0]; p.weight[ri * 3 + 1] = w[1]; p.weight[ri * 3 + 2] = w[2]; }
         if (p.face_inv_map)
 #pragma unroll
             for (int k = 0; k < 9; k++) p.face_inv_map[ri * 9 + k] = f.inv[k];
@@ -657,6 +669,11 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
         }
         if (p.depth) p.depth[ii] = zp;
         if (p.alpha) p.alpha[ii] = 1.0f;
+        if (p.mask) {  // flow_mask_kernel's arithmetic: (alpha > thresh) * (face + 1 inside the table ? lut : 1)
+            float m = (1.0f > p.alpha_thresh) ? 1.0f : 0.0f;
+            if (p.keep_lut) m = m * ((fn + 1 >= 0 && fn + 1 < p.n_lut) ? p.keep_lut[fn + 1] : 1.0f);
+            p.mask[ii] = m;
+        }
         if (p.rgb) {
             const int ts = p.ts;
             float tif[3];
@@ -697,7 +714,8 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
             const int64_t plane = (int64_t)is * is;
             const int64_t o = ((int64_t)b * 3 * is + (is - 1 - py)) * is + px;
 #pragma unroll
-            for (int k = 0; k < 3; k++) p.rgb[o + k * plane] = c[k] * 1.0f + 0.0f * bg[k];
+            for (int k = 0; k < 3; k++)
+                if (k < p.rgb_channels) p.rgb[o + k * plane] = c[k] * 1.0f + 0.0f * bg[k];
         }
     }
 }
@@ -851,6 +869,7 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
 
 template <bool FUSED, bool VC>
 static int launch_tiles(FwdParams& p, hipStream_t s) {
+    if (p.rgb_channels == 0) p.rgb_channels = 3;
     p.tiles_x = (p.is + TILE_W - 1) / TILE_W;
     p.tiles_y = (p.is + TILE_H - 1) / TILE_H;
     const int64_t nblocks = (int64_t)p.B * p.tiles_x * p.tiles_y;
@@ -1019,5 +1038,40 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
     p.verts = verts; p.fidx = faces_idx; p.vcolors = vcolors; p.V = num_verts; p.F0 = num_faces;
     p.dbg = (flags >> 8) & 0xffff;  // profiling experiments (scripts/fwd_vc_variants.py)
     if (p.dbg & 128) return MR_OK;  // ... binning pass alone
+    return launch_tiles<true, true>(p, s);
+}
+
+extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
+                                      const float* background, int bg_stride, const float* keep_lut, int n_lut,
+                                      float alpha_thresh, float* rgb_img, float* alpha_img, float* mask_img,
+                                      float* depth_img, float* weight_map, int32_t* face_index_map, void* workspace, int64_t workspace_bytes, int batch_size,
+                                      int num_verts, int num_faces, int fill_back, int image_size, float near_,
+                                      float far_, float eps, int flags, mr_stream_t stream) {
+    const int F = fill_back ? 2 * num_faces : num_faces;
+    if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
+    if (((!verts || !faces_idx || !vcolors) && num_faces > 0) || !face_index_map || !workspace) return MR_ERR_BADARG;
+    if (!rgb_img || !alpha_img || !mask_img || !background || !(eps >= 1e-6f)) return MR_ERR_BADARG;
+    if ((bg_stride != 0 && bg_stride != 3) || (keep_lut && n_lut <= 0)) return MR_ERR_BADARG;
+    if (workspace_bytes < mr_render_workspace_bytes(batch_size, F, image_size)) return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    FwdParams p{};
+    BinParams bp{};
+    bp.verts = verts; bp.fidx = faces_idx; bp.V = num_verts; bp.F0 = num_faces; bp.fill_back = fill_back;
+    bp.dbg = flags >> 24;
+    const int rc = launch_bins<true>(bp, p, workspace, batch_size, F, image_size, s);
+    if (rc != MR_OK) return rc;
+    p.background = background; p.bg_stride = bg_stride;
+    p.rgb = rgb_img; p.rgb_channels = 2;
+    p.alpha = alpha_img; p.mask = mask_img;
+    p.depth = depth_img; p.weight = weight_map; p.sparse_wd = 1;
+    p.keep_lut = keep_lut; p.n_lut = n_lut; p.alpha_thresh = alpha_thresh;
+    p.fim = face_index_map;
+    p.B = batch_size; p.F = F; p.is = image_size; p.ts = 2;
+    p.near_ = near_; p.far_ = far_; p.eps = eps;
+    p.verts = verts; p.fidx = faces_idx; p.vcolors = vcolors; p.V = num_verts; p.F0 = num_faces;
+    p.dbg = (flags >> 8) & 0xffff;
+    if (p.dbg & 128) return MR_OK;
     return launch_tiles<true, true>(p, s);
 }

@@ -334,6 +334,81 @@ class RasterizeVertexColorFunction(Function):
         return (None, None, grad_cols) + (None,) * 9
 
 
+class RasterizeFlowFunction(Function):
+    """``RasterizeVertexColorFunction`` restricted to what ``get_opticalflow`` consumes from a render
+    (mr_render_flow_forward): rgb [B,3,is,is] whose first two planes hold the rendered displacement (the third
+    is never written), alpha, the flow mask ``(alpha > 0.99999) * keep_lut[face + 1]`` of opticalflow.py:109-117
+    and face_index_map.  The depth image and the weight map are written at covered pixels only (the backward w.r.t.
+    the colours reads them there and nowhere else; they are not returned): 20 instead of 36 bytes per background
+    pixel leave the kernel, and the separate mask kernel is gone."""
+
+    @staticmethod
+    def forward(ctx, verts_ndc, faces_idx, vcolors, keep_lut, fill_back, image_size, near, far, eps, background_color,
+                alpha_thresh):
+        ctx.set_materialize_grads(False)
+        _lib.check_cuda(verts_ndc, faces_idx, vcolors, keep_lut)
+        if not (float(eps) >= 1e-6):
+            raise ValueError("vertex-colour rendering needs eps >= 1e-6")
+        verts = _lib.contig(verts_ndc.detach())
+        fidx = faces_idx.detach().to(torch.int32).contiguous()
+        cols = _lib.contig(vcolors.detach())
+        dev = verts.device
+        B, V = verts.shape[:2]
+        F0 = fidx.shape[1]
+        if fidx.shape != (B, F0, 3) or cols.shape != (B, V, 3) or verts.shape != (B, V, 3):
+            raise ValueError("expected vertices [B,V,3], faces [B,F,3], vertex colours [B,V,3]")
+        is_ = int(image_size)
+        bg, bg_stride = _background_tensor(background_color, dev, B)
+        lut = _lib.contig(keep_lut) if keep_lut is not None else None
+        empty = torch.empty
+        rgb = empty((B, 3, is_, is_), dtype=torch.float32, device=dev)
+        alpha = empty((B, is_, is_), dtype=torch.float32, device=dev)
+        mask = empty((B, is_, is_), dtype=torch.float32, device=dev)
+        fim = empty((B, is_, is_), dtype=torch.int32, device=dev)
+        depth = empty((B, is_, is_), dtype=torch.float32, device=dev)  # valid where fim >= 0 only
+        wmap = empty((B, is_, is_, 3), dtype=torch.float32, device=dev)  # valid where fim >= 0 only
+        F = 2 * F0 if fill_back else F0
+        wbytes = _lib.load().mr_render_workspace_bytes(B, F, is_)
+        work = empty((max(int(wbytes), 8),), dtype=torch.uint8, device=dev)
+        _lib.call("mr_render_flow_forward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(cols), _lib.ptr(bg), bg_stride,
+                  _lib.ptr(lut), int(lut.numel()) if lut is not None else 0, float(alpha_thresh), _lib.ptr(rgb),
+                  _lib.ptr(alpha), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(wmap), _lib.ptr(fim), _lib.ptr(work), int(wbytes),
+                  B, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps), 0, _lib.stream_ptr(dev))
+        ctx.cfg = (is_, float(eps), bool(fill_back))
+        ctx.save_for_backward(verts, fidx, fim, wmap, depth)
+        ctx.mark_non_differentiable(alpha, mask, fim)
+        return rgb, alpha, mask, fim
+
+    @staticmethod
+    def backward(ctx, grad_rgb, _ga, _gm, _gf):
+        verts, fidx, fim, wmap, depth = ctx.saved_tensors
+        is_, eps, fill_back = ctx.cfg
+        if not ctx.needs_input_grad[2]:
+            return (None,) * 11
+        B, V = verts.shape[:2]
+        grad_cols = torch.empty((B, V, 3), dtype=torch.float32, device=verts.device)
+        if grad_rgb is None:
+            grad_cols.zero_()
+        else:
+            g = _lib.contig(grad_rgb)
+            _lib.call("mr_render_vc_backward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(fim), _lib.ptr(wmap), _lib.ptr(depth),
+                      _lib.ptr(g), _lib.ptr(grad_cols), B, V, int(fidx.shape[1]), int(fill_back), is_, eps, 0,
+                      _lib.stream_ptr(verts.device))
+        return (None, None, grad_cols) + (None,) * 8
+
+
+def rasterize_flow(vertices_ndc, faces_idx, vertex_colors, keep_lut=None, fill_back=True,
+                   image_size=DEFAULT_IMAGE_SIZE, near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS,
+                   background_color=DEFAULT_BACKGROUND_COLOR, alpha_thresh=0.99999):
+    """The training-path render of get_opticalflow: {'rgb' (planes 0 and 1 valid), 'alpha', 'mask',
+    'face_index_map'} -- see ``RasterizeFlowFunction``.  No anti-aliasing."""
+    if background_color is None:
+        background_color = DEFAULT_BACKGROUND_COLOR
+    rgb, alpha, mask, fim = RasterizeFlowFunction.apply(vertices_ndc, faces_idx, vertex_colors, keep_lut, fill_back,
+                                                        image_size, near, far, eps, background_color, alpha_thresh)
+    return {"rgb": rgb, "alpha": alpha, "mask": mask, "face_index_map": fim}
+
+
 def rasterize_vertex_colors(
     vertices_ndc,
     faces_idx,

@@ -209,3 +209,12 @@ class Renderer(nn.Module):
         return rasterize.rasterize_vertex_colors(
             vertices_ndc.detach(), faces, vertex_colors, self.fill_back, self.image_size, self.anti_aliasing, self.near,
             self.far, self.rasterizer_eps, self.background_color)
+
+    def render_projected_flow(self, vertices_ndc, faces, vertex_colors, keep_lut=None):
+        """``render_projected_vertex_colors`` restricted to what ``get_opticalflow`` reads (rgb planes 0 / 1,
+        alpha, the thresholded + ignore-face flow mask, face_index_map): rasterize.rasterize_flow."""
+        if not self.no_light or self.anti_aliasing:
+            raise ValueError("render_projected_flow requires no_light=True and anti_aliasing=False")
+        return rasterize.rasterize_flow(
+            vertices_ndc.detach(), faces, vertex_colors, keep_lut, self.fill_back, self.image_size, self.near, self.far,
+            self.rasterizer_eps, self.background_color)

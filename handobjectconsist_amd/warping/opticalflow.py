@@ -73,6 +73,9 @@ def _render_flow(neurenderer, verts, faces, sample_flows, camintr, detach_textur
 # PyTorch launches; used with the vertex-colour render + fused epilogue.  False: op-by-op as in the
 # reference (same values up to fp32 rounding of the 3x3 products).
 USE_FUSED_VERTEX_STAGE = True
+# ... and render the stacked pair in flow mode (Renderer.render_projected_flow).  False: the full output set of
+# render_projected_vertex_colors + a separate mask kernel (same flows, bit for bit).
+USE_FLOW_RENDER = True
 
 
 class _FlowVertexStage(torch.autograd.Function):
@@ -241,7 +244,10 @@ class _FlowFinalizeStacked(torch.autograd.Function):
 def _fused_epilogue_stacked(ro, orig_img_size, ignore_face_idxs):
     """``_fused_epilogue`` on ONE render of the 2B stacked meshes (frame 1 of every pair, then frame 2)."""
     with torch.no_grad():
-        m, alpha = _flow_mask(ro, ignore_face_idxs)
+        if "mask" in ro:  # the flow-mode render wrote the mask itself
+            m, alpha = ro["mask"], ro["alpha"]
+        else:
+            m, alpha = _flow_mask(ro, ignore_face_idxs)
         rgb = _lib.contig(ro["rgb"].detach())
         B2, _, is_, _ = rgb.shape
         B = B2 // 2
@@ -303,8 +309,13 @@ def get_opticalflow(
             ro1 = neurenderer.render_projected_vertex_colors(ndc[:B], faces, cols[:B].detach())
             ro2 = neurenderer.render_projected_vertex_colors(ndc[B:], faces, cols[B:])
             return _fused_epilogue(ro1, ro2, orig_img_size, ignore_face_idxs)
-        # both renders of the pair as one launch over 2B meshes
-        ro = neurenderer.render_projected_vertex_colors(ndc, _stacked_faces(faces), cols)
+        # both renders of the pair as one launch over 2B meshes, in the training path's output set (no depth /
+        # weight maps, third colour plane untouched, flow mask folded into the render)
+        if USE_FLOW_RENDER and hasattr(neurenderer, "render_projected_flow") and not neurenderer.anti_aliasing:
+            lut = _keep_lut(ignore_face_idxs, dev) if ignore_face_idxs is not None else None
+            ro = neurenderer.render_projected_flow(ndc, _stacked_faces(faces), cols, lut)
+        else:
+            ro = neurenderer.render_projected_vertex_colors(ndc, _stacked_faces(faces), cols)
         return _fused_epilogue_stacked(ro, orig_img_size, ignore_face_idxs)
     gt_locs2d_1 = project.batch_proj2d(verts_cam[0], camintrs[0])
     gt_locs2d_2 = project.batch_proj2d(verts_cam[1], camintrs[1])

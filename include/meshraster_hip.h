@@ -186,6 +186,21 @@ MR_API int mr_render_vc_backward(const float* verts, const int32_t* faces_idx,
                                  int fill_back, int image_size, float eps, int flags,
                                  mr_stream_t stream);
 
+/* mr_render_vc_forward restricted to what get_opticalflow consumes from its two renders (opticalflow.py:108-118,
+ * 126-135, 146-154) -- the training path's output set: the first two colour planes (the rendered displacement;
+ * rgb_img[B,3,is,is], its third plane is left untouched), alpha, and the flow mask of opticalflow.py:109-117
+ *   mask = (alpha > alpha_thresh) * keep_lut[face_index + 1]   (keep_lut nullable; 1 beyond n_lut entries)
+ * in image orientation, plus face_index_map (raster orientation).  depth_img / weight_map (both nullable) are
+ * written at COVERED pixels only -- the loss never reads them and their one reader, mr_render_vc_backward, looks
+ * at covered pixels only; everywhere else the buffers keep whatever they held. */
+MR_API int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
+                                  const float* background, int bg_stride, const float* keep_lut, int n_lut,
+                                  float alpha_thresh, float* rgb_img, float* alpha_img, float* mask_img,
+                                  float* depth_img, float* weight_map, int32_t* face_index_map, void* workspace,
+                                  int64_t workspace_bytes,
+                                  int batch_size, int num_verts, int num_faces, int fill_back, int image_size,
+                                  float near_, float far_, float eps, int flags, mr_stream_t stream);
+
 /* Per-vertex front end of get_opticalflow in its training setting (SURVEY 8f "f1"): for the two
  * frames of a pair, in one launch
  *   p_k    = batch_proj2d(verts_k, K_k)                      (opticalflow.py:98-99)

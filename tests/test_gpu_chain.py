@@ -218,7 +218,7 @@ def _flow_check(got, want, key, max_support=4):
     return support
 
 
-@pytest.mark.parametrize("path", ["fused", "vertex_color", "textures"])
+@pytest.mark.parametrize("path", ["fused", "fused_full_outputs", "vertex_color", "textures"])
 def test_get_opticalflow_against_reference_glue(cuda, path):
     """Flows and d(flows)/d(vertices of both frames) for every fixture variant (ignore list, crop,
     detach_textures, detach_renders=False, mask_occlusions=False), through the fused vertex stage +
@@ -227,9 +227,10 @@ def test_get_opticalflow_against_reference_glue(cuda, path):
     from handobjectconsist_amd.warping import opticalflow
 
     z, meta = load("chain_opticalflow.npz")
-    saved = (opticalflow.USE_FUSED_VERTEX_STAGE, opticalflow.USE_VERTEX_COLOR_RENDER)
-    opticalflow.USE_FUSED_VERTEX_STAGE = path == "fused"
+    saved = (opticalflow.USE_FUSED_VERTEX_STAGE, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_FLOW_RENDER)
+    opticalflow.USE_FUSED_VERTEX_STAGE = path.startswith("fused")
     opticalflow.USE_VERTEX_COLOR_RENDER = path != "textures"
+    opticalflow.USE_FLOW_RENDER = path == "fused"  # flow-mode render (no depth / weights, mask folded in)
     try:
         for m in meta:
             s, k, is_ = m["scene"], m["key"], m["image_size"]
@@ -243,7 +244,7 @@ def test_get_opticalflow_against_reference_glue(cuda, path):
             for i, name in enumerate(("flow12", "flow21")):
                 assert tuple(flows[i].shape) == z[f"{k}_{name}"].shape
                 sup += _flow_check(n(flows[i]), z[f"{k}_{name}"], (path, k, name))
-            if path == "fused":
+            if path.startswith("fused"):
                 # the vertex stage reproduces the fixture's projections bit for bit: nothing may differ in support,
                 # so the strict (north-star) gradient tolerance below is the one that is exercised
                 assert sup == 0, (k, sup)
@@ -259,7 +260,37 @@ def test_get_opticalflow_against_reference_glue(cuda, path):
                 else:
                     assert l2_rel(got, want) < 5e-2, (path, k, name, l2_rel(got, want))
     finally:
-        opticalflow.USE_FUSED_VERTEX_STAGE, opticalflow.USE_VERTEX_COLOR_RENDER = saved
+        opticalflow.USE_FUSED_VERTEX_STAGE, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_FLOW_RENDER = saved
+
+
+def test_flow_render_equals_full_render(cuda):
+    """mr_render_flow_forward (the training path's output set) against mr_render_vc_forward + mr_flow_mask on the
+    same inputs: displacement planes, alpha, mask and face_index_map bit-equal; the colour gradient (barycentrics
+    recomputed instead of read back from the weight / depth maps) bit-equal too."""
+    from handobjectconsist_amd.utils import synth
+    from handobjectconsist_amd.warping import opticalflow
+
+    for B, is_, seed in ((3, 96, 3), (2, 256, 4)):
+        s = synth.random_scene(B, seed=seed, image_size=is_)
+        ren = _training_renderer(is_, cuda)
+        ndc = ren.project(t(s["verts1"], cuda), K=t(s["K1"], cuda)).detach()
+        faces = t(s["faces"], cuda)
+        rng = np.random.default_rng(seed)
+        g = t(rng.standard_normal((B, 3, is_, is_)).astype(np.float32), cuda)
+        g[:, 2] = 0  # the third plane of the flow render is never written (and never read downstream)
+        ignore = list(range(100, 900)) + list(range(3552 + 200, 3552 + 700))  # visible faces of both orientations
+        lut = opticalflow._keep_lut(ignore, cuda)
+        c1 = t(rng.standard_normal((B, ndc.shape[1], 3)).astype(np.float32), cuda, True)
+        full = ren.render_projected_vertex_colors(ndc, faces, c1)
+        m_full, _ = opticalflow._flow_mask(full, ignore)
+        (full["rgb"] * g).sum().backward()
+        c2 = c1.detach().clone().requires_grad_(True)
+        flow = ren.render_projected_flow(ndc, faces, c2, lut)
+        (flow["rgb"][:, :2] * g[:, :2]).sum().backward()
+        assert torch.equal(flow["rgb"][:, :2], full["rgb"][:, :2])
+        assert torch.equal(flow["alpha"], full["alpha"]) and torch.equal(flow["face_index_map"], full["face_index_map"])
+        assert torch.equal(flow["mask"], m_full) and float(m_full.sum()) < float(full["alpha"].sum())
+        assert norm_rel(n(c2.grad), n(c1.grad)) < 1e-6
 
 
 def test_flow_finalize_backward_against_reference_glue(cuda):
