@@ -27,8 +27,10 @@ BATCH_ENCODER = os.environ.get("HOC_BATCH_ENCODER", "1") != "0"
 
 def train_step(batches, premodel, optimizer, check_nan=True):
     """One optimiser step over `loader_nb = len(batches)` batches (epochpassconsist.py:57-68).  With
-    ``check_nan`` a NaN loss raises BEFORE zero_grad / backward / step, as the reference does (:61-63): the
-    parameters and the Adam state are not touched by a diverged step (one host synchronisation per step)."""
+    ``check_nan`` a NaN loss raises before ``optimizer.step()``: like the reference's check (:61-63) it keeps the
+    parameters and the Adam state clean of a diverged step.  The reference tests the loss before ``backward``;
+    here the host reads the flag after the backward pass has been ENQUEUED (it only writes ``.grad``), so the
+    GPU is not left idle while the host queues ~200 backward launches (measured: 1.3 ms per step)."""
     losses, logs = [], {}
     if (BATCH_POST or BATCH_ENCODER) and hasattr(premodel, "prepare"):
         premodel.prepare(batches, batch_encoder=BATCH_ENCODER)
@@ -43,11 +45,13 @@ def train_step(batches, premodel, optimizer, check_nan=True):
                 sample.pop("_features", None)
                 sample.pop("_post", None)
     loss = torch.stack(losses).sum()
-    if check_nan and bool(torch.isnan(loss)):
-        raise ValueError("Loss became nan!")
+    nan_flag = torch.isnan(loss.detach()) if check_nan else None
     optimizer.zero_grad(set_to_none=True)
     if loss.requires_grad:
         loss.backward()
+    if check_nan and bool(nan_flag):
+        raise ValueError("Loss became nan!")
+    if loss.requires_grad:
         optimizer.step()
     return loss.detach(), logs
 
