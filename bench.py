@@ -172,15 +172,25 @@ def kernel_bench(dev, B, is_, iters):
     keep_lut = torch.ones(2 * F0 + 2, **f32)
     keep_lut[torch.tensor(synth.HAND_IGNORE_FACES, device=dev) + 1] = 0
 
+    ptile_hit = torch.empty((B2, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=dev)
+    poccl = (torch.rand((B2, is_, is_), device=dev) < 0.9).float()
+    pg_flow = torch.randn((B2, is_, is_, 2), **f32)
+
     def render_flow_fwd_pair():  # the training path's output set: rgb planes 0 / 1, alpha, flow mask, face index
         _lib.call("mr_render_flow_forward", P(pv), P(pf), P(pcols), P(bg), 0, P(keep_lut), int(keep_lut.numel()), 0.99999,
-                  P(prgb), P(palpha), P(pmask), P(pdepth), P(pwmap), P(pfim), P(pwork), pwbytes, B2, pv.shape[1], F0, 1, is_, 0.1, 100.0, 1e-3,
+                  P(prgb), P(palpha), P(pmask), P(pdepth), P(pwmap), P(pfim), P(ptile_hit), P(pwork), pwbytes, B2, pv.shape[1], F0, 1, is_, 0.1, 100.0, 1e-3,
                   0, st)
 
     def render_vc_bwd_pair_recompute():  # ... and its backward: no weight / depth maps to read back
         _lib.call("mr_render_vc_backward", P(pv), P(pf), P(pfim), None, None, P(pg_rgb), P(pg_cols), B2, pv.shape[1], F0, 1,
                   is_, 1e-3, 0, st)
 
+    def render_flow_bwd_pair():  # what the training step launches: flow-space gradient + epilogue masks in, d colours out
+        _lib.call("mr_render_flow_backward", P(pv), P(pf), P(pfim), P(ptile_hit), P(pwmap), P(pdepth), None, P(pg_flow),
+                  P(pmask), P(pmask[:B]), P(palpha[B:]), B, P(poccl), is_, is_, P(pg_cols), B2, pv.shape[1], F0, 1, is_, 1e-3,
+                  0, st)
+
+    render_flow_fwd_pair()
     render_vc_fwd_pair()
     im_ref, im, jm_ref, jm = [t(a) for a in synth.random_images(B, is_, is_, 0)]
     flow12 = (torch.randn(B, is_, is_, 2, device=dev) * 2) * (torch.rand(B, is_, is_, 1, device=dev) < 0.1)
@@ -268,6 +278,8 @@ def kernel_bench(dev, B, is_, iters):
         ("render_vc_backward(train,E,both frames=2B)", render_vc_bwd_pair, 2 * ((12 + 4 + 12 + 4) * npx + (36 + 96) * BF)),
         ("render_flow_forward(train outputs,both frames=2B)", render_flow_fwd_pair, 2 * (132 * BF + 36 * npx)),
         ("render_vc_backward(train,E,2B,recomputed weights)", render_vc_bwd_pair_recompute, 2 * ((12 + 4 + 12 + 4) * npx + (36 + 96) * BF)),
+        # kernel E of SURVEY 8(d) (same algorithmic bytes) + the adjoint of the flow epilogue folded in
+        ("render_flow_backward(train,E+epilogue adjoint,2B)", render_flow_bwd_pair, 2 * ((12 + 4 + 12 + 4) * npx + (36 + 96) * BF)),
         ("render_backward_full(D+E+F)", render_bwd_full, 56 * npx + 168 * BF),
         ("pair_consist_forward", pair_fwd, 48 * npx),
         ("pair_consist_backward", pair_bwd, 64 * npx),

@@ -659,6 +659,215 @@ __global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(ScatterV
 }
 
 // ---------------------------------------------------------------------------------------
+// E for the flow-mode render (mr_render_flow_backward): tile-persistent scatter
+// ---------------------------------------------------------------------------------------
+// The forward pass left one byte per (32x8 tile, row pair) saying whether anything is covered there (~17 % of the
+// tiles of a hand + object frame).  ST_G workgroups of 4 waves share an image; every wave walks its own interleaved
+// subset of the image's tiles, skips the empty ones on that byte (one scalar load -- the region kernel above
+// dispatches 16 waves per 64x32 region only to find 70 % of them empty: 16 us of its 50 are wave dispatch), and
+// handles a covered tile alone: lane = 4 consecutive pixels of a row, so that one wave-wide 16-byte load fetches a
+// whole tile of a plane and a lane has four independent gather chains (face -> vertex ids -> vertex depths) in
+// flight.  The [V,3] fixed-point table in LDS is zeroed and flushed once per WORKGROUP (a quarter image), not once
+// per region; its scale comes from a first pass over the gradient of the workgroup's covered tiles.
+// FLOWGRAD: the incoming gradient is the FLOW-space gradient [B,H,W,2] plus the masks of opticalflow.py:146-154 --
+// the adjoint of crop / permute / mask products is applied on the fly with the arithmetic of
+// flow_finalize_backward_kernel ((g * (m_x * occl)) * m_pre; third colour plane: zero), so that the [B,3,is,is]
+// colour-space gradient is never materialised.
+constexpr int ST_G = 16;      // workgroups per image
+constexpr int ST_WAVES = 4;   // waves per workgroup
+constexpr int ST_TW = 32, ST_TH = 8;  // the forward's tile
+constexpr int ST_MAX_TILES = 4096;    // tiles per image the covered-tile list in LDS can hold (1024 x 1024 pixels)
+
+struct ScatterTilesParams {
+    GatherVCParams g;
+    const float* weight;        // [B,is,is,3] raster orientation, valid at covered pixels
+    const float* depth;         // [B,is,is] image orientation, valid at covered pixels
+    const uint32_t* tile_hit;   // [B, tiles] one byte per wave (row pair) of the forward's tile kernel; nullable
+    // FLOWGRAD
+    const float* grad_flow;     // [B,H,W,2]
+    const float* m_pre;         // [B,is,is] image orientation
+    const float* m_x_lo;        // images [0, split)
+    const float* m_x_hi;        // images [split, B)
+    const float* occl;
+    int split, H, W;
+    int tiles_x, tiles_y;
+};
+
+template <bool FLOWGRAD>
+__device__ __forceinline__ void st_load_grad(const ScatterTilesParams& sp, int b, int yi, int x, float (*g)[3]) {
+    const GatherVCParams& p = sp.g;
+    const int is = p.is;
+    const int yimg = is - 1 - yi;
+    if (!FLOWGRAD) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float4 v = *reinterpret_cast<const float4*>(p.grad_rgb + (((int64_t)b * 3 + ch) * is + yimg) * is + x);
+            g[0][ch] = v.x; g[1][ch] = v.y; g[2][ch] = v.z; g[3][ch] = v.w;
+        }
+    } else {
+        const int64_t o = ((int64_t)b * is + yimg) * is + x;
+        const float* mx = b < sp.split ? sp.m_x_lo + o : sp.m_x_hi + (o - (int64_t)sp.split * is * is);
+        const float4 a4 = *reinterpret_cast<const float4*>(sp.m_pre + o);
+        const float4 x4 = *reinterpret_cast<const float4*>(mx);
+        const float4 o4 = *reinterpret_cast<const float4*>(sp.occl + o);
+        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+        const float post[4] = {x4.x * o4.x, x4.y * o4.y, x4.z * o4.z, x4.w * o4.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float2 gf = make_float2(0.0f, 0.0f);
+            const bool in = yimg < sp.H && x + j < sp.W;
+            if (in) gf = *reinterpret_cast<const float2*>(sp.grad_flow + (((int64_t)b * sp.H + yimg) * sp.W + x + j) * 2);
+            g[j][0] = in ? (gf.x * post[j]) * a[j] : 0.0f;
+            g[j][1] = in ? (gf.y * post[j]) * a[j] : 0.0f;
+            g[j][2] = 0.0f;
+        }
+    }
+}
+
+template <bool FLOWGRAD>
+__global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(ScatterTilesParams sp) {
+    extern __shared__ long long vtab[];  // [V * 3] rounded up to an even count
+    __shared__ unsigned wmax[ST_WAVES];
+    __shared__ unsigned short hits[ST_MAX_TILES];  // the image's covered tiles, ascending
+    __shared__ int wcnt[ST_WAVES], n_hits_s;
+    const GatherVCParams& p = sp.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / ST_G, part = blockIdx.x % ST_G;
+    const int is = p.is;
+    const int T = sp.tiles_x * sp.tiles_y;
+    const int r = lane >> 3, x4 = (lane & 7) * 4;  // the lane's pixel quad inside a tile
+    const int32_t* fim_b = p.fim + (int64_t)b * is * is;
+    const float* verts_b = p.verts + (int64_t)b * p.V * 3;
+    const int32_t* fidx_b = p.fidx + (int64_t)b * p.F0 * 3;
+
+    const int n2 = (p.V * 3 + 1) >> 1;
+    for (int k = threadIdx.x; k < n2; k += blockDim.x) reinterpret_cast<int4*>(vtab)[k] = make_int4(0, 0, 0, 0);
+
+    // the list of covered tiles (block-wide compaction of the coverage bytes); the 16 waves that share an image
+    // then take them round-robin: every wave gets its share whatever part of the screen the mesh sits in
+    int n_hits = 0;
+    for (int t0 = 0; t0 < T; t0 += blockDim.x) {
+        const int t = t0 + threadIdx.x;
+        const bool hit = t < T && (sp.tile_hit ? sp.tile_hit[(int64_t)b * T + t] != 0u : true);
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int base = n_hits;
+        for (int w = 0; w < wave; w++) base += wcnt[w];
+        if (hit) hits[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)t;
+        for (int w = 0; w < ST_WAVES; w++) n_hits += wcnt[w];
+        __syncthreads();
+    }
+
+    // pass 1: largest |gradient| over the workgroup's covered tiles, as float bits
+    unsigned mx = 0u;
+    for (int h = part * ST_WAVES + wave; h < n_hits; h += ST_G * ST_WAVES) {
+        const int t = hits[h];
+        const int yi = (t / sp.tiles_x) * ST_TH + r, x = (t % sp.tiles_x) * ST_TW + x4;
+        if (yi >= is || x >= is) continue;  // partial tile at the image border (rows are multiples of 4 wide)
+        float g[4][3];
+        st_load_grad<FLOWGRAD>(sp, b, yi, x, g);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) mx = max(mx, __float_as_uint(g[j][ch]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();  // table zeroed, maxima visible
+    unsigned bm = 0u;
+#pragma unroll
+    for (int k = 0; k < ST_WAVES; k++) bm = max(bm, wmax[k]);
+    if (bm == 0u) return;                  // every gradient is +-0: nothing to add (block-uniform)
+    const bool finite = bm < 0x7f800000u;  // else: fp32 global atomics, Inf / NaN propagate
+    const int shift = SV_FIX_BITS - ((int)(bm >> 23) - 126);
+    float* out = p.grad_vcolors + (int64_t)b * p.V * 3;
+
+    // pass 2
+    for (int h = part * ST_WAVES + wave; h < n_hits; h += ST_G * ST_WAVES) {
+        const int t = hits[h];
+        const int yi = (t / sp.tiles_x) * ST_TH + r, x = (t % sp.tiles_x) * ST_TW + x4;
+        const bool inside = yi < is && x < is;
+        int4 f4 = make_int4(-1, -1, -1, -1);
+        if (inside) f4 = *reinterpret_cast<const int4*>(fim_b + (int64_t)yi * is + x);
+        const int fn[4] = {f4.x, f4.y, f4.z, f4.w};
+        if (__ballot(fn[0] >= 0 || fn[1] >= 0 || fn[2] >= 0 || fn[3] >= 0) == 0ull) continue;
+        float g[4][3], w[4][3], zp[4], vz[4][3];
+        int vid[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            zp[j] = 1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { g[j][k] = 0.0f; w[j][k] = 0.0f; }
+        }
+        if (inside) {
+            st_load_grad<FLOWGRAD>(sp, b, yi, x, g);
+            const float4* wq = reinterpret_cast<const float4*>(sp.weight + (((int64_t)b * is + yi) * is + x) * 3);
+            const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2];
+            w[0][0] = w0.x; w[0][1] = w0.y; w[0][2] = w0.z; w[1][0] = w0.w; w[1][1] = w1.x; w[1][2] = w1.y;
+            w[2][0] = w1.z; w[2][1] = w1.w; w[2][2] = w2.x; w[3][0] = w2.y; w[3][1] = w2.z; w[3][2] = w2.w;
+            const float4 d4 = *reinterpret_cast<const float4*>(sp.depth + ((int64_t)b * is + (is - 1 - yi)) * is + x);
+            zp[0] = d4.x; zp[1] = d4.y; zp[2] = d4.z; zp[3] = d4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool won = fn[j] >= 0;
+            const bool o = fn[j] >= p.F0;  // reversed copy of face fn - F0
+            const int32_t* ix = fidx_b + (int64_t)(won ? (o ? fn[j] - p.F0 : fn[j]) : 0) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) vid[j][k] = won ? ix[o ? 2 - k : k] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) vz[j][k] = fn[j] >= 0 ? verts_b[(int64_t)vid[j][k] * 3 + 2] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (fn[j] < 0) continue;
+            float fv[9];
+            fv[2] = vz[j][0]; fv[5] = vz[j][1]; fv[8] = vz[j][2];
+            float tif[3];
+            tex_coords(w[j], zp[j], fv, 2, p.eps, tif);
+            // taps pn = 1, 2, 4 are the texels holding the colours of vertices 0, 1, 2
+            float val[9];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int pn = 1 << k;
+                float wg = 1.0f;
+#pragma unroll
+                for (int q = 0; q < 3; q++) wg *= ((pn >> q) & 1) ? (tif[q] - 0.0f) : (1.0f - (tif[q] - 0.0f));
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) val[k * 3 + ch] = wg * g[j][ch];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    if (FLOWGRAD && ch == 2) continue;  // the third plane's gradient is identically zero
+                    const float v = val[k * 3 + ch];
+                    const int cell = vid[j][k] * 3 + ch;
+                    if (finite) {
+                        const long long q = (long long)ldexp((double)v, shift);
+                        if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&vtab[cell]), (unsigned long long)q);
+                    } else if (v != 0.0f) {
+                        atomicAdd(&out[cell], v);
+                    }
+                }
+        }
+    }
+    if (!finite) return;  // block-uniform
+    __syncthreads();
+    for (int k = threadIdx.x; k < p.V * 3; k += blockDim.x) {
+        const long long tsum = vtab[k];
+        if (tsum != 0) {
+            const float v = (float)ldexp((double)tsum, -shift);
+            if (v != 0.0f) atomicAdd(&out[k], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // E, generic texture size: per-pixel atomics on recomputed sampling weights
 // ---------------------------------------------------------------------------------------
 template <bool IMG>
@@ -1414,4 +1623,43 @@ extern "C" int mr_render_vc_backward(const float* verts, const int32_t* faces_id
     }
     if (image_size > 8192) return MR_ERR_BADARG;  // gather fragment encoding: 13 bits per bbox offset
     return launch1d(gather_vc_kernel<0>, (int64_t)batch_size * num_faces * GLPF, s, g);
+}
+
+extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_idx, const int32_t* face_index_map,
+                                       const uint32_t* tile_hit, const float* weight_map, const float* depth_img,
+                                       const float* grad_rgb_img, const float* grad_flow, const float* mask_pre,
+                                       const float* mask_x_lo, const float* mask_x_hi, int split, const float* occl,
+                                       int height, int width, float* grad_vcolors, int batch_size, int num_verts,
+                                       int num_faces, int fill_back, int image_size, float eps, int flags,
+                                       mr_stream_t stream) {
+    if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0) return MR_ERR_BADARG;
+    if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
+    if (batch_size == 0 || num_verts == 0) return MR_OK;
+    const bool flowgrad = grad_rgb_img == nullptr;
+    if (flowgrad && (!grad_flow || !mask_pre || !mask_x_lo || !occl || height <= 0 || width <= 0 || height > image_size ||
+                     width > image_size || split < 0 || split > batch_size || (split < batch_size && !mask_x_hi)))
+        return MR_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_vcolors, 0, (size_t)batch_size * num_verts * 3 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    if (num_faces == 0) return MR_OK;
+    if (!verts || !faces_idx || !face_index_map || !weight_map || !depth_img || !(eps >= 1e-6f)) return MR_ERR_BADARG;
+    const int64_t table_bytes = (((int64_t)num_verts * 3 + 1) / 2) * 16;
+    // the tile walk reads 4-pixel groups with 16-byte loads and keeps the colour table in LDS
+    if (image_size % 4 != 0 || table_bytes > SV_MAX_TABLE_BYTES ||
+        (int64_t)((image_size + ST_TW - 1) / ST_TW) * ((image_size + ST_TH - 1) / ST_TH) > ST_MAX_TILES)
+        return MR_ERR_NOTIMPL;
+    ScatterTilesParams sp{};
+    sp.g = GatherVCParams{verts, faces_idx, face_index_map, grad_rgb_img, grad_vcolors, batch_size, num_verts, num_faces,
+                          fill_back, image_size, eps, flags >> 8};
+    sp.weight = weight_map; sp.depth = depth_img; sp.tile_hit = tile_hit;
+    sp.grad_flow = grad_flow; sp.m_pre = mask_pre; sp.m_x_lo = mask_x_lo; sp.m_x_hi = mask_x_hi; sp.occl = occl;
+    sp.split = split; sp.H = height; sp.W = width;
+    sp.tiles_x = (image_size + ST_TW - 1) / ST_TW; sp.tiles_y = (image_size + ST_TH - 1) / ST_TH;
+    const int64_t blocks = (int64_t)batch_size * ST_G;
+    if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(flowgrad ? scatter_tiles_kernel<true> : scatter_tiles_kernel<false>, dim3((unsigned)blocks),
+                       dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
 }

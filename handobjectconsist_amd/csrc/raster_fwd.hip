@@ -272,6 +272,7 @@ struct FwdParams {
     int n_lut;
     float alpha_thresh;
     int rgb_channels;      // 3, or 2: the third colour plane is left untouched
+    uint8_t* tile_hit;     // nullable: [B, tiles, 4] 1 = wave w (rows 2w, 2w + 1) of the tile covers a pixel
     int sparse_wd;         // weight / depth are written at covered pixels only (their only reader, the colour
                            // backward, looks at nothing else)
     float* face_inv_map;   // [B,is,is,9] raster orientation (nullable)
@@ -388,6 +389,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
                             reinterpret_cast<float4*>(p.rgb + o + c * plane)[seg] = make_float4(bg[c], bg[c], bg[c], bg[c]);
                 }
             }
+            if (p.tile_hit && tid == 0) reinterpret_cast<uint32_t*>(p.tile_hit)[(int64_t)b * tiles_per_img + t] = 0u;
             if (p.weight && !p.sparse_wd && tid < TILE_H * 24) {
                 const int row = tid / 24, seg = tid % 24;
                 reinterpret_cast<float4*>(p.weight + (((int64_t)b * is + ty0 + row) * is + tx0) * 3)[seg] = zero4;
@@ -612,9 +614,13 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
     if (p.dbg & 2) return;
     // resolve: one pixel per thread (x = tid % 32, y = tid / 32)
     {
-        if (px >= is || py >= is) return;
         const unsigned long long key = zbuf[tid];
-        const bool hitpx = key != ~0ull;
+        const bool hitpx = key != ~0ull && px < is && py < is;
+        if (p.tile_hit) {
+            const unsigned long long any = __ballot(hitpx);
+            if (lane == 0) p.tile_hit[((int64_t)b * tiles_per_img + t) * 4 + wave] = any != 0ull ? 1 : 0;
+        }
+        if (px >= is || py >= is) return;
         const int64_t ri = ((int64_t)b * is + py) * is + px;            // raster orientation
         const int64_t ii = ((int64_t)b * is + (is - 1 - py)) * is + px;  // image orientation
         if (!hitpx) {
@@ -1044,7 +1050,8 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
 extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
                                       const float* background, int bg_stride, const float* keep_lut, int n_lut,
                                       float alpha_thresh, float* rgb_img, float* alpha_img, float* mask_img,
-                                      float* depth_img, float* weight_map, int32_t* face_index_map, void* workspace, int64_t workspace_bytes, int batch_size,
+                                      float* depth_img, float* weight_map, int32_t* face_index_map, uint8_t* tile_hit,
+                                      void* workspace, int64_t workspace_bytes, int batch_size,
                                       int num_verts, int num_faces, int fill_back, int image_size, float near_,
                                       float far_, float eps, int flags, mr_stream_t stream) {
     const int F = fill_back ? 2 * num_faces : num_faces;
@@ -1065,7 +1072,7 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
     p.background = background; p.bg_stride = bg_stride;
     p.rgb = rgb_img; p.rgb_channels = 2;
     p.alpha = alpha_img; p.mask = mask_img;
-    p.depth = depth_img; p.weight = weight_map; p.sparse_wd = 1;
+    p.depth = depth_img; p.weight = weight_map; p.sparse_wd = 1; p.tile_hit = tile_hit;
     p.keep_lut = keep_lut; p.n_lut = n_lut; p.alpha_thresh = alpha_thresh;
     p.fim = face_index_map;
     p.B = batch_size; p.F = F; p.is = image_size; p.ts = 2;

@@ -192,14 +192,35 @@ MR_API int mr_render_vc_backward(const float* verts, const int32_t* faces_idx,
  *   mask = (alpha > alpha_thresh) * keep_lut[face_index + 1]   (keep_lut nullable; 1 beyond n_lut entries)
  * in image orientation, plus face_index_map (raster orientation).  depth_img / weight_map (both nullable) are
  * written at COVERED pixels only -- the loss never reads them and their one reader, mr_render_vc_backward, looks
- * at covered pixels only; everywhere else the buffers keep whatever they held. */
+ * at covered pixels only; everywhere else the buffers keep whatever they held.  tile_hit (nullable): 4 bytes per
+ * 32x8 screen tile, [B, ceil(is / 8), ceil(is / 32), 4]; byte w is 1 when rows 2w, 2w + 1 of the tile hold a covered
+ * pixel -- what mr_render_flow_backward skips empty tiles on. */
 MR_API int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
                                   const float* background, int bg_stride, const float* keep_lut, int n_lut,
                                   float alpha_thresh, float* rgb_img, float* alpha_img, float* mask_img,
-                                  float* depth_img, float* weight_map, int32_t* face_index_map, void* workspace,
-                                  int64_t workspace_bytes,
+                                  float* depth_img, float* weight_map, int32_t* face_index_map, uint8_t* tile_hit,
+                                  void* workspace, int64_t workspace_bytes,
                                   int batch_size, int num_verts, int num_faces, int fill_back, int image_size,
                                   float near_, float far_, float eps, int flags, mr_stream_t stream);
+
+/* Adjoint of mr_render_flow_forward w.r.t. vcolors, with the adjoint of the flow epilogue of get_opticalflow
+ * (opticalflow.py:146-154: mask products, permute, [:2], crop) folded in.  The incoming gradient is either
+ *   grad_rgb_img[B,3,is,is] (image orientation; then the flow-space arguments are ignored), or, grad_rgb_img NULL,
+ *   grad_flow[B,height,width,2] with mask_pre / mask_x / occl [B,is,is] (image orientation):
+ *     grad_rgb[b, c, y, x] = (grad_flow[b, y, x, c] * (mask_x * occl)) * mask_pre  inside the crop, 0 outside and
+ *     for c = 2 -- never materialised.  mask_x of image b is mask_x_lo + b * is * is for b < split, else
+ *     mask_x_hi + (b - split) * is * is (the two directions of a stacked frame pair use different masks).
+ * weight_map / depth_img / tile_hit as written by mr_render_flow_forward (tile_hit nullable: every tile is read).
+ * Needs image_size to be a multiple of 4 with at most 4096 tiles, and the [V,3] table to fit LDS (V <= 2560);
+ * MR_ERR_NOTIMPL otherwise
+ * (callers then use mr_flow_finalize_backward + mr_render_vc_backward). */
+MR_API int mr_render_flow_backward(const float* verts, const int32_t* faces_idx, const int32_t* face_index_map,
+                                   const uint32_t* tile_hit, const float* weight_map, const float* depth_img,
+                                   const float* grad_rgb_img, const float* grad_flow, const float* mask_pre,
+                                   const float* mask_x_lo, const float* mask_x_hi, int split, const float* occl,
+                                   int height, int width, float* grad_vcolors, int batch_size, int num_verts,
+                                   int num_faces, int fill_back, int image_size, float eps, int flags,
+                                   mr_stream_t stream);
 
 /* Per-vertex front end of get_opticalflow in its training setting (SURVEY 8f "f1"): for the two
  * frames of a pair, in one launch

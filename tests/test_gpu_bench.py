@@ -67,3 +67,50 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(cuda):
     line = _json_line(res.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["parallelism"] == "dp2"
     assert line["config"]["global_batch"] == 8 and line["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_config4_per_gpu_workload_under_rccl_ddp(cuda):
+    """BASELINE config 4 (8 x MI355X, global B = 256): the per-GPU share -- B = 32 frame pairs of 256 x 256 -- through
+    the RCCL process group + DistributedDataParallel path (one rank: the test box has one GPU); the JSON line
+    carries the per-rank evidence (backend, device, per-rank step time, all-reduce volume)."""
+    env = dict(os.environ, HOC_FORCE_DDP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "32",
+           "--image-size", "256", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-bench",
+           "--no-stock-trunk"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _json_line(res.stdout)
+    assert line["config"]["global_batch"] == 32 and line["value"] > 0 and line["ms_per_step"] > 0
+    ranks = line["ranks"]
+    assert ranks["backend"] == "rccl" and ranks["world_size"] == 1 and len(ranks["per_rank"]) == 1
+    assert ranks["per_rank"][0]["rank"] == 0 and ranks["per_rank"][0]["ms_per_step"] > 0
+    assert 47.0 < ranks["grad_allreduce_MB"] < 49.0  # 11.98 M trainable fp32 parameters (SURVEY 8e)
+
+
+@pytest.mark.gpu
+def test_config2_data_only_step(cuda):
+    """BASELINE config 2 (trainmeshreg.py, B = 32): a fully supervised step -- encoder, heads, MANO layer, 2-D / 3-D
+    losses, backward, Adam -- with no render / warp in it; runs through this build's MANO / head
+    post-processing / trunk glue kernels."""
+    import torch
+
+    from handobjectconsist_amd.models.synthnet import SynthMeshRegNet
+    from handobjectconsist_amd.models.warpreg import WarpRegNet
+    from handobjectconsist_amd.netscripts import epochpassconsist as E
+
+    torch.manual_seed(0)
+    model = SynthMeshRegNet().to(cuda).eval()
+    pre = WarpRegNet((256, 256), model, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
+                     use_backward=True, mano_faces=model.mano_layer.th_faces, pair_outputs="loss").to(cuda)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5)
+    loader = E.SyntheticConsistLoader(32, 256, seed=0, device=cuda, pool=1)
+    data_batch = loader.step_batches(0)[0]
+    assert data_batch["supervision"] == "data"
+    before = [p.detach().clone() for p in model.parameters() if p.requires_grad][:4]
+    losses = [float(E.train_step([data_batch], pre, opt)[0]) for _ in range(3)]
+    assert all(l == l and l > 0 for l in losses)
+    assert losses[-1] < losses[0], losses  # three Adam steps on one batch reduce its loss
+    after = [p.detach() for p in model.parameters() if p.requires_grad][:4]
+    assert any(not torch.equal(a, b_) for a, b_ in zip(after, before))

@@ -218,7 +218,7 @@ def _flow_check(got, want, key, max_support=4):
     return support
 
 
-@pytest.mark.parametrize("path", ["fused", "fused_full_outputs", "vertex_color", "textures"])
+@pytest.mark.parametrize("path", ["fused", "fused_separate_nodes", "fused_full_outputs", "vertex_color", "textures"])
 def test_get_opticalflow_against_reference_glue(cuda, path):
     """Flows and d(flows)/d(vertices of both frames) for every fixture variant (ignore list, crop,
     detach_textures, detach_renders=False, mask_occlusions=False), through the fused vertex stage +
@@ -227,10 +227,12 @@ def test_get_opticalflow_against_reference_glue(cuda, path):
     from handobjectconsist_amd.warping import opticalflow
 
     z, meta = load("chain_opticalflow.npz")
-    saved = (opticalflow.USE_FUSED_VERTEX_STAGE, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_FLOW_RENDER)
+    saved = (opticalflow.USE_FUSED_VERTEX_STAGE, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_FLOW_RENDER,
+             opticalflow.USE_STACKED_FLOW_NODE)
     opticalflow.USE_FUSED_VERTEX_STAGE = path.startswith("fused")
     opticalflow.USE_VERTEX_COLOR_RENDER = path != "textures"
-    opticalflow.USE_FLOW_RENDER = path == "fused"  # flow-mode render (no depth / weights, mask folded in)
+    opticalflow.USE_FLOW_RENDER = path in ("fused", "fused_separate_nodes")  # flow-mode render (mask folded in)
+    opticalflow.USE_STACKED_FLOW_NODE = path == "fused"  # one autograd node, single fused backward launch
     try:
         for m in meta:
             s, k, is_ = m["scene"], m["key"], m["image_size"]
@@ -260,7 +262,8 @@ def test_get_opticalflow_against_reference_glue(cuda, path):
                 else:
                     assert l2_rel(got, want) < 5e-2, (path, k, name, l2_rel(got, want))
     finally:
-        opticalflow.USE_FUSED_VERTEX_STAGE, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_FLOW_RENDER = saved
+        (opticalflow.USE_FUSED_VERTEX_STAGE, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_FLOW_RENDER,
+         opticalflow.USE_STACKED_FLOW_NODE) = saved
 
 
 def test_flow_render_equals_full_render(cuda):

@@ -321,11 +321,24 @@ def _vc_abi_case(cuda, B, is_, seed, n_extra_verts=0):
 
 
 def _vc_backward(d, g_rgb_img, mode):
-    """mode: 'stored' (forward maps), 'recompute' (NULL maps), 'gather' (face-parallel kernel)."""
+    """mode: 'stored' (forward maps), 'recompute' (NULL maps), 'gather' (face-parallel kernel), 'tiles' (the
+    tile-persistent kernel of mr_render_flow_backward, every tile visited), 'tiles_hit' (... with coverage bytes)."""
     from handobjectconsist_amd import _lib
 
     P = _lib.ptr
     out = torch.full((d["B"], d["V"], 3), float("nan"), dtype=torch.float32, device=g_rgb_img.device)
+    if mode in ("tiles", "tiles_hit"):
+        hit = None
+        if mode == "tiles_hit":  # what mr_render_flow_forward writes: per (32x8 tile, row pair) "anything covered"
+            B, is_ = d["B"], d["is_"]
+            ty, tx = (is_ + 7) // 8, (is_ + 31) // 32
+            cov = torch.zeros((B, ty * 8, tx * 32), dtype=torch.bool, device=g_rgb_img.device)
+            cov[:, :is_, :is_] = d["fim"] >= 0
+            hit = cov.reshape(B, ty, 4, 2, tx, 32).permute(0, 1, 4, 2, 3, 5).reshape(B, ty, tx, 4, 64).any(-1).to(torch.uint8).contiguous()
+        _lib.call("mr_render_flow_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), P(hit), P(d["wmap"]), P(d["depth"]),
+                  P(g_rgb_img), None, None, None, None, 0, None, 0, 0, P(out), d["B"], d["V"], d["F0"], 1, d["is_"], 1e-3, 0,
+                  _lib.stream_ptr(g_rgb_img.device))
+        return out.cpu().numpy()
     stored = mode == "stored"
     _lib.call("mr_render_vc_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), P(d["wmap"]) if stored else None,
               P(d["depth"]) if stored else None, P(g_rgb_img), P(out), d["B"], d["V"], d["F0"], 1, d["is_"], 1e-3,
@@ -368,7 +381,7 @@ def test_vc_backward_kernels_match_oracle(cuda, B, is_, seed):
     # per-vertex tolerance: 1e-4 of the vertex's own absolute contributions would need the oracle's
     # partial sums; use 1e-4 relative + 1e-6 of the largest gradient the vertex's image region saw
     atol = 1e-6 * np.abs(ref).max()
-    for mode in ("stored", "recompute", "gather"):
+    for mode in ("stored", "recompute", "gather", "tiles", "tiles_hit"):
         got = _vc_backward(d, g_img, mode)
         assert np.isfinite(got).all(), mode
         assert_close(got, ref, 1e-4, atol, f"grad_vcolors[{mode}]")
@@ -380,7 +393,7 @@ def test_vc_backward_edge_cases(cuda):
     d = _vc_abi_case(cuda, 2, 96, 5)
     B, is_ = d["B"], d["is_"]
     zero = torch.zeros((B, 3, is_, is_), dtype=torch.float32, device=cuda)
-    for mode in ("stored", "recompute", "gather"):
+    for mode in ("stored", "recompute", "gather", "tiles", "tiles_hit"):
         assert (_vc_backward(d, zero, mode) == 0).all(), mode  # also: the output is zeroed by the call
     # a non-finite gradient on a covered pixel reaches exactly the three vertices of the winning face
     fim = d["fim"].cpu().numpy()
@@ -390,7 +403,7 @@ def test_vc_backward_edge_cases(cuda):
     tri = d["fidx_np"][0, fn % d["F0"]]
     g = torch.randn((B, 3, is_, is_), dtype=torch.float32, device=cuda)
     g[0, 1, is_ - 1 - y, x] = float("inf")
-    for mode in ("stored", "recompute", "gather"):
+    for mode in ("stored", "recompute", "gather", "tiles", "tiles_hit"):
         got = _vc_backward(d, g, mode)
         bad = np.argwhere(~np.isfinite(got))
         assert len(bad) > 0 and set(bad[:, 0]) == {0} and set(bad[:, 1]) <= set(tri.tolist()) and set(bad[:, 2]) == {1}, mode
@@ -399,6 +412,7 @@ def test_vc_backward_edge_cases(cuda):
         gs = torch.randn((B, 3, is_, is_), dtype=torch.float32, device=cuda) * scale
         a, b_ = _vc_backward(d, gs, "stored"), _vc_backward(d, gs, "gather")
         assert_close(a, b_, 1e-4, 1e-6 * np.abs(b_).max(), f"scale {scale}")
+        assert_close(_vc_backward(d, gs, "tiles_hit"), b_, 1e-4, 1e-6 * np.abs(b_).max(), f"tiles, scale {scale}")
         assert np.abs(b_).max() > 0
     # a colour table too large for LDS falls back to the gather kernel
     big = _vc_abi_case(cuda, 1, 64, 6, n_extra_verts=4000)
@@ -406,6 +420,35 @@ def test_vc_backward_edge_cases(cuda):
     a, b_ = _vc_backward(big, gb, "stored"), _vc_backward(big, gb, "gather")
     assert_close(a, b_, 1e-6, 1e-7 * np.abs(b_).max(), "large V")
     assert (a[:, -4000:] == 0).all()
+
+
+@pytest.mark.parametrize("B,is_,H,W", [(2, 96, 96, 96), (3, 128, 72, 128), (2, 40, 27, 40)])
+def test_flow_backward_flow_space_gradient(cuda, B, is_, H, W):
+    """mr_render_flow_backward fed with the FLOW-space gradient + epilogue masks == mr_flow_finalize_backward
+    followed by mr_render_vc_backward (two halves with different mask_x, as for a stacked frame pair), incl. a
+    non-square crop and an image size that is not a multiple of the tile."""
+    from handobjectconsist_amd import _lib
+
+    d = _vc_abi_case(cuda, 2 * B, is_, 11)
+    B2 = 2 * B
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    gf = torch.randn((B2, H, W, 2), generator=g).to(cuda)
+    m_pre = (torch.rand((B2, is_, is_), generator=g) < 0.8).float().to(cuda)
+    m_lo = (torch.rand((B, is_, is_), generator=g) < 0.8).float().to(cuda)
+    m_hi = torch.rand((B, is_, is_), generator=g).to(cuda)  # raw alpha may be any float (Q4)
+    occl = (torch.rand((B2, is_, is_), generator=g) < 0.9).float().to(cuda)
+    grad_rgb = torch.empty((B2, 3, is_, is_), dtype=torch.float32, device=cuda)
+    for lo, mx in ((0, m_lo), (B, m_hi)):
+        _lib.call("mr_flow_finalize_backward", P(gf[lo:lo + B]), P(m_pre[lo:lo + B]), P(mx), P(occl[lo:lo + B]),
+                  P(grad_rgb[lo:lo + B]), B, is_, H, W, st)
+    ref = _vc_backward(d, grad_rgb, "stored")
+    out = torch.full((B2, d["V"], 3), float("nan"), dtype=torch.float32, device=cuda)
+    _lib.call("mr_render_flow_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), None, P(d["wmap"]), P(d["depth"]), None,
+              P(gf), P(m_pre), P(m_lo), P(m_hi), B, P(occl), H, W, P(out), B2, d["V"], d["F0"], 1, is_, 1e-3, 0, st)
+    got = out.cpu().numpy()
+    assert np.abs(ref).max() > 0 and (got[:, :, 2] == 0).all()
+    assert_close(got, ref, 1e-5, 1e-6 * np.abs(ref).max(), "flow-space gradient form")
 
 
 def test_vertex_colour_render_adjoint_at_metric_size(cuda):
