@@ -54,9 +54,12 @@ namespace mr {
 
 constexpr int TILE_W = 32, TILE_H = 8;  // tile size in pixels (one pixel per thread)
 constexpr int TPB = 256;              // threads per workgroup (4 waves)
-constexpr int NB = 32;                // faces per batch (stage S1: one lane per face)
+constexpr int NB = 32;                // faces per batch (stage S1: one lane per face).  48 and 64 were measured (one
+                                      // batch per wave for the ~145 faces of a typical geometry tile): the larger face
+                                      // cache costs occupancy (5 / 4 instead of 7 waves per SIMD) and the kernel gets slower
+constexpr int NBP2 = 32;              // next power of two
 constexpr int FC_STRIDE = 21;         // dwords per face-cache slot (odd: conflict-free ds_read_b32): v 9, inv 9, slot, box
-constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 8 * 64, power of 2)
+constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 4 * 64, power of 2)
 constexpr int SCAN_UNROLL = 3;        // independent record loads in flight per lane
 constexpr int QCAP = 256;             // wave-private ring capacity (>= NB - 1 + 64 * SCAN_UNROLL, power of 2)
 
@@ -461,7 +464,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
         // (8 lanes per face would leave most of them idle for the 3 - 4-row faces of these meshes)
         int incl = nrows;
 #pragma unroll
-        for (int off = 1; off < NB; off <<= 1) {
+        for (int off = 1; off < NBP2; off <<= 1) {
             const int up = __shfl_up(incl, off);
             if (lane >= off) incl += up;
         }
@@ -482,7 +485,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
             // slot = the face whose row range holds this item: largest k with ro[k] <= item (5 halvings of [0, NB))
             int slot = 0;
 #pragma unroll
-            for (int step = NB / 2; step >= 1; step >>= 1)
+            for (int step = NBP2 / 2; step >= 1; step >>= 1)
                 slot += (ro[min(slot + step, NB)] <= item && slot + step < NB) ? step : 0;
             int row = 0;
             float ea[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, ey[3] = {0, 0, 0};
