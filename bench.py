@@ -52,6 +52,9 @@ def parse():
     p.add_argument("--kernel-iters", type=int, default=50)
     p.add_argument("--kernels-only", action="store_true", help="only the per-kernel benchmark (profiling aid)")
     p.add_argument("--hot-only", action="store_true", help="only the render+warp hot path fwd+bwd (profiling aid)")
+    p.add_argument("--roofline-only", action="store_true",
+                   help="launch only the two roofline kernels a few times (what the in-run PMC passes profile)")
+    p.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic")
     return p.parse_args()
 
 
@@ -84,9 +87,16 @@ def event_time_ms(fn, iters, warmup=5, flush=None):
     return total / iters
 
 
-def kernel_bench(dev, B, is_, iters):
+ROOF_BWD = "render_flow_backward(train,E+epilogue adjoint,2B)"
+ROOF_FWD = "render_flow_forward(train outputs,both frames=2B)"
+# the device kernels behind the two groups (names as rocprofv3 prints them)
+ROOF_KERNELS = {ROOF_BWD: ["scatter_tiles_kernel<true>"],
+                ROOF_FWD: ["face_records_kernel<true>", "bin_boxes_kernel", "raster_tile_kernel<true, true>"]}
+
+
+def kernel_bench(dev, B, is_, iters, only=None):
     """Each hot-path kernel group alone, on the bench workload's own tensors.  Algorithmic
-    bytes per launch follow SURVEY 8(d) / DESIGN.md."""
+    bytes per launch follow SURVEY 8(d) / DESIGN.md.  `only`: names of the groups to run."""
     from handobjectconsist_amd import _lib
     from handobjectconsist_amd.neurender import nr_ops
     from handobjectconsist_amd.utils import synth, textutils
@@ -293,26 +303,31 @@ def kernel_bench(dev, B, is_, iters):
         ("bn_add_relu_backward(layer1)[3B,64]", bn_bwd, 4 * 5 * l1_x.numel()),
     ]
     out = {}
+    if only is not None:
+        groups = [g for g in groups if g[0] in only]
     flush = torch.zeros(768 * 1024 * 1024 // 4, **f32)  # 768 MB > Infinity Cache (256 MB)
     for name, fn, nbytes in groups:
         ms = event_time_ms(fn, iters, flush=flush)
         ms_warm = event_time_ms(fn, iters)
         gbs = nbytes / (ms * 1e-3) / 1e9
         out[name] = {"ms": round(ms, 4), "ms_cache_warm": round(ms_warm, 4), "algorithmic_MB": round(nbytes / 1e6, 1), "algorithmic_bytes": int(nbytes),
-                     "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                     "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                     "frac_hbm_peak_cache_warm": round(nbytes / (ms_warm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del flush
     return out
 
 
-def cpu_baseline(B_sample, is_, B_full):
+def cpu_baseline(B_sample, is_, B_full, threads=None):
     """The CPU oracle (oracle/, a port -- the reference has no CPU render path) on a
     bounded sample of the hot path: 2 renders + flow masks + occlusion + pair loss forward, and
-    the texture / flow backward; extrapolated linearly in the batch size (images are independent)."""
+    the texture / flow backward; extrapolated linearly in the batch size (images are independent).
+    The rasteriser (kernels A, B, C, E) is C + OpenMP over batch x rows with `threads` threads; the warp /
+    occlusion / pair-loss half is single-threaded numpy (oracle/warp_ref.py)."""
     from handobjectconsist_amd.utils import synth
     from oracle import raster_ref as R
     from oracle import warp_ref as W
 
-    threads = os.cpu_count() or 1
+    threads = threads or os.cpu_count() or 1
     s = synth.random_scene(B_sample, seed=0, image_size=is_)
     kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
               dist_coeffs=np.zeros((1, 5), np.float32), orig_size=is_, image_size=is_, anti_aliasing=False,
@@ -338,22 +353,75 @@ def cpu_baseline(B_sample, is_, B_full):
     sec_per_iter = dt * (B_full / B_sample)
     return {"value": round(1.0 / sec_per_iter, 6), "unit": "iters/s", "cores": threads, "kind": "port",
             "sample": f"hot path only (2 renders fwd, flow masks, occlusion, pair loss fwd+bwd, texture bwd; encoder "
-                      f"and optimiser excluded), B={B_sample} of {B_full} at {is_}x{is_}, {dt:.1f} s measured on "
-                      f"{threads} threads, extrapolated x{B_full // B_sample}"}
+                      f"and optimiser excluded), B={B_sample} of {B_full} at {is_}x{is_}, {dt:.1f} s measured, "
+                      f"extrapolated x{B_full // B_sample}; rasteriser = C/OpenMP on {threads} threads, warp / occlusion / "
+                      f"pair loss = single-threaded numpy"}
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed PMC passes (PMC counters cannot be
-    collected from inside this process; scripts/pmc.sh runs them, profiles/r01_pmc_traffic.json
-    holds the corrected per-dispatch means).  None when the file or the kernel is missing."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            rec = json.load(fh)[kernel_name]
-        return {"traffic": rec["hbm_bytes"], "traffic_unit": "bytes/launch",
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"}
-    except (OSError, KeyError, ValueError):
+def pmc_traffic_in_run(args, timeout=420):
+    """HBM bytes per launch of the roofline kernels, measured NOW: two `rocprofv3 --pmc` passes (FETCH_SIZE, then
+    WRITE_SIZE -- they do not fit one pass, MI355X_MICROARCH.md PMC slots) over `bench.py --roofline-only` as a
+    subprocess, mean per dispatch and kernel.  FETCH_SIZE / WRITE_SIZE count KB; on gfx950 FETCH_SIZE reports
+    half of the bytes of wide coalesced reads (same guide, HBM section), so `hbm_bytes` = 1024 (2 FETCH + WRITE) is
+    the upper estimate and `hbm_bytes_low` = 1024 (FETCH + WRITE) the lower one.  {} when rocprofv3 is missing or a
+    pass fails (the committed profiles/ then hold the last good numbers)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
         return {}
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="hoc_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable,
+               os.path.abspath(__file__), "--roofline-only", "--batch", str(args.batch), "--image-size", str(args.image_size),
+               "--kernel-iters", "3"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout, capture_output=True, check=True)
+            files = glob.glob(os.path.join(tmp, "**", "p_counter_collection.csv"), recursive=True)
+            per = {}
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    key = (row["Kernel_Name"].split("(")[0].replace("void ", "").replace("mr::", ""), row["Dispatch_Id"])
+                    per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+            for (kname, _), v in per.items():
+                sums.setdefault(kname, {}).setdefault(counter, []).append(v)
+        except Exception as e:  # noqa: BLE001 -- the benchmark line must not depend on the profiler
+            sys.stderr.write(f"[bench] PMC pass {counter} failed: {e}\n")
+            return {}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for kname, c in sums.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            fe, wr = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]), sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+            out[kname] = {"FETCH_SIZE_KB": round(fe, 1), "WRITE_SIZE_KB": round(wr, 1), "hbm_bytes": int(1024 * (2 * fe + wr)),
+                          "hbm_bytes_low": int(1024 * (fe + wr)), "dispatches": len(c["FETCH_SIZE"])}
+    return out
+
+
+def roofline_block(name, k, pmc, units):
+    """`frac` = algorithmic bytes / HIP-event duration with cold caches / peak; `dram_frac` = the bytes the
+    PMC counters saw / the same duration / peak -- what the DRAM interface actually carried."""
+    roof = {"kernel": name, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": k["frac_hbm_peak"], "frac_cache_warm": k["frac_hbm_peak_cache_warm"], "traffic": None,
+            "algorithmic_bytes": k["algorithmic_bytes"], "launch_ms": k["ms"], "launch_ms_cache_warm": k["ms_cache_warm"],
+            "units_per_launch": units, "device_kernels": ROOF_KERNELS[name]}
+    found = [pmc[d] for d in ROOF_KERNELS[name] if d in pmc]
+    if len(found) == len(ROOF_KERNELS[name]):
+        hi, lo = sum(f["hbm_bytes"] for f in found), sum(f["hbm_bytes_low"] for f in found)
+        roof.update({"traffic": hi, "traffic_low": lo, "traffic_unit": "bytes/launch",
+                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this process "
+                                       "(1024 x (2 FETCH + WRITE); traffic_low: FETCH as reported)",
+                     "dram_frac": round(hi / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "dram_frac_low": round(lo / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    return roof
 
 
 def main():
@@ -397,8 +465,9 @@ def main():
     from handobjectconsist_amd.netscripts.epochpassconsist import SyntheticConsistLoader, train_step
 
     assert _lib.load().mr_device_ok() == 1, "libmeshraster_hip.so: no gfx950 device"
-    if args.kernels_only:
-        os.write(real_stdout, (json.dumps(kernel_bench(dev, args.batch, args.image_size, args.kernel_iters), indent=1) + "\n").encode())
+    if args.kernels_only or args.roofline_only:
+        only = (ROOF_BWD, ROOF_FWD) if args.roofline_only else None
+        os.write(real_stdout, (json.dumps(kernel_bench(dev, args.batch, args.image_size, args.kernel_iters, only), indent=1) + "\n").encode())
         return
     torch.manual_seed(rank)
     B, is_ = args.batch, args.image_size
@@ -525,18 +594,21 @@ def main():
             _sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark = saved
         torch.cuda.empty_cache()
 
-    kernels, roof, cpu = None, None, None
+    kernels, roof, roof_fwd, cpu = None, None, None, None
     if rank == 0 and not args.no_kernel_bench:
         kernels = kernel_bench(dev, B, is_, args.kernel_iters)
-        # the raster backward in the shape the training step launches it: one launch for both frames of the pair
-        dom = "render_vc_backward(train,E,both frames=2B)"
-        k = kernels[dom]
-        roof = {"kernel": dom, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": k["frac_hbm_peak"], "traffic": None, "algorithmic_bytes": k["algorithmic_bytes"],
-                "launch_ms": k["ms"], "units_per_launch": f"{2 * B} renders of {is_}x{is_}, 7104 faces"}
-        roof.update(pmc_traffic("mr::scatter_vc_kernel<true>"))
+        pmc = {} if (args.no_pmc or world > 1) else pmc_traffic_in_run(args)
+        units = f"{2 * B} renders of {is_}x{is_}, 7104 faces"
+        # the raster backward (north star) in the shape the training step launches it: one launch for both frames of
+        # the pair, the adjoint of the flow epilogue folded in
+        roof = roofline_block(ROOF_BWD, kernels[ROOF_BWD], pmc, units)
+        # ... and the forward of the same launch shape: the hot-path kernel that takes the most time
+        roof_fwd = roofline_block(ROOF_FWD, kernels[ROOF_FWD], pmc, units)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_sample, is_, B)
+        if (os.cpu_count() or 1) > 8:  # the figure that lines up with BASELINE.md's 8-thread reference measurement
+            c8 = cpu_baseline(max(args.cpu_sample // 4, 2), is_, B, threads=8)
+            cpu["at_8_threads"] = {"value": c8["value"], "sample": c8["sample"]}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -552,7 +624,7 @@ def main():
                                    f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {('fp32' if args.encoder_dtype == 'f32' else 'bf16-autocast') + ' (MIOpen convolutions, channels-last, + fused HIP BatchNorm/ReLU/residual/max-pool kernels)'}, Adam",
                        "global_batch": B * world, "image_size": is_, "parallelism": f"dp{world}"},
             "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),
-            "ranks": ranks, "stock_trunk": stock, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "ranks": ranks, "stock_trunk": stock, "roofline": roof, "roofline_forward": roof_fwd, "kernels": kernels, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

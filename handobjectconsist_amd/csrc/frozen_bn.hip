@@ -18,6 +18,11 @@
 
 namespace mr {
 
+// ReLU that propagates NaN like torch.relu (fmaxf(NaN, 0) would return 0 and hide a diverged trunk from the
+// "Loss became nan!" guard)
+__device__ __forceinline__ float relu_nan(float z) { return z > 0.0f ? z : (z != z ? z : 0.0f); }
+
+
 struct BnParams {
     const void* x;          // [N,C,HW]  fp32 or bf16 (the activation type T of the kernel)
     const void* residual;   // [N,C,HW] or NULL
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnParams p) {
             float z = d * a + b;
             if (p.residual) z = z + rv[i];
             if (!BACKWARD) {
-                out[i] = relu ? fmaxf(z, 0.0f) : z;
+                out[i] = relu ? relu_nan(z) : z;
             } else {
                 const float g = (relu && !(z > 0.0f)) ? 0.0f : gv[i];
                 gres[i] = g;
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_act_nhwc_kernel(BnParams p) {
             float z = d * a[i] + b[i];
             if (p.residual) z = z + rv[i];
             if (!BACKWARD) {
-                out[i] = relu ? fmaxf(z, 0.0f) : z;
+                out[i] = relu ? relu_nan(z) : z;
             } else {
                 const float g = (relu && !(z > 0.0f)) ? 0.0f : gv[i];
                 gres[i] = g;

@@ -11,6 +11,10 @@
 
 namespace mr {
 
+// ReLU / max that propagate NaN like torch.relu / max_pool2d ("val > max || isnan(val)")
+__device__ __forceinline__ float sp_relu_nan(float z) { return z > 0.0f ? z : (z != z ? z : 0.0f); }
+
+
 struct StemParams {
     const void* x;        // [N,C,H,W] convolution output, fp32 or bf16 (the activation type T of the kernels)
     const float* weight;  // [C]
@@ -114,7 +118,10 @@ __global__ __launch_bounds__(256) void stem_pool_forward_kernel(StemParams p) {
 #pragma unroll
         for (int kh = 0; kh < 3; kh++)
 #pragma unroll
-            for (int kw = 0; kw < 3; kw++) m = fmaxf(m, zt[2 * wy + kh][2 * wx + kw + SP_C0 - 1]);
+            for (int kw = 0; kw < 3; kw++) {
+                const float z = zt[2 * wy + kh][2 * wx + kw + SP_C0 - 1];
+                m = (z > m || z != z) ? z : m;
+            }
         static_cast<T*>(p.y)[((int64_t)plane * p.OH + oy) * p.OW + ox] = sp_from<T>(m);
     }
 }
@@ -148,8 +155,8 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(StemParams p) {
 #pragma unroll
             for (int k = 0; k < 9; k++) {
                 const float z = zt[2 * wy + k / 3][2 * wx + k % 3 + SP_C0 - 1];
-                const float v = fmaxf(z, 0.0f);
-                if (z != -__builtin_inff() && v > mv) { mv = v; best = k; }
+                const float v = sp_relu_nan(z);
+                if (z != -__builtin_inff() && (v > mv || v != v)) { mv = v; best = k; }
             }
         }
         gw[wy][wx] = g;
@@ -287,8 +294,8 @@ __global__ __launch_bounds__(256) void stem_pool_nhwc_forward_kernel(StemParams 
             sp_load4<T>(x, (((int64_t)n * p.H + iy) * p.W + ix) * p.C + c0, xv);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float v = fmaxf((xv[i] - mean[i]) * a[i] + b[i], 0.0f);
-                if (v > best[i]) { best[i] = v; bi[i] = (unsigned)k; }
+                const float v = sp_relu_nan((xv[i] - mean[i]) * a[i] + b[i]);
+                if (v > best[i] || v != v) { best[i] = v; bi[i] = (unsigned)k; }
             }
         }
         const int64_t o = op * p.C + c0;

@@ -390,3 +390,24 @@ def test_training_trajectory_fused_trunk_vs_stock_modules(cuda, monkeypatch):
     assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
     assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max(), (a, b)
     assert abs(b[-1] - b[0]) > 1e-6 * abs(b[0])  # the parameters do move
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_glue_kernels_propagate_nan_like_the_stock_modules(cuda, channels_last):
+    """torch.relu and max_pool2d propagate NaN; the fused kernels must too, or a diverged trunk would hand finite
+    features to the 'Loss became nan!' guard of the epoch loop."""
+    from handobjectconsist_amd.nn import frozen_bn
+
+    bn = torch.nn.BatchNorm2d(8).to(cuda).eval()
+    x = torch.randn(2, 8, 12, 12, device=cuda)
+    x[0, 3, 5, 5] = float("nan")
+    x[1, 0, 0, 0] = float("nan")
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = frozen_bn.bn_act(x, bn, relu=True)
+        ref = F.relu(bn(x))
+        assert torch.equal(torch.isnan(y), torch.isnan(ref)) and int(torch.isnan(y).sum()) == 2
+        yp = frozen_bn.stem_pool(x, bn)
+        refp = F.max_pool2d(F.relu(bn(x)), 3, 2, 1)
+        assert torch.equal(torch.isnan(yp), torch.isnan(refp)) and int(torch.isnan(yp).sum()) >= 2
