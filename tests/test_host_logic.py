@@ -212,3 +212,44 @@ def test_extend_collate_pads_by_cyclic_repetition():
     assert len(seq) == 2 and seq[0]["objverts3d"].shape == (2, 7, 3) and seq[1]["objfaces"].shape == (2, 3, 3)
     with pytest.raises(ValueError):
         collate.seq_extend_collate([[dict(a)], [dict(a), dict(b)]])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_train_step_nan_guard_keeps_parameters_and_optimizer_state_clean(fused):
+    """A NaN loss must not reach the parameters or the Adam state and must raise (reference
+    epochpassconsist.py:61-63).  With a fused optimiser the guard is the optimiser's device-side `found_inf`
+    operand and the ValueError comes when the next step starts; otherwise the check is synchronous."""
+    from handobjectconsist_amd.netscripts import epochpassconsist as E
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+            self.bad = False
+
+        def forward(self, batch):
+            loss = (self.w * batch["x"]).sum().reshape(1)
+            if self.bad:
+                loss = loss * float("nan")
+            return loss, {"l": loss.detach()}, None, None
+
+    net = Net()
+    opt = torch.optim.Adam(net.parameters(), lr=0.1, fused=fused)
+    batch = {"data": [{}], "x": torch.ones(3)}
+    E.train_step([batch], net, opt)
+    w1 = net.w.detach().clone()
+    assert not torch.equal(w1, torch.ones(3))
+    net.bad = True
+    with pytest.raises(ValueError, match="nan"):
+        E.train_step([batch], net, opt)   # synchronous check: raises here
+        net.bad = False
+        E.train_step([batch], net, opt)   # device-side guard: raises when the next step starts
+    assert torch.equal(net.w.detach(), w1), "the diverged step touched the parameters"
+    assert all(float(st["step"]) == 1.0 for st in opt.state.values())
+    # epoch_pass flushes a pending flag at the end of the epoch
+    net2, net2_opt = Net(), None
+    net2_opt = torch.optim.Adam(net2.parameters(), lr=0.1, fused=fused)
+    net2.bad = True
+    with pytest.raises(ValueError, match="nan"):
+        E.epoch_pass([batch], net2, net2_opt, loader_nb=1)
+    assert torch.equal(net2.w.detach(), torch.ones(3))
