@@ -44,6 +44,7 @@ SIGNATURES = {
     "mr_warp_forward": (_I, [_P] * 4 + [_I, _I, _I, _I, _F, _I, _P]),
     "mr_warp_backward": (_I, [_P] * 5 + [_I, _I, _I, _I, _F, _I, _P]),
     "mr_occlusion_mask": (_I, [_P] * 4 + [_L, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
+    "mr_occlusion_flow": (_I, [_P] * 4 + [_L] + [_P] * 6 + [_I, _I, _I, _I, _I, _F, _F, _P]),
     "mr_flow_mask": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _P]),
     "mr_flow_finalize_forward": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
     "mr_flow_finalize_backward": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),

@@ -392,6 +392,44 @@ __global__ void __launch_bounds__(256) occlusion_kernel(const float* __restrict_
     occl2[i] = occl_one(m2, m1, f21, f12, s21, s12, hw, H, W, xx, yy, dist_thresh, wthresh);
 }
 
+// occlusion_kernel + flow_finalize_forward_kernel of both directions in one pass (mr_occlusion_flow): the pixel
+// that has just computed its two occlusion bits also holds everything the final flows need --
+// out12[b, y, x, c] = (flow12[b, c, y, x] * scale12) * (mask1 * occl1), likewise 21 -- inside the crop.
+__global__ void __launch_bounds__(256) occlusion_flow_kernel(const float* __restrict__ mask1,
+                                                             const float* __restrict__ mask2,
+                                                             const float* __restrict__ flow12,
+                                                             const float* __restrict__ flow21, int64_t fbstride,
+                                                             const float* __restrict__ scale12,
+                                                             const float* __restrict__ scale21,
+                                                             float* __restrict__ occl1, float* __restrict__ occl2,
+                                                             float* __restrict__ out12, float* __restrict__ out21,
+                                                             int B, int H, int W, int crop_h, int crop_w,
+                                                             float dist_thresh, float wthresh) {
+    const int64_t hw = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * hw) return;
+    const int b = (int)(i / hw);
+    const int64_t pix = i % hw;
+    const int yy = (int)(pix / W), xx = (int)(pix % W);
+    const float* m1 = mask1 + (int64_t)b * hw;
+    const float* m2 = mask2 + (int64_t)b * hw;
+    const float* f12 = flow12 + (int64_t)b * fbstride;
+    const float* f21 = flow21 + (int64_t)b * fbstride;
+    const float* s12 = scale12 ? scale12 + (int64_t)b * hw : nullptr;
+    const float* s21 = scale21 ? scale21 + (int64_t)b * hw : nullptr;
+    const float o1 = occl_one(m1, m2, f12, f21, s12, s21, hw, H, W, xx, yy, dist_thresh, wthresh);
+    const float o2 = occl_one(m2, m1, f21, f12, s21, s12, hw, H, W, xx, yy, dist_thresh, wthresh);
+    occl1[i] = o1;
+    occl2[i] = o2;
+    if (yy < crop_h && xx < crop_w) {
+        const int64_t o = ((int64_t)b * crop_h + yy) * crop_w + xx;
+        const float a1 = s12 ? s12[pix] : 1.0f, a2 = s21 ? s21[pix] : 1.0f;
+        const float post1 = m1[pix] * o1, post2 = m2[pix] * o2;
+        *reinterpret_cast<float2*>(out12 + o * 2) = make_float2((f12[pix] * a1) * post1, (f12[hw + pix] * a1) * post1);
+        *reinterpret_cast<float2*>(out21 + o * 2) = make_float2((f21[pix] * a2) * post2, (f21[hw + pix] * a2) * post2);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // flow epilogue of opticalflow.get_opticalflow (opticalflow.py:109-154)
 // ---------------------------------------------------------------------------------------
@@ -781,6 +819,24 @@ extern "C" int mr_occlusion_mask(const float* mask_flow1, const float* mask_flow
     hipLaunchKernelGGL(occlusion_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, mask_flow1,
                        mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2, batch_size,
                        height, width, distance_thresh, warp_thresh);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_occlusion_flow(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                                 const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                                 const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
+                                 float* flow_out21, int batch_size, int height, int width, int crop_height,
+                                 int crop_width, float distance_thresh, float warp_thresh, mr_stream_t stream) {
+    if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2 || !flow_out12 || !flow_out21)
+        return MR_ERR_BADARG;
+    if (batch_size < 0 || height <= 0 || width <= 0 || flow_bstride < 2LL * height * width) return MR_ERR_BADARG;
+    if (crop_height <= 0 || crop_width <= 0 || crop_height > height || crop_width > width) return MR_ERR_BADARG;
+    const int64_t n = (int64_t)batch_size * height * width;
+    if (n == 0) return MR_OK;
+    hipLaunchKernelGGL(occlusion_flow_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, mask_flow1,
+                       mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2, flow_out12,
+                       flow_out21, batch_size, height, width, crop_height, crop_width, distance_thresh, warp_thresh);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

@@ -270,8 +270,8 @@ class _StackedFlowFunction(torch.autograd.Function):
     (ndc[2B,V,3], faces[2B,F0,3] int32, cols[2B,V,3]) -> flows[2B,H,W,2] (first half flow12, second half flow21).
 
     forward:  flow-mode render of the 2B stacked meshes (mr_render_flow_forward: displacement planes, alpha, flow
-              mask, face index, weights / depth at covered pixels, per-tile coverage bytes), occlusion check
-              (mr_occlusion_mask, SURVEY Q4 masks), crop / permute / mask products (mr_flow_finalize_forward);
+              mask, face index, weights / depth at covered pixels, per-tile coverage bytes), then occlusion check
+              (SURVEY Q4 masks) + crop / permute / mask products of both directions in one pass (mr_occlusion_flow);
     backward: ONE launch (mr_render_flow_backward): the adjoint of the epilogue is applied on the fly to the
               flow-space gradient, the colour-space gradient [2B,3,is,is] is never materialised, empty tiles are
               skipped on the coverage bytes.
@@ -302,14 +302,12 @@ class _StackedFlowFunction(torch.autograd.Function):
                   _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(wmap), _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(work), wbytes,
                   B2, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps), 0, st)
         occl = torch.empty((B2, is_, is_), **f32)
-        # mask_flow2 is the RAW alpha inside the occlusion block (Q4); flows are rgb * mask, on the fly
-        _lib.call("mr_occlusion_mask", _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(rgb[:B]), _lib.ptr(rgb[B:]),
-                  3 * is_ * is_, _lib.ptr(mask[:B]), _lib.ptr(mask[B:]), _lib.ptr(occl[:B]), _lib.ptr(occl[B:]), B, is_, is_,
-                  0.03, 0.99999, st)
         flow = torch.empty((B2, height, width, 2), **f32)
-        for lo, mask_x in ((0, mask[:B]), (B, alpha[B:])):
-            _lib.call("mr_flow_finalize_forward", _lib.ptr(rgb[lo:lo + B]), _lib.ptr(mask[lo:lo + B]), _lib.ptr(mask_x),
-                      _lib.ptr(occl[lo:lo + B]), _lib.ptr(flow[lo:lo + B]), B, is_, height, width, st)
+        # occlusion check + crop / permute / mask products of both directions in one pass.  mask_flow2 is the RAW
+        # alpha inside the occlusion block and afterwards (Q4); the masked flows rgb * mask are formed on the fly
+        _lib.call("mr_occlusion_flow", _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(rgb[:B]), _lib.ptr(rgb[B:]),
+                  3 * is_ * is_, _lib.ptr(mask[:B]), _lib.ptr(mask[B:]), _lib.ptr(occl[:B]), _lib.ptr(occl[B:]),
+                  _lib.ptr(flow[:B]), _lib.ptr(flow[B:]), B, is_, is_, height, width, 0.03, 0.99999, st)
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width)
         ctx.save_for_backward(verts, fidx, fim, tile_hit, wmap, depth, mask, alpha, occl)
         return flow

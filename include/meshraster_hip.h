@@ -332,6 +332,16 @@ MR_API int mr_occlusion_mask(const float* mask_flow1, const float* mask_flow2, c
                       int height, int width, float distance_thresh, float warp_thresh,
                       mr_stream_t stream);
 
+/* mr_occlusion_mask followed by the flow epilogue of opticalflow.py:146-154 for both directions, in one pass:
+ *   flow_out12[b, y, x, c] = (flow12[b, c, y, x] * flow12_scale) * (mask_flow1 * occl1),  c = 0, 1, y < crop_height,
+ *   x < crop_width  ([B, crop_height, crop_width, 2]); likewise flow_out21 with mask_flow2 / occl2.
+ * (= mr_flow_finalize_forward with mask_pre = the scale and mask_x = the mask the occlusion check used.) */
+MR_API int mr_occlusion_flow(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                             const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                             const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
+                             float* flow_out21, int batch_size, int height, int width, int crop_height,
+                             int crop_width, float distance_thresh, float warp_thresh, mr_stream_t stream);
+
 /* Flow epilogue of opticalflow.get_opticalflow (opticalflow.py:109-154), fused.
  * mr_flow_mask: mask[B,is,is] (IMAGE orientation) = (alpha_img > thresh) * keep, where keep
  *   looks the un-flipped face_index_map up in keep_lut[n_lut] (entry f+1 for face f, entry 0 =

@@ -449,3 +449,30 @@ def test_meshreg_post_hip_matches_torch_ops(cuda, B, Vo, monkeypatch):
             ga = a.grad if a.grad is not None else torch.zeros_like(a)
             gb = b_.grad if b_.grad is not None else torch.zeros_like(b_)
             close(ga.cpu().numpy(), gb.cpu().numpy(), 2e-4, 2e-5 * float(gb.abs().max()) + 1e-12, f"grad {name} {subset}")
+
+
+@pytest.mark.parametrize("B,is_,H,W", [(2, 64, 64, 64), (3, 96, 54, 96), (1, 40, 27, 33)])
+def test_occlusion_flow_equals_occlusion_then_finalize(cuda, B, is_, H, W):
+    """mr_occlusion_flow == mr_occlusion_mask followed by mr_flow_finalize_forward for both directions (SURVEY Q4
+    masks: direction 2 uses a raw, non-binary alpha), bit for bit."""
+    from handobjectconsist_amd import _lib
+
+    g = torch.Generator().manual_seed(5)
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    rgb1 = (torch.randn(B, 3, is_, is_, generator=g) * 2).to(cuda)
+    rgb2 = (torch.randn(B, 3, is_, is_, generator=g) * 2).to(cuda)
+    m1 = (torch.rand(B, is_, is_, generator=g) < 0.6).float().to(cuda)
+    m2 = (torch.rand(B, is_, is_, generator=g) < 0.6).float().to(cuda)
+    alpha2 = torch.maximum(m2, (torch.rand(B, is_, is_, generator=g) < 0.2).float().to(cuda) * 0.5)
+    new = lambda *s: torch.full(s, float("nan"), dtype=torch.float32, device=cuda)
+    o1, o2, o1f, o2f = new(B, is_, is_), new(B, is_, is_), new(B, is_, is_), new(B, is_, is_)
+    f12, f21, g12, g21 = new(B, H, W, 2), new(B, H, W, 2), new(B, H, W, 2), new(B, H, W, 2)
+    _lib.call("mr_occlusion_mask", P(m1), P(alpha2), P(rgb1), P(rgb2), 3 * is_ * is_, P(m1), P(m2), P(o1), P(o2), B, is_, is_,
+              0.03, 0.99999, st)
+    _lib.call("mr_flow_finalize_forward", P(rgb1), P(m1), P(m1), P(o1), P(f12), B, is_, H, W, st)
+    _lib.call("mr_flow_finalize_forward", P(rgb2), P(m2), P(alpha2), P(o2), P(f21), B, is_, H, W, st)
+    _lib.call("mr_occlusion_flow", P(m1), P(alpha2), P(rgb1), P(rgb2), 3 * is_ * is_, P(m1), P(m2), P(o1f), P(o2f), P(g12),
+              P(g21), B, is_, is_, H, W, 0.03, 0.99999, st)
+    assert torch.equal(o1, o1f) and torch.equal(o2, o2f)
+    assert torch.equal(f12, g12) and torch.equal(f21, g21)
+    assert float(f12.abs().sum()) > 0 and float(f21.abs().sum()) > 0
