@@ -203,8 +203,21 @@ def kernel_bench(dev, B, is_, iters, only=None):
     render_flow_fwd_pair()
     render_vc_fwd_pair()
     im_ref, im, jm_ref, jm = [t(a) for a in synth.random_images(B, is_, is_, 0)]
-    flow12 = (torch.randn(B, is_, is_, 2, device=dev) * 2) * (torch.rand(B, is_, is_, 1, device=dev) < 0.1)
-    flow21 = (torch.randn(B, is_, is_, 2, device=dev) * 2) * (torch.rand(B, is_, is_, 1, device=dev) < 0.1)
+    # the flows the pair loss sees in training: rendered displacement fields (zero outside the meshes, a few pixels
+    # inside), from the flow-mode render + occlusion / epilogue pass of this very scene
+    pflows = torch.empty((B2, is_, is_, 2), **f32)
+    pcols_flow = (pcols * 1.5).contiguous()
+    _lib.call("mr_render_flow_forward", P(pv), P(pf), P(pcols_flow), P(bg), 0, P(keep_lut), int(keep_lut.numel()), 0.99999,
+              P(prgb), P(palpha), P(pmask), P(pdepth), P(pwmap), P(pfim), P(ptile_hit), P(pwork), pwbytes, B2, pv.shape[1],
+              F0, 1, is_, 0.1, 100.0, 1e-3, 0, st)
+    pocc = torch.empty((B2, is_, is_), **f32)
+
+    def occlusion_flow():  # occlusion check + flow epilogue of both directions (what the training step launches)
+        _lib.call("mr_occlusion_flow", P(pmask[:B]), P(palpha[B:]), P(prgb[:B]), P(prgb[B:]), 3 * is_ * is_, P(pmask[:B]),
+                  P(pmask[B:]), P(pocc[:B]), P(pocc[B:]), P(pflows[:B]), P(pflows[B:]), B, is_, is_, is_, is_, 0.03, 0.99999, st)
+
+    occlusion_flow()
+    flow12, flow21 = pflows[:B], pflows[B:]
     pbytes = int(lib.mr_pair_consist_workspace_bytes(B, is_, is_))
     pcwork = torch.empty((pbytes,), dtype=torch.uint8, device=dev)
     sums, lf, lb = torch.empty((B, 4), **f32), torch.empty((B,), **f32), torch.empty((B,), **f32)
@@ -294,6 +307,8 @@ def kernel_bench(dev, B, is_, iters, only=None):
         ("pair_consist_forward", pair_fwd, 48 * npx),
         ("pair_consist_backward", pair_bwd, 64 * npx),
         ("occlusion_mask", occlusion, (8 + 16 + 8) * npx),
+        # + the two final flows written in the same pass (16 B per pixel)
+        ("occlusion_flow(train: occlusion + flow epilogue)", occlusion_flow, (8 + 16 + 8 + 16) * npx),
         # 3 source bytes in, 12 B image + 12 B three-channel jitter mask out, per output pixel of the 3B frames
         ("frames_to_batch(3B frames,640x480->crop)", frames_to_batch, (3 + 12 + 12) * NF * is_ * is_),
         # encoder glue: bytes = tensors read + written once

@@ -328,6 +328,9 @@ __device__ __forceinline__ float occl_one(const float* __restrict__ mask_a, cons
                                           int xx, int yy, float dist_thresh, float wthresh) {
     const int64_t pix = (int64_t)yy * W + xx;
     const float ma_p = mask_a[pix];
+    // The result is mask_a(p) * (...) * motion with finite factors (masks are 0 / 1 or a rendered alpha): a pixel
+    // outside its own mask -- 90 % of a hand + object frame -- is 0 without any of the dependent gathers below.
+    if (ma_p == 0.0f) return 0.0f;
     // second warp: sample warp_ab at p + flow_ab(p)   (flow = raw flow * scale when a scale map is given)
     float ix, iy;
     const float sa = scale_ab ? scale_ab[pix] : 1.0f;
@@ -425,8 +428,12 @@ __global__ void __launch_bounds__(256) occlusion_flow_kernel(const float* __rest
         const int64_t o = ((int64_t)b * crop_h + yy) * crop_w + xx;
         const float a1 = s12 ? s12[pix] : 1.0f, a2 = s21 ? s21[pix] : 1.0f;
         const float post1 = m1[pix] * o1, post2 = m2[pix] * o2;
-        *reinterpret_cast<float2*>(out12 + o * 2) = make_float2((f12[pix] * a1) * post1, (f12[hw + pix] * a1) * post1);
-        *reinterpret_cast<float2*>(out21 + o * 2) = make_float2((f21[pix] * a2) * post2, (f21[hw + pix] * a2) * post2);
+        // (x * a) * 0 is a zero for the finite rendered values: not loaded where the masks are 0
+        float2 r12 = make_float2(0.0f, 0.0f), r21 = make_float2(0.0f, 0.0f);
+        if (post1 != 0.0f && a1 != 0.0f) r12 = make_float2((f12[pix] * a1) * post1, (f12[hw + pix] * a1) * post1);
+        if (post2 != 0.0f && a2 != 0.0f) r21 = make_float2((f21[pix] * a2) * post2, (f21[hw + pix] * a2) * post2);
+        *reinterpret_cast<float2*>(out12 + o * 2) = r12;
+        *reinterpret_cast<float2*>(out21 + o * 2) = r21;
     }
 }
 
@@ -545,10 +552,13 @@ struct DirRaw {
     float jd;
 };
 
-__device__ __forceinline__ DirTaps pair_taps(const float* __restrict__ flow, int b, int xx, int yy, int H, int W) {
-    const int64_t hw = (int64_t)H * W;
+__device__ __forceinline__ float2 pair_flow(const float* __restrict__ flow, int b, int xx, int yy, int H, int W) {
+    return *reinterpret_cast<const float2*>(flow + ((int64_t)b * H * W + (int64_t)yy * W + xx) * 2);
+}
+
+__device__ __forceinline__ DirTaps pair_taps(float2 uv, int xx, int yy, int H, int W) {
     DirTaps d;
-    d.uv = *reinterpret_cast<const float2*>(flow + ((int64_t)b * hw + (int64_t)yy * W + xx) * 2);
+    d.uv = uv;
     float ix, iy;
     sample_pos((float)xx, (float)yy, d.uv.x, d.uv.y, W, H, ix, iy);
     d.t = make_taps(ix, iy);
@@ -649,15 +659,24 @@ __global__ void __launch_bounds__(256, 6) pair_consist_forward_kernel(PairParams
         const bool allj = p.warp_mask1 != nullptr || p.warp_mask2 != nullptr;
         // forward term: image_ref warped by flow21 vs image (imgflowarp.py:80,85-87,93-102)
         // backward term: image warped by flow12 vs image_ref (:84,82,88,99-107)
-        const DirTaps t1 = pair_taps(p.flow21, b, xx, yy, p.H, p.W);
-        const DirTaps t2 = pair_taps(p.flow12, b, xx, yy, p.H, p.W);
-        DirRaw2 q1, q2;
-        pair_load(t1, p.image_ref, p.image, p.jitter, p.jitter, p.Cj, allj, b, pix, hw, q1);
-        pair_load(t2, p.image, p.image_ref, p.jitter_ref, p.jitter_ref, p.Cj, allj, b, pix, hw, q2);
+        const float2 uv1 = pair_flow(p.flow21, b, xx, yy, p.H, p.W), uv2 = pair_flow(p.flow12, b, xx, yy, p.H, p.W);
+        // A pixel whose flow has a zero x component is invalid whatever the images hold (imgflowarp.py:93-100,
+        // SURVEY Q5) and adds nothing to the masked sums: unless the per-pixel outputs (warps, differences,
+        // warp masks) are requested, neither its taps are computed nor its 26 tap loads issued -- a rendered flow is
+        // exactly 0 outside the meshes, 90 % of a hand + object frame.
+        const bool per_pixel_out = p.warp1 || p.warp2 || p.diff1 || p.diff2 || p.warp_mask1 || p.warp_mask2;
+        const bool need1 = per_pixel_out || uv1.x != 0.0f, need2 = per_pixel_out || uv2.x != 0.0f;
+        DirTaps t1{}, t2{};
+        if (need1) t1 = pair_taps(uv1, xx, yy, p.H, p.W);
+        if (need2) t2 = pair_taps(uv2, xx, yy, p.H, p.W);
+        DirRaw2 q1{}, q2{};
+        if (need1) pair_load(t1, p.image_ref, p.image, p.jitter, p.jitter, p.Cj, allj, b, pix, hw, q1);
+        if (need2) pair_load(t2, p.image, p.image_ref, p.jitter_ref, p.jitter_ref, p.Cj, allj, b, pix, hw, q2);
         pin(q1); pin(q2);
         const DirRaw r1 = unpack(q1, t1.a), r2 = unpack(q2, t2.a);
-        const DirOut d1 = pair_eval(t1, r1, p.H, p.W, p.thresh, allj && p.Cj == 3);
-        const DirOut d2 = pair_eval(t2, r2, p.H, p.W, p.thresh, allj && p.Cj == 3);
+        DirOut d1{}, d2{};
+        if (need1) d1 = pair_eval(t1, r1, p.H, p.W, p.thresh, allj && p.Cj == 3);
+        if (need2) d2 = pair_eval(t2, r2, p.H, p.W, p.thresh, allj && p.Cj == 3);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int64_t o = ((int64_t)b * 3 + c) * hw + pix;
@@ -755,21 +774,30 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
     const float coef1 = p.grad_loss_fwd[b] / ((c1 == 0.0f) ? 1.0f : c1);
     const float coef2 = p.grad_loss_bwd ? p.grad_loss_bwd[b] / ((c2 == 0.0f) ? 1.0f : c2) : 0.0f;
     const bool both = p.grad_loss_bwd != nullptr;
-    const DirTaps t1 = pair_taps(p.flow21, b, xx, yy, p.H, p.W);
-    const DirTaps t2 = pair_taps(both ? p.flow12 : p.flow21, b, xx, yy, p.H, p.W);
-    DirRaw2 q1, q2;
-    pair_load(t1, p.image_ref, p.image, p.jitter, p.jitter, p.Cj, false, b, pix, hw, q1);
-    if (both) pair_load(t2, p.image, p.image_ref, p.jitter_ref, p.jitter_ref, p.Cj, false, b, pix, hw, q2);
-    else q2 = q1;
+    const float2 uv1 = pair_flow(p.flow21, b, xx, yy, p.H, p.W);
+    const float2 uv2 = pair_flow(both ? p.flow12 : p.flow21, b, xx, yy, p.H, p.W);
+    // the gradient of an invalid pixel is 0: no taps, no tap loads where the flow's x component is zero (see the
+    // forward kernel)
+    const bool need1 = uv1.x != 0.0f && coef1 != 0.0f, need2 = both && uv2.x != 0.0f && coef2 != 0.0f;
+    DirTaps t1{}, t2{};
+    if (need1) t1 = pair_taps(uv1, xx, yy, p.H, p.W);
+    if (need2) t2 = pair_taps(uv2, xx, yy, p.H, p.W);
+    DirRaw2 q1{}, q2{};
+    if (need1) pair_load(t1, p.image_ref, p.image, p.jitter, p.jitter, p.Cj, false, b, pix, hw, q1);
+    if (need2) pair_load(t2, p.image, p.image_ref, p.jitter_ref, p.jitter_ref, p.Cj, false, b, pix, hw, q2);
     pin(q1); pin(q2);
-    const DirRaw r1 = unpack(q1, t1.a), r2 = unpack(q2, t2.a);
-    const DirOut d1 = pair_eval(t1, r1, p.H, p.W, p.thresh, false);
-    *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = pair_grad(t1, r1, d1, p.H, p.W, coef1);
-    float2 g12 = make_float2(0.0f, 0.0f);
-    if (both) {
+    float2 g21 = make_float2(0.0f, 0.0f), g12 = make_float2(0.0f, 0.0f);
+    if (need1) {
+        const DirRaw r1 = unpack(q1, t1.a);
+        const DirOut d1 = pair_eval(t1, r1, p.H, p.W, p.thresh, false);
+        g21 = pair_grad(t1, r1, d1, p.H, p.W, coef1);
+    }
+    if (need2) {
+        const DirRaw r2 = unpack(q2, t2.a);
         const DirOut d2 = pair_eval(t2, r2, p.H, p.W, p.thresh, false);
         g12 = pair_grad(t2, r2, d2, p.H, p.W, coef2);
     }
+    *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = g21;
     *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = g12;
 }
 
