@@ -368,6 +368,24 @@ class _MeshRegPostFunction(torch.autograd.Function):
         return outs[0], outs[1], outs[2], outs[3], None, None, None, None, None
 
 
+def cat_or_view(tensors):
+    """``torch.cat(tensors)`` along dim 0 -- without the copy when the tensors already ARE consecutive slices of one
+    contiguous buffer (the frames of a step as `mr_frames_to_batch` or the synthetic loader lay them out: the
+    150 MB image concatenation of a B = 64 step then costs nothing)."""
+    first = tensors[0]
+    if all(t.is_contiguous() and t.dtype == first.dtype and t.device == first.device and t.shape[1:] == first.shape[1:]
+           for t in tensors):
+        base = first.untyped_storage().data_ptr()
+        end, ok = first.data_ptr(), True
+        for t in tensors:
+            ok = ok and t.untyped_storage().data_ptr() == base and t.data_ptr() == end
+            end += t.numel() * t.element_size()
+        if ok:
+            rows = sum(t.shape[0] for t in tensors)
+            return first.as_strided((rows,) + tuple(first.shape[1:]), first.stride(), first.storage_offset())
+    return torch.cat(tensors)
+
+
 class SynthMeshRegNet(nn.Module):
     """MeshRegNet (meshregnet.py:54-384) with the trainmeshwarp.py default loss weights.
 
@@ -411,7 +429,7 @@ class SynthMeshRegNet(nn.Module):
         if self.base_net.training:
             raise RuntimeError("encode_frames needs frozen BatchNorm statistics (model.eval())")
         sizes = [s["image"].shape[0] for s in samples]
-        feats = self.encode(torch.cat([s["image"] for s in samples]))
+        feats = self.encode(cat_or_view([s["image"] for s in samples]))
         for s, f in zip(samples, feats.split(sizes)):
             s["_features"] = f
 
@@ -462,7 +480,7 @@ class SynthMeshRegNet(nn.Module):
             if self.base_net.training:
                 raise RuntimeError("a single encoder pass needs frozen BatchNorm statistics (model.eval())")
             sizes_img = [s["image"].shape[0] for s in samples]
-            feats = list(self.encode(torch.cat([s["image"] for s in samples])).split(sizes_img))
+            feats = list(self.encode(cat_or_view([s["image"] for s in samples])).split(sizes_img))
         else:
             feats = [self.encode(s["image"]) for s in samples]
         sizes = [f.shape[0] for f in feats]

@@ -5,6 +5,7 @@ out of scope).  Loss is accumulated over ``loader_nb`` consecutive batches, then
 """
 import os
 
+import numpy as np
 import torch
 
 from handobjectconsist_amd.utils import synth
@@ -115,9 +116,15 @@ class SyntheticConsistLoader:
             # longer side, the images are its top rows (the render is cropped to the top-left H x W)
             im_ref, im, jm_ref, jm = synth.random_images(batch_size, image_height or image_size, image_size, seed * 1000 + k)
             canverts = t(ov[None].repeat(batch_size, 0).copy())
+            # the three frames of a step in ONE buffer, in the order the step consumes them (data frame, unannotated
+            # frame, annotated reference), as a GPU-side frame pipeline (mr_frames_to_batch) lays them out: the
+            # encoder's single pass over the step's frames then needs no concatenation copy
+            frames = t(np.concatenate([im_ref, im, im_ref]))
+            step_images = {"data": frames[:batch_size], "unannotated": frames[batch_size:2 * batch_size],
+                           "reference": frames[2 * batch_size:]}
 
             def sample(img, jmask, hand, obj, K, supervised):
-                d = {"image": t(img), "jittermask": t(jmask), "camintr": t(K), "objcanverts": canverts,
+                d = {"image": img if torch.is_tensor(img) else t(img), "jittermask": t(jmask), "camintr": t(K), "objcanverts": canverts,
                      "objfaces": t(s["obj_faces"][None].repeat(batch_size, 0).copy()),
                      # geometry of the frame, NOT read by the model (kernel-only benchmarks use it)
                      "_handverts3d": t(hand), "_objverts3d": t(obj)}
@@ -126,10 +133,10 @@ class SyntheticConsistLoader:
                               "joints3d": t(hand[:, :21].copy())})
                 return d
 
-            data = {"data": [sample(im_ref, jm_ref, s["hand_verts2"], s["obj_verts2"], s["K2"], True)],
+            data = {"data": [sample(step_images["data"], jm_ref, s["hand_verts2"], s["obj_verts2"], s["K2"], True)],
                     "supervision": "data"}
-            consist = {"data": [sample(im, jm, s["hand_verts1"], s["obj_verts1"], s["K1"], False),
-                                sample(im_ref, jm_ref, s["hand_verts2"], s["obj_verts2"], s["K2"], True)],
+            consist = {"data": [sample(step_images["unannotated"], jm, s["hand_verts1"], s["obj_verts1"], s["K1"], False),
+                                sample(step_images["reference"], jm_ref, s["hand_verts2"], s["obj_verts2"], s["K2"], True)],
                        "supervision": "consist"}
             self.batches.append((data, consist))
 

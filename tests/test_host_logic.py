@@ -253,3 +253,27 @@ def test_train_step_nan_guard_keeps_parameters_and_optimizer_state_clean(fused):
     with pytest.raises(ValueError, match="nan"):
         E.epoch_pass([batch], net2, net2_opt, loader_nb=1)
     assert torch.equal(net2.w.detach(), torch.ones(3))
+
+
+def test_cat_or_view_returns_a_view_only_for_consecutive_slices():
+    from handobjectconsist_amd.models.synthnet import cat_or_view
+
+    buf = torch.arange(48.0).reshape(6, 2, 4)
+    a, b, c = buf[:2], buf[2:4], buf[4:]
+    v = cat_or_view([a, b, c])
+    assert v.data_ptr() == buf.data_ptr() and torch.equal(v, buf)
+    v = cat_or_view([b, c])
+    assert v.data_ptr() == b.data_ptr() and torch.equal(v, buf[2:])
+    for parts in ([a, c], [b, a], [a, b.clone()], [a, b.double()], [a, buf[2:4, :1]]):
+        if parts[1].dtype == a.dtype and parts[1].shape[1:] == a.shape[1:]:
+            assert torch.equal(cat_or_view(parts), torch.cat(parts))
+            assert cat_or_view(parts).data_ptr() != a.data_ptr() or parts[0] is not a
+    # the synthetic loader lays the frames of a step out that way
+    from handobjectconsist_amd.netscripts.epochpassconsist import SyntheticConsistLoader
+
+    loader = SyntheticConsistLoader(2, 32, seed=0, device="cpu", pool=1)
+    data, consist = loader.step_batches(0)
+    frames = [data["data"][0]["image"], consist["data"][0]["image"], consist["data"][1]["image"]]
+    v = cat_or_view(frames)
+    assert v.shape[0] == 6 and v.data_ptr() == frames[0].data_ptr() and torch.equal(v, torch.cat(frames))
+    assert torch.equal(frames[0], frames[2])  # the data frame and the annotated reference are the same image
