@@ -189,7 +189,7 @@ def kernel_bench(dev, B, is_, iters, only=None):
     def render_flow_fwd_pair():  # the training path's output set: rgb planes 0 / 1, alpha, flow mask, face index
         _lib.call("mr_render_flow_forward", P(pv), P(pf), P(pcols), P(bg), 0, P(keep_lut), int(keep_lut.numel()), 0.99999,
                   P(prgb), P(palpha), P(pmask), P(pdepth), P(pwmap), P(pfim), P(ptile_hit), P(pwork), pwbytes, B2, pv.shape[1], F0, 1, is_, 0.1, 100.0, 1e-3,
-                  0, st)
+                  _lib.FLAG_SPARSE_TILES, st)
 
     def render_vc_bwd_pair_recompute():  # ... and its backward: no weight / depth maps to read back
         _lib.call("mr_render_vc_backward", P(pv), P(pf), P(pfim), None, None, P(pg_rgb), P(pg_cols), B2, pv.shape[1], F0, 1,
@@ -214,7 +214,8 @@ def kernel_bench(dev, B, is_, iters, only=None):
 
     def occlusion_flow():  # occlusion check + flow epilogue of both directions (what the training step launches)
         _lib.call("mr_occlusion_flow", P(pmask[:B]), P(palpha[B:]), P(prgb[:B]), P(prgb[B:]), 3 * is_ * is_, P(pmask[:B]),
-                  P(pmask[B:]), P(pocc[:B]), P(pocc[B:]), P(pflows[:B]), P(pflows[B:]), B, is_, is_, is_, is_, 0.03, 0.99999, st)
+                  P(pmask[B:]), P(pocc[:B]), P(pocc[B:]), P(pflows[:B]), P(pflows[B:]), P(ptile_hit[:B]), P(ptile_hit[B:]), B, is_,
+                  is_, is_, is_, 0.03, 0.99999, st)
 
     occlusion_flow()
     flow12, flow21 = pflows[:B], pflows[B:]

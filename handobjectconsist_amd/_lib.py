@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmeshraster_hip.so")
 ABI_VERSION = 1
 FLAG_REFERENCE_ALGO = 1
+FLAG_SPARSE_TILES = 2
 
 _c = ctypes
 _P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
@@ -44,7 +45,7 @@ SIGNATURES = {
     "mr_warp_forward": (_I, [_P] * 4 + [_I, _I, _I, _I, _F, _I, _P]),
     "mr_warp_backward": (_I, [_P] * 5 + [_I, _I, _I, _I, _F, _I, _P]),
     "mr_occlusion_mask": (_I, [_P] * 4 + [_L, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
-    "mr_occlusion_flow": (_I, [_P] * 4 + [_L] + [_P] * 6 + [_I, _I, _I, _I, _I, _F, _F, _P]),
+    "mr_occlusion_flow": (_I, [_P] * 4 + [_L] + [_P] * 8 + [_I, _I, _I, _I, _I, _F, _F, _P]),
     "mr_flow_mask": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _P]),
     "mr_flow_finalize_forward": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
     "mr_flow_finalize_backward": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),

@@ -740,9 +740,6 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
     const float* verts_b = p.verts + (int64_t)b * p.V * 3;
     const int32_t* fidx_b = p.fidx + (int64_t)b * p.F0 * 3;
 
-    const int n2 = (p.V * 3 + 1) >> 1;
-    for (int k = threadIdx.x; k < n2; k += blockDim.x) reinterpret_cast<int4*>(vtab)[k] = make_int4(0, 0, 0, 0);
-
     // the list of covered tiles (block-wide compaction of the coverage bytes); the 16 waves that share an image
     // then take them round-robin: every wave gets its share whatever part of the screen the mesh sits in
     int n_hits = 0;
@@ -758,6 +755,10 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
         for (int w = 0; w < ST_WAVES; w++) n_hits += wcnt[w];
         __syncthreads();
     }
+
+    if (part * ST_WAVES >= n_hits) return;  // fewer covered tiles than waves before this workgroup: nothing to do
+    const int n2 = (p.V * 3 + 1) >> 1;
+    for (int k = threadIdx.x; k < n2; k += blockDim.x) reinterpret_cast<int4*>(vtab)[k] = make_int4(0, 0, 0, 0);
 
     // pass 1: largest |gradient| over the workgroup's covered tiles, as float bits
     unsigned mx = 0u;

@@ -276,6 +276,7 @@ struct FwdParams {
     float alpha_thresh;
     int rgb_channels;      // 3, or 2: the third colour plane is left untouched
     uint8_t* tile_hit;     // nullable: [B, tiles, 4] 1 = wave w (rows 2w, 2w + 1) of the tile covers a pixel
+    int sparse_tiles;      // tiles without candidate faces write their coverage bytes (0) and NOTHING else
     int sparse_wd;         // weight / depth are written at covered pixels only (their only reader, the colour
                            // backward, looks at nothing else)
     float* face_inv_map;   // [B,is,is,9] raster orientation (nullable)
@@ -369,6 +370,10 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
         n_rec = n_bin + p.hdrs[b].n_large;
         if (p.dbg & 1) n_rec = 0;
         if (n_rec == 0 && (p.dbg & 256)) return;
+        if (FUSED && n_rec == 0 && p.sparse_tiles) {
+            if (tid == 0) reinterpret_cast<uint32_t*>(p.tile_hit)[(int64_t)b * tiles_per_img + t] = 0u;
+            return;
+        }
         if (FUSED && n_rec == 0 && (is & 3) == 0 && tx0 + TILE_W <= is && ty0 + TILE_H <= is && !p.face_inv_map) {
             // one 128-B row segment = 8 float4 (scalar planes) / 24 float4 (weight_map, 3 floats per pixel)
             const int64_t plane = (int64_t)is * is;
@@ -1076,6 +1081,8 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
     p.rgb = rgb_img; p.rgb_channels = 2;
     p.alpha = alpha_img; p.mask = mask_img;
     p.depth = depth_img; p.weight = weight_map; p.sparse_wd = 1; p.tile_hit = tile_hit;
+    p.sparse_tiles = (flags & MR_FLAG_SPARSE_TILES) ? 1 : 0;
+    if (p.sparse_tiles && !tile_hit) return MR_ERR_BADARG;
     p.keep_lut = keep_lut; p.n_lut = n_lut; p.alpha_thresh = alpha_thresh;
     p.fim = face_index_map;
     p.B = batch_size; p.F = F; p.is = image_size; p.ts = 2;

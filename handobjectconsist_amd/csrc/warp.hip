@@ -321,12 +321,24 @@ __global__ void __launch_bounds__(256) warp_backward_kernel(const float* __restr
 //   warp_ab(q)  = nearest(grid_a; q + flow_ba(q)) * mask_b(q)            (imgflowarp.py:132,134)
 //   warp_aba(p) = nearest(warp_ab; p + flow_ab(p)) * mask_a(p)           (:136,138)
 //   occl_a = occlusion_mask_from_warped_grid(grid_a, warp_aba)           (:145)
+// Coverage bytes of mr_render_flow_forward ([tiles_y, tiles_x, 4], RASTER orientation, one byte per 32 x 8 tile and row
+// pair; the planes read here are in IMAGE orientation): 0 = nothing covered there -- with MR_FLAG_SPARSE_TILES the
+// render did not even write those pixels, so every read of a rendered plane is guarded by this test.
+__device__ __forceinline__ bool tile_covered(const uint8_t* __restrict__ hit, int tiles_x, int H, int x, int y) {
+    if (!hit) return true;
+    const int ry = H - 1 - y;
+    return hit[((ry >> 3) * tiles_x + (x >> 5)) * 4 + ((ry & 7) >> 1)] != 0;
+}
+
 __device__ __forceinline__ float occl_one(const float* __restrict__ mask_a, const float* __restrict__ mask_b,
                                           const float* __restrict__ flow_ab,
                                           const float* __restrict__ flow_ba, const float* __restrict__ scale_ab,
                                           const float* __restrict__ scale_ba, int64_t hw, int H, int W,
-                                          int xx, int yy, float dist_thresh, float wthresh) {
+                                          int xx, int yy, float dist_thresh, float wthresh,
+                                          const uint8_t* __restrict__ hit_a = nullptr,
+                                          const uint8_t* __restrict__ hit_b = nullptr, int tiles_x = 0) {
     const int64_t pix = (int64_t)yy * W + xx;
+    if (!tile_covered(hit_a, tiles_x, H, xx, yy)) return 0.0f;
     const float ma_p = mask_a[pix];
     // The result is mask_a(p) * (...) * motion with finite factors (masks are 0 / 1 or a rendered alpha): a pixel
     // outside its own mask -- 90 % of a hand + object frame -- is 0 without any of the dependent gathers below.
@@ -343,6 +355,8 @@ __device__ __forceinline__ float occl_one(const float* __restrict__ mask_a, cons
     if (m2 < wthresh) m2 = 0.0f;
     if (m2 > 0.0f) {
         const int64_t qpix = (int64_t)qy * W + qx;
+        // nothing rendered around q: mask_b(q) = 0 zeroes the warped grid, hence the result
+        if (!tile_covered(hit_b, tiles_x, H, qx, qy)) return 0.0f;
         // first warp: sample grid_a at q + flow_ba(q)
         float jx, jy;
         const float sb = scale_ba ? scale_ba[qpix] : 1.0f;
@@ -354,7 +368,7 @@ __device__ __forceinline__ float occl_one(const float* __restrict__ mask_a, cons
         if (m1 < wthresh) m1 = 0.0f;
         if (m1 > 0.0f) {
             const float mb_q = mask_b[qpix];
-            const float ma_r = mask_a[(int64_t)ry * W + rx];
+            const float ma_r = tile_covered(hit_a, tiles_x, H, rx, ry) ? mask_a[(int64_t)ry * W + rx] : 0.0f;
             wg[0] = ((float)rx / (float)W) * m1 * mb_q;
             wg[1] = ((float)ry / (float)H) * m1 * mb_q;
             wg[2] = ma_r * m1 * mb_q;
@@ -407,7 +421,10 @@ __global__ void __launch_bounds__(256) occlusion_flow_kernel(const float* __rest
                                                              float* __restrict__ occl1, float* __restrict__ occl2,
                                                              float* __restrict__ out12, float* __restrict__ out21,
                                                              int B, int H, int W, int crop_h, int crop_w,
-                                                             float dist_thresh, float wthresh) {
+                                                             float dist_thresh, float wthresh,
+                                                             const uint8_t* __restrict__ hit1,
+                                                             const uint8_t* __restrict__ hit2, int tiles_x,
+                                                             int tiles_y) {
     const int64_t hw = (int64_t)H * W;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * hw) return;
@@ -420,14 +437,18 @@ __global__ void __launch_bounds__(256) occlusion_flow_kernel(const float* __rest
     const float* f21 = flow21 + (int64_t)b * fbstride;
     const float* s12 = scale12 ? scale12 + (int64_t)b * hw : nullptr;
     const float* s21 = scale21 ? scale21 + (int64_t)b * hw : nullptr;
-    const float o1 = occl_one(m1, m2, f12, f21, s12, s21, hw, H, W, xx, yy, dist_thresh, wthresh);
-    const float o2 = occl_one(m2, m1, f21, f12, s21, s12, hw, H, W, xx, yy, dist_thresh, wthresh);
+    const uint8_t* h1 = hit1 ? hit1 + (int64_t)b * tiles_x * tiles_y * 4 : nullptr;
+    const uint8_t* h2 = hit2 ? hit2 + (int64_t)b * tiles_x * tiles_y * 4 : nullptr;
+    const float o1 = occl_one(m1, m2, f12, f21, s12, s21, hw, H, W, xx, yy, dist_thresh, wthresh, h1, h2, tiles_x);
+    const float o2 = occl_one(m2, m1, f21, f12, s21, s12, hw, H, W, xx, yy, dist_thresh, wthresh, h2, h1, tiles_x);
     occl1[i] = o1;
     occl2[i] = o2;
     if (yy < crop_h && xx < crop_w) {
         const int64_t o = ((int64_t)b * crop_h + yy) * crop_w + xx;
-        const float a1 = s12 ? s12[pix] : 1.0f, a2 = s21 ? s21[pix] : 1.0f;
-        const float post1 = m1[pix] * o1, post2 = m2[pix] * o2;
+        // (an occlusion bit can only be non-zero at a pixel inside its own image's coverage: the guarded reads of
+        // occl_one came first)
+        const float a1 = (o1 != 0.0f && s12) ? s12[pix] : 1.0f, a2 = (o2 != 0.0f && s21) ? s21[pix] : 1.0f;
+        const float post1 = o1 != 0.0f ? m1[pix] * o1 : 0.0f, post2 = o2 != 0.0f ? m2[pix] * o2 : 0.0f;
         // (x * a) * 0 is a zero for the finite rendered values: not loaded where the masks are 0
         float2 r12 = make_float2(0.0f, 0.0f), r21 = make_float2(0.0f, 0.0f);
         if (post1 != 0.0f && a1 != 0.0f) r12 = make_float2((f12[pix] * a1) * post1, (f12[hw + pix] * a1) * post1);
@@ -854,17 +875,20 @@ extern "C" int mr_occlusion_mask(const float* mask_flow1, const float* mask_flow
 extern "C" int mr_occlusion_flow(const float* mask_flow1, const float* mask_flow2, const float* flow12,
                                  const float* flow21, int64_t flow_bstride, const float* flow12_scale,
                                  const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
-                                 float* flow_out21, int batch_size, int height, int width, int crop_height,
-                                 int crop_width, float distance_thresh, float warp_thresh, mr_stream_t stream) {
+                                 float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2, int batch_size,
+                                 int height, int width, int crop_height, int crop_width, float distance_thresh,
+                                 float warp_thresh, mr_stream_t stream) {
     if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2 || !flow_out12 || !flow_out21)
         return MR_ERR_BADARG;
+    if ((tile_hit1 == nullptr) != (tile_hit2 == nullptr) || (tile_hit1 && height != width)) return MR_ERR_BADARG;
     if (batch_size < 0 || height <= 0 || width <= 0 || flow_bstride < 2LL * height * width) return MR_ERR_BADARG;
     if (crop_height <= 0 || crop_width <= 0 || crop_height > height || crop_width > width) return MR_ERR_BADARG;
     const int64_t n = (int64_t)batch_size * height * width;
     if (n == 0) return MR_OK;
     hipLaunchKernelGGL(occlusion_flow_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, mask_flow1,
                        mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2, flow_out12,
-                       flow_out21, batch_size, height, width, crop_height, crop_width, distance_thresh, warp_thresh);
+                       flow_out21, batch_size, height, width, crop_height, crop_width, distance_thresh, warp_thresh,
+                       tile_hit1, tile_hit2, (width + 31) / 32, (height + 7) / 8);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

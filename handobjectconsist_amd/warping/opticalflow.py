@@ -79,6 +79,12 @@ USE_FLOW_RENDER = True
 # ... as one autograd node with a single fused backward launch (_StackedFlowFunction).  False: render, epilogue and
 # their backward passes as separate nodes / launches (same values).
 USE_STACKED_FLOW_NODE = True
+# ... and let the render skip the tiles of the screen that hold no candidate face entirely (MR_FLAG_SPARSE_TILES): the
+# occlusion / epilogue pass and the backward consult the render's coverage bytes before every read of a rendered plane.
+USE_SPARSE_TILES = True
+# tests: allocate the render's output planes filled with NaN / INT_MIN instead of uninitialised, so that any read of a
+# pixel the sparse render did not write shows up in the flows or the gradients
+DEBUG_POISON_RENDER_OUTPUTS = False
 
 
 class _FlowVertexStage(torch.autograd.Function):
@@ -288,10 +294,16 @@ class _StackedFlowFunction(torch.autograd.Function):
         B, F0, is_ = B2 // 2, fidx.shape[1], int(image_size)
         f32 = dict(dtype=torch.float32, device=dev)
         bg, bg_stride = rasterize._background_tensor(background_color, dev, B2)
-        rgb = torch.empty((B2, 3, is_, is_), **f32)
-        alpha, mask, depth = torch.empty((B2, is_, is_), **f32), torch.empty((B2, is_, is_), **f32), torch.empty((B2, is_, is_), **f32)
-        wmap = torch.empty((B2, is_, is_, 3), **f32)
-        fim = torch.empty((B2, is_, is_), dtype=torch.int32, device=dev)
+        if DEBUG_POISON_RENDER_OUTPUTS:
+            new_f = lambda *shape: torch.full(shape, float("nan"), **f32)
+            new_i = lambda *shape: torch.full(shape, -2 ** 31, dtype=torch.int32, device=dev)
+        else:
+            new_f = lambda *shape: torch.empty(shape, **f32)
+            new_i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+        rgb = new_f(B2, 3, is_, is_)
+        alpha, mask, depth = new_f(B2, is_, is_), new_f(B2, is_, is_), new_f(B2, is_, is_)
+        wmap = new_f(B2, is_, is_, 3)
+        fim = new_i(B2, is_, is_)
         tile_hit = torch.empty((B2, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=dev)
         F = 2 * F0 if fill_back else F0
         wbytes = int(_lib.load().mr_render_workspace_bytes(B2, F, is_))
@@ -300,14 +312,16 @@ class _StackedFlowFunction(torch.autograd.Function):
         _lib.call("mr_render_flow_forward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(c), _lib.ptr(bg), bg_stride,
                   _lib.ptr(lut), int(lut.numel()) if lut is not None else 0, 0.99999, _lib.ptr(rgb), _lib.ptr(alpha),
                   _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(wmap), _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(work), wbytes,
-                  B2, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps), 0, st)
+                  B2, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps),
+                  _lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0, st)
         occl = torch.empty((B2, is_, is_), **f32)
         flow = torch.empty((B2, height, width, 2), **f32)
         # occlusion check + crop / permute / mask products of both directions in one pass.  mask_flow2 is the RAW
         # alpha inside the occlusion block and afterwards (Q4); the masked flows rgb * mask are formed on the fly
         _lib.call("mr_occlusion_flow", _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(rgb[:B]), _lib.ptr(rgb[B:]),
                   3 * is_ * is_, _lib.ptr(mask[:B]), _lib.ptr(mask[B:]), _lib.ptr(occl[:B]), _lib.ptr(occl[B:]),
-                  _lib.ptr(flow[:B]), _lib.ptr(flow[B:]), B, is_, is_, height, width, 0.03, 0.99999, st)
+                  _lib.ptr(flow[:B]), _lib.ptr(flow[B:]), _lib.ptr(tile_hit[:B]), _lib.ptr(tile_hit[B:]), B, is_, is_, height,
+                  width, 0.03, 0.99999, st)
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width)
         ctx.save_for_backward(verts, fidx, fim, tile_hit, wmap, depth, mask, alpha, occl)
         return flow

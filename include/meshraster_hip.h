@@ -37,6 +37,10 @@ extern "C" {
  * algorithm (every pixel loops over every face / per-pixel global atomics) instead of the
  * tiled one.  Validation and A/B profiling only. */
 #define MR_FLAG_REFERENCE_ALGO 1
+/* mr_render_flow_forward: tiles of the screen without any candidate face write their coverage bytes (0) and
+ * NOTHING else -- the image planes and face_index_map keep whatever they held there.  For callers that consult
+ * tile_hit before every read of a rendered plane (mr_occlusion_flow and mr_render_flow_backward do). */
+#define MR_FLAG_SPARSE_TILES 2
 
 #if defined(__GNUC__)
 #define MR_API __attribute__((visibility("default")))
@@ -194,7 +198,7 @@ MR_API int mr_render_vc_backward(const float* verts, const int32_t* faces_idx,
  * written at COVERED pixels only -- the loss never reads them and their one reader, mr_render_vc_backward, looks
  * at covered pixels only; everywhere else the buffers keep whatever they held.  tile_hit (nullable): 4 bytes per
  * 32x8 screen tile, [B, ceil(is / 8), ceil(is / 32), 4]; byte w is 1 when rows 2w, 2w + 1 of the tile hold a covered
- * pixel -- what mr_render_flow_backward skips empty tiles on. */
+ * pixel -- what mr_render_flow_backward skips empty tiles on.  flags: MR_FLAG_SPARSE_TILES (requires tile_hit). */
 MR_API int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
                                   const float* background, int bg_stride, const float* keep_lut, int n_lut,
                                   float alpha_thresh, float* rgb_img, float* alpha_img, float* mask_img,
@@ -335,12 +339,16 @@ MR_API int mr_occlusion_mask(const float* mask_flow1, const float* mask_flow2, c
 /* mr_occlusion_mask followed by the flow epilogue of opticalflow.py:146-154 for both directions, in one pass:
  *   flow_out12[b, y, x, c] = (flow12[b, c, y, x] * flow12_scale) * (mask_flow1 * occl1),  c = 0, 1, y < crop_height,
  *   x < crop_width  ([B, crop_height, crop_width, 2]); likewise flow_out21 with mask_flow2 / occl2.
- * (= mr_flow_finalize_forward with mask_pre = the scale and mask_x = the mask the occlusion check used.) */
+ * (= mr_flow_finalize_forward with mask_pre = the scale and mask_x = the mask the occlusion check used.)
+ * tile_hit1 / tile_hit2 (both or neither; square rasters): the coverage bytes mr_render_flow_forward wrote for the
+ * images behind (mask_flow1, flow12) and (mask_flow2, flow21); where a byte is 0 the planes are not read (they
+ * count as background), which is what allows the render to run with MR_FLAG_SPARSE_TILES. */
 MR_API int mr_occlusion_flow(const float* mask_flow1, const float* mask_flow2, const float* flow12,
                              const float* flow21, int64_t flow_bstride, const float* flow12_scale,
                              const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
-                             float* flow_out21, int batch_size, int height, int width, int crop_height,
-                             int crop_width, float distance_thresh, float warp_thresh, mr_stream_t stream);
+                             float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2, int batch_size,
+                             int height, int width, int crop_height, int crop_width, float distance_thresh,
+                             float warp_thresh, mr_stream_t stream);
 
 /* Flow epilogue of opticalflow.get_opticalflow (opticalflow.py:109-154), fused.
  * mr_flow_mask: mask[B,is,is] (IMAGE orientation) = (alpha_img > thresh) * keep, where keep

@@ -218,7 +218,8 @@ def _flow_check(got, want, key, max_support=4):
     return support
 
 
-@pytest.mark.parametrize("path", ["fused", "fused_separate_nodes", "fused_full_outputs", "vertex_color", "textures"])
+@pytest.mark.parametrize("path", ["fused", "fused_poisoned", "fused_dense_tiles", "fused_separate_nodes", "fused_full_outputs",
+                                  "vertex_color", "textures"])
 def test_get_opticalflow_against_reference_glue(cuda, path):
     """Flows and d(flows)/d(vertices of both frames) for every fixture variant (ignore list, crop,
     detach_textures, detach_renders=False, mask_occlusions=False), through the fused vertex stage +
@@ -228,11 +229,15 @@ def test_get_opticalflow_against_reference_glue(cuda, path):
 
     z, meta = load("chain_opticalflow.npz")
     saved = (opticalflow.USE_FUSED_VERTEX_STAGE, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_FLOW_RENDER,
-             opticalflow.USE_STACKED_FLOW_NODE)
+             opticalflow.USE_STACKED_FLOW_NODE, opticalflow.USE_SPARSE_TILES, opticalflow.DEBUG_POISON_RENDER_OUTPUTS)
     opticalflow.USE_FUSED_VERTEX_STAGE = path.startswith("fused")
     opticalflow.USE_VERTEX_COLOR_RENDER = path != "textures"
-    opticalflow.USE_FLOW_RENDER = path in ("fused", "fused_separate_nodes")  # flow-mode render (mask folded in)
-    opticalflow.USE_STACKED_FLOW_NODE = path == "fused"  # one autograd node, single fused backward launch
+    one_node = path in ("fused", "fused_poisoned", "fused_dense_tiles")
+    opticalflow.USE_FLOW_RENDER = one_node or path == "fused_separate_nodes"  # flow-mode render (mask folded in)
+    opticalflow.USE_STACKED_FLOW_NODE = one_node  # one autograd node, single fused backward launch
+    opticalflow.USE_SPARSE_TILES = path != "fused_dense_tiles"  # the render skips tiles without candidate faces
+    # pixels the sparse render leaves unwritten hold NaN / INT_MIN: nothing downstream may have read them
+    opticalflow.DEBUG_POISON_RENDER_OUTPUTS = path == "fused_poisoned"
     try:
         for m in meta:
             s, k, is_ = m["scene"], m["key"], m["image_size"]
@@ -263,7 +268,7 @@ def test_get_opticalflow_against_reference_glue(cuda, path):
                     assert l2_rel(got, want) < 5e-2, (path, k, name, l2_rel(got, want))
     finally:
         (opticalflow.USE_FUSED_VERTEX_STAGE, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_FLOW_RENDER,
-         opticalflow.USE_STACKED_FLOW_NODE) = saved
+         opticalflow.USE_STACKED_FLOW_NODE, opticalflow.USE_SPARSE_TILES, opticalflow.DEBUG_POISON_RENDER_OUTPUTS) = saved
 
 
 def test_flow_render_equals_full_render(cuda):

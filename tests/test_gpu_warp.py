@@ -472,7 +472,7 @@ def test_occlusion_flow_equals_occlusion_then_finalize(cuda, B, is_, H, W):
     _lib.call("mr_flow_finalize_forward", P(rgb1), P(m1), P(m1), P(o1), P(f12), B, is_, H, W, st)
     _lib.call("mr_flow_finalize_forward", P(rgb2), P(m2), P(alpha2), P(o2), P(f21), B, is_, H, W, st)
     _lib.call("mr_occlusion_flow", P(m1), P(alpha2), P(rgb1), P(rgb2), 3 * is_ * is_, P(m1), P(m2), P(o1f), P(o2f), P(g12),
-              P(g21), B, is_, is_, H, W, 0.03, 0.99999, st)
+              P(g21), None, None, B, is_, is_, H, W, 0.03, 0.99999, st)
     assert torch.equal(o1, o1f) and torch.equal(o2, o2f)
     assert torch.equal(f12, g12) and torch.equal(f21, g21)
     assert float(f12.abs().sum()) > 0 and float(f21.abs().sum()) > 0
