@@ -47,9 +47,13 @@ USE_CHANNELS_LAST = os.environ.get("HOC_CHANNELS_LAST", "1") == "1"
 
 
 def _fused_bn(bn, x):
-    # x is the convolution's input here; under bf16 autocast the convolution outputs (the BN inputs) are bf16,
-    # which the kernels take as well
-    return USE_HIP_BN and not bn.training and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+    """x is the convolution's INPUT; the kernels see its output (the BN input), whose dtype is the autocast dtype
+    when autocast is on and x's own otherwise.  fp32 and bf16 take the kernels, anything else (fp16 autocast, fp64)
+    the stock modules."""
+    if not (USE_HIP_BN and not bn.training and x.is_cuda):
+        return False
+    out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    return out_dtype in (torch.float32, torch.bfloat16)
 
 
 class BasicBlock(nn.Module):

@@ -2,10 +2,16 @@
 ``libyana.renderutils.textutils`` (third-party, called at
 /root/reference/meshreg/warping/opticalflow.py:103,123).
 
-Layout (ASSUMED -- the package is not available to check): texture size 2,
-zero everywhere except texel (1,0,0) = colour of vertex 0, (0,1,0) = vertex 1,
-(0,0,1) = vertex 2.  Kept as an explicit tensor input of the renderer so that a different
-upstream layout would only change this helper, never a kernel."""
+Layout (ASSUMED -- libyana v0.2.0 is not available to check, no golden vector of
+the real helper exists): texture size 2, zero everywhere except texel (1,0,0) = colour of
+vertex 0, (0,1,0) = vertex 1, (0,0,1) = vertex 2.
+
+The SAME assumption is baked into the fused vertex-colour kernels (``mr_render_vc_*``,
+``mr_render_flow_*``: csrc/raster_fwd.hip resolve step, csrc/raster_bwd.hip ``gather_vc_pixel`` and the scatter kernels), which
+never materialise this tensor.  If the real libyana layout turns out to differ, set
+``warping.opticalflow.USE_VERTEX_COLOR_RENDER = False`` (the flow render then goes through this
+helper and the generic texture kernels, which take any [B,F,2,2,2,3] tensor) and change this
+function; the vertex-colour kernels would need the matching texel -> vertex table."""
 import torch
 
 

@@ -97,6 +97,26 @@ def test_resnet_trunk_fused_equals_stock(cuda, monkeypatch):
         _close(out[True][1][n], gref, 2e-3, f"grad {n}")
 
 
+def test_resnet_trunk_fp16_autocast_takes_the_stock_modules(cuda, monkeypatch):
+    """The fused glue is gated on the dtype the convolutions will PRODUCE: under fp16 autocast (neither fp32 nor
+    bf16) the trunk must run on the stock modules instead of raising from the kernels' dtype check."""
+    from handobjectconsist_amd.models import synthnet
+    from handobjectconsist_amd import _lib
+
+    calls = []
+    real_call = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), real_call(name, *a))[1])
+    net = synthnet.ResNet18Features().to(cuda).eval()
+    x = torch.randn(2, 3, 64, 64, device=cuda)
+    with torch.autocast("cuda", dtype=torch.float16):
+        feats = net(x)
+    assert feats.shape == (2, 512) and torch.isfinite(feats.float()).all()
+    assert not any(k.startswith(("mr_bn_act", "mr_stem_pool")) for k in calls), calls
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        net(x)
+    assert "mr_stem_pool_forward" in calls and "mr_bn_act_forward" in calls, calls
+
+
 @pytest.mark.parametrize("shape", [(4, 8, 32, 32), (3, 5, 17, 31), (2, 3, 1, 1), (2, 4, 135, 240), (6, 64, 64, 66),
                                    (1, 2, 2, 3)])
 def test_stem_pool_matches_stock_modules(cuda, shape):
