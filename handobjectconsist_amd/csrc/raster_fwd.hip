@@ -60,8 +60,6 @@ constexpr int NB = 32;                // faces per batch (stage S1: one lane per
 constexpr int NBP2 = 32;              // next power of two
 constexpr int FC_STRIDE = 21;         // dwords per face-cache slot (odd: conflict-free ds_read_b32): v 9, inv 9, slot, box
 constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 4 * 64, power of 2)
-constexpr int SCAN_UNROLL = 3;        // independent record loads in flight per lane
-constexpr int QCAP = 256;             // wave-private ring capacity (>= NB - 1 + 64 * SCAN_UNROLL, power of 2)
 
 // Per-image header written by bin_faces_kernel.
 struct ImageHdr {
@@ -341,7 +339,6 @@ __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float 
 template <bool FUSED, bool VC>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))) raster_tile_kernel(FwdParams p) {
     __shared__ unsigned long long zbuf[TILE_W * TILE_H];
-    __shared__ int queue[TPB / MR_WAVE][QCAP];
     __shared__ float fcache[TPB / MR_WAVE][NB * FC_STRIDE];
     __shared__ unsigned short fragq[TPB / MR_WAVE][FQCAP];  // slot << 8 | row << 5 | x
     __shared__ float xp_tab[TILE_W], yp_tab[TILE_H];
@@ -416,12 +413,9 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
     const RecVerts* rv_b = p.rverts + (int64_t)b * p.F0;
     // record i of this tile: the bin's list first, then the image's large list
     auto rec_at = [&](int i) -> const FaceRec* { return recs_b + (i < n_bin ? off_bin : off_large) + i; };
-    int* q = queue[wave];
     float* fc = fcache[wave];
     unsigned short* fq = fragq[wave];
     int* ro = rowoff[wave];
-    int qhead = 0, qn = 0;  // wave-uniform ring state
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     // S3: one lane per fragment -- barycentrics, near/far, depth test
     int fqh = 0, fqn = 0;  // fragment ring (wave-uniform)
@@ -445,12 +439,11 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
         __builtin_amdgcn_wave_barrier();
     };
 
-    auto process_batch = [&](int count) {
-        // S1: one lane per face
+    auto process_batch = [&](int first, int count) {
+        // S1: one lane per record
         int nrows = 0;  // rows of the face's bbox inside this tile
         if (lane < count && !(p.dbg & 4)) {
-            const int ri = q[(qhead + lane) & (QCAP - 1)];
-            const FaceRec r = *rec_at(ri);
+            const FaceRec r = *rec_at(first + lane);
             const int fn = (int)r.z;
             Face f;
             load_face_coords<VC>(p, rv_b, b, fn, f.v);
@@ -462,7 +455,8 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
             const int y0 = max((int)(r.y & 0xffffu), ty0) - ty0, y1 = min((int)(r.y >> 16), ty1) - ty0;
             c[18] = __int_as_float(fn);
             c[19] = __int_as_float(x0 | (x1 << 8) | (y0 << 16) | (y1 << 24));
-            nrows = y1 - y0 + 1;
+            // (a record of the image's large list, or of a bin taller than a tile, may miss this tile)
+            nrows = (x0 <= x1 && y0 <= y1) ? y1 - y0 + 1 : 0;
         }
         // (face, bbox row) items of the batch, compacted: exclusive prefix sum of the row counts -> the
         // S2 lanes take consecutive items, so a pass works on 64 real rows whatever the face sizes
@@ -581,39 +575,13 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
         }
     };
 
-    // each wave scans a contiguous quarter of the image's record list
+    // Each wave takes a contiguous quarter of the tile's records, NB at a time.  There is no candidate scan: the
+    // records of a bin overlap the bin by construction (a bin IS a tile unless the image has more than MAX_BINS
+    // tiles), and the few that do not -- the image's large list, taller bins -- get an empty row range in S1.
     const int per_wave = (n_rec + 3) / 4;
     const int r_begin = wave * per_wave;
     const int r_end = min(r_begin + per_wave, n_rec);
-    for (int base = r_begin;; base += MR_WAVE * SCAN_UNROLL) {
-        const bool flush = base >= r_end;
-        if (!flush) {
-            FaceRec rr[SCAN_UNROLL];
-#pragma unroll
-            for (int j = 0; j < SCAN_UNROLL; j++) {
-                const int ri = base + j * MR_WAVE + lane;
-                rr[j] = *rec_at(min(ri, r_end - 1));
-            }
-#pragma unroll
-            for (int j = 0; j < SCAN_UNROLL; j++) {
-                const int ri = base + j * MR_WAVE + lane;
-                const int bx0 = (int)(rr[j].x & 0xffffu), bx1 = (int)(rr[j].x >> 16);
-                const int by0 = (int)(rr[j].y & 0xffffu), by1 = (int)(rr[j].y >> 16);
-                const bool hit = ri < r_end && bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
-                const unsigned long long m = __ballot(hit);
-                if (hit) q[(qhead + qn + __popcll(m & lt_mask)) & (QCAP - 1)] = ri;
-                qn += __popcll(m);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        while (qn >= (flush ? 1 : NB)) {
-            const int c = min(qn, NB);
-            process_batch(c);
-            qhead = (qhead + c) & (QCAP - 1);
-            qn -= c;
-        }
-        if (flush) break;
-    }
+    for (int base = r_begin; base < r_end; base += NB) process_batch(base, min(NB, r_end - base));
     const int lxr = tid & (TILE_W - 1), ly = tid >> 5;
     const int px = tx0 + lxr, py = ty0 + ly;
     if (p.keys && px < is && py < is) zbuf[tid] = p.keys[((int64_t)b * is + py) * is + px];
