@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libmeshraster_hip.so")
 # exactly like the CPU oracle (SURVEY 7 "bit-faithful coverage").
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# profiling builds only (e.g. HOC_HIPCC_FLAGS=-DMR_WG_TIMELINE for scripts/wg_timeline.py); part of the source hash
+HIPCC_FLAGS += os.environ.get("HOC_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

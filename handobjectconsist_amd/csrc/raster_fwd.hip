@@ -336,8 +336,17 @@ __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float 
 
 // FUSED = true : write every pixel of every requested plane (fused epilogue).
 // FUSED = false: upstream-compatible forward_face_index_map: touch hit pixels only.
+#ifdef MR_WG_TIMELINE
+// profiling builds (scripts/wg_timeline.py): per tile with geometry, start / end of its S1-S3 phase on the 100 MHz
+// wall clock, candidate count, the compute unit it ran on and its workgroup
+__device__ unsigned long long mr_dbg_times[65536 * 4];
+#endif
+
 template <bool FUSED, bool VC>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))) raster_tile_kernel(FwdParams p) {
+#ifdef MR_WG_TIMELINE
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     __shared__ unsigned long long zbuf[TILE_W * TILE_H];
     __shared__ float fcache[TPB / MR_WAVE][NB * FC_STRIDE];
     __shared__ unsigned short fragq[TPB / MR_WAVE][FQCAP];  // slot << 8 | row << 5 | x
@@ -403,6 +412,16 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
         }
     }
 
+#ifdef MR_WG_TIMELINE
+    if (threadIdx.x == 0 && lid < 65536u) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        mr_dbg_times[lid * 4 + 0] = dbg_t0;
+        mr_dbg_times[lid * 4 + 2] = ((unsigned long long)n_rec << 32) | (xcc << 24) | (hwid & 0xffffffu);
+        mr_dbg_times[lid * 4 + 3] = blockIdx.x;
+    }
+#endif
     zbuf[tid] = ~0ull;
     // NDC coordinates of the tile's pixel centres (upstream: (2 * i + 1 - is) / is)
     if (tid < TILE_W) xp_tab[tid] = (float)(2 * (tx0 + tid) + 1 - is) / fis;
@@ -587,6 +606,9 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
     if (p.keys && px < is && py < is) zbuf[tid] = p.keys[((int64_t)b * is + py) * is + px];
     __syncthreads();
 
+#ifdef MR_WG_TIMELINE
+    if (threadIdx.x == 0 && lid < 65536u) mr_dbg_times[lid * 4 + 1] = wall_clock64();
+#endif
     if (p.dbg & 2) return;
     // resolve: one pixel per thread (x = tid % 32, y = tid / 32)
     {
@@ -1022,6 +1044,12 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
     if (p.dbg & 128) return MR_OK;  // ... binning pass alone
     return launch_tiles<true, true>(p, s);
 }
+
+#ifdef MR_WG_TIMELINE
+extern "C" __attribute__((visibility("default"))) int mr_debug_times(void* dst, long n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mr::mr_dbg_times), n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
                                       const float* background, int bg_stride, const float* keep_lut, int n_lut,
