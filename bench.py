@@ -141,7 +141,7 @@ def kernel_bench(dev, B, is_, iters, only=None):
     def render_bwd_full():  # kernels D + E + F
         _lib.call("mr_render_backward", P(faces), P(tex2), P(fim), P(rgb), P(alpha), P(g_rgb), P(g_alpha),
                   P(g_depth), P(grad_faces), P(grad_tex), P(bw_work), bw_bytes, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1,
-                  0, st)
+                  int(os.environ.get("HOC_BWD_FLAGS", "0")), st)  # (flags >> 8: kernel D's profiling switches)
 
     # vertex-colour mode: what the training path actually launches (opticalflow -> render_vertex_colors)
     fidx32 = faces_idx.to(torch.int32).contiguous()

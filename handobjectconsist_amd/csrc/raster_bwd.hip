@@ -23,6 +23,7 @@
 //   * pixel_pack_kernel + pixel_map_packed_kernel -- kernel D on packed row- and column-major records
 //     with item-parallel headers (the default when a workspace is given; see the comment there).
 #include "mr_common.hpp"
+#include <algorithm>
 
 namespace mr {
 
@@ -729,7 +730,7 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
     extern __shared__ long long vtab[];  // [V * 3] rounded up to an even count
     __shared__ unsigned wmax[ST_WAVES];
     __shared__ unsigned short hits[ST_MAX_TILES];  // the image's covered tiles, ascending
-    __shared__ int wcnt[ST_WAVES], n_hits_s;
+    __shared__ int wcnt[ST_WAVES];
     const GatherVCParams& p = sp.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x / ST_G, part = blockIdx.x % ST_G;
@@ -1236,19 +1237,53 @@ __device__ __forceinline__ float pm_bcast(float v, int src) {
 }
 __device__ __forceinline__ int pm_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
-__global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p, const PixRec* __restrict__ rec_row,
-                                                               const PixRec* __restrict__ rec_col,
-                                                               const uint8_t* __restrict__ owns) {
+// One wave-wide sweep, staged in LDS by the lane that owns the item and read back with a wave-uniform address (three
+// broadcast ds_read_b128 instead of a dozen v_readlane): 48 bytes.
+struct __attribute__((aligned(16))) PmSweep {
+    int info;    // d0 | k << 14 (k = 2 * edge + axis) | own_only << 17 | use0 << 18 | use1 << 19
+    int range;   // d1_from | d1_to << 16
+    float cross, k0;                 // d1_cross; c0 * 2 / is
+    float e0, k1, e1, a_ref;         // +-eps of term 0 ("out" sweeps: constant along the sweep); c1 * 2 / is; +-eps of term 1
+    float r_ref, g_ref, b_ref, pad;
+};
+constexpr int PM_SW_CAP = 2 * MR_WAVE;  // per round of 64 items: an "out" and a long "in" sweep per lane at most
+
+// The faces that own a pixel (typically a fifth of them), compacted into a list for the walk kernel; the others get
+// their zero rows here.  One workgroup per 4096 faces, ONE global atomic each.
+constexpr int CO_TPB = 1024, CO_PER = 4;
+__global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p, const uint8_t* __restrict__ owns,
+                                                                unsigned* __restrict__ counter, uint32_t* __restrict__ list) {
+    __shared__ unsigned s_cnt, s_base;
     const int64_t total = (int64_t)p.B * p.F;
-    // XCD-aware: every XCD works through a contiguous range of faces, i.e. a few images at a time, whose
-    // packed records (4 MB per 256 x 256 image) then stay in that XCD's L2 across the sweeps
-    const int64_t i = ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;  // face of this wave
-    const int lane = threadIdx.x & 63;
-    if (i >= total) return;  // wave-uniform
-    if (!owns[i]) {
-        if (lane < 9 && (p.write_backfacing || !backfacing(p.faces + i * 9))) p.grad_faces[i * 9 + lane] = 0.0f;
-        return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_cnt = 0u;
+    __syncthreads();
+    unsigned pos[CO_PER];
+    bool own[CO_PER];
+#pragma unroll
+    for (int k = 0; k < CO_PER; k++) {
+        const int64_t i = (int64_t)blockIdx.x * (CO_TPB * CO_PER) + k * CO_TPB + tid;
+        own[k] = i < total && owns[i] != 0;
+        if (i < total && !own[k] && (p.write_backfacing || !backfacing(p.faces + i * 9))) {
+#pragma unroll
+            for (int c = 0; c < 9; c++) p.grad_faces[i * 9 + c] = 0.0f;
+        }
+        const unsigned long long m = __ballot(own[k]);
+        unsigned wbase = 0u;
+        if (lane == 0 && m) wbase = atomicAdd(&s_cnt, (unsigned)__popcll(m));
+        pos[k] = (unsigned)__shfl((int)wbase, 0) + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
     }
+    __syncthreads();
+    if (tid == 0) s_base = atomicAdd(counter, s_cnt);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CO_PER; k++)
+        if (own[k]) list[s_base + pos[k]] = (uint32_t)((int64_t)blockIdx.x * (CO_TPB * CO_PER) + k * CO_TPB + tid);
+}
+
+__device__ __forceinline__ void pm_walk_face(const PixelMapParams& p, const PixRec* __restrict__ rec_row,
+                                             const PixRec* __restrict__ rec_col, const int64_t i, const int lane,
+                                             PmSweep* sw) {
     const int is = p.is;
     const float fis = (float)is;
     const float two_over_is = 2.0f / fis;
@@ -1287,22 +1322,7 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
 #pragma unroll
     for (int k = 0; k < 3; k++) { acc[k][0] = 0.0f; acc[k][1] = 0.0f; }
 
-    // one sweep of the whole wave: pixels d1_from .. d1_to of column / row d0
-    auto sweep = [&](int axis, int d0, int d1_from, int d1_to, float d1_cross, float c0, float c1, bool use0, bool use1,
-                     float a_ref, const float* rgb_ref, bool own_only, float& g0, float& g1) {
-        const PixRec* base = (axis == 0 ? col_b : row_b) + (int64_t)d0 * is;
-        for (int d1 = d1_from + lane; d1 <= d1_to; d1 += MR_WAVE) {
-            const PixRec r = base[d1];
-            if (own_only) {
-                const int xi = axis == 0 ? d0 : d1, yi = axis == 0 ? d1 : d0;
-                if (fim_b[yi * is + xi] != fn) continue;
-            }
-            const float dg = rec_diff_grad(r, a_ref, rgb_ref, ra, rr);
-            if (dg <= 0) continue;
-            if (use0) g0 -= pm_term(dg, c0, (float)d1, d1_cross, two_over_is, p.eps);
-            if (use1) g1 -= pm_term(dg, c1, (float)d1, d1_cross, two_over_is, p.eps);
-        }
-    };
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
 #pragma unroll 1
     for (int base_item = 0; base_item < off[6]; base_item += MR_WAVE) {
@@ -1379,36 +1399,88 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
                 acc[v][c] += (comp && v == (e + 1) % 3) ? g1 : 0.0f;
             }
 
-        // wave sweeps: "out" of every visible item, "in" of the long ones
+        // wave sweeps: "out" of every visible item, "in" of the long ones -- staged in LDS in lane order, then walked
+        // one after the other by the whole wave, 64 records per step from the copy that is contiguous along the sweep
         unsigned long long m_out = __ballot(visible), m_in = __ballot(long_in);
         if (p.dbg & 1) { m_out = 0ull; m_in = 0ull; }
         if (p.dbg & 4) { m_out &= 1ull; }
-        while (m_out | m_in) {
-            const bool is_out = m_out != 0ull;
-            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)(is_out ? m_out : m_in)) - 1);
-            if (is_out) m_out &= m_out - 1; else m_in &= m_in - 1;
-            const int s_axis = pm_bcast(axis, src), s_e = pm_bcast(e, src), s_d0 = pm_bcast(d0, src);
-            const float s_cross = pm_bcast(d1_cross, src), s_c0 = pm_bcast(c0, src), s_c1 = pm_bcast(c1, src);
-            const bool s_use0 = pm_bcast((int)use0, src) != 0, s_use1 = pm_bcast((int)use1, src) != 0;
-            int s_from, s_to;
-            float s_a, s_rgb[3];
-            if (is_out) {
-                const int s_dir = pm_bcast(direction, src), s_out = pm_bcast(d1_out, src);
-                const int lim = (0 < s_dir) ? is - 1 : 0;
-                s_from = max(min(s_out, lim), 0); s_to = min(max(s_out, lim), is - 1);
-                s_a = pm_bcast(a_in, src);
-#pragma unroll
-                for (int c = 0; c < 3; c++) s_rgb[c] = pm_bcast(rgb_in[c], src);
-            } else {
-                s_from = pm_bcast(in_from, src); s_to = pm_bcast(in_to, src);
-                s_a = pm_bcast(a_out, src);
-#pragma unroll
-                for (int c = 0; c < 3; c++) s_rgb[c] = pm_bcast(rgb_out[c], src);
+        const int n_out = __popcll(m_out), n_sw = n_out + __popcll(m_in);
+        {
+            const float k0 = c0 * two_over_is, k1 = c1 * two_over_is;
+            const int flags = (k << 14) | ((use0 ? 1 : 0) << 18) | ((use1 ? 1 : 0) << 19);
+            if ((m_out >> lane) & 1ull) {
+                const int lim = (0 < direction) ? is - 1 : 0;
+                const float fdir = (float)direction;  // the sign of d1 - d1_cross along the whole "out" sweep
+                PmSweep o;
+                o.info = d0 | flags;
+                o.range = max(min(d1_out, lim), 0) | (min(max(d1_out, lim), is - 1) << 16);
+                o.cross = d1_cross; o.k0 = k0; o.k1 = k1;
+                o.e0 = (0.0f < k0 * fdir) ? p.eps : -p.eps;
+                o.e1 = (0.0f < k1 * fdir) ? p.eps : -p.eps;
+                o.a_ref = a_in; o.r_ref = rgb_in[0]; o.g_ref = rgb_in[1]; o.b_ref = rgb_in[2]; o.pad = 0.0f;
+                sw[__popcll(m_out & lt_mask)] = o;
             }
+            if ((m_in >> lane) & 1ull) {
+                PmSweep o;
+                o.info = d0 | flags | (1 << 17);
+                o.range = in_from | (in_to << 16);
+                o.cross = d1_cross; o.k0 = k0; o.k1 = k1; o.e0 = 0.0f; o.e1 = 0.0f;
+                o.a_ref = a_out; o.r_ref = rgb_out[0]; o.g_ref = rgb_out[1]; o.b_ref = rgb_out[2]; o.pad = 0.0f;
+                sw[n_out + __popcll(m_in & lt_mask)] = o;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int i = 0; i < n_sw; i++) {
+            const float4* sp = reinterpret_cast<const float4*>(sw + i);
+            const float4 A = sp[0], Bq = sp[1], Cq = sp[2];
+            const int info = __builtin_amdgcn_readfirstlane(__float_as_int(A.x));
+            const int range = __builtin_amdgcn_readfirstlane(__float_as_int(A.y));
+            const int s_d0 = info & 0x3fff, s_k = (info >> 14) & 7;
+            const bool own_only = (info >> 17) & 1, s_use0 = (info >> 18) & 1, s_use1 = (info >> 19) & 1;
+            const int s_from = range & 0xffff, s_to = (range >> 16) & 0xffff;
+            const float s_cross = A.z, s_k0 = A.w, s_e0 = Bq.x, s_k1 = Bq.y, s_e1 = Bq.z;
+            const float s_a = Bq.w;
+            const float s_rgb[3] = {Cq.x, Cq.y, Cq.z};
+            const int s_axis = s_k & 1;
+            const PixRec* base = (s_axis == 0 ? col_b : row_b) + (int64_t)s_d0 * is;
             float w0 = 0.0f, w1 = 0.0f;
-            sweep(s_axis, s_d0, s_from, s_to, s_cross, s_c0, s_c1, s_use0, s_use1, s_a, s_rgb, !is_out, w0, w1);
+            auto visit = [&](int d1, const PixRec& r) {
+                if (own_only) {
+                    const int xi = s_axis == 0 ? s_d0 : d1, yi = s_axis == 0 ? d1 : s_d0;
+                    if (fim_b[yi * is + xi] != fn) return;
+                }
+                float dg = rec_diff_grad(r, s_a, s_rgb, ra, rr);
+                dg = (dg <= 0.0f) ? 0.0f : dg;  // (a NaN stays a NaN, as with upstream's `if (dg <= 0) continue`)
+                const float tt = (float)d1 - s_cross;
+                if (own_only) {
+                    if (s_use0) {
+                        float dist = s_k0 * tt;
+                        dist = (0 < dist) ? dist + p.eps : dist - p.eps;
+                        w0 = __builtin_fmaf(-dg, __builtin_amdgcn_rcpf(dist), w0);
+                    }
+                    if (s_use1) {
+                        float dist = s_k1 * tt;
+                        dist = (0 < dist) ? dist + p.eps : dist - p.eps;
+                        w1 = __builtin_fmaf(-dg, __builtin_amdgcn_rcpf(dist), w1);
+                    }
+                } else {
+                    // d1 - d1_cross keeps its sign beyond the edge: the +-eps of `dist` is a constant of the sweep
+                    if (s_use0) w0 = __builtin_fmaf(-dg, __builtin_amdgcn_rcpf(__builtin_fmaf(s_k0, tt, s_e0)), w0);
+                    if (s_use1) w1 = __builtin_fmaf(-dg, __builtin_amdgcn_rcpf(__builtin_fmaf(s_k1, tt, s_e1)), w1);
+                }
+            };
+            // two steps per trip, both records requested before the first is used (the walks are bound by the
+            // latency of these loads: one wave, one face, one sweep after the other)
+            for (int d1 = s_from + lane; d1 <= s_to; d1 += 2 * MR_WAVE) {
+                const int d1b = d1 + MR_WAVE;
+                const PixRec ra_ = base[d1];
+                const PixRec rb_ = base[min(d1b, s_to)];
+                visit(d1, ra_);
+                if (d1b <= s_to) visit(d1b, rb_);
+            }
             // the slots are wave-uniform here: scalar branches instead of 12 selects
-            const int sc = 1 - s_axis, v0 = s_e, v1 = s_e == 2 ? 0 : s_e + 1;
+            const int s_e = s_k >> 1, sc = 1 - s_axis, v0 = s_e, v1 = s_e == 2 ? 0 : s_e + 1;
 #pragma unroll
             for (int v = 0; v < 3; v++)
 #pragma unroll
@@ -1417,6 +1489,7 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
                     if (v == v1 && c == sc) acc[v][c] += w1;
                 }
         }
+        __builtin_amdgcn_wave_barrier();  // the next round of items overwrites the staged sweeps
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1)
@@ -1435,6 +1508,23 @@ __global__ void __launch_bounds__(256) pixel_map_packed_kernel(PixelMapParams p,
     }
 }
 
+// The walk kernel is PERSISTENT over the list of owning faces: one wave per face at a time.  (One wave per face of the
+// mesh left four fifths of the launched waves with nothing to do but read their flag, each holding a wave slot -- and
+// its workgroup's LDS -- for the microseconds that takes.)  Every XCD works through a contiguous eighth of the list, i.e.
+// a few images at a time, whose packed records (4 MB per 256 x 256 image) then stay in that XCD's L2 across the sweeps.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+pixel_map_packed_kernel(PixelMapParams p, const PixRec* __restrict__ rec_row, const PixRec* __restrict__ rec_col,
+                        const unsigned* __restrict__ counter, const uint32_t* __restrict__ list) {
+    __shared__ PmSweep sweeps[256 / MR_WAVE][PM_SW_CAP];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned count = *counter;
+    const unsigned G = gridDim.x, x = blockIdx.x & 7u;
+    const unsigned waves_x = ((G - x + 7u) / 8u) * (256 / MR_WAVE);  // waves of the workgroups with blockIdx % 8 == x
+    const unsigned lo = (unsigned)((uint64_t)count * x / 8u), hi = (unsigned)((uint64_t)count * (x + 1u) / 8u);
+    for (unsigned idx = lo + (blockIdx.x / 8u) * (256 / MR_WAVE) + wave; idx < hi; idx += waves_x)
+        pm_walk_face(p, rec_row, rec_col, (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)list[idx]), lane, sweeps[wave]);
+}
+
 template <typename K, typename... A>
 static int launch1d(K kernel, int64_t n, hipStream_t s, A... args) {
     if (n <= 0) return MR_OK;
@@ -1446,8 +1536,9 @@ static int launch1d(K kernel, int64_t n, hipStream_t s, A... args) {
 }
 
 static int64_t pixel_map_workspace_bytes(int B, int F, int is) {
-    // packed records (row- and column-major) | per-face "owns a pixel" flags
-    return 2LL * (int64_t)B * is * is * (int64_t)sizeof(PixRec) + (((int64_t)B * F + 255) & ~255LL);
+    // packed records (row- and column-major) | per-face "owns a pixel" flags | owner count | owner list
+    return 2LL * (int64_t)B * is * is * (int64_t)sizeof(PixRec) + (((int64_t)B * F + 255) & ~255LL) + 256 +
+           (((int64_t)B * F * 4 + 255) & ~255LL);
 }
 
 // kernel D: packed walks when a workspace of pixel_map_workspace_bytes is available, else the
@@ -1462,15 +1553,30 @@ static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t wo
     PixRec* rec_row = (PixRec*)workspace;
     PixRec* rec_col = rec_row + (int64_t)p.B * p.is * p.is;
     uint8_t* owns = (uint8_t*)(rec_col + (int64_t)p.B * p.is * p.is);
-    hipError_t e = hipMemsetAsync(owns, 0, (size_t)nfaces, s);
+    const size_t owns_bytes = (size_t)((nfaces + 255) & ~255LL);
+    unsigned* counter = (unsigned*)(owns + owns_bytes);
+    uint32_t* list = (uint32_t*)(owns + owns_bytes + 256);
+    if (nfaces > 0xffffffffLL) return MR_ERR_BADARG;
+    hipError_t e = hipMemsetAsync(owns, 0, owns_bytes + 256, s);  // flags and the counter behind them
     if (e != hipSuccess) return (int)e;
     const int tiles = (p.is + PK_T - 1) / PK_T;
     const int64_t nblk = (int64_t)p.B * tiles * tiles;
     if (nblk > 0x7fffffffLL) return MR_ERR_BADARG;
     hipLaunchKernelGGL(pixel_pack_kernel<IMG>, dim3((unsigned)nblk), dim3(256), 0, s, p, rec_row, rec_col, owns, tiles);
     MR_CHECK_LAUNCH();
-    return launch1d(pixel_map_packed_kernel, nfaces * MR_WAVE, s, p, (const PixRec*)rec_row, (const PixRec*)rec_col,
-                    (const uint8_t*)owns);
+    if (nfaces == 0) return MR_OK;
+    hipLaunchKernelGGL(compact_owners_kernel, dim3((unsigned)((nfaces + CO_TPB * CO_PER - 1) / (CO_TPB * CO_PER))),
+                       dim3(CO_TPB), 0, s, p, (const uint8_t*)owns, counter, list);
+    MR_CHECK_LAUNCH();
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const int64_t grid = std::min<int64_t>((nfaces + 3) / 4, (int64_t)cus * 6);  // 6 workgroups per compute unit fit
+    hipLaunchKernelGGL(pixel_map_packed_kernel, dim3((unsigned)grid), dim3(256), 0, s, p, (const PixRec*)rec_row,
+                       (const PixRec*)rec_col, (const unsigned*)counter, (const uint32_t*)list);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
 }
 
 }  // namespace mr
