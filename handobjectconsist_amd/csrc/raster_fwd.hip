@@ -527,20 +527,30 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
             // reciprocal: it only has to land within a pixel), the next ones step to the neighbour of the bound
             // that just moved -- two or three probes settle almost every item -- and whatever is still open after
             // three probes is bisected.  The three edges advance together.
-            int l[3] = {lx0 - 1, lx0 - 1, lx0 - 1}, h[3] = {lx1 + 1, lx1 + 1, lx1 + 1};
+            int l[3], h[3];
             const bool dec[3] = {dy[0] < 0.0f, dy[1] < 0.0f, dy[2] < 0.0f};
             int probe[3];
+            bool open_any = false;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 // (xp - a) dy = ey  ->  xp = a + ey / dy;  pixel index = (xp is + is - 1) / 2, tile-local
                 const float xs = ((ea[k] + ey[k] * __builtin_amdgcn_rcpf(dy[k])) * fis + fis - 1.0f) * 0.5f - (float)tx0;
-                // NaN (dy == 0) -> lx1: T is constant along the row then, one probe at the far end settles it
-                probe[k] = (int)fminf(fmaxf(floorf(xs), (float)lx0), (float)lx1);
-                if (!(xs == xs)) probe[k] = lx1;
+                // NaN (dy == 0) -> lx1: T is constant along the row then, the probe at the far end settles it
+                int c = (int)fminf(fmaxf(floorf(xs), (float)lx0), (float)lx1);
+                if (!(xs == xs)) c = lx1;
+                // straight-line first round: the exact predicate at c and c + 1 (the crossing is almost always
+                // between them); whatever this leaves open goes to the general bracketing loop below
+                const float xp0 = xp_tab[c & (TILE_W - 1)], xp1 = xp_tab[(c + 1) & (TILE_W - 1)];
+                const bool t0 = (!(ey[k] < (xp0 - ea[k]) * dy[k])) != dec[k];
+                const bool t1 = c < lx1 && ((!(ey[k] < (xp1 - ea[k]) * dy[k])) != dec[k]);
+                l[k] = t0 ? (t1 ? c + 1 : c) : lx0 - 1;
+                h[k] = t0 ? (t1 ? lx1 + 1 : c + 1) : c;
+                probe[k] = t0 ? c + 2 : c - 1;
+                open_any = open_any || (h[k] - l[k] > 1);
             }
-            if (!(p.dbg & 32)) {
-                for (int it = 0;; it++) {
-                    bool open_any = false;
+            if (!(p.dbg & 32) && __ballot(act && open_any) != 0ull) {
+                for (int it = 1;; it++) {
+                    open_any = false;
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         const bool go = h[k] - l[k] > 1;

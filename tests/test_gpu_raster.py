@@ -84,6 +84,31 @@ def test_fused_forward_matches_oracle(cuda, kind, B, is_, seed, reference_algo):
     assert set(out.keys()) == {"rgb", "alpha", "depth", "face_inv_map", "face_index_map", "weight_map"}
 
 
+def test_raster_beyond_the_bin_counters(cuda):
+    """A 1536-pixel raster has more tiles (9216) than the binning pass has LDS counters (8192): a bin is then a column of
+    two tiles, and a bin's records may miss one of its tiles -- they get an empty row range in the tile kernel, as do
+    the records of the image's large list (faces over more than 8 bins) in the tiles they do not touch."""
+    from handobjectconsist_amd.neurender import rasterize
+
+    is_, rng = 1536, np.random.default_rng(11)
+    n_small = 120
+    c = rng.uniform(-0.97, 0.97, (1, n_small, 1, 2))
+    small = np.concatenate([c + rng.uniform(-0.02, 0.02, (1, n_small, 3, 2)), rng.uniform(0.5, 2.0, (1, n_small, 3, 1))], -1)
+    big, _ = big_faces(1, is_, 12, n=4)
+    faces = np.concatenate([small, small[:, :, ::-1], big], 1).astype(np.float32)
+    tex = rng.uniform(-1, 1, (1, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    bg = (0.1, 0.2, 0.3)
+    ref = R.rasterize_rgbad(faces, tex, is_, False, 0.1, 100, 1e-3, bg, num_threads=8)
+    out = rasterize.rasterize_rgbad(t(faces, cuda), t(tex, cuda), is_, False, 0.1, 100, 1e-3, bg)
+    fim = out["face_index_map"].cpu().numpy()
+    assert (fim != ref["face_index_map"]).sum() == 0
+    won = np.unique(fim[fim >= 0])
+    assert (won < 2 * n_small).sum() > 60 and (won >= 2 * n_small).sum() >= 2, "small and large faces must both be visible"
+    assert_close(out["weight_map"].cpu().numpy(), ref["weight_map"], 0, 1e-6, "weight_map")
+    assert_close(out["depth"].cpu().numpy(), ref["depth"], 1e-6, 0, "depth")
+    assert_close(out["rgb"].cpu().numpy(), ref["rgb"], 1e-6, 1e-6, "rgb")
+
+
 @pytest.mark.parametrize("kind,B,is_,seed", CASES[:2] + CASES[3:4])
 def test_compat_five_entry_points_match_oracle(cuda, kind, B, is_, seed):
     """RasterizeFunction = the reference's structure on the 5 upstream-compatible entry points."""
