@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
             // reciprocal: it only has to land within a pixel), the next ones step to the neighbour of the bound
             // that just moved -- two or three probes settle almost every item -- and whatever is still open after
             // three probes is bisected.  The three edges advance together.
-            int l[3], h[3];
+            int l[3], h[3], cc[3], tt[3];
             const bool dec[3] = {dy[0] < 0.0f, dy[1] < 0.0f, dy[2] < 0.0f};
             int probe[3];
             bool open_any = false;
@@ -543,12 +543,18 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
                 const float xp0 = xp_tab[c & (TILE_W - 1)], xp1 = xp_tab[(c + 1) & (TILE_W - 1)];
                 const bool t0 = (!(ey[k] < (xp0 - ea[k]) * dy[k])) != dec[k];
                 const bool t1 = c < lx1 && ((!(ey[k] < (xp1 - ea[k]) * dy[k])) != dec[k]);
-                l[k] = t0 ? (t1 ? c + 1 : c) : lx0 - 1;
-                h[k] = t0 ? (t1 ? lx1 + 1 : c + 1) : c;
-                probe[k] = t0 ? c + 2 : c - 1;
-                open_any = open_any || (h[k] - l[k] > 1);
+                l[k] = t0 ? c + (t1 ? 1 : 0) : lx0 - 1;
+                // still open: T true at c + 1 < lx1 (the bound is further right) or false at c > lx0 (further left)
+                open_any = open_any || (t0 ? (t1 && c + 1 < lx1) : c > lx0);
+                cc[k] = c; tt[k] = (t0 ? 1 : 0) | (t1 ? 2 : 0);
             }
             if (!(p.dbg & 32) && __ballot(act && open_any) != 0ull) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const bool t0 = tt[k] & 1, t1 = tt[k] & 2;
+                    h[k] = t0 ? (t1 ? lx1 + 1 : cc[k] + 1) : cc[k];
+                    probe[k] = t0 ? cc[k] + 2 : cc[k] - 1;
+                }
                 for (int it = 1;; it++) {
                     open_any = false;
 #pragma unroll
@@ -709,14 +715,17 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
                 for (int k = 0; k < 3; k++)
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) vc[k][ch] = p.vcolors[((int64_t)b * p.V + vid[k]) * 3 + ch];
+                // (the five taps on zero texels are skipped: their weights are finite unless a sampling coordinate is
+                // NaN, in which case the three taps below are NaN as well, and c + (+-0) == c for the sums at hand,
+                // which start at +0 and therefore are never -0)
 #pragma unroll
-                for (int pn = 0; pn < 8; pn++) {
+                for (int pn = 1; pn <= 4; pn <<= 1) {
                     float wg = 1.0f;
 #pragma unroll
                     for (int k = 0; k < 3; k++) wg *= ((pn >> k) & 1) ? (tif[k] - 0.0f) : (1.0f - (tif[k] - 0.0f));
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
-                        const float tv = (pn == 1) ? vc[0][ch] : (pn == 2) ? vc[1][ch] : (pn == 4) ? vc[2][ch] : 0.0f;
+                        const float tv = (pn == 1) ? vc[0][ch] : (pn == 2) ? vc[1][ch] : vc[2][ch];
                         c[ch] += wg * tv;
                     }
                 }
