@@ -454,6 +454,17 @@ def main():
     # MIOpen's measured solver search (first call of every convolution shape, inside the warm-up steps) instead of its
     # find-db heuristics: 27.4 instead of 28.0 ms per step with the channels-last trunk; HOC_CUDNN_BENCHMARK=0 disables
     torch.backends.cudnn.benchmark = os.environ.get("HOC_CUDNN_BENCHMARK", "1") == "1"
+    # ... and PyTorch's TunableOp for the fp32 GEMMs of the heads (rocBLAS' default pick for [192,512] x [512,256] is a
+    # single-workgroup kernel: 91 us for 25 MFLOP, twice per step): every GEMM shape is timed over the rocBLAS / hipBLASLt
+    # solutions at its first call, inside the warm-up steps; 26.8 instead of 27.2 ms per step.  HOC_TUNABLEOP=0 disables.
+    # Its results file goes to the temp directory, not the working tree.
+    if os.environ.get("HOC_TUNABLEOP", "1") == "1":
+        import tempfile
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(True)
+        torch.cuda.tunable.set_max_tuning_duration(10)    # ms per candidate solution
+        torch.cuda.tunable.set_max_tuning_iterations(20)
+        torch.cuda.tunable.set_filename(os.path.join(tempfile.gettempdir(), "hoc_tunableop_%d.csv" % os.getpid()))
     # HOC_SHARE_GPU=1 (tests only): ranks beyond the device count share GPUs, with HOC_DIST_BACKEND=gloo -- RCCL
     # refuses two ranks on one device; this is how a world_size-2 job is exercised on the one-GPU test box
     dev_index = local_rank % torch.cuda.device_count() if os.environ.get("HOC_SHARE_GPU", "0") == "1" else local_rank
