@@ -50,7 +50,7 @@ def test_bench_single_process_line(cuda):
 
 @pytest.mark.gpu
 def test_bench_under_torchrun_rccl_ddp(cuda):
-    env = dict(os.environ, HOC_FORCE_DDP="1", HOC_CHECK_REPLICAS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HOC_FORCE_DDP="1", HOC_CHECK_REPLICAS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", HOC_TUNABLEOP="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline",
            "--no-kernel-bench"] + SMALL
@@ -66,7 +66,7 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(cuda):
     (RCCL refuses two ranks per device).  Exercises what N > 1 adds -- per-rank seeds and loaders, DDP's bucketed
     all-reduce through this build's autograd functions, the barrier + max-over-ranks timing, rank-0-only output;
     HOC_CHECK_REPLICAS makes bench.py assert that the replicas' parameters are bit-identical after the steps."""
-    env = dict(os.environ, HOC_SHARE_GPU="1", HOC_DIST_BACKEND="gloo", HOC_CHECK_REPLICAS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HOC_SHARE_GPU="1", HOC_DIST_BACKEND="gloo", HOC_CHECK_REPLICAS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", HOC_TUNABLEOP="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline",
            "--no-kernel-bench"] + SMALL
@@ -82,7 +82,7 @@ def test_config4_per_gpu_workload_under_rccl_ddp(cuda):
     """BASELINE config 4 (8 x MI355X, global B = 256): the per-GPU share -- B = 32 frame pairs of 256 x 256 -- through
     the RCCL process group + DistributedDataParallel path (one rank: the test box has one GPU); the JSON line
     carries the per-rank evidence (backend, device, per-rank step time, all-reduce volume)."""
-    env = dict(os.environ, HOC_FORCE_DDP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HOC_FORCE_DDP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", HOC_TUNABLEOP="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "32",
            "--image-size", "256", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-bench",
