@@ -218,6 +218,8 @@ def kernel_bench(dev, B, is_, iters, only=None):
                   is_, is_, is_, 0.03, 0.99999, st)
 
     occlusion_flow()
+    if os.environ.get("HOC_ZERO_FLOWS"):  # experiment: the pair kernels on all-zero flows (nothing but the flow reads)
+        pflows.zero_()
     flow12, flow21 = pflows[:B], pflows[B:]
     pbytes = int(lib.mr_pair_consist_workspace_bytes(B, is_, is_))
     pcwork = torch.empty((pbytes,), dtype=torch.uint8, device=dev)
@@ -227,11 +229,11 @@ def kernel_bench(dev, B, is_, iters, only=None):
 
     def pair_fwd():
         _lib.call("mr_pair_consist_forward", P(flow12), P(flow21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(pcwork),
-                  pbytes, P(sums), P(lf), P(lb), *([None] * 8), B, is_, is_, 0.99999, st)
+                  pbytes, P(sums), P(lf), P(lb), *([None] * 8), B, is_, is_, 0.99999, P(ptile_hit[:B]), P(ptile_hit[B:]), is_, st)
 
     def pair_bwd():
         _lib.call("mr_pair_consist_backward", P(flow12), P(flow21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(sums),
-                  P(gl), P(gl), P(g12), P(g21), B, is_, is_, 0.99999, st)
+                  P(gl), P(gl), P(g12), P(g21), B, is_, is_, 0.99999, P(ptile_hit[:B]), P(ptile_hit[B:]), is_, st)
 
     m1, m2 = alpha.unsqueeze(1).contiguous(), alpha.unsqueeze(1).contiguous()
     o1, o2 = torch.empty((B, is_, is_), **f32), torch.empty((B, is_, is_), **f32)

@@ -540,6 +540,11 @@ struct PairParams {
     float* diff2;
     int B, H, W, nblk, tiles_x;
     float thresh;
+    // optional coverage bytes of the renders the flows came from (mr_render_flow_forward): a flow is exactly 0
+    // where its render covered nothing, and is not even read there
+    const uint8_t* hit12;  // [B, tiles_y, tiles_x, 4] of the render behind flow12 (frame 1)
+    const uint8_t* hit21;
+    int hit_is, hit_tiles_x, hit_stride;  // raster size, tiles per raster row, bytes per image
 };
 
 // one direction at one pixel: warp `src` with `flow`, gate with the jitter mask `jwarp`
@@ -575,6 +580,12 @@ struct DirRaw {
 
 __device__ __forceinline__ float2 pair_flow(const float* __restrict__ flow, int b, int xx, int yy, int H, int W) {
     return *reinterpret_cast<const float2*>(flow + ((int64_t)b * H * W + (int64_t)yy * W + xx) * 2);
+}
+// ... guarded by the coverage bytes of the flow's render (hit == NULL: dense)
+__device__ __forceinline__ float2 pair_flow(const float* __restrict__ flow, const uint8_t* __restrict__ hit, int hit_is,
+                                            int hit_tiles_x, int hit_stride, int b, int xx, int yy, int H, int W) {
+    if (hit && !tile_covered(hit + (int64_t)b * hit_stride, hit_tiles_x, hit_is, xx, yy)) return make_float2(0.0f, 0.0f);
+    return pair_flow(flow, b, xx, yy, H, W);
 }
 
 __device__ __forceinline__ DirTaps pair_taps(float2 uv, int xx, int yy, int H, int W) {
@@ -653,6 +664,20 @@ __device__ __forceinline__ bool pair_tile_pixel(int H, int W, int tiles_x, int n
     return xx < W && yy < H;
 }
 
+// Does the render behind a flow cover anything in the block's PT_W x PT_H pixels?  Block-uniform (scalar loads of
+// the 4-byte coverage words of the <= 3 x 2 raster tiles the block touches); NULL = no information = yes.
+__device__ __forceinline__ bool pair_block_covered(const uint8_t* __restrict__ hit, int hit_is, int hit_tiles_x,
+                                                   int hit_stride, int b, int tile, int tiles_x, int H, int W) {
+    if (!hit) return true;
+    const int x0 = (tile % tiles_x) * PT_W, y0 = (tile / tiles_x) * PT_H;
+    const int x1 = min(x0 + PT_W, W) - 1, y1 = min(y0 + PT_H, H) - 1;
+    const uint32_t* h32 = reinterpret_cast<const uint32_t*>(hit + (int64_t)b * hit_stride);
+    uint32_t any = 0u;
+    for (int ty = (hit_is - 1 - y1) >> 3; ty <= (hit_is - 1 - y0) >> 3; ty++)
+        for (int tx = x0 >> 5; tx <= x1 >> 5; tx++) any |= h32[ty * hit_tiles_x + tx];
+    return any != 0u;
+}
+
 // block-wide sums of four values with ONE barrier: wave butterflies, 4 x 4 partials in LDS,
 // every thread adds the four wave partials in wave order (fixed order: deterministic)
 __device__ __forceinline__ void block_sum4(float* v, float (*red)[4]) {
@@ -674,13 +699,23 @@ __global__ void __launch_bounds__(256, 6) pair_consist_forward_kernel(PairParams
     const int64_t hw = (int64_t)p.H * p.W;
     int b, tile, xx, yy;
     const bool in_img = pair_tile_pixel(p.H, p.W, p.tiles_x, p.nblk, b, tile, xx, yy);
+    // nothing rendered under this block in either frame: both flows are zero here, no pixel is valid -- the block's
+    // partial sums are zero (no loads, no barrier), unless the per-pixel debug outputs want every pixel
+    if (p.hit12 && p.hit21 && !(p.warp1 || p.warp2 || p.diff1 || p.diff2 || p.warp_mask1 || p.warp_mask2 ||
+                                p.full_mask1 || p.full_mask2) &&
+        !pair_block_covered(p.hit12, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W) &&
+        !pair_block_covered(p.hit21, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W)) {
+        if (threadIdx.x < 4) p.partial[((int64_t)b * p.nblk + tile) * 4 + threadIdx.x] = 0.0f;
+        return;
+    }
     float sum1 = 0.0f, cnt1 = 0.0f, sum2 = 0.0f, cnt2 = 0.0f;
     if (in_img) {
         const int64_t pix = (int64_t)yy * p.W + xx;
         const bool allj = p.warp_mask1 != nullptr || p.warp_mask2 != nullptr;
         // forward term: image_ref warped by flow21 vs image (imgflowarp.py:80,85-87,93-102)
         // backward term: image warped by flow12 vs image_ref (:84,82,88,99-107)
-        const float2 uv1 = pair_flow(p.flow21, b, xx, yy, p.H, p.W), uv2 = pair_flow(p.flow12, b, xx, yy, p.H, p.W);
+        const float2 uv1 = pair_flow(p.flow21, p.hit21, p.hit_is, p.hit_tiles_x, p.hit_stride, b, xx, yy, p.H, p.W);
+        const float2 uv2 = pair_flow(p.flow12, p.hit12, p.hit_is, p.hit_tiles_x, p.hit_stride, b, xx, yy, p.H, p.W);
         // A pixel whose flow has a zero x component is invalid whatever the images hold (imgflowarp.py:93-100,
         // SURVEY Q5) and adds nothing to the masked sums: unless the per-pixel outputs (warps, differences,
         // warp masks) are requested, neither its taps are computed nor its 26 tap loads issued -- a rendered flow is
@@ -764,6 +799,9 @@ struct PairBwdParams {
     float* grad_flow21;
     int B, H, W, ntiles, tiles_x;
     float thresh;
+    const uint8_t* hit12;  // see PairParams
+    const uint8_t* hit21;
+    int hit_is, hit_tiles_x, hit_stride;
 };
 
 __device__ __forceinline__ float2 pair_grad(const DirTaps& d, const DirRaw& r, const DirOut& o, int H, int W,
@@ -791,12 +829,20 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
     int b, tile, xx, yy;
     if (!pair_tile_pixel(p.H, p.W, p.tiles_x, p.ntiles, b, tile, xx, yy)) return;
     const int64_t pix = (int64_t)yy * p.W + xx;
+    if (p.hit12 && p.hit21 &&
+        !pair_block_covered(p.hit12, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W) &&
+        !pair_block_covered(p.hit21, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W)) {
+        // nothing rendered under this block in either frame: zero gradient, nothing read
+        *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = make_float2(0.0f, 0.0f);
+        *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = make_float2(0.0f, 0.0f);
+        return;
+    }
     const float c1 = p.sums[b * 4 + 1], c2 = p.sums[b * 4 + 3];
     const float coef1 = p.grad_loss_fwd[b] / ((c1 == 0.0f) ? 1.0f : c1);
     const float coef2 = p.grad_loss_bwd ? p.grad_loss_bwd[b] / ((c2 == 0.0f) ? 1.0f : c2) : 0.0f;
     const bool both = p.grad_loss_bwd != nullptr;
-    const float2 uv1 = pair_flow(p.flow21, b, xx, yy, p.H, p.W);
-    const float2 uv2 = pair_flow(both ? p.flow12 : p.flow21, b, xx, yy, p.H, p.W);
+    const float2 uv1 = pair_flow(p.flow21, p.hit21, p.hit_is, p.hit_tiles_x, p.hit_stride, b, xx, yy, p.H, p.W);
+    const float2 uv2 = both ? pair_flow(p.flow12, p.hit12, p.hit_is, p.hit_tiles_x, p.hit_stride, b, xx, yy, p.H, p.W) : uv1;
     // the gradient of an invalid pixel is 0: no taps, no tap loads where the flow's x component is zero (see the
     // forward kernel)
     const bool need1 = uv1.x != 0.0f && coef1 != 0.0f, need2 = both && uv2.x != 0.0f && coef2 != 0.0f;
@@ -906,9 +952,11 @@ extern "C" int mr_pair_consist_forward(const float* flow12, const float* flow21,
                                        uint8_t* full_mask2, float* warp_mask1, float* warp_mask2,
                                        float* warp1, float* warp2, float* diff1, float* diff2,
                                        int batch_size, int height, int width, float thresh,
+                                       const uint8_t* tile_hit12, const uint8_t* tile_hit21, int hit_image_size,
                                        mr_stream_t stream) {
     if (!flow12 || !flow21 || !image_ref || !image || !jitter_ref || !jitter || !workspace || !sums)
         return MR_ERR_BADARG;
+    if ((tile_hit12 || tile_hit21) && (hit_image_size < height || hit_image_size < width)) return MR_ERR_BADARG;
     if (jitter_channels != 1 && jitter_channels != 3) return MR_ERR_BADARG;
     if (batch_size < 0 || height <= 0 || width <= 0) return MR_ERR_BADARG;
     if (workspace_bytes < mr_pair_consist_workspace_bytes(batch_size, height, width)) return MR_ERR_BADARG;
@@ -919,7 +967,8 @@ extern "C" int mr_pair_consist_forward(const float* flow12, const float* flow21,
     if ((int64_t)nblk * batch_size > 0x7fffffffLL) return MR_ERR_BADARG;
     PairParams p{flow12, flow21, image_ref, image, jitter_ref, jitter, jitter_channels, (float*)workspace,
                  full_mask1, full_mask2, warp_mask1, warp_mask2, warp1, warp2, diff1, diff2,
-                 batch_size, height, width, nblk, tiles_x, thresh};
+                 batch_size, height, width, nblk, tiles_x, thresh, tile_hit12, tile_hit21, hit_image_size,
+                 (hit_image_size + 31) / 32, ((hit_image_size + 31) / 32) * ((hit_image_size + 7) / 8) * 4};
     hipLaunchKernelGGL(pair_consist_forward_kernel, dim3((unsigned)(nblk * batch_size)), dim3(256), 0,
                        (hipStream_t)stream, p);
     MR_CHECK_LAUNCH();
@@ -934,10 +983,12 @@ extern "C" int mr_pair_consist_backward(const float* flow12, const float* flow21
                                         int jitter_channels, const float* sums, const float* grad_loss_fwd,
                                         const float* grad_loss_bwd, float* grad_flow12, float* grad_flow21,
                                         int batch_size, int height, int width, float thresh,
+                                        const uint8_t* tile_hit12, const uint8_t* tile_hit21, int hit_image_size,
                                         mr_stream_t stream) {
     if (!flow12 || !flow21 || !image_ref || !image || !jitter_ref || !jitter || !sums || !grad_loss_fwd ||
         !grad_flow12 || !grad_flow21)
         return MR_ERR_BADARG;
+    if ((tile_hit12 || tile_hit21) && (hit_image_size < height || hit_image_size < width)) return MR_ERR_BADARG;
     if (jitter_channels != 1 && jitter_channels != 3) return MR_ERR_BADARG;
     if (batch_size < 0 || height <= 0 || width <= 0) return MR_ERR_BADARG;
     if (width < 2 || (int64_t)height * width > (1LL << 29)) return MR_ERR_BADARG;  // row-pair taps, 32-bit byte offsets
@@ -947,7 +998,8 @@ extern "C" int mr_pair_consist_backward(const float* flow12, const float* flow21
     if ((int64_t)nblk * batch_size > 0x7fffffffLL) return MR_ERR_BADARG;
     PairBwdParams p{flow12, flow21, image_ref, image, jitter_ref, jitter, jitter_channels, sums,
                     grad_loss_fwd, grad_loss_bwd, grad_flow12, grad_flow21, batch_size, height, width, nblk,
-                    tiles_x, thresh};
+                    tiles_x, thresh, tile_hit12, tile_hit21, hit_image_size, (hit_image_size + 31) / 32,
+                    ((hit_image_size + 31) / 32) * ((hit_image_size + 7) / 8) * 4};
     hipLaunchKernelGGL(pair_consist_backward_kernel, dim3((unsigned)(nblk * batch_size)), dim3(256), 0,
                        (hipStream_t)stream, p);
     MR_CHECK_LAUNCH();

@@ -101,7 +101,7 @@ class _PairConsistFunction(torch.autograd.Function):
     flows only (the images / jitter masks are data on the training path)."""
 
     @staticmethod
-    def forward(ctx, flow12, flow21, image_ref, image, jitter_ref, jitter, thresh, want_debug):
+    def forward(ctx, flow12, flow21, image_ref, image, jitter_ref, jitter, thresh, want_debug, coverage=None, coverage_size=0):
         _lib.check_cuda(flow12, flow21, image_ref, image, jitter_ref, jitter)
         im_ref, im = _lib.contig(image_ref), _lib.contig(image)
         ctx.stacked = flow21 is None  # flow12 = [2B,H,W,2]: both flows in one tensor (get_opticalflow's fused path)
@@ -122,6 +122,15 @@ class _PairConsistFunction(torch.autograd.Function):
         if Cj not in (1, 3) or jm_ref.shape != jm.shape or jm.shape[2:] != (H, W):
             raise ValueError("jitter masks must be [B, 1 or 3, H, W]")
         dev = im.device
+        # coverage bytes of the renders behind the flows ([2B, tiles_y, tiles_x, 4], opticalflow._StackedFlowFunction)
+        hit12 = hit21 = None
+        if coverage is not None:
+            cs = int(coverage_size)
+            if (coverage.dtype != torch.uint8 or not coverage.is_contiguous() or coverage.device != dev
+                    or tuple(coverage.shape) != (2 * B, (cs + 7) // 8, (cs + 31) // 32, 4) or cs < H or cs < W):
+                raise ValueError("coverage must be the [2B, tiles_y, tiles_x, 4] byte array of a raster of coverage_size")
+            hit12, hit21 = coverage[:B], coverage[B:]
+        ctx.coverage = (hit12, hit21, int(coverage_size))
         lib = _lib.load()
         wbytes = int(lib.mr_pair_consist_workspace_bytes(B, H, W))
         work = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
@@ -136,7 +145,7 @@ class _PairConsistFunction(torch.autograd.Function):
         _lib.call("mr_pair_consist_forward", _lib.ptr(f12), _lib.ptr(f21), _lib.ptr(im_ref), _lib.ptr(im),
                   _lib.ptr(jm_ref), _lib.ptr(jm), Cj, _lib.ptr(work), wbytes, _lib.ptr(sums),
                   _lib.ptr(loss_fwd), _lib.ptr(loss_bwd), *[_lib.ptr(t) for t in dbg], B, H, W, float(thresh),
-                  _lib.stream_ptr(dev))
+                  _lib.ptr(hit12), _lib.ptr(hit21), int(coverage_size) if hit12 is not None else 0, _lib.stream_ptr(dev))
         ctx.save_for_backward(f12, f21, im_ref, im, jm_ref, jm, sums)
         ctx.thresh = float(thresh)
         ctx.set_materialize_grads(False)  # an unused direction arrives as None and is skipped
@@ -151,7 +160,8 @@ class _PairConsistFunction(torch.autograd.Function):
         f12, f21, im_ref, im, jm_ref, jm, sums = ctx.saved_tensors
         B, _, H, W = im.shape
         if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) or (g_fwd is None and g_bwd is None):
-            return (None,) * 8
+            return (None,) * 10
+        hit12, hit21, cov_size = ctx.coverage
         dev = im.device
         if g_fwd is None:
             g_fwd = torch.zeros((B,), dtype=torch.float32, device=dev)
@@ -165,10 +175,11 @@ class _PairConsistFunction(torch.autograd.Function):
             grad21 = torch.empty_like(f21)
         _lib.call("mr_pair_consist_backward", _lib.ptr(f12), _lib.ptr(f21), _lib.ptr(im_ref), _lib.ptr(im),
                   _lib.ptr(jm_ref), _lib.ptr(jm), int(jm.shape[1]), _lib.ptr(sums), _lib.ptr(g_fwd),
-                  _lib.ptr(g_bwd), _lib.ptr(grad12), _lib.ptr(grad21), B, H, W, ctx.thresh, _lib.stream_ptr(dev))
+                  _lib.ptr(g_bwd), _lib.ptr(grad12), _lib.ptr(grad21), B, H, W, ctx.thresh, _lib.ptr(hit12), _lib.ptr(hit21),
+                  cov_size if hit12 is not None else 0, _lib.stream_ptr(dev))
         if ctx.stacked:
-            return grad_both, None, None, None, None, None, None, None
-        return grad12, grad21, None, None, None, None, None, None
+            return (grad_both,) + (None,) * 9
+        return (grad12, grad21) + (None,) * 8
 
 
 def _stacked_base(flow12, flow21):
@@ -231,9 +242,10 @@ def pair_consist(
     if _is_fused_l1(criterion) and image.shape[1] == 3 and jitter_mask.shape[1] in (1, 3) and image.shape[-1] >= 2:
         want_debug = outputs == "full"
         stacked = _stacked_base(recons_flow[0], recons_flow[1])
+        coverage, coverage_size = getattr(stacked, "_hoc_coverage", (None, 0)) if stacked is not None else (None, 0)
         res = _PairConsistFunction.apply(stacked if stacked is not None else recons_flow[0],
                                          None if stacked is not None else recons_flow[1], image_ref, image,
-                                         jitter_mask_ref, jitter_mask, 0.99999, want_debug)
+                                         jitter_mask_ref, jitter_mask, 0.99999, want_debug, coverage, coverage_size)
         losses_fwd, losses_bwd = res[0], res[1]
         warp_loss = losses_bwd + losses_fwd if use_backward else losses_fwd
         if not want_debug:

@@ -324,10 +324,11 @@ class _StackedFlowFunction(torch.autograd.Function):
                   width, 0.03, 0.99999, st)
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width)
         ctx.save_for_backward(verts, fidx, fim, tile_hit, wmap, depth, mask, alpha, occl)
-        return flow
+        ctx.mark_non_differentiable(tile_hit)
+        return flow, tile_hit
 
     @staticmethod
-    def backward(ctx, grad_flow):
+    def backward(ctx, grad_flow, _grad_hit=None):
         verts, fidx, fim, tile_hit, wmap, depth, mask, alpha, occl = ctx.saved_tensors
         is_, eps, fill_back, height, width = ctx.cfg
         if grad_flow is None or not ctx.needs_input_grad[2]:
@@ -401,9 +402,12 @@ def get_opticalflow(
             is_ = int(neurenderer.image_size)
             W, H = (orig_img_size[0], orig_img_size[1]) if orig_img_size is not None else (is_, is_)
             lut = _keep_lut(ignore_face_idxs, dev) if ignore_face_idxs is not None else None
-            flows = _StackedFlowFunction.apply(
+            flows, tile_hit = _StackedFlowFunction.apply(
                 ndc, _stacked_faces(faces), cols, lut, neurenderer.fill_back, is_, neurenderer.near, neurenderer.far,
                 neurenderer.rasterizer_eps, neurenderer.background_color, min(int(H), is_), min(int(W), is_))
+            # the coverage bytes of the two renders ride along: a consumer that knows them (pair_consist) does not
+            # even read the flows where nothing was rendered (they are exactly zero there)
+            flows._hoc_coverage = (tile_hit, is_)
             return [flows[:B], flows[B:]]
         # both renders of the pair as one launch over 2B meshes, in the training path's output set (no depth /
         # weight maps, third colour plane untouched, flow mask folded into the render)

@@ -383,7 +383,12 @@ MR_API int64_t mr_pair_consist_workspace_bytes(int batch_size, int height, int w
  *   full_mask1/2[B,H,W] u8    warp_mask1/2[B,3,H,W]    warp1/2[B,3,H,W]    diff1/2[B,3,H,W]
  * The reduction is two-stage and deterministic (no float atomics).  Requires width >= 2 and
  * height * width <= 2^29 (the two taps of a row are fetched with one 8-byte load at a 32-bit
- * byte offset); smaller images go through mr_warp_forward. */
+ * byte offset); smaller images go through mr_warp_forward.
+ * tile_hit12 / tile_hit21 (optional, both or neither): the coverage bytes [B, tiles_y, tiles_x, 4] that
+ * mr_render_flow_forward wrote for the renders behind flow12 / flow21 (raster side hit_image_size >= height, width;
+ * the flows are the top-left height x width crop of the image-oriented raster).  A rendered flow is exactly zero
+ * where its render covered nothing -- such pixels add nothing to the sums -- and with the bytes given it is not even
+ * read there (the flows stay fully defined tensors; NULL, NULL, 0 = read everything). */
 MR_API int mr_pair_consist_forward(const float* flow12, const float* flow21, const float* image_ref,
                             const float* image, const float* jitter_ref, const float* jitter,
                             int jitter_channels, void* workspace, int64_t workspace_bytes,
@@ -391,17 +396,19 @@ MR_API int mr_pair_consist_forward(const float* flow12, const float* flow21, con
                             uint8_t* full_mask2, float* warp_mask1, float* warp_mask2,
                             float* warp1, float* warp2, float* diff1, float* diff2,
                             int batch_size, int height, int width, float thresh,
+                            const uint8_t* tile_hit12, const uint8_t* tile_hit21, int hit_image_size,
                             mr_stream_t stream);
 
 /* Adjoint of the pair loss w.r.t. the two flows (the only differentiable inputs on the
- * training path): grad_flow12/21[B,H,W,2] fully written.  grad_loss_fwd/bwd[B] are the
+ * training path): grad_flow12/21[B,H,W,2] fully written (zeros where the coverage bytes say so).  grad_loss_fwd/bwd[B] are the
  * incoming gradients of loss_fwd / loss_bwd (grad_loss_bwd may be NULL). */
 MR_API int mr_pair_consist_backward(const float* flow12, const float* flow21, const float* image_ref,
                              const float* image, const float* jitter_ref, const float* jitter,
                              int jitter_channels, const float* sums,
                              const float* grad_loss_fwd, const float* grad_loss_bwd,
                              float* grad_flow12, float* grad_flow21, int batch_size,
-                             int height, int width, float thresh, mr_stream_t stream);
+                             int height, int width, float thresh, const uint8_t* tile_hit12,
+                             const uint8_t* tile_hit21, int hit_image_size, mr_stream_t stream);
 
 /* ---- dataset pipeline: decoded frames -> network-input batch ------------------------------
  * One launch for a whole batch of what meshreg/datasets/handobjset.py:361-379 does per sample on the

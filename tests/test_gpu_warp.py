@@ -451,6 +451,62 @@ def test_meshreg_post_hip_matches_torch_ops(cuda, B, Vo, monkeypatch):
             close(ga.cpu().numpy(), gb.cpu().numpy(), 2e-4, 2e-5 * float(gb.abs().max()) + 1e-12, f"grad {name} {subset}")
 
 
+@pytest.mark.parametrize("B,is_,H,Wd", [(2, 128, 96, 128), (3, 64, 64, 64)])
+def test_pair_loss_with_coverage_bytes_equals_dense(cuda, B, is_, H, Wd):
+    """The stacked get_opticalflow hands the coverage bytes of its renders to pair_consist, which then does not read
+    the flows where nothing was rendered: same losses and flow gradients as the dense call, bit for bit -- also when
+    those flow values are poisoned (proof that they are not read)."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import imgflowarp, opticalflow
+
+    s = synth.random_scene(B, seed=31, image_size=is_)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
+                   no_light=True, light_intensity_ambient=0.8)
+    flows = opticalflow.get_opticalflow([t(s["verts1"], cuda), t(s["verts2"], cuda)], t(s["faces"], cuda),
+                                        [t(s["K1"], cuda), t(s["K2"], cuda)], ren, orig_img_size=(Wd, H),
+                                        detach_textures=False, detach_renders=True,
+                                        ignore_face_idxs=synth.HAND_IGNORE_FACES)
+    base = flows[0]._base
+    coverage, cov_size = base._hoc_coverage
+    assert cov_size == is_ and coverage.shape == (2 * B, is_ // 8, is_ // 32, 4)
+    im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, H, Wd, 3)]
+    crit = PyramidCriterion(criterion="l1")
+
+    def run(stacked_flows, with_coverage):
+        fl = stacked_flows.detach().clone().requires_grad_(True)
+        if with_coverage:
+            fl._hoc_coverage = (coverage, cov_size)
+        loss, _, _, _ = imgflowarp.pair_consist([fl[:B], fl[B:]], im_ref, im, jm_ref, jm, crit, use_backward=True,
+                                                outputs="loss")
+        loss.sum().backward()
+        return loss.detach(), fl.grad
+
+    calls = []
+    real_call = imgflowarp._lib.call
+    imgflowarp._lib.call = lambda name, *a: (calls.append((name, a)), real_call(name, *a))[1]
+    try:
+        loss_c, grad_c = run(base, True)
+    finally:
+        imgflowarp._lib.call = real_call
+    fwd_args = [a for n, a in calls if n == "mr_pair_consist_forward"][0]
+    assert fwd_args[-4].value and fwd_args[-3].value and fwd_args[-2] == is_, "the coverage bytes must reach the C-ABI"
+    loss_d, grad_d = run(base, False)
+    assert torch.equal(loss_c, loss_d) and torch.equal(grad_c, grad_d)
+    assert float(loss_d.abs().sum()) > 0 and float(grad_d.abs().sum()) > 0
+    # poison the flow wherever the coverage bytes say "nothing rendered" (image orientation: raster row is_ - 1 - y)
+    hit = coverage.view(2 * B, is_ // 8, is_ // 32, 4).cpu().numpy()
+    yy, xx = np.mgrid[0:H, 0:Wd]
+    ry = is_ - 1 - yy
+    covered = hit[:, ry >> 3, xx >> 5, (ry & 7) >> 1] != 0          # [2B, H, Wd]
+    poisoned = base.detach().clone()
+    poisoned[~torch.from_numpy(covered).to(cuda)] = float("nan")
+    assert int((~covered).sum()) > 0
+    loss_p, grad_p = run(poisoned, True)
+    assert torch.equal(loss_p, loss_d) and torch.equal(grad_p, grad_d)
+
+
 @pytest.mark.parametrize("B,is_,H,W", [(2, 64, 64, 64), (3, 96, 54, 96), (1, 40, 27, 33)])
 def test_occlusion_flow_equals_occlusion_then_finalize(cuda, B, is_, H, W):
     """mr_occlusion_flow == mr_occlusion_mask followed by mr_flow_finalize_forward for both directions (SURVEY Q4
