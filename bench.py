@@ -460,7 +460,7 @@ def main():
     # single-workgroup kernel: 91 us for 25 MFLOP, twice per step): every GEMM shape is timed over the rocBLAS / hipBLASLt
     # solutions at its first call, inside the warm-up steps; 26.8 instead of 27.2 ms per step.  HOC_TUNABLEOP=0 disables.
     # Its results file goes to the temp directory, not the working tree.
-    if os.environ.get("HOC_TUNABLEOP", "1") == "1":
+    if os.environ.get("HOC_TUNABLEOP", "1") == "1" and not (args.kernels_only or args.roofline_only or args.hot_only):
         import tempfile
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(True)
