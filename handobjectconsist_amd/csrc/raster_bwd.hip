@@ -1518,10 +1518,11 @@ pixel_map_packed_kernel(PixelMapParams p, const PixRec* __restrict__ rec_row, co
     __shared__ PmSweep sweeps[256 / MR_WAVE][PM_SW_CAP];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned count = *counter;
-    const unsigned G = gridDim.x, x = blockIdx.x & 7u;
-    const unsigned waves_x = ((G - x + 7u) / 8u) * (256 / MR_WAVE);  // waves of the workgroups with blockIdx % 8 == x
-    const unsigned lo = (unsigned)((uint64_t)count * x / 8u), hi = (unsigned)((uint64_t)count * (x + 1u) / 8u);
-    for (unsigned idx = lo + (blockIdx.x / 8u) * (256 / MR_WAVE) + wave; idx < hi; idx += waves_x)
+    // nq slices of the list, one per XCD (a launch of fewer than 8 workgroups has that many slices)
+    const unsigned G = gridDim.x, nq = min(G, 8u), x = blockIdx.x % nq;
+    const unsigned waves_x = ((G - x + nq - 1u) / nq) * (256 / MR_WAVE);  // waves of the workgroups with blockIdx % nq == x
+    const unsigned lo = (unsigned)((uint64_t)count * x / nq), hi = (unsigned)((uint64_t)count * (x + 1u) / nq);
+    for (unsigned idx = lo + (blockIdx.x / nq) * (256 / MR_WAVE) + wave; idx < hi; idx += waves_x)
         pm_walk_face(p, rec_row, rec_col, (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)list[idx]), lane, sweeps[wave]);
 }
 

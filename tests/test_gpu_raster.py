@@ -174,6 +174,25 @@ def test_fused_backward_matches_oracle(cuda, kind, B, is_, seed, reference_algo)
     assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * scale_f, "grad_faces")
 
 
+@pytest.mark.parametrize("n", [1, 3, 7])
+def test_fused_backward_few_faces(cuda, n):
+    """2n faces: kernel D's persistent walk kernel is launched with fewer workgroups than it has list slices for a
+    full chip (one per XCD) -- every owning face must still be walked."""
+    from handobjectconsist_amd.neurender import rasterize
+
+    faces, tex = big_faces(1, 64, 40 + n, n=n)
+    ref = R.rasterize_rgbad(faces, tex, 64, False, 0.1, 100, 1e-3, (0.0, 0.0, 0.0), num_threads=8, keep_saved=True)
+    saved = ref["_saved"]
+    raster_g, img_g = _img_grads(saved, n)
+    gf_ref, gt_ref = R.rasterize_backward(saved, *raster_g, num_threads=8)
+    f_t, x_t = t(faces, cuda).requires_grad_(True), t(tex, cuda).requires_grad_(True)
+    out = rasterize.rasterize_rgbad(f_t, x_t, 64, False, 0.1, 100, 1e-3, (0.0, 0.0, 0.0))
+    torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]], [t(g, cuda) for g in img_g])
+    assert np.abs(gf_ref).max() > 0
+    assert_close(x_t.grad.cpu().numpy(), gt_ref, 1e-4, 1e-5 * np.abs(gt_ref).max(), "grad_textures")
+    assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * np.abs(gf_ref).max(), "grad_faces")
+
+
 def test_training_mode_textures_only(cuda):
     """detach_renders=True (warpbranch.py:65-66): only grad_textures is live.  The gather sums a
     face's pixels as four row-interleaved partial sums (fixed order), so it matches the serial
