@@ -131,9 +131,12 @@ def kernel_bench(dev, B, is_, iters, only=None):
     g_rgb, g_alpha, g_depth = torch.randn_like(rgb), torch.randn_like(alpha), torch.randn_like(depth)
     grad_tex, grad_faces = torch.empty_like(tex2), torch.empty_like(faces)
 
-    def render_bwd_train():  # detach_renders=True: textures only (kernel E)
+    bl_bytes = int(lib.mr_render_backward_list_workspace_bytes(B, F))
+    bl_work = torch.empty((bl_bytes,), dtype=torch.uint8, device=dev)
+
+    def render_bwd_train():  # detach_renders=True: textures only (kernel E), as neurender.rasterize launches it
         _lib.call("mr_render_backward", P(faces), P(tex2), P(fim), P(rgb), P(alpha), P(g_rgb), None, None, None,
-                  P(grad_tex), None, 0, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+                  P(grad_tex), P(bl_work), bl_bytes, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
 
     bw_bytes = int(lib.mr_render_backward_workspace_bytes(B, F, is_))
     bw_work = torch.empty((bw_bytes,), dtype=torch.uint8, device=dev)

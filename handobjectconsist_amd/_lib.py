@@ -30,6 +30,7 @@ SIGNATURES = {
     "mr_render_forward": (_I, [_P, _P, _P, _I] + [_P] * 7 + [_L, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
     "mr_face_inv_map": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mr_render_backward_workspace_bytes": (_L, [_I, _I, _I]),
+    "mr_render_backward_list_workspace_bytes": (_L, [_I, _I]),
     "mr_render_backward": (_I, [_P] * 11 + [_L, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
     "mr_render_vc_forward": (_I, [_P, _P, _P, _P, _I] + [_P] * 6 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
     "mr_render_vc_backward": (_I, [_P] * 7 + [_I, _I, _I, _I, _I, _F, _I, _P]),

@@ -54,6 +54,10 @@ struct GatherParams {
     int B, F, is;
     float eps;
     int accumulate_faces;     // 1: grad_faces already holds the pixel-map term
+    // optional list of the faces that own a pixel (compact_owners_kernel): only those are walked, the rows of the
+    // others were zeroed when the list was built
+    const uint32_t* owners;
+    const unsigned* n_owners;
 };
 
 template <bool IMG, bool TEX, bool DEPTH>
@@ -125,12 +129,15 @@ __device__ __forceinline__ void gather_store(const GatherParams& p, int64_t i, c
 template <bool IMG, bool TEX, bool DEPTH>
 __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
     constexpr int NT = TEX ? 24 : 1, NF = DEPTH ? 9 : 1;
-    const int64_t total = (int64_t)p.B * p.F;
-    const int64_t gid = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    const int64_t i = gid / GLPF;
+    const int64_t total = p.owners ? (int64_t)*p.n_owners : (int64_t)p.B * p.F;
+    // (owner list: the entries in use are the first ones -- plain block order, so that they spread over the XCDs)
+    const int64_t gid = (int64_t)(p.owners ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
+    if ((gid - threadIdx.x) / GLPF >= total) return;  // block-uniform: nothing left in the list
+    const int64_t slot = gid / GLPF;
     const int sub = (int)(gid % GLPF);
     const int lane = threadIdx.x & 63;
-    const bool valid = i < total;
+    const bool valid = slot < total;
+    const int64_t i = p.owners ? (valid ? (int64_t)p.owners[slot] : 0) : slot;
     const int b = valid ? (int)(i / p.F) : 0;
     const int fn = valid ? (int)(i % p.F) : 0;
     const int is = p.is;
@@ -969,6 +976,7 @@ struct PixelMapParams {
     int return_rgb, return_alpha;
     int write_backfacing;  // fused path: also zero the rows of culled faces
     int dbg;               // profiling experiments (flags >> 8)
+    float* zero_textures;  // nullable: [B*F, 24] texture-gradient rows, zeroed for the faces that own no pixel
 };
 
 template <bool IMG>
@@ -1248,6 +1256,29 @@ struct __attribute__((aligned(16))) PmSweep {
 };
 constexpr int PM_SW_CAP = 2 * MR_WAVE;  // per round of 64 items: an "out" and a long "in" sweep per lane at most
 
+// owns[b * F + face] = 1 for every face that won a pixel (four pixels per thread; kernel D's pack pass does this on
+// the side, launches without D need it on its own)
+__global__ void __launch_bounds__(256) mark_owners_kernel(const int32_t* __restrict__ fim, uint8_t* __restrict__ owns,
+                                                          int64_t npx4, int64_t px_per_image, int F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx4) return;
+    const int4 f = reinterpret_cast<const int4*>(fim)[i];
+    uint8_t* o = owns + ((i * 4) / px_per_image) * F;
+    if (f.x >= 0) o[f.x] = 1;
+    if (f.y >= 0) o[f.y] = 1;
+    if (f.z >= 0) o[f.z] = 1;
+    if (f.w >= 0) o[f.w] = 1;
+}
+
+__global__ void __launch_bounds__(256) mark_owners_scalar_kernel(const int32_t* __restrict__ fim,
+                                                                 uint8_t* __restrict__ owns, int64_t npx,
+                                                                 int64_t px_per_image, int F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const int f = fim[i];
+    if (f >= 0) owns[(i / px_per_image) * F + f] = 1;
+}
+
 // The faces that own a pixel (typically a fifth of them), compacted into a list for the walk kernel; the others get
 // their zero rows here.  One workgroup per 4096 faces, ONE global atomic each.
 constexpr int CO_TPB = 1024, CO_PER = 4;
@@ -1264,9 +1295,16 @@ __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p
     for (int k = 0; k < CO_PER; k++) {
         const int64_t i = (int64_t)blockIdx.x * (CO_TPB * CO_PER) + k * CO_TPB + tid;
         own[k] = i < total && owns[i] != 0;
-        if (i < total && !own[k] && (p.write_backfacing || !backfacing(p.faces + i * 9))) {
+        if (i < total && !own[k]) {
+            if (p.grad_faces && (p.write_backfacing || !backfacing(p.faces + i * 9))) {
 #pragma unroll
-            for (int c = 0; c < 9; c++) p.grad_faces[i * 9 + c] = 0.0f;
+                for (int c = 0; c < 9; c++) p.grad_faces[i * 9 + c] = 0.0f;
+            }
+            if (p.zero_textures) {
+                float4* o = reinterpret_cast<float4*>(p.zero_textures + i * 24);
+#pragma unroll
+                for (int c = 0; c < 6; c++) o[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
         }
         const unsigned long long m = __ballot(own[k]);
         unsigned wbase = 0u;
@@ -1536,10 +1574,28 @@ static int launch1d(K kernel, int64_t n, hipStream_t s, A... args) {
     return MR_OK;
 }
 
+// backward workspace: per-face "owns a pixel" flags | owner count | owner list | packed records, row- and column-major
+// (the gather alone needs the first three)
+struct OwnerList {
+    uint8_t* owns;
+    unsigned* counter;
+    uint32_t* list;
+    size_t owns_bytes;
+};
+static int64_t owner_list_bytes(int B, int F) {
+    return (((int64_t)B * F + 255) & ~255LL) + 256 + (((int64_t)B * F * 4 + 255) & ~255LL);
+}
+static OwnerList owner_list(void* workspace, int B, int F) {
+    OwnerList o;
+    o.owns = (uint8_t*)workspace;
+    o.owns_bytes = (size_t)(((int64_t)B * F + 255) & ~255LL);
+    o.counter = (unsigned*)(o.owns + o.owns_bytes);
+    o.list = (uint32_t*)(o.owns + o.owns_bytes + 256);
+    return o;
+}
+
 static int64_t pixel_map_workspace_bytes(int B, int F, int is) {
-    // packed records (row- and column-major) | per-face "owns a pixel" flags | owner count | owner list
-    return 2LL * (int64_t)B * is * is * (int64_t)sizeof(PixRec) + (((int64_t)B * F + 255) & ~255LL) + 256 +
-           (((int64_t)B * F * 4 + 255) & ~255LL);
+    return owner_list_bytes(B, F) + 2LL * (int64_t)B * is * is * (int64_t)sizeof(PixRec);
 }
 
 // kernel D: packed walks when a workspace of pixel_map_workspace_bytes is available, else the
@@ -1551,14 +1607,14 @@ static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t wo
     if (!workspace || workspace_bytes < pixel_map_workspace_bytes(p.B, p.F, p.is) || (flags & MR_FLAG_REFERENCE_ALGO) ||
         (int64_t)p.is * p.is > (1LL << 26))
         return launch1d(pixel_map_kernel<IMG>, nfaces * MR_WAVE, s, p);
-    PixRec* rec_row = (PixRec*)workspace;
+    PixRec* rec_row = (PixRec*)((char*)workspace + owner_list_bytes(p.B, p.F));
     PixRec* rec_col = rec_row + (int64_t)p.B * p.is * p.is;
-    uint8_t* owns = (uint8_t*)(rec_col + (int64_t)p.B * p.is * p.is);
-    const size_t owns_bytes = (size_t)((nfaces + 255) & ~255LL);
-    unsigned* counter = (unsigned*)(owns + owns_bytes);
-    uint32_t* list = (uint32_t*)(owns + owns_bytes + 256);
+    const OwnerList ol = owner_list(workspace, p.B, p.F);
+    uint8_t* owns = ol.owns;
+    unsigned* counter = ol.counter;
+    uint32_t* list = ol.list;
     if (nfaces > 0xffffffffLL) return MR_ERR_BADARG;
-    hipError_t e = hipMemsetAsync(owns, 0, owns_bytes + 256, s);  // flags and the counter behind them
+    hipError_t e = hipMemsetAsync(owns, 0, ol.owns_bytes + 256, s);  // flags and the counter behind them
     if (e != hipSuccess) return (int)e;
     const int tiles = (p.is + PK_T - 1) / PK_T;
     const int64_t nblk = (int64_t)p.B * tiles * tiles;
@@ -1583,6 +1639,11 @@ static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t wo
 }  // namespace mr
 
 using namespace mr;
+
+extern "C" int64_t mr_render_backward_list_workspace_bytes(int batch_size, int num_faces) {
+    if (batch_size < 0 || num_faces < 0) return MR_ERR_BADARG;
+    return owner_list_bytes(batch_size, num_faces);
+}
 
 extern "C" int64_t mr_render_backward_workspace_bytes(int batch_size, int num_faces, int image_size) {
     if (batch_size < 0 || num_faces < 0 || image_size <= 0) return MR_ERR_BADARG;
@@ -1666,15 +1727,40 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
     // D: pixel-map term (writes all 9 slots of every face row)
     const bool want_d = grad_faces && ((return_rgb && grad_rgb_img && rgb_img) ||
                                        (return_alpha && grad_alpha_img && alpha_img));
+    const bool want_f = grad_faces && return_depth && grad_depth_img;
+    const bool gather_tex = grad_textures && texture_size == 2 && eps >= 1e-6f && !(flags & 1);
+    const bool run_gather = (gather_tex || grad_faces) && (gather_tex || want_f || !want_d);
+    // with a workspace the faces that own a pixel are listed once (kernel D needs the list anyway) and the gather
+    // walks only those: the others -- four fifths of a hand + object mesh -- get their zero rows when the list is built
+    const bool packed_d = workspace && workspace_bytes >= pixel_map_workspace_bytes(batch_size, num_faces, image_size) &&
+                          !(flags & MR_FLAG_REFERENCE_ALGO) && (int64_t)image_size * image_size <= (1LL << 26) &&
+                          nfaces <= 0xffffffffLL;  // (launch_pixel_map's own test)
+    const bool use_list = want_d ? packed_d
+                                 : (workspace && workspace_bytes >= owner_list_bytes(batch_size, num_faces) &&
+                                    !(flags & MR_FLAG_REFERENCE_ALGO) && nfaces <= 0xffffffffLL);
     if (want_d) {
         const int rr = return_rgb && grad_rgb_img && rgb_img, ra = return_alpha && grad_alpha_img && alpha_img;
         PixelMapParams p{faces, face_index_map, rgb_img, alpha_img, grad_rgb_img, grad_alpha_img,
                          grad_faces, batch_size, num_faces, image_size, eps, rr, ra, 1, flags >> 8};
+        p.zero_textures = (use_list && run_gather && gather_tex) ? grad_textures : nullptr;
         rc = launch_pixel_map<true>(p, workspace, workspace_bytes, flags, s);
         if (rc != MR_OK) return rc;
+    } else if (use_list && run_gather) {
+        const OwnerList ol = owner_list(workspace, batch_size, num_faces);
+        hipError_t e = hipMemsetAsync(ol.owns, 0, ol.owns_bytes + 256, s);  // flags and the counter behind them
+        if (e != hipSuccess) return (int)e;
+        const int64_t ppi = (int64_t)image_size * image_size;
+        if (ppi % 4 == 0) rc = launch1d(mark_owners_kernel, npx / 4, s, face_index_map, ol.owns, npx / 4, ppi, num_faces);
+        else rc = launch1d(mark_owners_scalar_kernel, npx, s, face_index_map, ol.owns, npx, ppi, num_faces);
+        if (rc != MR_OK) return rc;
+        PixelMapParams q{};
+        q.faces = faces; q.grad_faces = grad_faces; q.B = batch_size; q.F = num_faces; q.is = image_size;
+        q.write_backfacing = 1;
+        q.zero_textures = gather_tex ? grad_textures : nullptr;
+        hipLaunchKernelGGL(compact_owners_kernel, dim3((unsigned)((nfaces + CO_TPB * CO_PER - 1) / (CO_TPB * CO_PER))),
+                           dim3(CO_TPB), 0, s, q, (const uint8_t*)ol.owns, ol.counter, ol.list);
+        MR_CHECK_LAUNCH();
     }
-    const bool want_f = grad_faces && return_depth && grad_depth_img;
-    const bool gather_tex = grad_textures && texture_size == 2 && eps >= 1e-6f && !(flags & 1);
     if (grad_textures && !gather_tex) {
         const size_t bytes = (size_t)nfaces * texture_size * texture_size * texture_size * 3 * sizeof(float);
         hipError_t e = hipMemsetAsync(grad_textures, 0, bytes, s);
@@ -1683,7 +1769,7 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
                       grad_textures, npx, num_faces, image_size, texture_size, eps);
         if (rc != MR_OK) return rc;
     }
-    if (gather_tex || grad_faces) {
+    if (run_gather) {
         GatherParams g{};
         g.faces = faces; g.fim = face_index_map;
         g.grad_rgb = gather_tex ? grad_rgb_img : nullptr;
@@ -1692,13 +1778,15 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
         g.grad_textures = gather_tex ? grad_textures : nullptr;
         g.B = batch_size; g.F = num_faces; g.is = image_size; g.eps = eps;
         g.accumulate_faces = want_d ? 1 : 0;
-        if (gather_tex || want_f || !want_d) {
-            const int64_t nthreads = nfaces * GLPF;
-            if (gather_tex && want_f) rc = launch1d(gather_kernel<true, true, true>, nthreads, s, g);
-            else if (gather_tex) rc = launch1d(gather_kernel<true, true, false>, nthreads, s, g);
-            else if (want_f) rc = launch1d(gather_kernel<true, false, true>, nthreads, s, g);
-            else rc = launch1d(gather_kernel<true, false, false>, nthreads, s, g);
+        if (use_list) {
+            const OwnerList ol = owner_list(workspace, batch_size, num_faces);
+            g.owners = ol.list; g.n_owners = ol.counter;
         }
+        const int64_t nthreads = nfaces * GLPF;
+        if (gather_tex && want_f) rc = launch1d(gather_kernel<true, true, true>, nthreads, s, g);
+        else if (gather_tex) rc = launch1d(gather_kernel<true, true, false>, nthreads, s, g);
+        else if (want_f) rc = launch1d(gather_kernel<true, false, true>, nthreads, s, g);
+        else rc = launch1d(gather_kernel<true, false, false>, nthreads, s, g);
     }
     return rc;
 }

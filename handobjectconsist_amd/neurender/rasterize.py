@@ -259,10 +259,11 @@ class RasterizeFusedFunction(Function):
             else:
                 grad_textures = torch.empty_like(tex)
         if want_faces or want_tex:
-            work, wbytes = None, 0
             if want_faces and (g_rgb is not None or g_alpha is not None):  # kernel D runs: packed-walk scratch
                 wbytes = int(_lib.load().mr_render_backward_workspace_bytes(B, Fn, is_))
-                work = torch.empty((max(wbytes, 8),), dtype=torch.uint8, device=dev)
+            else:  # the list of the faces that own a pixel (the gather walks only those)
+                wbytes = int(_lib.load().mr_render_backward_list_workspace_bytes(B, Fn))
+            work = torch.empty((max(wbytes, 8),), dtype=torch.uint8, device=dev)
             _lib.call("mr_render_backward", _lib.ptr(faces), _lib.ptr(tex) if rr else None, _lib.ptr(fim),
                       _lib.ptr(rgb) if rr else None, _lib.ptr(alpha) if ra else None, _lib.ptr(g_rgb),
                       _lib.ptr(g_alpha), _lib.ptr(g_depth), _lib.ptr(grad_faces),

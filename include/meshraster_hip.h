@@ -148,8 +148,11 @@ MR_API int mr_face_inv_map(const float* faces, const int32_t* face_index_map, fl
  * workspace: optional scratch of mr_render_backward_workspace_bytes() bytes; with it kernel D
  * walks two packed copies of the maps (row- and column-major 32-byte records) instead of eight
  * strided planes.  NULL / too small: the plane-reading kernel runs (same result up to fp32
- * summation order). */
+ * summation order).  The workspace also holds the list of the faces that own a pixel: kernel D and the E / F gather
+ * then walk only those (a fifth of a hand + object mesh).  A call without the pixel-map term needs only that list:
+ * mr_render_backward_list_workspace_bytes() bytes. */
 MR_API int64_t mr_render_backward_workspace_bytes(int batch_size, int num_faces, int image_size);
+MR_API int64_t mr_render_backward_list_workspace_bytes(int batch_size, int num_faces);
 MR_API int mr_render_backward(const float* faces, const float* textures,
                        const int32_t* face_index_map, const float* rgb_img,
                        const float* alpha_img, const float* grad_rgb_img,
