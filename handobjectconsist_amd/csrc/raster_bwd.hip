@@ -1285,6 +1285,7 @@ constexpr int CO_TPB = 1024, CO_PER = 4;
 __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p, const uint8_t* __restrict__ owns,
                                                                 unsigned* __restrict__ counter, uint32_t* __restrict__ list) {
     __shared__ unsigned s_cnt, s_base;
+    __shared__ uint8_t s_own[CO_TPB * CO_PER];
     const int64_t total = (int64_t)p.B * p.F;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) s_cnt = 0u;
@@ -1295,17 +1296,9 @@ __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p
     for (int k = 0; k < CO_PER; k++) {
         const int64_t i = (int64_t)blockIdx.x * (CO_TPB * CO_PER) + k * CO_TPB + tid;
         own[k] = i < total && owns[i] != 0;
-        if (i < total && !own[k]) {
-            if (p.grad_faces && (p.write_backfacing || !backfacing(p.faces + i * 9))) {
-#pragma unroll
-                for (int c = 0; c < 9; c++) p.grad_faces[i * 9 + c] = 0.0f;
-            }
-            if (p.zero_textures) {
-                float4* o = reinterpret_cast<float4*>(p.zero_textures + i * 24);
-#pragma unroll
-                for (int c = 0; c < 6; c++) o[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-        }
+        // bit 0: owns a pixel; bit 1: its grad_faces row is to be zeroed here
+        const bool zero_row = i < total && !own[k] && p.grad_faces && (p.write_backfacing || !backfacing(p.faces + i * 9));
+        s_own[k * CO_TPB + tid] = (own[k] ? 1 : 0) | (zero_row ? 2 : 0);
         const unsigned long long m = __ballot(own[k]);
         unsigned wbase = 0u;
         if (lane == 0 && m) wbase = atomicAdd(&s_cnt, (unsigned)__popcll(m));
@@ -1317,6 +1310,20 @@ __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p
 #pragma unroll
     for (int k = 0; k < CO_PER; k++)
         if (own[k]) list[s_base + pos[k]] = (uint32_t)((int64_t)blockIdx.x * (CO_TPB * CO_PER) + k * CO_TPB + tid);
+    // the zero rows of the workgroup's faces without pixels (36 bytes of grad_faces, 96 bytes of texture gradient),
+    // consecutive lanes on consecutive addresses
+    const int64_t f0 = (int64_t)blockIdx.x * (CO_TPB * CO_PER);
+    const int nf = (int)min((int64_t)(CO_TPB * CO_PER), total - f0);
+    if (p.grad_faces) {
+        float* rows = p.grad_faces + f0 * 9;
+        for (int q = tid; q < nf * 9; q += CO_TPB)
+            if (s_own[q / 9] & 2) rows[q] = 0.0f;
+    }
+    if (p.zero_textures) {
+        float4* rows = reinterpret_cast<float4*>(p.zero_textures + f0 * 24);
+        for (int q = tid; q < nf * 6; q += CO_TPB)
+            if (!(s_own[q / 6] & 1)) rows[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
 }
 
 __device__ __forceinline__ void pm_walk_face(const PixelMapParams& p, const PixRec* __restrict__ rec_row,
