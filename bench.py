@@ -186,22 +186,26 @@ def kernel_bench(dev, B, is_, iters, only=None):
     keep_lut[torch.tensor(synth.HAND_IGNORE_FACES, device=dev) + 1] = 0
 
     ptile_hit = torch.empty((B2, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=dev)
+    # per-pixel records of the flow-mode render: vertex ids + sampling weights (its own weight buffer: pwmap holds the
+    # barycentrics of the full-output render)
+    pvid = torch.empty((B2, is_, is_, 3), dtype=torch.int32, device=dev)
+    pwrec = torch.empty((B2, is_, is_, 3), **f32)
     poccl = (torch.rand((B2, is_, is_), device=dev) < 0.9).float()
     pg_flow = torch.randn((B2, is_, is_, 2), **f32)
 
     def render_flow_fwd_pair():  # the training path's output set: rgb planes 0 / 1, alpha, flow mask, face index
         _lib.call("mr_render_flow_forward", P(pv), P(pf), P(pcols), P(bg), 0, P(keep_lut), int(keep_lut.numel()), 0.99999,
-                  P(prgb), P(palpha), P(pmask), P(pdepth), P(pwmap), P(pfim), P(ptile_hit), P(pwork), pwbytes, B2, pv.shape[1], F0, 1, is_, 0.1, 100.0, 1e-3,
-                  _lib.FLAG_SPARSE_TILES, st)
+                  P(prgb), P(palpha), P(pmask), None, P(pwrec), P(pfim), P(ptile_hit), P(pwork), pwbytes, B2, pv.shape[1], F0, 1, is_, 0.1, 100.0, 1e-3,
+                  _lib.FLAG_SPARSE_TILES, P(pvid), st)
 
     def render_vc_bwd_pair_recompute():  # ... and its backward: no weight / depth maps to read back
         _lib.call("mr_render_vc_backward", P(pv), P(pf), P(pfim), None, None, P(pg_rgb), P(pg_cols), B2, pv.shape[1], F0, 1,
                   is_, 1e-3, 0, st)
 
     def render_flow_bwd_pair():  # what the training step launches: flow-space gradient + epilogue masks in, d colours out
-        _lib.call("mr_render_flow_backward", P(pv), P(pf), P(pfim), P(ptile_hit), P(pwmap), P(pdepth), None, P(pg_flow),
+        _lib.call("mr_render_flow_backward", P(pv), P(pf), P(pfim), P(ptile_hit), P(pwrec), None, None, P(pg_flow),
                   P(pmask), P(pmask[:B]), P(palpha[B:]), B, P(poccl), is_, is_, P(pg_cols), B2, pv.shape[1], F0, 1, is_, 1e-3,
-                  0, st)
+                  0, P(pvid), st)
 
     render_flow_fwd_pair()
     render_vc_fwd_pair()
@@ -211,8 +215,8 @@ def kernel_bench(dev, B, is_, iters, only=None):
     pflows = torch.empty((B2, is_, is_, 2), **f32)
     pcols_flow = (pcols * 1.5).contiguous()
     _lib.call("mr_render_flow_forward", P(pv), P(pf), P(pcols_flow), P(bg), 0, P(keep_lut), int(keep_lut.numel()), 0.99999,
-              P(prgb), P(palpha), P(pmask), P(pdepth), P(pwmap), P(pfim), P(ptile_hit), P(pwork), pwbytes, B2, pv.shape[1],
-              F0, 1, is_, 0.1, 100.0, 1e-3, 0, st)
+              P(prgb), P(palpha), P(pmask), None, P(pwrec), P(pfim), P(ptile_hit), P(pwork), pwbytes, B2, pv.shape[1],
+              F0, 1, is_, 0.1, 100.0, 1e-3, 0, P(pvid), st)
     pocc = torch.empty((B2, is_, is_), **f32)
 
     def occlusion_flow():  # occlusion check + flow epilogue of both directions (what the training step launches)

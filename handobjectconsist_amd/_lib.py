@@ -34,8 +34,8 @@ SIGNATURES = {
     "mr_render_backward": (_I, [_P] * 11 + [_L, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
     "mr_render_vc_forward": (_I, [_P, _P, _P, _P, _I] + [_P] * 6 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
     "mr_render_vc_backward": (_I, [_P] * 7 + [_I, _I, _I, _I, _I, _F, _I, _P]),
-    "mr_render_flow_backward": (_I, [_P] * 11 + [_I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
-    "mr_render_flow_forward": (_I, [_P, _P, _P, _P, _I, _P, _I, _F] + [_P] * 8 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _P]),
+    "mr_render_flow_backward": (_I, [_P] * 11 + [_I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "mr_render_flow_forward": (_I, [_P, _P, _P, _P, _I, _P, _I, _F] + [_P] * 8 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _P, _P]),
     "mr_flow_vertices_forward": (_I, [_P] * 7 + [_I, _F] + [_P] * 4 + [_I, _I, _P]),
     "mr_flow_vertices_backward": (_I, [_P] * 8 + [_I, _I, _P]),
     "mr_mano_workspace_floats": (_L, [_I]),

@@ -691,6 +691,8 @@ struct ScatterTilesParams {
     const float* weight;        // [B,is,is,3] raster orientation, valid at covered pixels
     const float* depth;         // [B,is,is] image orientation, valid at covered pixels
     const uint32_t* tile_hit;   // [B, tiles] one byte per wave (row pair) of the forward's tile kernel; nullable
+    const int32_t* vid_map;     // nullable: [B,is,is,3] vertex ids of the winner, written by mr_render_flow_forward; then
+                                // `weight` holds the three sampling weights of the colour taps (not barycentrics)
     // FLOWGRAD
     const float* grad_flow;     // [B,H,W,2]
     const float* m_pre;         // [B,is,is] image orientation
@@ -732,7 +734,7 @@ __device__ __forceinline__ void st_load_grad(const ScatterTilesParams& sp, int b
     }
 }
 
-template <bool FLOWGRAD>
+template <bool FLOWGRAD, bool REC>
 __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(ScatterTilesParams sp) {
     extern __shared__ long long vtab[];  // [V * 3] rounded up to an even count
     __shared__ unsigned wmax[ST_WAVES];
@@ -816,39 +818,58 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
             const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2];
             w[0][0] = w0.x; w[0][1] = w0.y; w[0][2] = w0.z; w[1][0] = w0.w; w[1][1] = w1.x; w[1][2] = w1.y;
             w[2][0] = w1.z; w[2][1] = w1.w; w[2][2] = w2.x; w[3][0] = w2.y; w[3][1] = w2.z; w[3][2] = w2.w;
-            const float4 d4 = *reinterpret_cast<const float4*>(sp.depth + ((int64_t)b * is + (is - 1 - yi)) * is + x);
-            zp[0] = d4.x; zp[1] = d4.y; zp[2] = d4.z; zp[3] = d4.w;
+            if (REC) {
+                // per-pixel records of the forward: the winner's vertex ids next to its sampling weights -- every load
+                // of the pixel group is in flight at once, no index -> vertex chain
+                const int4* vq = reinterpret_cast<const int4*>(sp.vid_map + (((int64_t)b * is + yi) * is + x) * 3);
+                const int4 v0 = vq[0], v1 = vq[1], v2 = vq[2];
+                vid[0][0] = v0.x; vid[0][1] = v0.y; vid[0][2] = v0.z; vid[1][0] = v0.w; vid[1][1] = v1.x; vid[1][2] = v1.y;
+                vid[2][0] = v1.z; vid[2][1] = v1.w; vid[2][2] = v2.x; vid[3][0] = v2.y; vid[3][1] = v2.z; vid[3][2] = v2.w;
+            } else {
+                const float4 d4 = *reinterpret_cast<const float4*>(sp.depth + ((int64_t)b * is + (is - 1 - yi)) * is + x);
+                zp[0] = d4.x; zp[1] = d4.y; zp[2] = d4.z; zp[3] = d4.w;
+            }
         }
+        if (!REC) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const bool won = fn[j] >= 0;
-            const bool o = fn[j] >= p.F0;  // reversed copy of face fn - F0
-            const int32_t* ix = fidx_b + (int64_t)(won ? (o ? fn[j] - p.F0 : fn[j]) : 0) * 3;
+            for (int j = 0; j < 4; j++) {
+                const bool won = fn[j] >= 0;
+                const bool o = fn[j] >= p.F0;  // reversed copy of face fn - F0
+                const int32_t* ix = fidx_b + (int64_t)(won ? (o ? fn[j] - p.F0 : fn[j]) : 0) * 3;
 #pragma unroll
-            for (int k = 0; k < 3; k++) vid[j][k] = won ? ix[o ? 2 - k : k] : 0;
+                for (int k = 0; k < 3; k++) vid[j][k] = won ? ix[o ? 2 - k : k] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) vz[j][k] = fn[j] >= 0 ? verts_b[(int64_t)vid[j][k] * 3 + 2] : 1.0f;
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) vz[j][k] = fn[j] >= 0 ? verts_b[(int64_t)vid[j][k] * 3 + 2] : 1.0f;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (fn[j] < 0) continue;
-            float fv[9];
-            fv[2] = vz[j][0]; fv[5] = vz[j][1]; fv[8] = vz[j][2];
-            float tif[3];
-            tex_coords(w[j], zp[j], fv, 2, p.eps, tif);
-            // taps pn = 1, 2, 4 are the texels holding the colours of vertices 0, 1, 2
+            float wgs[3];
+            if (REC) {
+                wgs[0] = w[j][0]; wgs[1] = w[j][1]; wgs[2] = w[j][2];
+            } else {
+                float fv[9];
+                fv[2] = vz[j][0]; fv[5] = vz[j][1]; fv[8] = vz[j][2];
+                float tif[3];
+                tex_coords(w[j], zp[j], fv, 2, p.eps, tif);
+                // taps pn = 1, 2, 4 are the texels holding the colours of vertices 0, 1, 2
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int pn = 1 << k;
+                    float wg = 1.0f;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) wg *= ((pn >> q) & 1) ? (tif[q] - 0.0f) : (1.0f - (tif[q] - 0.0f));
+                    wgs[k] = wg;
+                }
+            }
             float val[9];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int pn = 1 << k;
-                float wg = 1.0f;
+            for (int k = 0; k < 3; k++)
 #pragma unroll
-                for (int q = 0; q < 3; q++) wg *= ((pn >> q) & 1) ? (tif[q] - 0.0f) : (1.0f - (tif[q] - 0.0f));
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) val[k * 3 + ch] = wg * g[j][ch];
-            }
+                for (int ch = 0; ch < 3; ch++) val[k * 3 + ch] = wgs[k] * g[j][ch];
 #pragma unroll
             for (int k = 0; k < 3; k++)
 #pragma unroll
@@ -1834,7 +1855,7 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
                                        const float* mask_x_lo, const float* mask_x_hi, int split, const float* occl,
                                        int height, int width, float* grad_vcolors, int batch_size, int num_verts,
                                        int num_faces, int fill_back, int image_size, float eps, int flags,
-                                       mr_stream_t stream) {
+                                       const int32_t* vertex_id_map, mr_stream_t stream) {
     if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0) return MR_ERR_BADARG;
     if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
     if (batch_size == 0 || num_verts == 0) return MR_OK;
@@ -1846,7 +1867,8 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
     hipError_t e = hipMemsetAsync(grad_vcolors, 0, (size_t)batch_size * num_verts * 3 * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
     if (num_faces == 0) return MR_OK;
-    if (!verts || !faces_idx || !face_index_map || !weight_map || !depth_img || !(eps >= 1e-6f)) return MR_ERR_BADARG;
+    if (!face_index_map || !weight_map || !(eps >= 1e-6f)) return MR_ERR_BADARG;
+    if (!vertex_id_map && (!verts || !faces_idx || !depth_img)) return MR_ERR_BADARG;
     const int64_t table_bytes = (((int64_t)num_verts * 3 + 1) / 2) * 16;
     // the tile walk reads 4-pixel groups with 16-byte loads and keeps the colour table in LDS
     if (image_size % 4 != 0 || table_bytes > SV_MAX_TABLE_BYTES ||
@@ -1855,14 +1877,15 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
     ScatterTilesParams sp{};
     sp.g = GatherVCParams{verts, faces_idx, face_index_map, grad_rgb_img, grad_vcolors, batch_size, num_verts, num_faces,
                           fill_back, image_size, eps, flags >> 8};
-    sp.weight = weight_map; sp.depth = depth_img; sp.tile_hit = tile_hit;
+    sp.weight = weight_map; sp.depth = depth_img; sp.tile_hit = tile_hit; sp.vid_map = vertex_id_map;
     sp.grad_flow = grad_flow; sp.m_pre = mask_pre; sp.m_x_lo = mask_x_lo; sp.m_x_hi = mask_x_hi; sp.occl = occl;
     sp.split = split; sp.H = height; sp.W = width;
     sp.tiles_x = (image_size + ST_TW - 1) / ST_TW; sp.tiles_y = (image_size + ST_TH - 1) / ST_TH;
     const int64_t blocks = (int64_t)batch_size * ST_G;
     if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
-    hipLaunchKernelGGL(flowgrad ? scatter_tiles_kernel<true> : scatter_tiles_kernel<false>, dim3((unsigned)blocks),
-                       dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
+    auto kernel = vertex_id_map ? (flowgrad ? scatter_tiles_kernel<true, true> : scatter_tiles_kernel<false, true>)
+                                : (flowgrad ? scatter_tiles_kernel<true, false> : scatter_tiles_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

@@ -273,6 +273,9 @@ struct FwdParams {
     int n_lut;
     float alpha_thresh;
     int rgb_channels;      // 3, or 2: the third colour plane is left untouched
+    int32_t* vid_map;      // VC flow mode, nullable: [B,is,is,3] raster orientation: the winner's vertex ids; with it
+                           // `weight` receives the three SAMPLING weights of the colour taps instead of the
+                           // barycentrics -- all the colour backward needs, in one load round trip per pixel
     uint8_t* tile_hit;     // nullable: [B, tiles, 4] 1 = wave w (rows 2w, 2w + 1) of the tile covers a pixel
     int sparse_tiles;      // tiles without candidate faces write their coverage bytes (0) and NOTHING else
     int sparse_wd;         // weight / depth are written at covered pixels only (their only reader, the colour
@@ -677,7 +680,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
         bary(f, px, py, zp2, w);
         (void)zp2;
         p.fim[ri] = fn;
-        if (p.weight) { p.weight[ri * 3 + 0] = w[0]; p.weight[ri * 3 + 1] = w[1]; p.weight[ri * 3 + 2] = w[2]; }
+        if (p.weight && !(VC && p.vid_map)) { p.weight[ri * 3 + 0] = w[0]; p.weight[ri * 3 + 1] = w[1]; p.weight[ri * 3 + 2] = w[2]; }
         if (p.face_inv_map)
 #pragma unroll
             for (int k = 0; k < 9; k++) p.face_inv_map[ri * 9 + k] = f.inv[k];
@@ -718,15 +721,24 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
                 // (the five taps on zero texels are skipped: their weights are finite unless a sampling coordinate is
                 // NaN, in which case the three taps below are NaN as well, and c + (+-0) == c for the sums at hand,
                 // which start at +0 and therefore are never -0)
+                float wgs[3];
 #pragma unroll
                 for (int pn = 1; pn <= 4; pn <<= 1) {
                     float wg = 1.0f;
 #pragma unroll
                     for (int k = 0; k < 3; k++) wg *= ((pn >> k) & 1) ? (tif[k] - 0.0f) : (1.0f - (tif[k] - 0.0f));
+                    wgs[pn >> 1] = wg;  // pn = 1, 2, 4 -> vertex 0, 1, 2
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
                         const float tv = (pn == 1) ? vc[0][ch] : (pn == 2) ? vc[1][ch] : vc[2][ch];
                         c[ch] += wg * tv;
+                    }
+                }
+                if (p.vid_map) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        p.vid_map[ri * 3 + k] = vid[k];
+                        if (p.weight) p.weight[ri * 3 + k] = wgs[k];
                     }
                 }
             }
@@ -1074,10 +1086,11 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
                                       float* depth_img, float* weight_map, int32_t* face_index_map, uint8_t* tile_hit,
                                       void* workspace, int64_t workspace_bytes, int batch_size,
                                       int num_verts, int num_faces, int fill_back, int image_size, float near_,
-                                      float far_, float eps, int flags, mr_stream_t stream) {
+                                      float far_, float eps, int flags, int32_t* vertex_id_map, mr_stream_t stream) {
     const int F = fill_back ? 2 * num_faces : num_faces;
     if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
     if (((!verts || !faces_idx || !vcolors) && num_faces > 0) || !face_index_map || !workspace) return MR_ERR_BADARG;
+    if (vertex_id_map && !weight_map) return MR_ERR_BADARG;
     if (!rgb_img || !alpha_img || !mask_img || !background || !(eps >= 1e-6f)) return MR_ERR_BADARG;
     if ((bg_stride != 0 && bg_stride != 3) || (keep_lut && n_lut <= 0)) return MR_ERR_BADARG;
     if (workspace_bytes < mr_render_workspace_bytes(batch_size, F, image_size)) return MR_ERR_BADARG;
@@ -1093,7 +1106,7 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
     p.background = background; p.bg_stride = bg_stride;
     p.rgb = rgb_img; p.rgb_channels = 2;
     p.alpha = alpha_img; p.mask = mask_img;
-    p.depth = depth_img; p.weight = weight_map; p.sparse_wd = 1; p.tile_hit = tile_hit;
+    p.depth = depth_img; p.weight = weight_map; p.sparse_wd = 1; p.tile_hit = tile_hit; p.vid_map = vertex_id_map;
     p.sparse_tiles = (flags & MR_FLAG_SPARSE_TILES) ? 1 : 0;
     if (p.sparse_tiles && !tile_hit) return MR_ERR_BADARG;
     p.keep_lut = keep_lut; p.n_lut = n_lut; p.alpha_thresh = alpha_thresh;

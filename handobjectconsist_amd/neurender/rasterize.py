@@ -374,7 +374,7 @@ class RasterizeFlowFunction(Function):
         _lib.call("mr_render_flow_forward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(cols), _lib.ptr(bg), bg_stride,
                   _lib.ptr(lut), int(lut.numel()) if lut is not None else 0, float(alpha_thresh), _lib.ptr(rgb),
                   _lib.ptr(alpha), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(wmap), _lib.ptr(fim), None, _lib.ptr(work), int(wbytes),
-                  B, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps), 0, _lib.stream_ptr(dev))
+                  B, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps), 0, None, _lib.stream_ptr(dev))
         ctx.cfg = (is_, float(eps), bool(fill_back))
         ctx.save_for_backward(verts, fidx, fim, wmap, depth)
         ctx.mark_non_differentiable(alpha, mask, fim)

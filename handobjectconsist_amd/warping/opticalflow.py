@@ -84,6 +84,11 @@ USE_STACKED_FLOW_NODE = True
 USE_SPARSE_TILES = True
 # tests: allocate the render's output planes filled with NaN / INT_MIN instead of uninitialised, so that any read of a
 # pixel the sparse render did not write shows up in the flows or the gradients
+# ... and leaves per-pixel RECORDS for its backward: the winner's three vertex ids and the three sampling weights their
+# colours enter the pixel with (instead of barycentrics + depth, from which the backward had to walk face index ->
+# vertex ids -> vertex depths): one load round trip per pixel in mr_render_flow_backward.  Same products, same sums.
+USE_PIXEL_RECORDS = True
+
 DEBUG_POISON_RENDER_OUTPUTS = False
 
 
@@ -301,7 +306,10 @@ class _StackedFlowFunction(torch.autograd.Function):
             new_f = lambda *shape: torch.empty(shape, **f32)
             new_i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
         rgb = new_f(B2, 3, is_, is_)
-        alpha, mask, depth = new_f(B2, is_, is_), new_f(B2, is_, is_), new_f(B2, is_, is_)
+        alpha, mask = new_f(B2, is_, is_), new_f(B2, is_, is_)
+        # the backward's inputs, valid at covered pixels only: sampling weights + vertex ids, or barycentrics + depth
+        depth = None if USE_PIXEL_RECORDS else new_f(B2, is_, is_)
+        vid = new_i(B2, is_, is_, 3) if USE_PIXEL_RECORDS else None
         wmap = new_f(B2, is_, is_, 3)
         fim = new_i(B2, is_, is_)
         tile_hit = torch.empty((B2, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=dev)
@@ -313,7 +321,7 @@ class _StackedFlowFunction(torch.autograd.Function):
                   _lib.ptr(lut), int(lut.numel()) if lut is not None else 0, 0.99999, _lib.ptr(rgb), _lib.ptr(alpha),
                   _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(wmap), _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(work), wbytes,
                   B2, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps),
-                  _lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0, st)
+                  _lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0, _lib.ptr(vid), st)
         occl = torch.empty((B2, is_, is_), **f32)
         flow = torch.empty((B2, height, width, 2), **f32)
         # occlusion check + crop / permute / mask products of both directions in one pass.  mask_flow2 is the RAW
@@ -323,13 +331,15 @@ class _StackedFlowFunction(torch.autograd.Function):
                   _lib.ptr(flow[:B]), _lib.ptr(flow[B:]), _lib.ptr(tile_hit[:B]), _lib.ptr(tile_hit[B:]), B, is_, is_, height,
                   width, 0.03, 0.99999, st)
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width)
-        ctx.save_for_backward(verts, fidx, fim, tile_hit, wmap, depth, mask, alpha, occl)
+        ctx.save_for_backward(verts, fidx, fim, tile_hit, wmap, depth if depth is not None else vid, mask, alpha, occl)
+        ctx.records = depth is None
         ctx.mark_non_differentiable(tile_hit)
         return flow, tile_hit
 
     @staticmethod
     def backward(ctx, grad_flow, _grad_hit=None):
-        verts, fidx, fim, tile_hit, wmap, depth, mask, alpha, occl = ctx.saved_tensors
+        verts, fidx, fim, tile_hit, wmap, depth_or_vid, mask, alpha, occl = ctx.saved_tensors
+        depth, vid = (None, depth_or_vid) if ctx.records else (depth_or_vid, None)
         is_, eps, fill_back, height, width = ctx.cfg
         if grad_flow is None or not ctx.needs_input_grad[2]:
             return (None,) * 12
@@ -340,7 +350,7 @@ class _StackedFlowFunction(torch.autograd.Function):
         _lib.call("mr_render_flow_backward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(wmap),
                   _lib.ptr(depth), None, _lib.ptr(g), _lib.ptr(mask), _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), B,
                   _lib.ptr(occl), height, width, _lib.ptr(grad_cols), B2, V, int(fidx.shape[1]), int(fill_back), is_, eps, 0,
-                  _lib.stream_ptr(verts.device))
+                  _lib.ptr(vid), _lib.stream_ptr(verts.device))
         return (None, None, grad_cols) + (None,) * 9
 
 

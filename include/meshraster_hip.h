@@ -201,14 +201,20 @@ MR_API int mr_render_vc_backward(const float* verts, const int32_t* faces_idx,
  * written at COVERED pixels only -- the loss never reads them and their one reader, mr_render_vc_backward, looks
  * at covered pixels only; everywhere else the buffers keep whatever they held.  tile_hit (nullable): 4 bytes per
  * 32x8 screen tile, [B, ceil(is / 8), ceil(is / 32), 4]; byte w is 1 when rows 2w, 2w + 1 of the tile hold a covered
- * pixel -- what mr_render_flow_backward skips empty tiles on.  flags: MR_FLAG_SPARSE_TILES (requires tile_hit). */
+ * pixel -- what mr_render_flow_backward skips empty tiles on.  flags: MR_FLAG_SPARSE_TILES (requires tile_hit).
+ * vertex_id_map (nullable; needs weight_map): [B,is,is,3] int32, raster orientation.  When given, every covered pixel
+ * gets the vertex ids of its winning face there and weight_map receives the three SAMPLING weights of the colour
+ * taps (the factors the colours of those vertices enter the pixel with) instead of the barycentrics; depth_img may
+ * then be NULL.  These per-pixel records are all mr_render_flow_backward needs: one load round trip per pixel
+ * instead of face index -> vertex ids -> vertex depths. */
 MR_API int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
                                   const float* background, int bg_stride, const float* keep_lut, int n_lut,
                                   float alpha_thresh, float* rgb_img, float* alpha_img, float* mask_img,
                                   float* depth_img, float* weight_map, int32_t* face_index_map, uint8_t* tile_hit,
                                   void* workspace, int64_t workspace_bytes,
                                   int batch_size, int num_verts, int num_faces, int fill_back, int image_size,
-                                  float near_, float far_, float eps, int flags, mr_stream_t stream);
+                                  float near_, float far_, float eps, int flags, int32_t* vertex_id_map,
+                                  mr_stream_t stream);
 
 /* Adjoint of mr_render_flow_forward w.r.t. vcolors, with the adjoint of the flow epilogue of get_opticalflow
  * (opticalflow.py:146-154: mask products, permute, [:2], crop) folded in.  The incoming gradient is either
@@ -218,6 +224,9 @@ MR_API int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, 
  *     for c = 2 -- never materialised.  mask_x of image b is mask_x_lo + b * is * is for b < split, else
  *     mask_x_hi + (b - split) * is * is (the two directions of a stacked frame pair use different masks).
  * weight_map / depth_img / tile_hit as written by mr_render_flow_forward (tile_hit nullable: every tile is read).
+ * vertex_id_map: as written by mr_render_flow_forward together with the sampling weights in weight_map, or NULL
+ * (weight_map then holds barycentrics and verts / faces_idx / depth_img are read instead; with the records given those
+ * three may be NULL).
  * Needs image_size to be a multiple of 4 with at most 4096 tiles, and the [V,3] table to fit LDS (V <= 2560);
  * MR_ERR_NOTIMPL otherwise
  * (callers then use mr_flow_finalize_backward + mr_render_vc_backward). */
@@ -227,7 +236,7 @@ MR_API int mr_render_flow_backward(const float* verts, const int32_t* faces_idx,
                                    const float* mask_x_lo, const float* mask_x_hi, int split, const float* occl,
                                    int height, int width, float* grad_vcolors, int batch_size, int num_verts,
                                    int num_faces, int fill_back, int image_size, float eps, int flags,
-                                   mr_stream_t stream);
+                                   const int32_t* vertex_id_map, mr_stream_t stream);
 
 /* Per-vertex front end of get_opticalflow in its training setting (SURVEY 8f "f1"): for the two
  * frames of a pair, in one launch

@@ -193,6 +193,60 @@ def test_fused_backward_few_faces(cuda, n):
     assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * np.abs(gf_ref).max(), "grad_faces")
 
 
+@pytest.mark.parametrize("B,is_,sparse", [(2, 64, False), (3, 96, True), (2, 256, True)])
+def test_flow_pixel_records_equal_stored_maps(cuda, B, is_, sparse):
+    """mr_render_flow_forward with a vertex-id map leaves per-pixel records (the winner's vertex ids + the sampling
+    weights of its three colour taps) instead of barycentrics + depth; mr_render_flow_backward on the records gives the
+    gradient of the stored-map path (same products, same fixed-point sums per workgroup), for both gradient forms."""
+    from handobjectconsist_amd import _lib
+
+    d = _vc_abi_case(cuda, B, is_, 21)
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    f32 = dict(dtype=torch.float32, device=cuda)
+    V, F0 = d["V"], d["F0"]
+    bg = torch.zeros(3, **f32)
+    wbytes = int(_lib.load().mr_render_workspace_bytes(B, 2 * F0, is_))
+    work = torch.empty((wbytes,), dtype=torch.uint8, device=cuda)
+    outs = {}
+    for rec in (False, True):
+        rgb, alpha, mask = torch.empty((B, 3, is_, is_), **f32), torch.empty((B, is_, is_), **f32), torch.empty((B, is_, is_), **f32)
+        depth = torch.full((B, is_, is_), float("nan"), **f32)
+        wmap = torch.full((B, is_, is_, 3), float("nan"), **f32)
+        fim = torch.full((B, is_, is_), -7, dtype=torch.int32, device=cuda)
+        vid = torch.full((B, is_, is_, 3), -7, dtype=torch.int32, device=cuda)
+        hit = torch.empty((B, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=cuda)
+        _lib.call("mr_render_flow_forward", P(d["v"]), P(d["fidx"]), P(d["cols"]), P(bg), 0, None, 0, 0.99999, P(rgb), P(alpha),
+                  P(mask), None if rec else P(depth), P(wmap), P(fim), P(hit), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0,
+                  1e-3, _lib.FLAG_SPARSE_TILES if sparse else 0, P(vid) if rec else None, st)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        g_rgb = torch.randn((B, 3, is_, is_), generator=g).to(cuda)
+        gf = torch.randn((B, is_, is_, 2), generator=g).to(cuda)
+        m_pre = (torch.rand((B, is_, is_), generator=g) < 0.8).float().to(cuda)
+        m_x = torch.rand((B, is_, is_), generator=g).to(cuda)
+        occl = (torch.rand((B, is_, is_), generator=g) < 0.9).float().to(cuda)
+        grads = []
+        for flowgrad in (False, True):
+            out = torch.full((B, V, 3), float("nan"), **f32)
+            _lib.call("mr_render_flow_backward", None if rec else P(d["v"]), None if rec else P(d["fidx"]), P(fim), P(hit), P(wmap),
+                      None if rec else P(depth), None if flowgrad else P(g_rgb), P(gf), P(m_pre), P(m_x), None, B, P(occl), is_, is_,
+                      P(out), B, V, F0, 1, is_, 1e-3, 0, P(vid) if rec else None, st)
+            grads.append(out)
+        outs[rec] = (rgb, fim, hit, grads, vid, wmap)
+    covered = outs[True][1] >= 0
+    if not sparse:
+        assert torch.equal(outs[False][1], outs[True][1])
+    assert torch.equal(outs[False][2], outs[True][2]), "coverage bytes"
+    assert int(covered.sum()) > 100
+    vid, wrec = outs[True][4], outs[True][5]
+    assert int((vid[covered] < 0).sum()) == 0 and int((vid[covered] >= V).sum()) == 0
+    assert torch.isfinite(wrec[covered]).all() and float(wrec[covered].min()) >= 0 and float(wrec[covered].max()) <= 1
+    for a, b_ in zip(outs[False][3], outs[True][3]):
+        assert torch.isfinite(a).all() and float(a.abs().sum()) > 0
+        # (per workgroup the sums are exact fixed-point integers of identical products; the 16 workgroups of an image
+        # then meet in fp32 global atomics, whose order varies from run to run)
+        assert_close(b_.cpu().numpy(), a.cpu().numpy(), 1e-5, 1e-6 * float(a.abs().max()), "gradient on the pixel records")
+
+
 def test_training_mode_textures_only(cuda):
     """detach_renders=True (warpbranch.py:65-66): only grad_textures is live.  The gather sums a
     face's pixels as four row-interleaved partial sums (fixed order), so it matches the serial
@@ -381,7 +435,7 @@ def _vc_backward(d, g_rgb_img, mode):
             hit = cov.reshape(B, ty, 4, 2, tx, 32).permute(0, 1, 4, 2, 3, 5).reshape(B, ty, tx, 4, 64).any(-1).to(torch.uint8).contiguous()
         _lib.call("mr_render_flow_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), P(hit), P(d["wmap"]), P(d["depth"]),
                   P(g_rgb_img), None, None, None, None, 0, None, 0, 0, P(out), d["B"], d["V"], d["F0"], 1, d["is_"], 1e-3, 0,
-                  _lib.stream_ptr(g_rgb_img.device))
+                  None, _lib.stream_ptr(g_rgb_img.device))
         return out.cpu().numpy()
     stored = mode == "stored"
     _lib.call("mr_render_vc_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), P(d["wmap"]) if stored else None,
@@ -489,7 +543,7 @@ def test_flow_backward_flow_space_gradient(cuda, B, is_, H, W):
     ref = _vc_backward(d, grad_rgb, "stored")
     out = torch.full((B2, d["V"], 3), float("nan"), dtype=torch.float32, device=cuda)
     _lib.call("mr_render_flow_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), None, P(d["wmap"]), P(d["depth"]), None,
-              P(gf), P(m_pre), P(m_lo), P(m_hi), B, P(occl), H, W, P(out), B2, d["V"], d["F0"], 1, is_, 1e-3, 0, st)
+              P(gf), P(m_pre), P(m_lo), P(m_hi), B, P(occl), H, W, P(out), B2, d["V"], d["F0"], 1, is_, 1e-3, 0, None, st)
     got = out.cpu().numpy()
     assert np.abs(ref).max() > 0 and (got[:, :, 2] == 0).all()
     assert_close(got, ref, 1e-5, 1e-6 * np.abs(ref).max(), "flow-space gradient form")
