@@ -90,7 +90,7 @@ def event_time_ms(fn, iters, warmup=5, flush=None):
 ROOF_BWD = "render_flow_backward(train,E+epilogue adjoint,2B)"
 ROOF_FWD = "render_flow_forward(train outputs,both frames=2B)"
 # the device kernels behind the two groups (names as rocprofv3 prints them)
-ROOF_KERNELS = {ROOF_BWD: ["scatter_tiles_kernel<true>"],
+ROOF_KERNELS = {ROOF_BWD: ["scatter_tiles_kernel<true, true>"],
                 ROOF_FWD: ["face_records_kernel<true>", "bin_boxes_kernel", "raster_tile_kernel<true, true>"]}
 
 

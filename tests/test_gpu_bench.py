@@ -35,7 +35,7 @@ def test_bench_single_process_line(cuda):
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert abs(roof["achieved"] - roof["algorithmic_bytes"] / (roof["launch_ms"] * 1e-3) / 1e9) <= 0.02 * roof["achieved"]
-    assert roof["device_kernels"] == ["scatter_tiles_kernel<true>"] and 0 < roof["frac_cache_warm"]
+    assert roof["device_kernels"] == ["scatter_tiles_kernel<true, true>"] and 0 < roof["frac_cache_warm"]
     fwd = line["roofline_forward"]
     assert fwd["bound"] == "hbm" and "raster_tile_kernel<true, true>" in fwd["device_kernels"] and fwd["launch_ms"] > 0
     for r in (roof, fwd):  # HBM bytes from the PMC passes this very run made (None only if rocprofv3 is unavailable)
