@@ -25,6 +25,8 @@ Files:
                            lighting, detach_renders), render_rgb / _silhouettes / _depth, project, look_at
     chain_opticalflow.npz  get_opticalflow: ignore list, non-square crop, detach_* and mask_occlusions
                            combinations; flows + d/d vertices of both frames
+    chain_opticalflow_cfg.npz  get_opticalflow (training setting) at the raster sizes of BASELINE.json's configs:
+                           480 (crop 480 x 270) and 640 (crop 640 x 480); d/d vertices in full, flows as seeded samples
     chain_warpbranch.npz   warpbranch.forward: gt_refs, use_backward, first_only, 2 and 3 frames;
                            loss, per-pair losses, flows, masks, d loss / d predicted vertices
 """
@@ -357,6 +359,50 @@ def gen_opticalflow():
     save("chain_opticalflow.npz", arrays, meta)
 
 
+def flow_grad_inputs(seed, B, H, W):
+    """The upstream gradients of the two flows, reproducible from a seed (tests regenerate them instead of reading
+    megabytes of noise from the fixture)."""
+    r = np.random.default_rng(seed)
+    return r.standard_normal((B, H, W, 2)).astype(np.float32), r.standard_normal((B, H, W, 2)).astype(np.float32)
+
+
+def gen_opticalflow_config_sizes():
+    """get_opticalflow at the raster sizes of BASELINE.json's configs 2 and 4 (480 x 270 frame pairs; 640 x 480
+    frames), training setting.  Stored: the inputs, d loss / d vertices in full, and of the two flows a seeded sample of
+    40 000 pixels each plus support counts and sums (the flows themselves are megabytes)."""
+    rng = np.random.default_rng(17)
+    arrays, meta = {}, []
+    for sname, (B, is_, crop, gseed) in {"c480": (1, 480, (480, 270), 101), "c640": (1, 640, (640, 480), 102)}.items():
+        sc = scene(rng, B, is_, hand_subdiv=3, obj_subdiv=2)
+        Vh, Fh = sc["hand1"].shape[1], sc["hand_faces"].shape[0]
+        v1 = np.concatenate([sc["hand1"], sc["obj1"]], 1)
+        v2 = np.concatenate([sc["hand2"], sc["obj2"]], 1)
+        faces = np.concatenate([sc["hand_faces"], sc["obj_faces"] + Vh], 0)[None].repeat(B, 0)
+        ignore = list(range(Fh - 24, Fh))
+        H, W = crop[1], crop[0]
+        g12, g21 = flow_grad_inputs(gseed, B, H, W)
+        a, b = T(v1, True), T(v2, True)
+        flows = ref.opticalflow.get_opticalflow([a, b], T(faces), [T(sc["K1"]), T(sc["K2"])], training_renderer(is_),
+                                                orig_img_size=crop, mask_occlusions=True, detach_textures=False,
+                                                detach_renders=True, ignore_face_idxs=ignore)
+        loss = (flows[0] * T(g12)).sum() + (flows[1] * T(g21)).sum()
+        loss.backward()
+        idx = np.random.default_rng(gseed + 1000).choice(B * H * W, 40000, replace=False)
+        arrays.update({f"{sname}_verts1": v1, f"{sname}_verts2": v2, f"{sname}_faces": faces, f"{sname}_K1": sc["K1"],
+                       f"{sname}_K2": sc["K2"], f"{sname}_grad_verts1": N(a.grad), f"{sname}_grad_verts2": N(b.grad),
+                       f"{sname}_sample_idx": idx.astype(np.int64)})
+        for i, name in enumerate(("flow12", "flow21")):
+            fl = N(flows[i]).reshape(-1, 2)
+            arrays[f"{sname}_{name}_sample"] = fl[idx]
+            arrays[f"{sname}_{name}_support"] = np.array([(fl[:, 0] != 0).sum(), (fl[:, 1] != 0).sum()], np.int64)
+            arrays[f"{sname}_{name}_sum"] = fl.astype(np.float64).sum(0)
+        meta.append(dict(key=sname, scene=sname, image_size=is_, orig_img_size=crop, ignore_face_idxs=ignore,
+                         grad_seed=gseed, batch=B))
+        print(sname, "faces", faces.shape[1], "covered px", int((flows[0][..., 0] != 0).sum()),
+              int((flows[1][..., 0] != 0).sum()), "|grad1|", float(a.grad.abs().sum()), "loss", float(loss))
+    save("chain_opticalflow_cfg.npz", arrays, meta)
+
+
 # ---------------------------------------------------------------------------------------------------
 # 4. warpbranch.forward
 # ---------------------------------------------------------------------------------------------------
@@ -434,4 +480,5 @@ if __name__ == "__main__":
     gen_rasterize()
     gen_renderer()
     gen_opticalflow()
+    gen_opticalflow_config_sizes()
     gen_warpbranch()

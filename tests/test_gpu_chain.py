@@ -271,6 +271,47 @@ def test_get_opticalflow_against_reference_glue(cuda, path):
          opticalflow.USE_STACKED_FLOW_NODE, opticalflow.USE_SPARSE_TILES, opticalflow.DEBUG_POISON_RENDER_OUTPUTS) = saved
 
 
+@pytest.mark.parametrize("poisoned", [False, True])
+def test_get_opticalflow_at_baseline_config_sizes_against_reference_glue(cuda, poisoned):
+    """The training path (stacked node: flow-mode render with sparse tiles and per-pixel records, occlusion + epilogue,
+    one backward launch) at the raster sizes of BASELINE.json's configs -- 480 (crop 480 x 270) and 640 (crop
+    640 x 480) -- against what the reference's own get_opticalflow returned on CPU: flows at 40 000 seeded pixels, their
+    support counts and sums, and d loss / d vertices of both frames in full (north-star tolerance)."""
+    from handobjectconsist_amd.warping import opticalflow
+
+    z, meta = load("chain_opticalflow_cfg.npz")
+    saved = opticalflow.DEBUG_POISON_RENDER_OUTPUTS
+    opticalflow.DEBUG_POISON_RENDER_OUTPUTS = poisoned
+    try:
+        for m in meta:
+            s, is_, (W, H), B = m["scene"], m["image_size"], m["orig_img_size"], m["batch"]
+            v1, v2 = t(z[f"{s}_verts1"], cuda, True), t(z[f"{s}_verts2"], cuda, True)
+            flows = opticalflow.get_opticalflow(
+                [v1, v2], t(z[f"{s}_faces"], cuda), [t(z[f"{s}_K1"], cuda), t(z[f"{s}_K2"], cuda)],
+                _training_renderer(is_, cuda), orig_img_size=(W, H), mask_occlusions=True, detach_textures=False,
+                detach_renders=True, ignore_face_idxs=m["ignore_face_idxs"])
+            assert hasattr(flows[0]._base, "_hoc_coverage"), "the stacked training node must have been taken"
+            idx = z[f"{s}_sample_idx"]
+            for i, name in enumerate(("flow12", "flow21")):
+                assert tuple(flows[i].shape) == (B, H, W, 2)
+                got = n(flows[i]).reshape(-1, 2)
+                want = z[f"{s}_{name}_sample"]
+                assert np.array_equal((got[:, 0] != 0).sum(), z[f"{s}_{name}_support"][0]), (s, name, "support")
+                assert np.array_equal(got[idx] != 0, want != 0), (s, name, "sampled support")
+                assert np.abs(got[idx] - want).max() <= 1e-6 * max(np.abs(want).max(), 1.0), (s, name)
+                assert np.allclose(got.astype(np.float64).sum(0), z[f"{s}_{name}_sum"], rtol=1e-5, atol=1e-3), (s, name, "sum")
+            r = np.random.default_rng(m["grad_seed"])  # = tests/golden/make_golden_chain.py::flow_grad_inputs
+            g12 = r.standard_normal((B, H, W, 2)).astype(np.float32)
+            g21 = r.standard_normal((B, H, W, 2)).astype(np.float32)
+            ((flows[0] * t(g12, cuda)).sum() + (flows[1] * t(g21, cuda)).sum()).backward()
+            for v, name in ((v1, "grad_verts1"), (v2, "grad_verts2")):
+                want = z[f"{s}_{name}"]
+                assert np.abs(want).max() > 0
+                assert norm_rel(n(v.grad), want) < 1e-4, (s, name, norm_rel(n(v.grad), want))
+    finally:
+        opticalflow.DEBUG_POISON_RENDER_OUTPUTS = saved
+
+
 def test_flow_render_equals_full_render(cuda):
     """mr_render_flow_forward (the training path's output set) against mr_render_vc_forward + mr_flow_mask on the
     same inputs: displacement planes, alpha, mask and face_index_map bit-equal; the colour gradient (barycentrics

@@ -150,6 +150,31 @@ def test_get_opticalflow_matches_reference_glue(scene):
     assert ran >= 1
 
 
+def test_get_opticalflow_config_size_matches_reference_glue():
+    """The oracle chain at the raster size of BASELINE.json's config 2 (480, crop 480 x 270) against the flows the
+    reference's own get_opticalflow returned (40 000 seeded pixels per flow + support counts)."""
+    z, meta = load("chain_opticalflow_cfg.npz")
+    m = next(mm for mm in meta if mm["scene"] == "c480")
+    s, is_ = m["scene"], m["image_size"]
+    kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
+              dist_coeffs=np.zeros((1, 5), np.float32), orig_size=is_, image_size=is_, anti_aliasing=False,
+              near=0.1, far=100, eps=1e-3)
+    flows = W.get_opticalflow(R, [z[f"{s}_verts1"], z[f"{s}_verts2"]], z[f"{s}_faces"], [z[f"{s}_K1"], z[f"{s}_K2"]], kw,
+                              orig_img_size=tuple(m["orig_img_size"]), mask_occlusions=True,
+                              ignore_face_idxs=m["ignore_face_idxs"])
+    idx = z[f"{s}_sample_idx"]
+    for i, name in enumerate(("flow12", "flow21")):
+        got = flows[i].reshape(-1, 2)
+        want = z[f"{s}_{name}_sample"]
+        # (numpy matmul here, torch matmul in the fixture: a rounding difference in the projected vertices may move
+        # a handful of edge pixels)
+        assert abs(int((got[:, 0] != 0).sum()) - int(z[f"{s}_{name}_support"][0])) <= 4
+        both = (got[idx] != 0) & (want != 0)
+        assert int(((got[idx] != 0) != (want != 0)).sum()) <= 4 and both.sum() > 1000
+        assert np.abs((got[idx] - want) * both).max() < 5e-3
+        assert np.median(np.abs(got[idx] - want)[both]) < 1e-5
+
+
 def test_warpbranch_matches_reference_glue():
     """warpbranch.forward (warpbranch.py:28-96) restated with the oracle: which vertices feed frame k,
     flows per (0, k) pair, pair_consist per pair, mean over pairs."""
