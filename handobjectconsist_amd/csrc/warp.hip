@@ -654,9 +654,11 @@ __device__ __forceinline__ DirOut pair_eval(const DirTaps& d, const DirRaw& r, i
 // 64 x 4 pixel tiles (one 256-B row per wave); logical tile id -> (sample, tile) with the XCD-aware remap so that
 // vertically adjacent tiles (which share bilinear taps) run behind the same L2.
 constexpr int PT_W = 64, PT_H = 4;
-__device__ __forceinline__ bool pair_tile_pixel(int H, int W, int tiles_x, int ntiles, int& b, int& tile, int& xx,
-                                                int& yy) {
-    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+// tiles per workgroup of the BACKWARD kernel: once most blocks leave early a launch is bound by its workgroup count (43
+// instead of 46 us in the training step).  The forward, with its block reduction per tile, is slower that way (56 us).
+constexpr int PT_SUB = 4;
+__device__ __forceinline__ bool pair_tile_pixel(unsigned lid, int H, int W, int tiles_x, int ntiles, int& b, int& tile,
+                                                int& xx, int& yy) {
     b = lid / ntiles;
     tile = lid % ntiles;
     xx = (tile % tiles_x) * PT_W + (threadIdx.x % PT_W);
@@ -698,7 +700,7 @@ __global__ void __launch_bounds__(256, 6) pair_consist_forward_kernel(PairParams
     __shared__ float red[4][4];
     const int64_t hw = (int64_t)p.H * p.W;
     int b, tile, xx, yy;
-    const bool in_img = pair_tile_pixel(p.H, p.W, p.tiles_x, p.nblk, b, tile, xx, yy);
+    const bool in_img = pair_tile_pixel(xcd_remap(blockIdx.x, gridDim.x), p.H, p.W, p.tiles_x, p.nblk, b, tile, xx, yy);
     // nothing rendered under this block in either frame: both flows are zero here, no pixel is valid -- the block's
     // partial sums are zero (no loads, no barrier), unless the per-pixel debug outputs want every pixel
     if (p.hit12 && p.hit21 && !(p.warp1 || p.warp2 || p.diff1 || p.diff2 || p.warp_mask1 || p.warp_mask2 ||
@@ -826,8 +828,12 @@ __device__ __forceinline__ float2 pair_grad(const DirTaps& d, const DirRaw& r, c
 
 __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParams p) {
     const int64_t hw = (int64_t)p.H * p.W;
+    const unsigned total = (unsigned)p.ntiles * (unsigned)p.B;
+    const unsigned lid0 = xcd_remap(blockIdx.x, gridDim.x) * PT_SUB;
+#pragma unroll 1
+    for (unsigned lid = lid0; lid < min(lid0 + PT_SUB, total); lid++) {
     int b, tile, xx, yy;
-    if (!pair_tile_pixel(p.H, p.W, p.tiles_x, p.ntiles, b, tile, xx, yy)) return;
+    if (!pair_tile_pixel(lid, p.H, p.W, p.tiles_x, p.ntiles, b, tile, xx, yy)) continue;
     const int64_t pix = (int64_t)yy * p.W + xx;
     if (p.hit12 && p.hit21 &&
         !pair_block_covered(p.hit12, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W) &&
@@ -835,7 +841,7 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
         // nothing rendered under this block in either frame: zero gradient, nothing read
         *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = make_float2(0.0f, 0.0f);
         *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = make_float2(0.0f, 0.0f);
-        return;
+        continue;
     }
     const float c1 = p.sums[b * 4 + 1], c2 = p.sums[b * 4 + 3];
     const float coef1 = p.grad_loss_fwd[b] / ((c1 == 0.0f) ? 1.0f : c1);
@@ -866,6 +872,7 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
     }
     *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = g21;
     *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = g12;
+    }
 }
 
 }  // namespace mr
@@ -1000,7 +1007,7 @@ extern "C" int mr_pair_consist_backward(const float* flow12, const float* flow21
                     grad_loss_fwd, grad_loss_bwd, grad_flow12, grad_flow21, batch_size, height, width, nblk,
                     tiles_x, thresh, tile_hit12, tile_hit21, hit_image_size, (hit_image_size + 31) / 32,
                     ((hit_image_size + 31) / 32) * ((hit_image_size + 7) / 8) * 4};
-    hipLaunchKernelGGL(pair_consist_backward_kernel, dim3((unsigned)(nblk * batch_size)), dim3(256), 0,
+    hipLaunchKernelGGL(pair_consist_backward_kernel, dim3((unsigned)((nblk * batch_size + PT_SUB - 1) / PT_SUB)), dim3(256), 0,
                        (hipStream_t)stream, p);
     MR_CHECK_LAUNCH();
     return MR_OK;
