@@ -11,7 +11,8 @@ ResNet-18 forwards, MANO LBS, 2 differentiable renders (1780 verts / 7104 faces 
 fill-back), occlusion check, 2-direction photometric pair loss, ONE backward through all of
 it, Adam step.  Inputs are synthetic (seeded) and resident in HBM before the timed region.
 Per-GPU work is fixed as N grows (weak scaling, batch-sharded DP; the model's gradients are
-all-reduced by DDP over RCCL, the render/warp kernels need no collective).
+all-reduced over RCCL in 8 MB buckets issued from inside backward -- netscripts/gradreduce.py --
+the render/warp kernels need no collective).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   "roofline":     algorithmic bytes / live HIP-event duration of the dominant hot-path kernel,
@@ -25,8 +26,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# this image's host driver supports only dmabuf IPC: without this RCCL's (and torch's) cross-process buffer
+# sharing fails with "hipIpcGetMemHandle: invalid argument".  Read when the HIP runtime starts, i.e. it has to be
+# in the environment before the first GPU call of the process; a value set by the launcher wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -480,7 +486,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    # HOC_FORCE_DDP=1: take the multi-GPU code path (RCCL process group, DDP wrapper, barriers, max-over-ranks
+    # HOC_FORCE_DDP=1: take the multi-GPU code path (RCCL process group, bucketed gradient reducer, barriers, max-over-ranks
     # all-reduce) with a single rank too -- how the path is exercised on a one-GPU box (tests/test_gpu_bench.py)
     use_dist = world > 1 or os.environ.get("HOC_FORCE_DDP", "0") == "1"
     if use_dist:
@@ -511,14 +517,20 @@ def main():
     model.eval()  # --freeze_batchnorm: BN statistics frozen, affine parameters trainable
     if args.encoder_dtype == "bf16":
         model.encoder_dtype = torch.bfloat16
-    net = model
-    if use_dist:
+    net, reducer = model, None
+    torch_ddp = os.environ.get("HOC_TORCH_DDP", "0") == "1"  # A/B only: torch's DistributedDataParallel wrapper
+    if use_dist and torch_ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
 
-        # 8 MB buckets overlap the RCCL all-reduce with the encoder backward; frozen BN statistics
-        # -> no buffer broadcast (the three forwards of a step share the buffers)
         net = DDP(model, device_ids=[dev_index], bucket_cap_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "8")),
                   broadcast_buffers=False, gradient_as_bucket_view=os.environ.get("HOC_DDP_BUCKET_VIEW", "1") == "1")
+    elif use_dist:
+        from handobjectconsist_amd.netscripts.gradreduce import BucketedGradReducer
+
+        # the model is NOT wrapped: 8 MB buckets, filled by one multi-tensor copy each from inside backward(), one
+        # asynchronous RCCL all-reduce (average) per bucket overlapping the encoder backward; frozen BN statistics
+        # -> no buffer exchange (netscripts/gradreduce.py)
+        reducer = BucketedGradReducer(model.parameters(), bucket_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "8")))
     ih_ = args.image_height or is_
     assert ih_ <= is_, "--image-height must not exceed --image-size (the raster is the square of the longer side)"
     premodel = WarpRegNet((is_, ih_), net, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
@@ -539,14 +551,14 @@ def main():
     # kept inside the timed region (HOC_CHECK_NAN=0 measures the step without it)
     check_nan = os.environ.get("HOC_CHECK_NAN", "1") == "1"
     for i in range(0 if args.hot_only else args.warmup):
-        train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan)
+        train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan, reducer=reducer)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = torch.zeros(1)
     for i in range(0 if args.hot_only else args.steps):
-        loss, _ = train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan)
+        loss, _ = train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan, reducer=reducer)
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0  # this rank's own K steps, before it waits for the others
     barrier()
@@ -564,7 +576,9 @@ def main():
         ranks = {"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "world_size": world,
                  "per_rank": [{"rank": int(r_[0]), "device": int(r_[1]), "ms_per_step": round(float(r_[2]), 3)} for r_ in allr],
                  "grad_allreduce_MB": round(sum(p_.numel() for p_ in model.parameters() if p_.requires_grad) * 4 / 1e6, 1),
-                 "ddp_bucket_MB": int(os.environ.get("HOC_DDP_BUCKET_MB", "8"))}
+                 "bucket_MB": int(os.environ.get("HOC_DDP_BUCKET_MB", "8")),
+                 "reducer": "torch DistributedDataParallel (HOC_TORCH_DDP=1)" if torch_ddp else
+                            f"gradreduce.BucketedGradReducer, {len(reducer.buckets)} buckets, all-reduce issued from backward"}
     assert torch.isfinite(loss).all(), "loss is not finite"
     if dist is not None and os.environ.get("HOC_CHECK_REPLICAS", "0") == "1":
         # data-parallel replicas must stay bit-identical: same averaged gradients, same Adam update on every rank

@@ -1,0 +1,150 @@
+"""Bucketed gradient all-reduce for the batch-sharded trainer: one process per GPU, the only
+exchange of a step is the mean of the trainable parameters' gradients over the ranks (RCCL over xGMI on
+MI355X; gloo in the CPU tests).
+
+Why not ``torch.nn.parallel.DistributedDataParallel``: a step of epochpassconsist.py:57-68 is SEVERAL forward
+passes (data batch, both frames of the consist batch, here also the shared ``prepare`` pass) and ONE backward.
+The wrapper re-arms its reducer and walks its inputs on every forward and post-processes every parameter's
+gradient on its own (a copy / scale launch per parameter): measured on one MI355X, one rank, no byte
+communicated: 30.1-30.7 ms per step against 26.6 ms without the wrapper, 430 against 352 launches
+(profiles/r02_ddp_one_rank_overlap.txt).  Nothing of that is needed here:
+
+* the model is NOT wrapped -- forwards cost what they cost without data parallelism;
+* parameters are grouped, in reverse registration order (the order their gradients become ready in), into
+  buckets of ``bucket_mb`` (xGMI is point-to-point: 8 MB keeps a ring step per link well above its latency);
+  each bucket owns ONE flat buffer and per-parameter views of it with the parameter's own (dense) strides;
+* a post-accumulate hook per parameter counts the bucket down; the hook of the LAST gradient of a bucket copies
+  the bucket's gradients into the flat buffer with one multi-tensor copy, points ``p.grad`` at the views and
+  issues ONE asynchronous all-reduce (average) of the flat buffer -- on the collective's own stream, behind the
+  copy, overlapping the rest of the backward pass (the encoder's, ~17 ms at B = 64);
+* ``finish()`` after ``backward()`` flushes buckets with parameters that received no gradient (zeros, so that
+  every rank reduces the same buckets) and makes the compute stream wait for the collectives; the optimiser
+  then reads the averaged gradients straight from the views.
+
+The same code runs for every world size, including 1 (no short cut: the one-rank run is how the cost of the
+path is measured on a one-GPU box).
+"""
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    __slots__ = ("params", "flat", "views", "pending", "work", "launched")
+
+    def __init__(self, params):
+        self.params = params
+        total = sum(p.numel() for p in params)
+        first = params[0]
+        self.flat = torch.zeros(total, dtype=first.dtype, device=first.device)
+        self.views, off = [], 0
+        for p in params:
+            n = p.numel()
+            chunk = self.flat[off:off + n]
+            dense = p.is_contiguous() or _is_dense_permutation(p)
+            self.views.append(chunk.as_strided(p.size(), p.stride()) if dense and n > 0 else chunk.view(p.size()))
+            off += n
+        self.pending, self.work, self.launched = len(params), None, False
+
+
+def _is_dense_permutation(t):
+    """True when ``t``'s strides are a permutation of a contiguous layout over exactly ``numel`` elements
+    (channels-last convolution weights): a view with the same strides then fits a flat chunk of ``numel``."""
+    expect = 1
+    for size, stride in sorted(zip(t.size(), t.stride()), key=lambda s: (s[1], s[0])):
+        if size == 1:
+            continue
+        if stride != expect:
+            return False
+        expect *= size
+    return expect == t.numel()
+
+
+class BucketedGradReducer:
+    """``reducer = BucketedGradReducer(model.parameters())``; per step: forwards, ``loss.backward()``,
+    ``reducer.finish()``, ``optimizer.step()`` (with ``zero_grad`` anywhere before the next backward; ONE
+    backward per ``finish()`` -- the step structure of epochpassconsist.py:57-68).  ``process_group=None`` = the
+    default group."""
+
+    def __init__(self, params, process_group=None, bucket_mb=8, broadcast_from=0):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.backend = dist.get_backend(process_group)
+        # RCCL averages inside the collective; gloo has no AVG: sum, then one scale per bucket
+        self._avg_in_collective = self.backend == "nccl"
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("no trainable parameter")
+        if broadcast_from is not None:
+            self._broadcast(params, broadcast_from)
+        cap = int(bucket_mb * (1 << 20))
+        self.buckets, cur, cur_bytes, key = [], [], 0, None
+        for p in reversed(params):
+            k, nbytes = (p.dtype, p.device), p.numel() * p.element_size()
+            if cur and (k != key or cur_bytes + nbytes > cap):
+                self.buckets.append(_Bucket(cur))
+                cur, cur_bytes = [], 0
+            key = k
+            cur.append(p)
+            cur_bytes += nbytes
+        self.buckets.append(_Bucket(cur))
+        self._handles = []
+        for b in self.buckets:
+            for p in b.params:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+        self.grad_bytes = sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)
+
+    # ------------------------------------------------------------------ set-up
+    def _broadcast(self, params, src):
+        """Replicas start from rank ``src``'s parameters (one flat broadcast per dtype / device group)."""
+        groups = {}
+        for p in params:
+            groups.setdefault((p.dtype, p.device), []).append(p)
+        with torch.no_grad():
+            for plist in groups.values():
+                flat = torch.cat([p.detach().reshape(-1) if p.is_contiguous() else p.detach().contiguous().reshape(-1)
+                                  for p in plist])
+                dist.broadcast(flat, src=src, group=self.group)
+                off = 0
+                for p in plist:
+                    n = p.numel()
+                    p.copy_(flat[off:off + n].view(p.size()))  # logical order; strides of p are kept
+                    off += n
+
+    def _make_hook(self, bucket):
+        def hook(_param):
+            bucket.pending -= 1
+            if bucket.pending == 0:
+                self._launch(bucket)
+        return hook
+
+    # ------------------------------------------------------------------ per step
+    def _launch(self, b):
+        with torch.no_grad():
+            have = [(v, p.grad) for v, p in zip(b.views, b.params)
+                    if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            for v, p in zip(b.views, b.params):
+                if p.grad is None:
+                    v.zero_()  # a parameter without a gradient contributes zeros on this rank
+                p.grad = v
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+        b.launched = True
+
+    def finish(self):
+        """After ``backward()``: every bucket reduced, the current stream ordered behind the collectives,
+        ``p.grad`` = the rank-averaged gradient (a view into the bucket's flat buffer)."""
+        for b in self.buckets:
+            if not b.launched:
+                self._launch(b)
+        for b in self.buckets:
+            b.work.wait()
+            if not self._avg_in_collective and self.world > 1:
+                b.flat.div_(self.world)
+            b.work, b.launched, b.pending = None, False, len(b.params)
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

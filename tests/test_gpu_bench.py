@@ -1,5 +1,5 @@
 """bench.py's contract on one MI355X, launched the way the driver launches it: as a plain script (N=1) and
-under ``torch.distributed.run`` through the RCCL process group + DistributedDataParallel code path (one rank
+under ``torch.distributed.run`` through the RCCL process group + bucketed gradient reducer code path (one rank
 here -- the box has a single GPU; two gloo ranks on CPU are in test_dist_gloo.py)."""
 import json
 import os
@@ -12,6 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--batch", "4", "--image-size", "64", "--steps", "2", "--warmup", "1", "--kernel-iters", "2", "--cpu-sample", "2"]
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config")
+
+
+EVIDENCE = os.path.join(ROOT, "gpurun_out", "evidence")  # scratch; merged back from the GPU box, copied to profiles/
+
+
+def _keep(name, line):
+    os.makedirs(EVIDENCE, exist_ok=True)
+    with open(os.path.join(EVIDENCE, name), "w") as fh:
+        fh.write(json.dumps(line) + "\n")
 
 
 def _json_line(out):
@@ -50,7 +59,8 @@ def test_bench_single_process_line(cuda):
 
 @pytest.mark.gpu
 def test_bench_under_torchrun_rccl_ddp(cuda):
-    env = dict(os.environ, HOC_FORCE_DDP="1", HOC_CHECK_REPLICAS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", HOC_TUNABLEOP="0")
+    env = dict(os.environ, HOC_FORCE_DDP="1", HOC_CHECK_REPLICAS="1", HOC_TUNABLEOP="0")
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)  # bench.py sets what RCCL needs itself
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline",
            "--no-kernel-bench"] + SMALL
@@ -58,13 +68,14 @@ def test_bench_under_torchrun_rccl_ddp(cuda):
     assert res.returncode == 0, res.stderr[-2000:]
     line = _json_line(res.stdout)
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "dp1"
+    assert line["ranks"]["backend"] == "rccl" and "BucketedGradReducer" in line["ranks"]["reducer"]
 
 
 @pytest.mark.gpu
 def test_bench_two_ranks_share_the_gpu_over_gloo(cuda):
-    """world_size 2 on the one-GPU box: both ranks on cuda:0, gradient all-reduce of DistributedDataParallel over gloo
-    (RCCL refuses two ranks per device).  Exercises what N > 1 adds -- per-rank seeds and loaders, DDP's bucketed
-    all-reduce through this build's autograd functions, the barrier + max-over-ranks timing, rank-0-only output;
+    """world_size 2 on the one-GPU box: both ranks on cuda:0, the bucketed gradient all-reduce over gloo
+    (RCCL refuses two ranks per device).  Exercises what N > 1 adds -- per-rank seeds and loaders, the reducer's
+    all-reduces issued from inside the backward pass of this build's autograd functions, the barrier + max-over-ranks timing, rank-0-only output;
     HOC_CHECK_REPLICAS makes bench.py assert that the replicas' parameters are bit-identical after the steps."""
     env = dict(os.environ, HOC_SHARE_GPU="1", HOC_DIST_BACKEND="gloo", HOC_CHECK_REPLICAS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", HOC_TUNABLEOP="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -75,14 +86,35 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(cuda):
     line = _json_line(res.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["parallelism"] == "dp2"
     assert line["config"]["global_batch"] == 8 and line["cpu_baseline"] is None
+    assert line["ranks"]["world_size"] == 2 and len(line["ranks"]["per_rank"]) == 2
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_step_costs_what_the_plain_step_costs(cuda):
+    """The data-parallel code path must not tax the step before a byte is communicated (round 2 measured torch's
+    DistributedDataParallel wrapper at +13-15 % on one rank).  Headline workload (B = 64, 256 x 256), same solver /
+    GEMM settings in both runs: one rank through the RCCL process group + BucketedGradReducer <= 1.03 x plain."""
+    common = ["--gpus", "1", "--steps", "20", "--warmup", "8", "--no-cpu-baseline", "--no-kernel-bench", "--no-stock-trunk"]
+    bench = os.path.join(ROOT, "bench.py")
+    plain = subprocess.run([sys.executable, bench] + common, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29549", bench] + common
+    dist = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HOC_FORCE_DDP="1"))
+    assert dist.returncode == 0, dist.stderr[-2000:]
+    a, b = _json_line(plain.stdout), _json_line(dist.stdout)
+    assert a["ranks"] is None and b["ranks"]["backend"] == "rccl"
+    _keep("one_rank_reducer_vs_plain.json", {"plain_ms": a["ms_per_step"], "one_rank_rccl_ms": b["ms_per_step"],
+                                             "ratio": round(b["ms_per_step"] / a["ms_per_step"], 4), "ranks": b["ranks"]})
+    assert b["ms_per_step"] <= 1.03 * a["ms_per_step"], (a["ms_per_step"], b["ms_per_step"])
 
 
 @pytest.mark.gpu
 def test_config4_per_gpu_workload_under_rccl_ddp(cuda):
     """BASELINE config 4 (8 x MI355X, global B = 256): the per-GPU share -- B = 32 frame pairs of 256 x 256 -- through
-    the RCCL process group + DistributedDataParallel path (one rank: the test box has one GPU); the JSON line
+    the RCCL process group + gradient reducer path (one rank: the test box has one GPU); the JSON line
     carries the per-rank evidence (backend, device, per-rank step time, all-reduce volume)."""
-    env = dict(os.environ, HOC_FORCE_DDP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", HOC_TUNABLEOP="0")
+    env = dict(os.environ, HOC_FORCE_DDP="1", HOC_TUNABLEOP="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "32",
            "--image-size", "256", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-bench",
