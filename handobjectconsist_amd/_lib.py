@@ -10,9 +10,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmeshraster_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 3  # MR_ABI_VERSION of include/meshraster_hip.h
 FLAG_REFERENCE_ALGO = 1
 FLAG_SPARSE_TILES = 2
+FLAG_OUTPUT_ZEROED = 4
 
 _c = ctypes
 _P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
@@ -32,10 +33,10 @@ SIGNATURES = {
     "mr_render_backward_workspace_bytes": (_L, [_I, _I, _I]),
     "mr_render_backward_list_workspace_bytes": (_L, [_I, _I]),
     "mr_render_backward": (_I, [_P] * 11 + [_L, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
-    "mr_render_vc_forward": (_I, [_P, _P, _P, _P, _I] + [_P] * 6 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
-    "mr_render_vc_backward": (_I, [_P] * 7 + [_I, _I, _I, _I, _I, _F, _I, _P]),
-    "mr_render_flow_backward": (_I, [_P] * 11 + [_I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
-    "mr_render_flow_forward": (_I, [_P, _P, _P, _P, _I, _P, _I, _F] + [_P] * 8 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _P, _P]),
+    "mr_render_vc_forward": (_I, [_P, _P, _P, _P, _I] + [_P] * 6 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _I, _P]),
+    "mr_render_vc_backward": (_I, [_P] * 7 + [_I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "mr_render_flow_backward": (_I, [_P] * 11 + [_I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
+    "mr_render_flow_forward": (_I, [_P, _P, _P, _P, _I, _P, _I, _F] + [_P] * 8 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _P, _I, _P, _P, _L, _I, _P]),
     "mr_flow_vertices_forward": (_I, [_P] * 7 + [_I, _F] + [_P] * 4 + [_I, _I, _P]),
     "mr_flow_vertices_backward": (_I, [_P] * 8 + [_I, _I, _P]),
     "mr_mano_workspace_floats": (_L, [_I]),

@@ -78,10 +78,15 @@ __device__ __forceinline__ void load_face(const float* __restrict__ g, Face& f, 
 struct BoxShared {
     float px[3], py[3];
     float two_longest;
-    FaceBox box;      // clipped bbox (empty if off screen)
+    float tight_need;  // (pa - pb) must exceed this for the tight box to be provably complete (see face_box_orient)
+    FaceBox box;       // clipped bbox with a one-pixel margin (empty if off screen)
+    FaceBox tight;     // clipped bbox with a 1/16-pixel margin (empty if it holds no pixel centre)
     bool anynan;
-    bool nonfinite;   // a pixel coordinate is Inf (or NaN)
+    bool nonfinite;    // a pixel coordinate is Inf (or NaN)
 };
+
+// Margin of the tight box, in pixels.
+#define MR_TIGHT_MARGIN 0.0625f
 
 __device__ __forceinline__ void face_box_shared(const float* f, int is, BoxShared& s) {
     s.anynan = false;
@@ -113,6 +118,30 @@ __device__ __forceinline__ void face_box_shared(const float* f, int is, BoxShare
         s.box.y0 = (int16_t)fmaxf(ylo, 0.0f);
         s.box.y1 = (int16_t)fminf(yhi, lim);
     }
+    // The tight box: the pixel centres (integers in this coordinate system) within MR_TIGHT_MARGIN of the vertices'
+    // bounding box.  floor(min) .. ceil(max) above keeps everything closer than ONE pixel, i.e. on average two rows and
+    // two columns that no pixel of a well-shaped face can be in: for the few-pixel faces of a dense mesh (5.9 x 5.4
+    // -> 4.0 x 3.5 pixels on the bench scene) that is more than half of the box, a third of the (face, row) items and
+    // a fifth of the (face, tile) records of the tile rasteriser.  Which faces may use it: face_box_orient.
+    s.tight.x0 = 1; s.tight.x1 = 0; s.tight.y0 = 1; s.tight.y1 = 0;
+    {
+        const float m = MR_TIGHT_MARGIN;
+        const float txlo = fmaxf(ceilf(fminf(s.px[0], fminf(s.px[1], s.px[2])) - m), 0.0f);
+        const float txhi = fminf(floorf(fmaxf(s.px[0], fmaxf(s.px[1], s.px[2])) + m), lim);
+        const float tylo = fmaxf(ceilf(fminf(s.py[0], fminf(s.py[1], s.py[2])) - m), 0.0f);
+        const float tyhi = fminf(floorf(fmaxf(s.py[0], fmaxf(s.py[1], s.py[2])) + m), lim);
+        if (txlo <= txhi && tylo <= tyhi) {
+            s.tight.x0 = (int16_t)txlo; s.tight.x1 = (int16_t)txhi;
+            s.tight.y0 = (int16_t)tylo; s.tight.y1 = (int16_t)tyhi;
+        }
+    }
+    // 64 u (emax is / margin) x (product of the two longest edges), u = 2^-24; +Inf when a vertex lies more than four
+    // screens away (the bound below assumes |pixel - vertex| <= ~8.5 is)
+    float far_out = 0.0f;
+#pragma unroll
+    for (int n = 0; n < 3; n++) far_out = fmaxf(far_out, fmaxf(fabsf(s.px[n]), fabsf(s.py[n])));
+    s.tight_need = (far_out <= 4.0f * fis) ? (64.0f * 5.9604645e-8f / MR_TIGHT_MARGIN) * (emax * fis) * s.two_longest
+                                            : __builtin_inff();
 }
 
 // The order-dependent part, for the vertex order (a, b, c) = (0, 1, 2) or, REV, (2, 1, 0).
@@ -132,6 +161,19 @@ __device__ __forceinline__ FaceBox face_box_orient(const float* f, int is, const
         b.x0 = 0; b.x1 = (int16_t)(is - 1); b.y0 = 0; b.y1 = (int16_t)(is - 1);
         return b;
     }
+    // Tight box.  A pixel p the three fp32 edge tests accept lies, for every edge (S -> Q), on the inner side of the
+    // edge's line or within an ANGLE of 6 u of it seen from S (each side of `(yp - Sy)(Qx - Sx) < (xp - Sx)(Qy - Sy)`
+    // is two roundings of exact differences away from a product of magnitude <= |p - S| |Q - S|).  Take the vertex M of
+    // largest x: the face's wedge at M lies in x <= Mx, so a pixel with x > Mx is outside one of M's two edges, hence
+    // within 6 u |p - S| of that edge's line; either it sits next to the edge itself -- then x - Mx <= 6 u |p - S|
+    // -- or on the line's extension beyond M, at distance r from M, where it is r sin(angle at M) outside M's OTHER
+    // edge, which the second test forgives only if r sin(angle) <= 6 u (r + L): r <= 6 u L / (sin(angle) - 6 u).  With
+    // sin(smallest angle) >= (pa - pb) / (2 x product of the two longest edges) (max-norm lengths) and L <= sqrt(2)
+    // emax is / 2 pixels, `pa - pb > tight_need` gives r < margin / 7, and |p - S| <= 8.5 is bounds the first case
+    // by 3e-6 is pixels: every accepted pixel is within the margin of the bounding box for rasters up to 16384.
+    // The same holds for the other three sides.  Thin faces (smallest angle below ~1e-4 rad at 256 pixels) keep the
+    // one-pixel box.
+    if (pa - pb > s.tight_need) return s.tight;
     return s.box;
 }
 
@@ -176,6 +218,24 @@ __device__ __forceinline__ bool cover(const Face& f, int xi, int yi, int is, flo
     if (!(zp > near_ && zp < far_)) return false;
     return true;
 }
+
+// Texel layout of the 2x2x2 vertex-colour texture (libyana's batch_vertex_textures -- source absent): the
+// texel with a 1 on axis a -- (1,0,0), (0,1,0), (0,0,1) -- holds the colour of vertex sigma(a) of the face.  `code`
+// packs sigma two bits per axis (MR_TEXEL_LAYOUT_DEFAULT = identity: what utils/textutils.py assumes); 0 = default.
+// For the reversed copy of a face (fill-back: vertices in reverse order, texture axes mirrored, renderer.py:250-252) the
+// same texel holds the colour of the copy's vertex 2 - sigma(2 - a).  Sampling coordinate a is the barycentric weight of
+// geometry vertex a, so this table is all that ties geometry to colours in the fused vertex-colour kernels.
+__device__ __forceinline__ int texel_vertex(int code, int axis, bool reversed) {
+    const int a = reversed ? 2 - axis : axis;
+    const int s = ((code ? code : MR_TEXEL_LAYOUT_DEFAULT) >> (2 * a)) & 3;
+    return reversed ? 2 - s : s;
+}
+static inline bool texel_layout_ok(int code) {  // 0 (default) or a permutation of {0, 1, 2}, two bits per axis
+    if (code == 0) return true;
+    const int a = code & 3, b = (code >> 2) & 3, c = (code >> 4) & 3;
+    return (code >> 6) == 0 && a < 3 && b < 3 && c < 3 && a != b && a != c && b != c;
+}
+__device__ __forceinline__ int sel3(int v0, int v1, int v2, int s) { return s == 0 ? v0 : (s == 1 ? v1 : v2); }
 
 // Order-preserving map float -> uint32 (so that an unsigned min is a float min).
 __device__ __forceinline__ uint32_t f2ord(float x) {

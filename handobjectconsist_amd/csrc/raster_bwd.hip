@@ -241,7 +241,8 @@ struct GatherVCParams {
     float* grad_vcolors;    // [B,V,3], pre-zeroed, accumulated with fp32 atomics
     int B, V, F0, fill_back, is;
     float eps;
-    int dbg;  // profiling experiments (flags >> 8)
+    int dbg;    // profiling experiments (flags >> 8)
+    int texel;  // texel layout code of the vertex-colour texture (mr_common.hpp: texel_vertex)
 };
 
 // contribution of one won pixel to the colours of the face's three vertices (its own order)
@@ -476,7 +477,15 @@ __global__ void __launch_bounds__(256) gather_vc_kernel(GatherVCParams p) {
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) acc[o ? 2 - k : k][c] += fa[slot_own * 9 + k * 3 + c];
+            for (int c = 0; c < 3; c++) {
+                // tap k of this orientation holds the colour of its vertex texel_vertex(k), i.e. of the REAL face's
+                // vertex at position (o ? 2 - that : that)
+                const int tv = texel_vertex(p.texel, k, o != 0);
+                const int real = o ? 2 - tv : tv;
+                const float add = fa[slot_own * 9 + k * 3 + c];
+#pragma unroll
+                for (int q = 0; q < 3; q++) acc[q][c] += (q == real) ? add : 0.0f;
+            }
         __builtin_amdgcn_wave_barrier();
     }
     if (valid && sub == 0 && !(p.dbg & 1)) {
@@ -552,10 +561,12 @@ __global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(ScatterV
     const int32_t* fidx_b = p.fidx + (int64_t)b * p.F0 * 3;
     float g[SV_RPW][3], w[SV_RPW][3], zp[SV_RPW];
     int vid[SV_RPW][3];
+    bool rev_r[SV_RPW];
 #pragma unroll
     for (int r = 0; r < SV_RPW; r++) {
         const bool won = fnv[r] >= 0;
         const bool o = fnv[r] >= p.F0;  // reversed copy of face fn - F0
+        rev_r[r] = o;
         const int32_t* ix = fidx_b + (int64_t)(won ? (o ? fnv[r] - p.F0 : fnv[r]) : 0) * 3;
 #pragma unroll
         for (int k = 0; k < 3; k++) vid[r][k] = won ? ix[o ? 2 - k : k] : 0;
@@ -643,7 +654,7 @@ __global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(ScatterV
                 int sl = j + rot;
                 sl = sl >= 9 ? sl - 9 : sl;
                 const int k = (sl >= 3) + (sl >= 6), ch = sl - 3 * k;
-                const int cell = (k == 0 ? vid[r][0] : (k == 1 ? vid[r][1] : vid[r][2])) * 3 + ch;
+                const int cell = sel3(vid[r][0], vid[r][1], vid[r][2], texel_vertex(p.texel, k, rev_r[r])) * 3 + ch;
                 if (p.dbg & 4) {
                     if (val[j] == 12345.0f) vtab[0] = 1;
                 } else if (finite) {
@@ -792,7 +803,15 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
     for (int k = 0; k < ST_WAVES; k++) bm = max(bm, wmax[k]);
     if (bm == 0u) return;                  // every gradient is +-0: nothing to add (block-uniform)
     const bool finite = bm < 0x7f800000u;  // else: fp32 global atomics, Inf / NaN propagate
-    const int shift = SV_FIX_BITS - ((int)(bm >> 23) - 126);
+    // A table cell receives at most 3 terms per pixel (a face may name one vertex three times) of every tile this
+    // workgroup walks, each below 2^SV_FIX_BITS in magnitude: 2^13 terms fit an int64.  A workgroup with more
+    // (beyond ten covered tiles: large rasters, screen-filling meshes) gives up one bit of the 50 per doubling -- at
+    // the 256 tiles the list can hold per workgroup that is still 2^-45 of the largest gradient per term.
+    const int rem = n_hits - part * ST_WAVES;
+    const long long terms = 3LL * ST_TW * ST_TH * ((rem / (ST_G * ST_WAVES)) * ST_WAVES + min(rem % (ST_G * ST_WAVES), ST_WAVES));
+    int headroom = 0;
+    while ((terms >> headroom) >= (1LL << (63 - SV_FIX_BITS))) headroom++;
+    const int shift = SV_FIX_BITS - headroom - ((int)(bm >> 23) - 126);
     float* out = p.grad_vcolors + (int64_t)b * p.V * 3;
 
     // pass 2
@@ -876,7 +895,9 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
                 for (int ch = 0; ch < 3; ch++) {
                     if (FLOWGRAD && ch == 2) continue;  // the third plane's gradient is identically zero
                     const float v = val[k * 3 + ch];
-                    const int cell = vid[j][k] * 3 + ch;
+                    // (records name the vertex behind tap k themselves; else: the texel layout table)
+                    const int cell = (REC ? vid[j][k]
+                                          : sel3(vid[j][0], vid[j][1], vid[j][2], texel_vertex(p.texel, k, fn[j] >= p.F0))) * 3 + ch;
                     if (finite) {
                         const long long q = (long long)ldexp((double)v, shift);
                         if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&vtab[cell]), (unsigned long long)q);
@@ -1822,8 +1843,8 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
 extern "C" int mr_render_vc_backward(const float* verts, const int32_t* faces_idx, const int32_t* face_index_map,
                                      const float* weight_map, const float* depth_img, const float* grad_rgb_img,
                                      float* grad_vcolors, int batch_size, int num_verts, int num_faces, int fill_back,
-                                     int image_size, float eps, int flags, mr_stream_t stream) {
-    if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0) return MR_ERR_BADARG;
+                                     int image_size, float eps, int flags, int texel_layout, mr_stream_t stream) {
+    if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || !texel_layout_ok(texel_layout)) return MR_ERR_BADARG;
     if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
     if (batch_size == 0 || num_verts == 0) return MR_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -1832,7 +1853,7 @@ extern "C" int mr_render_vc_backward(const float* verts, const int32_t* faces_id
     if (num_faces == 0) return MR_OK;
     if (!verts || !faces_idx || !face_index_map || !grad_rgb_img || !(eps >= 1e-6f)) return MR_ERR_BADARG;
     GatherVCParams g{verts, faces_idx, face_index_map, grad_rgb_img, grad_vcolors, batch_size, num_verts, num_faces,
-                     fill_back, image_size, eps, flags >> 8};
+                     fill_back, image_size, eps, flags >> 8, texel_layout};
     // pixel-parallel scatter when the per-image colour table fits LDS (dbg bit 32 forces the gather)
     const int64_t table_bytes = (((int64_t)num_verts * 3 + 1) / 2) * 16;
     if (table_bytes <= SV_MAX_TABLE_BYTES && !(g.dbg & 32)) {
@@ -1855,8 +1876,8 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
                                        const float* mask_x_lo, const float* mask_x_hi, int split, const float* occl,
                                        int height, int width, float* grad_vcolors, int batch_size, int num_verts,
                                        int num_faces, int fill_back, int image_size, float eps, int flags,
-                                       const int32_t* vertex_id_map, mr_stream_t stream) {
-    if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0) return MR_ERR_BADARG;
+                                       const int32_t* vertex_id_map, int texel_layout, mr_stream_t stream) {
+    if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || !texel_layout_ok(texel_layout)) return MR_ERR_BADARG;
     if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
     if (batch_size == 0 || num_verts == 0) return MR_OK;
     const bool flowgrad = grad_rgb_img == nullptr;
@@ -1864,8 +1885,10 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
                      width > image_size || split < 0 || split > batch_size || (split < batch_size && !mask_x_hi)))
         return MR_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(grad_vcolors, 0, (size_t)batch_size * num_verts * 3 * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
+    if (!(flags & MR_FLAG_OUTPUT_ZEROED)) {  // (the workgroups of an image meet in global atomics on a zeroed output)
+        hipError_t e = hipMemsetAsync(grad_vcolors, 0, (size_t)batch_size * num_verts * 3 * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
     if (num_faces == 0) return MR_OK;
     if (!face_index_map || !weight_map || !(eps >= 1e-6f)) return MR_ERR_BADARG;
     if (!vertex_id_map && (!verts || !faces_idx || !depth_img)) return MR_ERR_BADARG;
@@ -1876,7 +1899,7 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
         return MR_ERR_NOTIMPL;
     ScatterTilesParams sp{};
     sp.g = GatherVCParams{verts, faces_idx, face_index_map, grad_rgb_img, grad_vcolors, batch_size, num_verts, num_faces,
-                          fill_back, image_size, eps, flags >> 8};
+                          fill_back, image_size, eps, flags >> 8, texel_layout};
     sp.weight = weight_map; sp.depth = depth_img; sp.tile_hit = tile_hit; sp.vid_map = vertex_id_map;
     sp.grad_flow = grad_flow; sp.m_pre = mask_pre; sp.m_x_lo = mask_x_lo; sp.m_x_hi = mask_x_hi; sp.occl = occl;
     sp.split = split; sp.H = height; sp.W = width;

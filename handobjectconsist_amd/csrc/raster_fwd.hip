@@ -70,6 +70,11 @@ struct ImageHdr {
 struct BinHdr {
     unsigned off, cnt;  // the bin's records: recs[image base + off .. + cnt)
 };
+// Header of the tile list of a launch (one per call, in the workspace).
+struct TileList {
+    unsigned n;       // tiles with at least one candidate record, all images
+    unsigned pad[63];
+};
 
 // {x0 | x1 << 16, y0 | y1 << 16, (virtual) face index, unused}
 typedef uint4 FaceRec;
@@ -108,6 +113,12 @@ struct BinParams {
     int nbx, nby, ysh;       // bins per row / column; a bin is TILE_W x (TILE_H << ysh) pixels
     int lds_boxes;           // bin_boxes_kernel keeps the image's boxes in LDS between its two passes
     int dbg;                 // profiling experiments (scripts/fwd_vc_variants.py)
+    // compacted list of the tiles with candidate records (sparse-tile launches; nullptr = none is built)
+    TileList* tlist;         // counter, zeroed by face_records_kernel, bumped once per image by bin_boxes_kernel
+    uint32_t* tile_ids;      // [B * tiles] global tile ids (image * tiles per image + tile), grouped by image
+    uint8_t* tile_hit;       // [B, tiles, 4]: the binning pass writes the (zero) coverage bytes of the other tiles
+    float* zero_fill;        // nullable: cleared by the binning pass (the matching backward's gradient buffer)
+    int64_t zero_count;
 };
 
 // Pass A, one thread per REAL face, grid = (ceil(F0 / 256), B): back-face cull + conservative pixel bbox of the
@@ -119,6 +130,7 @@ template <bool VC>
 __global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
     const int b = blockIdx.y;
     const int f0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p.tlist && b == 0 && f0 == 0) p.tlist->n = 0u;  // (this launch precedes the binning pass on the stream)
     if (f0 >= p.F0) return;
     const int is = p.is;
     float f[9];
@@ -169,8 +181,8 @@ __global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
 // with a ballot loop, folding runs of equal neighbours into one atomic, prefetching 8 iterations of boxes.)
 __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     extern __shared__ int bin_smem[];
-    __shared__ int s_large;
-    __shared__ int wsum[BIN_TPB / MR_WAVE];
+    __shared__ int s_large, s_nlarge, s_lbase;
+    __shared__ unsigned long long wsum[BIN_TPB / MR_WAVE];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbins = p.nbx * p.nby;
     int* cnt = bin_smem;
@@ -178,7 +190,9 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     const FaceBox* box_b = p.boxes + (int64_t)b * p.F;
 
     for (int i = tid; i < nbins; i += BIN_TPB) cnt[i] = 0;
-    if (tid == 0) s_large = 0;
+    if (tid == 0) { s_large = 0; s_nlarge = 0; }
+    if (p.zero_fill)
+        for (int64_t i = (int64_t)b * BIN_TPB + tid; i < p.zero_count; i += (int64_t)gridDim.x * BIN_TPB) p.zero_fill[i] = 0.0f;
     __syncthreads();
 
     // pass 1: records per bin
@@ -188,29 +202,44 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         if (bx.x0 > bx.x1) continue;
         const int bx0 = bx.x0 / TILE_W, bx1 = bx.x1 / TILE_W;
         const int by0 = bx.y0 >> (3 + p.ysh), by1 = bx.y1 >> (3 + p.ysh);
-        if ((bx1 - bx0 + 1) * (by1 - by0 + 1) > SMALL_MAX_BINS) continue;  // large list (counted in pass 2)
+        if ((bx1 - bx0 + 1) * (by1 - by0 + 1) > SMALL_MAX_BINS) {  // large list (filled in pass 2)
+            if (p.tlist) atomicAdd(&s_nlarge, 1);
+            continue;
+        }
         for (int y = by0; y <= by1; y++)
             for (int x = bx0; x <= bx1; x++) atomicAdd(&cnt[y * p.nbx + x], 1);
     }
     __syncthreads();
 
     // exclusive scan of the bin counts (each thread owns a run of consecutive bins); headers out, counters
-    // become fill cursors
+    // become fill cursors.  The high half of the scanned value counts the bins that hold candidates (every bin,
+    // if the image has a large list): the places of the image's entries in the launch's tile list.
     const int per = (nbins + BIN_TPB - 1) / BIN_TPB;
     const int i0 = min(tid * per, nbins), i1 = min(i0 + per, nbins);
-    int local = 0;
-    for (int i = i0; i < i1; i++) local += cnt[i];
-    int incl = local;
+    const bool all_live = p.tlist && s_nlarge > 0;
+    unsigned long long local = 0;
+    for (int i = i0; i < i1; i++) {
+        const int c = cnt[i];
+        local += (unsigned long long)(unsigned)c | ((unsigned long long)((c > 0 || all_live) ? 1u : 0u) << 32);
+    }
+    unsigned long long incl = local;
 #pragma unroll
     for (int off = 1; off < MR_WAVE; off <<= 1) {
-        const int up = __shfl_up(incl, off);
+        const unsigned long long up = __shfl_up(incl, off);
         if (lane >= off) incl += up;
     }
     if (lane == MR_WAVE - 1) wsum[wave] = incl;
     __syncthreads();
-    int base = incl - local;
-    for (int w = 0; w < wave; w++) base += wsum[w];
+    unsigned long long base64 = incl - local, total64 = 0;
+    for (int w = 0; w < BIN_TPB / MR_WAVE; w++) {
+        const unsigned long long ws = wsum[w];
+        if (w < wave) base64 += ws;
+        total64 += ws;
+    }
+    int base = (int)(unsigned)(base64 & 0xffffffffull);
+    if (p.tlist && tid == 0) s_lbase = (int)atomicAdd(&p.tlist->n, (unsigned)(total64 >> 32));
     BinHdr* bh = p.bins + (int64_t)b * nbins;
+    unsigned livebits = 0u;  // (per <= MAX_BINS / BIN_TPB = 8 bins per thread)
     for (int i = i0; i < i1; i++) {
         const int c = cnt[i];
         BinHdr h;
@@ -218,8 +247,20 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         bh[i] = h;
         cnt[i] = base;
         base += c;
+        livebits |= (c > 0 ? 1u : 0u) << (i - i0);
     }
     __syncthreads();
+    if (p.tlist) {
+        // the image's tiles with candidates go to the launch's tile list (a bin IS a tile here: ysh == 0), the
+        // others get their (zero) coverage bytes now -- no workgroup is dispatched for them
+        unsigned at = (unsigned)s_lbase + (unsigned)(base64 >> 32);
+        uint32_t* hit32 = reinterpret_cast<uint32_t*>(p.tile_hit) + (int64_t)b * nbins;
+        for (int i = i0; i < i1; i++) {
+            const bool live = all_live || ((livebits >> (i - i0)) & 1u);
+            if (live) p.tile_ids[at++] = (uint32_t)(b * nbins + i);
+            else hit32[i] = 0u;
+        }
+    }
     if (p.dbg & 2) return;
 
     // pass 2: fill
@@ -286,12 +327,19 @@ struct FwdParams {
     int tiles_x, tiles_y;  // tiles per row / per column
     const unsigned long long* keys;  // validation only: precomputed z-buffer keys (skip the scan)
     int dbg;                         // profiling experiments (flags >> 8)
+    // listed launches (sparse tiles): the binning pass's list of tiles with candidates
+    const TileList* tlist;
+    const uint32_t* tile_ids;
+    uint32_t* tile_count_out;        // nullable, any device-writable address (e.g. pinned host memory): the list
+                                     // length of this launch, for the caller's next grid-size guess
+    unsigned list_first;             // first list entry this launch handles
     // vertex-colour mode (VC): indexed geometry + per-vertex colours, fill-back done by index
     // arithmetic: virtual face fn >= F0 is face fn - F0 with its vertex order reversed
     const float* verts;              // [B,V,3] projected vertices (x,y NDC, z metric)
     const int32_t* fidx;             // [B,F0,3] vertex indices
     const float* vcolors;            // [B,V,3]
     int V, F0;
+    int texel;                       // texel layout code of the vertex-colour texture (mr_common.hpp: texel_vertex)
 };
 
 // the 9 coordinates of (virtual) face fn in ONE load phase: from the faces tensor, or (VC) from the gathered
@@ -345,8 +393,10 @@ __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float 
 __device__ unsigned long long mr_dbg_times[65536 * 4];
 #endif
 
-template <bool FUSED, bool VC>
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))) raster_tile_kernel(FwdParams p) {
+// LOOP: listed launches only -- the workgroup walks the tile list with a grid stride (the loop keeps every kernel
+// argument live in scalar registers across the trips; see launch_tiles for what that costs and when it is used).
+template <bool FUSED, bool VC, bool LOOP = false, int WAVES = 7>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) raster_tile_kernel(FwdParams p) {
 #ifdef MR_WG_TIMELINE
     const unsigned long long dbg_t0 = wall_clock64();
 #endif
@@ -356,8 +406,11 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
     __shared__ float xp_tab[TILE_W], yp_tab[TILE_H];
     __shared__ int rowoff[TPB / MR_WAVE][NB + 1];  // prefix sums of the batch's per-face row counts
 
-    const unsigned nblocks = gridDim.x;
-    const unsigned lid = xcd_remap(blockIdx.x, nblocks);
+    // One tile per workgroup (lid = workgroup index, XCD-aware), or -- listed launches, p.tlist -- the workgroups
+    // walk the list of the tiles that hold candidates with a grid stride: the grid is sized by the caller's guess of
+    // the list length, no workgroup is dispatched for the empty 80 % of the screen and none pulls work through an
+    // atomic (a queue cursor serialised the launch, profiles/r02_persistent_tile_kernel_experiment.patch).
+    auto tile_body = [&](const unsigned lid) {
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int b = lid / tiles_per_img;
     const int t = lid % tiles_per_img;
@@ -713,11 +766,15 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
                 // the 2x2x2 vertex-colour texture of batch_vertex_textures, never materialised:
                 // texel (1,0,0) = colour of vertex 0, (0,1,0) = vertex 1, (0,0,1) = vertex 2, else 0;
                 // same 8-tap accumulation order as the texture path (bit-identical)
+                // (tap axis k carries the colour of the face's vertex texel_vertex(k): the identity in the assumed layout)
                 float vc[3][3];
+                int cid[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++)
+                for (int k = 0; k < 3; k++) {
+                    cid[k] = sel3(vid[0], vid[1], vid[2], texel_vertex(p.texel, k, fn >= p.F0));
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) vc[k][ch] = p.vcolors[((int64_t)b * p.V + vid[k]) * 3 + ch];
+                    for (int ch = 0; ch < 3; ch++) vc[k][ch] = p.vcolors[((int64_t)b * p.V + cid[k]) * 3 + ch];
+                }
                 // (the five taps on zero texels are skipped: their weights are finite unless a sampling coordinate is
                 // NaN, in which case the three taps below are NaN as well, and c + (+-0) == c for the sums at hand,
                 // which start at +0 and therefore are never -0)
@@ -737,7 +794,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
                 if (p.vid_map) {
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
-                        p.vid_map[ri * 3 + k] = vid[k];
+                        p.vid_map[ri * 3 + k] = cid[k];
                         if (p.weight) p.weight[ri * 3 + k] = wgs[k];
                     }
                 }
@@ -749,6 +806,21 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
 #pragma unroll
             for (int k = 0; k < 3; k++)
                 if (k < p.rgb_channels) p.rgb[o + k * plane] = c[k] * 1.0f + 0.0f * bg[k];
+        }
+    }
+    };  // tile_body
+
+    const bool listed = p.tlist != nullptr;
+    const unsigned n_work = listed ? p.tlist->n : gridDim.x;
+    if (listed && p.tile_count_out && p.list_first == 0u && blockIdx.x == 0 && threadIdx.x == 0) *p.tile_count_out = n_work;
+    // (consecutive list entries are tiles of one image: xcd_remap keeps them on one XCD / L2)
+    unsigned wi = p.list_first + xcd_remap(blockIdx.x, gridDim.x);
+    if (!LOOP) {
+        if (wi < n_work) tile_body(listed ? p.tile_ids[wi] : wi);
+    } else {
+        for (; wi < n_work; wi += gridDim.x) {
+            tile_body(p.tile_ids[wi]);
+            __syncthreads();
         }
     }
 }
@@ -839,10 +911,10 @@ __global__ void __launch_bounds__(256) face_inv_map_kernel(const float* __restri
 }
 
 // workspace layout: [B] ImageHdr | [B * nbins] BinHdr | [B * F] FaceBox | [B * REC_CAP * F] FaceRec | [B * F] RecVerts
-// (every byte the tile kernel reads is written by the two setup kernels: no memset)
+// | TileList | [B * tiles] tile ids    (every byte the tile kernel reads is written by the two setup kernels: no memset)
 struct WorkLayout {
     int nbx, nby, ysh;
-    size_t off_bins, off_boxes, off_recs, off_rverts, total;
+    size_t off_bins, off_boxes, off_recs, off_rverts, off_tlist, off_tile_ids, total;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -858,16 +930,27 @@ static WorkLayout work_layout(int B, int F, int is) {
     w.off_boxes = w.off_bins + align256((size_t)B * w.nbx * w.nby * sizeof(BinHdr));
     w.off_recs = w.off_boxes + align256((size_t)B * F * sizeof(FaceBox));
     w.off_rverts = w.off_recs + align256((size_t)B * REC_CAP * F * sizeof(FaceRec));
-    w.total = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (VC needs F / 2 of it with fill-back)
+    w.off_tlist = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (VC needs F / 2 of it with fill-back)
+    w.off_tile_ids = w.off_tlist + align256(sizeof(TileList));
+    w.total = w.off_tile_ids + align256((size_t)B * tiles_x * tiles_y * sizeof(uint32_t));
     return w;
 }
 
 // per-face records + boxes (pass A), bin lists (pass B); fills the record-source fields of `fp`
+// `tile_hit` != nullptr asks for the tile list too (sparse-tile launches of rasters whose bins are tiles): fp.tlist is
+// set when one is built
 template <bool VC>
-static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int F, int is, hipStream_t s) {
+static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int F, int is, hipStream_t s,
+                       uint8_t* tile_hit = nullptr) {
     const WorkLayout w = work_layout(B, F, is);
     if (w.nbx > MAX_BINS) return MR_ERR_BADARG;  // (image_size <= 16384 keeps a row of bins within the counters)
     char* base = (char*)workspace;
+    if (tile_hit && w.ysh == 0 && (int64_t)B * w.nbx * w.nby <= 0x7fffffffLL) {
+        bp.tlist = (TileList*)(base + w.off_tlist);
+        bp.tile_ids = (uint32_t*)(base + w.off_tile_ids);
+        bp.tile_hit = tile_hit;
+        fp.tlist = bp.tlist; fp.tile_ids = bp.tile_ids;
+    }
     bp.hdrs = (ImageHdr*)base;
     bp.bins = (BinHdr*)(base + w.off_bins);
     bp.boxes = (FaceBox*)(base + w.off_boxes);
@@ -900,14 +983,41 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     return MR_OK;
 }
 
+// `tile_bound` (listed launches): the caller's guess of the tile-list length = workgroups to dispatch; a longer list
+// is walked with a grid stride, surplus workgroups leave after one scalar load
 template <bool FUSED, bool VC>
-static int launch_tiles(FwdParams& p, hipStream_t s) {
+static int launch_tiles(FwdParams& p, hipStream_t s, int64_t tile_bound = 0) {
     if (p.rgb_channels == 0) p.rgb_channels = 3;
     p.tiles_x = (p.is + TILE_W - 1) / TILE_W;
     p.tiles_y = (p.is + TILE_H - 1) / TILE_H;
-    const int64_t nblocks = (int64_t)p.B * p.tiles_x * p.tiles_y;
+    int64_t nblocks = (int64_t)p.B * p.tiles_x * p.tiles_y;
     if (nblocks == 0) return MR_OK;
     if (nblocks > 0x7fffffffLL) return MR_ERR_BADARG;
+    if (p.tlist) {
+        // Listed launch: `bound` workgroups take one list entry each (the straight-line kernel: one tile per
+        // workgroup, no loop-carried state); whatever the list holds beyond the caller's guess is walked by a second,
+        // small launch of the looping variant, whose workgroups leave after one scalar load when the guess was good.
+        if (tile_bound <= 0) tile_bound = (nblocks + 3) / 4;
+        const int64_t bound = std::min<int64_t>(nblocks, std::max<int64_t>((tile_bound + 7) & ~(int64_t)7, 256));
+        if constexpr (FUSED && VC) {
+            if (p.dbg & 512) {  // experiment: the looping variant alone (7 waves per SIMD; 1024: 6)
+                if (p.dbg & 1024) hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, true, 6>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
+                else hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, true, 7>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
+                MR_CHECK_LAUNCH();
+                return MR_OK;
+            }
+            hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, false, 7>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
+            MR_CHECK_LAUNCH();
+            if (bound < nblocks) {
+                p.list_first = (unsigned)bound;
+                const int64_t rest = std::min<int64_t>(nblocks - bound, 512);
+                hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, true, 7>), dim3((unsigned)((rest + 7) & ~(int64_t)7)), dim3(TPB), 0, s, p);
+                MR_CHECK_LAUNCH();
+            }
+            return MR_OK;
+        }
+        return MR_ERR_NOTIMPL;  // (lists are built for the flow-mode render only)
+    }
     hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC>), dim3((unsigned)nblocks), dim3(TPB), 0, s, p);
     MR_CHECK_LAUNCH();
     return MR_OK;
@@ -1043,8 +1153,9 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
                                     void* workspace, int64_t workspace_bytes, int batch_size, int num_verts,
                                     int num_faces, int fill_back, int image_size, float near_, float far_,
                                     float eps, int return_rgb, int return_alpha, int return_depth, int flags,
-                                    mr_stream_t stream) {
+                                    int texel_layout, mr_stream_t stream) {
     const int F = fill_back ? 2 * num_faces : num_faces;
+    if (!texel_layout_ok(texel_layout)) return MR_ERR_BADARG;
     if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
     if (((!verts || !faces_idx) && num_faces > 0) || !face_index_map || !weight_map || !workspace) return MR_ERR_BADARG;
     if (return_rgb && (!rgb_img || (!vcolors && num_faces > 0) || !background || !(eps >= 1e-6f))) return MR_ERR_BADARG;
@@ -1069,6 +1180,7 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
     p.B = batch_size; p.F = F; p.is = image_size; p.ts = 2;
     p.near_ = near_; p.far_ = far_; p.eps = eps;
     p.verts = verts; p.fidx = faces_idx; p.vcolors = vcolors; p.V = num_verts; p.F0 = num_faces;
+    p.texel = texel_layout;
     p.dbg = (flags >> 8) & 0xffff;  // profiling experiments (scripts/fwd_vc_variants.py)
     if (p.dbg & 128) return MR_OK;  // ... binning pass alone
     return launch_tiles<true, true>(p, s);
@@ -1086,23 +1198,34 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
                                       float* depth_img, float* weight_map, int32_t* face_index_map, uint8_t* tile_hit,
                                       void* workspace, int64_t workspace_bytes, int batch_size,
                                       int num_verts, int num_faces, int fill_back, int image_size, float near_,
-                                      float far_, float eps, int flags, int32_t* vertex_id_map, mr_stream_t stream) {
+                                      float far_, float eps, int flags, int32_t* vertex_id_map, int tile_bound,
+                                      uint32_t* tile_count_out, float* zero_fill, int64_t zero_fill_count,
+                                      int texel_layout, mr_stream_t stream) {
     const int F = fill_back ? 2 * num_faces : num_faces;
+    if (!texel_layout_ok(texel_layout)) return MR_ERR_BADARG;
     if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
     if (((!verts || !faces_idx || !vcolors) && num_faces > 0) || !face_index_map || !workspace) return MR_ERR_BADARG;
     if (vertex_id_map && !weight_map) return MR_ERR_BADARG;
     if (!rgb_img || !alpha_img || !mask_img || !background || !(eps >= 1e-6f)) return MR_ERR_BADARG;
     if ((bg_stride != 0 && bg_stride != 3) || (keep_lut && n_lut <= 0)) return MR_ERR_BADARG;
     if (workspace_bytes < mr_render_workspace_bytes(batch_size, F, image_size)) return MR_ERR_BADARG;
-    if (batch_size == 0) return MR_OK;
-    if (batch_size > 65535) return MR_ERR_BADARG;
+    if (zero_fill_count < 0 || (zero_fill_count > 0 && !zero_fill)) return MR_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
+    if (batch_size == 0) {
+        if (zero_fill && zero_fill_count > 0) return (int)hipMemsetAsync(zero_fill, 0, (size_t)zero_fill_count * sizeof(float), s);
+        return MR_OK;
+    }
+    if (batch_size > 65535) return MR_ERR_BADARG;
     FwdParams p{};
     BinParams bp{};
     bp.verts = verts; bp.fidx = faces_idx; bp.V = num_verts; bp.F0 = num_faces; bp.fill_back = fill_back;
     bp.dbg = flags >> 24;
-    const int rc = launch_bins<true>(bp, p, workspace, batch_size, F, image_size, s);
+    bp.zero_fill = zero_fill_count > 0 ? zero_fill : nullptr; bp.zero_count = zero_fill_count;
+    if ((flags & MR_FLAG_SPARSE_TILES) && !tile_hit) return MR_ERR_BADARG;
+    const bool listed = (flags & MR_FLAG_SPARSE_TILES) && tile_bound != 0;
+    const int rc = launch_bins<true>(bp, p, workspace, batch_size, F, image_size, s, listed ? tile_hit : nullptr);
     if (rc != MR_OK) return rc;
+    p.tile_count_out = p.tlist ? tile_count_out : nullptr;
     p.background = background; p.bg_stride = bg_stride;
     p.rgb = rgb_img; p.rgb_channels = 2;
     p.alpha = alpha_img; p.mask = mask_img;
@@ -1114,7 +1237,8 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
     p.B = batch_size; p.F = F; p.is = image_size; p.ts = 2;
     p.near_ = near_; p.far_ = far_; p.eps = eps;
     p.verts = verts; p.fidx = faces_idx; p.vcolors = vcolors; p.V = num_verts; p.F0 = num_faces;
+    p.texel = texel_layout;
     p.dbg = (flags >> 8) & 0xffff;
     if (p.dbg & 128) return MR_OK;
-    return launch_tiles<true, true>(p, s);
+    return launch_tiles<true, true>(p, s, tile_bound);
 }

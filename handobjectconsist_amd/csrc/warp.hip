@@ -1013,7 +1013,7 @@ extern "C" int mr_pair_consist_backward(const float* flow12, const float* flow21
     return MR_OK;
 }
 
-extern "C" int mr_abi_version(void) { return 1; }
+extern "C" int mr_abi_version(void) { return MR_ABI_VERSION; }
 
 extern "C" int mr_device_ok(void) {
     // the calling thread's CURRENT device: that is where every entry point of this library launches

@@ -29,10 +29,16 @@ def consist_lambdas(step_count, lambda_data, lambda_consist, progressive_consist
 
 
 def _mean_over_samples(per_sample_losses):
-    """{name: mean over samples} for the entries the FIRST sample reports (warpreg.py:97-101)."""
+    """{name: mean over samples} for the entries the FIRST sample reports (warpreg.py:97-101: ``torch.stack(...).mean()``
+    per name).  Same values from fewer launches: a batch of one frame needs none (the mean of one number is that
+    number), several frames take ONE stack and ONE mean over the sample axis for all names together."""
     first = per_sample_losses[0]
-    return {name: torch.stack([ls[name] for ls in per_sample_losses]).mean()
-            for name, value in first.items() if value is not None}
+    names = [name for name, value in first.items() if value is not None]
+    if len(per_sample_losses) == 1:
+        return {name: first[name].reshape(()) for name in names}
+    table = torch.stack([ls[name].reshape(()) for name in names for ls in per_sample_losses])
+    means = table.view(len(names), len(per_sample_losses)).mean(1)
+    return dict(zip(names, means.unbind(0)))
 
 
 class WarpRegNet(torch.nn.Module):
@@ -113,11 +119,15 @@ class WarpRegNet(torch.nn.Module):
 
         loss, pair_results = 0, None
         if "data" in supervision:
-            aggregate_losses["reg_loss"] = torch.cat(mesh_losses).mean()
+            # torch.cat(mesh_losses).mean() (warpreg.py:111); a one-frame batch IS its mean
+            aggregate_losses["reg_loss"] = mesh_losses[0].reshape(()) if (len(mesh_losses) == 1 and mesh_losses[0].numel() == 1) \
+                else torch.cat(mesh_losses).mean()
             loss = loss + lambda_data * aggregate_losses["reg_loss"]
         if "consist" in supervision:
             warp_loss, pair_results = self.warp_forward(samples, all_results)
-            pose_shape_reg = torch.stack([ls["mano_reg_loss"] for ls in all_losses]).mean()
+            # (= torch.stack([...mano_reg_loss...]).mean(), warpreg.py:117: the aggregate computed above)
+            pose_shape_reg = aggregate_losses["mano_reg_loss"] if all_losses[0].get("mano_reg_loss") is not None \
+                else torch.stack([ls["mano_reg_loss"] for ls in all_losses]).mean()
             loss = loss + lambda_data * pose_shape_reg + lambda_consist * warp_loss
             aggregate_losses["warp_consist"] = warp_loss
             self.step_count += 1

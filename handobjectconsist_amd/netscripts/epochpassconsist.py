@@ -47,8 +47,14 @@ def train_step(batches, premodel, optimizer, check_nan=True, reducer=None):
     and raises ``ValueError``.  The reference reads the loss on the host before ``backward`` -- a pipeline drain
     per step (measured here: 1.3 ms with the check before ``backward``, 0.7 ms before ``step``).  Here the flag
     stays on the device: it switches the fused optimiser's update off (its ``found_inf`` operand), and the host
-    looks at it when the NEXT step starts (or in ``raise_pending_nan`` / at the end of ``epoch_pass``), when it
-    has long been computed.  Optimisers without that operand get the synchronous check before ``step``.
+    looks at it when the NEXT step starts, when it has long been computed.
+
+    Contract for callers that drive ``train_step`` themselves (``epoch_pass`` does this for its callers): the
+    ``ValueError`` of step k is raised by the call for step k + 1, so after the LAST step call
+    ``raise_pending_nan(optimizer)`` -- otherwise a NaN in the last step goes unreported (its update was skipped, but
+    the returned / logged loss of that step is NaN).  An ``optimizer.grad_scale`` / ``found_inf`` a caller has set
+    (AMP's GradScaler protocol) is put back after the step.  Optimisers without the ``found_inf`` operand get the
+    synchronous check before ``step`` (one host read per step, as in the reference).
     ``reducer`` (data-parallel runs): a ``gradreduce.BucketedGradReducer`` over the model's parameters; its
     all-reduces are issued from inside ``backward`` and joined before the optimiser reads the gradients."""
     if check_nan:
@@ -70,15 +76,20 @@ def train_step(batches, premodel, optimizer, check_nan=True, reducer=None):
     nan_flag = torch.isnan(loss.detach()) if check_nan else None
     optimizer.zero_grad(set_to_none=True)
     if loss.requires_grad:
-        loss.backward()
+        if reducer is not None and reducer.loss_scale != 1.0:
+            (loss * reducer.loss_scale).backward()  # summed over the ranks: the mean gradient
+        else:
+            loss.backward()
         if reducer is not None:
             reducer.finish()
         if check_nan and _device_guarded(optimizer):
+            had = {k: optimizer.__dict__[k] for k in ("grad_scale", "found_inf") if k in optimizer.__dict__}
             optimizer.grad_scale, optimizer.found_inf = None, nan_flag.to(torch.float32).reshape(())
             try:
                 optimizer.step()
             finally:
                 del optimizer.grad_scale, optimizer.found_inf
+                optimizer.__dict__.update(had)
             optimizer._hoc_pending_nan = nan_flag
         else:
             if check_nan and bool(nan_flag):

@@ -15,8 +15,12 @@ communicated: 30.1-30.7 ms per step against 26.6 ms without the wrapper, 430 aga
   each bucket owns ONE flat buffer and per-parameter views of it with the parameter's own (dense) strides;
 * a post-accumulate hook per parameter counts the bucket down; the hook of the LAST gradient of a bucket copies
   the bucket's gradients into the flat buffer with one multi-tensor copy, points ``p.grad`` at the views and
-  issues ONE asynchronous all-reduce (average) of the flat buffer -- on the collective's own stream, behind the
+  issues ONE asynchronous all-reduce (sum) of the flat buffer -- on the collective's own stream, behind the
   copy, overlapping the rest of the backward pass (the encoder's, ~17 ms at B = 64);
+* the mean over the ranks comes from scaling the LOSS by ``loss_scale`` = 1 / world size before ``backward()``
+  (``train_step`` does it; exact for the power-of-two rank counts of a node) instead of from an averaging
+  collective or a division pass over the gradients (RCCL's AVG is a pre-multiplied sum: an extra 47.9 MB
+  scaling kernel per step even on one rank, profiles/r03_one_rank_reducer_overlap_v1.txt);
 * ``finish()`` after ``backward()`` flushes buckets with parameters that received no gradient (zeros, so that
   every rank reduces the same buckets) and makes the compute stream wait for the collectives; the optimiser
   then reads the averaged gradients straight from the views.
@@ -60,7 +64,7 @@ def _is_dense_permutation(t):
 
 
 class BucketedGradReducer:
-    """``reducer = BucketedGradReducer(model.parameters())``; per step: forwards, ``loss.backward()``,
+    """``reducer = BucketedGradReducer(model.parameters())``; per step: forwards, ``(loss * reducer.loss_scale).backward()``,
     ``reducer.finish()``, ``optimizer.step()`` (with ``zero_grad`` anywhere before the next backward; ONE
     backward per ``finish()`` -- the step structure of epochpassconsist.py:57-68).  ``process_group=None`` = the
     default group."""
@@ -69,8 +73,7 @@ class BucketedGradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.backend = dist.get_backend(process_group)
-        # RCCL averages inside the collective; gloo has no AVG: sum, then one scale per bucket
-        self._avg_in_collective = self.backend == "nccl"
+        self.loss_scale = 1.0 / self.world  # multiply the loss by this before backward(): summed gradients = the mean
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError("no trainable parameter")
@@ -128,20 +131,17 @@ class BucketedGradReducer:
                 if p.grad is None:
                     v.zero_()  # a parameter without a gradient contributes zeros on this rank
                 p.grad = v
-        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
-        b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         b.launched = True
 
     def finish(self):
         """After ``backward()``: every bucket reduced, the current stream ordered behind the collectives,
-        ``p.grad`` = the rank-averaged gradient (a view into the bucket's flat buffer)."""
+        ``p.grad`` = the rank-summed gradient of the pre-scaled loss = the mean gradient (a view into the bucket's flat buffer)."""
         for b in self.buckets:
             if not b.launched:
                 self._launch(b)
         for b in self.buckets:
             b.work.wait()
-            if not self._avg_in_collective and self.world > 1:
-                b.flat.div_(self.world)
             b.work, b.launched, b.pending = None, False, len(b.params)
 
     def remove(self):

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from handobjectconsist_amd import _lib
+from handobjectconsist_amd.utils import textutils
 
 DEFAULT_IMAGE_SIZE = 256
 DEFAULT_ANTI_ALIASING = True
@@ -309,7 +310,7 @@ class RasterizeVertexColorFunction(Function):
         _lib.call("mr_render_vc_forward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(cols), _lib.ptr(bg), bg_stride,
                   _lib.ptr(rgb), _lib.ptr(alpha), _lib.ptr(depth), _lib.ptr(fim), _lib.ptr(wmap), _lib.ptr(work),
                   int(wbytes), B, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps),
-                  int(return_rgb), int(return_alpha), int(return_depth), 0, _lib.stream_ptr(dev))
+                  int(return_rgb), int(return_alpha), int(return_depth), 0, textutils.texel_layout_code(), _lib.stream_ptr(dev))
         ctx.cfg = (is_, float(eps), bool(fill_back), bool(return_rgb), bool(return_depth))
         # the forward's own weight / depth maps feed the backward (no extra memory: they are outputs)
         ctx.save_for_backward(verts, fidx, fim, wmap, depth if return_depth else fim)
@@ -330,7 +331,7 @@ class RasterizeVertexColorFunction(Function):
         else:
             g = _lib.contig(grad_rgb)
             _lib.call("mr_render_vc_backward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(fim),
-                      _lib.ptr(wmap) if rd else None, _lib.ptr(depth) if rd else None, _lib.ptr(g), _lib.ptr(grad_cols), B, V, int(fidx.shape[1]), int(fill_back), is_, eps, 0,
+                      _lib.ptr(wmap) if rd else None, _lib.ptr(depth) if rd else None, _lib.ptr(g), _lib.ptr(grad_cols), B, V, int(fidx.shape[1]), int(fill_back), is_, eps, 0, textutils.texel_layout_code(),
                       _lib.stream_ptr(verts.device))
         return (None, None, grad_cols) + (None,) * 9
 
@@ -374,7 +375,7 @@ class RasterizeFlowFunction(Function):
         _lib.call("mr_render_flow_forward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(cols), _lib.ptr(bg), bg_stride,
                   _lib.ptr(lut), int(lut.numel()) if lut is not None else 0, float(alpha_thresh), _lib.ptr(rgb),
                   _lib.ptr(alpha), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(wmap), _lib.ptr(fim), None, _lib.ptr(work), int(wbytes),
-                  B, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps), 0, None, _lib.stream_ptr(dev))
+                  B, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps), 0, None, 0, None, None, 0, textutils.texel_layout_code(), _lib.stream_ptr(dev))
         ctx.cfg = (is_, float(eps), bool(fill_back))
         ctx.save_for_backward(verts, fidx, fim, wmap, depth)
         ctx.mark_non_differentiable(alpha, mask, fim)
@@ -393,7 +394,7 @@ class RasterizeFlowFunction(Function):
         else:
             g = _lib.contig(grad_rgb)
             _lib.call("mr_render_vc_backward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(fim), _lib.ptr(wmap), _lib.ptr(depth),
-                      _lib.ptr(g), _lib.ptr(grad_cols), B, V, int(fidx.shape[1]), int(fill_back), is_, eps, 0,
+                      _lib.ptr(g), _lib.ptr(grad_cols), B, V, int(fidx.shape[1]), int(fill_back), is_, eps, 0, textutils.texel_layout_code(),
                       _lib.stream_ptr(verts.device))
         return (None, None, grad_cols) + (None,) * 8
 

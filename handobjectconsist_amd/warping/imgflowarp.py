@@ -209,6 +209,15 @@ def _is_fused_l1(criterion):
 DEFAULT_PAIR_OUTPUTS = "full"
 
 
+def _coverage_of(stacked):
+    """The coverage bytes ``get_opticalflow`` attached to its stacked flows -- (None, 0) when there are none or when
+    the flows were written in place since (their version moved on: the bytes describe values that no longer exist)."""
+    note = getattr(stacked, "_hoc_coverage", None) if stacked is not None else None
+    if note is None or note[2] != stacked._version:
+        return None, 0
+    return note[0], note[1]
+
+
 def pair_consist(
     recons_flow,
     image_ref: torch.Tensor,
@@ -242,7 +251,7 @@ def pair_consist(
     if _is_fused_l1(criterion) and image.shape[1] == 3 and jitter_mask.shape[1] in (1, 3) and image.shape[-1] >= 2:
         want_debug = outputs == "full"
         stacked = _stacked_base(recons_flow[0], recons_flow[1])
-        coverage, coverage_size = getattr(stacked, "_hoc_coverage", (None, 0)) if stacked is not None else (None, 0)
+        coverage, coverage_size = _coverage_of(stacked)
         res = _PairConsistFunction.apply(stacked if stacked is not None else recons_flow[0],
                                          None if stacked is not None else recons_flow[1], image_ref, image,
                                          jitter_mask_ref, jitter_mask, 0.99999, want_debug, coverage, coverage_size)

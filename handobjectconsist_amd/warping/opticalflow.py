@@ -82,14 +82,31 @@ USE_STACKED_FLOW_NODE = True
 # ... and let the render skip the tiles of the screen that hold no candidate face entirely (MR_FLAG_SPARSE_TILES): the
 # occlusion / epilogue pass and the backward consult the render's coverage bytes before every read of a rendered plane.
 USE_SPARSE_TILES = True
-# tests: allocate the render's output planes filled with NaN / INT_MIN instead of uninitialised, so that any read of a
-# pixel the sparse render did not write shows up in the flows or the gradients
 # ... and leaves per-pixel RECORDS for its backward: the winner's three vertex ids and the three sampling weights their
 # colours enter the pixel with (instead of barycentrics + depth, from which the backward had to walk face index ->
 # vertex ids -> vertex depths): one load round trip per pixel in mr_render_flow_backward.  Same products, same sums.
 USE_PIXEL_RECORDS = True
-
+# tests: allocate the render's output planes filled with NaN / INT_MIN instead of uninitialised, so that any read of a
+# pixel the sparse render did not write shows up in the flows or the gradients
 DEBUG_POISON_RENDER_OUTPUTS = False
+# ... and dispatches workgroups only for the tiles that DO hold candidates: the binning pass compacts them into a list,
+# the tile kernel is launched over as many workgroups as the previous call on this (device, batch, raster) had
+# list entries (+ margin) -- the kernel reports its list length into a pinned host word, read here without any
+# synchronisation; a stale or missing value only changes how the list is split over launches, never the images.
+USE_TILE_LIST = True
+
+_TILE_COUNTS = {}
+
+
+def _tile_bound(dev, B2, is_):
+    """(guess of the tile-list length for mr_render_flow_forward, pinned word the kernel writes the real one to)."""
+    key = (dev.index, B2, is_)
+    word = _TILE_COUNTS.get(key)
+    if word is None:
+        word = torch.zeros(1, dtype=torch.int32).pin_memory()
+        _TILE_COUNTS[key] = word
+    last = int(word[0])  # host memory: no device synchronisation
+    return (last + last // 8 + 64 if last > 0 else -1), word
 
 
 class _FlowVertexStage(torch.autograd.Function):
@@ -293,10 +310,16 @@ class _StackedFlowFunction(torch.autograd.Function):
         from handobjectconsist_amd.neurender import rasterize
 
         ctx.set_materialize_grads(False)
+        _lib.check_cuda(ndc, faces2, cols, lut)
+        if not (float(eps) >= 1e-6):
+            raise ValueError("vertex-colour rendering needs eps >= 1e-6")
         verts, fidx, c = _lib.contig(ndc.detach()), faces2, _lib.contig(cols.detach())
         dev = verts.device
         B2, V = verts.shape[:2]
         B, F0, is_ = B2 // 2, fidx.shape[1], int(image_size)
+        if (fidx.dtype != torch.int32 or not fidx.is_contiguous() or B2 % 2 or fidx.shape != (B2, F0, 3)
+                or verts.shape != (B2, V, 3) or c.shape != (B2, V, 3)):
+            raise ValueError("expected stacked vertices / colours [2B,V,3] and contiguous int32 faces [2B,F,3]")
         f32 = dict(dtype=torch.float32, device=dev)
         bg, bg_stride = rasterize._background_tensor(background_color, dev, B2)
         if DEBUG_POISON_RENDER_OUTPUTS:
@@ -317,11 +340,16 @@ class _StackedFlowFunction(torch.autograd.Function):
         wbytes = int(_lib.load().mr_render_workspace_bytes(B2, F, is_))
         work = torch.empty((max(wbytes, 8),), dtype=torch.uint8, device=dev)
         st = _lib.stream_ptr(dev)
+        bound, count_word = _tile_bound(dev, B2, is_) if (USE_SPARSE_TILES and USE_TILE_LIST) else (0, None)
+        # the backward's output buffer is cleared by the render's binning pass on its way (its own clearing would be a
+        # launch on the backward pass's critical path); a second backward through this node clears its own
+        grad_buf = torch.empty((B2, V, 3), **f32) if ctx.needs_input_grad[2] else None
         _lib.call("mr_render_flow_forward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(c), _lib.ptr(bg), bg_stride,
                   _lib.ptr(lut), int(lut.numel()) if lut is not None else 0, 0.99999, _lib.ptr(rgb), _lib.ptr(alpha),
                   _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(wmap), _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(work), wbytes,
                   B2, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps),
-                  _lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0, _lib.ptr(vid), st)
+                  _lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0, _lib.ptr(vid), bound, _lib.ptr(count_word), _lib.ptr(grad_buf),
+                  int(grad_buf.numel()) if grad_buf is not None else 0, textutils.texel_layout_code(), st)
         occl = torch.empty((B2, is_, is_), **f32)
         flow = torch.empty((B2, height, width, 2), **f32)
         # occlusion check + crop / permute / mask products of both directions in one pass.  mask_flow2 is the RAW
@@ -333,6 +361,7 @@ class _StackedFlowFunction(torch.autograd.Function):
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width)
         ctx.save_for_backward(verts, fidx, fim, tile_hit, wmap, depth if depth is not None else vid, mask, alpha, occl)
         ctx.records = depth is None
+        ctx.grad_buf = grad_buf
         ctx.mark_non_differentiable(tile_hit)
         return flow, tile_hit
 
@@ -346,11 +375,14 @@ class _StackedFlowFunction(torch.autograd.Function):
         B2, V = verts.shape[:2]
         B = B2 // 2
         g = _lib.contig(grad_flow)
-        grad_cols = torch.empty((B2, V, 3), dtype=torch.float32, device=verts.device)
+        grad_cols, ctx.grad_buf = ctx.grad_buf, None
+        zeroed = grad_cols is not None
+        if not zeroed:
+            grad_cols = torch.empty((B2, V, 3), dtype=torch.float32, device=verts.device)
         _lib.call("mr_render_flow_backward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(wmap),
                   _lib.ptr(depth), None, _lib.ptr(g), _lib.ptr(mask), _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), B,
-                  _lib.ptr(occl), height, width, _lib.ptr(grad_cols), B2, V, int(fidx.shape[1]), int(fill_back), is_, eps, 0,
-                  _lib.ptr(vid), _lib.stream_ptr(verts.device))
+                  _lib.ptr(occl), height, width, _lib.ptr(grad_cols), B2, V, int(fidx.shape[1]), int(fill_back), is_, eps,
+                  _lib.FLAG_OUTPUT_ZEROED if zeroed else 0, _lib.ptr(vid), textutils.texel_layout_code(), _lib.stream_ptr(verts.device))
         return (None, None, grad_cols) + (None,) * 9
 
 
@@ -417,7 +449,8 @@ def get_opticalflow(
                 neurenderer.rasterizer_eps, neurenderer.background_color, min(int(H), is_), min(int(W), is_))
             # the coverage bytes of the two renders ride along: a consumer that knows them (pair_consist) does not
             # even read the flows where nothing was rendered (they are exactly zero there)
-            flows._hoc_coverage = (tile_hit, is_)
+            # (recorded with the tensor's version: an in-place write into the flows invalidates the hand-over)
+            flows._hoc_coverage = (tile_hit, is_, flows._version)
             return [flows[:B], flows[B:]]
         # both renders of the pair as one launch over 2B meshes, in the training path's output set (no depth /
         # weight maps, third colour plane untouched, flow mask folded into the render)
@@ -427,49 +460,46 @@ def get_opticalflow(
         else:
             ro = neurenderer.render_projected_vertex_colors(ndc, _stacked_faces(faces), cols)
         return _fused_epilogue_stacked(ro, orig_img_size, ignore_face_idxs)
-    gt_locs2d_1 = project.batch_proj2d(verts_cam[0], camintrs[0])
-    gt_locs2d_2 = project.batch_proj2d(verts_cam[1], camintrs[1])
-    # forward optical flow
-    verts_displ2d_12 = gt_locs2d_2 - gt_locs2d_1
-    sample_flows = torch.cat([verts_displ2d_12, torch.ones_like(verts_displ2d_12[:, :, :1])], -1)
-    renderout = _render_flow(neurenderer, verts_cam[0], faces, sample_flows, camintrs[0], detach_textures,
-                             detach_renders)
-    fuse = (USE_FUSED_EPILOGUE and mask_occlusions and renderout["rgb"].is_cuda and renderout["rgb"].dim() == 4
-            and renderout["rgb"].shape[2] == renderout["rgb"].shape[3] == renderout["face_index_map"].shape[1])
-    if fuse:
-        verts_displ2d_21 = gt_locs2d_1 - gt_locs2d_2
-        sample_flows = torch.cat([verts_displ2d_21, torch.ones_like(verts_displ2d_21[:, :, :1])], -1)
-        renderout2 = _render_flow(neurenderer, verts_cam[1], faces, sample_flows, camintrs[1], False, detach_renders)
-        return _fused_epilogue(renderout, renderout2, orig_img_size, ignore_face_idxs)
-    mask_flow1 = (renderout["alpha"].unsqueeze(1) > 0.99999).float()
-    if ignore_face_idxs is not None:
-        mask_flow1 = mask_flow1 * _ignore_mask(renderout["face_index_map"], ignore_face_idxs)
-    pred_flow12 = renderout["rgb"] * mask_flow1
-
-    # backward optical flow
-    verts_displ2d_21 = gt_locs2d_1 - gt_locs2d_2
-    sample_flows = torch.cat([verts_displ2d_21, torch.ones_like(verts_displ2d_21[:, :, :1])], -1)
-    # (the reference never detaches the second texture set, opticalflow.py:123)
-    renderout = _render_flow(neurenderer, verts_cam[1], faces, sample_flows, camintrs[1], False, detach_renders)
-    mask_flow2 = (renderout["alpha"].unsqueeze(1) > 0.99999).float()
-    if ignore_face_idxs is not None:
-        mask_flow2 = mask_flow2 * _ignore_mask(renderout["face_index_map"], ignore_face_idxs)
-    pred_flow21 = renderout["rgb"] * mask_flow2
-
+    # Every other setting (attached renders, materialised textures, no occlusion masking, CPU-side callers of the
+    # drop-in): the same algebra from this module's own pieces, one direction at a time.
+    pixels = [project.batch_proj2d(v, K) for v, K in zip(verts_cam, camintrs)]
+    renders, valid = [], []
+    # (only the FIRST direction's texture honours detach_textures, opticalflow.py:100-102 vs :123)
+    for src, detach_tex in ((0, detach_textures), (1, False)):
+        ro, m = _render_direction(neurenderer, verts_cam[src], faces, pixels[1 - src] - pixels[src], camintrs[src], detach_tex,
+                                  detach_renders, ignore_face_idxs)
+        renders.append(ro)
+        valid.append(m)
+    rgb = renders[0]["rgb"]
+    if (USE_FUSED_EPILOGUE and mask_occlusions and rgb.is_cuda and rgb.dim() == 4
+            and rgb.shape[2] == rgb.shape[3] == renders[0]["face_index_map"].shape[1]):
+        return _fused_epilogue(renders[0], renders[1], orig_img_size, ignore_face_idxs)
+    flows = [ro["rgb"] * m for ro, m in zip(renders, valid)]
     if mask_occlusions:
+        # from here on the second direction's mask is the RAW alpha of its render (no threshold, no ignore list)
+        raw_alpha2 = renders[1]["alpha"].unsqueeze(1)
         with torch.no_grad():
-            mask_flow2 = renderout["alpha"].unsqueeze(1)
-            occl_mask1, occl_mask2 = imgflowarp.get_occlusion_mask(
-                mask_flow1, mask_flow2, pred_flow12, pred_flow21
-            )
-        mask_flow1 = mask_flow1 * occl_mask1.unsqueeze(1)
-        mask_flow2 = mask_flow2 * occl_mask2.unsqueeze(1)
-        pred_flow12 = pred_flow12 * mask_flow1
-        pred_flow21 = pred_flow21 * mask_flow2
-    pred_flow12 = pred_flow12.permute(0, 2, 3, 1)[:, :, :, :2]
-    pred_flow21 = pred_flow21.permute(0, 2, 3, 1)[:, :, :, :2]
+            visible = imgflowarp.get_occlusion_mask(valid[0], raw_alpha2, flows[0], flows[1])
+        flows = [flow * (m * vis.unsqueeze(1)) for flow, m, vis in zip(flows, (valid[0], raw_alpha2), visible)]
+    return [_pixels_last_xy(flow, orig_img_size) for flow in flows]
+
+
+def _render_direction(neurenderer, verts, faces, displacement, camintr, detach_textures, detach_renders, ignore_face_idxs):
+    """One direction of the pair: the per-vertex displacement painted as colours ``(dx, dy, 1)`` on the mesh at
+    ``verts`` and rendered (opticalflow.py:100-108 / :121-126), and where that render is to be believed: opaque
+    pixels whose winning face is not on the ignore list (:109-117 / :127-135)."""
+    colours = torch.cat([displacement, torch.ones_like(displacement[:, :, :1])], -1)
+    renderout = _render_flow(neurenderer, verts, faces, colours, camintr, detach_textures, detach_renders)
+    believed = (renderout["alpha"].unsqueeze(1) > 0.99999).float()
+    if ignore_face_idxs is not None:
+        believed = believed * _ignore_mask(renderout["face_index_map"], ignore_face_idxs)
+    return renderout, believed
+
+
+def _pixels_last_xy(flow, orig_img_size):
+    """[B,3,is,is] -> [B,H,W,2]: channels last, the constant third channel dropped, cropped to the frame
+    (opticalflow.py:146-154; ``orig_img_size`` is (width, height))."""
+    flow = flow.permute(0, 2, 3, 1)[:, :, :, :2]
     if orig_img_size is not None:
-        pred_flow12 = pred_flow12[:, : orig_img_size[1], : orig_img_size[0]]
-        pred_flow21 = pred_flow21[:, : orig_img_size[1], : orig_img_size[0]]
-    pred_flows = [pred_flow12, pred_flow21]
-    return pred_flows
+        flow = flow[:, : orig_img_size[1], : orig_img_size[0]]
+    return flow

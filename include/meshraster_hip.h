@@ -41,6 +41,16 @@ extern "C" {
  * NOTHING else -- the image planes and face_index_map keep whatever they held there.  For callers that consult
  * tile_hit before every read of a rendered plane (mr_occlusion_flow and mr_render_flow_backward do). */
 #define MR_FLAG_SPARSE_TILES 2
+/* mr_render_flow_backward: grad_vcolors holds zeros on entry (mr_render_flow_forward's zero_fill wrote them, or the
+ * caller did): the call does not clear it again -- one launch and 12 B per vertex less on the backward's critical path. */
+#define MR_FLAG_OUTPUT_ZEROED 4
+
+/* texel_layout argument of the vertex-colour entry points (mr_render_vc_*, mr_render_flow_*): which vertex's colour the
+ * three non-zero texels of the 2x2x2 texture of libyana's batch_vertex_textures hold -- two bits per texel axis,
+ * sigma(0) | sigma(1) << 2 | sigma(2) << 4, texel (1,0,0) = vertex sigma(0), (0,1,0) = sigma(1), (0,0,1) = sigma(2) of
+ * the face.  libyana's source is absent from the reference tree; the default is the identity (ASSUMED).
+ * 0 selects the default; anything else must be a permutation of {0,1,2}. */
+#define MR_TEXEL_LAYOUT_DEFAULT (0 | 1 << 2 | 2 << 4)
 
 #if defined(__GNUC__)
 #define MR_API __attribute__((visibility("default")))
@@ -50,7 +60,11 @@ extern "C" {
 
 typedef void* mr_stream_t;
 
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any signature change): what mr_abi_version() of a matching library returns.
+ * 2: mr_pair_consist_* coverage arguments, mr_occlusion_flow, mr_render_flow_*, workspace queries (round 2);
+ * 3: mr_render_flow_forward tile_bound / tile_count_out / zero_fill, MR_FLAG_OUTPUT_ZEROED, texel_layout of the four
+ *    vertex-colour entry points. */
+#define MR_ABI_VERSION 3
 MR_API int mr_abi_version(void);
 /* 1 if the calling thread's CURRENT HIP device is a gfx950, else 0.
  * Device contract of every entry point below: kernels are launched on the calling thread's current HIP
@@ -171,14 +185,16 @@ MR_API int mr_render_backward(const float* faces, const float* textures,
  * coordinates, nor the [B,F,2,2,2,3] textures, nor their fill-back copies ever exist in HBM.
  * With fill_back, face index fn >= F0 denotes face fn - F0 with reversed vertex order.
  * Outputs as mr_render_forward (face_index_map values in [0, 2 F0)); bit-identical to rendering
- * the materialised textures.  workspace: mr_render_workspace_bytes(B, fill_back ? 2 F0 : F0, is). */
+ * the materialised textures.  workspace: mr_render_workspace_bytes(B, fill_back ? 2 F0 : F0, is).
+ * texel_layout: see MR_TEXEL_LAYOUT_DEFAULT (0 = default). */
 MR_API int mr_render_vc_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
                                 const float* background, int bg_stride, float* rgb_img,
                                 float* alpha_img, float* depth_img, int32_t* face_index_map,
                                 float* weight_map, void* workspace, int64_t workspace_bytes,
                                 int batch_size, int num_verts, int num_faces, int fill_back,
                                 int image_size, float near_, float far_, float eps, int return_rgb,
-                                int return_alpha, int return_depth, int flags, mr_stream_t stream);
+                                int return_alpha, int return_depth, int flags, int texel_layout,
+                                mr_stream_t stream);
 
 /* Adjoint of the above w.r.t. vcolors (kernel E composed with the adjoints of
  * batch_vertex_textures and of the fill-back concatenation): grad_vcolors[B,V,3] is zeroed
@@ -190,7 +206,7 @@ MR_API int mr_render_vc_backward(const float* verts, const int32_t* faces_idx,
                                  const int32_t* face_index_map, const float* weight_map,
                                  const float* depth_img, const float* grad_rgb_img,
                                  float* grad_vcolors, int batch_size, int num_verts, int num_faces,
-                                 int fill_back, int image_size, float eps, int flags,
+                                 int fill_back, int image_size, float eps, int flags, int texel_layout,
                                  mr_stream_t stream);
 
 /* mr_render_vc_forward restricted to what get_opticalflow consumes from its two renders (opticalflow.py:108-118,
@@ -206,7 +222,18 @@ MR_API int mr_render_vc_backward(const float* verts, const int32_t* faces_idx,
  * gets the vertex ids of its winning face there and weight_map receives the three SAMPLING weights of the colour
  * taps (the factors the colours of those vertices enter the pixel with) instead of the barycentrics; depth_img may
  * then be NULL.  These per-pixel records are all mr_render_flow_backward needs: one load round trip per pixel
- * instead of face index -> vertex ids -> vertex depths. */
+ * instead of face index -> vertex ids -> vertex depths.
+ * tile_bound (with MR_FLAG_SPARSE_TILES, rasters of at most 8192 tiles): != 0 makes the binning pass compact the tiles
+ * that hold candidate faces into a list -- it writes the zero coverage bytes of all other tiles itself -- and the tile
+ * kernel is launched over about tile_bound workgroups that walk this list with a grid stride, instead of one workgroup
+ * per screen tile of which four in five find nothing to do.  tile_bound is the caller's GUESS of the list length (> 0;
+ * < 0: a quarter of the tiles); any value gives the same images -- a list longer than the grid is walked in several
+ * rounds, surplus workgroups leave at once.  tile_count_out (nullable; any address the device can write, e.g. pinned
+ * host memory): receives the list length of this call, the natural guess for the next call on similar scenes.
+ * tile_bound == 0: one workgroup per tile.
+ * zero_fill (nullable) / zero_fill_count: a float buffer the binning pass clears on its way -- meant for the gradient
+ * buffer [B, V, 3] of the matching mr_render_flow_backward call (MR_FLAG_OUTPUT_ZEROED there), whose own clearing
+ * would sit on the backward pass's critical path. */
 MR_API int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
                                   const float* background, int bg_stride, const float* keep_lut, int n_lut,
                                   float alpha_thresh, float* rgb_img, float* alpha_img, float* mask_img,
@@ -214,7 +241,8 @@ MR_API int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, 
                                   void* workspace, int64_t workspace_bytes,
                                   int batch_size, int num_verts, int num_faces, int fill_back, int image_size,
                                   float near_, float far_, float eps, int flags, int32_t* vertex_id_map,
-                                  mr_stream_t stream);
+                                  int tile_bound, uint32_t* tile_count_out, float* zero_fill,
+                                  int64_t zero_fill_count, int texel_layout, mr_stream_t stream);
 
 /* Adjoint of mr_render_flow_forward w.r.t. vcolors, with the adjoint of the flow epilogue of get_opticalflow
  * (opticalflow.py:146-154: mask products, permute, [:2], crop) folded in.  The incoming gradient is either
@@ -226,7 +254,7 @@ MR_API int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, 
  * weight_map / depth_img / tile_hit as written by mr_render_flow_forward (tile_hit nullable: every tile is read).
  * vertex_id_map: as written by mr_render_flow_forward together with the sampling weights in weight_map, or NULL
  * (weight_map then holds barycentrics and verts / faces_idx / depth_img are read instead; with the records given those
- * three may be NULL).
+ * three may be NULL, and texel_layout is not consulted: the records already name the vertices behind the colour taps).
  * Needs image_size to be a multiple of 4 with at most 4096 tiles, and the [V,3] table to fit LDS (V <= 2560);
  * MR_ERR_NOTIMPL otherwise
  * (callers then use mr_flow_finalize_backward + mr_render_vc_backward). */
@@ -236,7 +264,7 @@ MR_API int mr_render_flow_backward(const float* verts, const int32_t* faces_idx,
                                    const float* mask_x_lo, const float* mask_x_hi, int split, const float* occl,
                                    int height, int width, float* grad_vcolors, int batch_size, int num_verts,
                                    int num_faces, int fill_back, int image_size, float eps, int flags,
-                                   const int32_t* vertex_id_map, mr_stream_t stream);
+                                   const int32_t* vertex_id_map, int texel_layout, mr_stream_t stream);
 
 /* Per-vertex front end of get_opticalflow in its training setting (SURVEY 8f "f1"): for the two
  * frames of a pair, in one launch

@@ -43,5 +43,5 @@ if os.environ.get("ONLY_FULL"):
     VARIANTS = (("full", 0),)
 for name, dbg in VARIANTS:
     fn = lambda: _lib.call("mr_render_vc_forward", P(pv), P(pf), P(cols), P(bg), 0, P(rgb), P(alpha), P(depth), P(fim),
-                           P(wmap), P(work), wbytes, B2, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, dbg << 8, st)
+                           P(wmap), P(work), wbytes, B2, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, dbg << 8, 0, st)
     print(f"{name:42s} {bench.event_time_ms(fn, 20, flush=flush) * 1e3:8.1f} us cold {bench.event_time_ms(fn, 30) * 1e3:8.1f} us warm")

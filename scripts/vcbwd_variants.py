@@ -21,12 +21,12 @@ rgb, alpha, depth = torch.empty((B, 3, is_, is_), **f32), torch.empty((B, is_, i
 fim = torch.empty((B, is_, is_), dtype=torch.int32, device=dev); wmap = torch.empty((B, is_, is_, 3), **f32)
 wbytes = int(lib.mr_render_workspace_bytes(B, 2 * F0, is_)); work = torch.empty((wbytes,), dtype=torch.uint8, device=dev)
 bg = torch.zeros(3, **f32)
-_lib.call("mr_render_vc_forward", P(v), P(fidx), P(colors), P(bg), 0, P(rgb), P(alpha), P(depth), P(fim), P(wmap), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+_lib.call("mr_render_vc_forward", P(v), P(fidx), P(colors), P(bg), 0, P(rgb), P(alpha), P(depth), P(fim), P(wmap), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, 0, 0, st)
 g_rgb = torch.randn_like(rgb); g_cols = torch.empty_like(colors)
 flush = torch.zeros(768 * 1024 * 1024 // 4, **f32)
 G = 32  # force the face-parallel gather kernel
 for name, dbg in (("scatter: full", 0), ("scatter: no flush", 1), ("scatter: no shade", 2), ("scatter: no shade, no flush", 3), ("scatter: no lds atomics", 4), ("scatter: fim pass only", 8), ("scatter: loads + zeroing only", 16), ("scatter, recompute: full", 64),
                   ("gather: full", G), ("gather: no global atomics", G | 1), ("gather: no shade", G | 2),
                   ("gather: no probes (setup only)", G | 7), ("gather: loads only", G | 8), ("gather: loads + boxes", G | 16)):
-    fn = lambda: _lib.call("mr_render_vc_backward", P(v), P(fidx), P(fim), P(wmap), P(depth), P(g_rgb), P(g_cols), B, V, F0, 1, is_, 1e-3, dbg << 8, st)
+    fn = lambda: _lib.call("mr_render_vc_backward", P(v), P(fidx), P(fim), P(wmap), P(depth), P(g_rgb), P(g_cols), B, V, F0, 1, is_, 1e-3, dbg << 8, 0, st)
     print(f"{name:30s} cold {bench.event_time_ms(fn, 20, flush=flush) * 1e3:8.1f} us   warm {bench.event_time_ms(fn, 20) * 1e3:8.1f} us")

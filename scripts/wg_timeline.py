@@ -28,7 +28,7 @@ wbytes = int(lib.mr_render_workspace_bytes(B2, 2 * F0, is_)); work = torch.empty
 bg = torch.zeros(3, **f32)
 lut = torch.ones(2 * F0 + 2, **f32)
 flush = torch.zeros(768 * 1024 * 1024 // 4, **f32)
-fn = lambda: _lib.call("mr_render_flow_forward", P(pv), P(pf), P(cols), P(bg), 0, P(lut), int(lut.numel()), 0.99999, P(rgb), P(alpha), P(mask), P(depth), P(wmap), P(fim), P(hit), P(work), wbytes, B2, V, F0, 1, is_, 0.1, 100.0, 1e-3, _lib.FLAG_SPARSE_TILES, None, st)
+fn = lambda: _lib.call("mr_render_flow_forward", P(pv), P(pf), P(cols), P(bg), 0, P(lut), int(lut.numel()), 0.99999, P(rgb), P(alpha), P(mask), P(depth), P(wmap), P(fim), P(hit), P(work), wbytes, B2, V, F0, 1, is_, 0.1, 100.0, 1e-3, _lib.FLAG_SPARSE_TILES, None, 0, None, None, 0, 0, st)
 print("cold %.1f us" % (bench.event_time_ms(fn, 10, flush=flush) * 1e3))
 flush.add_(1.0); torch.cuda.synchronize()
 fn(); torch.cuda.synchronize()

@@ -244,11 +244,30 @@ def gen_renderer():
     def run_render(key, ctor, call, detach_renders=False):
         ren = ref.renderer.Renderer(**{k: (T(arrays[v]) if isinstance(v, str) else v) for k, v in ctor.items()})
         vt, tt = T(verts, True), T(tex, True)
-        out = ren(vt, T(faces), tt, detach_renders=detach_renders,
-                  **{k: (T(arrays[v]) if isinstance(v, str) else v) for k, v in call.items()})
+        # the projected vertices the reference's render fed its rasteriser with, and the gradient that came back to
+        # them: a test that hands THESE to the HIP rasteriser sees no difference between two fp32 projections
+        nr_mod, seen = sys.modules["neural_renderer"], []
+        real_projection = nr_mod.projection
+
+        def recording_projection(*a, **kw):
+            out = real_projection(*a, **kw)
+            if out.requires_grad:
+                out.retain_grad()
+            seen.append(out)
+            return out
+
+        nr_mod.projection = recording_projection
+        try:
+            out = ren(vt, T(faces), tt, detach_renders=detach_renders,
+                      **{k: (T(arrays[v]) if isinstance(v, str) else v) for k, v in call.items()})
+        finally:
+            nr_mod.projection = real_projection
         loss = (out["rgb"] * T(arrays["g_rgb"])).sum() + (out["alpha"] * T(arrays["g_alpha"])).sum() \
             + (out["depth"] * T(arrays["g_depth"])).sum()
         loss.backward()
+        assert len(seen) == 1
+        arrays[f"{key}_ndc"] = N(seen[0])
+        arrays[f"{key}_grad_ndc"] = N(seen[0].grad) if seen[0].grad is not None else None
         for name in ("rgb", "alpha", "depth", "face_index_map", "weight_map", "face_inv_map"):
             arrays[f"{key}_{name}"] = N(out[name])
         arrays[f"{key}_grad_verts"] = N(vt.grad)
@@ -477,8 +496,7 @@ def gen_warpbranch():
 
 
 if __name__ == "__main__":
-    gen_rasterize()
-    gen_renderer()
-    gen_opticalflow()
-    gen_opticalflow_config_sizes()
-    gen_warpbranch()
+    gens = dict(rasterize=gen_rasterize, renderer=gen_renderer, opticalflow=gen_opticalflow,
+                opticalflow_cfg=gen_opticalflow_config_sizes, warpbranch=gen_warpbranch)
+    for name in (sys.argv[1:] or list(gens)):  # (every generator seeds its own rng: any subset reproduces its file)
+        gens[name]()

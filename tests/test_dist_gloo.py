@@ -44,7 +44,7 @@ def _worker(rank, world, port, out):
     for sample in consist["data"]:
         losses.append(0.5 * net(sample)[0])
     opt.zero_grad(set_to_none=True)
-    torch.stack([l.flatten() for l in losses]).sum().backward()
+    (torch.stack([l.flatten() for l in losses]).sum() * reducer.loss_scale).backward()
     launched_in_backward = sum(b.launched for b in reducer.buckets)
     reducer.finish()
     assert launched_in_backward == len(reducer.buckets), "every bucket is issued by the hook of its last gradient"

@@ -43,10 +43,14 @@ def test_bench_single_process_line(cuda):
     roof, cpu = line["roofline"], line["cpu_baseline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    assert abs(roof["achieved"] - roof["algorithmic_bytes"] / (roof["launch_ms"] * 1e-3) / 1e9) <= 0.02 * roof["achieved"]
+    assert abs(roof["achieved"] - roof["bytes"] / (roof["launch_ms"] * 1e-3) / 1e9) <= 0.02 * roof["achieved"]
     assert roof["device_kernels"] == ["scatter_tiles_kernel<true, true>"] and 0 < roof["frac_cache_warm"]
+    # the backward's fraction is on its own compulsory traffic (covered tiles), below 1 by construction; the SURVEY 8(d)
+    # figure rides along
+    assert 0 < roof["frac"] < 1 and roof["bytes"] < roof["algorithmic_bytes"] and roof["frac_algorithmic"] > roof["frac"]
     fwd = line["roofline_forward"]
-    assert fwd["bound"] == "hbm" and "raster_tile_kernel<true, true>" in fwd["device_kernels"] and fwd["launch_ms"] > 0
+    assert fwd["bound"] == "hbm" and "raster_tile_kernel<true, true, false, 7>" in fwd["device_kernels"] and fwd["launch_ms"] > 0
+    assert fwd["bytes"] == fwd["algorithmic_bytes"]
     for r in (roof, fwd):  # HBM bytes from the PMC passes this very run made (None only if rocprofv3 is unavailable)
         if r["traffic"] is not None:
             assert r["traffic"] >= r["traffic_low"] > 0 and r["dram_frac"] > 0
@@ -150,7 +154,31 @@ def test_config2_data_only_step(cuda):
     assert data_batch["supervision"] == "data"
     before = [p.detach().clone() for p in model.parameters() if p.requires_grad][:4]
     losses = [float(E.train_step([data_batch], pre, opt)[0]) for _ in range(3)]
+    E.raise_pending_nan(opt)  # (train_step's contract for direct callers: the last step's device-side flag)
     assert all(l == l and l > 0 for l in losses)
     assert losses[-1] < losses[0], losses  # three Adam steps on one batch reduce its loss
     after = [p.detach() for p in model.parameters() if p.requires_grad][:4]
     assert any(not torch.equal(a, b_) for a, b_ in zip(after, before))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,extra,dtype", [
+    ("config3", ["--batch", "8", "--image-size", "480", "--image-height", "270"], "f32"),
+    ("config5", ["--batch", "32", "--image-size", "640", "--image-height", "480", "--encoder-dtype", "bf16"], "bf16"),
+])
+def test_baseline_configs_3_and_5_full_steps(cuda, name, extra, dtype):
+    """Full optimiser steps of BASELINE.json's config 3 (trainmeshwarp.py on 480 x 270 frame pairs: 480-pixel raster,
+    cropped) and config 5 (640 x 480 frames, trunk under bf16 autocast, render / warp / heads in fp32) through bench.py:
+    the line names the workload and the precision, the loss is finite (bench.py asserts it), and the line is kept as
+    evidence (gpurun_out/evidence -> profiles/)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "2", "--no-kernel-bench",
+           "--no-cpu-baseline", "--no-stock-trunk"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _json_line(res.stdout)
+    w, h = extra[3], extra[5]
+    assert f"{w}x{h}" in line["config"]["workload"] and f"B={extra[1]}" in line["config"]["workload"]
+    assert line["config"]["image_size"] == int(w) and line["value"] > 0 and line["ms_per_step"] > 0
+    assert line["dtype"].startswith(dtype) and ("bf16-autocast" in line["config"]["workload"]) == (dtype == "bf16")
+    assert line["hot_path_ms"] > 0
+    _keep(f"bench_{name}.json", line)

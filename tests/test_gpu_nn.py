@@ -406,6 +406,7 @@ def test_training_trajectory_fused_trunk_vs_stock_modules(cuda, monkeypatch):
         opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3)
         loader = E.SyntheticConsistLoader(4, 64, seed=0, device=cuda, pool=2)
         traj[fused] = [float(E.train_step(loader.step_batches(i), pre, opt)[0]) for i in range(10)]
+        E.raise_pending_nan(opt)
     a, b = np.array(traj[True]), np.array(traj[False])
     assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
     assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max(), (a, b)

@@ -217,7 +217,7 @@ def test_flow_pixel_records_equal_stored_maps(cuda, B, is_, sparse):
         hit = torch.empty((B, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=cuda)
         _lib.call("mr_render_flow_forward", P(d["v"]), P(d["fidx"]), P(d["cols"]), P(bg), 0, None, 0, 0.99999, P(rgb), P(alpha),
                   P(mask), None if rec else P(depth), P(wmap), P(fim), P(hit), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0,
-                  1e-3, _lib.FLAG_SPARSE_TILES if sparse else 0, P(vid) if rec else None, st)
+                  1e-3, _lib.FLAG_SPARSE_TILES if sparse else 0, P(vid) if rec else None, 0, None, None, 0, 0, st)
         g = torch.Generator(device="cpu").manual_seed(5)
         g_rgb = torch.randn((B, 3, is_, is_), generator=g).to(cuda)
         gf = torch.randn((B, is_, is_, 2), generator=g).to(cuda)
@@ -229,7 +229,7 @@ def test_flow_pixel_records_equal_stored_maps(cuda, B, is_, sparse):
             out = torch.full((B, V, 3), float("nan"), **f32)
             _lib.call("mr_render_flow_backward", None if rec else P(d["v"]), None if rec else P(d["fidx"]), P(fim), P(hit), P(wmap),
                       None if rec else P(depth), None if flowgrad else P(g_rgb), P(gf), P(m_pre), P(m_x), None, B, P(occl), is_, is_,
-                      P(out), B, V, F0, 1, is_, 1e-3, 0, P(vid) if rec else None, st)
+                      P(out), B, V, F0, 1, is_, 1e-3, 0, P(vid) if rec else None, 0, st)
             grads.append(out)
         outs[rec] = (rgb, fim, hit, grads, vid, wmap)
     covered = outs[True][1] >= 0
@@ -245,6 +245,168 @@ def test_flow_pixel_records_equal_stored_maps(cuda, B, is_, sparse):
         # (per workgroup the sums are exact fixed-point integers of identical products; the 16 workgroups of an image
         # then meet in fp32 global atomics, whose order varies from run to run)
         assert_close(b_.cpu().numpy(), a.cpu().numpy(), 1e-5, 1e-6 * float(a.abs().max()), "gradient on the pixel records")
+
+
+@pytest.mark.parametrize("B,is_", [(3, 96), (2, 256), (5, 64)])
+def test_flow_forward_tile_list_equals_one_workgroup_per_tile(cuda, B, is_):
+    """Sparse-tile launches over the compacted list of tiles with candidates (tile_bound != 0): whatever the caller's
+    guess of the list length -- 1 (almost everything goes through the looping overflow launch), exact, far too large,
+    'auto' -- every output byte equals the one-workgroup-per-tile launch, on poisoned buffers (nothing else is
+    written), and the reported list length is the number of tiles with candidates."""
+    from handobjectconsist_amd import _lib
+
+    d = _vc_abi_case(cuda, B, is_, 33)
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    f32 = dict(dtype=torch.float32, device=cuda)
+    V, F0 = d["V"], d["F0"]
+    bg = torch.zeros(3, **f32)
+    wbytes = int(_lib.load().mr_render_workspace_bytes(B, 2 * F0, is_))
+    work = torch.empty((wbytes,), dtype=torch.uint8, device=cuda)
+    word = torch.zeros(1, dtype=torch.int32).pin_memory()
+
+    def run(bound, flags=0):
+        rgb = torch.full((B, 3, is_, is_), float("nan"), **f32)
+        alpha, mask = torch.full((B, is_, is_), float("nan"), **f32), torch.full((B, is_, is_), float("nan"), **f32)
+        wmap = torch.full((B, is_, is_, 3), float("nan"), **f32)
+        fim = torch.full((B, is_, is_), -7, dtype=torch.int32, device=cuda)
+        vid = torch.full((B, is_, is_, 3), -7, dtype=torch.int32, device=cuda)
+        hit = torch.full((B, (is_ + 7) // 8, (is_ + 31) // 32, 4), 9, dtype=torch.uint8, device=cuda)
+        _lib.call("mr_render_flow_forward", P(d["v"]), P(d["fidx"]), P(d["cols"]), P(bg), 0, None, 0, 0.99999, P(rgb), P(alpha),
+                  P(mask), None, P(wmap), P(fim), P(hit), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3,
+                  _lib.FLAG_SPARSE_TILES | flags, P(vid), bound, P(word) if bound else None, None, 0, 0, st)
+        torch.cuda.synchronize()
+        return [x.view(torch.int32) if x.dtype == torch.float32 else x for x in (rgb, alpha, mask, wmap, fim, vid, hit)]
+
+    dense = run(0)
+    assert int((dense[4] >= 0).sum()) > 100
+    n_tiles = None
+    for bound, flags in ((1, 0), (-1, 0), (10 ** 6, 0), (7, 512 << 8), (64, (512 | 1024) << 8)):
+        got = run(bound, flags)
+        for a, b_, name in zip(dense, got, ("rgb", "alpha", "mask", "weights", "face_index_map", "vertex ids", "coverage bytes")):
+            assert torch.equal(a, b_), f"{name} differs with tile_bound={bound} flags={flags}"
+        n = int(word[0])
+        assert n_tiles in (None, n)
+        n_tiles = n
+    total = B * ((is_ + 7) // 8) * ((is_ + 31) // 32)
+    assert 0 < n_tiles < total
+    # every tile that reports coverage is on the list (the list also holds tiles whose candidates cover nothing)
+    assert n_tiles >= int((dense[6].view(B, -1, 4).amax(2) > 0).sum())
+    run(n_tiles)  # the guess a caller makes from the previous call
+    assert int(word[0]) == n_tiles
+
+
+def test_flow_forward_clears_the_backwards_output_buffer(cuda):
+    """mr_render_flow_forward's zero_fill + MR_FLAG_OUTPUT_ZEROED of mr_render_flow_backward: the binning pass clears the
+    (poisoned) gradient buffer, the backward adds into it without its own memset and gives what the self-clearing call
+    gives; through autograd a second backward of the same node (retain_graph) falls back to the self-clearing call."""
+    from handobjectconsist_amd import _lib
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.warping import opticalflow
+
+    B, is_ = 3, 96
+    d = _vc_abi_case(cuda, B, is_, 44)
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    f32 = dict(dtype=torch.float32, device=cuda)
+    V, F0 = d["V"], d["F0"]
+    bg = torch.zeros(3, **f32)
+    wbytes = int(_lib.load().mr_render_workspace_bytes(B, 2 * F0, is_))
+    work = torch.empty((wbytes,), dtype=torch.uint8, device=cuda)
+    rgb, alpha, mask = torch.empty((B, 3, is_, is_), **f32), torch.empty((B, is_, is_), **f32), torch.empty((B, is_, is_), **f32)
+    wmap = torch.empty((B, is_, is_, 3), **f32)
+    fim = torch.empty((B, is_, is_), dtype=torch.int32, device=cuda)
+    vid = torch.empty((B, is_, is_, 3), dtype=torch.int32, device=cuda)
+    hit = torch.empty((B, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=cuda)
+    gbuf = torch.full((B, V, 3), float("nan"), **f32)
+    _lib.call("mr_render_flow_forward", P(d["v"]), P(d["fidx"]), P(d["cols"]), P(bg), 0, None, 0, 0.99999, P(rgb), P(alpha), P(mask),
+              None, P(wmap), P(fim), P(hit), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, _lib.FLAG_SPARSE_TILES, P(vid), -1,
+              None, P(gbuf), int(gbuf.numel()), 0, st)
+    assert float(gbuf.abs().max()) == 0.0 and not torch.isnan(gbuf).any()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    g_rgb = torch.randn((B, 3, is_, is_), generator=g).to(cuda)
+    ref = torch.full((B, V, 3), float("nan"), **f32)
+    for out, flags in ((ref, 0), (gbuf, _lib.FLAG_OUTPUT_ZEROED)):
+        _lib.call("mr_render_flow_backward", None, None, P(fim), P(hit), P(wmap), None, P(g_rgb), None, None, None, None, B, None,
+                  is_, is_, P(out), B, V, F0, 1, is_, 1e-3, flags, P(vid), 0, st)
+    assert float(ref.abs().sum()) > 0
+    assert_close(gbuf.cpu().numpy(), ref.cpu().numpy(), 1e-5, 1e-6 * float(ref.abs().max()), "gradient in the pre-cleared buffer")
+
+    # autograd: two backward passes through one stacked node
+    s = synth.random_scene(2, seed=3, image_size=64)
+    ren = Renderer(image_size=64, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda), K=torch.ones(1, 3, 3, device=cuda),
+                   orig_size=64, anti_aliasing=False, fill_back=True, near=0.1, no_light=True)
+    v1 = t(s["verts1"], cuda).requires_grad_(True)
+    flows = opticalflow.get_opticalflow([v1, t(s["verts2"], cuda)], t(s["faces"], cuda), [t(s["K1"], cuda), t(s["K2"], cuda)], ren,
+                                        orig_img_size=(64, 64), ignore_face_idxs=synth.HAND_IGNORE_FACES)
+    gf = torch.randn_like(flows[0])
+    (g1,) = torch.autograd.grad((flows[0] * gf).sum(), v1, retain_graph=True)
+    (g2,) = torch.autograd.grad((flows[0] * gf).sum(), v1)
+    assert float(g1.abs().sum()) > 0
+    assert_close(g2.cpu().numpy(), g1.cpu().numpy(), 1e-5, 1e-6 * float(g1.abs().max()), "second backward of the node")
+
+
+@pytest.mark.parametrize("table", [(0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)])
+def test_vertex_colour_kernels_follow_the_texel_table(cuda, table):
+    """Which texel of libyana's 2x2x2 vertex-colour texture holds which vertex is an ASSUMPTION (source absent): it is
+    a table (utils/textutils.TEXEL_VERTEX -> the C-ABI's texel_layout), not code.  For every permutation the fused
+    vertex-colour kernels (full-output render, flow-mode render with and without per-pixel records, their backward
+    passes) agree with the generic path on the materialised textures of the same table -- with fill-back, whose
+    reversed copies mirror the texture axes."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.utils import textutils
+    from handobjectconsist_amd.warping import opticalflow
+
+    B, is_ = 2, 64
+    s = synth.random_scene(B, seed=12, image_size=is_)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda), K=torch.ones(1, 3, 3, device=cuda),
+                   orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1, no_light=True)
+    faces, K1, K2 = t(s["faces"], cuda), t(s["K1"], cuda), t(s["K2"], cuda)
+    g = torch.Generator().manual_seed(2)
+    cols0 = torch.randn(B, s["verts1"].shape[1], 3, generator=g).to(cuda)
+    g_rgb = torch.randn(B, 3, is_, is_, generator=g).to(cuda)
+    saved = (textutils.TEXEL_VERTEX, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_PIXEL_RECORDS)
+    textutils.TEXEL_VERTEX = table
+    try:
+        # full-output render: fused vertex-colour kernels vs materialised textures
+        outs = []
+        for fused in (True, False):
+            cols = cols0.clone().requires_grad_(True)
+            if fused:
+                out = ren.render_vertex_colors(t(s["verts1"], cuda), faces, cols, K=K1)
+            else:
+                out = ren(t(s["verts1"], cuda), faces, textutils.batch_vertex_textures(faces, cols), K=K1, detach_renders=True)
+            (out["rgb"] * g_rgb).sum().backward()
+            outs.append((out["rgb"].detach(), out["face_index_map"], cols.grad))
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-6 * float(outs[1][0].abs().max())
+        assert_close(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy(), 1e-4, 1e-5 * float(outs[1][2].abs().max()), "d rgb / d colours")
+        if table != (0, 1, 2):  # ... and the table matters: the identity layout gives another image
+            textutils.TEXEL_VERTEX = (0, 1, 2)
+            other = ren.render_vertex_colors(t(s["verts1"], cuda), faces, cols0, K=K1)["rgb"]
+            textutils.TEXEL_VERTEX = table
+            assert float((other - outs[0][0]).abs().max()) > 1e-3
+        # get_opticalflow: stacked training node (records / stored maps) vs the op-by-op path on materialised textures
+        res = []
+        for vc, rec in ((True, True), (True, False), (False, True)):
+            opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_PIXEL_RECORDS = vc, rec
+            v1, v2 = t(s["verts1"], cuda).requires_grad_(True), t(s["verts2"], cuda).requires_grad_(True)
+            flows = opticalflow.get_opticalflow([v1, v2], faces, [K1, K2], ren, orig_img_size=(is_, is_),
+                                                ignore_face_idxs=synth.HAND_IGNORE_FACES)
+            gf = torch.Generator().manual_seed(4)
+            w12, w21 = torch.randn(flows[0].shape, generator=gf).to(cuda), torch.randn(flows[1].shape, generator=gf).to(cuda)
+            ((flows[0] * w12).sum() + (flows[1] * w21).sum()).backward()
+            res.append((flows[0].detach(), flows[1].detach(), v1.grad, v2.grad))
+        for got in res[:2]:
+            for a, b_, name in zip(got, res[2], ("flow12", "flow21", "d / d verts1", "d / d verts2")):
+                if name.startswith("flow"):
+                    assert int(((a != 0) != (b_ != 0)).sum()) <= 4, name  # (independent projections: README caveat)
+                    both = (a != 0) & (b_ != 0)
+                    assert float(((a - b_) * both).abs().max()) < 5e-3 and float((a - b_)[both].abs().median()) < 1e-5, name
+                else:
+                    assert float((a - b_).norm() / b_.norm()) < 5e-2, name
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])  # records vs stored maps: same flows
+        assert_close(res[0][2].cpu().numpy(), res[1][2].cpu().numpy(), 1e-5, 1e-6 * float(res[1][2].abs().max()), "records vs maps")
+    finally:
+        textutils.TEXEL_VERTEX, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_PIXEL_RECORDS = saved
 
 
 def test_training_mode_textures_only(cuda):
@@ -413,7 +575,7 @@ def _vc_abi_case(cuda, B, is_, seed, n_extra_verts=0):
     work = torch.empty((wbytes,), dtype=torch.uint8, device=cuda)
     bg = torch.zeros(3, **f32)
     _lib.call("mr_render_vc_forward", P(d["v"]), P(d["fidx"]), P(d["cols"]), P(bg), 0, P(d["rgb"]), P(d["alpha"]),
-              P(d["depth"]), P(d["fim"]), P(d["wmap"]), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+              P(d["depth"]), P(d["fim"]), P(d["wmap"]), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, 0, 0, st)
     d.update(B=B, V=V, F0=F0, is_=is_, v_np=v, fidx_np=fidx, cols_np=cols)
     return d
 
@@ -435,12 +597,12 @@ def _vc_backward(d, g_rgb_img, mode):
             hit = cov.reshape(B, ty, 4, 2, tx, 32).permute(0, 1, 4, 2, 3, 5).reshape(B, ty, tx, 4, 64).any(-1).to(torch.uint8).contiguous()
         _lib.call("mr_render_flow_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), P(hit), P(d["wmap"]), P(d["depth"]),
                   P(g_rgb_img), None, None, None, None, 0, None, 0, 0, P(out), d["B"], d["V"], d["F0"], 1, d["is_"], 1e-3, 0,
-                  None, _lib.stream_ptr(g_rgb_img.device))
+                  None, 0, _lib.stream_ptr(g_rgb_img.device))
         return out.cpu().numpy()
     stored = mode == "stored"
     _lib.call("mr_render_vc_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), P(d["wmap"]) if stored else None,
               P(d["depth"]) if stored else None, P(g_rgb_img), P(out), d["B"], d["V"], d["F0"], 1, d["is_"], 1e-3,
-              (32 << 8) if mode == "gather" else 0, _lib.stream_ptr(g_rgb_img.device))
+              (32 << 8) if mode == "gather" else 0, 0, _lib.stream_ptr(g_rgb_img.device))
     return out.cpu().numpy()
 
 
@@ -543,7 +705,7 @@ def test_flow_backward_flow_space_gradient(cuda, B, is_, H, W):
     ref = _vc_backward(d, grad_rgb, "stored")
     out = torch.full((B2, d["V"], 3), float("nan"), dtype=torch.float32, device=cuda)
     _lib.call("mr_render_flow_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), None, P(d["wmap"]), P(d["depth"]), None,
-              P(gf), P(m_pre), P(m_lo), P(m_hi), B, P(occl), H, W, P(out), B2, d["V"], d["F0"], 1, is_, 1e-3, 0, None, st)
+              P(gf), P(m_pre), P(m_lo), P(m_hi), B, P(occl), H, W, P(out), B2, d["V"], d["F0"], 1, is_, 1e-3, 0, None, 0, st)
     got = out.cpu().numpy()
     assert np.abs(ref).max() > 0 and (got[:, :, 2] == 0).all()
     assert_close(got, ref, 1e-5, 1e-6 * np.abs(ref).max(), "flow-space gradient form")
@@ -566,7 +728,7 @@ def test_vertex_colour_render_adjoint_at_metric_size(cuda):
     def render(cols):
         rgb = torch.empty((B, 3, is_, is_), **f32)
         _lib.call("mr_render_vc_forward", P(d["v"]), P(d["fidx"]), P(cols), P(bg), 0, P(rgb), P(d["alpha"]), P(d["depth"]),
-                  P(d["fim"]), P(d["wmap"]), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+                  P(d["fim"]), P(d["wmap"]), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, 0, 0, st)
         return rgb
 
     g = torch.Generator(device="cpu").manual_seed(0)

@@ -469,7 +469,8 @@ def test_pair_loss_with_coverage_bytes_equals_dense(cuda, B, is_, H, Wd):
                                         detach_textures=False, detach_renders=True,
                                         ignore_face_idxs=synth.HAND_IGNORE_FACES)
     base = flows[0]._base
-    coverage, cov_size = base._hoc_coverage
+    coverage, cov_size, noted_version = base._hoc_coverage
+    assert noted_version == base._version
     assert cov_size == is_ and coverage.shape == (2 * B, is_ // 8, is_ // 32, 4)
     im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, H, Wd, 3)]
     crit = PyramidCriterion(criterion="l1")
@@ -477,7 +478,7 @@ def test_pair_loss_with_coverage_bytes_equals_dense(cuda, B, is_, H, Wd):
     def run(stacked_flows, with_coverage):
         fl = stacked_flows.detach().clone().requires_grad_(True)
         if with_coverage:
-            fl._hoc_coverage = (coverage, cov_size)
+            fl._hoc_coverage = (coverage, cov_size, fl._version)
         loss, _, _, _ = imgflowarp.pair_consist([fl[:B], fl[B:]], im_ref, im, jm_ref, jm, crit, use_backward=True,
                                                 outputs="loss")
         loss.sum().backward()
@@ -505,6 +506,11 @@ def test_pair_loss_with_coverage_bytes_equals_dense(cuda, B, is_, H, Wd):
     assert int((~covered).sum()) > 0
     loss_p, grad_p = run(poisoned, True)
     assert torch.equal(loss_p, loss_d) and torch.equal(grad_p, grad_d)
+    # an in-place write into the flows after get_opticalflow invalidates the hand-over (the bytes describe other values)
+    assert imgflowarp._coverage_of(base)[0] is coverage
+    with torch.no_grad():
+        base.mul_(1.0)
+    assert imgflowarp._coverage_of(base) == (None, 0)
 
 
 @pytest.mark.parametrize("B,is_,H,W", [(2, 64, 64, 64), (3, 96, 54, 96), (1, 40, 27, 33)])
