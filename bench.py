@@ -97,11 +97,10 @@ ROOF_BWD = "render_flow_backward(train,E+epilogue adjoint,2B)"
 ROOF_FWD = "render_flow_forward(train outputs,both frames=2B)"
 # the device kernels behind the two groups (names as rocprofv3 prints them)
 ROOF_KERNELS = {ROOF_BWD: ["scatter_tiles_kernel<true, true>"],
-                ROOF_FWD: ["face_records_kernel<true>", "bin_boxes_kernel", "raster_tile_kernel<true, true, false, 7>",
-                           "raster_tile_kernel<true, true, true, 7>"]}
+                ROOF_FWD: ["face_records_kernel<true>", "bin_boxes_kernel", "raster_tile_kernel<true, true, 0, 7>"]}
 
 
-ROOF_OPTIONAL = ("raster_tile_kernel<true, true, true, 7>",)
+ROOF_OPTIONAL = ()
 
 
 def kernel_bench(dev, B, is_, iters, only=None):
@@ -482,7 +481,6 @@ def roofline_block(name, k, pmc, units):
             "launch_ms": k["ms"], "launch_ms_cache_warm": k["ms_cache_warm"],
             "units_per_launch": units, "device_kernels": ROOF_KERNELS[name]}
     found = [pmc[d] for d in ROOF_KERNELS[name] if d in pmc]
-    # (the looping overflow launch of the tile kernel only exists when the list may be longer than the first grid)
     if len(found) >= len([d for d in ROOF_KERNELS[name] if d not in ROOF_OPTIONAL]):
         hi, lo = sum(f["hbm_bytes"] for f in found), sum(f["hbm_bytes_low"] for f in found)
         roof.update({"traffic": hi, "traffic_low": lo, "traffic_unit": "bytes/launch",

@@ -22,6 +22,7 @@ _P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
 SIGNATURES = {
     "mr_abi_version": (_I, []),
     "mr_device_ok": (_I, []),
+    "mr_selftest_division": (_I, [_P, _P, _P, _P, _L, _P]),
     "mr_forward_face_index_map": (_I, [_P] * 6 + [_I, _I, _I, _F, _F, _I, _I, _I, _P]),
     "mr_forward_texture_sampling": (_I, [_P] * 8 + [_I, _I, _I, _I, _F, _P]),
     "mr_backward_pixel_map": (_I, [_P] * 7 + [_I, _I, _I, _F, _I, _I, _P]),

@@ -201,6 +201,109 @@ __device__ __forceinline__ void bary(const Face& f, int xi, int yi, float& zp, f
     zp = 1.0f / (w[0] / f.v[2] + w[1] / f.v[5] + w[2] / f.v[8]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// IEEE divisions that share work.  Two of every five vector instructions of the forward tile kernel used to be the
+// twelve-instruction sequence the compiler emits for a correctly rounded fp32 `/` (v_div_scale x 2, v_rcp_f32, six
+// fma / mul, v_div_fmas, v_div_fixup): nine divisions by ONE determinant per face set-up, three by one weight sum and
+// three by the face's three vertex depths per fragment, the same again per resolved pixel.  Without the scaling
+// steps (which only exist to keep intermediates of extreme operands out of the denormal / overflow range) that
+// sequence is: y = refined reciprocal of b (rcp + one Newton step), then q0 = a y, two residual corrections q <- q +
+// (a - b q) y.  The residual a - b q is exact in fp32 (one fma) as long as nothing underflows, and the corrected
+// quotient is the correctly rounded a / b -- the SAME bits as `/` and as the CPU oracle's division -- for every
+// operand pair whose magnitudes keep the intermediates normal.  y depends on b alone, so divisions by a common b share
+// it: 3 + 5 n instead of 12 n instructions.  (CPU emulation with the reciprocal perturbed by +-1 ulp: 12 M random and
+// adversarial pairs, 0 mismatches; on the GPU tests/test_gpu_raster.py compares the tile kernel with these paths on
+// and off bit for bit, and mr_selftest_division the primitives themselves against `/`.)
+// Range discipline: `division_safe_face` (evaluated once per face by the per-face pass) admits a face to the fast
+// paths only if its pixel coordinates are 0 or within [2^-24, 2^24], its determinant and its three depths within
+// [2^-30, 2^30]: then every numerator of the set-up is 0 or within [2^-71, 2^49] and every inverse entry 0 or above
+// 2^-101, with residuals that are multiples of 2^-118 or more.  Per fragment, the weight sum must be at least 2^-30 and
+// each clamped weight 0 or at least 2^-60 (the quotients are then 0 or at least 2^-62, their residuals multiples of
+// 2^-109), per resolved pixel the depth within [2^-30, 2^30].  Everything else takes the plain `/` path.
+__device__ __forceinline__ float rcp_refined(float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+// a / b correctly rounded, y = rcp_refined(b); operands within the ranges stated above
+__device__ __forceinline__ float div_refined(float a, float b, float y) {
+    const float q0 = a * y;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    // (a zero numerator: the corrections add a +0 residual to q0 = -0 and lose the sign IEEE gives the quotient
+    // (-0 / b = -0 for b > 0); q0 = a y always carries the right one)
+    return __builtin_copysignf(__builtin_fmaf(r1, y, q1), q0);
+}
+// |x| within [2^lo, 2^hi] (false for NaN / Inf / zero / denormals)
+__device__ __forceinline__ bool mag_within(float x, int lo, int hi) {
+    const uint32_t u = __float_as_uint(x) & 0x7fffffffu;
+    return u - ((uint32_t)(lo + 127) << 23) <= (((uint32_t)(hi + 127) << 23) - ((uint32_t)(lo + 127) << 23));
+}
+// x == 0 or |x| within [2^lo, 2^hi]
+__device__ __forceinline__ bool zero_or_mag_within(float x, int lo, int hi) {
+    return (__float_as_uint(x) & 0x7fffffffu) == 0u || mag_within(x, lo, hi);
+}
+
+__device__ __forceinline__ bool division_safe_face(const float* f, int is) {
+    const float fis = (float)is;
+    float p[3][2];
+    bool ok = true;
+#pragma unroll
+    for (int n = 0; n < 3; n++) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            p[n][d] = 0.5f * (f[3 * n + d] * fis + fis - 1.0f);
+            ok = ok && zero_or_mag_within(p[n][d], -24, 24);
+        }
+        ok = ok && mag_within(f[3 * n + 2], -30, 30);
+    }
+    const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]));
+    return ok && mag_within(den, -30, 30);
+}
+
+// face_inverse for division-safe faces: the nine divisions by the determinant share one reciprocal (bit-identical)
+__device__ __forceinline__ void face_inverse_shared(const float* f, float* inv, int is) {
+    const float fis = (float)is;
+    float p[3][2];
+#pragma unroll
+    for (int n = 0; n < 3; n++)
+#pragma unroll
+        for (int d = 0; d < 2; d++) p[n][d] = 0.5f * (f[3 * n + d] * fis + fis - 1.0f);
+    float a[9] = {p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                  p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                  p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+    const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
+                       p[1][0] * (p[2][1] - p[0][1]));
+    const float y = rcp_refined(den);
+#pragma unroll
+    for (int k = 0; k < 9; k++) inv[k] = div_refined(a[k], den, y);
+}
+
+// bary() for fragments of division-safe faces; yz[k] = rcp_refined(f.v[3 k + 2]).  Returns false -- with zp and w
+// untouched -- when this fragment's weights are outside the fast range: the caller then uses bary().
+__device__ __forceinline__ bool bary_shared(const Face& f, const float* yz, int xi, int yi, float& zp, float* w) {
+    const float fx = (float)xi, fy = (float)yi;
+    float t[3];
+    t[0] = f.inv[0] * fx + f.inv[1] * fy + f.inv[2];
+    t[1] = f.inv[3] * fx + f.inv[4] * fy + f.inv[5];
+    t[2] = f.inv[6] * fx + f.inv[7] * fy + f.inv[8];
+    float ws = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        t[k] = fminf(fmaxf(t[k], 0.0f), 1.0f);
+        ws += t[k];
+    }
+    // each weight 0 or >= 2^-60 (they are non-negative: u - 1 wraps for +0), the sum >= 2^-30
+    const uint32_t lo = min(min(__float_as_uint(t[0]) - 1u, __float_as_uint(t[1]) - 1u), __float_as_uint(t[2]) - 1u);
+    if (!(lo >= ((uint32_t)(127 - 60) << 23) - 1u && ws >= 9.313225746154785e-10f)) return false;
+    const float y = rcp_refined(ws);
+#pragma unroll
+    for (int k = 0; k < 3; k++) w[k] = div_refined(t[k], ws, y);
+    zp = 1.0f / (div_refined(w[0], f.v[2], yz[0]) + div_refined(w[1], f.v[5], yz[1]) + div_refined(w[2], f.v[8], yz[2]));
+    return true;
+}
+
 // Coverage + barycentric weights + perspective-correct depth of one pixel against one
 // front-facing face (upstream kernel forward_face_index_map_2, body of the face loop).
 __device__ __forceinline__ bool cover(const Face& f, int xi, int yi, int is, float near_, float far_,

@@ -58,7 +58,8 @@ constexpr int NB = 32;                // faces per batch (stage S1: one lane per
                                       // batch per wave for the ~145 faces of a typical geometry tile): the larger face
                                       // cache costs occupancy (5 / 4 instead of 7 waves per SIMD) and the kernel gets slower
 constexpr int NBP2 = 32;              // next power of two
-constexpr int FC_STRIDE = 21;         // dwords per face-cache slot (odd: conflict-free ds_read_b32): v 9, inv 9, slot, box
+constexpr int FC_STRIDE = 25;         // dwords per face-cache slot (odd: conflict-free ds_read_b32): v 9, inv 9, face index,
+                                      // box, refined reciprocals of the three depths, "division-safe" flag
 constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 4 * 64, power of 2)
 
 // Per-image header written by bin_faces_kernel.
@@ -115,7 +116,9 @@ struct BinParams {
     int dbg;                 // profiling experiments (scripts/fwd_vc_variants.py)
     // compacted list of the tiles with candidate records (sparse-tile launches; nullptr = none is built)
     TileList* tlist;         // counter, zeroed by face_records_kernel, bumped once per image by bin_boxes_kernel
-    uint32_t* tile_ids;      // [B * tiles] global tile ids (image * tiles per image + tile), grouped by image
+    uint4* tile_ids;         // [B * tiles] list entries {global tile id = image * tiles per image + tile, offset and
+                             // count of the bin's records, length of the image's large list}, grouped by image: everything
+                             // a tile's workgroup needs to start on its records after ONE scalar load
     uint8_t* tile_hit;       // [B, tiles, 4]: the binning pass writes the (zero) coverage bytes of the other tiles
     float* zero_fill;        // nullable: cleared by the binning pass (the matching backward's gradient buffer)
     int64_t zero_count;
@@ -169,7 +172,8 @@ __global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
         float4* rv = reinterpret_cast<float4*>(p.rverts + (int64_t)b * p.F0 + f0);
         rv[0] = make_float4(f[0], f[1], f[2], f[3]);
         rv[1] = make_float4(f[4], f[5], f[6], f[7]);
-        rv[2] = make_float4(f[8], 0.0f, 0.0f, 0.0f);
+        // (second float: the face may take the shared-reciprocal division paths of the tile kernel, mr_common.hpp)
+        rv[2] = make_float4(f[8], division_safe_face(f, is) ? 1.0f : 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -195,19 +199,29 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         for (int64_t i = (int64_t)b * BIN_TPB + tid; i < p.zero_count; i += (int64_t)gridDim.x * BIN_TPB) p.zero_fill[i] = 0.0f;
     __syncthreads();
 
-    // pass 1: records per bin
-    for (int fn = tid; fn < p.F; fn += BIN_TPB) {
-        const FaceBox bx = box_b[fn];
-        if (p.lds_boxes) sbox[fn] = bx;
-        if (bx.x0 > bx.x1) continue;
-        const int bx0 = bx.x0 / TILE_W, bx1 = bx.x1 / TILE_W;
-        const int by0 = bx.y0 >> (3 + p.ysh), by1 = bx.y1 >> (3 + p.ysh);
-        if ((bx1 - bx0 + 1) * (by1 - by0 + 1) > SMALL_MAX_BINS) {  // large list (filled in pass 2)
-            if (p.tlist) atomicAdd(&s_nlarge, 1);
-            continue;
+    // pass 1: records per bin.  The boxes of BIN_PF trips are requested together (unconditional loads from clamped
+    // addresses): one load round trip per BIN_PF x 1024 faces instead of one per trip -- a hand + object mesh (7104
+    // virtual faces) is seven trips, i.e. seven dependent round trips of the single workgroup an image has.
+    constexpr int BIN_PF = 8;
+    for (int base = 0; base < p.F; base += BIN_PF * BIN_TPB) {
+        FaceBox bxs[BIN_PF];
+#pragma unroll
+        for (int k = 0; k < BIN_PF; k++) bxs[k] = box_b[min(base + k * BIN_TPB + tid, p.F - 1)];
+#pragma unroll
+        for (int k = 0; k < BIN_PF; k++) {
+            const int fn = base + k * BIN_TPB + tid;
+            const FaceBox bx = bxs[k];
+            if (fn < p.F && p.lds_boxes) sbox[fn] = bx;
+            if (fn >= p.F || bx.x0 > bx.x1) continue;
+            const int bx0 = bx.x0 / TILE_W, bx1 = bx.x1 / TILE_W;
+            const int by0 = bx.y0 >> (3 + p.ysh), by1 = bx.y1 >> (3 + p.ysh);
+            if ((bx1 - bx0 + 1) * (by1 - by0 + 1) > SMALL_MAX_BINS) {  // large list (filled in pass 2)
+                if (p.tlist) atomicAdd(&s_nlarge, 1);
+                continue;
+            }
+            for (int y = by0; y <= by1; y++)
+                for (int x = bx0; x <= bx1; x++) atomicAdd(&cnt[y * p.nbx + x], 1);
         }
-        for (int y = by0; y <= by1; y++)
-            for (int x = bx0; x <= bx1; x++) atomicAdd(&cnt[y * p.nbx + x], 1);
     }
     __syncthreads();
 
@@ -255,11 +269,15 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         // others get their (zero) coverage bytes now -- no workgroup is dispatched for them
         unsigned at = (unsigned)s_lbase + (unsigned)(base64 >> 32);
         uint32_t* hit32 = reinterpret_cast<uint32_t*>(p.tile_hit) + (int64_t)b * nbins;
+        const unsigned nlarge = (unsigned)s_nlarge;
         for (int i = i0; i < i1; i++) {
             const bool live = all_live || ((livebits >> (i - i0)) & 1u);
-            if (live) p.tile_ids[at++] = (uint32_t)(b * nbins + i);
+            // (cnt[] holds the bins' fill cursors = record offsets until pass 2 starts; `base` is the end of this run)
+            const unsigned off = (unsigned)cnt[i], end = (unsigned)(i + 1 < i1 ? cnt[i + 1] : base);
+            if (live) p.tile_ids[at++] = make_uint4((unsigned)(b * nbins + i), off, end - off, nlarge);
             else hit32[i] = 0u;
         }
+        __syncthreads();  // (pass 2 moves the cursors)
     }
     if (p.dbg & 2) return;
 
@@ -329,7 +347,7 @@ struct FwdParams {
     int dbg;                         // profiling experiments (flags >> 8)
     // listed launches (sparse tiles): the binning pass's list of tiles with candidates
     const TileList* tlist;
-    const uint32_t* tile_ids;
+    const uint4* tile_ids;
     uint32_t* tile_count_out;        // nullable, any device-writable address (e.g. pinned host memory): the list
                                      // length of this launch, for the caller's next grid-size guess
     unsigned list_first;             // first list entry this launch handles
@@ -345,11 +363,12 @@ struct FwdParams {
 // the 9 coordinates of (virtual) face fn in ONE load phase: from the faces tensor, or (VC) from the gathered
 // coordinates of real face fn mod F0, read back to front for the reversed copy
 template <bool VC>
-__device__ __forceinline__ void load_face_coords(const FwdParams& p, const RecVerts* rv_b, int b, int fn, float* v) {
+__device__ __forceinline__ bool load_face_coords(const FwdParams& p, const RecVerts* rv_b, int b, int fn, float* v) {
     if (!VC) {
         const float* g = p.faces + ((int64_t)b * p.F + fn) * 9;
 #pragma unroll
         for (int k = 0; k < 9; k++) v[k] = g[k];
+        return false;  // (the generic path keeps the plain divisions: no per-face pass has vetted its faces)
     } else {
         const bool rev = fn >= p.F0;
         const float4* rv = reinterpret_cast<const float4*>(rv_b + (rev ? fn - p.F0 : fn));
@@ -357,6 +376,7 @@ __device__ __forceinline__ void load_face_coords(const FwdParams& p, const RecVe
         v[0] = rev ? v1.z : v0.x; v[1] = rev ? v1.w : v0.y; v[2] = rev ? v2.x : v0.z;
         v[3] = v0.w; v[4] = v1.x; v[5] = v1.y;
         v[6] = rev ? v0.x : v1.z; v[7] = rev ? v0.y : v1.w; v[8] = rev ? v0.z : v2.x;
+        return v2.y != 0.0f && !(p.dbg & 4096);  // division-safe (dbg 4096: plain divisions everywhere, for the A/B test)
     }
 }
 
@@ -393,10 +413,10 @@ __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float 
 __device__ unsigned long long mr_dbg_times[65536 * 4];
 #endif
 
-// LOOP: listed launches only -- the workgroup walks the tile list with a grid stride (the loop keeps every kernel
-// argument live in scalar registers across the trips; see launch_tiles for what that costs and when it is used).
-template <bool FUSED, bool VC, bool LOOP = false, int WAVES = 7>
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) raster_tile_kernel(FwdParams p) {
+// One screen tile `lid` (= image * tiles per image + tile): candidates -> z-buffer -> resolve (design at the top).
+// `ent` (listed launches): the tile's list entry {lid, record offset, record count, large-list length}; else nullptr
+template <bool FUSED, bool VC>
+__device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsigned lid, const uint4* ent = nullptr) {
 #ifdef MR_WG_TIMELINE
     const unsigned long long dbg_t0 = wall_clock64();
 #endif
@@ -406,11 +426,6 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES,
     __shared__ float xp_tab[TILE_W], yp_tab[TILE_H];
     __shared__ int rowoff[TPB / MR_WAVE][NB + 1];  // prefix sums of the batch's per-face row counts
 
-    // One tile per workgroup (lid = workgroup index, XCD-aware), or -- listed launches, p.tlist -- the workgroups
-    // walk the list of the tiles that hold candidates with a grid stride: the grid is sized by the caller's guess of
-    // the list length, no workgroup is dispatched for the empty 80 % of the screen and none pulls work through an
-    // atomic (a queue cursor serialised the launch, profiles/r02_persistent_tile_kernel_experiment.patch).
-    auto tile_body = [&](const unsigned lid) {
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int b = lid / tiles_per_img;
     const int t = lid % tiles_per_img;
@@ -425,11 +440,17 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES,
     int n_rec = 0, n_bin = 0;
     int64_t off_bin = 0, off_large = 0;  // record indices relative to the image's record base
     if (!p.keys) {
-        const BinHdr bh = p.bins[(int64_t)b * (p.nbx * p.nby) + ((t / p.tiles_x) >> p.ysh) * p.nbx + (t % p.tiles_x)];
-        n_bin = (int)bh.cnt;
-        off_bin = (int64_t)bh.off;
+        if (ent) {
+            n_bin = (int)ent->z;
+            off_bin = (int64_t)ent->y;
+            n_rec = n_bin + (int)ent->w;
+        } else {
+            const BinHdr bh = p.bins[(int64_t)b * (p.nbx * p.nby) + ((t / p.tiles_x) >> p.ysh) * p.nbx + (t % p.tiles_x)];
+            n_bin = (int)bh.cnt;
+            off_bin = (int64_t)bh.off;
+            n_rec = n_bin + p.hdrs[b].n_large;
+        }
         off_large = (int64_t)SMALL_MAX_BINS * p.F - n_bin;  // so that record i >= n_bin sits at off_large + i
-        n_rec = n_bin + p.hdrs[b].n_large;
         if (p.dbg & 1) n_rec = 0;
         if (n_rec == 0 && (p.dbg & 256)) return;
         if (FUSED && n_rec == 0 && p.sparse_tiles) {
@@ -505,7 +526,8 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES,
             f.v[2] = c[2]; f.v[5] = c[5]; f.v[8] = c[8];
             const int fslot = __float_as_int(c[18]);  // the face index
             float zp, w[3];
-            bary(f, tx0 + lx, ty0 + ly, zp, w);
+            const float yz[3] = {c[20], c[21], c[22]};
+            if (!(c[23] != 0.0f && bary_shared(f, yz, tx0 + lx, ty0 + ly, zp, w))) bary(f, tx0 + lx, ty0 + ly, zp, w);
             // upstream: `if (zp <= near || far <= zp) continue; if (zp < depth) win`.  A NaN depth (faces whose
             // vertices coincide in x, y pass every edge test and have no inverse) survives the first test and
             // loses the second, so it must not reach the z-buffer -- both comparisons below are false for NaN
@@ -521,9 +543,15 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES,
             const FaceRec r = *rec_at(first + lane);
             const int fn = (int)r.z;
             Face f;
-            load_face_coords<VC>(p, rv_b, b, fn, f.v);
-            face_inverse(f.v, f.inv, is);
+            const bool safe = load_face_coords<VC>(p, rv_b, b, fn, f.v);
             float* c = fc + lane * FC_STRIDE;
+            if (safe) {
+                face_inverse_shared(f.v, f.inv, is);
+                c[20] = rcp_refined(f.v[2]); c[21] = rcp_refined(f.v[5]); c[22] = rcp_refined(f.v[8]);
+            } else {
+                face_inverse(f.v, f.inv, is);
+            }
+            c[23] = safe ? 1.0f : 0.0f;
 #pragma unroll
             for (int k = 0; k < 9; k++) { c[k] = f.v[k]; c[9 + k] = f.inv[k]; }
             const int x0 = max((int)(r.x & 0xffffu), tx0) - tx0, x1 = min((int)(r.x >> 16), tx1) - tx0;
@@ -672,8 +700,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES,
     // bins -- get an empty row range in S1.
     for (int base = wave * NB; base < n_rec; base += (TPB / MR_WAVE) * NB) process_batch(base, min(NB, n_rec - base));
     const int lxr = tid & (TILE_W - 1), ly = tid >> 5;
-    const int px = tx0 + lxr, py = ty0 + ly;
-    if (p.keys && px < is && py < is) zbuf[tid] = p.keys[((int64_t)b * is + py) * is + px];
+    if (p.keys && tx0 + lxr < is && ty0 + ly < is) zbuf[tid] = p.keys[((int64_t)b * is + ty0 + ly) * is + tx0 + lxr];
     __syncthreads();
 
 #ifdef MR_WG_TIMELINE
@@ -683,15 +710,16 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES,
     // resolve: one pixel per thread (x = tid % 32, y = tid / 32)
     {
         const unsigned long long key = zbuf[tid];
-        const bool hitpx = key != ~0ull && px < is && py < is;
+        const int opx = tx0 + lxr, opy = ty0 + ly;  // this thread's own pixel: coverage bytes, background
+        const bool hitpx = key != ~0ull && opx < is && opy < is;
         if (p.tile_hit) {
             const unsigned long long any = __ballot(hitpx);
             if (lane == 0) p.tile_hit[((int64_t)b * tiles_per_img + t) * 4 + wave] = any != 0ull ? 1 : 0;
         }
-        if (px >= is || py >= is) return;
-        const int64_t ri = ((int64_t)b * is + py) * is + px;            // raster orientation
-        const int64_t ii = ((int64_t)b * is + (is - 1 - py)) * is + px;  // image orientation
-        if (!hitpx) {
+        const bool inside = opx < is && opy < is;
+        if (inside && !hitpx) {
+            const int64_t ri = ((int64_t)b * is + opy) * is + opx;            // raster orientation
+            const int64_t ii = ((int64_t)b * is + (is - 1 - opy)) * is + opx;  // image orientation
             if (FUSED) {
                 p.fim[ri] = -1;
                 if (p.weight && !p.sparse_wd) { p.weight[ri * 3 + 0] = 0.0f; p.weight[ri * 3 + 1] = 0.0f; p.weight[ri * 3 + 2] = 0.0f; }
@@ -701,7 +729,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES,
                 if (p.rgb) {
                     const float* bg = p.background + (int64_t)b * p.bg_stride;
                     const int64_t plane = (int64_t)is * is;
-                    const int64_t o = ((int64_t)b * 3 * is + (is - 1 - py)) * is + px;
+                    const int64_t o = ((int64_t)b * 3 * is + (is - 1 - opy)) * is + opx;
                     p.rgb[o] = bg[0]; p.rgb[o + plane] = bg[1];
                     if (p.rgb_channels > 2) p.rgb[o + 2 * plane] = bg[2];
                 }
@@ -709,28 +737,64 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES,
 #pragma unroll
                     for (int k = 0; k < 9; k++) p.face_inv_map[ri * 9 + k] = 0.0f;
             }
-            return;
         }
-        int fn = (int)(unsigned)(key & 0xffffffffull);
-        const float zp = ord2f((uint32_t)(key >> 32));
+        // The covered pixels of the tile (two fifths of a tile with geometry, in runs of a few pixels per row) are
+        // compacted before the expensive part -- the winner's set-up, barycentrics and sampling, ~180 instructions --
+        // so that it runs in ceil(covered / 64) waves instead of in every wave that owns a covered pixel.  The list
+        // lives in the (now idle) fragment ring of wave 0, the per-wave counts in its row-offset table.
+        int q = tid;
+        bool active = hitpx;
+        if (!(p.dbg & 8192)) {
+            unsigned short* hlist = fragq[0];
+            int* hcnt = rowoff[0];
+            const unsigned long long m = __ballot(hitpx);
+            if (lane == 0) hcnt[wave] = __popcll(m);
+            __syncthreads();
+            int hbase = 0, htotal = 0;
+#pragma unroll
+            for (int w = 0; w < TPB / MR_WAVE; w++) {
+                const int c = hcnt[w];
+                hbase += w < wave ? c : 0;
+                htotal += c;
+            }
+            if (hitpx) hlist[hbase + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+            __syncthreads();
+            active = tid < htotal;
+            q = active ? (int)hlist[tid] : tid;
+        }
+        if (!active) return;
+        const unsigned long long wkey = zbuf[q];
+        const int px = tx0 + (q & (TILE_W - 1)), py = ty0 + (q >> 5);
+        const int64_t ri = ((int64_t)b * is + py) * is + px;            // raster orientation
+        const int64_t ii = ((int64_t)b * is + (is - 1 - py)) * is + px;  // image orientation
+        int fn = (int)(unsigned)(wkey & 0xffffffffull);
+        const float zp = ord2f((uint32_t)(wkey >> 32));
         Face f;
         int vid[3] = {0, 0, 0};
+        bool safe = false;
+        float yz[3] = {0.0f, 0.0f, 0.0f};
         if (p.keys) {  // validation path: keys carry face indices, no binning pass ran
             fetch_verts<VC>(p, b, fn, f.v, vid);
             face_inverse(f.v, f.inv, is);
         } else {
-            load_face_coords<VC>(p, rv_b, b, fn, f.v);
+            safe = load_face_coords<VC>(p, rv_b, b, fn, f.v);
             if (VC) {
                 const bool rev = fn >= p.F0;
                 const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + (rev ? fn - p.F0 : fn)) * 3;
                 const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
                 vid[0] = rev ? i2 : i0; vid[1] = i1; vid[2] = rev ? i0 : i2;
             }
-            face_inverse(f.v, f.inv, is);
+            if (safe) {
+                face_inverse_shared(f.v, f.inv, is);
+                yz[0] = rcp_refined(f.v[2]); yz[1] = rcp_refined(f.v[5]); yz[2] = rcp_refined(f.v[8]);
+            } else {
+                face_inverse(f.v, f.inv, is);
+            }
         }
         // barycentrics of the winner, recomputed with the arithmetic of cover()
         float w[3], zp2;
-        bary(f, px, py, zp2, w);
+        const bool shared_w = safe && bary_shared(f, yz, px, py, zp2, w);
+        if (!shared_w) bary(f, px, py, zp2, w);
         (void)zp2;
         p.fim[ri] = fn;
         if (p.weight && !(VC && p.vid_map)) { p.weight[ri * 3 + 0] = w[0]; p.weight[ri * 3 + 1] = w[1]; p.weight[ri * 3 + 2] = w[2]; }
@@ -751,7 +815,16 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES,
         if (p.rgb) {
             const int ts = p.ts;
             float tif[3];
-            tex_coords(w, zp, f.v, ts, p.eps, tif);
+            if (shared_w && mag_within(zp, -30, 30)) {  // tex_coords with depth / z_k through the depths' reciprocals
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float t = w[k] * (float)(ts - 1) * div_refined(zp, f.v[3 * k + 2], yz[k]);
+                    t = fmaxf(t, 0.0f);
+                    tif[k] = fminf(t, (float)(ts - 1) - p.eps);
+                }
+            } else {
+                tex_coords(w, zp, f.v, ts, p.eps, tif);
+            }
             float c[3] = {0.0f, 0.0f, 0.0f};
             if (!VC) {
                 const float* tex = p.textures + ((int64_t)b * p.F + fn) * ts * ts * ts * 3;
@@ -808,18 +881,56 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES,
                 if (k < p.rgb_channels) p.rgb[o + k * plane] = c[k] * 1.0f + 0.0f * bg[k];
         }
     }
-    };  // tile_body
+}
 
+// Listed launches whose tile list turned out LONGER than the grid (the caller's guess was low): the entries beyond the
+// grid, with a grid stride.  Deliberately NOT inlined, and reading the kernel's arguments from the kernarg segment
+// itself: a loop around the tile body keeps every kernel argument live in scalar registers across its trips and
+// spills 36 vector registers (175 instead of 142 us when the loop is the kernel; +2 us even as a never-entered second
+// copy of the body); as a called function its registers and spills are its own business, and nothing of it is executed
+// when the guess held.  (A separate small looping launch for the overflow costs ~5 us on the timeline.)
+template <bool FUSED, bool VC>
+__device__ __attribute__((noinline)) void raster_overflow_tiles(const FwdParams* kernargs, unsigned wi, const unsigned n_work,
+                                                                const unsigned stride) {
+    const FwdParams& p = *kernargs;
+    for (; wi < n_work; wi += stride) {
+        __syncthreads();
+        const uint4 ent = p.tile_ids[wi];
+        raster_one_tile<FUSED, VC>(p, ent.x, &ent);
+    }
+}
+
+// MODE 0: one tile per workgroup: workgroup i takes tile i (XCD-aware) or -- listed launches, p.tlist -- entry i of the
+//         list of tiles that hold candidates: the grid is sized by the caller's guess of the list length, no workgroup
+//         is dispatched for the empty 80 % of the screen and none pulls work through an atomic (a queue cursor serialised
+//         the launch, profiles/r02_persistent_tile_kernel_experiment.patch).  A longer list: raster_overflow_tiles.
+// MODE 1: experiment: the workgroup walks the tile list with a grid-stride loop around the inlined body.
+// MODE 2: experiment: MODE 0 without the overflow call (the caller adds a MODE 1 launch for entries beyond the grid).
+template <bool FUSED, bool VC, int MODE = 0, int WAVES = 7>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) raster_tile_kernel(FwdParams p) {
     const bool listed = p.tlist != nullptr;
     const unsigned n_work = listed ? p.tlist->n : gridDim.x;
     if (listed && p.tile_count_out && p.list_first == 0u && blockIdx.x == 0 && threadIdx.x == 0) *p.tile_count_out = n_work;
     // (consecutive list entries are tiles of one image: xcd_remap keeps them on one XCD / L2)
     unsigned wi = p.list_first + xcd_remap(blockIdx.x, gridDim.x);
-    if (!LOOP) {
-        if (wi < n_work) tile_body(listed ? p.tile_ids[wi] : wi);
+    if (MODE != 1) {
+        if (wi < n_work) {
+            if (listed) {
+                const uint4 ent = p.tile_ids[wi];
+                raster_one_tile<FUSED, VC>(p, ent.x, &ent);
+            } else {
+                raster_one_tile<FUSED, VC>(p, wi);
+            }
+        }
+        if (MODE == 0 && FUSED && VC && listed && n_work > gridDim.x)  // (workgroup-uniform; false whenever the guess held)
+            // (the kernel's own argument block, in the kernarg segment: C cast out of address space 4; the intrinsic is
+            // only valid in the kernel itself -- inside the callee it read as a null pointer)
+            raster_overflow_tiles<FUSED, VC>((const FwdParams*)__builtin_amdgcn_kernarg_segment_ptr(), wi + gridDim.x, n_work,
+                                             gridDim.x);
     } else {
         for (; wi < n_work; wi += gridDim.x) {
-            tile_body(p.tile_ids[wi]);
+            const uint4 ent = p.tile_ids[wi];
+            raster_one_tile<FUSED, VC>(p, ent.x, &ent);
             __syncthreads();
         }
     }
@@ -932,7 +1043,7 @@ static WorkLayout work_layout(int B, int F, int is) {
     w.off_rverts = w.off_recs + align256((size_t)B * REC_CAP * F * sizeof(FaceRec));
     w.off_tlist = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (VC needs F / 2 of it with fill-back)
     w.off_tile_ids = w.off_tlist + align256(sizeof(TileList));
-    w.total = w.off_tile_ids + align256((size_t)B * tiles_x * tiles_y * sizeof(uint32_t));
+    w.total = w.off_tile_ids + align256((size_t)B * tiles_x * tiles_y * sizeof(uint4));
     return w;
 }
 
@@ -947,7 +1058,7 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     char* base = (char*)workspace;
     if (tile_hit && w.ysh == 0 && (int64_t)B * w.nbx * w.nby <= 0x7fffffffLL) {
         bp.tlist = (TileList*)(base + w.off_tlist);
-        bp.tile_ids = (uint32_t*)(base + w.off_tile_ids);
+        bp.tile_ids = (uint4*)(base + w.off_tile_ids);
         bp.tile_hit = tile_hit;
         fp.tlist = bp.tlist; fp.tile_ids = bp.tile_ids;
     }
@@ -994,26 +1105,30 @@ static int launch_tiles(FwdParams& p, hipStream_t s, int64_t tile_bound = 0) {
     if (nblocks == 0) return MR_OK;
     if (nblocks > 0x7fffffffLL) return MR_ERR_BADARG;
     if (p.tlist) {
-        // Listed launch: `bound` workgroups take one list entry each (the straight-line kernel: one tile per
-        // workgroup, no loop-carried state); whatever the list holds beyond the caller's guess is walked by a second,
-        // small launch of the looping variant, whose workgroups leave after one scalar load when the guess was good.
+        // Listed launch: `bound` workgroups take one list entry each; whatever the list holds beyond the caller's guess
+        // is walked afterwards by the same workgroups (raster_overflow_tiles).
         if (tile_bound <= 0) tile_bound = (nblocks + 3) / 4;
-        const int64_t bound = std::min<int64_t>(nblocks, std::max<int64_t>((tile_bound + 7) & ~(int64_t)7, 256));
+        const int64_t bound = std::min<int64_t>(nblocks, std::max<int64_t>((tile_bound + 7) & ~(int64_t)7, 8));
         if constexpr (FUSED && VC) {
             if (p.dbg & 512) {  // experiment: the looping variant alone (7 waves per SIMD; 1024: 6)
-                if (p.dbg & 1024) hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, true, 6>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
-                else hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, true, 7>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
+                if (p.dbg & 1024) hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, 1, 6>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
+                else hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, 1, 7>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
                 MR_CHECK_LAUNCH();
                 return MR_OK;
             }
-            hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, false, 7>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
-            MR_CHECK_LAUNCH();
-            if (bound < nblocks) {
-                p.list_first = (unsigned)bound;
-                const int64_t rest = std::min<int64_t>(nblocks - bound, 512);
-                hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, true, 7>), dim3((unsigned)((rest + 7) & ~(int64_t)7)), dim3(TPB), 0, s, p);
+            if (p.dbg & 2048) {  // experiment: overflow through a second (looping) launch, ~5 us on the timeline
+                hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, 2, 7>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
                 MR_CHECK_LAUNCH();
+                if (bound < nblocks) {
+                    p.list_first = (unsigned)bound;
+                    const int64_t rest = std::min<int64_t>(nblocks - bound, 512);
+                    hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, 1, 7>), dim3((unsigned)((rest + 7) & ~(int64_t)7)), dim3(TPB), 0, s, p);
+                    MR_CHECK_LAUNCH();
+                }
+                return MR_OK;
             }
+            hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, 0, 7>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
+            MR_CHECK_LAUNCH();
             return MR_OK;
         }
         return MR_ERR_NOTIMPL;  // (lists are built for the flow-mode render only)
@@ -1023,9 +1138,30 @@ static int launch_tiles(FwdParams& p, hipStream_t s, int64_t tile_bound = 0) {
     return MR_OK;
 }
 
+// mr_selftest_division: the shared-reciprocal division primitives next to the compiler's `/`, element by element
+__global__ void __launch_bounds__(256) selftest_division_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                float* __restrict__ refined, float* __restrict__ plain,
+                                                                int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    refined[i] = div_refined(a[i], b[i], rcp_refined(b[i]));
+    plain[i] = a[i] / b[i];
+}
+
 }  // namespace mr
 
 using namespace mr;
+
+extern "C" int mr_selftest_division(const float* a, const float* b, float* refined, float* plain, int64_t n,
+                                    mr_stream_t stream) {
+    if (n < 0 || (n > 0 && (!a || !b || !refined || !plain))) return MR_ERR_BADARG;
+    if (n == 0) return MR_OK;
+    const int64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(selftest_division_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, refined, plain, n);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
 
 extern "C" int64_t mr_render_workspace_bytes(int batch_size, int num_faces, int image_size) {
     if (batch_size < 0 || num_faces < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;

@@ -72,6 +72,11 @@ MR_API int mr_abi_version(void);
  * selects the device (hipSetDevice) before calling; the Python binding does so from the device of the
  * tensors it passes (handobjectconsist_amd/_lib.py: call). */
 MR_API int mr_device_ok(void);
+/* Validation only: refined[i] = a[i] / b[i] through the shared-reciprocal sequence the forward tile kernel uses for
+ * division-safe faces (csrc/mr_common.hpp: rcp_refined + div_refined), plain[i] = a[i] / b[i] as the compiler divides.
+ * Within the operand ranges stated there the two are the same bits (and the CPU's). */
+MR_API int mr_selftest_division(const float* a, const float* b, float* refined, float* plain, int64_t n,
+                                mr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * 1. Upstream-compatible entry points (neural_renderer.cuda.rasterize)

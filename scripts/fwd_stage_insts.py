@@ -36,5 +36,5 @@ if __name__ == "__main__":
         for _ in range(3):
             _lib.call("mr_render_flow_forward", P(pv), P(pf), P(cols), P(bg), 0, P(lut), int(lut.numel()), 0.99999, P(rgb),
                       P(alpha), P(mask), P(depth), P(wmap), P(fim), P(hit), P(work), wbytes, B2, V, F0, 1, is_, 0.1, 100.0,
-                      1e-3, _lib.FLAG_SPARSE_TILES | (dbg << 8), None, 0, None, None, 0, 0, st)
+                      1e-3, _lib.FLAG_SPARSE_TILES | (dbg << 8), None, -1, None, None, 0, 0, st)  # listed launch, a quarter of the tiles as the guess
         torch.cuda.synchronize()

@@ -35,3 +35,40 @@ for e in evs:
 print("launches", len(evs), "total device us", sum(tim.values()))
 for k, v in sorted(tim.items(), key=lambda kv: -kv[1])[:40]:
     print(f"{cnt[k]:4d} x {v:9.1f} us  {k}")
+
+if os.environ.get("HOC_HOST_PROFILE", "0") == "1":
+    # host side of the hot path: wall time per call with the GPU idle in between, and a cProfile of 30 calls
+    import cProfile, pstats, time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        hot()
+    t_issue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"30 calls: host issue time {t_issue / 30 * 1e6:.0f} us per call, with the GPU drained {t_all / 30 * 1e6:.0f} us per call")
+    # host time inside each C-ABI call (launches are asynchronous: this is argument marshalling + hipLaunchKernel)
+    from handobjectconsist_amd import _lib as L
+    real, spent = L.call, collections.Counter()
+
+    def timed(name, *a):
+        t = time.perf_counter()
+        try:
+            return real(name, *a)
+        finally:
+            spent[name] += time.perf_counter() - t
+
+    L.call = timed
+    for _ in range(30):
+        hot()
+    torch.cuda.synchronize()
+    L.call = real
+    for k, v in spent.most_common():
+        print(f"    {v / 30 * 1e6:7.1f} us per call inside _lib.call({k})")
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(30):
+        hot()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)

@@ -288,7 +288,7 @@ def test_flow_forward_tile_list_equals_one_workgroup_per_tile(cuda, B, is_):
         assert n_tiles in (None, n)
         n_tiles = n
     total = B * ((is_ + 7) // 8) * ((is_ + 31) // 32)
-    assert 0 < n_tiles < total
+    assert 8 < n_tiles < total  # (a guess of 1 launches 8 workgroups: the rest of the list went through the overflow path)
     # every tile that reports coverage is on the list (the list also holds tiles whose candidates cover nothing)
     assert n_tiles >= int((dense[6].view(B, -1, 4).amax(2) > 0).sum())
     run(n_tiles)  # the guess a caller makes from the previous call
@@ -407,6 +407,83 @@ def test_vertex_colour_kernels_follow_the_texel_table(cuda, table):
         assert_close(res[0][2].cpu().numpy(), res[1][2].cpu().numpy(), 1e-5, 1e-6 * float(res[1][2].abs().max()), "records vs maps")
     finally:
         textutils.TEXEL_VERTEX, opticalflow.USE_VERTEX_COLOR_RENDER, opticalflow.USE_PIXEL_RECORDS = saved
+
+
+def test_shared_reciprocal_division_is_the_ieee_quotient(cuda):
+    """rcp_refined + div_refined (the 3 + 5 n instruction sequence behind the tile kernel's divisions by a common
+    denominator) against the compiler's `/` on the GPU and numpy's on the CPU: the same bits for 6 M operand pairs over
+    the admitted ranges -- magnitudes 2^-30 .. 2^30, numerators also 0 and down to 2^-62, mantissas next to powers of two."""
+    from handobjectconsist_amd import _lib
+
+    rng = np.random.default_rng(7)
+    n = 6_000_000
+    sign = lambda: rng.choice(np.array([-1.0, 1.0], np.float32), n)
+    b = (np.exp2(rng.uniform(-30, 30, n)).astype(np.float32) * sign())
+    a = (np.exp2(rng.uniform(-62, 30, n)).astype(np.float32) * sign())
+    third = n // 3
+    a[:third] = (np.exp2(rng.uniform(-3, 3, third)).astype(np.float32) * sign()[:third])  # quotients of comparable numbers
+    edge = rng.integers(0, 6, n)
+    pow2 = lambda x: np.exp2(np.round(np.log2(np.abs(x)))).astype(np.float32)
+    b = np.where(edge == 0, np.nextafter(pow2(b), np.float32(0)), b).astype(np.float32)          # mantissa all ones
+    b = np.where(edge == 1, np.nextafter(pow2(b), np.float32(np.inf)), b).astype(np.float32)     # 1 + ulp
+    a = np.where(edge == 2, np.nextafter(pow2(a), np.float32(0)), a).astype(np.float32)
+    a[::97] = 0.0
+    a[1::97] = -0.0
+    ta, tb = t(a, cuda), t(b, cuda)
+    refined, plain = torch.empty_like(ta), torch.empty_like(ta)
+    _lib.call("mr_selftest_division", _lib.ptr(ta), _lib.ptr(tb), _lib.ptr(refined), _lib.ptr(plain), n, _lib.stream_ptr(cuda))
+    want = (a / b).astype(np.float32)
+    assert np.array_equal(plain.cpu().numpy().view(np.uint32), want.view(np.uint32)), "the GPU's `/` is the IEEE quotient"
+    bad = refined.cpu().numpy().view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), (int(bad.sum()), a[bad][:4], b[bad][:4])
+
+
+@pytest.mark.parametrize("case", ["bench scene", "small faces", "mixed magnitudes"])
+def test_tile_kernel_divisions_shared_vs_plain(cuda, case):
+    """The forward tile kernel with its shared-reciprocal division paths (faces the per-face pass admits) and with the
+    plain `/` everywhere (profiling switch 4096): every output plane, the face index map, the per-pixel records and the
+    coverage bytes are the same bits."""
+    from handobjectconsist_amd import _lib
+    from handobjectconsist_amd.neurender import nr_ops
+
+    f32 = dict(dtype=torch.float32, device=cuda)
+    if case == "bench scene":
+        B, is_ = 6, 256
+        s = synth.random_scene(B, seed=0, image_size=is_)
+        v = nr_ops.projection(t(s["verts1"], cuda), t(s["K1"], cuda), torch.eye(3, device=cuda)[None], torch.zeros(1, 3, device=cuda),
+                              torch.zeros(1, 5, device=cuda), is_).contiguous()
+        fidx = t(s["faces"], cuda).to(torch.int32).contiguous()
+    else:
+        B, is_ = 4, 96
+        d = _vc_abi_case(cuda, B, is_, 51)
+        v, fidx = d["v"].clone(), d["fidx"]
+        if case == "mixed magnitudes":  # some depths / coordinates outside the admitted ranges: those faces keep `/`
+            v[:, ::5, 2] *= 1e12
+            v[:, 1::7, :2] *= 3e4
+            v[:, 2::11, 2] = 1e-20
+    V, F0 = v.shape[1], fidx.shape[1]
+    cols = torch.randn(B, V, 3, generator=torch.Generator().manual_seed(1)).to(cuda)
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    bg = torch.zeros(3, **f32)
+    wbytes = int(_lib.load().mr_render_workspace_bytes(B, 2 * F0, is_))
+    work = torch.empty((wbytes,), dtype=torch.uint8, device=cuda)
+    outs = []
+    for dbg in (0, 4096):
+        for records in (True, False):
+            rgb = torch.zeros((B, 3, is_, is_), **f32)
+            alpha, mask, depth = torch.zeros((B, is_, is_), **f32), torch.zeros((B, is_, is_), **f32), torch.zeros((B, is_, is_), **f32)
+            wmap = torch.zeros((B, is_, is_, 3), **f32)
+            fim = torch.full((B, is_, is_), -7, dtype=torch.int32, device=cuda)
+            vid = torch.full((B, is_, is_, 3), -7, dtype=torch.int32, device=cuda)
+            hit = torch.zeros((B, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=cuda)
+            _lib.call("mr_render_flow_forward", P(v), P(fidx), P(cols), P(bg), 0, None, 0, 0.99999, P(rgb), P(alpha), P(mask),
+                      None if records else P(depth), P(wmap), P(fim), P(hit), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3,
+                      _lib.FLAG_SPARSE_TILES | (dbg << 8), P(vid) if records else None, -1, None, None, 0, 0, st)
+            outs.append([x.view(torch.int32) if x.dtype == torch.float32 else x for x in (rgb, alpha, mask, depth, wmap, fim, vid, hit)])
+    assert int((outs[0][5] >= 0).sum()) > 200
+    for fast, plain in ((outs[0], outs[2]), (outs[1], outs[3])):
+        for a, b_, name in zip(fast, plain, ("rgb", "alpha", "mask", "depth", "weights", "face_index_map", "vertex ids", "coverage")):
+            assert torch.equal(a, b_), f"{case}: {name} differs between the shared-reciprocal and the plain divisions"
 
 
 def test_training_mode_textures_only(cuda):
