@@ -73,9 +73,14 @@ struct BinHdr {
 };
 // Header of the tile list of a launch (one per call, in the workspace).
 struct TileList {
-    unsigned n;       // tiles with at least one candidate record, all images
-    unsigned pad[63];
+    unsigned n_heavy;  // tiles with at least HEAVY_RECS candidate records, all images: dispatched FIRST
+    unsigned n_light;  // the other tiles with at least one candidate record
+    unsigned pad[62];
 };
+// A tile's S1-S3 phase takes 6 us below 50 records and 16 - 20 us above 200 (workgroup timeline): handed out in screen
+// order, the last heavy tiles start when the launch is nearly over and the chip drains for 20 us behind them.  The list
+// therefore has two parts -- tiles with >= HEAVY_RECS records first -- so that the tail is made of light tiles.
+constexpr unsigned HEAVY_RECS = 128;
 
 // {x0 | x1 << 16, y0 | y1 << 16, (virtual) face index, unused}
 typedef uint4 FaceRec;
@@ -116,7 +121,8 @@ struct BinParams {
     int dbg;                 // profiling experiments (scripts/fwd_vc_variants.py)
     // compacted list of the tiles with candidate records (sparse-tile launches; nullptr = none is built)
     TileList* tlist;         // counter, zeroed by face_records_kernel, bumped once per image by bin_boxes_kernel
-    uint4* tile_ids;         // [B * tiles] list entries {global tile id = image * tiles per image + tile, offset and
+    int64_t tile_cap;        // B * tiles: the list's heavy part starts at entry 0, its light part at entry tile_cap
+    uint4* tile_ids;         // [2 * B * tiles] list entries {global tile id = image * tiles per image + tile, offset and
                              // count of the bin's records, length of the image's large list}, grouped by image: everything
                              // a tile's workgroup needs to start on its records after ONE scalar load
     uint8_t* tile_hit;       // [B, tiles, 4]: the binning pass writes the (zero) coverage bytes of the other tiles
@@ -133,7 +139,7 @@ template <bool VC>
 __global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
     const int b = blockIdx.y;
     const int f0 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p.tlist && b == 0 && f0 == 0) p.tlist->n = 0u;  // (this launch precedes the binning pass on the stream)
+    if (p.tlist && b == 0 && f0 == 0) { p.tlist->n_heavy = 0u; p.tlist->n_light = 0u; }  // (this launch precedes the binning pass)
     if (f0 >= p.F0) return;
     const int is = p.is;
     float f[9];
@@ -183,9 +189,24 @@ __global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
 // (Measured and dropped, each SLOWER than the plain per-lane LDS atomics below -- the kernel is bound by the
 // length of each wave's dependent instruction chain, not by LDS conflicts: combining the lanes that hit one bin
 // with a ballot loop, folding runs of equal neighbours into one atomic, prefetching 8 iterations of boxes.)
+#ifdef MR_WG_TIMELINE
+__device__ unsigned long long mr_dbg_bin[1024 * 8];  // profiling builds: phase stamps of the binning pass per image
+#define MR_BIN_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) mr_dbg_bin[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define MR_BIN_STAMP(k) do { } while (0)
+#endif
+
+// Where its time goes (scripts/wg_timeline.py on a -DMR_WG_TIMELINE build, 7104 virtual faces, 1024 bins): 10 us inside the
+// kernel per image -- counting pass 4.1 (of which the boxes' load round trip ~1.5), scan + headers 1.6, fill pass 3.9
+// -- + ~3 us of launch and ~2 us between the first image's start and the last one's end.  Measured WITHOUT effect on
+// those numbers, and not kept: walking the faces in a strided order so that a wave's lanes land in different bins,
+// padding the counter rows against LDS bank conflicts (32 bins per row = 32 banks), four predicated straight-line atomics
+// instead of the bin loops for faces within 2 x 2 bins.  What is left is memory latency at three dependent points
+// (boxes in, headers / records out) around ~2 x 2 us of atomics.
 __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
+    MR_BIN_STAMP(0);
     extern __shared__ int bin_smem[];
-    __shared__ int s_large, s_nlarge, s_lbase;
+    __shared__ int s_large, s_nlarge, s_lbase, s_hbase;
     __shared__ unsigned long long wsum[BIN_TPB / MR_WAVE];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbins = p.nbx * p.nby;
@@ -198,6 +219,7 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     if (p.zero_fill)
         for (int64_t i = (int64_t)b * BIN_TPB + tid; i < p.zero_count; i += (int64_t)gridDim.x * BIN_TPB) p.zero_fill[i] = 0.0f;
     __syncthreads();
+    MR_BIN_STAMP(1);
 
     // pass 1: records per bin.  The boxes of BIN_PF trips are requested together (unconditional loads from clamped
     // addresses): one load round trip per BIN_PF x 1024 faces instead of one per trip -- a hand + object mesh (7104
@@ -224,6 +246,7 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         }
     }
     __syncthreads();
+    MR_BIN_STAMP(2);
 
     // exclusive scan of the bin counts (each thread owns a run of consecutive bins); headers out, counters
     // become fill cursors.  The high half of the scanned value counts the bins that hold candidates (every bin,
@@ -234,7 +257,10 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     unsigned long long local = 0;
     for (int i = i0; i < i1; i++) {
         const int c = cnt[i];
-        local += (unsigned long long)(unsigned)c | ((unsigned long long)((c > 0 || all_live) ? 1u : 0u) << 32);
+        // (bits 32-47: bins that hold candidates, bits 48-63: those of them that are heavy; at most 8192 bins per image)
+        const unsigned nrec_i = (unsigned)c + (unsigned)s_nlarge;
+        local += (unsigned long long)(unsigned)c | ((unsigned long long)((c > 0 || all_live) ? 1u : 0u) << 32) |
+                 ((unsigned long long)((p.tlist && nrec_i >= HEAVY_RECS) ? 1u : 0u) << 48);
     }
     unsigned long long incl = local;
 #pragma unroll
@@ -251,7 +277,11 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         total64 += ws;
     }
     int base = (int)(unsigned)(base64 & 0xffffffffull);
-    if (p.tlist && tid == 0) s_lbase = (int)atomicAdd(&p.tlist->n, (unsigned)(total64 >> 32));
+    if (p.tlist && tid == 0) {
+        const unsigned n_ne = (unsigned)(total64 >> 32) & 0xffffu, n_hv = (unsigned)(total64 >> 48);
+        s_hbase = (int)atomicAdd(&p.tlist->n_heavy, n_hv);
+        s_lbase = (int)atomicAdd(&p.tlist->n_light, n_ne - n_hv);
+    }
     BinHdr* bh = p.bins + (int64_t)b * nbins;
     unsigned livebits = 0u;  // (per <= MAX_BINS / BIN_TPB = 8 bins per thread)
     for (int i = i0; i < i1; i++) {
@@ -264,29 +294,34 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         livebits |= (c > 0 ? 1u : 0u) << (i - i0);
     }
     __syncthreads();
+    MR_BIN_STAMP(3);
     if (p.tlist) {
         // the image's tiles with candidates go to the launch's tile list (a bin IS a tile here: ysh == 0), the
         // others get their (zero) coverage bytes now -- no workgroup is dispatched for them
-        unsigned at = (unsigned)s_lbase + (unsigned)(base64 >> 32);
+        const unsigned hv_before = (unsigned)(base64 >> 48), ne_before = (unsigned)(base64 >> 32) & 0xffffu;
+        unsigned at_h = (unsigned)s_hbase + hv_before;                                   // heavy part: from the front
+        unsigned at_l = (unsigned)p.tile_cap + (unsigned)s_lbase + (ne_before - hv_before);  // light part: second half
         uint32_t* hit32 = reinterpret_cast<uint32_t*>(p.tile_hit) + (int64_t)b * nbins;
         const unsigned nlarge = (unsigned)s_nlarge;
         for (int i = i0; i < i1; i++) {
             const bool live = all_live || ((livebits >> (i - i0)) & 1u);
             // (cnt[] holds the bins' fill cursors = record offsets until pass 2 starts; `base` is the end of this run)
             const unsigned off = (unsigned)cnt[i], end = (unsigned)(i + 1 < i1 ? cnt[i + 1] : base);
-            if (live) p.tile_ids[at++] = make_uint4((unsigned)(b * nbins + i), off, end - off, nlarge);
+            const uint4 ent = make_uint4((unsigned)(b * nbins + i), off, end - off, nlarge);
+            if (live && end - off + nlarge >= HEAVY_RECS) p.tile_ids[at_h++] = ent;
+            else if (live) p.tile_ids[at_l++] = ent;
             else hit32[i] = 0u;
         }
         __syncthreads();  // (pass 2 moves the cursors)
     }
+    MR_BIN_STAMP(4);
     if (p.dbg & 2) return;
 
     // pass 2: fill
     FaceRec* recs_b = p.recs + (int64_t)b * REC_CAP * p.F;
     FaceRec* large_b = recs_b + (int64_t)SMALL_MAX_BINS * p.F;
-    for (int fn = tid; fn < p.F; fn += BIN_TPB) {
-        const FaceBox bx = p.lds_boxes ? sbox[fn] : box_b[fn];
-        if (bx.x0 > bx.x1) continue;
+    auto fill_face = [&](const int fn, const FaceBox bx) __attribute__((always_inline)) {
+        if (bx.x0 > bx.x1) return;
         FaceRec rec;
         rec.x = (unsigned)(unsigned short)bx.x0 | ((unsigned)(unsigned short)bx.x1 << 16);
         rec.y = (unsigned)(unsigned short)bx.y0 | ((unsigned)(unsigned short)bx.y1 << 16);
@@ -300,8 +335,16 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
             for (int y = by0; y <= by1; y++)
                 for (int x = bx0; x <= bx1; x++) recs_b[atomicAdd(&cnt[y * p.nbx + x], 1)] = rec;
         }
+    };
+    // (two loops, not one over `lds_boxes ? sbox[fn] : box_b[fn]`: the merged pointer is a generic one, and every box
+    // then costs two dependent FLAT loads with a full wait each, also when it sits in LDS)
+    if (p.lds_boxes) {
+        for (int fn = tid; fn < p.F; fn += BIN_TPB) fill_face(fn, sbox[fn]);
+    } else {
+        for (int fn = tid; fn < p.F; fn += BIN_TPB) fill_face(fn, box_b[fn]);
     }
     __syncthreads();
+    MR_BIN_STAMP(5);
     if (tid == 0) {
         ImageHdr h;
         h.n_live = 0; h.n_large = s_large;
@@ -347,10 +390,10 @@ struct FwdParams {
     int dbg;                         // profiling experiments (flags >> 8)
     // listed launches (sparse tiles): the binning pass's list of tiles with candidates
     const TileList* tlist;
-    const uint4* tile_ids;
+    const uint4* tile_ids;           // heavy entries [0, n_heavy), light entries [tile_cap, tile_cap + n_light)
+    unsigned tile_cap;
     uint32_t* tile_count_out;        // nullable, any device-writable address (e.g. pinned host memory): the list
                                      // length of this launch, for the caller's next grid-size guess
-    unsigned list_first;             // first list entry this launch handles
     // vertex-colour mode (VC): indexed geometry + per-vertex colours, fill-back done by index
     // arithmetic: virtual face fn >= F0 is face fn - F0 with its vertex order reversed
     const float* verts;              // [B,V,3] projected vertices (x,y NDC, z metric)
@@ -883,57 +926,70 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
     }
 }
 
-// Listed launches whose tile list turned out LONGER than the grid (the caller's guess was low): the entries beyond the
-// grid, with a grid stride.  Deliberately NOT inlined, and reading the kernel's arguments from the kernarg segment
-// itself: a loop around the tile body keeps every kernel argument live in scalar registers across its trips and
-// spills 36 vector registers (175 instead of 142 us when the loop is the kernel; +2 us even as a never-entered second
-// copy of the body); as a called function its registers and spills are its own business, and nothing of it is executed
-// when the guess held.  (A separate small looping launch for the overflow costs ~5 us on the timeline.)
+// A workgroup's place in a listed launch.  The dispatcher puts workgroup i on XCD i % 8, and every XCD has its own L2:
+// each XCD gets a contiguous eighth of the list's heavy part followed by the same eighth of its light part (the entries
+// of an image are contiguous in both parts, so an image's records stay in one L2, every XCD gets the same share of the
+// heavy tiles, and within an XCD the heavy ones are dispatched first).  Local entry j of XCD x is list entry slot(j).
+struct ListSlice {
+    unsigned first_heavy, n_heavy, first_light, n_local, stride;
+    __device__ __forceinline__ unsigned slot(unsigned j, unsigned cap) const {
+        return j < n_heavy ? first_heavy + j : cap + first_light + (j - n_heavy);
+    }
+};
+__device__ __forceinline__ ListSlice list_slice(unsigned n_heavy, unsigned n_light, unsigned& j) {
+    const unsigned nx = (gridDim.x & 7u) ? 1u : 8u;  // (grids that are no multiple of 8: one slice)
+    const unsigned x = blockIdx.x % nx;
+    j = blockIdx.x / nx;
+    ListSlice s;
+    s.first_heavy = (unsigned)((unsigned long long)n_heavy * x / nx);
+    s.n_heavy = (unsigned)((unsigned long long)n_heavy * (x + 1) / nx) - s.first_heavy;
+    s.first_light = (unsigned)((unsigned long long)n_light * x / nx);
+    s.n_local = s.n_heavy + (unsigned)((unsigned long long)n_light * (x + 1) / nx) - s.first_light;
+    s.stride = gridDim.x / nx;
+    return s;
+}
+
+// Listed launches whose tile list turned out LONGER than the grid (the caller's guess was low): the slice's entries
+// beyond the first round, with the slice's stride.  Deliberately NOT inlined, and handed the kernel's argument block
+// as a pointer into the kernarg segment: a loop around the tile body keeps every kernel argument live in scalar
+// registers across its trips and spills 36 vector registers (175 instead of 142 us when the loop is the kernel, +2 us
+// even as a never-entered second inlined copy of the body); as a called function its registers and spills are its own
+// business, and nothing of it is executed when the guess held.  (A separate small looping launch for the overflow
+// costs ~5 us on the timeline.)
 template <bool FUSED, bool VC>
-__device__ __attribute__((noinline)) void raster_overflow_tiles(const FwdParams* kernargs, unsigned wi, const unsigned n_work,
-                                                                const unsigned stride) {
+__device__ __attribute__((noinline)) void raster_overflow_tiles(const FwdParams* kernargs, const ListSlice sl, unsigned j) {
     const FwdParams& p = *kernargs;
-    for (; wi < n_work; wi += stride) {
+    for (; j < sl.n_local; j += sl.stride) {
         __syncthreads();
-        const uint4 ent = p.tile_ids[wi];
+        const uint4 ent = p.tile_ids[sl.slot(j, p.tile_cap)];
         raster_one_tile<FUSED, VC>(p, ent.x, &ent);
     }
 }
 
-// MODE 0: one tile per workgroup: workgroup i takes tile i (XCD-aware) or -- listed launches, p.tlist -- entry i of the
-//         list of tiles that hold candidates: the grid is sized by the caller's guess of the list length, no workgroup
-//         is dispatched for the empty 80 % of the screen and none pulls work through an atomic (a queue cursor serialised
-//         the launch, profiles/r02_persistent_tile_kernel_experiment.patch).  A longer list: raster_overflow_tiles.
-// MODE 1: experiment: the workgroup walks the tile list with a grid-stride loop around the inlined body.
-// MODE 2: experiment: MODE 0 without the overflow call (the caller adds a MODE 1 launch for entries beyond the grid).
-template <bool FUSED, bool VC, int MODE = 0, int WAVES = 7>
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) raster_tile_kernel(FwdParams p) {
+// One tile per workgroup: workgroup i takes tile i (XCD-aware) or -- listed launches, p.tlist -- one entry of the list
+// of tiles that hold candidates: the grid is sized by the caller's guess of the list length, no workgroup is dispatched
+// for the empty 80 % of the screen and none pulls work through an atomic (a queue cursor serialised the launch,
+// profiles/r02_persistent_tile_kernel_experiment.patch).  A list longer than the grid: raster_overflow_tiles.
+template <bool FUSED, bool VC>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))) raster_tile_kernel(FwdParams p) {
+    // (ONE call site of the tile body: a second inlined copy costs the listed path 60 more scalar spills)
     const bool listed = p.tlist != nullptr;
-    const unsigned n_work = listed ? p.tlist->n : gridDim.x;
-    if (listed && p.tile_count_out && p.list_first == 0u && blockIdx.x == 0 && threadIdx.x == 0) *p.tile_count_out = n_work;
-    // (consecutive list entries are tiles of one image: xcd_remap keeps them on one XCD / L2)
-    unsigned wi = p.list_first + xcd_remap(blockIdx.x, gridDim.x);
-    if (MODE != 1) {
-        if (wi < n_work) {
-            if (listed) {
-                const uint4 ent = p.tile_ids[wi];
-                raster_one_tile<FUSED, VC>(p, ent.x, &ent);
-            } else {
-                raster_one_tile<FUSED, VC>(p, wi);
-            }
-        }
-        if (MODE == 0 && FUSED && VC && listed && n_work > gridDim.x)  // (workgroup-uniform; false whenever the guess held)
-            // (the kernel's own argument block, in the kernarg segment: C cast out of address space 4; the intrinsic is
-            // only valid in the kernel itself -- inside the callee it read as a null pointer)
-            raster_overflow_tiles<FUSED, VC>((const FwdParams*)__builtin_amdgcn_kernarg_segment_ptr(), wi + gridDim.x, n_work,
-                                             gridDim.x);
-    } else {
-        for (; wi < n_work; wi += gridDim.x) {
-            const uint4 ent = p.tile_ids[wi];
-            raster_one_tile<FUSED, VC>(p, ent.x, &ent);
-            __syncthreads();
-        }
+    unsigned j = 0;
+    ListSlice sl{};
+    uint4 ent = make_uint4(xcd_remap(blockIdx.x, gridDim.x), 0u, 0u, 0u);
+    bool have = true;
+    if (listed) {
+        const unsigned n_heavy = p.tlist->n_heavy, n_light = p.tlist->n_light;
+        if (p.tile_count_out && blockIdx.x == 0 && threadIdx.x == 0) *p.tile_count_out = n_heavy + n_light;
+        sl = list_slice(n_heavy, n_light, j);
+        have = j < sl.n_local;
+        if (have) ent = p.tile_ids[sl.slot(j, p.tile_cap)];
     }
+    if (have) raster_one_tile<FUSED, VC>(p, ent.x, listed ? &ent : nullptr);
+    if (FUSED && VC && listed && sl.n_local > sl.stride)  // (uniform per slice; false whenever the guess held)
+        // (the kernel's own argument block, in the kernarg segment: C cast out of address space 4; the intrinsic is
+        // only valid in the kernel itself -- inside the callee it read as a null pointer)
+        raster_overflow_tiles<FUSED, VC>((const FwdParams*)__builtin_amdgcn_kernarg_segment_ptr(), sl, j + sl.stride);
 }
 
 // Validation-only variant (flags & MR_FLAG_REFERENCE_ALGO): upstream's structure, every pixel
@@ -1043,7 +1099,7 @@ static WorkLayout work_layout(int B, int F, int is) {
     w.off_rverts = w.off_recs + align256((size_t)B * REC_CAP * F * sizeof(FaceRec));
     w.off_tlist = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (VC needs F / 2 of it with fill-back)
     w.off_tile_ids = w.off_tlist + align256(sizeof(TileList));
-    w.total = w.off_tile_ids + align256((size_t)B * tiles_x * tiles_y * sizeof(uint4));
+    w.total = w.off_tile_ids + align256((size_t)2 * B * tiles_x * tiles_y * sizeof(uint4));  // heavy part | light part
     return w;
 }
 
@@ -1060,7 +1116,8 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
         bp.tlist = (TileList*)(base + w.off_tlist);
         bp.tile_ids = (uint4*)(base + w.off_tile_ids);
         bp.tile_hit = tile_hit;
-        fp.tlist = bp.tlist; fp.tile_ids = bp.tile_ids;
+        bp.tile_cap = (int64_t)B * w.nbx * w.nby;
+        fp.tlist = bp.tlist; fp.tile_ids = bp.tile_ids; fp.tile_cap = (unsigned)bp.tile_cap;
     }
     bp.hdrs = (ImageHdr*)base;
     bp.bins = (BinHdr*)(base + w.off_bins);
@@ -1110,24 +1167,7 @@ static int launch_tiles(FwdParams& p, hipStream_t s, int64_t tile_bound = 0) {
         if (tile_bound <= 0) tile_bound = (nblocks + 3) / 4;
         const int64_t bound = std::min<int64_t>(nblocks, std::max<int64_t>((tile_bound + 7) & ~(int64_t)7, 8));
         if constexpr (FUSED && VC) {
-            if (p.dbg & 512) {  // experiment: the looping variant alone (7 waves per SIMD; 1024: 6)
-                if (p.dbg & 1024) hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, 1, 6>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
-                else hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, 1, 7>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
-                MR_CHECK_LAUNCH();
-                return MR_OK;
-            }
-            if (p.dbg & 2048) {  // experiment: overflow through a second (looping) launch, ~5 us on the timeline
-                hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, 2, 7>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
-                MR_CHECK_LAUNCH();
-                if (bound < nblocks) {
-                    p.list_first = (unsigned)bound;
-                    const int64_t rest = std::min<int64_t>(nblocks - bound, 512);
-                    hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, 1, 7>), dim3((unsigned)((rest + 7) & ~(int64_t)7)), dim3(TPB), 0, s, p);
-                    MR_CHECK_LAUNCH();
-                }
-                return MR_OK;
-            }
-            hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC, 0, 7>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
+            hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
             MR_CHECK_LAUNCH();
             return MR_OK;
         }
@@ -1325,6 +1365,9 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
 #ifdef MR_WG_TIMELINE
 extern "C" __attribute__((visibility("default"))) int mr_debug_times(void* dst, long n) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mr::mr_dbg_times), n, 0, hipMemcpyDeviceToHost);
+}
+extern "C" __attribute__((visibility("default"))) int mr_debug_bin_times(void* dst, long n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mr::mr_dbg_bin), n, 0, hipMemcpyDeviceToHost);
 }
 #endif
 

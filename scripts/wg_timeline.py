@@ -28,10 +28,18 @@ wbytes = int(lib.mr_render_workspace_bytes(B2, 2 * F0, is_)); work = torch.empty
 bg = torch.zeros(3, **f32)
 lut = torch.ones(2 * F0 + 2, **f32)
 flush = torch.zeros(768 * 1024 * 1024 // 4, **f32)
-fn = lambda: _lib.call("mr_render_flow_forward", P(pv), P(pf), P(cols), P(bg), 0, P(lut), int(lut.numel()), 0.99999, P(rgb), P(alpha), P(mask), P(depth), P(wmap), P(fim), P(hit), P(work), wbytes, B2, V, F0, 1, is_, 0.1, 100.0, 1e-3, _lib.FLAG_SPARSE_TILES, None, 0, None, None, 0, 0, st)
+fn = lambda: _lib.call("mr_render_flow_forward", P(pv), P(pf), P(cols), P(bg), 0, P(lut), int(lut.numel()), 0.99999, P(rgb), P(alpha), P(mask), P(depth), P(wmap), P(fim), P(hit), P(work), wbytes, B2, V, F0, 1, is_, 0.1, 100.0, 1e-3, _lib.FLAG_SPARSE_TILES, None, -1, None, None, 0, 0, st)
 print("cold %.1f us" % (bench.event_time_ms(fn, 10, flush=flush) * 1e3))
 flush.add_(1.0); torch.cuda.synchronize()
 fn(); torch.cuda.synchronize()
+# phases of the binning pass (one workgroup per image): mean over the images, microseconds
+bb = np.zeros(1024 * 8, dtype=np.uint64)
+lib.mr_debug_bin_times.argtypes = [ctypes.c_void_p, ctypes.c_long]
+assert lib.mr_debug_bin_times(bb.ctypes.data, bb.nbytes) == 0
+bt = bb.reshape(1024, 8)[:B2, :6].astype(np.int64)
+names = ["zero counters (+ zero_fill)", "pass 1: count", "scan + bin headers", "tile list", "pass 2: fill"]
+print("binning pass, per image (us):", {n_: round(float((bt[:, k + 1] - bt[:, k]).mean()) * 0.01, 2) for k, n_ in enumerate(names)},
+      "total %.2f" % (float((bt[:, 5] - bt[:, 0]).mean()) * 0.01), "first start -> last end %.2f" % ((bt[:, 5].max() - bt[:, 0].min()) * 0.01))
 n = 32768
 buf = np.zeros(n * 4, dtype=np.uint64)
 lib.mr_debug_times.argtypes = [ctypes.c_void_p, ctypes.c_long]
