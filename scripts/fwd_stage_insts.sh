@@ -12,7 +12,7 @@ sys.path.insert(0, sys.argv[2] + "/scripts")
 from collections import defaultdict, OrderedDict
 rows = defaultdict(dict)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "raster_tile_kernel<true, true, 0, 7>" in r["Kernel_Name"]:
+    if "raster_tile_kernel<true, true>" in r["Kernel_Name"]:
         rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(rows)
 import importlib.util
