@@ -723,7 +723,10 @@ def main():
         line = {
             "metric": "trainmeshwarp iters/sec (render+warp, B=64, 256x256)",
             "value": round(world * args.steps / dt, 4),
-            "unit": "iters/s (each: 1 data batch + 1 consist batch of B per GPU, one optimizer step)",
+            "unit": "iters/s (each: 1 data batch + 1 consist batch of B per GPU, one optimizer step; the figure with the encoder "
+                    "entirely on stock PyTorch-ROCm modules, as the north star words it, is stock_trunk.value -- `value` adds this "
+                    "build's fused BatchNorm/ReLU/residual/max-pool kernels between the stock convolutions; render + warp itself "
+                    "is hot_path.device_ms_graph_replay ms of the step)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
