@@ -201,6 +201,7 @@ def kernel_bench(dev, B, is_, iters, only=None):
     pwrec = torch.empty((B2, is_, is_, 3), **f32)
     poccl = (torch.rand((B2, is_, is_), device=dev) < 0.9).float()
     pg_flow = torch.randn((B2, is_, is_, 2), **f32)
+    pg_bound = pg_flow.abs().amax((1, 2, 3)).contiguous()  # (in training: left by the pair loss's backward kernel)
 
     # the list length of the previous launch, written by the kernel into pinned host memory: the next launch's grid
     tile_word = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -223,7 +224,8 @@ def kernel_bench(dev, B, is_, iters, only=None):
         # timing loop keep adding into it, which changes no instruction the kernel executes)
         _lib.call("mr_render_flow_backward", P(pv), P(pf), P(pfim), P(ptile_hit), P(pwrec), None, None, P(pg_flow),
                   P(pmask), P(pmask[:B]), P(palpha[B:]), B, P(poccl), is_, is_, P(pg_cols), B2, pv.shape[1], F0, 1, is_, 1e-3,
-                  _lib.FLAG_OUTPUT_ZEROED, P(pvid), 0, st)
+                  _lib.FLAG_OUTPUT_ZEROED | (int(os.environ.get("HOC_FLOW_BWD_DBG", "0")) << 8), P(pvid), 0,
+                  P(pg_bound) if os.environ.get("HOC_GRAD_BOUND", "1") == "1" else None, st)
 
     render_flow_fwd_pair()
     render_vc_fwd_pair()
@@ -256,9 +258,12 @@ def kernel_bench(dev, B, is_, iters, only=None):
         _lib.call("mr_pair_consist_forward", P(flow12), P(flow21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(pcwork),
                   pbytes, P(sums), P(lf), P(lb), *([None] * 8), B, is_, is_, 0.99999, P(ptile_hit[:B]), P(ptile_hit[B:]), is_, st)
 
+    pgmax = torch.zeros(2 * B, **f32)  # per-image gradient maxima, as the training path asks for them
+
     def pair_bwd():
         _lib.call("mr_pair_consist_backward", P(flow12), P(flow21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(sums),
-                  P(gl), P(gl), P(g12), P(g21), B, is_, is_, 0.99999, P(ptile_hit[:B]), P(ptile_hit[B:]), is_, st)
+                  P(gl), P(gl), P(g12), P(g21), B, is_, is_, 0.99999, P(ptile_hit[:B]), P(ptile_hit[B:]), is_,
+                  P(pgmax) if os.environ.get("HOC_GRAD_BOUND", "1") == "1" else None, st)
 
     m1, m2 = alpha.unsqueeze(1).contiguous(), alpha.unsqueeze(1).contiguous()
     o1, o2 = torch.empty((B, is_, is_), **f32), torch.empty((B, is_, is_), **f32)

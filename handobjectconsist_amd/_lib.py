@@ -36,7 +36,7 @@ SIGNATURES = {
     "mr_render_backward": (_I, [_P] * 11 + [_L, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
     "mr_render_vc_forward": (_I, [_P, _P, _P, _P, _I] + [_P] * 6 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _I, _P]),
     "mr_render_vc_backward": (_I, [_P] * 7 + [_I, _I, _I, _I, _I, _F, _I, _I, _P]),
-    "mr_render_flow_backward": (_I, [_P] * 11 + [_I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
+    "mr_render_flow_backward": (_I, [_P] * 11 + [_I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P]),
     "mr_render_flow_forward": (_I, [_P, _P, _P, _P, _I, _P, _I, _F] + [_P] * 8 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _P, _I, _P, _P, _L, _I, _P]),
     "mr_flow_vertices_forward": (_I, [_P] * 7 + [_I, _F] + [_P] * 4 + [_I, _I, _P]),
     "mr_flow_vertices_backward": (_I, [_P] * 8 + [_I, _I, _P]),
@@ -54,7 +54,7 @@ SIGNATURES = {
     "mr_flow_finalize_backward": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
     "mr_pair_consist_workspace_bytes": (_L, [_I, _I, _I]),
     "mr_pair_consist_forward": (_I, [_P] * 6 + [_I, _P, _L] + [_P] * 11 + [_I, _I, _I, _F, _P, _P, _I, _P]),
-    "mr_pair_consist_backward": (_I, [_P] * 6 + [_I] + [_P] * 5 + [_I, _I, _I, _F, _P, _P, _I, _P]),
+    "mr_pair_consist_backward": (_I, [_P] * 6 + [_I] + [_P] * 5 + [_I, _I, _I, _F, _P, _P, _I, _P, _P]),
     "mr_frames_to_batch_workspace_bytes": (_L, [_I, _I, _I]),
     "mr_frames_to_batch": (_I, [_P] * 3 + [_F] * 6 + [_P, _L, _P, _P] + [_I] * 6 + [_P]),
     "mr_bn_act_forward": (_I, [_P] * 6 + [_F, _I, _I, _I, _P, _I, _I, _I, _P]),

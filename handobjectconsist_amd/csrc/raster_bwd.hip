@@ -692,8 +692,14 @@ __global__ void __launch_bounds__(SV_WAVES * MR_WAVE) scatter_vc_kernel(ScatterV
 // the adjoint of crop / permute / mask products is applied on the fly with the arithmetic of
 // flow_finalize_backward_kernel ((g * (m_x * occl)) * m_pre; third colour plane: zero), so that the [B,3,is,is]
 // colour-space gradient is never materialised.
-constexpr int ST_G = 16;      // workgroups per image
-constexpr int ST_WAVES = 4;   // waves per workgroup
+// Launch shape.  The [V, channels] fixed-point table is what limits residency (42.7 KB for a hand + object mesh with
+// three channels: 3 workgroups per compute unit, 768 for 2048 launched, i.e. three rounds of ~9 us each -- workgroup
+// timeline, scripts/bwd_timeline.py).  The flow-space gradient has two channels (the third colour plane's gradient is
+// identically zero): its table is a third smaller; and eight workgroups of EIGHT waves per image instead of sixteen of
+// four keep the 64 waves per image while halving the per-image fixed work (covered-tile list, table zeroing, flush):
+// 4 x 8 waves fit a compute unit, so all 1024 workgroups of a 128-image launch are resident at once.
+constexpr int ST_G = 8;       // workgroups per image (sp.groups; profiling: flags >> 8 bits 4-6 select 2 / 4 / 16 / 32)
+constexpr int ST_WAVES = 8;   // waves per workgroup
 constexpr int ST_TW = 32, ST_TH = 8;  // the forward's tile
 constexpr int ST_MAX_TILES = 4096;    // tiles per image the covered-tile list in LDS can hold (1024 x 1024 pixels)
 
@@ -712,6 +718,8 @@ struct ScatterTilesParams {
     const float* occl;
     int split, H, W;
     int tiles_x, tiles_y;
+    int groups;  // workgroups per image
+    const float* grad_bound;  // nullable (FLOWGRAD): [B] upper bounds of |grad_flow| per image
 };
 
 template <bool FLOWGRAD>
@@ -745,15 +753,25 @@ __device__ __forceinline__ void st_load_grad(const ScatterTilesParams& sp, int b
     }
 }
 
+#ifdef MR_WG_TIMELINE
+__device__ unsigned long long mr_dbg_st[4096 * 8];  // profiling builds: phase stamps of the first 4096 workgroups
+#define MR_ST_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) mr_dbg_st[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define MR_ST_STAMP(k) do { } while (0)
+#endif
+
 template <bool FLOWGRAD, bool REC>
 __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(ScatterTilesParams sp) {
-    extern __shared__ long long vtab[];  // [V * 3] rounded up to an even count
+    MR_ST_STAMP(0);
+    extern __shared__ long long vtab[];  // [V * NCH] rounded up to an even count
+    constexpr int NCH = FLOWGRAD ? 2 : 3;  // (the flow-space gradient has no third channel)
     __shared__ unsigned wmax[ST_WAVES];
     __shared__ unsigned short hits[ST_MAX_TILES];  // the image's covered tiles, ascending
     __shared__ int wcnt[ST_WAVES];
     const GatherVCParams& p = sp.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x / ST_G, part = blockIdx.x % ST_G;
+    const int G = sp.groups;
+    const int b = blockIdx.x / G, part = blockIdx.x % G;
     const int is = p.is;
     const int T = sp.tiles_x * sp.tiles_y;
     const int r = lane >> 3, x4 = (lane & 7) * 4;  // the lane's pixel quad inside a tile
@@ -777,13 +795,16 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
         __syncthreads();
     }
 
+    MR_ST_STAMP(1);
     if (part * ST_WAVES >= n_hits) return;  // fewer covered tiles than waves before this workgroup: nothing to do
-    const int n2 = (p.V * 3 + 1) >> 1;
+    const int n2 = (p.V * NCH + 1) >> 1;
     for (int k = threadIdx.x; k < n2; k += blockDim.x) reinterpret_cast<int4*>(vtab)[k] = make_int4(0, 0, 0, 0);
 
-    // pass 1: largest |gradient| over the workgroup's covered tiles, as float bits
+    // pass 1: largest |gradient| over the workgroup's covered tiles, as float bits -- or the caller's bound for the image
     unsigned mx = 0u;
-    for (int h = part * ST_WAVES + wave; h < n_hits; h += ST_G * ST_WAVES) {
+    const bool bounded = FLOWGRAD && sp.grad_bound != nullptr;
+    if (bounded) mx = __float_as_uint(sp.grad_bound[b]) & 0x7fffffffu;
+    for (int h = part * ST_WAVES + wave; h < n_hits && !bounded; h += G * ST_WAVES) {
         const int t = hits[h];
         const int yi = (t / sp.tiles_x) * ST_TH + r, x = (t % sp.tiles_x) * ST_TW + x4;
         if (yi >= is || x >= is) continue;  // partial tile at the image border (rows are multiples of 4 wide)
@@ -798,6 +819,7 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
     for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
     if (lane == 0) wmax[wave] = mx;
     __syncthreads();  // table zeroed, maxima visible
+    MR_ST_STAMP(2);
     unsigned bm = 0u;
 #pragma unroll
     for (int k = 0; k < ST_WAVES; k++) bm = max(bm, wmax[k]);
@@ -808,21 +830,23 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
     // (beyond ten covered tiles: large rasters, screen-filling meshes) gives up one bit of the 50 per doubling -- at
     // the 256 tiles the list can hold per workgroup that is still 2^-45 of the largest gradient per term.
     const int rem = n_hits - part * ST_WAVES;
-    const long long terms = 3LL * ST_TW * ST_TH * ((rem / (ST_G * ST_WAVES)) * ST_WAVES + min(rem % (ST_G * ST_WAVES), ST_WAVES));
+    const long long terms = 3LL * ST_TW * ST_TH * ((rem / (G * ST_WAVES)) * ST_WAVES + min(rem % (G * ST_WAVES), ST_WAVES));
     int headroom = 0;
     while ((terms >> headroom) >= (1LL << (63 - SV_FIX_BITS))) headroom++;
     const int shift = SV_FIX_BITS - headroom - ((int)(bm >> 23) - 126);
     float* out = p.grad_vcolors + (int64_t)b * p.V * 3;
 
     // pass 2
-    for (int h = part * ST_WAVES + wave; h < n_hits; h += ST_G * ST_WAVES) {
+    for (int h = part * ST_WAVES + wave; h < n_hits; h += G * ST_WAVES) {
         const int t = hits[h];
         const int yi = (t / sp.tiles_x) * ST_TH + r, x = (t % sp.tiles_x) * ST_TW + x4;
         const bool inside = yi < is && x < is;
         int4 f4 = make_int4(-1, -1, -1, -1);
         if (inside) f4 = *reinterpret_cast<const int4*>(fim_b + (int64_t)yi * is + x);
         const int fn[4] = {f4.x, f4.y, f4.z, f4.w};
-        if (__ballot(fn[0] >= 0 || fn[1] >= 0 || fn[2] >= 0 || fn[3] >= 0) == 0ull) continue;
+        // (a tile the coverage bytes name holds a covered pixel, and the wave IS the tile: testing here would only put
+        // the face-index round trip in front of all the other loads; without coverage bytes every tile is walked)
+        if (!sp.tile_hit && __ballot(fn[0] >= 0 || fn[1] >= 0 || fn[2] >= 0 || fn[3] >= 0) == 0ull) continue;
         float g[4][3], w[4][3], zp[4], vz[4][3];
         int vid[4][3];
 #pragma unroll
@@ -896,26 +920,28 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
                     if (FLOWGRAD && ch == 2) continue;  // the third plane's gradient is identically zero
                     const float v = val[k * 3 + ch];
                     // (records name the vertex behind tap k themselves; else: the texel layout table)
-                    const int cell = (REC ? vid[j][k]
-                                          : sel3(vid[j][0], vid[j][1], vid[j][2], texel_vertex(p.texel, k, fn[j] >= p.F0))) * 3 + ch;
+                    const int vtx = REC ? vid[j][k] : sel3(vid[j][0], vid[j][1], vid[j][2], texel_vertex(p.texel, k, fn[j] >= p.F0));
+                    const int cell = vtx * NCH + ch;
                     if (finite) {
                         const long long q = (long long)ldexp((double)v, shift);
                         if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&vtab[cell]), (unsigned long long)q);
                     } else if (v != 0.0f) {
-                        atomicAdd(&out[cell], v);
+                        atomicAdd(&out[vtx * 3 + ch], v);
                     }
                 }
         }
     }
     if (!finite) return;  // block-uniform
     __syncthreads();
-    for (int k = threadIdx.x; k < p.V * 3; k += blockDim.x) {
+    MR_ST_STAMP(3);
+    for (int k = threadIdx.x; k < p.V * NCH; k += blockDim.x) {
         const long long tsum = vtab[k];
         if (tsum != 0) {
             const float v = (float)ldexp((double)tsum, -shift);
-            if (v != 0.0f) atomicAdd(&out[k], v);
+            if (v != 0.0f) atomicAdd(&out[(k / NCH) * 3 + k % NCH], v);
         }
     }
+    MR_ST_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1876,7 +1902,8 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
                                        const float* mask_x_lo, const float* mask_x_hi, int split, const float* occl,
                                        int height, int width, float* grad_vcolors, int batch_size, int num_verts,
                                        int num_faces, int fill_back, int image_size, float eps, int flags,
-                                       const int32_t* vertex_id_map, int texel_layout, mr_stream_t stream) {
+                                       const int32_t* vertex_id_map, int texel_layout, const float* grad_bound,
+                                       mr_stream_t stream) {
     if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || !texel_layout_ok(texel_layout)) return MR_ERR_BADARG;
     if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
     if (batch_size == 0 || num_verts == 0) return MR_OK;
@@ -1892,7 +1919,7 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
     if (num_faces == 0) return MR_OK;
     if (!face_index_map || !weight_map || !(eps >= 1e-6f)) return MR_ERR_BADARG;
     if (!vertex_id_map && (!verts || !faces_idx || !depth_img)) return MR_ERR_BADARG;
-    const int64_t table_bytes = (((int64_t)num_verts * 3 + 1) / 2) * 16;
+    const int64_t table_bytes = (((int64_t)num_verts * (flowgrad ? 2 : 3) + 1) / 2) * 16;
     // the tile walk reads 4-pixel groups with 16-byte loads and keeps the colour table in LDS
     if (image_size % 4 != 0 || table_bytes > SV_MAX_TABLE_BYTES ||
         (int64_t)((image_size + ST_TW - 1) / ST_TW) * ((image_size + ST_TH - 1) / ST_TH) > ST_MAX_TILES)
@@ -1904,7 +1931,10 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
     sp.grad_flow = grad_flow; sp.m_pre = mask_pre; sp.m_x_lo = mask_x_lo; sp.m_x_hi = mask_x_hi; sp.occl = occl;
     sp.split = split; sp.H = height; sp.W = width;
     sp.tiles_x = (image_size + ST_TW - 1) / ST_TW; sp.tiles_y = (image_size + ST_TH - 1) / ST_TH;
-    const int64_t blocks = (int64_t)batch_size * ST_G;
+    sp.grad_bound = flowgrad ? grad_bound : nullptr;
+    sp.groups = ST_G;
+    switch ((flags >> 12) & 7) { case 1: sp.groups = 2; break; case 2: sp.groups = 4; break; case 3: sp.groups = 16; break; case 4: sp.groups = 32; break; default: break; }
+    const int64_t blocks = (int64_t)batch_size * sp.groups;
     if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
     auto kernel = vertex_id_map ? (flowgrad ? scatter_tiles_kernel<true, true> : scatter_tiles_kernel<false, true>)
                                 : (flowgrad ? scatter_tiles_kernel<true, false> : scatter_tiles_kernel<false, false>);
@@ -1912,3 +1942,9 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
+
+#ifdef MR_WG_TIMELINE
+extern "C" __attribute__((visibility("default"))) int mr_debug_st_times(void* dst, long n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mr::mr_dbg_st), n, 0, hipMemcpyDeviceToHost);
+}
+#endif

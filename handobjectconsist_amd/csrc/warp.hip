@@ -804,6 +804,7 @@ struct PairBwdParams {
     const uint8_t* hit12;  // see PairParams
     const uint8_t* hit21;
     int hit_is, hit_tiles_x, hit_stride;
+    unsigned* grad_max;    // nullable: [2B] float bits, zero on entry: max |grad_flow12[b]| at [b], |grad_flow21[b]| at [B + b]
 };
 
 __device__ __forceinline__ float2 pair_grad(const DirTaps& d, const DirRaw& r, const DirOut& o, int H, int W,
@@ -832,8 +833,10 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
     const unsigned lid0 = xcd_remap(blockIdx.x, gridDim.x) * PT_SUB;
 #pragma unroll 1
     for (unsigned lid = lid0; lid < min(lid0 + PT_SUB, total); lid++) {
+    unsigned u12 = 0u, u21 = 0u;  // |gradient| of this thread's pixel as float bits (NaN > Inf > finite: a plain unsigned max)
+    [&] {
     int b, tile, xx, yy;
-    if (!pair_tile_pixel(lid, p.H, p.W, p.tiles_x, p.ntiles, b, tile, xx, yy)) continue;
+    if (!pair_tile_pixel(lid, p.H, p.W, p.tiles_x, p.ntiles, b, tile, xx, yy)) return;
     const int64_t pix = (int64_t)yy * p.W + xx;
     if (p.hit12 && p.hit21 &&
         !pair_block_covered(p.hit12, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W) &&
@@ -841,7 +844,7 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
         // nothing rendered under this block in either frame: zero gradient, nothing read
         *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = make_float2(0.0f, 0.0f);
         *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = make_float2(0.0f, 0.0f);
-        continue;
+        return;
     }
     const float c1 = p.sums[b * 4 + 1], c2 = p.sums[b * 4 + 3];
     const float coef1 = p.grad_loss_fwd[b] / ((c1 == 0.0f) ? 1.0f : c1);
@@ -872,6 +875,25 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
     }
     *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = g21;
     *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = g12;
+    u12 = max(__float_as_uint(g12.x) & 0x7fffffffu, __float_as_uint(g12.y) & 0x7fffffffu);
+    u21 = max(__float_as_uint(g21.x) & 0x7fffffffu, __float_as_uint(g21.y) & 0x7fffffffu);
+    }();
+    // the largest |gradient| per image and direction, for the consumer of these gradients that scales them into fixed
+    // point (mr_render_flow_backward's grad_bound: it saves that kernel a pass over its inputs).  Wave maximum at a
+    // converged point, then one atomic per wave and direction -- and only while it still raises the stored value
+    // (nine tenths of a rendered frame's pixels have a zero gradient).
+    if (p.grad_max && __ballot((u12 | u21) != 0u) != 0ull) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            u12 = max(u12, (unsigned)__shfl_xor((int)u12, off));
+            u21 = max(u21, (unsigned)__shfl_xor((int)u21, off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned b = lid / (unsigned)p.ntiles;
+            if (u12 > p.grad_max[b]) atomicMax(&p.grad_max[b], u12);
+            if (u21 > p.grad_max[p.B + b]) atomicMax(&p.grad_max[p.B + b], u21);
+        }
+    }
     }
 }
 
@@ -991,7 +1013,7 @@ extern "C" int mr_pair_consist_backward(const float* flow12, const float* flow21
                                         const float* grad_loss_bwd, float* grad_flow12, float* grad_flow21,
                                         int batch_size, int height, int width, float thresh,
                                         const uint8_t* tile_hit12, const uint8_t* tile_hit21, int hit_image_size,
-                                        mr_stream_t stream) {
+                                        float* grad_max, mr_stream_t stream) {
     if (!flow12 || !flow21 || !image_ref || !image || !jitter_ref || !jitter || !sums || !grad_loss_fwd ||
         !grad_flow12 || !grad_flow21)
         return MR_ERR_BADARG;
@@ -1006,7 +1028,7 @@ extern "C" int mr_pair_consist_backward(const float* flow12, const float* flow21
     PairBwdParams p{flow12, flow21, image_ref, image, jitter_ref, jitter, jitter_channels, sums,
                     grad_loss_fwd, grad_loss_bwd, grad_flow12, grad_flow21, batch_size, height, width, nblk,
                     tiles_x, thresh, tile_hit12, tile_hit21, hit_image_size, (hit_image_size + 31) / 32,
-                    ((hit_image_size + 31) / 32) * ((hit_image_size + 7) / 8) * 4};
+                    ((hit_image_size + 31) / 32) * ((hit_image_size + 7) / 8) * 4, reinterpret_cast<unsigned*>(grad_max)};
     hipLaunchKernelGGL(pair_consist_backward_kernel, dim3((unsigned)((nblk * batch_size + PT_SUB - 1) / PT_SUB)), dim3(256), 0,
                        (hipStream_t)stream, p);
     MR_CHECK_LAUNCH();

@@ -96,6 +96,11 @@ def warp(x, flow, thresh=0.99999, mode="bilinear"):
     return _WarpFunction.apply(x, flow, thresh, 0 if mode == "bilinear" else 1)
 
 
+# the stacked pair loss hands the per-image maximum of its flow gradients to the raster backward (mr_render_flow_backward's
+# grad_bound); False: that kernel finds its scale itself
+PASS_GRADIENT_BOUND = True
+
+
 class _PairConsistFunction(torch.autograd.Function):
     """Fused both-direction masked-L1 photometric loss.  Differentiable w.r.t. the two
     flows only (the images / jitter masks are data on the training path)."""
@@ -167,17 +172,24 @@ class _PairConsistFunction(torch.autograd.Function):
             g_fwd = torch.zeros((B,), dtype=torch.float32, device=dev)
         g_fwd = _lib.contig(g_fwd)
         g_bwd = _lib.contig(g_bwd) if g_bwd is not None else None
+        gmax = None
         if ctx.stacked:  # one gradient tensor for the stacked flows: no slice / cat nodes in autograd
             grad_both = torch.empty((2 * B, H, W, 2), dtype=torch.float32, device=dev)
             grad12, grad21 = grad_both[:B], grad_both[B:]
+            # the kernel also leaves the largest |gradient| per image of the stack: the next consumer of these
+            # gradients on the training path (the raster backward) needs it as its fixed-point scale and would
+            # otherwise make a pass over its inputs to find it
+            gmax = torch.zeros((2 * B,), dtype=torch.float32, device=dev) if PASS_GRADIENT_BOUND else None
         else:
             grad12 = torch.empty_like(f12)
             grad21 = torch.empty_like(f21)
         _lib.call("mr_pair_consist_backward", _lib.ptr(f12), _lib.ptr(f21), _lib.ptr(im_ref), _lib.ptr(im),
                   _lib.ptr(jm_ref), _lib.ptr(jm), int(jm.shape[1]), _lib.ptr(sums), _lib.ptr(g_fwd),
                   _lib.ptr(g_bwd), _lib.ptr(grad12), _lib.ptr(grad21), B, H, W, ctx.thresh, _lib.ptr(hit12), _lib.ptr(hit21),
-                  cov_size if hit12 is not None else 0, _lib.stream_ptr(dev))
+                  cov_size if hit12 is not None else 0, _lib.ptr(gmax), _lib.stream_ptr(dev))
         if ctx.stacked:
+            if gmax is not None:  # (rides on the gradient tensor, tied to its version like the coverage bytes of the flows)
+                grad_both._hoc_grad_bound = (gmax, grad_both._version)
             return (grad_both,) + (None,) * 9
         return (grad12, grad21) + (None,) * 8
 

@@ -375,6 +375,10 @@ class _StackedFlowFunction(torch.autograd.Function):
         B2, V = verts.shape[:2]
         B = B2 // 2
         g = _lib.contig(grad_flow)
+        # an upper bound of |grad_flow| per image, if the producer of the gradient left one (the stacked pair loss does)
+        note = getattr(grad_flow, "_hoc_grad_bound", None)
+        bound = note[0] if (note is not None and g is grad_flow and note[1] == grad_flow._version
+                            and tuple(note[0].shape) == (B2,) and note[0].device == g.device) else None
         grad_cols, ctx.grad_buf = ctx.grad_buf, None
         zeroed = grad_cols is not None
         if not zeroed:
@@ -382,7 +386,8 @@ class _StackedFlowFunction(torch.autograd.Function):
         _lib.call("mr_render_flow_backward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(wmap),
                   _lib.ptr(depth), None, _lib.ptr(g), _lib.ptr(mask), _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), B,
                   _lib.ptr(occl), height, width, _lib.ptr(grad_cols), B2, V, int(fidx.shape[1]), int(fill_back), is_, eps,
-                  _lib.FLAG_OUTPUT_ZEROED if zeroed else 0, _lib.ptr(vid), textutils.texel_layout_code(), _lib.stream_ptr(verts.device))
+                  _lib.FLAG_OUTPUT_ZEROED if zeroed else 0, _lib.ptr(vid), textutils.texel_layout_code(), _lib.ptr(bound),
+                  _lib.stream_ptr(verts.device))
         return (None, None, grad_cols) + (None,) * 9
 
 

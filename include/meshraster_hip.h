@@ -260,6 +260,10 @@ MR_API int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, 
  * vertex_id_map: as written by mr_render_flow_forward together with the sampling weights in weight_map, or NULL
  * (weight_map then holds barycentrics and verts / faces_idx / depth_img are read instead; with the records given those
  * three may be NULL, and texel_layout is not consulted: the records already name the vertices behind the colour taps).
+ * grad_bound (nullable; flow-space gradient only): [B] floats, per image an upper bound of |grad_flow| -- e.g. the
+ * grad_max mr_pair_consist_backward wrote.  The kernel scales the products into 64-bit fixed point by its workgroup's
+ * largest |gradient|; given a bound it does not have to find that maximum in a first pass over its inputs (the masks only
+ * shrink the gradient, so any bound of |grad_flow| holds; a bound 2^k too large costs k of the 50 fraction bits).
  * Needs image_size to be a multiple of 4 with at most 4096 tiles, and the [V,3] table to fit LDS (V <= 2560);
  * MR_ERR_NOTIMPL otherwise
  * (callers then use mr_flow_finalize_backward + mr_render_vc_backward). */
@@ -269,7 +273,8 @@ MR_API int mr_render_flow_backward(const float* verts, const int32_t* faces_idx,
                                    const float* mask_x_lo, const float* mask_x_hi, int split, const float* occl,
                                    int height, int width, float* grad_vcolors, int batch_size, int num_verts,
                                    int num_faces, int fill_back, int image_size, float eps, int flags,
-                                   const int32_t* vertex_id_map, int texel_layout, mr_stream_t stream);
+                                   const int32_t* vertex_id_map, int texel_layout, const float* grad_bound,
+                                   mr_stream_t stream);
 
 /* Per-vertex front end of get_opticalflow in its training setting (SURVEY 8f "f1"): for the two
  * frames of a pair, in one launch
@@ -446,14 +451,16 @@ MR_API int mr_pair_consist_forward(const float* flow12, const float* flow21, con
 
 /* Adjoint of the pair loss w.r.t. the two flows (the only differentiable inputs on the
  * training path): grad_flow12/21[B,H,W,2] fully written (zeros where the coverage bytes say so).  grad_loss_fwd/bwd[B] are the
- * incoming gradients of loss_fwd / loss_bwd (grad_loss_bwd may be NULL). */
+ * incoming gradients of loss_fwd / loss_bwd (grad_loss_bwd may be NULL).
+ * grad_max (nullable): [2 B] floats, ZERO on entry; on return [b] holds max |grad_flow12[b]| and [B + b] max
+ * |grad_flow21[b]| (NaN / Inf if any) -- the grad_bound mr_render_flow_backward accepts for the stacked flows. */
 MR_API int mr_pair_consist_backward(const float* flow12, const float* flow21, const float* image_ref,
                              const float* image, const float* jitter_ref, const float* jitter,
                              int jitter_channels, const float* sums,
                              const float* grad_loss_fwd, const float* grad_loss_bwd,
                              float* grad_flow12, float* grad_flow21, int batch_size,
                              int height, int width, float thresh, const uint8_t* tile_hit12,
-                             const uint8_t* tile_hit21, int hit_image_size, mr_stream_t stream);
+                             const uint8_t* tile_hit21, int hit_image_size, float* grad_max, mr_stream_t stream);
 
 /* ---- dataset pipeline: decoded frames -> network-input batch ------------------------------
  * One launch for a whole batch of what meshreg/datasets/handobjset.py:361-379 does per sample on the

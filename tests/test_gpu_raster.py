@@ -229,7 +229,7 @@ def test_flow_pixel_records_equal_stored_maps(cuda, B, is_, sparse):
             out = torch.full((B, V, 3), float("nan"), **f32)
             _lib.call("mr_render_flow_backward", None if rec else P(d["v"]), None if rec else P(d["fidx"]), P(fim), P(hit), P(wmap),
                       None if rec else P(depth), None if flowgrad else P(g_rgb), P(gf), P(m_pre), P(m_x), None, B, P(occl), is_, is_,
-                      P(out), B, V, F0, 1, is_, 1e-3, 0, P(vid) if rec else None, 0, st)
+                      P(out), B, V, F0, 1, is_, 1e-3, 0, P(vid) if rec else None, 0, None, st)
             grads.append(out)
         outs[rec] = (rgb, fim, hit, grads, vid, wmap)
     covered = outs[True][1] >= 0
@@ -326,7 +326,7 @@ def test_flow_forward_clears_the_backwards_output_buffer(cuda):
     ref = torch.full((B, V, 3), float("nan"), **f32)
     for out, flags in ((ref, 0), (gbuf, _lib.FLAG_OUTPUT_ZEROED)):
         _lib.call("mr_render_flow_backward", None, None, P(fim), P(hit), P(wmap), None, P(g_rgb), None, None, None, None, B, None,
-                  is_, is_, P(out), B, V, F0, 1, is_, 1e-3, flags, P(vid), 0, st)
+                  is_, is_, P(out), B, V, F0, 1, is_, 1e-3, flags, P(vid), 0, None, st)
     assert float(ref.abs().sum()) > 0
     assert_close(gbuf.cpu().numpy(), ref.cpu().numpy(), 1e-5, 1e-6 * float(ref.abs().max()), "gradient in the pre-cleared buffer")
 
@@ -674,7 +674,7 @@ def _vc_backward(d, g_rgb_img, mode):
             hit = cov.reshape(B, ty, 4, 2, tx, 32).permute(0, 1, 4, 2, 3, 5).reshape(B, ty, tx, 4, 64).any(-1).to(torch.uint8).contiguous()
         _lib.call("mr_render_flow_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), P(hit), P(d["wmap"]), P(d["depth"]),
                   P(g_rgb_img), None, None, None, None, 0, None, 0, 0, P(out), d["B"], d["V"], d["F0"], 1, d["is_"], 1e-3, 0,
-                  None, 0, _lib.stream_ptr(g_rgb_img.device))
+                  None, 0, None, _lib.stream_ptr(g_rgb_img.device))
         return out.cpu().numpy()
     stored = mode == "stored"
     _lib.call("mr_render_vc_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), P(d["wmap"]) if stored else None,
@@ -782,7 +782,7 @@ def test_flow_backward_flow_space_gradient(cuda, B, is_, H, W):
     ref = _vc_backward(d, grad_rgb, "stored")
     out = torch.full((B2, d["V"], 3), float("nan"), dtype=torch.float32, device=cuda)
     _lib.call("mr_render_flow_backward", P(d["v"]), P(d["fidx"]), P(d["fim"]), None, P(d["wmap"]), P(d["depth"]), None,
-              P(gf), P(m_pre), P(m_lo), P(m_hi), B, P(occl), H, W, P(out), B2, d["V"], d["F0"], 1, is_, 1e-3, 0, None, 0, st)
+              P(gf), P(m_pre), P(m_lo), P(m_hi), B, P(occl), H, W, P(out), B2, d["V"], d["F0"], 1, is_, 1e-3, 0, None, 0, None, st)
     got = out.cpu().numpy()
     assert np.abs(ref).max() > 0 and (got[:, :, 2] == 0).all()
     assert_close(got, ref, 1e-5, 1e-6 * np.abs(ref).max(), "flow-space gradient form")

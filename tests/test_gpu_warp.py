@@ -513,6 +513,65 @@ def test_pair_loss_with_coverage_bytes_equals_dense(cuda, B, is_, H, Wd):
     assert imgflowarp._coverage_of(base) == (None, 0)
 
 
+def test_gradient_bound_travels_from_the_pair_loss_to_the_raster_backward(cuda):
+    """mr_pair_consist_backward's grad_max = the per-image maxima of |grad_flow| (bit-exact, both directions);
+    mr_render_flow_backward with that bound gives the gradient it finds with its own maximum pass (the bound only sets the
+    fixed-point scale); and get_opticalflow -> pair_consist -> backward hands the bound over (spied on the C-ABI call)."""
+    from handobjectconsist_amd import _lib
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import imgflowarp, opticalflow
+
+    B, is_ = 3, 96
+    s = synth.random_scene(B, seed=8, image_size=is_)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda), K=torch.ones(1, 3, 3, device=cuda),
+                   orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1, no_light=True)
+    im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, is_, is_, 2)]
+    crit = PyramidCriterion("l1")
+    res = {}
+    for handed in (True, False):
+        imgflowarp.PASS_GRADIENT_BOUND = handed
+        calls = []
+        real = _lib.call
+        spy = lambda name, *a: (calls.append((name, a)), real(name, *a))[1]
+        imgflowarp._lib.call = opticalflow._lib.call = spy
+        try:
+            v1 = t(s["verts1"], cuda).requires_grad_(True)
+            flows = opticalflow.get_opticalflow([v1, t(s["verts2"], cuda)], t(s["faces"], cuda), [t(s["K1"], cuda), t(s["K2"], cuda)], ren,
+                                                orig_img_size=(is_, is_), ignore_face_idxs=synth.HAND_IGNORE_FACES)
+            flows[0].retain_grad() if False else None
+            loss = imgflowarp.pair_consist(flows, im_ref, im, jm_ref, jm, crit, use_backward=True, outputs="loss")[0]
+            loss.sum().backward()
+        finally:
+            imgflowarp._lib.call = opticalflow._lib.call = real
+            imgflowarp.PASS_GRADIENT_BOUND = True
+        pair_args = [a for n_, a in calls if n_ == "mr_pair_consist_backward"][0]
+        flow_args = [a for n_, a in calls if n_ == "mr_render_flow_backward"][0]
+        assert bool(pair_args[-2].value if pair_args[-2] is not None else 0) == handed, "grad_max pointer of the pair backward"
+        assert bool(flow_args[-2].value if flow_args[-2] is not None else 0) == handed, "grad_bound pointer of the raster backward"
+        res[handed] = v1.grad.clone()
+    assert float(res[True].abs().sum()) > 0
+    close(res[True].cpu().numpy(), res[False].cpu().numpy(), 1e-5, 1e-6 * float(res[False].abs().max()), "gradient with the handed-over bound")
+
+    # the maxima themselves
+    g = torch.Generator().manual_seed(3)
+    f12 = ((torch.rand(B, is_, is_, 2, generator=g) - 0.5) * 6).to(cuda) * (torch.rand(B, is_, is_, 1, generator=g) < 0.4).to(cuda)
+    f21 = ((torch.rand(B, is_, is_, 2, generator=g) - 0.5) * 6).to(cuda) * (torch.rand(B, is_, is_, 1, generator=g) < 0.4).to(cuda)
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    f32 = dict(dtype=torch.float32, device=cuda)
+    wbytes = int(_lib.load().mr_pair_consist_workspace_bytes(B, is_, is_))
+    work, sums = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=cuda), torch.empty((B, 4), **f32)
+    lf, lb = torch.empty((B,), **f32), torch.empty((B,), **f32)
+    _lib.call("mr_pair_consist_forward", P(f12), P(f21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(work), wbytes, P(sums), P(lf), P(lb),
+              *([None] * 8), B, is_, is_, 0.99999, None, None, 0, st)
+    gl = torch.tensor([1.0, -2.5, 0.3], **f32)
+    g12, g21, gmax = torch.empty_like(f12), torch.empty_like(f21), torch.zeros(2 * B, **f32)
+    _lib.call("mr_pair_consist_backward", P(f12), P(f21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(sums), P(gl), P(gl), P(g12), P(g21),
+              B, is_, is_, 0.99999, None, None, 0, P(gmax), st)
+    want = torch.cat([g12.abs().amax((1, 2, 3)), g21.abs().amax((1, 2, 3))])
+    assert float(want.max()) > 0 and torch.equal(gmax, want), (gmax, want)
+
+
 @pytest.mark.parametrize("B,is_,H,W", [(2, 64, 64, 64), (3, 96, 54, 96), (1, 40, 27, 33)])
 def test_occlusion_flow_equals_occlusion_then_finalize(cuda, B, is_, H, W):
     """mr_occlusion_flow == mr_occlusion_mask followed by mr_flow_finalize_forward for both directions (SURVEY Q4
