@@ -28,6 +28,9 @@ def render(verts, faces, input_res, camintrs=None, colors=None, fill_back=True, 
         width, height = input_res[0], input_res[1]
         rgb, alpha = rgb[:, :, :height, :width], alpha[:, :height, :width]
     if bg_color is not None:
+        # (fastrender.py:57 multiplies [B,3,H,W] by [B,H,W]: that broadcasts for B = 1 only -- B = 2 raises, B = 3 would
+        # take the alpha of SAMPLE c for channel c.  Per-sample alpha here: a conscious fix, equal to the reference
+        # wherever it runs; tests/test_gpu_chain.py::test_fastrender_render_against_the_reference)
         a = alpha.unsqueeze(1)
         rgb = rgb * a + bg_color * (1 - a) * torch.ones_like(rgb)
     return torch.cat([rgb, alpha.unsqueeze(1)], 1).permute(0, 2, 3, 1)

@@ -495,8 +495,55 @@ def gen_warpbranch():
     save("chain_warpbranch.npz", arrays, meta)
 
 
+# ---------------------------------------------------------------------------------------------------
+# 5. fastrender.render (visualisation path, SURVEY 8f "f3")
+# ---------------------------------------------------------------------------------------------------
+
+
+def gen_fastrender():
+    """meshreg/neurender/fastrender.py:14-59 run from the reference: the lit RGBA render of a posed mesh (ambient 0.8 +
+    the renderer's default directional light), crop to the frame, optional background compositing.  Beside the stubs of
+    oracle/ref_glue.py the module-level imports of that file need manopth (manoutils) and the figure helpers of
+    meshreg.visualize -- none of them is touched by ``render``.  Its compositing line multiplies [B,3,H,W] by
+    [B,H,W]: that broadcasts only for B = 1 (and, wrongly, for B = 3: channel c gets the alpha of SAMPLE c); recorded
+    here: B = 1 with a background, B = 2 without, and that B = 2 with a background raises."""
+    import types
+
+    for name in ("manopth", "manopth.manolayer", "meshreg.visualize", "meshreg.visualize.consistdisplay",
+                 "meshreg.visualize.rotateverts", "meshreg.visualize.samplevis"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["manopth.manolayer"].ManoLayer = object
+    sys.modules["manopth"].manolayer = sys.modules["manopth.manolayer"]
+    for sub in ("consistdisplay", "rotateverts", "samplevis"):
+        setattr(sys.modules["meshreg.visualize"], sub, sys.modules["meshreg.visualize." + sub])
+    from meshreg.neurender import fastrender
+
+    rng = np.random.default_rng(15)
+    arrays, meta = {}, []
+    for key, B, res, bg, crop in (("b1_bg", 1, (40, 28), 0.25, True), ("b2", 2, (36, 36), None, True),
+                                  ("b2_nocrop", 2, (40, 24), None, False)):
+        side = max(res)
+        sc = scene(rng, B, side, hand_subdiv=1, obj_subdiv=0)
+        verts = np.concatenate([sc["hand1"], sc["obj1"]], 1)
+        faces = np.concatenate([sc["hand_faces"], sc["obj_faces"] + sc["hand1"].shape[1]], 0)[None].repeat(B, 0)
+        colors = rng.uniform(0, 1, (B, verts.shape[1], 4)).astype(np.float32)  # (a fourth column: render takes [:, :, :3])
+        out = fastrender.render(T(verts), T(faces), res, camintrs=T(sc["K1"]), colors=T(colors), bg_color=bg, crop_to_img=crop)
+        arrays.update({f"{key}_verts": verts, f"{key}_faces": faces, f"{key}_K": sc["K1"], f"{key}_colors": colors,
+                       f"{key}_out": N(out)})
+        meta.append(dict(key=key, input_res=list(res), bg_color=bg, crop_to_img=crop, batch=B))
+        print(key, tuple(out.shape), "covered", float((out[..., 3] > 0).float().mean()))
+    raised = False
+    try:
+        fastrender.render(T(verts), T(faces), res, camintrs=T(sc["K1"]), colors=T(colors), bg_color=0.5)
+    except RuntimeError:
+        raised = True
+    meta.append(dict(key="b2_bg_raises_in_the_reference", value=raised))
+    print("B = 2 with bg_color raises in the reference:", raised)
+    save("chain_fastrender.npz", arrays, meta)
+
+
 if __name__ == "__main__":
-    gens = dict(rasterize=gen_rasterize, renderer=gen_renderer, opticalflow=gen_opticalflow,
+    gens = dict(fastrender=gen_fastrender, rasterize=gen_rasterize, renderer=gen_renderer, opticalflow=gen_opticalflow,
                 opticalflow_cfg=gen_opticalflow_config_sizes, warpbranch=gen_warpbranch)
     for name in (sys.argv[1:] or list(gens)):  # (every generator seeds its own rng: any subset reproduces its file)
         gens[name]()

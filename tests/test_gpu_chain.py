@@ -463,3 +463,38 @@ def test_warpbranch_forward_against_reference_glue(cuda, keys):
                     assert norm_rel(got, want) < 1e-4, (k, f, name, norm_rel(got, want))
                 else:
                     assert l2_rel(got, want) < 5e-2, (k, f, name, l2_rel(got, want))
+
+
+def test_fastrender_render_against_the_reference(cuda):
+    """meshreg/neurender/fastrender.py:14-59 run from the reference (tests/golden/make_golden_chain.py fastrender): lit RGBA
+    render, crop / no crop, background compositing.  The reference's compositing line multiplies [B,3,H,W] by [B,H,W],
+    which only broadcasts for B = 1 (the fixture records that B = 2 raises there; B = 3 would silently take the alpha of
+    sample c for channel c): the mirror composites per sample -- a conscious fix, equal to the reference where it works."""
+    from handobjectconsist_amd.neurender import fastrender
+
+    z, meta = load("chain_fastrender.npz")
+    ran = 0
+    for m in meta:
+        k = m["key"]
+        if k == "b2_bg_raises_in_the_reference":
+            assert m["value"] is True
+            continue
+        out = fastrender.render(t(z[f"{k}_verts"], cuda), t(z[f"{k}_faces"], cuda), tuple(m["input_res"]), camintrs=t(z[f"{k}_K"], cuda),
+                                colors=t(z[f"{k}_colors"], cuda), bg_color=m["bg_color"], crop_to_img=m["crop_to_img"])
+        want = z[f"{k}_out"]
+        assert tuple(out.shape) == want.shape, (k, out.shape, want.shape)
+        got = n(out)
+        support = (got[..., 3] > 0) != (want[..., 3] > 0)
+        assert int(support.sum()) <= 2, (k, int(support.sum()))  # (independent projections: README caveat)
+        assert np.abs((got - want) * ~support[..., None]).max() <= 2e-4, (k, np.abs((got - want) * ~support[..., None]).max())
+        ran += 1
+    assert ran == 3
+    # the per-sample compositing where the reference cannot run: alpha of sample b, for every channel of sample b
+    k = "b2"
+    m = [x for x in meta if x["key"] == k][0]
+    plain = fastrender.render(t(z[f"{k}_verts"], cuda), t(z[f"{k}_faces"], cuda), tuple(m["input_res"]), camintrs=t(z[f"{k}_K"], cuda),
+                              colors=t(z[f"{k}_colors"], cuda))
+    comp = fastrender.render(t(z[f"{k}_verts"], cuda), t(z[f"{k}_faces"], cuda), tuple(m["input_res"]), camintrs=t(z[f"{k}_K"], cuda),
+                             colors=t(z[f"{k}_colors"], cuda), bg_color=0.5)
+    a = plain[..., 3:4]
+    assert torch.allclose(comp[..., :3], plain[..., :3] * a + 0.5 * (1 - a), atol=1e-6) and torch.equal(comp[..., 3], plain[..., 3])
