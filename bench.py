@@ -550,6 +550,8 @@ def main():
     assert _lib.load().mr_device_ok() == 1, "libmeshraster_hip.so: no gfx950 device"
     if args.kernels_only or args.roofline_only:
         only = (ROOF_BWD, ROOF_FWD) if args.roofline_only else None
+        if os.environ.get("HOC_KERNEL_GROUPS"):  # profiling aid: comma-separated group names (kernel_bench's list)
+            only = tuple(os.environ["HOC_KERNEL_GROUPS"].split(","))
         os.write(real_stdout, (json.dumps(kernel_bench(dev, args.batch, args.image_size, args.kernel_iters, only), indent=1) + "\n").encode())
         return
     torch.manual_seed(rank)

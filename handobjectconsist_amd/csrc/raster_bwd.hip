@@ -20,10 +20,11 @@
 //     variants (per-pixel atomics on stored or recomputed sampling weights) behind the five-entry-point API.
 //   * pixel_map_kernel<IMG> -- kernel D as upstream walks it, one wave per face, reading the eight
 //     planes in place (reference algorithm; no workspace needed).
-//   * pixel_pack_kernel + pixel_map_packed_kernel -- kernel D on packed row- and column-major records
-//     with item-parallel headers (the default when a workspace is given; see the comment there).
+//   * pixel_map_strip_kernel<IMG, L> -- kernel D by strips of image lines staged in LDS, fed by per-image owner
+//     records from compact_owners_kernel (the default when a workspace is given; see the comment there).
 #include "mr_common.hpp"
 #include <algorithm>
+#include <type_traits>
 
 namespace mr {
 
@@ -1045,6 +1046,7 @@ struct PixelMapParams {
     int write_backfacing;  // fused path: also zero the rows of culled faces
     int dbg;               // profiling experiments (flags >> 8)
     float* zero_textures;  // nullable: [B*F, 24] texture-gradient rows, zeroed for the faces that own no pixel
+    int zero_owner_rows;   // compact_owners_kernel: zero the grad_faces rows of the owning faces too (kernel D by strips adds into them)
 };
 
 template <bool IMG>
@@ -1212,93 +1214,9 @@ __global__ void __launch_bounds__(256) pixel_map_kernel(PixelMapParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// D, packed: the same walks on two packed copies of the maps
+// D by strips: helpers
 // ---------------------------------------------------------------------------------------
-// The per-face walks of kernel D sweep whole image columns (axis 0) and rows (axis 1).  Reading
-// eight separate planes with a stride of one image row per lane costs 8 cache lines per lane and
-// sweep step (measured: 2.8 GB of fabric traffic per launch for 311 algorithmic MB).  A pre-pass
-// therefore packs the eight values a sweep step needs -- alpha, d alpha, rgb, d rgb -- into one
-// 32-byte record per pixel and writes the records twice, row-major and column-major, so that
-// BOTH kinds of sweep read 2 KB of contiguous records per wave and step.
-struct PixRec {
-    float4 a;  // alpha, grad_alpha, r, g
-    float4 b;  // b, grad_r, grad_g, grad_b
-};
-
-constexpr int PK_T = 32;  // transpose tile
-
-template <bool IMG>
-__global__ void __launch_bounds__(256) pixel_pack_kernel(PixelMapParams p, PixRec* __restrict__ rec_row,
-                                                         PixRec* __restrict__ rec_col, uint8_t* __restrict__ owns,
-                                                         int tiles) {
-    __shared__ float tile[8][PK_T][PK_T + 1];
-    const int is = p.is;
-    const int b = blockIdx.x / (tiles * tiles);
-    const int t = blockIdx.x % (tiles * tiles);
-    const int x0 = (t % tiles) * PK_T, y0 = (t / tiles) * PK_T;
-    const int tx = threadIdx.x % PK_T, ty8 = threadIdx.x / PK_T;  // 32 x 8 threads, 4 rows each
-#pragma unroll
-    for (int r = 0; r < PK_T / 8; r++) {
-        const int ly = ty8 + r * 8;
-        const int x = x0 + tx, y = y0 + ly;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (x < is && y < is) {
-            if (p.return_alpha) {
-                const int64_t ia = idx1<IMG>(b, y, x, is);
-                v[0] = p.alpha[ia]; v[1] = p.grad_alpha[ia];
-            }
-            if (p.return_rgb) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const int64_t ic = idx3<IMG>(b, y, x, k, is);
-                    v[2 + k] = p.rgb[ic]; v[5 + k] = p.grad_rgb[ic];
-                }
-            }
-            PixRec rr;
-            rr.a = make_float4(v[0], v[1], v[2], v[3]);
-            rr.b = make_float4(v[4], v[5], v[6], v[7]);
-            rec_row[((int64_t)b * is + y) * is + x] = rr;
-            // a face that owns no pixel contributes nothing to D (both sweeps are gated on ownership)
-            const int fn = p.fim[((int64_t)b * is + y) * is + x];
-            if (fn >= 0) owns[(int64_t)b * p.F + fn] = 1;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) tile[k][ly][tx] = v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < PK_T / 8; r++) {
-        const int lx = ty8 + r * 8;      // column of the tile this thread row writes
-        const int x = x0 + lx, y = y0 + tx;  // consecutive threads -> consecutive y
-        if (x < is && y < is) {
-            PixRec rr;
-            rr.a = make_float4(tile[0][tx][lx], tile[1][tx][lx], tile[2][tx][lx], tile[3][tx][lx]);
-            rr.b = make_float4(tile[4][tx][lx], tile[5][tx][lx], tile[6][tx][lx], tile[7][tx][lx]);
-            rec_col[((int64_t)b * is + x) * is + y] = rr;
-        }
-    }
-}
-
-__device__ __forceinline__ float rec_diff_grad(const PixRec& r, float a_ref, const float* rgb_ref, bool ra, bool rr) {
-#pragma clang fp contract(fast)  // fused multiply-adds: D is compared to 1e-4, not bit for bit
-    float d = 0.0f;
-    if (ra) d += (r.a.x - a_ref) * r.a.y;
-    if (rr) {
-        d += (r.a.z - rgb_ref[0]) * r.b.y;
-        d += (r.a.w - rgb_ref[1]) * r.b.z;
-        d += (r.b.x - rgb_ref[2]) * r.b.w;
-    }
-    return d;
-}
-
-// One WAVE per face.  The (edge, axis, column) crossings of the face are enumerated as items;
-// a lane takes an item: crossing, in / out pixels and their records (all items' header loads in
-// flight together instead of one dependent round trip per column), then walks the item's short
-// "in" sweep by itself.  The "out" sweeps (up to the image border) and unusually long "in"
-// sweeps are walked by the whole wave, one item after the other, 64 records per step from the
-// copy that is contiguous along the sweep.  Same arithmetic per term as pixel_map_kernel; only
-// the order of the fp32 additions differs (and the two divisions per term, see pm_term).
-constexpr int PM_LONG = 12;  // "in" sweeps longer than this are walked by the wave
+constexpr int PM_LONG = 12;  // "in" sweeps longer than this are cut into chunk tasks, shorter ones are walked by the lane that found them
 
 // one accepted term of a walk: -dg / (c * (d1 - d1_cross) * 2 / is +- eps), with the two divisions
 // done as multiplications by reciprocals (v_rcp_f32, 1 ulp): the walks evaluate > 10^8 of these per
@@ -1308,24 +1226,7 @@ __device__ __forceinline__ float pm_term(float dg, float c, float fd1, float d1_
     dist = (0 < dist) ? dist + eps : dist - eps;
     return dg * __builtin_amdgcn_rcpf(dist);
 }
-__device__ __forceinline__ float pm_bcast(float v, int src) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-__device__ __forceinline__ int pm_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
-
-// One wave-wide sweep, staged in LDS by the lane that owns the item and read back with a wave-uniform address (three
-// broadcast ds_read_b128 instead of a dozen v_readlane): 48 bytes.
-struct __attribute__((aligned(16))) PmSweep {
-    int info;    // d0 | k << 14 (k = 2 * edge + axis) | own_only << 17 | use0 << 18 | use1 << 19
-    int range;   // d1_from | d1_to << 16
-    float cross, k0;                 // d1_cross; c0 * 2 / is
-    float e0, k1, e1, a_ref;         // +-eps of term 0 ("out" sweeps: constant along the sweep); c1 * 2 / is; +-eps of term 1
-    float r_ref, g_ref, b_ref, pad;
-};
-constexpr int PM_SW_CAP = 2 * MR_WAVE;  // per round of 64 items: an "out" and a long "in" sweep per lane at most
-
-// owns[b * F + face] = 1 for every face that won a pixel (four pixels per thread; kernel D's pack pass does this on
-// the side, launches without D need it on its own)
+// owns[b * F + face] = 1 for every face that won a pixel (four pixels per thread)
 __global__ void __launch_bounds__(256) mark_owners_kernel(const int32_t* __restrict__ fim, uint8_t* __restrict__ owns,
                                                           int64_t npx4, int64_t px_per_image, int F) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1347,41 +1248,124 @@ __global__ void __launch_bounds__(256) mark_owners_scalar_kernel(const int32_t* 
     if (f >= 0) owns[(i / px_per_image) * F + f] = 1;
 }
 
-// The faces that own a pixel (typically a fifth of them), compacted into a list for the walk kernel; the others get
-// their zero rows here.  One workgroup per 4096 faces, ONE global atomic each.
+// the sum of a value over the wave, valid in lane 63: row shifts and the two row broadcasts of the gfx9 DPP unit
+// (six VALU instructions, no LDS crossbar)
+__device__ __forceinline__ float wave_sum_last(float v) {
+    auto step = [](float x, auto ctrl, auto row_mask) {
+        return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false));
+    };
+    v = step(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+    v = step(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+    v = step(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+    v = step(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8 -> lane 15 of a row = the row
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1, 3
+    v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2, 3
+    return v;
+}
+// the maximum of a non-negative value over the wave, valid in lane 63
+__device__ __forceinline__ float wave_max_last(float v) {
+    auto step = [](float x, auto ctrl, auto row_mask) {
+        return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false)));
+    };
+    v = step(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+    v = step(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+    v = step(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+    v = step(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+    v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+    return v;
+}
+
+// The faces that own a pixel (typically a fifth of them), compacted into a list for the gather / the walk kernel; the
+// others get their zero rows here.  One workgroup per image and 4096 faces of it, ONE global atomic each (two with
+// `img_recs`: the front-facing ones once more image by image, [B][F] records of two float4 -- the vertices in pixel
+// coordinates, 0.5 * (v * is + is - 1) as kernel D computes them, and the face number -- with the counts in
+// img_count[b] and the range of lines their crossings can fall on in img_count[B + 4 b ..]: kernel D by strips walks
+// the owners of ONE image and reads nothing else of a face).
 constexpr int CO_TPB = 1024, CO_PER = 4;
 __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p, const uint8_t* __restrict__ owns,
-                                                                unsigned* __restrict__ counter, uint32_t* __restrict__ list) {
-    __shared__ unsigned s_cnt, s_base;
+                                                                unsigned* __restrict__ counter, uint32_t* __restrict__ list,
+                                                                unsigned* __restrict__ img_count, float4* __restrict__ img_recs,
+                                                                int chunks) {
+    __shared__ unsigned s_cnt, s_base, s_icnt, s_ibase, s_range[4];
     __shared__ uint8_t s_own[CO_TPB * CO_PER];
-    const int64_t total = (int64_t)p.B * p.F;
+    const int b = blockIdx.x / chunks, fc0 = (blockIdx.x % chunks) * (CO_TPB * CO_PER);
+    const int nf = min(CO_TPB * CO_PER, p.F - fc0);  // faces of this workgroup
+    const int64_t f0 = (int64_t)b * p.F + fc0;
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) s_cnt = 0u;
+    if (tid == 0) { s_cnt = 0u; s_icnt = 0u; }
+    if (tid < 4) s_range[tid] = 0u;
     __syncthreads();
-    unsigned pos[CO_PER];
-    bool own[CO_PER];
+    unsigned pos[CO_PER], ipos[CO_PER];
+    bool own[CO_PER], iown[CO_PER];
+    float pxy[CO_PER][6];
 #pragma unroll
     for (int k = 0; k < CO_PER; k++) {
-        const int64_t i = (int64_t)blockIdx.x * (CO_TPB * CO_PER) + k * CO_TPB + tid;
-        own[k] = i < total && owns[i] != 0;
+        iown[k] = false; ipos[k] = 0u;
+        const int q = k * CO_TPB + tid;
+        const int64_t i = f0 + q;
+        own[k] = q < nf && owns[i] != 0;
         // bit 0: owns a pixel; bit 1: its grad_faces row is to be zeroed here
-        const bool zero_row = i < total && !own[k] && p.grad_faces && (p.write_backfacing || !backfacing(p.faces + i * 9));
-        s_own[k * CO_TPB + tid] = (own[k] ? 1 : 0) | (zero_row ? 2 : 0);
+        const bool zero_row = q < nf && (!own[k] || p.zero_owner_rows) && p.grad_faces &&
+                              (p.write_backfacing || !backfacing(p.faces + i * 9));
+        s_own[q] = (own[k] ? 1 : 0) | (zero_row ? 2 : 0);
         const unsigned long long m = __ballot(own[k]);
         unsigned wbase = 0u;
         if (lane == 0 && m) wbase = atomicAdd(&s_cnt, (unsigned)__popcll(m));
         pos[k] = (unsigned)__shfl((int)wbase, 0) + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (img_recs) {
+            // the record, and the lines (columns, rows) the crossings of the face can fall on: the union over its edges
+            // of kernel D's d0 ranges, kept per image as {max d0_to + 1, is - min d0_from} per axis (0 = none)
+            const float fis = (float)p.is;
+            float f9[9];
+#pragma unroll
+            for (int c = 0; c < 9; c++) f9[c] = own[k] ? p.faces[i * 9 + c] : 0.0f;
+            iown[k] = own[k] && !backfacing(f9);
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                pxy[k][2 * v] = 0.5f * (f9[3 * v] * fis + fis - 1.0f);
+                pxy[k][2 * v + 1] = 0.5f * (f9[3 * v + 1] * fis + fis - 1.0f);
+            }
+            float hi[2] = {0.0f, 0.0f}, lo[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int axis = 0; axis < 2; axis++) {
+                const float q0 = pxy[k][axis], q1 = pxy[k][2 + axis], q2 = pxy[k][4 + axis];
+                const int from = (int)fmaxf(ceilf(fminf(fminf(q0, q1), q2)), 0.0f);
+                const int to = (int)fminf(fmaxf(fmaxf(q0, q1), q2), fis - 1.0f);
+                if (iown[k] && from <= to) { hi[axis] = (float)(to + 1); lo[axis] = (float)(p.is - from); }
+            }
+            const unsigned long long mi = __ballot(iown[k]);
+            if (mi) {  // (wave-uniform)
+                const float r0 = wave_max_last(hi[0]), r1 = wave_max_last(lo[0]), r2 = wave_max_last(hi[1]), r3 = wave_max_last(lo[1]);
+                unsigned ibase = 0u;
+                if (lane == 63) {
+                    ibase = atomicAdd(&s_icnt, (unsigned)__popcll(mi));
+                    atomicMax(&s_range[0], (unsigned)r0); atomicMax(&s_range[1], (unsigned)r1);
+                    atomicMax(&s_range[2], (unsigned)r2); atomicMax(&s_range[3], (unsigned)r3);
+                }
+                ipos[k] = (unsigned)__shfl((int)ibase, 63) + (unsigned)__popcll(mi & ((1ull << lane) - 1ull));
+            }
+        }
     }
     __syncthreads();
-    if (tid == 0) s_base = atomicAdd(counter, s_cnt);
+    if (tid == 0) {
+        s_base = atomicAdd(counter, s_cnt);
+        if (img_recs) s_ibase = atomicAdd(&img_count[b], s_icnt);
+    }
+    if (img_recs && tid < 4 && s_range[tid]) atomicMax(&img_count[p.B + 4 * b + tid], s_range[tid]);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < CO_PER; k++)
-        if (own[k]) list[s_base + pos[k]] = (uint32_t)((int64_t)blockIdx.x * (CO_TPB * CO_PER) + k * CO_TPB + tid);
-    // the zero rows of the workgroup's faces without pixels (36 bytes of grad_faces, 96 bytes of texture gradient),
-    // consecutive lanes on consecutive addresses
-    const int64_t f0 = (int64_t)blockIdx.x * (CO_TPB * CO_PER);
-    const int nf = (int)min((int64_t)(CO_TPB * CO_PER), total - f0);
+        if (own[k]) {
+            list[s_base + pos[k]] = (uint32_t)(f0 + k * CO_TPB + tid);
+            if (iown[k]) {
+                float4* rec = img_recs + 2 * ((int64_t)b * p.F + s_ibase + ipos[k]);
+                rec[0] = make_float4(pxy[k][0], pxy[k][1], pxy[k][2], pxy[k][3]);
+                rec[1] = make_float4(pxy[k][4], pxy[k][5], __int_as_float(fc0 + k * CO_TPB + tid), 0.0f);
+            }
+        }
+    // the zero rows of the workgroup's faces (36 bytes of grad_faces, 96 bytes of texture gradient), consecutive
+    // lanes on consecutive addresses
     if (p.grad_faces) {
         float* rows = p.grad_faces + f0 * 9;
         for (int q = tid; q < nf * 9; q += CO_TPB)
@@ -1394,250 +1378,408 @@ __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p
     }
 }
 
-__device__ __forceinline__ void pm_walk_face(const PixelMapParams& p, const PixRec* __restrict__ rec_row,
-                                             const PixRec* __restrict__ rec_col, const int64_t i, const int lane,
-                                             PmSweep* sw) {
-    const int is = p.is;
-    const float fis = (float)is;
-    const float two_over_is = 2.0f / fis;
-    const int b = (int)(i / p.F);
-    const int fn = (int)(i % p.F);
-    float face[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) face[k] = p.faces[i * 9 + k];
-    if (backfacing(face)) {
-        if (p.write_backfacing && lane < 9) p.grad_faces[i * 9 + lane] = 0.0f;
-        return;
+// ---------------------------------------------------------------------------------------
+// D by STRIPS: the sweeps read the maps from LDS, every map byte is fetched once per axis
+// ---------------------------------------------------------------------------------------
+// The walks of kernel D are sweeps along image columns (axis 0) and rows (axis 1): 1.5 x 10^8 terms per launch of the
+// bench workload, every term the eight map values of a pixel.  Walking face by face (pixel_map_kernel; rounds 1-2 also
+// on two packed copies of the maps, 2 x 32 B per pixel of workspace and a pack pass in front) re-reads a line once per
+// face that crosses it -- dozens of times -- from L2 or beyond.  Here a workgroup OWNS a strip of L adjacent lines of
+// one image and one axis: it stages the strip's values in LDS once (for axis 0 straight from the planes, L * 4 bytes
+// per image row: the other columns of those cache lines are the neighbouring strips', which run next to it on the same
+// XCD -- all strips of an image do, blockIdx -> (image, strip) below -- so they come from that XCD's L2), lists the
+// (face, edge) pairs of the image's owning faces whose crossings fall into the strip, and runs their sweeps out of LDS.
+//   * owners: compact_owners_kernel leaves, per image, the front-facing owners as records of pixel-space vertices and
+//     the range of lines their crossings can fall on; a strip outside the range returns after one load;
+//   * enumeration: a thread per owner, 256 a round (the records of the first rounds requested before the strip is
+//     staged, all of a workgroup's global loads in flight together), entries (owner | edge | first line | lines - 1)
+//     appended to an LDS queue, flushed when another round might not fit;
+//   * waves take batches of 64 / L entries, one LANE per (entry, line): crossing, "in" / "out" pixels, short "in"
+//     sweep -- the per-item header of upstream's walk, same arithmetic;
+//   * the "out" sweeps and the long "in" sweeps are cut into chunks of 16 positions and handed out one per LANE: the
+//     lane fetches its item's header from the lane that computed it (ds_bpermute) and walks the chunk by itself, its
+//     start rotated so that the 16 lanes of a ds_read_b128 group never share a bank; two positions' values requested
+//     while the previous two are worked on; both distances of a term in packed fp32 and one v_rcp_f32 for the two;
+//   * sums: a workgroup contributes to ONE component (1 - axis) of a face's three vertices: chunk sums meet in LDS
+//     atomics per item, the lines of an entry in a shuffle, one pair of global atomic adds per entry (rows zeroed by
+//     compact_owners_kernel).  Float atomics: the order of the additions across chunks and strips is not fixed -- as
+//     for the texture / depth terms of this backward pass upstream; MR_FLAG_REFERENCE_ALGO keeps the ordered walk.
+// Measured (B = 64, 256 x 256, 3076 faces, MI355X): 310 us + 21 us (owner records) + 6 us (flags), against 425 us
+// + 95 us (pack) + 15 us of the packed per-face walk; ~70 % of it is VALU issue of the 1.5 x 10^8 terms (31
+// instructions a term), the rest the per-strip phases that wait on memory.  Profiling switches (flags >> 8): 1 no
+// chunk tasks, 2 no short "in" sweeps, 4 enumeration only, 8 tasks without their steps.
+#ifdef MR_WG_TIMELINE
+__device__ unsigned long long mr_dbg_ps[8192 * 16];  // profiling builds: phase stamps and counts of the first 8192 strips
+#define MR_PS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) mr_dbg_ps[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define MR_PS_COUNT(k, n) do { if (lane == 0) atomicAdd(&s_dbg[k], (unsigned)(n)); } while (0)
+#else
+#define MR_PS_STAMP(k) do { } while (0)
+#define MR_PS_COUNT(k, n) do { } while (0)
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// sum over the channels of (value - reference) * gradient: v = (alpha, r, g, b), g = their gradients (channels a launch
+// does not render are staged as zeros); two packed subtractions, a packed multiply and a packed fma
+__device__ __forceinline__ float ps_diff_grad(const float4 v, const float4 g, const float4 ref) {
+#pragma clang fp contract(fast)  // D is compared to 1e-4, not bit for bit
+    const f32x2 v0 = {v.x, v.y}, v1 = {v.z, v.w}, r0 = {ref.x, ref.y}, r1 = {ref.z, ref.w};
+    const f32x2 g0 = {g.x, g.y}, g1 = {g.z, g.w};
+    const f32x2 d = (v0 - r0) * g0 + (v1 - r1) * g1;
+    return d.x + d.y;
+}
+constexpr int PS_T = 256;
+constexpr int PS_QCAP = 1024;  // queued entries; a round of PS_T faces adds at most 3 * PS_T
+
+// lines per strip: the most whose records leave room for three workgroups per compute unit; 0 = raster too wide
+static int strip_lines(int is) {
+    for (int L = 4; L >= 1; L >>= 1)
+        if (L * (is + 1) * 36LL <= 37 * 1024) return L;
+    return ((is + 1) * 36LL <= 50 * 1024) ? 1 : 0;  // (one workgroup of 64 KB)
+}
+constexpr int PS_TASKS = 1024;  // chunk tasks of a wave's batch: 64 items, at most 16 chunks each
+static int64_t strip_lds_bytes(int is, int L) {
+    return 2LL * L * (is + 1) * 16 + (((int64_t)L * (is + 1) * 4 + 15) & ~15LL) + PS_QCAP * 4LL +
+           (PS_T / MR_WAVE) * (PS_TASKS * 2LL + MR_WAVE * 8LL);
+}
+
+template <bool IMG, int L>
+__global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p, const unsigned* __restrict__ img_count,
+                                                               const float4* __restrict__ img_recs, int strips_axis) {
+    extern __shared__ float4 ps_lds[];
+    __shared__ unsigned s_qn, s_next;
+#ifdef MR_WG_TIMELINE
+    __shared__ unsigned s_dbg[12];
+    if (threadIdx.x < 12) s_dbg[threadIdx.x] = 0u;
+#endif
+    MR_PS_STAMP(0);
+    constexpr int ENT = MR_WAVE / L;  // entries per batch of a wave
+    const int is = p.is, stride = is + 1;  // (+1: the L lines of a staging store fall into different banks)
+    float4* recA = ps_lds;                 // [L][stride]  alpha, r, g, b
+    float4* recB = recA + L * stride;      // [L][stride]  d alpha, d r, d g, d b
+    int* fimL = reinterpret_cast<int*>(recB + L * stride);  // [L][stride]  face index map
+    unsigned* queue = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(fimL) + ((L * stride * 4 + 15) & ~15));
+    unsigned* sweeps = queue + PS_QCAP;  // (the task lists and the per-item sums of the waves)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // blockIdx -> XCD blockIdx % 8: every strip of an image on the same XCD
+    const unsigned S = 2u * (unsigned)strips_axis, xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const int b = (int)((j / S) * 8u + xcd);
+    if (b >= p.B) return;
+    const unsigned sidx = j % S;
+    const int axis = (int)(sidx & 1u), l0 = (int)(sidx >> 1) * L;
+    {   // no owner of this image has a crossing on these lines: nothing to add
+        const unsigned hi1 = img_count[p.B + 4 * b + 2 * axis], lo1 = img_count[p.B + 4 * b + 2 * axis + 1];
+        if ((int)hi1 <= l0 || is - (int)lo1 > l0 + L - 1) return;
     }
+    const int nl = min(L, is - l0);
     const bool ra = p.return_alpha != 0, rr = p.return_rgb != 0;
+    const float fis = (float)is, two_over_is = 2.0f / fis;
     const int32_t* fim_b = p.fim + (int64_t)b * is * is;
-    const PixRec* row_b = rec_row + (int64_t)b * is * is;
-    const PixRec* col_b = rec_col + (int64_t)b * is * is;
-    float px[3], py[3];  // pixel coordinates of the vertices
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        px[k] = 0.5f * (face[3 * k] * fis + fis - 1.0f);
-        py[k] = 0.5f * (face[3 * k + 1] * fis + fis - 1.0f);
-    }
-    // item ranges: k = 2 * edge + axis, columns d0_from[k] .. d0_to[k] (wave-uniform)
-    int from[6], off[7];
-    off[0] = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const int e = k >> 1, axis = k & 1;
-        const float q00 = axis == 0 ? px[e] : py[e], q10 = axis == 0 ? px[(e + 1) % 3] : py[(e + 1) % 3];
-        const int d0_from = (int)fmaxf(ceilf(fminf(q00, q10)), 0.0f);
-        const int d0_to = (int)fminf(fmaxf(q00, q10), fis - 1.0f);
-        from[k] = d0_from;
-        off[k + 1] = off[k] + max(d0_to - d0_from + 1, 0);
-    }
-    float acc[3][2];  // [vertex][component] partial sums of this lane
-#pragma unroll
-    for (int k = 0; k < 3; k++) { acc[k][0] = 0.0f; acc[k][1] = 0.0f; }
 
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    auto stage = [&](int line, int d1) {
+        const int x = axis == 0 ? l0 + line : d1, y = axis == 0 ? d1 : l0 + line;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ra) {
+            const int64_t ia = idx1<IMG>(b, y, x, is);
+            v[0] = p.alpha[ia]; v[1] = p.grad_alpha[ia];
+        }
+        if (rr) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int64_t ic = idx3<IMG>(b, y, x, k, is);
+                v[2 + k] = p.rgb[ic]; v[5 + k] = p.grad_rgb[ic];
+            }
+        }
+        recA[line * stride + d1] = make_float4(v[0], v[2], v[3], v[4]);
+        recB[line * stride + d1] = make_float4(v[1], v[5], v[6], v[7]);
+        fimL[line * stride + d1] = fim_b[y * is + x];
+    };
+    auto stage_strip = [&]() {
+        if (axis == 0) {
+            for (int idx = tid; idx < L * is; idx += PS_T)
+                if ((idx % L) < nl) stage(idx % L, idx / L);
+        } else {
+            for (int line = 0; line < nl; line++)
+                for (int d1 = tid; d1 < is; d1 += PS_T) stage(line, d1);
+        }
+    };
+    if (tid == 0) { s_qn = 0u; s_next = 0u; }
+    const unsigned n_own = img_count[b];
+    const float4* own_b = img_recs + 2 * (int64_t)b * p.F;
 
+    const int comp = 1 - axis;
+    uint16_t* tasks = reinterpret_cast<uint16_t*>(sweeps) + wave * PS_TASKS;
+    float2* acc = reinterpret_cast<float2*>(reinterpret_cast<uint16_t*>(sweeps) + (PS_T / MR_WAVE) * PS_TASKS) + wave * MR_WAVE;
+    // a sweep is cut into chunks of CH positions (a power of two >= is / 16: at most 16 chunks per sweep; short chunks
+    // fill the lanes of the task rounds: a batch of 64 items has a few hundred)
+    int CH = 16;
+    while (CH * 16 < is) CH <<= 1;
+
+    auto process = [&](unsigned qn) {
 #pragma unroll 1
-    for (int base_item = 0; base_item < off[6]; base_item += MR_WAVE) {
-        const int item = base_item + lane;
-        bool valid = item < off[6];
-        int k = 0;
+        for (;;) {
+            unsigned base = 0u;
+            if (lane == 0) base = atomicAdd(&s_next, (unsigned)ENT);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (base >= qn) break;
+            MR_PS_COUNT(3, 1);
+            const unsigned ei = base + (unsigned)(lane / L);
+            const int loff = lane % L;
+            const bool have = ei < qn;
+            const unsigned ent = have ? queue[ei] : 0u;
+            const int slot = (int)(ent & 0xffffffu), e = (int)((ent >> 24) & 3u);
+            const int lfirst = (int)((ent >> 26) & 3u), lcnt = (int)((ent >> 28) & 3u);
+            bool valid = have && loff <= lcnt;
+            const int line = min(lfirst + loff, L - 1), d0 = l0 + line;
+            const float4 v01 = own_b[2 * slot], v2n = own_b[2 * slot + 1];
+            const float px[3] = {v01.x, v01.z, v2n.x}, py[3] = {v01.y, v01.w, v2n.y};
+            const int fn = __float_as_int(v2n.z);
+            const int64_t i = (int64_t)b * p.F + fn;
+            // q[num]: vertices e, e+1, e+2, the coordinate pair swapped for axis 1
+            float qx[3], qy[3];
 #pragma unroll
-        for (int j = 1; j < 6; j++) k += (item >= off[j]) ? 1 : 0;
-        const int e = k >> 1, axis = k & 1;
-        int fromk = from[0], offk = off[0];
-#pragma unroll
-        for (int j = 1; j < 6; j++) { fromk = (k == j) ? from[j] : fromk; offk = (k == j) ? off[j] : offk; }
-        const int d0 = fromk + item - offk;
-        // q[num][dim]: vertices e, e+1, e+2 with the coordinate pair swapped for axis 1
-        float qx[3], qy[3];
-#pragma unroll
-        for (int num = 0; num < 3; num++) {
-            const float vx = (e == 0) ? px[num] : ((e == 1) ? px[(num + 1) % 3] : px[(num + 2) % 3]);
-            const float vy = (e == 0) ? py[num] : ((e == 1) ? py[(num + 1) % 3] : py[(num + 2) % 3]);
-            qx[num] = axis == 0 ? vx : vy;
-            qy[num] = axis == 0 ? vy : vx;
-        }
-        const int direction = (axis == 0) ? ((qx[0] < qx[1]) ? -1 : 1) : ((qx[0] < qx[1]) ? 1 : -1);
-        const float fd0 = (float)d0;
-        const float d1_cross = (qy[1] - qy[0]) / (qx[1] - qx[0]) * (fd0 - qx[0]) + qy[0];
-        const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
-        const int d1_out = d1_in + direction;
-        valid = valid && !(d1_in < 0 || is <= d1_in) && !(d1_out < 0 || is <= d1_out);
-        const int d1_in_c = min(max(d1_in, 0), is - 1), d1_out_c = min(max(d1_out, 0), is - 1), d0_c = min(d0, is - 1);
-        const int xin = axis == 0 ? d0_c : d1_in_c, yin = axis == 0 ? d1_in_c : d0_c;
-        const int xout = axis == 0 ? d0_c : d1_out_c, yout = axis == 0 ? d1_out_c : d0_c;
-        // header: both records and the owner of the "in" pixel (unconditional, clamped)
-        const PixRec r_in = row_b[yin * is + xin], r_out = row_b[yout * is + xout];
-        const bool visible = valid && fim_b[yin * is + xin] == fn;
-        const float a_in = r_in.a.x, a_out = r_out.a.x;
-        const float rgb_in[3] = {r_in.a.z, r_in.a.w, r_in.b.x}, rgb_out[3] = {r_out.a.z, r_out.a.w, r_out.b.x};
-        const float c0 = (qx[1] - qx[0]) / (qx[1] - fd0);
-        const float c1 = (qx[1] - qx[0]) / (fd0 - qx[0]);
-        const bool use0 = qx[1] != fd0, use1 = qx[0] != fd0;
-        // "in" sweep limits
-        float d0_cross2;
-        if ((fd0 - qx[0]) * (fd0 - qx[2]) < 0)
-            d0_cross2 = (qy[2] - qy[0]) / (qx[2] - qx[0]) * (fd0 - qx[0]) + qy[0];
-        else
-            d0_cross2 = (qy[1] - qy[2]) / (qx[1] - qx[2]) * (fd0 - qx[2]) + qy[2];
-        // (the float -> int conversion saturates on the GPU and in C alike only inside the int range:
-        // clamp in float first, the limits are clamped to the image below anyway)
-        const float lim_f = (0 < direction) ? ceilf(d0_cross2) : floorf(d0_cross2);
-        const int d1_limit = (lim_f == lim_f) ? (int)fminf(fmaxf(lim_f, -2.0f), fis + 1.0f) : (int)0x80000000;
-        const int in_from = max(min(d1_in, d1_limit), 0), in_to = min(max(d1_in, d1_limit), is - 1);
-        const bool long_in = valid && (in_to - in_from) >= PM_LONG;
-
-        float g0 = 0.0f, g1 = 0.0f;  // this lane's sums for (pi[0], 1 - axis) and (pi[1], 1 - axis)
-        // short "in" sweeps: the lane walks its own item
-        if (valid && !long_in && !(p.dbg & 2)) {
-            const PixRec* base = (axis == 0 ? col_b : row_b) + (int64_t)d0 * is;
-            for (int d1 = in_from; d1 <= in_to; d1++) {
-                const int xi = axis == 0 ? d0 : d1, yi = axis == 0 ? d1 : d0;
-                if (fim_b[yi * is + xi] != fn) continue;
-                const PixRec r = base[d1];
-                const float dg = rec_diff_grad(r, a_out, rgb_out, ra, rr);
-                if (dg <= 0) continue;
-                if (use0) g0 -= pm_term(dg, c0, (float)d1, d1_cross, two_over_is, p.eps);
-                if (use1) g1 -= pm_term(dg, c1, (float)d1, d1_cross, two_over_is, p.eps);
+            for (int num = 0; num < 3; num++) {
+                const float vx = (e == 0) ? px[num] : ((e == 1) ? px[(num + 1) % 3] : px[(num + 2) % 3]);
+                const float vy = (e == 0) ? py[num] : ((e == 1) ? py[(num + 1) % 3] : py[(num + 2) % 3]);
+                qx[num] = axis == 0 ? vx : vy;
+                qy[num] = axis == 0 ? vy : vx;
             }
-        }
-        // lane-private sums -> accumulator slots (vertex pi[0] = e, pi[1] = e + 1; component 1 - axis)
-#pragma unroll
-        for (int v = 0; v < 3; v++)
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                const bool comp = c == 1 - axis;
-                acc[v][c] += (comp && v == e) ? g0 : 0.0f;
-                acc[v][c] += (comp && v == (e + 1) % 3) ? g1 : 0.0f;
-            }
+            const int direction = (axis == 0) ? ((qx[0] < qx[1]) ? -1 : 1) : ((qx[0] < qx[1]) ? 1 : -1);
+            const float fd0 = (float)d0;
+            const float d1_cross = (qy[1] - qy[0]) / (qx[1] - qx[0]) * (fd0 - qx[0]) + qy[0];
+            const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
+            const int d1_out = d1_in + direction;
+            valid = valid && !(d1_in < 0 || is <= d1_in) && !(d1_out < 0 || is <= d1_out);
+            const int d1_in_c = min(max(d1_in, 0), is - 1), d1_out_c = min(max(d1_out, 0), is - 1);
+            const float4 iA = recA[line * stride + d1_in_c], oA = recA[line * stride + d1_out_c];
+            const bool visible = valid && fimL[line * stride + d1_in_c] == fn;
+            const float a_in = iA.x, a_out = oA.x;
+            const float rgb_in[3] = {iA.y, iA.z, iA.w}, rgb_out[3] = {oA.y, oA.z, oA.w};
+            const float c0 = (qx[1] - qx[0]) / (qx[1] - fd0);
+            const float c1 = (qx[1] - qx[0]) / (fd0 - qx[0]);
+            const bool use0 = qx[1] != fd0, use1 = qx[0] != fd0;
+            float d0_cross2;
+            if ((fd0 - qx[0]) * (fd0 - qx[2]) < 0)
+                d0_cross2 = (qy[2] - qy[0]) / (qx[2] - qx[0]) * (fd0 - qx[0]) + qy[0];
+            else
+                d0_cross2 = (qy[1] - qy[2]) / (qx[1] - qx[2]) * (fd0 - qx[2]) + qy[2];
+            const float lim_f = (0 < direction) ? ceilf(d0_cross2) : floorf(d0_cross2);
+            const int d1_limit = (lim_f == lim_f) ? (int)fminf(fmaxf(lim_f, -2.0f), fis + 1.0f) : (int)0x80000000;
+            const int in_from = max(min(d1_in, d1_limit), 0), in_to = min(max(d1_in, d1_limit), is - 1);
+            const bool long_in = valid && (in_to - in_from) >= PM_LONG;
 
-        // wave sweeps: "out" of every visible item, "in" of the long ones -- staged in LDS in lane order, then walked
-        // one after the other by the whole wave, 64 records per step from the copy that is contiguous along the sweep
-        unsigned long long m_out = __ballot(visible), m_in = __ballot(long_in);
-        if (p.dbg & 1) { m_out = 0ull; m_in = 0ull; }
-        if (p.dbg & 4) { m_out &= 1ull; }
-        const int n_out = __popcll(m_out), n_sw = n_out + __popcll(m_in);
-        {
+            float g0 = 0.0f, g1 = 0.0f;  // short "in" sweep: the lane walks its own item
+            if (valid && !long_in && !(p.dbg & 2)) {
+                for (int d1 = in_from; d1 <= in_to; d1++) {
+                    if (fimL[line * stride + d1] != fn) continue;
+                    const float dg = ps_diff_grad(recA[line * stride + d1], recB[line * stride + d1],
+                                                  make_float4(a_out, rgb_out[0], rgb_out[1], rgb_out[2]));
+                    if (dg <= 0) continue;
+                    if (use0) g0 -= pm_term(dg, c0, (float)d1, d1_cross, two_over_is, p.eps);
+                    if (use1) g1 -= pm_term(dg, c1, (float)d1, d1_cross, two_over_is, p.eps);
+                }
+            }
+            acc[lane] = make_float2(0.0f, 0.0f);  // the sums of this lane's item over its chunks (LDS atomics of the task lanes)
+
+            // The "out" sweeps of the visible items and the long "in" sweeps, one LANE per chunk of CH positions.  A lane
+            // fetches the header of its chunk's item from the lane that computed it (ds_bpermute) and walks the chunk
+            // by itself -- no staging of headers, no sums across lanes -- starting at the position that puts its
+            // records on the LDS bank quad of its lane number: base + position = lane (mod 16) for all lanes and steps
+            // alike, so the 16 lanes of a ds_read_b128 group never share a bank.
             const float k0 = c0 * two_over_is, k1 = c1 * two_over_is;
-            const int flags = (k << 14) | ((use0 ? 1 : 0) << 18) | ((use1 ? 1 : 0) << 19);
-            if ((m_out >> lane) & 1ull) {
-                const int lim = (0 < direction) ? is - 1 : 0;
-                const float fdir = (float)direction;  // the sign of d1 - d1_cross along the whole "out" sweep
-                PmSweep o;
-                o.info = d0 | flags;
-                o.range = max(min(d1_out, lim), 0) | (min(max(d1_out, lim), is - 1) << 16);
-                o.cross = d1_cross; o.k0 = k0; o.k1 = k1;
-                o.e0 = (0.0f < k0 * fdir) ? p.eps : -p.eps;
-                o.e1 = (0.0f < k1 * fdir) ? p.eps : -p.eps;
-                o.a_ref = a_in; o.r_ref = rgb_in[0]; o.g_ref = rgb_in[1]; o.b_ref = rgb_in[2]; o.pad = 0.0f;
-                sw[__popcll(m_out & lt_mask)] = o;
-            }
-            if ((m_in >> lane) & 1ull) {
-                PmSweep o;
-                o.info = d0 | flags | (1 << 17);
-                o.range = in_from | (in_to << 16);
-                o.cross = d1_cross; o.k0 = k0; o.k1 = k1; o.e0 = 0.0f; o.e1 = 0.0f;
-                o.a_ref = a_out; o.r_ref = rgb_out[0]; o.g_ref = rgb_out[1]; o.b_ref = rgb_out[2]; o.pad = 0.0f;
-                sw[n_out + __popcll(m_in & lt_mask)] = o;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+            const int lim = (0 < direction) ? is - 1 : 0;
+            const int o_from = max(min(d1_out, lim), 0), o_to = min(max(d1_out, lim), is - 1);
+            const int hdr = line | (e << 4) | ((0 < direction ? 1 : 0) << 6) | ((use0 ? 1 : 0) << 7) | ((use1 ? 1 : 0) << 8);
+            const int r_out = o_from | (o_to << 16), r_in = in_from | (in_to << 16);
 #pragma unroll 1
-        for (int i = 0; i < n_sw; i++) {
-            const float4* sp = reinterpret_cast<const float4*>(sw + i);
-            const float4 A = sp[0], Bq = sp[1], Cq = sp[2];
-            const int info = __builtin_amdgcn_readfirstlane(__float_as_int(A.x));
-            const int range = __builtin_amdgcn_readfirstlane(__float_as_int(A.y));
-            const int s_d0 = info & 0x3fff, s_k = (info >> 14) & 7;
-            const bool own_only = (info >> 17) & 1, s_use0 = (info >> 18) & 1, s_use1 = (info >> 19) & 1;
-            const int s_from = range & 0xffff, s_to = (range >> 16) & 0xffff;
-            const float s_cross = A.z, s_k0 = A.w, s_e0 = Bq.x, s_k1 = Bq.y, s_e1 = Bq.z;
-            const float s_a = Bq.w;
-            const float s_rgb[3] = {Cq.x, Cq.y, Cq.z};
-            const int s_axis = s_k & 1;
-            const PixRec* base = (s_axis == 0 ? col_b : row_b) + (int64_t)s_d0 * is;
-            float w0 = 0.0f, w1 = 0.0f;
-            auto visit = [&](int d1, const PixRec& r) {
-                if (own_only) {
-                    const int xi = s_axis == 0 ? s_d0 : d1, yi = s_axis == 0 ? d1 : s_d0;
-                    if (fim_b[yi * is + xi] != fn) return;
-                }
-                float dg = rec_diff_grad(r, s_a, s_rgb, ra, rr);
-                dg = (dg <= 0.0f) ? 0.0f : dg;  // (a NaN stays a NaN, as with upstream's `if (dg <= 0) continue`)
-                const float tt = (float)d1 - s_cross;
-                if (own_only) {
-                    if (s_use0) {
-                        float dist = s_k0 * tt;
-                        dist = (0 < dist) ? dist + p.eps : dist - p.eps;
-                        w0 = __builtin_fmaf(-dg, __builtin_amdgcn_rcpf(dist), w0);
+            for (int kind = 0; kind < 2; kind++) {  // 0: "out" sweeps, 1: long "in" sweeps (only this face's pixels)
+                const bool want = kind == 0 ? visible : long_in;
+                const int span = kind == 0 ? o_to - o_from : in_to - in_from;
+                const int n = want ? span / CH + 1 : 0;
+                const int incl = (int)wave_sum_last((float)n);  // (inclusive scan; exact: at most 1024)
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                if (total == 0 || (p.dbg & 1)) continue;
+                for (int c = 0; c < n; c++) tasks[incl - n + c] = (uint16_t)(lane | (c << 6));
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+                for (int t0 = 0; t0 < total; t0 += MR_WAVE) {
+                    const bool mine = t0 + lane < total;
+                    const int task = mine ? (int)tasks[t0 + lane] : 0;
+                    const int src = task & 63, c = task >> 6;
+                    const float t_cross = __shfl(d1_cross, src), t_k0 = __shfl(k0, src), t_k1 = __shfl(k1, src);
+                    const int t_hdr = __shfl(hdr, src), t_range = __shfl(kind == 0 ? r_out : r_in, src);
+                    const float4 ref = make_float4(__shfl(kind == 0 ? a_in : a_out, src), __shfl(kind == 0 ? rgb_in[0] : rgb_out[0], src),
+                                                   __shfl(kind == 0 ? rgb_in[1] : rgb_out[1], src),
+                                                   __shfl(kind == 0 ? rgb_in[2] : rgb_out[2], src));
+                    const int t_line = t_hdr & 15;
+                    const bool t_use0 = (t_hdr >> 7) & 1, t_use1 = (t_hdr >> 8) & 1;
+                    const int from = (t_range & 0xffff) + c * CH, to = min(t_range >> 16, from + CH - 1);
+                    const int cnt = mine ? to - from + 1 : 0;
+                    const int base = t_line * stride + from;
+                    const int rot = (lane - base) & 15;
+                    const int t_fn = __shfl(fn, src);
+                    MR_PS_COUNT(1, 1);
+                    MR_PS_COUNT(2, cnt);
+                    f32x2 ww = {0.0f, 0.0f};
+                    // an unused term gets the distance 1 and the weight 0
+                    const f32x2 kk = {t_use0 ? t_k0 : 0.0f, t_use1 ? t_k1 : 0.0f};
+                    // The records of PG steps are requested together, the next PG while these are worked on (the
+                    // compiler keeps the steps of an unrolled loop one behind the other, each waiting for its own LDS
+                    // round trip).  No branch in a step: positions behind the chunk's end are read -- LDS, inside the
+                    // workgroup's allocation -- and weighted 0.
+                    constexpr int PG = 2;  // steps requested together
+                    struct Quad { float4 a[PG], g[PG]; int owner[PG], pos[PG]; };
+                    auto request = [&](Quad& q, int it0) {
+#pragma unroll
+                        for (int u = 0; u < PG; u++) {
+                            const int pos = (rot + it0 + u) & (CH - 1);
+                            q.pos[u] = pos;
+                            q.a[u] = recA[base + pos];
+                            q.g[u] = recB[base + pos];
+                            q.owner[u] = kind == 0 ? 0 : fimL[base + pos];
+                        }
+                    };
+                    if (kind == 0) {
+                        // d1 - d1_cross keeps its sign beyond the edge: the +-eps of `dist` is a constant of the sweep.
+                        // Both distances of a step at once (packed fp32) and ONE reciprocal for the two,
+                        // 1 / (x y) * y and 1 / (x y) * x: v_rcp_f32 is a quarter-rate instruction
+                        const float fdir = ((t_hdr >> 6) & 1) ? 1.0f : -1.0f;
+                        const f32x2 ee = {t_use0 ? ((0.0f < t_k0 * fdir) ? p.eps : -p.eps) : 1.0f,
+                                          t_use1 ? ((0.0f < t_k1 * fdir) ? p.eps : -p.eps) : 1.0f};
+                        auto work = [&](const Quad& q) {
+#pragma unroll
+                            for (int u = 0; u < PG; u++) {
+                                float dg = ps_diff_grad(q.a[u], q.g[u], ref);
+                                dg = (dg <= 0.0f) ? 0.0f : dg;  // (a NaN stays a NaN, as with upstream's `if (dg <= 0) continue`)
+                                dg = q.pos[u] < cnt ? dg : 0.0f;
+                                const float tt = (float)(from + q.pos[u]) - t_cross;
+                                const f32x2 tt2 = {tt, tt};
+                                const f32x2 dist = __builtin_elementwise_fma(kk, tt2, ee);
+                                const float r = __builtin_amdgcn_rcpf(dist.x * dist.y);
+                                const f32x2 inv = {r * dist.y, r * dist.x};
+                                const f32x2 mdg = {-dg, -dg};
+                                ww = __builtin_elementwise_fma(mdg, inv, ww);
+                            }
+                        };
+                        Quad x, y;
+                        request(x, 0);
+#pragma unroll 1
+                        for (int it0 = 0; it0 < ((p.dbg & 8) ? 0 : CH); it0 += 2 * PG) {
+                            request(y, it0 + PG);
+                            work(x);
+                            if (it0 + 2 * PG < CH) request(x, it0 + 2 * PG);
+                            work(y);
+                        }
+                    } else {
+                        auto work = [&](const Quad& q) {
+#pragma unroll
+                            for (int u = 0; u < PG; u++) {
+                                float dg = ps_diff_grad(q.a[u], q.g[u], ref);
+                                dg = (dg <= 0.0f) ? 0.0f : dg;
+                                dg = ((q.pos[u] < cnt) & (q.owner[u] == t_fn)) ? dg : 0.0f;
+                                const float tt = (float)(from + q.pos[u]) - t_cross;
+                                float d0_ = t_k0 * tt, d1_ = t_k1 * tt;
+                                const float s0 = (0 < d0_) ? p.eps : -p.eps, s1 = (0 < d1_) ? p.eps : -p.eps;
+                                d0_ += s0; d1_ += s1;
+                                d0_ = t_use0 ? d0_ : 1.0f;
+                                d1_ = t_use1 ? d1_ : 1.0f;
+                                const float r = __builtin_amdgcn_rcpf(d0_ * d1_);
+                                ww.x = __builtin_fmaf(-dg, r * d1_, ww.x);
+                                ww.y = __builtin_fmaf(-dg, r * d0_, ww.y);
+                            }
+                        };
+                        Quad x, y;
+                        request(x, 0);
+#pragma unroll 1
+                        for (int it0 = 0; it0 < ((p.dbg & 8) ? 0 : CH); it0 += 2 * PG) {
+                            request(y, it0 + PG);
+                            work(x);
+                            if (it0 + 2 * PG < CH) request(x, it0 + 2 * PG);
+                            work(y);
+                        }
                     }
-                    if (s_use1) {
-                        float dist = s_k1 * tt;
-                        dist = (0 < dist) ? dist + p.eps : dist - p.eps;
-                        w1 = __builtin_fmaf(-dg, __builtin_amdgcn_rcpf(dist), w1);
+                    if (mine) {
+                        if (t_use0 && ww.x != 0.0f) unsafeAtomicAdd(&acc[src].x, ww.x);
+                        if (t_use1 && ww.y != 0.0f) unsafeAtomicAdd(&acc[src].y, ww.y);
                     }
-                } else {
-                    // d1 - d1_cross keeps its sign beyond the edge: the +-eps of `dist` is a constant of the sweep
-                    if (s_use0) w0 = __builtin_fmaf(-dg, __builtin_amdgcn_rcpf(__builtin_fmaf(s_k0, tt, s_e0)), w0);
-                    if (s_use1) w1 = __builtin_fmaf(-dg, __builtin_amdgcn_rcpf(__builtin_fmaf(s_k1, tt, s_e1)), w1);
                 }
-            };
-            // two steps per trip, both records requested before the first is used (the walks are bound by the
-            // latency of these loads: one wave, one face, one sweep after the other)
-            for (int d1 = s_from + lane; d1 <= s_to; d1 += 2 * MR_WAVE) {
-                const int d1b = d1 + MR_WAVE;
-                const PixRec ra_ = base[d1];
-                const PixRec rb_ = base[min(d1b, s_to)];
-                visit(d1, ra_);
-                if (d1b <= s_to) visit(d1b, rb_);
+                __builtin_amdgcn_wave_barrier();  // (the next kind / batch overwrites the task list)
             }
-            // the slots are wave-uniform here: scalar branches instead of 12 selects
-            const int s_e = s_k >> 1, sc = 1 - s_axis, v0 = s_e, v1 = s_e == 2 ? 0 : s_e + 1;
+            // an entry's lines -> one pair of sums -> the face's row (zeroed by compact_owners_kernel)
+            g0 += acc[lane].x;
+            g1 += acc[lane].y;
 #pragma unroll
-            for (int v = 0; v < 3; v++)
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    if (v == v0 && c == sc) acc[v][c] += w0;
-                    if (v == v1 && c == sc) acc[v][c] += w1;
-                }
+            for (int o = 1; o < L; o <<= 1) {
+                g0 += __shfl_xor(g0, o);
+                g1 += __shfl_xor(g1, o);
+            }
+            if (have && loff == 0) {
+                if (g0 != 0.0f) unsafeAtomicAdd(&p.grad_faces[i * 9 + 3 * e + comp], g0);
+                if (g1 != 0.0f) unsafeAtomicAdd(&p.grad_faces[i * 9 + 3 * (e == 2 ? 0 : e + 1) + comp], g1);
+            }
         }
-        __builtin_amdgcn_wave_barrier();  // the next round of items overwrites the staged sweeps
+    };
+
+    // The image's front-facing owners, one per thread and round; the records of the first PRE rounds are requested
+    // before the strip is staged, so that all of a workgroup's global loads are in flight together.
+    constexpr int PRE = 3;
+    float4 pre[PRE][2];
+#pragma unroll
+    for (int j = 0; j < PRE; j++) {
+        const unsigned k = (unsigned)(j * PS_T + tid);
+        const unsigned kc = k < n_own ? k : 0u;
+        pre[j][0] = own_b[2 * kc]; pre[j][1] = own_b[2 * kc + 1];
     }
+    stage_strip();
+    __syncthreads();
+    MR_PS_STAMP(1);
+    for (unsigned k0 = 0, j = 0; k0 < n_own; k0 += PS_T, j++) {
+        const unsigned k = k0 + tid;
+        float4 v01, v2n;
+        if (j < PRE) {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1)
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            acc[k][0] += __shfl_xor(acc[k][0], o);
-            acc[k][1] += __shfl_xor(acc[k][1], o);
+            for (int jj = 0; jj < PRE; jj++)
+                if ((unsigned)jj == j) { v01 = pre[jj][0]; v2n = pre[jj][1]; }
+        } else {
+            const unsigned kc = k < n_own ? k : 0u;
+            v01 = own_b[2 * kc]; v2n = own_b[2 * kc + 1];
         }
-    if (lane == 0) {
+        if (k < n_own) {
+            const float q[3] = {axis == 0 ? v01.x : v01.y, axis == 0 ? v01.z : v01.w, axis == 0 ? v2n.x : v2n.y};
+            unsigned ent[3];
+            int n = 0;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            p.grad_faces[i * 9 + 3 * k + 0] = acc[k][0];
-            p.grad_faces[i * 9 + 3 * k + 1] = acc[k][1];
-            p.grad_faces[i * 9 + 3 * k + 2] = 0.0f;
+            for (int e = 0; e < 3; e++) {
+                const float q00 = q[e], q10 = q[e == 2 ? 0 : e + 1];
+                const int d0_from = (int)fmaxf(ceilf(fminf(q00, q10)), 0.0f);
+                const int d0_to = (int)fminf(fmaxf(q00, q10), fis - 1.0f);
+                const int lo = max(d0_from, l0), hi = min(d0_to, l0 + L - 1);
+                const bool hit = lo <= hi;
+                ent[e] = hit ? (k | ((unsigned)e << 24) | ((unsigned)(lo - l0) << 26) | ((unsigned)(hi - lo) << 28)) : 0xffffffffu;
+                n += hit ? 1 : 0;
+            }
+            if (n) {
+                unsigned at = atomicAdd(&s_qn, (unsigned)n);
+#pragma unroll
+                for (int e = 0; e < 3; e++)
+                    if (ent[e] != 0xffffffffu) queue[at++] = ent[e];
+            }
+        }
+        __syncthreads();
+        const unsigned qn = s_qn;
+        if (qn + 3u * PS_T > (unsigned)PS_QCAP || k0 + PS_T >= n_own) {
+            MR_PS_STAMP(2);
+            MR_PS_COUNT(0, tid == 0 ? qn : 0);
+            if (qn && !(p.dbg & 4)) process(qn);
+            __syncthreads();
+            if (tid == 0) { s_qn = 0u; s_next = 0u; }
+            __syncthreads();
         }
     }
+    MR_PS_STAMP(3);
+#ifdef MR_WG_TIMELINE
+    if (tid < 12 && blockIdx.x < 8192) mr_dbg_ps[blockIdx.x * 16 + 4 + tid] = s_dbg[tid];
+#endif
 }
 
-// The walk kernel is PERSISTENT over the list of owning faces: one wave per face at a time.  (One wave per face of the
-// mesh left four fifths of the launched waves with nothing to do but read their flag, each holding a wave slot -- and
-// its workgroup's LDS -- for the microseconds that takes.)  Every XCD works through a contiguous eighth of the list, i.e.
-// a few images at a time, whose packed records (4 MB per 256 x 256 image) then stay in that XCD's L2 across the sweeps.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
-pixel_map_packed_kernel(PixelMapParams p, const PixRec* __restrict__ rec_row, const PixRec* __restrict__ rec_col,
-                        const unsigned* __restrict__ counter, const uint32_t* __restrict__ list) {
-    __shared__ PmSweep sweeps[256 / MR_WAVE][PM_SW_CAP];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned count = *counter;
-    // nq slices of the list, one per XCD (a launch of fewer than 8 workgroups has that many slices)
-    const unsigned G = gridDim.x, nq = min(G, 8u), x = blockIdx.x % nq;
-    const unsigned waves_x = ((G - x + nq - 1u) / nq) * (256 / MR_WAVE);  // waves of the workgroups with blockIdx % nq == x
-    const unsigned lo = (unsigned)((uint64_t)count * x / nq), hi = (unsigned)((uint64_t)count * (x + 1u) / nq);
-    for (unsigned idx = lo + (blockIdx.x / nq) * (256 / MR_WAVE) + wave; idx < hi; idx += waves_x)
-        pm_walk_face(p, rec_row, rec_col, (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)list[idx]), lane, sweeps[wave]);
-}
 
 template <typename K, typename... A>
 static int launch1d(K kernel, int64_t n, hipStream_t s, A... args) {
@@ -1649,64 +1791,81 @@ static int launch1d(K kernel, int64_t n, hipStream_t s, A... args) {
     return MR_OK;
 }
 
-// backward workspace: per-face "owns a pixel" flags | owner count | owner list | packed records, row- and column-major
-// (the gather alone needs the first three)
+// backward workspace: per-face "owns a pixel" flags | owner count | per-image counts and line ranges | owner list |
+// per-image owner records (the gather needs the flags, the count and the list)
 struct OwnerList {
     uint8_t* owns;
     unsigned* counter;
+    unsigned* img_count;  // [B] owners per image, then [B][4] their line ranges (behind the counter: one memset clears all)
     uint32_t* list;
-    size_t owns_bytes;
+    float4* img_recs;     // [B][F][2] the front-facing owners image by image (compact_owners_kernel)
+    size_t owns_bytes, clear_bytes;
 };
+static int64_t round256(int64_t n) { return (n + 255) & ~255LL; }
 static int64_t owner_list_bytes(int B, int F) {
-    return (((int64_t)B * F + 255) & ~255LL) + 256 + (((int64_t)B * F * 4 + 255) & ~255LL);
+    return round256((int64_t)B * F) + 256 + round256(20LL * B) + round256((int64_t)B * F * 4) + round256((int64_t)B * F * 32);
 }
 static OwnerList owner_list(void* workspace, int B, int F) {
     OwnerList o;
     o.owns = (uint8_t*)workspace;
-    o.owns_bytes = (size_t)(((int64_t)B * F + 255) & ~255LL);
+    o.owns_bytes = (size_t)round256((int64_t)B * F);
     o.counter = (unsigned*)(o.owns + o.owns_bytes);
-    o.list = (uint32_t*)(o.owns + o.owns_bytes + 256);
+    o.img_count = (unsigned*)(o.owns + o.owns_bytes + 256);
+    o.clear_bytes = o.owns_bytes + 256 + (size_t)round256(20LL * B);
+    o.list = (uint32_t*)(o.owns + o.clear_bytes);
+    o.img_recs = (float4*)(o.owns + o.clear_bytes + round256((int64_t)B * F * 4));
     return o;
+}
+// flags -> lists (+ zero rows); the workspace's flags and counts must have been cleared (ol.clear_bytes) and marked
+static int launch_compact(const PixelMapParams& q, const OwnerList& ol, bool per_image, hipStream_t s) {
+    const int chunks = (q.F + CO_TPB * CO_PER - 1) / (CO_TPB * CO_PER);
+    const int64_t blocks = (int64_t)q.B * chunks;
+    if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
+    if (blocks == 0) return MR_OK;
+    hipLaunchKernelGGL(compact_owners_kernel, dim3((unsigned)blocks), dim3(CO_TPB), 0, s, q, (const uint8_t*)ol.owns, ol.counter,
+                       ol.list, per_image ? ol.img_count : (unsigned*)nullptr, per_image ? ol.img_recs : (float4*)nullptr, chunks);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
 }
 
 static int64_t pixel_map_workspace_bytes(int B, int F, int is) {
-    return owner_list_bytes(B, F) + 2LL * (int64_t)B * is * is * (int64_t)sizeof(PixRec);
+    (void)is;
+    return owner_list_bytes(B, F);
 }
 
-// kernel D: packed walks when a workspace of pixel_map_workspace_bytes is available, else the
-// plane-reading kernel (same results up to the order of the fp32 additions)
+// kernel D by strips needs the workspace, a raster whose lines fit LDS and 24-bit owner numbers
+static bool strips_apply(int B, int F, int is, const void* workspace, int64_t workspace_bytes, int flags) {
+    return workspace && workspace_bytes >= pixel_map_workspace_bytes(B, F, is) && !(flags & MR_FLAG_REFERENCE_ALGO) &&
+           strip_lines(is) != 0 && (int64_t)B * F < 0x7fffffffLL && F < (1 << 24);
+}
+
+// kernel D: by strips when a workspace of pixel_map_workspace_bytes is available (leaves the owner list for the gather
+// behind), else the plane-reading per-face walk (same results up to the order of the fp32 additions)
 template <bool IMG>
 static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t workspace_bytes, int flags,
                             hipStream_t s) {
     const int64_t nfaces = (int64_t)p.B * p.F;
-    if (!workspace || workspace_bytes < pixel_map_workspace_bytes(p.B, p.F, p.is) || (flags & MR_FLAG_REFERENCE_ALGO) ||
-        (int64_t)p.is * p.is > (1LL << 26))
+    if (!strips_apply(p.B, p.F, p.is, workspace, workspace_bytes, flags))
         return launch1d(pixel_map_kernel<IMG>, nfaces * MR_WAVE, s, p);
-    PixRec* rec_row = (PixRec*)((char*)workspace + owner_list_bytes(p.B, p.F));
-    PixRec* rec_col = rec_row + (int64_t)p.B * p.is * p.is;
-    const OwnerList ol = owner_list(workspace, p.B, p.F);
-    uint8_t* owns = ol.owns;
-    unsigned* counter = ol.counter;
-    uint32_t* list = ol.list;
-    if (nfaces > 0xffffffffLL) return MR_ERR_BADARG;
-    hipError_t e = hipMemsetAsync(owns, 0, ol.owns_bytes + 256, s);  // flags and the counter behind them
-    if (e != hipSuccess) return (int)e;
-    const int tiles = (p.is + PK_T - 1) / PK_T;
-    const int64_t nblk = (int64_t)p.B * tiles * tiles;
-    if (nblk > 0x7fffffffLL) return MR_ERR_BADARG;
-    hipLaunchKernelGGL(pixel_pack_kernel<IMG>, dim3((unsigned)nblk), dim3(256), 0, s, p, rec_row, rec_col, owns, tiles);
-    MR_CHECK_LAUNCH();
-    if (nfaces == 0) return MR_OK;
-    hipLaunchKernelGGL(compact_owners_kernel, dim3((unsigned)((nfaces + CO_TPB * CO_PER - 1) / (CO_TPB * CO_PER))),
-                       dim3(CO_TPB), 0, s, p, (const uint8_t*)owns, counter, list);
-    MR_CHECK_LAUNCH();
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
-    const int64_t grid = std::min<int64_t>((nfaces + 3) / 4, (int64_t)cus * 6);  // 6 workgroups per compute unit fit
-    hipLaunchKernelGGL(pixel_map_packed_kernel, dim3((unsigned)grid), dim3(256), 0, s, p, (const PixRec*)rec_row,
-                       (const PixRec*)rec_col, (const unsigned*)counter, (const uint32_t*)list);
+    const OwnerList ol0 = owner_list(workspace, p.B, p.F);
+    const int strip_l = strip_lines(p.is);
+    hipError_t e0 = hipMemsetAsync(ol0.owns, 0, ol0.clear_bytes, s);  // flags and the counts behind them
+    if (e0 != hipSuccess) return (int)e0;
+    const int64_t ppi = (int64_t)p.is * p.is, npx = ppi * p.B;
+    int rc = (ppi % 4 == 0) ? launch1d(mark_owners_kernel, npx / 4, s, p.fim, ol0.owns, npx / 4, ppi, p.F)
+                            : launch1d(mark_owners_scalar_kernel, npx, s, p.fim, ol0.owns, npx, ppi, p.F);
+    if (rc != MR_OK || nfaces == 0) return rc;
+    PixelMapParams q = p;
+    q.zero_owner_rows = 1;
+    rc = launch_compact(q, ol0, true, s);
+    if (rc != MR_OK) return rc;
+    const int strips_axis = (p.is + strip_l - 1) / strip_l;
+    const int64_t grid = 8LL * 2 * strips_axis * ((p.B + 7) / 8);
+    if (grid > 0x7fffffffLL) return MR_ERR_BADARG;
+    const size_t lds = (size_t)strip_lds_bytes(p.is, strip_l);
+    auto kernel = strip_l == 4 ? pixel_map_strip_kernel<IMG, 4> : (strip_l == 2 ? pixel_map_strip_kernel<IMG, 2> : pixel_map_strip_kernel<IMG, 1>);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PS_T), lds, s, p, (const unsigned*)ol0.img_count,
+                       (const float4*)ol0.img_recs, strips_axis);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1738,7 +1897,7 @@ extern "C" int mr_backward_pixel_map(const float* faces, const int32_t* face_ind
     PixelMapParams p{faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
                      batch_size, num_faces, image_size, eps, return_rgb, return_alpha, 0, 0};
     if (batch_size == 0 || num_faces == 0) return MR_OK;
-    // scratch for the packed walks, stream-ordered like the forward entry point's record list;
+    // scratch for the walk by strips, stream-ordered like the forward entry point's record list;
     // if it cannot be had the plane-reading kernel does the same job
     hipStream_t s = (hipStream_t)stream;
     void* work = nullptr;
@@ -1807,10 +1966,8 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
     const bool run_gather = (gather_tex || grad_faces) && (gather_tex || want_f || !want_d);
     // with a workspace the faces that own a pixel are listed once (kernel D needs the list anyway) and the gather
     // walks only those: the others -- four fifths of a hand + object mesh -- get their zero rows when the list is built
-    const bool packed_d = workspace && workspace_bytes >= pixel_map_workspace_bytes(batch_size, num_faces, image_size) &&
-                          !(flags & MR_FLAG_REFERENCE_ALGO) && (int64_t)image_size * image_size <= (1LL << 26) &&
-                          nfaces <= 0xffffffffLL;  // (launch_pixel_map's own test)
-    const bool use_list = want_d ? packed_d
+    const bool strips_d = strips_apply(batch_size, num_faces, image_size, workspace, workspace_bytes, flags);
+    const bool use_list = want_d ? strips_d
                                  : (workspace && workspace_bytes >= owner_list_bytes(batch_size, num_faces) &&
                                     !(flags & MR_FLAG_REFERENCE_ALGO) && nfaces <= 0xffffffffLL);
     if (want_d) {
@@ -1822,7 +1979,7 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
         if (rc != MR_OK) return rc;
     } else if (use_list && run_gather) {
         const OwnerList ol = owner_list(workspace, batch_size, num_faces);
-        hipError_t e = hipMemsetAsync(ol.owns, 0, ol.owns_bytes + 256, s);  // flags and the counter behind them
+        hipError_t e = hipMemsetAsync(ol.owns, 0, ol.clear_bytes, s);  // flags and the counts behind them
         if (e != hipSuccess) return (int)e;
         const int64_t ppi = (int64_t)image_size * image_size;
         if (ppi % 4 == 0) rc = launch1d(mark_owners_kernel, npx / 4, s, face_index_map, ol.owns, npx / 4, ppi, num_faces);
@@ -1832,9 +1989,8 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
         q.faces = faces; q.grad_faces = grad_faces; q.B = batch_size; q.F = num_faces; q.is = image_size;
         q.write_backfacing = 1;
         q.zero_textures = gather_tex ? grad_textures : nullptr;
-        hipLaunchKernelGGL(compact_owners_kernel, dim3((unsigned)((nfaces + CO_TPB * CO_PER - 1) / (CO_TPB * CO_PER))),
-                           dim3(CO_TPB), 0, s, q, (const uint8_t*)ol.owns, ol.counter, ol.list);
-        MR_CHECK_LAUNCH();
+        rc = launch_compact(q, ol, false, s);
+        if (rc != MR_OK) return rc;
     }
     if (grad_textures && !gather_tex) {
         const size_t bytes = (size_t)nfaces * texture_size * texture_size * texture_size * 3 * sizeof(float);
@@ -1944,6 +2100,9 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
 }
 
 #ifdef MR_WG_TIMELINE
+extern "C" __attribute__((visibility("default"))) int mr_debug_ps_times(void* dst, long n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mr::mr_dbg_ps), n, 0, hipMemcpyDeviceToHost);
+}
 extern "C" __attribute__((visibility("default"))) int mr_debug_st_times(void* dst, long n) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mr::mr_dbg_st), n, 0, hipMemcpyDeviceToHost);
 }

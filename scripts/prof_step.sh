@@ -9,6 +9,6 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_step
 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o p -- python $ROOT/bench.py --steps 8 --warmup 5 --no-pmc --no-stock-trunk --no-kernel-bench --no-cpu-baseline > $OUT/step_bench_line.json 2> $OUT/step_bench.err
 f=$(find /tmp/prof_step -name "p_kernel_trace.csv" | head -1)
-python $ROOT/scripts/step_top_kernels.py "$f" 80 > $OUT/step_kernels.txt
+python $ROOT/scripts/step_top_kernels.py "$f" 80 $OUT/step_sequence.txt > $OUT/step_kernels.txt
 python $ROOT/scripts/hot_launches.py > $OUT/hot_path_launches.txt 2>&1
 head -4 $OUT/step_kernels.txt; cut -c1-300 $OUT/step_bench_line.json | head -2

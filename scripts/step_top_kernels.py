@@ -1,5 +1,6 @@
 """Kernels of ONE steady-state training step by total time, from a rocprofv3 kernel trace of bench.py (step
-boundaries = the Adam kernels).  Usage: step_top_kernels.py <kernel_trace.csv> [rows]"""
+boundaries = the Adam kernels).  Usage: step_top_kernels.py <kernel_trace.csv> [rows] [sequence-file]
+(the optional third argument writes the step's launches in issue order: start offset, duration, gap, name)"""
 import collections
 import csv
 import sys
@@ -24,3 +25,9 @@ span = seg[-1][1] - seg[0][0]
 print(f"step: {len(seg)} launches, span {span / 1e6:.2f} ms, busy {sum(tot.values()) / 1e6:.2f} ms")
 for k, v in tot.most_common(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     print(f"{cnt[k]:5d} x {v / cnt[k] / 1e3:9.1f} us = {v / 1e6:7.3f} ms  {k}")
+if len(sys.argv) > 3:
+    with open(sys.argv[3], "w") as fh:
+        prev_end = seg[0][0]
+        for s, e, n in seg:
+            fh.write(f"{(s - seg[0][0]) / 1e3:10.1f} us  {(e - s) / 1e3:8.1f} us  gap {(s - prev_end) / 1e3:7.1f}  {n.replace('void ', '')[:110]}\n")
+            prev_end = max(prev_end, e)

@@ -174,10 +174,32 @@ def test_fused_backward_matches_oracle(cuda, kind, B, is_, seed, reference_algo)
     assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * scale_f, "grad_faces")
 
 
+@pytest.mark.parametrize("kind,B,is_,seed", [("big", 1, 67, 11), ("scene", 9, 64, 12), ("scene", 1, 320, 13), ("big", 2, 300, 14),
+                                            ("scene", 1, 600, 15), ("big", 1, 1100, 16)])
+def test_fused_backward_strip_widths(cuda, kind, B, is_, seed):
+    """Kernel D by strips (raster_bwd.hip) beyond the sizes of CASES: an odd raster (partial last strip, flags marked pixel
+    by pixel), more images than XCDs, rasters that take two lines (257..527) and one line (528..1055) per strip, and one
+    too wide for LDS (the plane-reading walk) -- all against the C oracle's ordered walk."""
+    from handobjectconsist_amd.neurender import rasterize
+
+    faces, tex = make_case(kind, B, is_, seed)
+    bg = (0.0, 0.0, 0.0)
+    ref = R.rasterize_rgbad(faces, tex, is_, False, 0.1, 100, 1e-3, bg, num_threads=8, keep_saved=True)
+    saved = ref["_saved"]
+    raster_g, img_g = _img_grads(saved, seed)
+    gf_ref, gt_ref = R.rasterize_backward(saved, *raster_g, num_threads=8)
+    f_t = t(faces, cuda).requires_grad_(True)
+    x_t = t(tex, cuda).requires_grad_(True)
+    out = rasterize.rasterize_rgbad(f_t, x_t, is_, False, 0.1, 100, 1e-3, bg)
+    torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]], [t(g, cuda) for g in img_g])
+    assert np.abs(gf_ref).max() > 0
+    assert_close(x_t.grad.cpu().numpy(), gt_ref, 1e-4, 1e-5 * np.abs(gt_ref).max(), "grad_textures")
+    assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * np.abs(gf_ref).max(), "grad_faces")
+
+
 @pytest.mark.parametrize("n", [1, 3, 7])
 def test_fused_backward_few_faces(cuda, n):
-    """2n faces: kernel D's persistent walk kernel is launched with fewer workgroups than it has list slices for a
-    full chip (one per XCD) -- every owning face must still be walked."""
+    """2n faces of one image: most strips of kernel D have no owner to walk, the others one or two."""
     from handobjectconsist_amd.neurender import rasterize
 
     faces, tex = big_faces(1, 64, 40 + n, n=n)
