@@ -260,7 +260,7 @@ class RasterizeFusedFunction(Function):
             else:
                 grad_textures = torch.empty_like(tex)
         if want_faces or want_tex:
-            if want_faces and (g_rgb is not None or g_alpha is not None):  # kernel D runs: packed-walk scratch
+            if want_faces and (g_rgb is not None or g_alpha is not None):  # kernel D runs: owner flags / list / records
                 wbytes = int(_lib.load().mr_render_backward_workspace_bytes(B, Fn, is_))
             else:  # the list of the faces that own a pixel (the gather walks only those)
                 wbytes = int(_lib.load().mr_render_backward_list_workspace_bytes(B, Fn))

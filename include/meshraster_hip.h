@@ -164,12 +164,13 @@ MR_API int mr_face_inv_map(const float* faces, const int32_t* face_index_map, fl
  * (faces, face_index_map) instead of being stored.  grad_faces[B,F,3,3] /
  * grad_textures[B,F,ts,ts,ts,3] are fully written (no pre-zeroing needed); either may
  * be NULL to skip it.  rgb_img / alpha_img are only read by the pixel-map term.
- * workspace: optional scratch of mr_render_backward_workspace_bytes() bytes; with it kernel D
- * walks two packed copies of the maps (row- and column-major 32-byte records) instead of eight
- * strided planes.  NULL / too small: the plane-reading kernel runs (same result up to fp32
- * summation order).  The workspace also holds the list of the faces that own a pixel: kernel D and the E / F gather
- * then walk only those (a fifth of a hand + object mesh).  A call without the pixel-map term needs only that list:
- * mr_render_backward_list_workspace_bytes() bytes. */
+ * workspace: optional scratch of mr_render_backward_workspace_bytes() bytes (41 bytes per face + 20 per image): it
+ * holds the flags / the list of the faces that own a pixel -- kernel D and the E / F gather then walk only those (a
+ * fifth of a hand + object mesh) -- and, image by image, the owners' pixel-space vertices: with it kernel D runs by
+ * strips of image lines staged in LDS (rasters up to 1055 pixels wide; its sums meet in float atomics, so the order
+ * of the fp32 additions is not fixed).  NULL / too small / MR_FLAG_REFERENCE_ALGO: the plane-reading per-face walk in
+ * upstream's order (same result up to fp32 summation order).  mr_render_backward_list_workspace_bytes() returns the
+ * same size (kept for callers of ABI 2, when a call without the pixel-map term needed less). */
 MR_API int64_t mr_render_backward_workspace_bytes(int batch_size, int num_faces, int image_size);
 MR_API int64_t mr_render_backward_list_workspace_bytes(int batch_size, int num_faces);
 MR_API int mr_render_backward(const float* faces, const float* textures,
