@@ -30,8 +30,8 @@ g_rgb, g_alpha = torch.randn_like(rgb), torch.randn_like(alpha)
 grad_faces = torch.empty_like(faces)
 bw = int(lib.mr_render_backward_workspace_bytes(B, F, is_)); bwork = torch.empty((bw,), dtype=torch.uint8, device=dev)
 flush = torch.zeros(768 * 1024 * 1024 // 4, **f32)
-for name, dbg, ws in (("packed: full", 0, True), ("packed: no wave sweeps", 1, True), ("packed: no lane in-sweeps", 2, True), ("packed: headers only", 3, True),
-                      ("packed: one out sweep per chunk", 4, True), ("planes kernel", 0, False)):
+for name, dbg, ws in (("strips: full", 0, True), ("strips: no chunk tasks", 1, True), ("strips: no lane in-sweeps", 2, True), ("strips: headers only", 3, True),
+                      ("strips: listing + staging only", 4, True), ("strips: tasks without their steps", 8, True), ("planes kernel", 0, False)):
     fn = lambda: _lib.call("mr_render_backward", P(faces), None, P(fim), P(rgb), P(alpha), P(g_rgb), P(g_alpha), None, P(grad_faces), None,
                            P(bwork) if ws else None, bw if ws else 0, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 0, dbg << 8, st)
     print(f"{name:34s} cold {bench.event_time_ms(fn, 10, flush=flush) * 1e3:8.1f} us   warm {bench.event_time_ms(fn, 10) * 1e3:8.1f} us")
