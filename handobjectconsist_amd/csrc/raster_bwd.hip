@@ -1426,6 +1426,7 @@ __device__ __forceinline__ float ps_diff_grad(const float4 v, const float4 g, co
     const f32x2 d = (v0 - r0) * g0 + (v1 - r1) * g1;
     return d.x + d.y;
 }
+__device__ __forceinline__ float ps_bound_k(float k) { return (k == k) ? fminf(fmaxf(k, -1e15f), 1e15f) : k; }
 constexpr int PS_T = 256;
 constexpr int PS_QCAP = 1024;  // queued entries; a round of PS_T faces adds at most 3 * PS_T
 
@@ -1604,7 +1605,10 @@ __global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p,
                     const bool mine = t0 + lane < total;
                     const int task = mine ? (int)tasks[t0 + lane] : 0;
                     const int src = task & 63, c = task >> 6;
-                    const float t_cross = __shfl(d1_cross, src), t_k0 = __shfl(k0, src), t_k1 = __shfl(k1, src);
+                    // (the two distances of a term share ONE reciprocal, 1 / (x y): |k| is kept below 1e15 so that the
+                    // product stays finite -- an edge that all but touches the line has k up to inf, its terms are 0 in
+                    // upstream's dg / dist and < 1e-15 dg here; a NaN stays a NaN)
+                    const float t_cross = __shfl(d1_cross, src), t_k0 = ps_bound_k(__shfl(k0, src)), t_k1 = ps_bound_k(__shfl(k1, src));
                     const int t_hdr = __shfl(hdr, src), t_range = __shfl(kind == 0 ? r_out : r_in, src);
                     const float4 ref = make_float4(__shfl(kind == 0 ? a_in : a_out, src), __shfl(kind == 0 ? rgb_in[0] : rgb_out[0], src),
                                                    __shfl(kind == 0 ? rgb_in[1] : rgb_out[1], src),
@@ -1650,7 +1654,9 @@ __global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p,
                                 float dg = ps_diff_grad(q.a[u], q.g[u], ref);
                                 dg = (dg <= 0.0f) ? 0.0f : dg;  // (a NaN stays a NaN, as with upstream's `if (dg <= 0) continue`)
                                 dg = q.pos[u] < cnt ? dg : 0.0f;
-                                const float tt = (float)(from + q.pos[u]) - t_cross;
+                                // (the distance of a position behind the chunk's end is taken at the end: beyond it the
+                                // sweep may cross the edge, where k * tt + e passes through 0 and 0 * inf would be a NaN)
+                                const float tt = (float)(from + min(q.pos[u], cnt - 1)) - t_cross;
                                 const f32x2 tt2 = {tt, tt};
                                 const f32x2 dist = __builtin_elementwise_fma(kk, tt2, ee);
                                 const float r = __builtin_amdgcn_rcpf(dist.x * dist.y);

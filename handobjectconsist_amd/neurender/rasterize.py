@@ -34,6 +34,8 @@ DEFAULT_BACKGROUND_COLOR = (0, 0, 0)
 USE_FUSED = True
 # validation / A-B profiling: run the upstream-structured algorithms inside the fused calls
 REFERENCE_ALGO = False
+# profiling only (scripts/): the backward kernels' switches, `flags >> 8` of mr_render_backward
+BACKWARD_DEBUG = 0
 
 
 def _dummy(device, dtype=torch.float32):
@@ -242,6 +244,7 @@ class RasterizeFusedFunction(Function):
     def backward(ctx, grad_rgb, grad_alpha, grad_depth, _gfim, _gw):
         faces, tex, fim, rgb, alpha = ctx.saved_tensors
         is_, near, far, eps, rr, ra, rd, ts, flags = ctx.cfg
+        flags |= BACKWARD_DEBUG << 8
         dev = faces.device
         B, Fn = faces.shape[:2]
         want_faces, want_tex = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and rr

@@ -1,5 +1,6 @@
 """Randomised parity sweeps of the HIP path against the CPU oracle (not collected by pytest: a bug hunt to run
-on the GPU box).  Usage: python tests/fuzz_parity.py [n_cases] [first_seed].  Found the NaN-depth point-face bug
+on the GPU box).  Usage: python tests/fuzz_parity.py [n_cases] [first_seed]  (HOC_FUZZ_RASTER_ONLY=1: the first sweep
+alone; HOC_FUZZ_DEBUG=1: details of non-finite gradients).  Found the NaN-depth point-face bug
 and the collinear-face bounding-box bug; 24 000+ cases clean since."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -77,7 +78,21 @@ for case in range(n_cases):
     torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]], [t(a) for a in img])
     for got, want, name in ((x_t.grad, gt_ref, "grad_textures"), (f_t.grad, gf_ref, "grad_faces")):
         gotn = got.cpu().numpy().astype(np.float64)
-        if not np.isfinite(gotn).all() and np.isfinite(want).all(): msg.append(f"{name} non-finite")
+        if not np.isfinite(gotn).all() and np.isfinite(want).all():
+            msg.append(f"{name} non-finite")
+            if os.environ.get("HOC_FUZZ_DEBUG"):  # which rows, and does the ordered walk (MR_FLAG_REFERENCE_ALGO) agree with the oracle?
+                rows = np.argwhere(~np.isfinite(gotn).reshape(gotn.shape[0], gotn.shape[1], -1).all(-1))
+                print("   non-finite rows (image, face):", rows[:6].tolist(), "eps", eps, "near/far", near, far)
+                for bi, fi in rows[:3]:
+                    print("   face", faces[bi, fi].tolist(), "\n   got", gotn[bi, fi].reshape(-1).tolist(), "\n   want", np.asarray(want)[bi, fi].reshape(-1).tolist())
+                rasterize.REFERENCE_ALGO = True
+                try:
+                    f_r, x_r = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
+                    o_r = rasterize.rasterize_rgbad(f_r, x_r, is_, False, near, far, eps, (0.1, 0.2, 0.3))
+                    torch.autograd.backward([o_r["rgb"], o_r["alpha"], o_r["depth"]], [t(a) for a in img])
+                    print("   ordered walk finite:", bool(torch.isfinite(f_r.grad).all()), bool(torch.isfinite(x_r.grad).all()))
+                finally:
+                    rasterize.REFERENCE_ALGO = False
         sc = np.abs(want[np.isfinite(want)]).max() if np.isfinite(want).any() else 1.0
         e = np.abs(np.nan_to_num(gotn - want)).max()
         # absolute floor: a face covering the whole image sums is^2 unit-variance terms that largely cancel; the fp32
@@ -161,6 +176,9 @@ for case in range(n_cases):
         print(f"seed {seed} {kind} B={B} is={is_} F={faces.shape[1]}: " + "; ".join(msg))
 print(f"{n_cases} cases, {bad} with mismatches, {time.time() - t0:.0f} s; mean covered fraction by kind:",
       {k: round(float(np.mean(v)), 3) for k, v in COVER.items()})
+
+if os.environ.get("HOC_FUZZ_RASTER_ONLY"):  # (a long run of the first sweep alone)
+    sys.exit(1 if bad else 0)
 
 # ---- second sweep: vertex-colour path (indexed meshes, shared vertices, degenerate triangles), compat API,
 # ---- reference-algorithm flag, anti-aliasing, warp / occlusion kernels

@@ -197,6 +197,26 @@ def test_fused_backward_strip_widths(cuda, kind, B, is_, seed):
     assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * np.abs(gf_ref).max(), "grad_faces")
 
 
+def test_strip_chunks_behind_a_sweeps_end_stay_finite(cuda):
+    """Fuzz seed 91002: an "out" sweep that runs towards pixel 0 ends next to the edge; the positions of its last chunk
+    BEHIND its end (weighted 0) cross the edge, where the distance k * (d1 - d1_cross) +- eps passes through exactly 0 --
+    0 * (1 / 0) must not reach the sums.  One face with pixel-lattice vertices, eps = 0.01, raster 57."""
+    from handobjectconsist_amd.neurender import rasterize
+
+    tri = np.array([[[-0.75, -1.25, 2.5], [0.875, 1.0, 0.625], [-0.25, 0.0, 0.125]]], np.float32)
+    faces = np.ascontiguousarray(np.stack([tri[0], tri[0][::-1]])[None])
+    tex = np.random.default_rng(5).uniform(-1, 1, (1, 2, 2, 2, 2, 3)).astype(np.float32)
+    ref = R.rasterize_rgbad(faces, tex, 57, False, 0.1, 100, 1e-2, (0.1, 0.2, 0.3), num_threads=2, keep_saved=True)
+    saved = ref["_saved"]
+    raster_g, img_g = _img_grads(saved, 91002)
+    gf_ref, gt_ref = R.rasterize_backward(saved, *raster_g, num_threads=2)
+    f_t, x_t = t(faces, cuda).requires_grad_(True), t(tex, cuda).requires_grad_(True)
+    out = rasterize.rasterize_rgbad(f_t, x_t, 57, False, 0.1, 100, 1e-2, (0.1, 0.2, 0.3))
+    torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]], [t(g, cuda) for g in img_g])
+    assert np.isfinite(gf_ref).all() and torch.isfinite(f_t.grad).all()
+    assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * np.abs(gf_ref).max(), "grad_faces")
+
+
 @pytest.mark.parametrize("n", [1, 3, 7])
 def test_fused_backward_few_faces(cuda, n):
     """2n faces of one image: most strips of kernel D have no owner to walk, the others one or two."""
