@@ -167,7 +167,7 @@ MR_API int mr_face_inv_map(const float* faces, const int32_t* face_index_map, fl
  * workspace: optional scratch of mr_render_backward_workspace_bytes() bytes (41 bytes per face + 20 per image): it
  * holds the flags / the list of the faces that own a pixel -- kernel D and the E / F gather then walk only those (a
  * fifth of a hand + object mesh) -- and, image by image, the owners' pixel-space vertices: with it kernel D runs by
- * strips of image lines staged in LDS (rasters up to 1055 pixels wide; its sums meet in float atomics, so the order
+ * strips of image lines staged in LDS (rasters up to 1421 pixels wide; its sums meet in float atomics, so the order
  * of the fp32 additions is not fixed).  NULL / too small / MR_FLAG_REFERENCE_ALGO: the plane-reading per-face walk in
  * upstream's order (same result up to fp32 summation order).  mr_render_backward_list_workspace_bytes() returns the
  * same size (kept for callers of ABI 2, when a call without the pixel-map term needed less). */

@@ -175,11 +175,11 @@ def test_fused_backward_matches_oracle(cuda, kind, B, is_, seed, reference_algo)
 
 
 @pytest.mark.parametrize("kind,B,is_,seed", [("big", 1, 67, 11), ("scene", 9, 64, 12), ("scene", 1, 320, 13), ("big", 2, 300, 14),
-                                            ("scene", 1, 600, 15), ("big", 1, 1100, 16)])
+                                            ("scene", 1, 600, 15), ("big", 1, 1100, 16), ("big", 1, 1500, 17)])
 def test_fused_backward_strip_widths(cuda, kind, B, is_, seed):
     """Kernel D by strips (raster_bwd.hip) beyond the sizes of CASES: an odd raster (partial last strip, flags marked pixel
-    by pixel), more images than XCDs, rasters that take two lines (257..527) and one line (528..1055) per strip, and one
-    too wide for LDS (the plane-reading walk) -- all against the C oracle's ordered walk."""
+    by pixel), more images than XCDs, rasters that take two lines (257..527) and one line (528..1421) per strip, and one
+    too wide for LDS (1500: the plane-reading walk) -- all against the C oracle's ordered walk."""
     from handobjectconsist_amd.neurender import rasterize
 
     faces, tex = make_case(kind, B, is_, seed)
