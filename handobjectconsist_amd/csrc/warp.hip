@@ -680,6 +680,22 @@ __device__ __forceinline__ bool pair_block_covered(const uint8_t* __restrict__ h
     return any != 0u;
 }
 
+// ... in either of two renders: the words of both are requested before any is looked at (one round trip, not two --
+// five sixths of the blocks of a hand + object frame pair end here, and their number times this latency over the
+// resident workgroups is the floor of the launch)
+__device__ __forceinline__ bool pair_block_covered2(const uint8_t* __restrict__ hit_a, const uint8_t* __restrict__ hit_b,
+                                                    int hit_is, int hit_tiles_x, int hit_stride, int b, int tile, int tiles_x,
+                                                    int H, int W) {
+    const int x0 = (tile % tiles_x) * PT_W, y0 = (tile / tiles_x) * PT_H;
+    const int x1 = min(x0 + PT_W, W) - 1, y1 = min(y0 + PT_H, H) - 1;
+    const uint32_t* a32 = reinterpret_cast<const uint32_t*>(hit_a + (int64_t)b * hit_stride);
+    const uint32_t* b32 = reinterpret_cast<const uint32_t*>(hit_b + (int64_t)b * hit_stride);
+    uint32_t any = 0u;
+    for (int ty = (hit_is - 1 - y1) >> 3; ty <= (hit_is - 1 - y0) >> 3; ty++)
+        for (int tx = x0 >> 5; tx <= x1 >> 5; tx++) any |= a32[ty * hit_tiles_x + tx] | b32[ty * hit_tiles_x + tx];
+    return any != 0u;
+}
+
 // block-wide sums of four values with ONE barrier: wave butterflies, 4 x 4 partials in LDS,
 // every thread adds the four wave partials in wave order (fixed order: deterministic)
 __device__ __forceinline__ void block_sum4(float* v, float (*red)[4]) {
@@ -705,8 +721,7 @@ __global__ void __launch_bounds__(256, 6) pair_consist_forward_kernel(PairParams
     // partial sums are zero (no loads, no barrier), unless the per-pixel debug outputs want every pixel
     if (p.hit12 && p.hit21 && !(p.warp1 || p.warp2 || p.diff1 || p.diff2 || p.warp_mask1 || p.warp_mask2 ||
                                 p.full_mask1 || p.full_mask2) &&
-        !pair_block_covered(p.hit12, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W) &&
-        !pair_block_covered(p.hit21, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W)) {
+        !pair_block_covered2(p.hit12, p.hit21, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W)) {
         if (threadIdx.x < 4) p.partial[((int64_t)b * p.nblk + tile) * 4 + threadIdx.x] = 0.0f;
         return;
     }
@@ -839,8 +854,7 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
     if (!pair_tile_pixel(lid, p.H, p.W, p.tiles_x, p.ntiles, b, tile, xx, yy)) return;
     const int64_t pix = (int64_t)yy * p.W + xx;
     if (p.hit12 && p.hit21 &&
-        !pair_block_covered(p.hit12, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W) &&
-        !pair_block_covered(p.hit21, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W)) {
+        !pair_block_covered2(p.hit12, p.hit21, p.hit_is, p.hit_tiles_x, p.hit_stride, b, tile, p.tiles_x, p.H, p.W)) {
         // nothing rendered under this block in either frame: zero gradient, nothing read
         *reinterpret_cast<float2*>(p.grad_flow21 + ((int64_t)b * hw + pix) * 2) = make_float2(0.0f, 0.0f);
         *reinterpret_cast<float2*>(p.grad_flow12 + ((int64_t)b * hw + pix) * 2) = make_float2(0.0f, 0.0f);
