@@ -107,7 +107,7 @@ for case in range(n_cases):
         if np.abs(sil - r2["alpha"]).max() > 1e-6: msg.append("silhouette mode")
         dd = np.abs(dep - r2["depth"]); dd = dd[np.isfinite(dd)]
         if dd.size and dd.max() > 1e-5 * max(1.0, float(np.abs(r2["depth"][np.isfinite(r2["depth"])]).max())): msg.append(f"depth mode err {dd.max():.2e}")
-        if ts == 2 or kind == "scene":
+        if kind == "scene" or ts == 2:
             f5, x5 = t(faces).requires_grad_(True), t(tex).requires_grad_(True)
             o5 = rasterize.rasterize_rgbad(f5, x5, is_, True, near, far, eps, (0.1, 0.2, 0.3))
             r5 = R.rasterize_rgbad(faces, tex, is_, True, near, far, eps, (0.1, 0.2, 0.3), num_threads=8, keep_saved=True)
