@@ -193,8 +193,11 @@ def test_fused_backward_strip_widths(cuda, kind, B, is_, seed):
     out = rasterize.rasterize_rgbad(f_t, x_t, is_, False, 0.1, 100, 1e-3, bg)
     torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]], [t(g, cuda) for g in img_g])
     assert np.abs(gf_ref).max() > 0
-    assert_close(x_t.grad.cpu().numpy(), gt_ref, 1e-4, 1e-5 * np.abs(gt_ref).max(), "grad_textures")
-    assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * np.abs(gf_ref).max(), "grad_faces")
+    # (sweeps of a thousand and more terms: the order of the fp32 additions -- sequential in the oracle, by lanes on the
+    # GPU -- shows at 5e-5 of the largest gradient on the 1500-pixel raster)
+    floor = 1e-5 if is_ < 1000 else 1e-4
+    assert_close(x_t.grad.cpu().numpy(), gt_ref, 1e-4, floor * np.abs(gt_ref).max(), "grad_textures")
+    assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, floor * np.abs(gf_ref).max(), "grad_faces")
 
 
 def test_strip_chunks_behind_a_sweeps_end_stay_finite(cuda):
