@@ -19,6 +19,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   "kernels":      the same for every hot-path kernel group (render fwd, render bwd, pair loss...),
   "cpu_baseline": the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
                   bounded sample of the same hot path (N=1 only).
+
+Profiling switches (environment, scripts/ only; none of them is set in a measured run): HOC_KERNEL_GROUPS (comma-separated
+group names of --kernels-only), HOC_FWD_DBG / HOC_BWD_FLAGS / HOC_FLOW_BWD_DBG (the kernels' own `flags >> 8` switches),
+HOC_TILE_LIST, HOC_GRAD_BOUND, HOC_PAIR_EMPTY (the warp kernels on coverage bytes that say "nothing rendered"),
+HOC_TORCH_DDP / HOC_FORCE_DDP (A/B of the data-parallel path on one rank), HOC_TUNABLEOP.
 """
 import argparse
 import json
