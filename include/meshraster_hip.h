@@ -164,7 +164,7 @@ MR_API int mr_face_inv_map(const float* faces, const int32_t* face_index_map, fl
  * (faces, face_index_map) instead of being stored.  grad_faces[B,F,3,3] /
  * grad_textures[B,F,ts,ts,ts,3] are fully written (no pre-zeroing needed); either may
  * be NULL to skip it.  rgb_img / alpha_img are only read by the pixel-map term.
- * workspace: optional scratch of mr_render_backward_workspace_bytes() bytes (41 bytes per face + 20 per image): it
+ * workspace: optional scratch of mr_render_backward_workspace_bytes() bytes (37 bytes per face + 20 per image): it
  * holds the flags / the list of the faces that own a pixel -- kernel D and the E / F gather then walk only those (a
  * fifth of a hand + object mesh) -- and, image by image, the owners' pixel-space vertices: with it kernel D runs by
  * strips of image lines staged in LDS (rasters up to 1421 pixels wide; its sums meet in float atomics, so the order
