@@ -332,7 +332,11 @@ for case in range(min(n_cases, 200)):
             msg.append(f"flow{i}: {nbig} px differ by > 1e-4 relative (max {d.max():.2e}, scale {np.abs(b_).max():.1f})")
     ga, gb = res[True][1], res[False][1]
     e, sc = np.abs(ga - gb).max(), np.abs(gb).max() + 1e-12
-    if e > 0.15 * sc: msg.append(f"vertex grad err {e:.2e} (scale {sc:.2e})")   # (same conditioning; gross errors only)
+    # (same conditioning; gross errors only -- and only where both paths rendered the same faces: the vertices of the two
+    # paths differ by an ulp, which can hand a pixel to another of several sub-pixel faces (seed 600094: 0.1 px^2 faces
+    # on a 44-pixel raster, one pixel's flow 0.85 apart) and with it the whole gradient of a vertex)
+    same_winners = all(np.abs(res[True][0][i] - res[False][0][i]).max() <= 1e-2 for i in (0, 1))
+    if same_winners and e > 0.15 * sc: msg.append(f"vertex grad err {e:.2e} (scale {sc:.2e})")
     # ... and the fused path (the one training runs: stacked 2B render) against the CPU oracle, tightly
     kw4 = dict(KW, orig_size=is_, image_size=is_, anti_aliasing=False, near=0.1, far=100, eps=1e-3)
     ref4 = W.get_opticalflow(R, [s["verts1"], s["verts2"]], s["faces"], [s["K1"], s["K2"]], kw4, orig_img_size=(Wd, H),
