@@ -20,8 +20,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   "cpu_baseline": the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
                   bounded sample of the same hot path (N=1 only).
 
-Profiling switches (environment, scripts/ only; none of them is set in a measured run): HOC_KERNEL_GROUPS (comma-separated
-group names of --kernels-only), HOC_FWD_DBG / HOC_BWD_FLAGS / HOC_FLOW_BWD_DBG (the kernels' own `flags >> 8` switches),
+Profiling switches (environment, scripts/ only; none of them is set in a measured run): HOC_KERNEL_GROUPS (group names
+of --kernels-only, separated by ';'), HOC_FWD_DBG / HOC_BWD_FLAGS / HOC_FLOW_BWD_DBG (the kernels' own `flags >> 8` switches),
 HOC_TILE_LIST, HOC_GRAD_BOUND, HOC_PAIR_EMPTY (the warp kernels on coverage bytes that say "nothing rendered"),
 HOC_TORCH_DDP / HOC_FORCE_DDP (A/B of the data-parallel path on one rank), HOC_TUNABLEOP.
 """
@@ -557,8 +557,8 @@ def main():
     assert _lib.load().mr_device_ok() == 1, "libmeshraster_hip.so: no gfx950 device"
     if args.kernels_only or args.roofline_only:
         only = (ROOF_BWD, ROOF_FWD) if args.roofline_only else None
-        if os.environ.get("HOC_KERNEL_GROUPS"):  # profiling aid: comma-separated group names (kernel_bench's list)
-            only = tuple(os.environ["HOC_KERNEL_GROUPS"].split(","))
+        if os.environ.get("HOC_KERNEL_GROUPS"):  # profiling aid: group names of kernel_bench, separated by ";"
+            only = tuple(os.environ["HOC_KERNEL_GROUPS"].split(";"))
         os.write(real_stdout, (json.dumps(kernel_bench(dev, args.batch, args.image_size, args.kernel_iters, only), indent=1) + "\n").encode())
         return
     torch.manual_seed(rank)
