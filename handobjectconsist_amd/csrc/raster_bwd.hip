@@ -104,10 +104,11 @@ __device__ __forceinline__ void gather_pixel(const GatherParams& p, const Face& 
     }
 }
 
-// GLPF lanes per face: lane `sub` walks bbox rows sub, sub + GLPF, ...; the four partial sums are
-// combined with two quad shuffles (fixed order: deterministic).  Faces whose bbox exceeds
-// GATHER_BIG pixels are walked by the whole wave instead.
+// GGL (generic gather) / GLPF (vertex-colour gather) lanes per face: lane `sub` walks bbox rows sub, sub + lanes, ...;
+// the partial sums are combined with shuffles inside the lane group (fixed order: deterministic).  Faces whose bbox
+// exceeds GATHER_BIG pixels are walked by the whole wave instead.
 constexpr int GLPF = 4;
+constexpr int GGL = 8;   // lanes per face of the generic gather (E: 74 -> 64 us, E + F: 105 -> 93 us against 4; 16: 70 / 101)
 constexpr int GATHER_BIG = 128;          // vertex-colour gather: bbox area above which the whole wave probes
 constexpr int GATHER_BIG_GENERIC = 256;  // generic gather (direct accumulation on the wave-cooperative path)
 
@@ -133,9 +134,9 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
     const int64_t total = p.owners ? (int64_t)*p.n_owners : (int64_t)p.B * p.F;
     // (owner list: the entries in use are the first ones -- plain block order, so that they spread over the XCDs)
     const int64_t gid = (int64_t)(p.owners ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
-    if ((gid - threadIdx.x) / GLPF >= total) return;  // block-uniform: nothing left in the list
-    const int64_t slot = gid / GLPF;
-    const int sub = (int)(gid % GLPF);
+    if ((gid - threadIdx.x) / GGL >= total) return;  // block-uniform: nothing left in the list
+    const int64_t slot = gid / GGL;
+    const int sub = (int)(gid % GGL);
     const int lane = threadIdx.x & 63;
     const bool valid = slot < total;
     const int64_t i = p.owners ? (valid ? (int64_t)p.owners[slot] : 0) : slot;
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
         Face f;
         load_face(p.faces + i * 9, f, is);
         const int32_t* fim_b = p.fim + (int64_t)b * is * is;
-        for (int yi = bx.y0 + sub; yi <= bx.y1; yi += GLPF)
+        for (int yi = bx.y0 + sub; yi <= bx.y1; yi += GGL)
             for (int xi = bx.x0; xi <= bx.x1; xi += 4) {
                 int hit[4];  // four probes in flight
 #pragma unroll
@@ -220,7 +221,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
     }
     // quad reduction: afterwards every lane of the quad holds the face's sums
 #pragma unroll
-    for (int off = 1; off < GLPF; off <<= 1) {
+    for (int off = 1; off < GGL; off <<= 1) {
         if (TEX)
 #pragma unroll
             for (int k = 0; k < NT; k++) gt[k] += __shfl_xor(gt[k], off);
@@ -2019,7 +2020,7 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
             const OwnerList ol = owner_list(workspace, batch_size, num_faces);
             g.owners = ol.list; g.n_owners = ol.counter;
         }
-        const int64_t nthreads = nfaces * GLPF;
+        const int64_t nthreads = nfaces * GGL;
         if (gather_tex && want_f) rc = launch1d(gather_kernel<true, true, true>, nthreads, s, g);
         else if (gather_tex) rc = launch1d(gather_kernel<true, true, false>, nthreads, s, g);
         else if (want_f) rc = launch1d(gather_kernel<true, false, true>, nthreads, s, g);
