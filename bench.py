@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- trainmeshwarp optimiser-steps/sec with render + warp in the loop.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (one per GPU, torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W   # ... or under a launcher: same ranks, same line
 
 One "step" = one optimiser step of trainmeshwarp.py at B=64, 256x256 (BASELINE.json metric;
 SURVEY Q15): a supervised data batch (B frames) + a consistency batch (B frame pairs): 3B
@@ -66,6 +66,10 @@ def parse():
     p.add_argument("--roofline-only", action="store_true",
                    help="launch only the two roofline kernels a few times (what the in-run PMC passes profile)")
     p.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic")
+    p.add_argument("--reducer-ab", type=int, default=0, metavar="PAIRS",
+                   help="A/B inside ONE process (one model, one set of MIOpen / TunableOp solver choices): PAIRS x "
+                        "(--steps plain steps, then --steps steps through the RCCL process group + bucketed gradient "
+                        "reducer on one rank); prints {plain_ms, one_rank_rccl_ms, ratios}")
     return p.parse_args()
 
 
@@ -103,9 +107,17 @@ ROOF_FWD = "render_flow_forward(train outputs,both frames=2B)"
 # the device kernels behind the two groups (names as rocprofv3 prints them)
 ROOF_KERNELS = {ROOF_BWD: ["scatter_tiles_kernel<true, true>"],
                 ROOF_FWD: ["face_records_kernel<true>", "bin_boxes_kernel", "raster_tile_kernel<true, true>"]}
+WARP_TILES_KERNELS = ("occlusion_flow_tiles_kernel", "pair_consist_forward_tiles_kernel", "pair_consist_backward_tiles_kernel")
 
 
 ROOF_OPTIONAL = ()
+# the warp half over the render's tile list (round 4) and what one pixel of a covered tile makes each pass move
+WARP_TILES = ("occlusion_flow_tiles(train: occlusion + flow epilogue, sparse)", "pair_consist_forward_tiles(train, sparse)",
+              "pair_consist_backward_tiles(train, sparse)")
+WARP_TILES_BYTES = (44, 40, 48)
+WARP_TILES_WHAT = ("per pixel of a covered tile: own mask 4 + scale 4 + flow 8, gathered flow 8 + scale 4 + mask 4, out occl 4 + flow 8",
+                   "per pixel of a covered tile: flow 8 + source 12 + target 12 + two jitter values 8 (each image pixel counted once)",
+                   "per pixel of a covered tile: flow 8 + source 12 + target 12 + two jitter values 8, out grad_flow 8")
 
 
 def kernel_bench(dev, B, is_, iters, only=None):
@@ -241,13 +253,22 @@ def kernel_bench(dev, B, is_, iters, only=None):
     pcols_flow = (pcols * 1.5).contiguous()
     _lib.call("mr_render_flow_forward", P(pv), P(pf), P(pcols_flow), P(bg), 0, P(keep_lut), int(keep_lut.numel()), 0.99999,
               P(prgb), P(palpha), P(pmask), None, P(pwrec), P(pfim), P(ptile_hit), P(pwork), pwbytes, B2, pv.shape[1],
-              F0, 1, is_, 0.1, 100.0, 1e-3, 0, P(pvid), 0, None, None, 0, 0, st)
+              F0, 1, is_, 0.1, 100.0, 1e-3, _lib.FLAG_SPARSE_TILES, P(pvid), -1, P(tile_word), None, 0, 0, st)
+    torch.cuda.synchronize()
     pocc = torch.empty((B2, is_, is_), **f32)
+    # the render's tile list (in its workspace): what the sparse warp kernels of the training path are launched over
+    tlist = _lib.tile_list(pwork, B2, F, is_)
+    tl_bound = int(tile_word[0]) + int(tile_word[0]) // 8 + 64
 
     def occlusion_flow():  # occlusion check + flow epilogue of both directions (what the training step launches)
         _lib.call("mr_occlusion_flow", P(pmask[:B]), P(palpha[B:]), P(prgb[:B]), P(prgb[B:]), 3 * is_ * is_, P(pmask[:B]),
                   P(pmask[B:]), P(pocc[:B]), P(pocc[B:]), P(pflows[:B]), P(pflows[B:]), P(ptile_hit[:B]), P(ptile_hit[B:]), B, is_,
                   is_, is_, is_, 0.03, 0.99999, st)
+
+    def occlusion_flow_tiles():  # ... as the training step launches it since round 4: over the tile list, sparse outputs
+        _lib.call("mr_occlusion_flow_tiles", P(pmask[:B]), P(palpha[B:]), P(prgb[:B]), P(prgb[B:]), 3 * is_ * is_, P(pmask[:B]),
+                  P(pmask[B:]), P(pocc[:B]), P(pocc[B:]), P(pflows[:B]), P(pflows[B:]), P(ptile_hit[:B]), P(ptile_hit[B:]), B, is_,
+                  is_, is_, 0.03, 0.99999, tlist[0], tlist[1], tlist[2], tl_bound, st)
 
     occlusion_flow()
     if os.environ.get("HOC_ZERO_FLOWS"):  # experiment: the pair kernels on all-zero flows (nothing but the flow reads)
@@ -269,6 +290,19 @@ def kernel_bench(dev, B, is_, iters, only=None):
         _lib.call("mr_pair_consist_backward", P(flow12), P(flow21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(sums),
                   P(gl), P(gl), P(g12), P(g21), B, is_, is_, 0.99999, P(ptile_hit[:B]), P(ptile_hit[B:]), is_,
                   P(pgmax) if os.environ.get("HOC_GRAD_BOUND", "1") == "1" else None, st)
+
+    ptbytes = int(lib.mr_pair_consist_tiles_workspace_bytes(B, is_))
+    ptwork = torch.empty((ptbytes,), dtype=torch.uint8, device=dev)
+
+    def pair_fwd_tiles():
+        _lib.call("mr_pair_consist_forward_tiles", P(flow12), P(flow21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(ptwork), ptbytes,
+                  P(sums), P(lf), P(lb), B, is_, is_, 0.99999, P(ptile_hit[:B]), P(ptile_hit[B:]), is_, tlist[0], tlist[1],
+                  tlist[2], tl_bound, st)
+
+    def pair_bwd_tiles():
+        _lib.call("mr_pair_consist_backward_tiles", P(flow12), P(flow21), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(sums), P(gl),
+                  P(gl), P(g12), P(g21), B, is_, is_, 0.99999, P(ptile_hit[:B]), P(ptile_hit[B:]), is_,
+                  P(pgmax) if os.environ.get("HOC_GRAD_BOUND", "1") == "1" else None, tlist[0], tlist[1], tlist[2], tl_bound, st)
 
     m1, m2 = alpha.unsqueeze(1).contiguous(), alpha.unsqueeze(1).contiguous()
     o1, o2 = torch.empty((B, is_, is_), **f32), torch.empty((B, is_, is_), **f32)
@@ -344,6 +378,11 @@ def kernel_bench(dev, B, is_, iters, only=None):
         ("render_backward_full(D+E+F)", render_bwd_full, 56 * npx + 168 * BF),
         ("pair_consist_forward", pair_fwd, 48 * npx),
         ("pair_consist_backward", pair_bwd, 64 * npx),
+        # the same three passes as the training step launches them (round 4): over the render's tile list, outputs
+        # written under the covered tiles only -- same SURVEY 8(d) bytes, `compulsory_bytes` = what they have to move
+        (WARP_TILES[0], occlusion_flow_tiles, (8 + 16 + 8 + 16) * npx),
+        (WARP_TILES[1], pair_fwd_tiles, 48 * npx),
+        (WARP_TILES[2], pair_bwd_tiles, 64 * npx),
         ("occlusion_mask", occlusion, (8 + 16 + 8) * npx),
         # + the two final flows written in the same pass (16 B per pixel)
         ("occlusion_flow(train: occlusion + flow epilogue)", occlusion_flow, (8 + 16 + 8 + 16) * npx),
@@ -369,6 +408,16 @@ def kernel_bench(dev, B, is_, iters, only=None):
                      "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                      "frac_hbm_peak_cache_warm": round(nbytes / (ms_warm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del flush
+    covered_words = int((ptile_hit.view(torch.int32) != 0).sum())
+    for name, per_px, what in zip(WARP_TILES, WARP_TILES_BYTES, WARP_TILES_WHAT):
+        if name in out:
+            comp = covered_words * 32 * 8 * per_px + ptile_hit.numel()
+            k = out[name]
+            k.update({"covered_tiles": covered_words, "tiles": int(ptile_hit.numel() // 4), "compulsory_bytes": int(comp),
+                      "compulsory_bytes_are": what,
+                      "compulsory_GBps": round(comp / (k["ms"] * 1e-3) / 1e9, 1),
+                      "compulsory_frac_hbm_peak": round(comp / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "compulsory_frac_hbm_peak_cache_warm": round(comp / (k["ms_cache_warm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     if ROOF_BWD in out:
         # What the raster backward of the training path HAS to move, at least once, for this scene: per tile the forward
         # reports as covered (coverage bytes) the 256 pixels of face_index_map 4 + vertex ids 12 + sampling weights 12 +
@@ -503,8 +552,36 @@ def roofline_block(name, k, pmc, units):
     return roof
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` started as a PLAIN script (no RANK / WORLD_SIZE in the environment) with N > 1:
+    become the launcher -- re-execute this very command line under ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>``, one rank per GPU.  The ranks inherit this
+    process' stdout, so rank 0's ONE JSON line is this command's output.  Never returns."""
+    import socket
+
+    share = os.environ.get("HOC_SHARE_GPU", "0") == "1"
+    have = torch.cuda.device_count()
+    if have < 1:
+        sys.exit("bench.py needs a GPU")
+    if have < args.gpus and not share:
+        sys.exit(f"bench.py: --gpus {args.gpus} asks for {args.gpus} devices, this node shows {have} "
+                 f"(HOC_SHARE_GPU=1 HOC_DIST_BACKEND=gloo lets the ranks share devices: tests only)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("[bench] --gpus %d without a launcher: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    # one OpenMP thread per rank unless the caller says otherwise (what torchrun itself would set, without its warning)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_launch(args)
     # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 (RCCL prints its
     # version banner there, buffered until exit) is sent to stderr for the duration of the run
     real_stdout = os.dup(1)
@@ -536,7 +613,7 @@ def main():
     dist = None
     # HOC_FORCE_DDP=1: take the multi-GPU code path (RCCL process group, bucketed gradient reducer, barriers, max-over-ranks
     # all-reduce) with a single rank too -- how the path is exercised on a one-GPU box (tests/test_gpu_bench.py)
-    use_dist = world > 1 or os.environ.get("HOC_FORCE_DDP", "0") == "1"
+    use_dist = world > 1 or os.environ.get("HOC_FORCE_DDP", "0") == "1" or args.reducer_ab > 0
     if use_dist:
         import torch.distributed as dist
 
@@ -547,7 +624,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks "
+                 f"(plain `python bench.py --gpus N` starts its own N ranks)")
 
     from handobjectconsist_amd import _lib
     from handobjectconsist_amd.models.synthnet import SynthMeshRegNet
@@ -556,7 +635,7 @@ def main():
 
     assert _lib.load().mr_device_ok() == 1, "libmeshraster_hip.so: no gfx950 device"
     if args.kernels_only or args.roofline_only:
-        only = (ROOF_BWD, ROOF_FWD) if args.roofline_only else None
+        only = (ROOF_BWD, ROOF_FWD) + WARP_TILES if args.roofline_only else None
         if os.environ.get("HOC_KERNEL_GROUPS"):  # profiling aid: group names of kernel_bench, separated by ";"
             only = tuple(os.environ["HOC_KERNEL_GROUPS"].split(";"))
         os.write(real_stdout, (json.dumps(kernel_bench(dev, args.batch, args.image_size, args.kernel_iters, only), indent=1) + "\n").encode())
@@ -574,7 +653,7 @@ def main():
 
         net = DDP(model, device_ids=[dev_index], bucket_cap_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "8")),
                   broadcast_buffers=False, gradient_as_bucket_view=os.environ.get("HOC_DDP_BUCKET_VIEW", "1") == "1")
-    elif use_dist:
+    elif use_dist and not args.reducer_ab:
         from handobjectconsist_amd.netscripts.gradreduce import BucketedGradReducer
 
         # the model is NOT wrapped: 8 MB buckets, filled by one multi-tensor copy each from inside backward(), one
@@ -600,6 +679,40 @@ def main():
     # the reference raises on a NaN loss before backward / step (epochpassconsist.py:61-63): one host sync per step,
     # kept inside the timed region (HOC_CHECK_NAN=0 measures the step without it)
     check_nan = os.environ.get("HOC_CHECK_NAN", "1") == "1"
+    if args.reducer_ab:
+        # the cost of the data-parallel code path before a byte is communicated, decided inside one process: the plain
+        # loop and the reducer loop share the model, the optimiser state and every solver / GEMM choice
+        from handobjectconsist_amd.netscripts.gradreduce import BucketedGradReducer
+
+        def block(red):
+            for i in range(args.warmup):
+                train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan, reducer=red)
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for i in range(args.steps):
+                train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan, reducer=red)
+            if check_nan:
+                raise_pending_nan(optimizer)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / args.steps * 1e3
+
+        block(None)  # solver searches + allocator warm-up, outside every measured block
+        plain_ms, red_ms, nb = [], [], 0
+        for _ in range(args.reducer_ab):
+            plain_ms.append(round(block(None), 4))
+            red = BucketedGradReducer(model.parameters(), bucket_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "8")))
+            nb = len(red.buckets)
+            red_ms.append(round(block(red), 4))
+            red.remove()
+            optimizer.zero_grad(set_to_none=True)
+            del red
+        out = {"plain_ms": plain_ms, "one_rank_rccl_ms": red_ms, "ratios": [round(b_ / a_, 4) for a_, b_ in zip(plain_ms, red_ms)],
+               "backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "buckets": nb, "steps": args.steps,
+               "warmup": args.warmup, "what": "one process, one model; alternating blocks without / with the bucketed gradient "
+                                              "reducer (one rank: no byte leaves the device)"}
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        dist.destroy_process_group()
+        return
     for i in range(0 if args.hot_only else args.warmup):
         train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan, reducer=reducer)
     torch.cuda.synchronize()
@@ -716,7 +829,7 @@ def main():
             _sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark = saved
         torch.cuda.empty_cache()
 
-    kernels, roof, roof_fwd, cpu = None, None, None, None
+    kernels, roof, roof_fwd, cpu, warp_tiles = None, None, None, None, None
     if rank == 0 and not args.no_kernel_bench:
         kernels = kernel_bench(dev, B, is_, args.kernel_iters)
         pmc = {} if (args.no_pmc or world > 1) else pmc_traffic_in_run(args)
@@ -726,6 +839,18 @@ def main():
         roof = roofline_block(ROOF_BWD, kernels[ROOF_BWD], pmc, units)
         # ... and the forward of the same launch shape: the hot-path kernel that takes the most time
         roof_fwd = roofline_block(ROOF_FWD, kernels[ROOF_FWD], pmc, units)
+        # the warp half of the step (launched over the render's tile list): compulsory-bytes fractions + PMC traffic
+        warp_tiles = {}
+        for name, dk in zip(WARP_TILES, WARP_TILES_KERNELS):
+            k = kernels[name]
+            w = {"kernel": dk, "launch_ms": k["ms"], "launch_ms_cache_warm": k["ms_cache_warm"], "bytes": k["compulsory_bytes"],
+                 "bytes_are": k["compulsory_bytes_are"], "frac": k["compulsory_frac_hbm_peak"],
+                 "frac_cache_warm": k["compulsory_frac_hbm_peak_cache_warm"], "frac_algorithmic": k["frac_hbm_peak"],
+                 "traffic": None}
+            if dk in pmc:
+                w.update({"traffic": pmc[dk]["hbm_bytes"], "traffic_low": pmc[dk]["hbm_bytes_low"],
+                          "write_bytes": int(pmc[dk]["WRITE_SIZE_KB"] * 1024), "fetch_bytes_as_reported": int(pmc[dk]["FETCH_SIZE_KB"] * 1024)})
+            warp_tiles[name] = w
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_sample, is_, B)
         if (os.cpu_count() or 1) > 8:  # the figure that lines up with BASELINE.md's 8-thread reference measurement
@@ -754,7 +879,7 @@ def main():
                         "epilogue, pair loss, their backward passes)",
                 "device_ms_graph_replay": None if hot_graph_ms is None else round(hot_graph_ms, 3),
                 "eager_ms_host_bound": round(hot_eager_ms, 3)},
-            "ranks": ranks, "stock_trunk": stock, "roofline": roof, "roofline_forward": roof_fwd, "kernels": kernels, "cpu_baseline": cpu,
+            "ranks": ranks, "stock_trunk": stock, "roofline": roof, "roofline_forward": roof_fwd, "warp_tiles": warp_tiles, "kernels": kernels, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

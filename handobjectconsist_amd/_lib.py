@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmeshraster_hip.so")
-ABI_VERSION = 3  # MR_ABI_VERSION of include/meshraster_hip.h
+ABI_VERSION = 4  # MR_ABI_VERSION of include/meshraster_hip.h
 FLAG_REFERENCE_ALGO = 1
 FLAG_SPARSE_TILES = 2
 FLAG_OUTPUT_ZEROED = 4
@@ -55,6 +55,11 @@ SIGNATURES = {
     "mr_pair_consist_workspace_bytes": (_L, [_I, _I, _I]),
     "mr_pair_consist_forward": (_I, [_P] * 6 + [_I, _P, _L] + [_P] * 11 + [_I, _I, _I, _F, _P, _P, _I, _P]),
     "mr_pair_consist_backward": (_I, [_P] * 6 + [_I] + [_P] * 5 + [_I, _I, _I, _F, _P, _P, _I, _P, _P]),
+    "mr_render_tile_list": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "mr_occlusion_flow_tiles": (_I, [_P] * 4 + [_L] + [_P] * 8 + [_I, _I, _I, _I, _F, _F, _P, _P, _L, _L, _P]),
+    "mr_pair_consist_tiles_workspace_bytes": (_L, [_I, _I]),
+    "mr_pair_consist_forward_tiles": (_I, [_P] * 6 + [_I, _P, _L, _P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P, _P, _L, _L, _P]),
+    "mr_pair_consist_backward_tiles": (_I, [_P] * 6 + [_I] + [_P] * 5 + [_I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _L, _L, _P]),
     "mr_frames_to_batch_workspace_bytes": (_L, [_I, _I, _I]),
     "mr_frames_to_batch": (_I, [_P] * 3 + [_F] * 6 + [_P, _L, _P, _P] + [_I] * 6 + [_P]),
     "mr_bn_act_forward": (_I, [_P] * 6 + [_F, _I, _I, _I, _P, _I, _I, _I, _P]),
@@ -138,6 +143,19 @@ def call(name, *args):
         kind = {-1: "bad argument", -2: "not implemented"}.get(rc, f"hipError_t {rc}")
         raise RuntimeError(f"{name} failed: {kind}")
     return rc
+
+
+def tile_list(workspace, batch_size, num_faces, image_size):
+    """Where mr_render_flow_forward left the tile list in its ``workspace`` tensor: (header pointer, entries pointer,
+    capacity) for the *_tiles entry points, or None for raster sizes that build no list."""
+    hdr, ents, cap = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+    rc = load().mr_render_tile_list(ptr(workspace), int(batch_size), int(num_faces), int(image_size), ctypes.byref(hdr),
+                                    ctypes.byref(ents), ctypes.byref(cap))
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError(f"mr_render_tile_list failed: {rc}")
+    return hdr, ents, int(cap.value)
 
 
 def contig(t, dtype=torch.float32):

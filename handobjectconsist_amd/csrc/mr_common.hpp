@@ -441,4 +441,36 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
     return (bid & 7u) * (nblocks >> 3) + (bid >> 3);
 }
 
+// Header of the tile list of a render launch (one per call, in the render's workspace; raster_fwd.hip builds it, the
+// listed warp kernels of warp.hip walk it too).  Entries are uint4 {global tile id = image * tiles per image + tile (raster
+// orientation, row-major), offset and count of the bin's records, length of the image's large list}.
+struct TileList {
+    unsigned n_heavy;  // tiles with at least HEAVY_RECS candidate records, all images: dispatched FIRST; entries [0, n_heavy)
+    unsigned n_light;  // the other tiles with at least one candidate record; entries [cap, cap + n_light)
+    unsigned pad[62];
+};
+
+// A workgroup's place in a listed launch.  The dispatcher puts workgroup i on XCD i % 8, and every XCD has its own L2:
+// each XCD gets a contiguous eighth of the list's heavy part followed by the same eighth of its light part (the entries
+// of an image are contiguous in both parts, so an image's records stay in one L2, every XCD gets the same share of the
+// heavy tiles, and within an XCD the heavy ones are dispatched first).  Local entry j of XCD x is list entry slot(j).
+struct ListSlice {
+    unsigned first_heavy, n_heavy, first_light, n_local, stride;
+    __device__ __forceinline__ unsigned slot(unsigned j, unsigned cap) const {
+        return j < n_heavy ? first_heavy + j : cap + first_light + (j - n_heavy);
+    }
+};
+__device__ __forceinline__ ListSlice list_slice(unsigned n_heavy, unsigned n_light, unsigned& j) {
+    const unsigned nx = (gridDim.x & 7u) ? 1u : 8u;  // (grids that are no multiple of 8: one slice)
+    const unsigned x = blockIdx.x % nx;
+    j = blockIdx.x / nx;
+    ListSlice s;
+    s.first_heavy = (unsigned)((unsigned long long)n_heavy * x / nx);
+    s.n_heavy = (unsigned)((unsigned long long)n_heavy * (x + 1) / nx) - s.first_heavy;
+    s.first_light = (unsigned)((unsigned long long)n_light * x / nx);
+    s.n_local = s.n_heavy + (unsigned)((unsigned long long)n_light * (x + 1) / nx) - s.first_light;
+    s.stride = gridDim.x / nx;
+    return s;
+}
+
 }  // namespace mr

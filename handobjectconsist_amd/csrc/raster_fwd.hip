@@ -71,12 +71,7 @@ struct ImageHdr {
 struct BinHdr {
     unsigned off, cnt;  // the bin's records: recs[image base + off .. + cnt)
 };
-// Header of the tile list of a launch (one per call, in the workspace).
-struct TileList {
-    unsigned n_heavy;  // tiles with at least HEAVY_RECS candidate records, all images: dispatched FIRST
-    unsigned n_light;  // the other tiles with at least one candidate record
-    unsigned pad[62];
-};
+// (TileList, the header of a launch's tile list, lives in mr_common.hpp: the warp kernels walk the same list)
 // A tile's S1-S3 phase takes 6 us below 50 records and 16 - 20 us above 200 (workgroup timeline): handed out in screen
 // order, the last heavy tiles start when the launch is nearly over and the chip drains for 20 us behind them.  The list
 // therefore has two parts -- tiles with >= HEAVY_RECS records first -- so that the tail is made of light tiles.
@@ -926,28 +921,7 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
     }
 }
 
-// A workgroup's place in a listed launch.  The dispatcher puts workgroup i on XCD i % 8, and every XCD has its own L2:
-// each XCD gets a contiguous eighth of the list's heavy part followed by the same eighth of its light part (the entries
-// of an image are contiguous in both parts, so an image's records stay in one L2, every XCD gets the same share of the
-// heavy tiles, and within an XCD the heavy ones are dispatched first).  Local entry j of XCD x is list entry slot(j).
-struct ListSlice {
-    unsigned first_heavy, n_heavy, first_light, n_local, stride;
-    __device__ __forceinline__ unsigned slot(unsigned j, unsigned cap) const {
-        return j < n_heavy ? first_heavy + j : cap + first_light + (j - n_heavy);
-    }
-};
-__device__ __forceinline__ ListSlice list_slice(unsigned n_heavy, unsigned n_light, unsigned& j) {
-    const unsigned nx = (gridDim.x & 7u) ? 1u : 8u;  // (grids that are no multiple of 8: one slice)
-    const unsigned x = blockIdx.x % nx;
-    j = blockIdx.x / nx;
-    ListSlice s;
-    s.first_heavy = (unsigned)((unsigned long long)n_heavy * x / nx);
-    s.n_heavy = (unsigned)((unsigned long long)n_heavy * (x + 1) / nx) - s.first_heavy;
-    s.first_light = (unsigned)((unsigned long long)n_light * x / nx);
-    s.n_local = s.n_heavy + (unsigned)((unsigned long long)n_light * (x + 1) / nx) - s.first_light;
-    s.stride = gridDim.x / nx;
-    return s;
-}
+// (ListSlice / list_slice: mr_common.hpp)
 
 // Listed launches whose tile list turned out LONGER than the grid (the caller's guess was low): the slice's entries
 // beyond the first round, with the slice's stride.  Deliberately NOT inlined, and handed the kernel's argument block
@@ -1138,6 +1112,11 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
         hipLaunchKernelGGL((face_records_kernel<VC>), dim3((unsigned)((bp.F0 + 255) / 256), (unsigned)B), dim3(256), 0, s,
                            bp);
         MR_CHECK_LAUNCH();
+    } else if (bp.tlist) {
+        // no face, no per-face pass: the list counters that pass clears (thread 0 of image 0) are cleared here, before
+        // the binning pass adds to them -- an empty mesh gives an empty list, not whatever the workspace held
+        hipError_t e = hipMemsetAsync(bp.tlist, 0, sizeof(TileList), s);
+        if (e != hipSuccess) return (int)e;
     }
     static size_t allowed = 48 * 1024;  // dynamic LDS beyond the default limit is an opt-in, raised on demand
     if (lds > allowed) {
@@ -1206,6 +1185,20 @@ extern "C" int mr_selftest_division(const float* a, const float* b, float* refin
 extern "C" int64_t mr_render_workspace_bytes(int batch_size, int num_faces, int image_size) {
     if (batch_size < 0 || num_faces < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
     return (int64_t)work_layout(batch_size, num_faces, image_size).total;
+}
+
+extern "C" int mr_render_tile_list(const void* workspace, int batch_size, int num_faces, int image_size,
+                                   const void** list_header, const void** list_entries, int64_t* list_capacity) {
+    if (!workspace || !list_header || !list_entries || !list_capacity) return MR_ERR_BADARG;
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
+    const WorkLayout w = work_layout(batch_size, num_faces, image_size);
+    // (a list is built when a bin is a tile and the global tile ids fit 31 bits: launch_bins)
+    if (w.ysh != 0 || (int64_t)batch_size * w.nbx * w.nby > 0x7fffffffLL) return MR_ERR_NOTIMPL;
+    const char* base = (const char*)workspace;
+    *list_header = base + w.off_tlist;
+    *list_entries = base + w.off_tile_ids;
+    *list_capacity = (int64_t)batch_size * w.nbx * w.nby;
+    return MR_OK;
 }
 
 extern "C" int mr_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,

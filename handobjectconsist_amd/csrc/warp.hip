@@ -19,6 +19,8 @@
 //
 // grid_sample semantics restated (torch, zeros padding, align_corners=False):
 //   vx = 2 (x + u) / max(W - 1, 1) - 1 ;  ix = ((vx + 1) W - 1) / 2        
+#include <algorithm>
+
 #include "mr_common.hpp"
 
 namespace mr {
@@ -911,6 +913,246 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Listed launches (mr_*_tiles): the warp half of the training path over the render's tile list
+// ---------------------------------------------------------------------------------------
+// A frame pair's hand + object meshes cover a sixth of the screen.  The dense kernels above launch a workgroup for
+// every block of every image (16 384 of them at B = 64, 256 x 256), five sixths of which read their coverage words and
+// leave -- residency x lifetime of those workgroups is half of the dense launch (27 / 23 / 21 us of 47 / 45 / 39), and
+// the epilogue and the pair backward still WRITE their zeros under them (98 + 66 MB per step, for no reader: every
+// consumer on the training path consults the coverage bytes first).  The render of the stacked pair (2B images: frame
+// 1 of every pair, then frame 2) already holds the list of the tiles with candidate faces (raster_fwd.hip:
+// bin_boxes_kernel); everything the warp half computes about direction 1 -> 2 lives at pixels frame 1's render covers
+// (occl1, flow12, the pair loss's backward term, grad_flow12), and likewise for 2 -> 1 -- so ONE list entry (image of
+// the stack, 32 x 8 raster tile) is one workgroup's work in all three kernels, one pixel per thread, and nothing is
+// dispatched, read or written for the rest of the screen.  Granularity of the contract: a tile whose 4-byte coverage
+// word is non-zero gets all its pixels (inside the crop) written; tiles with a zero word -- listed or not -- get
+// NOTHING, and no reader may look there.  Same XCD slices as the render's tile kernel (list_slice): what it wrote for
+// a tile is read back behind the same L2.
+struct ListArgs {
+    const TileList* tlist;
+    const uint4* ids;
+    unsigned cap;
+};
+
+struct TileAt {
+    int img, dir, b, tile, x, ry, y;  // image of the stack, direction (0: frame 1's grid, 1: frame 2's), pair, raster tile,
+    uint32_t word;                    // pixel column, raster row, image row of this thread; the tile's coverage word
+    bool row_covered;                 // this thread's row pair holds a covered pixel (the planes are defined there)
+};
+__device__ __forceinline__ TileAt tile_at(unsigned gtile, int B, int tiles_x, int T, int is, const uint8_t* __restrict__ hit_lo,
+                                          const uint8_t* __restrict__ hit_hi) {
+    TileAt t;
+    t.img = (int)(gtile / (unsigned)T);
+    t.tile = (int)(gtile % (unsigned)T);
+    t.dir = t.img >= B ? 1 : 0;
+    t.b = t.img - t.dir * B;
+    t.word = *reinterpret_cast<const uint32_t*>((t.dir ? hit_hi : hit_lo) + ((int64_t)t.b * T + t.tile) * 4);
+    t.x = (t.tile % tiles_x) * 32 + (int)(threadIdx.x & 31u);
+    t.ry = (t.tile / tiles_x) * 8 + (int)(threadIdx.x >> 5);
+    t.y = is - 1 - t.ry;
+    t.row_covered = ((t.word >> (8 * ((t.ry & 7) >> 1))) & 0xffu) != 0u;
+    return t;
+}
+
+struct OcclTilesParams {
+    const float* mask[2];    // mask_flow1 / mask_flow2  [B,is,is]
+    const float* flow[2];    // flow12 / flow21 planes (batch stride fbstride)
+    const float* scale[2];   // nullable
+    float* occl[2];
+    float* out[2];           // [B,crop_h,crop_w,2]
+    const uint8_t* hit[2];
+    int64_t fbstride;
+    int B, is, crop_h, crop_w, tiles_x, tiles_y;
+    float dist_thresh, wthresh;
+    ListArgs list;
+};
+
+__global__ void __launch_bounds__(256) occlusion_flow_tiles_kernel(OcclTilesParams p) {
+    unsigned j;
+    const ListSlice sl = list_slice(p.list.tlist->n_heavy, p.list.tlist->n_light, j);
+    const int T = p.tiles_x * p.tiles_y, is = p.is;
+    const int64_t hw = (int64_t)is * is;
+    for (; j < sl.n_local; j += sl.stride) {
+        const TileAt t = tile_at(p.list.ids[sl.slot(j, p.list.cap)].x, p.B, p.tiles_x, T, is, p.hit[0], p.hit[1]);
+        if (t.word == 0u || t.x >= is || t.ry >= is) continue;  // (uniform | border tiles of rasters that are no multiple of the tile)
+        const int a = t.dir, o_ = 1 - t.dir;
+        const float* ma = p.mask[a] + (int64_t)t.b * hw;
+        const float* mb = p.mask[o_] + (int64_t)t.b * hw;
+        const float* fab = p.flow[a] + (int64_t)t.b * p.fbstride;
+        const float* fba = p.flow[o_] + (int64_t)t.b * p.fbstride;
+        const float* sab = p.scale[a] ? p.scale[a] + (int64_t)t.b * hw : nullptr;
+        const float* sba = p.scale[o_] ? p.scale[o_] + (int64_t)t.b * hw : nullptr;
+        const uint8_t* ha = p.hit[a] + (int64_t)t.b * T * 4;
+        const uint8_t* hb = p.hit[o_] + (int64_t)t.b * T * 4;
+        const int64_t pix = (int64_t)t.y * is + t.x;
+        float o = 0.0f;
+        if (t.row_covered) o = occl_one(ma, mb, fab, fba, sab, sba, hw, is, is, t.x, t.y, p.dist_thresh, p.wthresh, ha, hb, p.tiles_x);
+        p.occl[a][(int64_t)t.b * hw + pix] = o;
+        if (t.y < p.crop_h && t.x < p.crop_w) {
+            // (an occlusion bit can only be non-zero inside its own image's coverage: occl_one's guarded reads came first)
+            const float sc = (o != 0.0f && sab) ? sab[pix] : 1.0f;
+            const float post = o != 0.0f ? ma[pix] * o : 0.0f;
+            float2 r = make_float2(0.0f, 0.0f);
+            if (post != 0.0f && sc != 0.0f) r = make_float2((fab[pix] * sc) * post, (fab[hw + pix] * sc) * post);
+            *reinterpret_cast<float2*>(p.out[a] + (((int64_t)t.b * p.crop_h + t.y) * p.crop_w + t.x) * 2) = r;
+        }
+    }
+}
+
+struct PairTilesParams {
+    const float* flow[2];     // flow12 / flow21 [B,H,W,2]
+    const float* image_ref;   // [B,3,H,W]
+    const float* image;
+    const float* jitter_ref;  // [B,Cj,H,W]
+    const float* jitter;
+    int Cj;
+    float* partial;           // forward: [2B, T, 2] {masked L1 sum, 3 x valid count} of stack image i's direction
+    const uint8_t* hit[2];
+    int B, H, W, is, tiles_x, tiles_y;
+    float thresh;
+    ListArgs list;
+    // backward
+    const float* sums;        // [B,4]
+    const float* grad_loss_fwd;
+    const float* grad_loss_bwd;  // nullable
+    float* grad_flow[2];
+    unsigned* grad_max;       // nullable, [2B]
+};
+
+// direction 0 = frame 1's pixel grid: flow12 warps `image` towards image_ref, gated by jitter_ref (imgflowarp.py:84,82,88,
+// 99-107: the loss's "backward" term, sums[2..3]); direction 1 = frame 2's grid: flow21 warps image_ref towards image,
+// gated by jitter (:80,85-87,93-102: the "forward" term, sums[0..1])
+struct PairDir {
+    const float* src;
+    const float* tgt;
+    const float* jit;
+};
+__device__ __forceinline__ PairDir pair_dir(const PairTilesParams& p, int dir) {
+    PairDir d;
+    d.src = dir ? p.image_ref : p.image;
+    d.tgt = dir ? p.image : p.image_ref;
+    d.jit = dir ? p.jitter : p.jitter_ref;
+    return d;
+}
+
+__global__ void __launch_bounds__(256, 6) pair_consist_forward_tiles_kernel(PairTilesParams p) {
+    __shared__ float red[2][4][2];
+    unsigned j;
+    const ListSlice sl = list_slice(p.list.tlist->n_heavy, p.list.tlist->n_light, j);
+    const int T = p.tiles_x * p.tiles_y;
+    const int64_t hw = (int64_t)p.H * p.W;
+    unsigned round = 0;
+    for (; j < sl.n_local; j += sl.stride, round++) {
+        const TileAt t = tile_at(p.list.ids[sl.slot(j, p.list.cap)].x, p.B, p.tiles_x, T, p.is, p.hit[0], p.hit[1]);
+        if (t.word == 0u) continue;
+        float sum = 0.0f, cnt = 0.0f;
+        if (t.row_covered && t.x < p.W && t.y >= 0 && t.y < p.H) {
+            const int64_t pix = (int64_t)t.y * p.W + t.x;
+            const float2 uv = pair_flow(p.flow[t.dir], t.b, t.x, t.y, p.H, p.W);
+            // a pixel whose flow has a zero x component is invalid whatever the images hold (imgflowarp.py:93-100)
+            if (uv.x != 0.0f) {
+                const PairDir d = pair_dir(p, t.dir);
+                const DirTaps tp = pair_taps(uv, t.x, t.y, p.H, p.W);
+                DirRaw2 q{};
+                pair_load(tp, d.src, d.tgt, d.jit, d.jit, p.Cj, false, t.b, pix, hw, q);
+                pin(q);
+                const DirRaw r = unpack(q, tp.a);
+                const DirOut e = pair_eval(tp, r, p.H, p.W, p.thresh, false);
+                if (e.valid) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) sum += fabsf(e.s[c] - r.tgt[c]);
+                    cnt = 3.0f;
+                }
+            }
+        }
+        // block sums, fixed order (wave butterflies, then the four wave partials in wave order); the LDS slots alternate
+        // between rounds so that a round needs ONE barrier
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { sum += __shfl_xor(sum, off); cnt += __shfl_xor(cnt, off); }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = round & 1u;
+        if (lane == 0) { red[slot][wave][0] = sum; red[slot][wave][1] = cnt; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* o = p.partial + ((int64_t)t.img * T + t.tile) * 2;
+            o[0] = red[slot][0][0] + red[slot][1][0] + red[slot][2][0] + red[slot][3][0];
+            o[1] = red[slot][0][1] + red[slot][1][1] + red[slot][2][1] + red[slot][3][1];
+        }
+    }
+}
+
+// per-sample fixed-order reduction of the tile partials, read only where the coverage words say a workgroup wrote one
+__global__ void __launch_bounds__(64) pair_consist_finalize_tiles_kernel(const float* __restrict__ partial,
+                                                                         const uint32_t* __restrict__ hit12,
+                                                                         const uint32_t* __restrict__ hit21, int B, int T,
+                                                                         float* __restrict__ sums, float* __restrict__ loss_fwd,
+                                                                         float* __restrict__ loss_bwd) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = lane; t < T; t += 64) {
+        if (hit21[(int64_t)b * T + t] != 0u) {
+            const float2 v = *reinterpret_cast<const float2*>(partial + ((int64_t)(B + b) * T + t) * 2);
+            a[0] += v.x; a[1] += v.y;
+        }
+        if (hit12[(int64_t)b * T + t] != 0u) {
+            const float2 v = *reinterpret_cast<const float2*>(partial + ((int64_t)b * T + t) * 2);
+            a[2] += v.x; a[3] += v.y;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[k] += __shfl_xor(a[k], off);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) sums[b * 4 + k] = a[k];
+        const float n1 = (a[1] == 0.0f) ? 1.0f : a[1], n2 = (a[3] == 0.0f) ? 1.0f : a[3];
+        if (loss_fwd) loss_fwd[b] = a[0] / n1;
+        if (loss_bwd) loss_bwd[b] = a[2] / n2;
+    }
+}
+
+__global__ void __launch_bounds__(256) pair_consist_backward_tiles_kernel(PairTilesParams p) {
+    unsigned j;
+    const ListSlice sl = list_slice(p.list.tlist->n_heavy, p.list.tlist->n_light, j);
+    const int T = p.tiles_x * p.tiles_y;
+    const int64_t hw = (int64_t)p.H * p.W;
+    for (; j < sl.n_local; j += sl.stride) {
+        const TileAt t = tile_at(p.list.ids[sl.slot(j, p.list.cap)].x, p.B, p.tiles_x, T, p.is, p.hit[0], p.hit[1]);
+        if (t.word == 0u) continue;
+        unsigned u = 0u;
+        if (t.x < p.W && t.y >= 0 && t.y < p.H) {
+            const int64_t pix = (int64_t)t.y * p.W + t.x;
+            float2 g = make_float2(0.0f, 0.0f);
+            const float c = p.sums[t.b * 4 + (t.dir ? 1 : 3)];
+            const float* gl = t.dir ? p.grad_loss_fwd : p.grad_loss_bwd;
+            const float coef = gl ? gl[t.b] / ((c == 0.0f) ? 1.0f : c) : 0.0f;
+            if (t.row_covered && coef != 0.0f) {
+                const float2 uv = pair_flow(p.flow[t.dir], t.b, t.x, t.y, p.H, p.W);
+                if (uv.x != 0.0f) {  // the gradient of an invalid pixel is 0 (see the forward kernel)
+                    const PairDir d = pair_dir(p, t.dir);
+                    const DirTaps tp = pair_taps(uv, t.x, t.y, p.H, p.W);
+                    DirRaw2 q{};
+                    pair_load(tp, d.src, d.tgt, d.jit, d.jit, p.Cj, false, t.b, pix, hw, q);
+                    pin(q);
+                    const DirRaw r = unpack(q, tp.a);
+                    const DirOut e = pair_eval(tp, r, p.H, p.W, p.thresh, false);
+                    g = pair_grad(tp, r, e, p.H, p.W, coef);
+                }
+            }
+            *reinterpret_cast<float2*>(p.grad_flow[t.dir] + ((int64_t)t.b * hw + pix) * 2) = g;
+            u = max(__float_as_uint(g.x) & 0x7fffffffu, __float_as_uint(g.y) & 0x7fffffffu);
+        }
+        // the largest |gradient| per image of the stack (see pair_consist_backward_kernel)
+        if (p.grad_max && __ballot(u != 0u) != 0ull) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, off));
+            if ((threadIdx.x & 63) == 0 && u > p.grad_max[t.img]) atomicMax(&p.grad_max[t.img], u);
+        }
+    }
+}
+
 }  // namespace mr
 
 using namespace mr;
@@ -1098,6 +1340,121 @@ extern "C" int mr_flow_finalize_backward(const float* grad_flow, const float* ma
     if (n == 0) return MR_OK;
     hipLaunchKernelGGL(flow_finalize_backward_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream,
                        grad_flow, mask_pre, mask_x, occl, grad_rgb_img, batch_size, image_size, height, width);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+
+// ---- listed launches of the warp half (see the kernels) --------------------------------------------------------------
+static unsigned listed_grid(int64_t tile_bound, int64_t cap) {
+    if (tile_bound <= 0) tile_bound = (cap + 3) / 4;
+    const int64_t bound = std::min<int64_t>((cap + 7) & ~(int64_t)7, std::max<int64_t>((tile_bound + 7) & ~(int64_t)7, 8));
+    return (unsigned)bound;
+}
+
+extern "C" int mr_occlusion_flow_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                                       const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                                       const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
+                                       float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2, int batch_size,
+                                       int image_size, int crop_height, int crop_width, float distance_thresh,
+                                       float warp_thresh, const void* list_header, const void* list_entries,
+                                       int64_t list_capacity, int64_t tile_bound, mr_stream_t stream) {
+    if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2 || !flow_out12 || !flow_out21 || !tile_hit1 ||
+        !tile_hit2 || !list_header || !list_entries)
+        return MR_ERR_BADARG;
+    if (batch_size < 0 || image_size <= 0 || flow_bstride < 2LL * image_size * image_size) return MR_ERR_BADARG;
+    if (crop_height <= 0 || crop_width <= 0 || crop_height > image_size || crop_width > image_size) return MR_ERR_BADARG;
+    const int tiles_x = (image_size + 31) / 32, tiles_y = (image_size + 7) / 8;
+    if (list_capacity != 2LL * batch_size * tiles_x * tiles_y || list_capacity > 0x7fffffffLL) return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    OcclTilesParams p{{mask_flow1, mask_flow2}, {flow12, flow21}, {flow12_scale, flow21_scale}, {occl1, occl2},
+                      {flow_out12, flow_out21}, {tile_hit1, tile_hit2}, flow_bstride, batch_size, image_size, crop_height,
+                      crop_width, tiles_x, tiles_y, distance_thresh, warp_thresh,
+                      {(const TileList*)list_header, (const uint4*)list_entries, (unsigned)list_capacity}};
+    hipLaunchKernelGGL(occlusion_flow_tiles_kernel, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int64_t mr_pair_consist_tiles_workspace_bytes(int batch_size, int hit_image_size) {
+    if (batch_size < 0 || hit_image_size <= 0) return MR_ERR_BADARG;
+    return 2LL * batch_size * ((hit_image_size + 31) / 32) * ((hit_image_size + 7) / 8) * 2 * (int64_t)sizeof(float);
+}
+
+static int pair_tiles_args_ok(const float* flow12, const float* flow21, const float* image_ref, const float* image,
+                              const float* jitter_ref, const float* jitter, int jitter_channels, int batch_size, int height,
+                              int width, const uint8_t* tile_hit12, const uint8_t* tile_hit21, int hit_image_size,
+                              const void* list_header, const void* list_entries, int64_t list_capacity) {
+    if (!flow12 || !flow21 || !image_ref || !image || !jitter_ref || !jitter || !tile_hit12 || !tile_hit21 || !list_header ||
+        !list_entries)
+        return MR_ERR_BADARG;
+    if (jitter_channels != 1 && jitter_channels != 3) return MR_ERR_BADARG;
+    if (batch_size < 0 || height <= 0 || width <= 0 || hit_image_size < height || hit_image_size < width) return MR_ERR_BADARG;
+    if (width < 2 || (int64_t)height * width > (1LL << 29)) return MR_ERR_BADARG;  // row-pair taps, 32-bit byte offsets
+    const int64_t T = (int64_t)((hit_image_size + 31) / 32) * ((hit_image_size + 7) / 8);
+    if (list_capacity != 2LL * batch_size * T || list_capacity > 0x7fffffffLL) return MR_ERR_BADARG;
+    return MR_OK;
+}
+
+extern "C" int mr_pair_consist_forward_tiles(const float* flow12, const float* flow21, const float* image_ref,
+                                             const float* image, const float* jitter_ref, const float* jitter,
+                                             int jitter_channels, void* workspace, int64_t workspace_bytes, float* sums,
+                                             float* loss_fwd, float* loss_bwd, int batch_size, int height, int width,
+                                             float thresh, const uint8_t* tile_hit12, const uint8_t* tile_hit21,
+                                             int hit_image_size, const void* list_header, const void* list_entries,
+                                             int64_t list_capacity, int64_t tile_bound, mr_stream_t stream) {
+    const int rc = pair_tiles_args_ok(flow12, flow21, image_ref, image, jitter_ref, jitter, jitter_channels, batch_size, height,
+                                      width, tile_hit12, tile_hit21, hit_image_size, list_header, list_entries, list_capacity);
+    if (rc != MR_OK) return rc;
+    if (!workspace || !sums || workspace_bytes < mr_pair_consist_tiles_workspace_bytes(batch_size, hit_image_size))
+        return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    PairTilesParams p{};
+    p.flow[0] = flow12; p.flow[1] = flow21;
+    p.image_ref = image_ref; p.image = image; p.jitter_ref = jitter_ref; p.jitter = jitter; p.Cj = jitter_channels;
+    p.partial = (float*)workspace;
+    p.hit[0] = tile_hit12; p.hit[1] = tile_hit21;
+    p.B = batch_size; p.H = height; p.W = width; p.is = hit_image_size;
+    p.tiles_x = (hit_image_size + 31) / 32; p.tiles_y = (hit_image_size + 7) / 8;
+    p.thresh = thresh;
+    p.list = ListArgs{(const TileList*)list_header, (const uint4*)list_entries, (unsigned)list_capacity};
+    hipLaunchKernelGGL(pair_consist_forward_tiles_kernel, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    MR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(64), 0, (hipStream_t)stream,
+                       (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit12),
+                       reinterpret_cast<const uint32_t*>(tile_hit21), batch_size, p.tiles_x * p.tiles_y, sums, loss_fwd, loss_bwd);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_pair_consist_backward_tiles(const float* flow12, const float* flow21, const float* image_ref,
+                                              const float* image, const float* jitter_ref, const float* jitter,
+                                              int jitter_channels, const float* sums, const float* grad_loss_fwd,
+                                              const float* grad_loss_bwd, float* grad_flow12, float* grad_flow21,
+                                              int batch_size, int height, int width, float thresh,
+                                              const uint8_t* tile_hit12, const uint8_t* tile_hit21, int hit_image_size,
+                                              float* grad_max, const void* list_header, const void* list_entries,
+                                              int64_t list_capacity, int64_t tile_bound, mr_stream_t stream) {
+    const int rc = pair_tiles_args_ok(flow12, flow21, image_ref, image, jitter_ref, jitter, jitter_channels, batch_size, height,
+                                      width, tile_hit12, tile_hit21, hit_image_size, list_header, list_entries, list_capacity);
+    if (rc != MR_OK) return rc;
+    if (!sums || !grad_loss_fwd || !grad_flow12 || !grad_flow21) return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    PairTilesParams p{};
+    p.flow[0] = flow12; p.flow[1] = flow21;
+    p.image_ref = image_ref; p.image = image; p.jitter_ref = jitter_ref; p.jitter = jitter; p.Cj = jitter_channels;
+    p.hit[0] = tile_hit12; p.hit[1] = tile_hit21;
+    p.B = batch_size; p.H = height; p.W = width; p.is = hit_image_size;
+    p.tiles_x = (hit_image_size + 31) / 32; p.tiles_y = (hit_image_size + 7) / 8;
+    p.thresh = thresh;
+    p.list = ListArgs{(const TileList*)list_header, (const uint4*)list_entries, (unsigned)list_capacity};
+    p.sums = sums; p.grad_loss_fwd = grad_loss_fwd; p.grad_loss_bwd = grad_loss_bwd;
+    p.grad_flow[0] = grad_flow12; p.grad_flow[1] = grad_flow21;
+    p.grad_max = reinterpret_cast<unsigned*>(grad_max);
+    hipLaunchKernelGGL(pair_consist_backward_tiles_kernel, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
+                       (hipStream_t)stream, p);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

@@ -73,7 +73,9 @@ def forward(
             supervision-by-consistency, later frames are the references it is compared with
         hand_face: closed hand faces [F,3] (or already batched [B,F,3])
         use_backward: also compare the warp of the unannotated frame with the annotated image
-        pair_outputs: "full" (masks / warps / diffs as the reference returns them) or "loss"
+        pair_outputs: "full" (masks / warps / diffs as the reference returns them) or "loss" (the trainer's setting:
+            masks / warps / diffs are None and ``recons_flows`` hold defined values only where their renders cover
+            something -- ``flow._base._hoc_coverage`` -- everything else is unspecified memory)
 
     Returns:
         (mean pair loss, {"masks", "warps", "recons_flows", "diffs", "diff_losses"})
@@ -88,6 +90,9 @@ def forward(
         detach_textures=False,
         detach_renders=True,
         ignore_face_idxs=hand_ignore_faces,
+        # "loss": nobody but pair_consist looks at the flows -- they (and the gradient that comes back for them) are then
+        # computed and stored under the renders' covered tiles only
+        sparse_flows=(pair_outputs == "loss"),
     )
     ref_image, ref_jitter = _q(samples[0], "image").cuda(), _q(samples[0], "jittermask").cuda()
     per_pair = [

@@ -56,7 +56,10 @@ def train_step(batches, premodel, optimizer, check_nan=True, reducer=None):
     (AMP's GradScaler protocol) is put back after the step.  Optimisers without the ``found_inf`` operand get the
     synchronous check before ``step`` (one host read per step, as in the reference).
     ``reducer`` (data-parallel runs): a ``gradreduce.BucketedGradReducer`` over the model's parameters; its
-    all-reduces are issued from inside ``backward`` and joined before the optimiser reads the gradients."""
+    all-reduces are issued from inside ``backward`` and joined before the optimiser reads the gradients.  The NaN
+    flag is then GLOBAL: it rides through the last bucket's all-reduce, so a NaN loss on any rank skips the update
+    and raises on every rank in the same step (the replicas stay identical and no rank is left waiting in a
+    collective)."""
     if check_nan:
         raise_pending_nan(optimizer)
     losses, logs = [], {}
@@ -76,12 +79,18 @@ def train_step(batches, premodel, optimizer, check_nan=True, reducer=None):
     nan_flag = torch.isnan(loss.detach()) if check_nan else None
     optimizer.zero_grad(set_to_none=True)
     if loss.requires_grad:
+        if reducer is not None and check_nan:
+            reducer.set_flag(nan_flag)  # travels with the last gradient bucket
         if reducer is not None and reducer.loss_scale != 1.0:
             (loss * reducer.loss_scale).backward()  # summed over the ranks: the mean gradient
         else:
             loss.backward()
         if reducer is not None:
             reducer.finish()
+            if check_nan:
+                # the gradients are rank-summed: ONE rank's NaN loss is every rank's NaN gradient.  The guard must
+                # therefore be the same decision everywhere -- any rank's flag skips the update (and raises) on all
+                nan_flag = reducer.flag()
         if check_nan and _device_guarded(optimizer):
             had = {k: optimizer.__dict__[k] for k in ("grad_scale", "found_inf") if k in optimizer.__dict__}
             optimizer.grad_scale, optimizer.found_inf = None, nan_flag.to(torch.float32).reshape(())

@@ -23,7 +23,18 @@ communicated: 30.1-30.7 ms per step against 26.6 ms without the wrapper, 430 aga
   scaling kernel per step even on one rank, profiles/r03_one_rank_reducer_overlap_v1.txt);
 * ``finish()`` after ``backward()`` flushes buckets with parameters that received no gradient (zeros, so that
   every rank reduces the same buckets) and makes the compute stream wait for the collectives; the optimiser
-  then reads the averaged gradients straight from the views.
+  then reads the averaged gradients straight from the views;
+* collectives are issued STRICTLY in bucket order on every rank: a bucket whose gradients are complete waits for
+  its predecessors (a rank whose graph happens to finish bucket 3 before bucket 2 must not pair its all-reduce
+  with another rank's bucket 2 -- RCCL matches collectives by issue order, not by buffer);
+* one extra element behind the last bucket's gradients carries a per-step FLAG through the same all-reduce
+  (``set_flag`` before ``backward()``, ``flag()`` after ``finish()``): the trainer's NaN guard becomes a
+  decision every rank takes identically, at no extra collective.
+
+All ranks must train the same parameter set.  A parameter that received no gradient on a rank contributes zeros
+and ends up with a zero (not ``None``) gradient: under Adam without weight decay (trainmeshwarp.py's optimiser)
+such a parameter does not move while its moments are zero, but unlike the single-process path its step counter
+advances.
 
 The same code runs for every world size, including 1 (no short cut: the one-rank run is how the cost of the
 path is measured on a one-GPU box).
@@ -35,11 +46,11 @@ import torch.distributed as dist
 class _Bucket:
     __slots__ = ("params", "flat", "views", "pending", "work", "launched")
 
-    def __init__(self, params):
+    def __init__(self, params, extra=0):
         self.params = params
         total = sum(p.numel() for p in params)
         first = params[0]
-        self.flat = torch.zeros(total, dtype=first.dtype, device=first.device)
+        self.flat = torch.zeros(total + extra, dtype=first.dtype, device=first.device)
         self.views, off = [], 0
         for p in params:
             n = p.numel()
@@ -89,7 +100,9 @@ class BucketedGradReducer:
             key = k
             cur.append(p)
             cur_bytes += nbytes
-        self.buckets.append(_Bucket(cur))
+        self.buckets.append(_Bucket(cur, extra=1))
+        self._flag = self.buckets[-1].flat[-1:]  # rides through the last bucket's all-reduce (sum over the ranks)
+        self._next = 0  # index of the first bucket not yet issued in this step
         self._handles = []
         for b in self.buckets:
             for p in b.params:
@@ -116,9 +129,24 @@ class BucketedGradReducer:
     def _make_hook(self, bucket):
         def hook(_param):
             bucket.pending -= 1
-            if bucket.pending == 0:
-                self._launch(bucket)
+            # strictly in bucket order: a complete bucket behind an incomplete one waits for it
+            while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+                self._launch(self.buckets[self._next])
+                self._next += 1
         return hook
+
+    def set_flag(self, flag):
+        """Before ``backward()``: this rank's flag of the step (0-dim or 1-element tensor or Python number, non-zero =
+        raised).  ``flag()`` after ``finish()`` tells whether ANY rank raised it."""
+        with torch.no_grad():
+            if torch.is_tensor(flag):
+                self._flag.copy_(flag.reshape(1).to(self._flag.dtype))
+            else:
+                self._flag.fill_(float(bool(flag)))
+
+    def flag(self):
+        """After ``finish()``: 0-dim bool tensor on the parameters' device, identical on every rank."""
+        return (self._flag != 0).reshape(()).clone()
 
     # ------------------------------------------------------------------ per step
     def _launch(self, b):
@@ -137,12 +165,12 @@ class BucketedGradReducer:
     def finish(self):
         """After ``backward()``: every bucket reduced, the current stream ordered behind the collectives,
         ``p.grad`` = the rank-summed gradient of the pre-scaled loss = the mean gradient (a view into the bucket's flat buffer)."""
-        for b in self.buckets:
-            if not b.launched:
-                self._launch(b)
+        for b in self.buckets[self._next:]:
+            self._launch(b)
         for b in self.buckets:
             b.work.wait()
             b.work, b.launched, b.pending = None, False, len(b.params)
+        self._next = 0
 
     def remove(self):
         for h in self._handles:

@@ -99,6 +99,12 @@ def warp(x, flow, thresh=0.99999, mode="bilinear"):
 # the stacked pair loss hands the per-image maximum of its flow gradients to the raster backward (mr_render_flow_backward's
 # grad_bound); False: that kernel finds its scale itself
 PASS_GRADIENT_BOUND = True
+# outputs="loss" on flows that carry their render's tile list (get_opticalflow(..., sparse_flows=True)): both pair kernels
+# run over that list (mr_pair_consist_*_tiles) and the flow gradient is WRITTEN under the covered tiles only -- its one
+# reader on the training path, mr_render_flow_backward, consults the same coverage bytes.  False: the dense kernels.
+USE_TILE_LIST_KERNELS = True
+# tests: fill the sparse gradient buffer with NaN first, so that a read outside the covered tiles shows up downstream
+DEBUG_POISON_SPARSE_GRADS = False
 
 
 class _PairConsistFunction(torch.autograd.Function):
@@ -106,7 +112,8 @@ class _PairConsistFunction(torch.autograd.Function):
     flows only (the images / jitter masks are data on the training path)."""
 
     @staticmethod
-    def forward(ctx, flow12, flow21, image_ref, image, jitter_ref, jitter, thresh, want_debug, coverage=None, coverage_size=0):
+    def forward(ctx, flow12, flow21, image_ref, image, jitter_ref, jitter, thresh, want_debug, coverage=None, coverage_size=0,
+                tiles=None):
         _lib.check_cuda(flow12, flow21, image_ref, image, jitter_ref, jitter)
         im_ref, im = _lib.contig(image_ref), _lib.contig(image)
         ctx.stacked = flow21 is None  # flow12 = [2B,H,W,2]: both flows in one tensor (get_opticalflow's fused path)
@@ -137,11 +144,26 @@ class _PairConsistFunction(torch.autograd.Function):
             hit12, hit21 = coverage[:B], coverage[B:]
         ctx.coverage = (hit12, hit21, int(coverage_size))
         lib = _lib.load()
-        wbytes = int(lib.mr_pair_consist_workspace_bytes(B, H, W))
-        work = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
         sums = torch.empty((B, 4), dtype=torch.float32, device=dev)
         loss_fwd = torch.empty((B,), dtype=torch.float32, device=dev)
         loss_bwd = torch.empty((B,), dtype=torch.float32, device=dev)
+        # the sparse contract: stacked flows with their render's tile list, nobody asking for per-pixel outputs
+        listed = (tiles is not None and USE_TILE_LIST_KERNELS and ctx.stacked and hit12 is not None and not want_debug
+                  and tiles[2] == coverage.numel() // 4)
+        ctx.tiles = tiles if listed else None
+        if listed:
+            wbytes = int(lib.mr_pair_consist_tiles_workspace_bytes(B, int(coverage_size)))
+            work = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
+            _lib.call("mr_pair_consist_forward_tiles", _lib.ptr(f12), _lib.ptr(f21), _lib.ptr(im_ref), _lib.ptr(im),
+                      _lib.ptr(jm_ref), _lib.ptr(jm), Cj, _lib.ptr(work), wbytes, _lib.ptr(sums), _lib.ptr(loss_fwd),
+                      _lib.ptr(loss_bwd), B, H, W, float(thresh), _lib.ptr(hit12), _lib.ptr(hit21), int(coverage_size),
+                      tiles[0], tiles[1], tiles[2], tiles[3], _lib.stream_ptr(dev))
+            ctx.save_for_backward(f12, f21, im_ref, im, jm_ref, jm, sums)
+            ctx.thresh = float(thresh)
+            ctx.set_materialize_grads(False)
+            return loss_fwd, loss_bwd
+        wbytes = int(lib.mr_pair_consist_workspace_bytes(B, H, W))
+        work = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
         dbg = [None] * 8
         if want_debug:
             fm1 = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
@@ -165,7 +187,7 @@ class _PairConsistFunction(torch.autograd.Function):
         f12, f21, im_ref, im, jm_ref, jm, sums = ctx.saved_tensors
         B, _, H, W = im.shape
         if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) or (g_fwd is None and g_bwd is None):
-            return (None,) * 10
+            return (None,) * 11
         hit12, hit21, cov_size = ctx.coverage
         dev = im.device
         if g_fwd is None:
@@ -173,6 +195,19 @@ class _PairConsistFunction(torch.autograd.Function):
         g_fwd = _lib.contig(g_fwd)
         g_bwd = _lib.contig(g_bwd) if g_bwd is not None else None
         gmax = None
+        tiles = ctx.tiles
+        if tiles is not None:
+            # sparse contract: written under the covered tiles only (the raster backward reads nothing else)
+            grad_both = (torch.full((2 * B, H, W, 2), float("nan"), dtype=torch.float32, device=dev) if DEBUG_POISON_SPARSE_GRADS
+                         else torch.empty((2 * B, H, W, 2), dtype=torch.float32, device=dev))
+            gmax = torch.zeros((2 * B,), dtype=torch.float32, device=dev) if PASS_GRADIENT_BOUND else None
+            _lib.call("mr_pair_consist_backward_tiles", _lib.ptr(f12), _lib.ptr(f21), _lib.ptr(im_ref), _lib.ptr(im),
+                      _lib.ptr(jm_ref), _lib.ptr(jm), int(jm.shape[1]), _lib.ptr(sums), _lib.ptr(g_fwd), _lib.ptr(g_bwd),
+                      _lib.ptr(grad_both[:B]), _lib.ptr(grad_both[B:]), B, H, W, ctx.thresh, _lib.ptr(hit12), _lib.ptr(hit21),
+                      cov_size, _lib.ptr(gmax), tiles[0], tiles[1], tiles[2], tiles[3], _lib.stream_ptr(dev))
+            if gmax is not None:
+                grad_both._hoc_grad_bound = (gmax, grad_both._version)
+            return (grad_both,) + (None,) * 10
         if ctx.stacked:  # one gradient tensor for the stacked flows: no slice / cat nodes in autograd
             grad_both = torch.empty((2 * B, H, W, 2), dtype=torch.float32, device=dev)
             grad12, grad21 = grad_both[:B], grad_both[B:]
@@ -190,8 +225,8 @@ class _PairConsistFunction(torch.autograd.Function):
         if ctx.stacked:
             if gmax is not None:  # (rides on the gradient tensor, tied to its version like the coverage bytes of the flows)
                 grad_both._hoc_grad_bound = (gmax, grad_both._version)
-            return (grad_both,) + (None,) * 9
-        return (grad12, grad21) + (None,) * 8
+            return (grad_both,) + (None,) * 10
+        return (grad12, grad21) + (None,) * 9
 
 
 def _stacked_base(flow12, flow21):
@@ -230,6 +265,15 @@ def _coverage_of(stacked):
     return note[0], note[1]
 
 
+def _tiles_of(stacked):
+    """... and the tile list of the renders behind them, when ``get_opticalflow(..., sparse_flows=True)`` produced flows
+    that are defined under the covered tiles only (None otherwise)."""
+    note = getattr(stacked, "_hoc_coverage", None) if stacked is not None else None
+    if note is None or note[2] != stacked._version or len(note) < 4:
+        return None
+    return note[3]
+
+
 def pair_consist(
     recons_flow,
     image_ref: torch.Tensor,
@@ -264,9 +308,13 @@ def pair_consist(
         want_debug = outputs == "full"
         stacked = _stacked_base(recons_flow[0], recons_flow[1])
         coverage, coverage_size = _coverage_of(stacked)
+        tiles = _tiles_of(stacked)
+        if tiles is not None and (want_debug or not USE_TILE_LIST_KERNELS):
+            raise ValueError('flows from get_opticalflow(..., sparse_flows=True) are defined under their renders\' coverage '
+                             'only: pair_consist reads them with outputs="loss" (the tile-list kernels)')
         res = _PairConsistFunction.apply(stacked if stacked is not None else recons_flow[0],
                                          None if stacked is not None else recons_flow[1], image_ref, image,
-                                         jitter_mask_ref, jitter_mask, 0.99999, want_debug, coverage, coverage_size)
+                                         jitter_mask_ref, jitter_mask, 0.99999, want_debug, coverage, coverage_size, tiles)
         losses_fwd, losses_bwd = res[0], res[1]
         warp_loss = losses_bwd + losses_fwd if use_backward else losses_fwd
         if not want_debug:

@@ -30,10 +30,13 @@ def get_opticalflows(
     detach_textures: bool = False,
     detach_renders: bool = False,
     ignore_face_idxs=None,
+    sparse_flows: bool = False,
 ):
     """
     Compute optical flow between pairs of meshes (the same mesh at different time steps),
     always comparing to the first mesh (reference opticalflow.py:10-48).
+
+    ``sparse_flows`` (not in the reference): see ``get_opticalflow``.
     """
     all_flows = []
     for vert_world, camintr in zip(verts_cam[1:], camintrs[1:]):
@@ -46,6 +49,7 @@ def get_opticalflows(
             detach_textures=detach_textures,
             detach_renders=detach_renders,
             ignore_face_idxs=ignore_face_idxs,
+            sparse_flows=sparse_flows,
         )
         all_flows.append(flows)
     return all_flows
@@ -94,6 +98,10 @@ DEBUG_POISON_RENDER_OUTPUTS = False
 # list entries (+ margin) -- the kernel reports its list length into a pinned host word, read here without any
 # synchronisation; a stale or missing value only changes how the list is split over launches, never the images.
 USE_TILE_LIST = True
+# ... and, for callers that ask for ``sparse_flows``, runs the occlusion check + flow epilogue over that same list
+# (mr_occlusion_flow_tiles): the flows and the occlusion masks are WRITTEN under the covered tiles only, and the list rides
+# along with the coverage bytes so that pair_consist (outputs="loss") does the same with its two kernels.
+USE_TILE_LIST_WARP = True
 
 _TILE_COUNTS = {}
 
@@ -303,10 +311,15 @@ class _StackedFlowFunction(torch.autograd.Function):
     backward: ONE launch (mr_render_flow_backward): the adjoint of the epilogue is applied on the fly to the
               flow-space gradient, the colour-space gradient [2B,3,is,is] is never materialised, empty tiles are
               skipped on the coverage bytes.
-    Differentiable w.r.t. ``cols`` only (detach_renders=True)."""
+    Differentiable w.r.t. ``cols`` only (detach_renders=True).
+    ``sparse``: the occlusion / epilogue pass runs over the render's tile list and writes ``flow`` / ``occl`` under the
+    covered tiles only (mr_occlusion_flow_tiles); ``last_tiles`` hands the list to ``get_opticalflow``."""
+
+    last_tiles = None
 
     @staticmethod
-    def forward(ctx, ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, height, width):
+    def forward(ctx, ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, height, width,
+                sparse=False):
         from handobjectconsist_amd.neurender import rasterize
 
         ctx.set_materialize_grads(False)
@@ -350,14 +363,28 @@ class _StackedFlowFunction(torch.autograd.Function):
                   B2, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps),
                   _lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0, _lib.ptr(vid), bound, _lib.ptr(count_word), _lib.ptr(grad_buf),
                   int(grad_buf.numel()) if grad_buf is not None else 0, textutils.texel_layout_code(), st)
-        occl = torch.empty((B2, is_, is_), **f32)
-        flow = torch.empty((B2, height, width, 2), **f32)
+        # the render's tile list, for callers that accept flows defined under the covered tiles only
+        tiles = None
+        if sparse and USE_TILE_LIST_WARP and bound != 0:
+            where = _lib.tile_list(work, B2, F, is_)
+            if where is not None:
+                tiles = (where[0], where[1], where[2], int(bound), work)  # (`work` rides along: the list lives in it)
+        _StackedFlowFunction.last_tiles = tiles
+        occl = new_f(B2, is_, is_) if tiles else torch.empty((B2, is_, is_), **f32)
+        flow = new_f(B2, height, width, 2) if tiles else torch.empty((B2, height, width, 2), **f32)
         # occlusion check + crop / permute / mask products of both directions in one pass.  mask_flow2 is the RAW
         # alpha inside the occlusion block and afterwards (Q4); the masked flows rgb * mask are formed on the fly
-        _lib.call("mr_occlusion_flow", _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(rgb[:B]), _lib.ptr(rgb[B:]),
-                  3 * is_ * is_, _lib.ptr(mask[:B]), _lib.ptr(mask[B:]), _lib.ptr(occl[:B]), _lib.ptr(occl[B:]),
-                  _lib.ptr(flow[:B]), _lib.ptr(flow[B:]), _lib.ptr(tile_hit[:B]), _lib.ptr(tile_hit[B:]), B, is_, is_, height,
-                  width, 0.03, 0.99999, st)
+        if tiles:
+            _lib.call("mr_occlusion_flow_tiles", _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(rgb[:B]), _lib.ptr(rgb[B:]),
+                      3 * is_ * is_, _lib.ptr(mask[:B]), _lib.ptr(mask[B:]), _lib.ptr(occl[:B]), _lib.ptr(occl[B:]),
+                      _lib.ptr(flow[:B]), _lib.ptr(flow[B:]), _lib.ptr(tile_hit[:B]), _lib.ptr(tile_hit[B:]), B, is_, height,
+                      width, 0.03, 0.99999, tiles[0], tiles[1], tiles[2], tiles[3], st)
+        else:
+            _lib.call("mr_occlusion_flow", _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(rgb[:B]), _lib.ptr(rgb[B:]),
+                      3 * is_ * is_, _lib.ptr(mask[:B]), _lib.ptr(mask[B:]), _lib.ptr(occl[:B]), _lib.ptr(occl[B:]),
+                      _lib.ptr(flow[:B]), _lib.ptr(flow[B:]), _lib.ptr(tile_hit[:B]), _lib.ptr(tile_hit[B:]), B, is_, is_, height,
+                      width, 0.03, 0.99999, st)
+        ctx.tiles = tiles
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width)
         ctx.save_for_backward(verts, fidx, fim, tile_hit, wmap, depth if depth is not None else vid, mask, alpha, occl)
         ctx.records = depth is None
@@ -371,7 +398,7 @@ class _StackedFlowFunction(torch.autograd.Function):
         depth, vid = (None, depth_or_vid) if ctx.records else (depth_or_vid, None)
         is_, eps, fill_back, height, width = ctx.cfg
         if grad_flow is None or not ctx.needs_input_grad[2]:
-            return (None,) * 12
+            return (None,) * 13
         B2, V = verts.shape[:2]
         B = B2 // 2
         g = _lib.contig(grad_flow)
@@ -388,7 +415,7 @@ class _StackedFlowFunction(torch.autograd.Function):
                   _lib.ptr(occl), height, width, _lib.ptr(grad_cols), B2, V, int(fidx.shape[1]), int(fill_back), is_, eps,
                   _lib.FLAG_OUTPUT_ZEROED if zeroed else 0, _lib.ptr(vid), textutils.texel_layout_code(), _lib.ptr(bound),
                   _lib.stream_ptr(verts.device))
-        return (None, None, grad_cols) + (None,) * 9
+        return (None, None, grad_cols) + (None,) * 10
 
 
 def _stacked_flow_node_ok(neurenderer, num_verts):
@@ -425,10 +452,17 @@ def get_opticalflow(
     detach_textures: bool = False,
     detach_renders: bool = True,
     ignore_face_idxs=None,
+    sparse_flows: bool = False,
 ):
     """
     Compute optical flow in image space given the displacement of the vertices in
     verts_cam (reference opticalflow.py:51-156).
+
+    ``sparse_flows`` (not in the reference; default off = fully defined tensors): the caller promises to read the
+    returned flows only where the coverage bytes that ride on them (``flows[0]._base._hoc_coverage``) are non-zero --
+    ``pair_consist(..., outputs="loss")`` does.  The training path then neither computes nor WRITES anything under the
+    five sixths of the screen no mesh touches (the flows are exactly zero there; with this flag those zeros are simply
+    not stored).  Ignored on every path but the stacked training node.
 
     Returns:
         [pred_flow12, pred_flow21], each [batch_size, H, W, 2] in pixel units.
@@ -451,11 +485,14 @@ def get_opticalflow(
             lut = _keep_lut(ignore_face_idxs, dev) if ignore_face_idxs is not None else None
             flows, tile_hit = _StackedFlowFunction.apply(
                 ndc, _stacked_faces(faces), cols, lut, neurenderer.fill_back, is_, neurenderer.near, neurenderer.far,
-                neurenderer.rasterizer_eps, neurenderer.background_color, min(int(H), is_), min(int(W), is_))
+                neurenderer.rasterizer_eps, neurenderer.background_color, min(int(H), is_), min(int(W), is_),
+                bool(sparse_flows))
+            tiles, _StackedFlowFunction.last_tiles = _StackedFlowFunction.last_tiles, None
             # the coverage bytes of the two renders ride along: a consumer that knows them (pair_consist) does not
-            # even read the flows where nothing was rendered (they are exactly zero there)
+            # even read the flows where nothing was rendered (they are exactly zero there -- or, with sparse_flows,
+            # not even written: then the render's tile list rides along too)
             # (recorded with the tensor's version: an in-place write into the flows invalidates the hand-over)
-            flows._hoc_coverage = (tile_hit, is_, flows._version)
+            flows._hoc_coverage = (tile_hit, is_, flows._version, tiles)
             return [flows[:B], flows[B:]]
         # both renders of the pair as one launch over 2B meshes, in the training path's output set (no depth /
         # weight maps, third colour plane untouched, flow mask folded into the render)
@@ -482,7 +519,8 @@ def get_opticalflow(
     flows = [ro["rgb"] * m for ro, m in zip(renders, valid)]
     if mask_occlusions:
         # from here on the second direction's mask is the RAW alpha of its render (no threshold, no ignore list)
-        raw_alpha2 = renders[1]["alpha"].unsqueeze(1)
+        # -- assigned inside the reference's no_grad block (opticalflow.py:137-139): it carries NO gradient into the render
+        raw_alpha2 = renders[1]["alpha"].detach().unsqueeze(1)
         with torch.no_grad():
             visible = imgflowarp.get_occlusion_mask(valid[0], raw_alpha2, flows[0], flows[1])
         flows = [flow * (m * vis.unsqueeze(1)) for flow, m, vis in zip(flows, (valid[0], raw_alpha2), visible)]

@@ -63,8 +63,10 @@ typedef void* mr_stream_t;
 /* ABI version of this header (bumped on any signature change): what mr_abi_version() of a matching library returns.
  * 2: mr_pair_consist_* coverage arguments, mr_occlusion_flow, mr_render_flow_*, workspace queries (round 2);
  * 3: mr_render_flow_forward tile_bound / tile_count_out / zero_fill, MR_FLAG_OUTPUT_ZEROED, texel_layout of the four
- *    vertex-colour entry points. */
-#define MR_ABI_VERSION 3
+ *    vertex-colour entry points;
+ * 4: mr_render_tile_list, mr_occlusion_flow_tiles, mr_pair_consist_{forward,backward}_tiles, mr_pair_consist_tiles_workspace_bytes
+ *    (the warp half of the training path over the render's tile list: the sparse contract, round 4). */
+#define MR_ABI_VERSION 4
 MR_API int mr_abi_version(void);
 /* 1 if the calling thread's CURRENT HIP device is a gfx950, else 0.
  * Device contract of every entry point below: kernels are launched on the calling thread's current HIP
@@ -462,6 +464,53 @@ MR_API int mr_pair_consist_backward(const float* flow12, const float* flow21, co
                              float* grad_flow12, float* grad_flow21, int batch_size,
                              int height, int width, float thresh, const uint8_t* tile_hit12,
                              const uint8_t* tile_hit21, int hit_image_size, float* grad_max, mr_stream_t stream);
+
+/* ---- the warp half of the training path over the render's tile list (the SPARSE contract) -----------------------
+ * The stacked render of a frame pair (mr_render_flow_forward over 2B images: frame 1 of every pair, then frame 2; called
+ * with MR_FLAG_SPARSE_TILES and tile_bound != 0) leaves in its workspace the list of the 32 x 8 screen tiles that hold
+ * candidate faces.  mr_render_tile_list returns where (device pointers into `workspace`, valid until the workspace is
+ * reused; MR_ERR_NOTIMPL for raster sizes that build no list):
+ *   list_header: two counters {n_heavy, n_light};  list_entries: uint4[2 * capacity], entry.x = image * tiles + tile
+ *   (heavy entries at [0, n_heavy), light ones at [capacity, capacity + n_light));  capacity = batch * tiles.
+ * The three *_tiles entry points below are mr_occlusion_flow / mr_pair_consist_forward / mr_pair_consist_backward of that
+ * stacked pair launched over the list -- one workgroup per (image of the stack, tile), nothing dispatched for the five
+ * sixths of the screen no mesh touches -- with SPARSE outputs:
+ *   a tile whose 4-byte coverage word (tile_hit) is non-zero gets every pixel of its outputs written (zeros where
+ *   nothing is to be computed); under all other tiles the output buffers keep WHATEVER THEY HELD.
+ * Legal for callers that consult the coverage bytes before every read of those buffers: the three entry points do so
+ * among themselves, and so does mr_render_flow_backward for grad_flow / occl.  Callers that hand the tensors to anyone else
+ * use the dense entry points above.  Arguments are those of the dense entry points (batch_size = B pairs; *1 / *12 =
+ * frame 1's grid, images [0, B) of the stack; *2 / *21 = frame 2's, images [B, 2B)) plus the list (capacity must equal
+ * 2 B tiles) and tile_bound = the caller's guess of the list length, as for mr_render_flow_forward (any value gives
+ * the same results; <= 0: a quarter of the tiles).
+ * mr_pair_consist_forward_tiles: workspace of mr_pair_consist_tiles_workspace_bytes(B, hit_image_size) bytes; the
+ * reduction is two-stage and deterministic (per-tile partials in fixed order), but its order differs from the dense
+ * entry point's (32 x 8 instead of 64 x 4 blocks): sums agree to fp32 rounding, not bit for bit.  No debug outputs. */
+MR_API int mr_render_tile_list(const void* workspace, int batch_size, int num_faces, int image_size,
+                               const void** list_header, const void** list_entries, int64_t* list_capacity);
+MR_API int mr_occlusion_flow_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                                   const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                                   const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
+                                   float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2, int batch_size,
+                                   int image_size, int crop_height, int crop_width, float distance_thresh,
+                                   float warp_thresh, const void* list_header, const void* list_entries,
+                                   int64_t list_capacity, int64_t tile_bound, mr_stream_t stream);
+MR_API int64_t mr_pair_consist_tiles_workspace_bytes(int batch_size, int hit_image_size);
+MR_API int mr_pair_consist_forward_tiles(const float* flow12, const float* flow21, const float* image_ref,
+                                         const float* image, const float* jitter_ref, const float* jitter,
+                                         int jitter_channels, void* workspace, int64_t workspace_bytes, float* sums,
+                                         float* loss_fwd, float* loss_bwd, int batch_size, int height, int width,
+                                         float thresh, const uint8_t* tile_hit12, const uint8_t* tile_hit21,
+                                         int hit_image_size, const void* list_header, const void* list_entries,
+                                         int64_t list_capacity, int64_t tile_bound, mr_stream_t stream);
+MR_API int mr_pair_consist_backward_tiles(const float* flow12, const float* flow21, const float* image_ref,
+                                          const float* image, const float* jitter_ref, const float* jitter,
+                                          int jitter_channels, const float* sums, const float* grad_loss_fwd,
+                                          const float* grad_loss_bwd, float* grad_flow12, float* grad_flow21,
+                                          int batch_size, int height, int width, float thresh,
+                                          const uint8_t* tile_hit12, const uint8_t* tile_hit21, int hit_image_size,
+                                          float* grad_max, const void* list_header, const void* list_entries,
+                                          int64_t list_capacity, int64_t tile_bound, mr_stream_t stream);
 
 /* ---- dataset pipeline: decoded frames -> network-input batch ------------------------------
  * One launch for a whole batch of what meshreg/datasets/handobjset.py:361-379 does per sample on the

@@ -88,3 +88,81 @@ def test_ddp_gloo_two_ranks(tmp_path):
     expect = (_local_grad(0) + _local_grad(1)) / 2
     err = (res["g"][0] - expect).abs().max() / expect.abs().max()
     assert err < 1e-4, err
+
+
+def _worker_guard(rank, world, port, out):
+    """NaN on ONE rank, and buckets that complete out of order."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from handobjectconsist_amd.netscripts import epochpassconsist as E
+    from handobjectconsist_amd.netscripts.gradreduce import BucketedGradReducer
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            # registration order outer, inner; the data flows inner -> outer, so the gradient of `outer` (LAST bucket:
+            # buckets are filled in reverse registration order) is complete BEFORE the gradient of `inner` (first bucket)
+            self.outer = torch.nn.Linear(300, 1)
+            self.inner = torch.nn.Linear(4, 300)
+            self.bad = False
+
+        def forward(self, batch):
+            loss = self.outer(torch.tanh(self.inner(batch["x"]))).mean().reshape(1)
+            if self.bad:
+                loss = loss * float("nan")
+            return loss, {}, None, None
+
+    res = {}
+    for fused in (False, True):
+        torch.manual_seed(7 + rank)
+        net = Net()
+        reducer = BucketedGradReducer(net.parameters(), bucket_mb=0.001)  # 1 KB: one parameter tensor per bucket
+        assert len(reducer.buckets) == 4
+        order = []
+        launch = reducer._launch
+        reducer._launch = lambda b: (order.append(reducer.buckets.index(b)), launch(b))[1]
+        opt = torch.optim.Adam(net.parameters(), lr=0.1, fused=fused)
+        batch = {"data": [{}], "x": torch.randn(5, 4)}
+        E.train_step([batch], net, opt, reducer=reducer)
+        assert order == [0, 1, 2, 3], order  # ready order is 2/3 first: held until 0 and 1 went out
+        w1 = torch.cat([p.detach().flatten() for p in net.parameters()])
+        net.bad = rank == 1  # only rank 1 diverges
+        raised = []
+        try:
+            E.train_step([batch], net, opt, reducer=reducer)   # synchronous check: raises here, on BOTH ranks
+            net.bad = False
+            E.train_step([batch], net, opt, reducer=reducer)   # device-side guard: raises when the next step starts
+        except ValueError as e:
+            raised.append(str(e))
+        w2 = torch.cat([p.detach().flatten() for p in net.parameters()])
+        steps = [float(st["step"]) for st in opt.state.values()]
+        # the healthy rank must have skipped the update too, and both must still be able to talk to each other
+        probe = torch.ones(1)
+        dist.all_reduce(probe)
+        res[fused] = {"raised": raised, "same": bool(torch.equal(w1, w2)), "steps": steps, "probe": float(probe), "w": w2}
+        reducer.remove()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_nan_on_one_rank_stops_every_rank_in_the_same_step(tmp_path):
+    """A NaN loss on one rank is NaN gradients on all of them after the all-reduce: the guard has to be global
+    (the flag rides through the last gradient bucket).  Also: collectives go out in bucket order whatever order the
+    gradients complete in."""
+    out = str(tmp_path / "guard.pt")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_guard, args=(2, port, out), nprocs=2, join=True)
+    per_rank = torch.load(out, weights_only=False)
+    for fused in (False, True):
+        for r in per_rank:
+            assert len(r[fused]["raised"]) == 1 and "nan" in r[fused]["raised"][0]
+            assert r[fused]["same"], "the diverged step touched the parameters of a rank"
+            assert all(s == 1.0 for s in r[fused]["steps"])
+            assert r[fused]["probe"] == 2.0
+        assert torch.equal(per_rank[0][fused]["w"], per_rank[1][fused]["w"])

@@ -340,6 +340,40 @@ def test_flow_forward_tile_list_equals_one_workgroup_per_tile(cuda, B, is_):
     assert int(word[0]) == n_tiles
 
 
+def test_flow_forward_tile_list_of_an_empty_mesh(cuda):
+    """num_faces = 0 with a listed launch: the per-face pass (which clears the list counters) does not run, so the entry
+    point clears them itself -- on a workspace full of garbage the result is the background everywhere, an empty list and
+    zero coverage bytes, for every tile_bound."""
+    from handobjectconsist_amd import _lib
+
+    B, is_, V = 2, 64, 5
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    f32 = dict(dtype=torch.float32, device=cuda)
+    v, cols = torch.randn((B, V, 3), **f32), torch.randn((B, V, 3), **f32)
+    fidx = torch.zeros((B, 1, 3), dtype=torch.int32, device=cuda)
+    bg = torch.tensor([0.25, 0.5, 0.75], **f32)
+    wbytes = int(_lib.load().mr_render_workspace_bytes(B, 2, is_))
+    word = torch.zeros(1, dtype=torch.int32).pin_memory()
+    for bound in (0, -1, 1, 10 ** 6):
+        work = torch.full((wbytes,), 0xFF, dtype=torch.uint8, device=cuda)
+        rgb = torch.full((B, 3, is_, is_), float("nan"), **f32)
+        alpha, mask = torch.full((B, is_, is_), float("nan"), **f32), torch.full((B, is_, is_), float("nan"), **f32)
+        wmap = torch.full((B, is_, is_, 3), float("nan"), **f32)
+        fim = torch.full((B, is_, is_), -7, dtype=torch.int32, device=cuda)
+        vid = torch.full((B, is_, is_, 3), -7, dtype=torch.int32, device=cuda)
+        hit = torch.full((B, (is_ + 7) // 8, (is_ + 31) // 32, 4), 9, dtype=torch.uint8, device=cuda)
+        word[0] = 123
+        _lib.call("mr_render_flow_forward", P(v), P(fidx), P(cols), P(bg), 0, None, 0, 0.99999, P(rgb), P(alpha), P(mask), None,
+                  P(wmap), P(fim), P(hit), P(work), wbytes, B, V, 0, 1, is_, 0.1, 100.0, 1e-3, _lib.FLAG_SPARSE_TILES, P(vid),
+                  bound, P(word) if bound else None, None, 0, 0, st)
+        torch.cuda.synchronize()
+        assert int(hit.max()) == 0, f"coverage bytes, tile_bound={bound}"
+        if bound:
+            assert int(word[0]) == 0, f"list length {int(word[0])}, tile_bound={bound}"
+        # nothing is rendered: a sparse launch writes no pixel (the coverage bytes say so); nothing may be garbage either
+        assert int((fim != -7).sum()) == 0 or int((fim[fim != -7] != -1).sum()) == 0
+
+
 def test_flow_forward_clears_the_backwards_output_buffer(cuda):
     """mr_render_flow_forward's zero_fill + MR_FLAG_OUTPUT_ZEROED of mr_render_flow_backward: the binning pass clears the
     (poisoned) gradient buffer, the backward adds into it without its own memset and gives what the self-clearing call

@@ -469,7 +469,7 @@ def test_pair_loss_with_coverage_bytes_equals_dense(cuda, B, is_, H, Wd):
                                         detach_textures=False, detach_renders=True,
                                         ignore_face_idxs=synth.HAND_IGNORE_FACES)
     base = flows[0]._base
-    coverage, cov_size, noted_version = base._hoc_coverage
+    coverage, cov_size, noted_version = base._hoc_coverage[:3]
     assert noted_version == base._version
     assert cov_size == is_ and coverage.shape == (2 * B, is_ // 8, is_ // 32, 4)
     im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, H, Wd, 3)]
@@ -597,3 +597,73 @@ def test_occlusion_flow_equals_occlusion_then_finalize(cuda, B, is_, H, W):
     assert torch.equal(o1, o1f) and torch.equal(o2, o2f)
     assert torch.equal(f12, g12) and torch.equal(f21, g21)
     assert float(f12.abs().sum()) > 0 and float(f21.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("B,is_,H,Wd,bound", [(3, 256, 256, 256, None), (2, 96, 64, 96, 8), (2, 480, 270, 480, None),
+                                              (5, 64, 64, 64, 10 ** 6)])
+def test_sparse_warp_half_equals_dense(cuda, monkeypatch, B, is_, H, Wd, bound):
+    """The sparse contract of the training path (get_opticalflow(sparse_flows=True) -> pair_consist(outputs="loss")):
+    occlusion + epilogue, pair loss and pair-loss backward run over the render's tile list and WRITE under the covered
+    tiles only.  On NaN-poisoned buffers: the flows equal the dense path's bit for bit under every tile with a non-zero
+    coverage word and are untouched elsewhere; losses agree to fp32 rounding (the per-tile partial sums are added in
+    another fixed order); the gradient that reaches the vertices of both frames agrees -- i.e. the raster backward read
+    the flow gradient and the occlusion mask nowhere outside the coverage.  `bound`: the tile-list guess (8 = nearly the
+    whole list goes through the kernels' grid-stride rounds; None: 'auto' first, then the previous call's length)."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import imgflowarp, opticalflow
+
+    s = synth.random_scene(B, seed=7, image_size=is_)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
+                   no_light=True, light_intensity_ambient=0.8)
+    im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, H, Wd, 5)]
+    crit = PyramidCriterion(criterion="l1")
+    weights = torch.linspace(0.5, 1.5, B, device=cuda)
+    monkeypatch.setattr(opticalflow, "DEBUG_POISON_RENDER_OUTPUTS", True)
+    monkeypatch.setattr(imgflowarp, "DEBUG_POISON_SPARSE_GRADS", True)
+    if bound is not None:
+        real_bound = opticalflow._tile_bound
+        monkeypatch.setattr(opticalflow, "_tile_bound", lambda dev, B2, size: (bound, real_bound(dev, B2, size)[1]))
+    calls = []
+    real_call = imgflowarp._lib.call
+    monkeypatch.setattr(imgflowarp._lib, "call", lambda name, *a: (calls.append(name), real_call(name, *a))[1])
+
+    def run(sparse):
+        v1, v2 = t(s["verts1"], cuda).requires_grad_(True), t(s["verts2"], cuda).requires_grad_(True)
+        flows = opticalflow.get_opticalflow([v1, v2], t(s["faces"], cuda), [t(s["K1"], cuda), t(s["K2"], cuda)], ren,
+                                            orig_img_size=(Wd, H), detach_textures=False, detach_renders=True,
+                                            ignore_face_idxs=synth.HAND_IGNORE_FACES, sparse_flows=sparse)
+        base = flows[0]._base
+        loss, masks, _, _ = imgflowarp.pair_consist(flows, im_ref, im, jm_ref, jm, crit, use_backward=True, outputs="loss")
+        assert masks is None
+        (loss * weights).sum().backward()
+        torch.cuda.synchronize()
+        return base.detach().clone(), base._hoc_coverage, loss.detach().clone(), v1.grad.clone(), v2.grad.clone()
+
+    flow_d, note_d, loss_d, g1_d, g2_d = run(False)
+    assert note_d[3] is None and "mr_occlusion_flow_tiles" not in calls
+    assert float(loss_d.abs().sum()) > 0 and float(g1_d.abs().sum()) > 0 and torch.isfinite(flow_d).all()
+    for _ in range(2):  # (the second call takes the first one's list length as its guess)
+        del calls[:]
+        flow_s, note_s, loss_s, g1_s, g2_s = run(True)
+        for name in ("mr_occlusion_flow_tiles", "mr_pair_consist_forward_tiles", "mr_pair_consist_backward_tiles"):
+            assert name in calls, f"{name} was not launched: {calls}"
+        assert not any(n in calls for n in ("mr_occlusion_flow", "mr_pair_consist_forward", "mr_pair_consist_backward"))
+        assert note_s[3] is not None and torch.equal(note_s[0], note_d[0])
+        # per pixel of the crop: is the coverage WORD of its tile non-zero?  (image orientation: raster row is_ - 1 - y)
+        words = note_s[0].contiguous().view(torch.int32).view(2 * B, (is_ + 7) // 8, (is_ + 31) // 32).cpu().numpy() != 0
+        yy, xx = np.mgrid[0:H, 0:Wd]
+        defined = torch.from_numpy(words[:, (is_ - 1 - yy) >> 3, xx >> 5]).to(cuda)  # [2B, H, Wd]
+        assert 0 < int(defined.sum()) < defined.numel()
+        assert torch.equal(flow_s[defined], flow_d[defined]), "flows under the covered tiles"
+        assert torch.isnan(flow_s[~defined]).all(), "something was written outside the covered tiles"
+        close(loss_s.cpu().numpy(), loss_d.cpu().numpy(), 2e-6, 1e-9, "pair loss")
+        for a, b_, what in ((g1_s, g1_d, "d/d vertices of frame 1"), (g2_s, g2_d, "d/d vertices of frame 2")):
+            assert torch.isfinite(a).all(), what
+            close(a.cpu().numpy(), b_.cpu().numpy(), 1e-5, 1e-6 * float(b_.abs().max()), what)
+    # flows that are defined under the coverage only must not reach the per-pixel ("full") outputs
+    flows = opticalflow.get_opticalflow([t(s["verts1"], cuda), t(s["verts2"], cuda)], t(s["faces"], cuda),
+                                        [t(s["K1"], cuda), t(s["K2"], cuda)], ren, orig_img_size=(Wd, H), sparse_flows=True)
+    with pytest.raises(ValueError, match="sparse_flows"):
+        imgflowarp.pair_consist(flows, im_ref, im, jm_ref, jm, crit, use_backward=True, outputs="full")

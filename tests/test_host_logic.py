@@ -277,3 +277,91 @@ def test_cat_or_view_returns_a_view_only_for_consecutive_slices():
     v = cat_or_view(frames)
     assert v.shape[0] == 6 and v.data_ptr() == frames[0].data_ptr() and torch.equal(v, torch.cat(frames))
     assert torch.equal(frames[0], frames[2])  # the data frame and the annotated reference are the same image
+
+
+class _AlphaSpy(torch.autograd.Function):
+    """alpha as given; any gradient that reaches it is handed to the vertices in full (sum over the image), so a leak
+    through alpha cannot hide behind a flat region of a smooth stand-in."""
+
+    @staticmethod
+    def forward(ctx, alpha, verts):
+        ctx.shape = verts.shape
+        return alpha.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g.sum((1, 2))[:, None, None].expand(ctx.shape).clone()
+
+
+class _SoftRenderer:
+    """Differentiable stand-in for ``Renderer.__call__`` on CPU (the real one needs the HIP library): a disc whose
+    colour depends smoothly on the vertices and whose alpha passes every incoming gradient on to them."""
+    no_light, camera_mode = True, "projection"
+
+    def __init__(self, size):
+        self.size = size
+        ys, xs = torch.meshgrid(torch.arange(size, dtype=torch.float32), torch.arange(size, dtype=torch.float32), indexing="ij")
+        self.grid = torch.stack([xs, ys], -1)
+
+    def __call__(self, verts, faces, textures, K=None, detach_renders=False):
+        v = verts.detach() if detach_renders else verts
+        c = v.detach()[:, :, :2].mean(1) * 2 + self.size / 2                       # [B,2] disc centre
+        hard = (((self.grid[None] - c[:, None, None]) ** 2).sum(-1) < (self.size / 3.0) ** 2).float()
+        alpha = _AlphaSpy.apply(hard, v) if v.requires_grad else hard
+        colour = textures.mean((1, 2, 3, 4))                                       # [B,3]
+        rgb = colour[:, :, None, None] * hard[:, None] * (1 + 0.01 * v[:, :, 2].mean(1))[:, None, None, None]
+        fim = torch.where(hard > 0.5, 0, -1).to(torch.int32)
+        return {"rgb": rgb, "alpha": alpha, "face_index_map": fim}
+
+
+def test_general_flow_path_keeps_the_second_alpha_out_of_autograd(monkeypatch):
+    """opticalflow.py:137-139 assigns ``mask_flow2 = renderout["alpha"]`` INSIDE ``torch.no_grad()``: with attached
+    renders the product ``flow21 * (alpha2 * occl2)`` must not backpropagate through alpha2.  Compared against the
+    reference's statement order written out here (the occlusion check, a no-grad kernel call in the product, is the
+    numpy oracle's on this CPU run)."""
+    from handobjectconsist_amd.utils import project, textutils
+    from handobjectconsist_amd.warping import imgflowarp, opticalflow
+    from oracle import warp_ref
+
+    def occlusion_on_cpu(m1, m2, f12, f21):
+        o1, o2 = warp_ref.get_occlusion_mask(*[t_.detach().numpy() for t_ in (m1, m2, f12, f21)])
+        return torch.from_numpy(np.ascontiguousarray(o1)), torch.from_numpy(np.ascontiguousarray(o2))
+
+    monkeypatch.setattr(imgflowarp, "get_occlusion_mask", occlusion_on_cpu)
+
+    torch.manual_seed(3)
+    B, V, size = 2, 12, 16
+    faces = torch.randint(0, V, (B, 7, 3))
+    K = torch.tensor([[[20.0, 0, 8], [0, 20.0, 8], [0, 0, 1]]]).repeat(B, 1, 1)
+    base = torch.randn(B, V, 3) * 0.3 + torch.tensor([0.0, 0.0, 2.0])
+    rend = _SoftRenderer(size)
+
+    def reference_order(v1, v2):
+        p1, p2 = project.batch_proj2d(v1, K), project.batch_proj2d(v2, K)
+        d12 = p2 - p1
+        ro = rend(v1, faces, textutils.batch_vertex_textures(faces, torch.cat([d12, torch.ones_like(d12[:, :, :1])], -1)),
+                  K=K, detach_renders=False)
+        m1 = (ro["alpha"].unsqueeze(1) > 0.99999).float()
+        f12 = ro["rgb"] * m1
+        d21 = p1 - p2
+        ro = rend(v2, faces, textutils.batch_vertex_textures(faces, torch.cat([d21, torch.ones_like(d21[:, :, :1])], -1)),
+                  K=K, detach_renders=False)
+        m2 = (ro["alpha"].unsqueeze(1) > 0.99999).float()
+        f21 = ro["rgb"] * m2
+        with torch.no_grad():
+            m2 = ro["alpha"].unsqueeze(1)
+            o1, o2 = imgflowarp.get_occlusion_mask(m1, m2, f12, f21)
+        f12, f21 = f12 * (m1 * o1.unsqueeze(1)), f21 * (m2 * o2.unsqueeze(1))
+        return [f.permute(0, 2, 3, 1)[:, :, :, :2] for f in (f12, f21)]
+
+    grads = []
+    for fn in (reference_order,
+               lambda a, b: opticalflow.get_opticalflow([a, b], faces, [K, K], rend, mask_occlusions=True,
+                                                        detach_textures=False, detach_renders=False)):
+        v1, v2 = base.clone().requires_grad_(True), (base + 0.05).clone().requires_grad_(True)
+        f12, f21 = fn(v1, v2)
+        assert f21.abs().sum() > 0
+        ((f12 * 0.7).sum() + (f21 * 1.3).sum()).backward()
+        grads.append((v1.grad.clone(), v2.grad.clone(), f12.detach(), f21.detach()))
+    for a, b in zip(*grads):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), float((a - b).abs().max())
