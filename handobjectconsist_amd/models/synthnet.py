@@ -205,8 +205,11 @@ class _ManoLBSFunction(torch.autograd.Function):
 class SynthManoLayer(nn.Module):
     """manopth ManoLayer.forward on synthetic MANO-shaped parameters."""
 
-    def __init__(self, ncomps=15, use_pca=True, flat_hand_mean=False, center_idx=9, seed=0):
+    def __init__(self, ncomps=15, use_pca=True, flat_hand_mean=False, center_idx=9, seed=0, torch_variants=False):
         super().__init__()
+        # GPU calls the HIP kernels do not cover (axis-angle input, a translation, a finger-tip centre, non-fp32) RAISE
+        # unless the layer was built with torch_variants=True: nothing on a GPU falls back to PyTorch silently
+        self.torch_variants = torch_variants
         rng = np.random.default_rng(seed)
         v, f = synth.hand_template()
         self.use_pca, self.ncomps, self.center_idx = use_pca, ncomps, center_idx
@@ -265,14 +268,23 @@ class SynthManoLayer(nn.Module):
                 and th_trans is None and center_ok and th_pose_coeffs.shape[1] == 3 + self.ncomps)
 
     def forward(self, th_pose_coeffs, th_betas=None, th_trans=None):
+        """GPU: the HIP kernels (mr_mano_forward / _backward).  CPU tensors (no device: the gloo tests, host-side
+        tools) take the PyTorch restatement below.  A GPU call outside the kernels' coverage raises unless the layer
+        was built with ``torch_variants=True`` (or USE_HIP_MANO was switched off for an A/B): no silent fallback."""
         if self._hip_path(th_pose_coeffs, th_betas, th_trans):
             if th_betas is None:
                 th_betas = th_pose_coeffs.new_zeros((th_pose_coeffs.shape[0], 10))
             return _ManoLBSFunction.apply(th_pose_coeffs, th_betas, self)
+        if th_pose_coeffs.is_cuda and USE_HIP_MANO and not self.torch_variants:
+            raise RuntimeError(
+                "SynthManoLayer: no HIP kernel for this call (needs fp32 PCA coefficients [B, 3 + ncomps], no translation, a "
+                "centre among the 16 articulated joints); build the layer with torch_variants=True to run the PyTorch "
+                "restatement on the GPU instead")
         return self.forward_torch(th_pose_coeffs, th_betas, th_trans)
 
     def forward_torch(self, th_pose_coeffs, th_betas=None, th_trans=None):
-        """Same contractions as manopth, arranged as a few dense GEMMs (rocBLAS /
+        """PyTorch restatement (CPU tensors; GPU only on request, see ``forward``), checked against oracle/mano_ref.py.
+        Same contractions as manopth, arranged as a few dense GEMMs (rocBLAS /
         MFMA) instead of many tiny batched ones: blend shapes as ONE [B,145] x [145,2334] product,
         joints from pre-multiplied regressors, the kinematic chain level by level (3 batched
         products instead of 15 sequential ones), skinning as one [778,16] x [16,B*16] product

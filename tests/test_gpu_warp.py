@@ -397,6 +397,58 @@ def test_mano_lbs_hip_matches_torch_layer(cuda, B, center_idx):
     close(b3.grad.cpu().numpy(), b4.grad.cpu().numpy(), 1e-4, 1e-5 * float(b4.grad.abs().max()), "grad betas (joints only)")
 
 
+@pytest.mark.parametrize("B,center_idx", [(4, 9), (33, 9), (2, None)])
+def test_mano_lbs_hip_matches_the_numpy_oracle(cuda, B, center_idx):
+    """mr_mano_forward / mr_mano_backward against oracle/mano_ref.py -- manopth's ManoLayer.forward restated joint by
+    joint in numpy, OUTSIDE the product (manobranch.py:70-85, 130-136): vertices / joints to 1e-5 of
+    their scale against its fp64 evaluation, gradients along random directions to 1e-4 against its central
+    differences."""
+    from handobjectconsist_amd.models import synthnet
+    from oracle import mano_ref as M
+
+    layer = synthnet.SynthManoLayer(ncomps=15, use_pca=True, center_idx=center_idx).to(cuda)
+    c = {k: getattr(layer, k).detach().cpu().numpy() for k in
+         ("th_v_template", "th_shapedirs", "th_posedirs", "th_J_regressor", "th_weights", "th_comps", "th_hands_mean")}
+    g = torch.Generator().manual_seed(100 + B)
+    pose = 0.4 * torch.randn(B, 18, generator=g)
+    pose[0, :3] = 0  # a zero axis-angle: the 1e-8 guard of the Rodrigues formula
+    beta = torch.randn(B, 10, generator=g)
+    p, b_ = pose.to(cuda).requires_grad_(True), beta.to(cuda).requires_grad_(True)
+    v_hip, j_hip = layer(p, b_)
+    v_ref, j_ref = M.mano_forward(c, pose.numpy(), beta.numpy(), center_idx=center_idx)
+    scale = float(np.abs(v_ref).max())
+    close(v_hip.detach().cpu().numpy(), v_ref, 1e-5, 1e-5 * scale, "verts")
+    close(j_hip.detach().cpu().numpy(), j_ref, 1e-5, 1e-5 * scale, "joints")
+    wv, wj = torch.randn(v_hip.shape, generator=g), torch.randn(j_hip.shape, generator=g)
+    ((v_hip * wv.to(cuda)).sum() + (j_hip * wj.to(cuda)).sum()).backward()
+    gp, gb = p.grad.double().cpu(), b_.grad.double().cpu()
+    for k in range(6):
+        dp, db = torch.randn(pose.shape, generator=g), torch.randn(beta.shape, generator=g)
+        if k == 0:
+            dp[1:], db[1:] = 0, 0  # sample 0 alone (its root rotation is the guarded zero axis-angle)
+        num = M.directional_derivative(c, pose.numpy(), beta.numpy(), wv.numpy(), wj.numpy(), dp.numpy(), db.numpy(),
+                                       center_idx=center_idx)
+        ana = float((gp * dp.double()).sum() + (gb * db.double()).sum())
+        assert abs(ana - num) <= 1e-4 * max(abs(num), 1.0) + 1e-4 * float(gp.abs().max()), (k, ana, num)
+
+
+def test_mano_layer_has_no_silent_gpu_fallback(cuda):
+    """Calls the HIP kernels do not cover raise on a GPU unless the layer was built with torch_variants=True."""
+    from handobjectconsist_amd.models import synthnet
+
+    layer = synthnet.SynthManoLayer(ncomps=15, use_pca=True, center_idx=9).to(cuda)
+    pose, beta = torch.zeros(2, 18, device=cuda), torch.zeros(2, 10, device=cuda)
+    with pytest.raises(RuntimeError, match="no HIP kernel"):
+        layer(pose, beta, th_trans=torch.ones(2, 3, device=cuda))
+    with pytest.raises(RuntimeError, match="no HIP kernel"):
+        layer(pose.double(), beta.double())
+    with pytest.raises(RuntimeError, match="no HIP kernel"):
+        synthnet.SynthManoLayer(ncomps=15, use_pca=False, center_idx=None).to(cuda)(torch.zeros(2, 48, device=cuda), beta)
+    allowed = synthnet.SynthManoLayer(ncomps=15, use_pca=True, center_idx=9, torch_variants=True).to(cuda)
+    v, _ = allowed(pose, beta, th_trans=torch.ones(2, 3, device=cuda))
+    assert v.shape == (2, 778, 3)
+
+
 def test_mano_constants_follow_the_buffers(cuda):
     """The HIP path's pre-arranged model constants are rebuilt when the layer's buffers are overwritten
     (load_state_dict) -- no stale blend shapes."""
