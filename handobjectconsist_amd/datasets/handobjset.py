@@ -52,7 +52,7 @@ class HandObjSet(Dataset):
         self.train, self.scale_jittering, self.center_jittering = train, scale_jittering, center_jittering
         self.queries = tuple(queries)
         self.has_dist2strong = has_dist2strong
-        self.color_fn = color_fn  # (frame_u8, dataset, color_augm | None) -> (frame_u8, color_augm)
+        self.color_fn = color_fn  # (frame_u8, dataset, color_augm | None, blur_radius) -> (frame_u8, color_augm)
 
     def __len__(self):
         return len(self.pose_dataset)
@@ -94,8 +94,12 @@ class HandObjSet(Dataset):
             affinetrans, post_rot_trans = handutils.get_affine_transform(space_augm["center"], space_augm["scale"],
                                                                         self.inp_res, rot=rot)
             sample["affinetrans"] = affinetrans
-            if self.train and self.color_fn is not None:
-                frame, color_augm = self.color_fn(frame, self, color_augm)
+            if self.train:
+                # the blur radius is drawn for EVERY training frame, also for the companions of a sequence that inherit
+                # their colour parameters (handobjset.py:341): part of how far a sample advances torch's RNG stream
+                blur_radius = Uniform(low=0, high=1).sample().item() * self.blur_radius
+                if self.color_fn is not None:
+                    frame, color_augm = self.color_fn(frame, self, color_augm, blur_radius)
             sample["color_augm"] = color_augm if self.train else None
             sample["frame"] = np.ascontiguousarray(frame)
             sample["flip"] = bool(flip)
