@@ -60,6 +60,8 @@ SIGNATURES = {
     "mr_pair_consist_tiles_workspace_bytes": (_L, [_I, _I]),
     "mr_pair_consist_forward_tiles": (_I, [_P] * 6 + [_I, _P, _L, _P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P, _P, _L, _L, _P]),
     "mr_pair_consist_backward_tiles": (_I, [_P] * 6 + [_I] + [_P] * 5 + [_I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _L, _L, _P]),
+    "mr_flow_pair_forward_tiles": (_I, [_P] * 4 + [_L] + [_P] * 12 + [_I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _L, _L, _P]),
+    "mr_flow_pair_backward_tiles": (_I, [_P] * 9 + [_I] + [_P] * 8 + [_I, _I, _P, _I, _I, _I, _I, _I, _F, _F, _I, _I, _P]),
     "mr_frames_to_batch_workspace_bytes": (_L, [_I, _I, _I]),
     "mr_frames_to_batch": (_I, [_P] * 3 + [_F] * 6 + [_P, _L, _P, _P] + [_I] * 6 + [_P]),
     "mr_bn_act_forward": (_I, [_P] * 6 + [_F, _I, _I, _I, _P, _I, _I, _I, _P]),
@@ -156,6 +158,13 @@ def tile_list(workspace, batch_size, num_faces, image_size):
     if rc != 0:
         raise RuntimeError(f"mr_render_tile_list failed: {rc}")
     return hdr, ents, int(cap.value)
+
+
+def has_tile_list(batch_size, num_faces, image_size):
+    """Does mr_render_flow_forward build a tile list for this raster (a bin is a tile; <= 2^31 tiles)?  Sizes only."""
+    hdr, ents, cap = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+    return load().mr_render_tile_list(ctypes.c_void_p(256), int(batch_size), int(num_faces), int(image_size), ctypes.byref(hdr),
+                                      ctypes.byref(ents), ctypes.byref(cap)) == 0
 
 
 def contig(t, dtype=torch.float32):

@@ -23,6 +23,7 @@
 //   * pixel_map_strip_kernel<IMG, L> -- kernel D by strips of image lines staged in LDS, fed by per-image owner
 //     records from compact_owners_kernel (the default when a workspace is given; see the comment there).
 #include "mr_common.hpp"
+#include "warp_device.hpp"
 #include <algorithm>
 #include <type_traits>
 
@@ -722,14 +723,34 @@ struct ScatterTilesParams {
     int tiles_x, tiles_y;
     int groups;  // workgroups per image
     const float* grad_bound;  // nullable (FLOWGRAD): [B] upper bounds of |grad_flow| per image
+    // PAIR (mr_flow_pair_backward_tiles): the pair loss's backward folded in -- pass 1 computes the flow gradient of the
+    // workgroup's tiles itself (it used to be a kernel of its own + 8 B per pixel written and read back)
+    float* stash;             // [B,H,W,2] scratch: the masked flow-space gradient, pass 1 -> pass 2 of the same workgroup
+    const float* flow;        // [B,H,W,2] the stacked final flows (images [0, split): flow12, [split, B): flow21)
+    const float* image_ref;   // [split,3,H,W]
+    const float* image;
+    const float* jitter_ref;  // [split,Cj,H,W]
+    const float* jitter;
+    int Cj;
+    const float* sums;        // [split,4] of the pair loss's forward
+    const float* gl_fwd;      // [split] incoming gradients of loss_fwd / loss_bwd (gl_bwd nullable)
+    const float* gl_bwd;
+    float pair_thresh;
 };
 
-template <bool FLOWGRAD>
+template <bool FLOWGRAD, bool PAIR = false>
 __device__ __forceinline__ void st_load_grad(const ScatterTilesParams& sp, int b, int yi, int x, float (*g)[3]) {
     const GatherVCParams& p = sp.g;
     const int is = p.is;
     const int yimg = is - 1 - yi;
-    if (!FLOWGRAD) {
+    if (PAIR) {  // pass 1 of this workgroup left the gradient, masks applied, in the stash
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float2 gf = make_float2(0.0f, 0.0f);
+            if (yimg < sp.H && x + j < sp.W) gf = *reinterpret_cast<const float2*>(sp.stash + (((int64_t)b * sp.H + yimg) * sp.W + x + j) * 2);
+            g[j][0] = gf.x; g[j][1] = gf.y; g[j][2] = 0.0f;
+        }
+    } else if (!FLOWGRAD) {
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             const float4 v = *reinterpret_cast<const float4*>(p.grad_rgb + (((int64_t)b * 3 + ch) * is + yimg) * is + x);
@@ -762,8 +783,8 @@ __device__ unsigned long long mr_dbg_st[4096 * 8];  // profiling builds: phase s
 #define MR_ST_STAMP(k) do { } while (0)
 #endif
 
-template <bool FLOWGRAD, bool REC>
-__global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(ScatterTilesParams sp) {
+template <bool FLOWGRAD, bool REC, bool PAIR>
+__device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp) {
     MR_ST_STAMP(0);
     extern __shared__ long long vtab[];  // [V * NCH] rounded up to an even count
     constexpr int NCH = FLOWGRAD ? 2 : 3;  // (the flow-space gradient has no third channel)
@@ -804,8 +825,53 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
 
     // pass 1: largest |gradient| over the workgroup's covered tiles, as float bits -- or the caller's bound for the image
     unsigned mx = 0u;
-    const bool bounded = FLOWGRAD && sp.grad_bound != nullptr;
-    if (bounded) mx = __float_as_uint(sp.grad_bound[b]) & 0x7fffffffu;
+    const bool bounded = PAIR || (FLOWGRAD && sp.grad_bound != nullptr);
+    if (bounded && !PAIR) mx = __float_as_uint(sp.grad_bound[b]) & 0x7fffffffu;
+    if constexpr (PAIR) {
+        // ... PAIR: the pair loss's backward for the workgroup's tiles (pair_consist_backward_tiles_kernel's arithmetic, one
+        // pixel per thread, two tiles at a time), times the epilogue masks as st_load_grad forms them, into the stash;
+        // the maximum comes out on the way.  A final flow with a zero x component (everything the masks or the
+        // occlusion check removed) has a zero gradient: no taps.
+        const int rem1 = n_hits - part * ST_WAVES;
+        const int n_mine = (rem1 / (G * ST_WAVES)) * ST_WAVES + min(rem1 % (G * ST_WAVES), ST_WAVES);
+        const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+        const int dir = b >= sp.split ? 1 : 0, pb = b - dir * sp.split;
+        const float cnt = sp.sums[pb * 4 + (dir ? 1 : 3)];
+        const float* gl = dir ? sp.gl_fwd : sp.gl_bwd;
+        const float coef = gl ? gl[pb] / ((cnt == 0.0f) ? 1.0f : cnt) : 0.0f;
+        const float* src = dir ? sp.image_ref : sp.image;
+        const float* tgt = dir ? sp.image : sp.image_ref;
+        const float* jit = dir ? sp.jitter : sp.jitter_ref;
+        const int64_t hw_img = (int64_t)sp.H * sp.W;
+        for (int m = half; m < n_mine; m += 2) {
+            const int t = hits[part * ST_WAVES + (m % ST_WAVES) + (m / ST_WAVES) * G * ST_WAVES];
+            const int x = (t % sp.tiles_x) * ST_TW + (tid & 31), ry = (t / sp.tiles_x) * ST_TH + (tid >> 5);
+            const int y = is - 1 - ry;
+            if (x >= sp.W || ry >= is || y >= sp.H) continue;
+            const int64_t pixc = (int64_t)y * sp.W + x;
+            float2 gq = make_float2(0.0f, 0.0f);
+            const uint32_t word = sp.tile_hit[(int64_t)b * T + t];
+            if (coef != 0.0f && ((word >> (8 * ((ry & 7) >> 1))) & 0xffu) != 0u) {
+                const float2 uv = *reinterpret_cast<const float2*>(sp.flow + ((int64_t)b * hw_img + pixc) * 2);
+                if (uv.x != 0.0f) {
+                    const int64_t o = ((int64_t)b * is + y) * is + x;
+                    const float a = sp.m_pre[o];
+                    const float post = (b < sp.split ? sp.m_x_lo[o] : sp.m_x_hi[o - (int64_t)sp.split * is * is]) * sp.occl[o];
+                    const DirTaps tp = pair_taps(uv, x, y, sp.H, sp.W);
+                    DirRaw2 q{};
+                    pair_load(tp, src, tgt, jit, jit, sp.Cj, false, pb, pixc, hw_img, q);
+                    pin(q);
+                    const DirRaw r = unpack(q, tp.a);
+                    const DirOut e = pair_eval(tp, r, sp.H, sp.W, sp.pair_thresh, false);
+                    const float2 gp = pair_grad(tp, r, e, sp.H, sp.W, coef);
+                    gq = make_float2((gp.x * post) * a, (gp.y * post) * a);
+                }
+            }
+            *reinterpret_cast<float2*>(sp.stash + ((int64_t)b * hw_img + pixc) * 2) = gq;
+            mx = max(mx, max(__float_as_uint(gq.x) & 0x7fffffffu, __float_as_uint(gq.y) & 0x7fffffffu));
+        }
+        __threadfence_block();  // the stash is read back by other waves of this workgroup after the barrier below
+    }
     for (int h = part * ST_WAVES + wave; h < n_hits && !bounded; h += G * ST_WAVES) {
         const int t = hits[h];
         const int yi = (t / sp.tiles_x) * ST_TH + r, x = (t % sp.tiles_x) * ST_TW + x4;
@@ -858,7 +924,7 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
             for (int k = 0; k < 3; k++) { g[j][k] = 0.0f; w[j][k] = 0.0f; }
         }
         if (inside) {
-            st_load_grad<FLOWGRAD>(sp, b, yi, x, g);
+            st_load_grad<FLOWGRAD, PAIR>(sp, b, yi, x, g);
             const float4* wq = reinterpret_cast<const float4*>(sp.weight + (((int64_t)b * is + yi) * is + x) * 3);
             const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2];
             w[0][0] = w0.x; w[0][1] = w0.y; w[0][2] = w0.z; w[1][0] = w0.w; w[1][1] = w1.x; w[1][2] = w1.y;
@@ -944,6 +1010,18 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
         }
     }
     MR_ST_STAMP(4);
+}
+
+template <bool FLOWGRAD, bool REC>
+__global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(ScatterTilesParams sp) {
+    scatter_tiles_body<FLOWGRAD, REC, false>(sp);
+}
+
+// ... with the pair loss's backward folded into pass 1 (mr_flow_pair_backward_tiles).  Eight waves per SIMD: four of
+// these 8-wave workgroups per compute unit, i.e. all 1024 of a 128-image launch resident at once, as for the kernel above.
+__global__ void __launch_bounds__(ST_WAVES * MR_WAVE) __attribute__((amdgpu_waves_per_eu(8, 8)))
+pair_scatter_tiles_kernel(ScatterTilesParams sp) {
+    scatter_tiles_body<true, true, true>(sp);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2102,6 +2180,55 @@ extern "C" int mr_render_flow_backward(const float* verts, const int32_t* faces_
     auto kernel = vertex_id_map ? (flowgrad ? scatter_tiles_kernel<true, true> : scatter_tiles_kernel<false, true>)
                                 : (flowgrad ? scatter_tiles_kernel<true, false> : scatter_tiles_kernel<false, false>);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_flow_pair_backward_tiles(const int32_t* face_index_map, const uint32_t* tile_hit, const float* weight_map,
+                                           const int32_t* vertex_id_map, const float* flows, const float* image_ref,
+                                           const float* image, const float* jitter_ref, const float* jitter,
+                                           int jitter_channels, const float* sums, const float* grad_loss_fwd,
+                                           const float* grad_loss_bwd, const float* mask_pre, const float* mask_x_lo,
+                                           const float* mask_x_hi, const float* occl, float* grad_flow_scratch, int height,
+                                           int width, float* grad_vcolors, int batch_size, int num_verts, int num_faces,
+                                           int fill_back, int image_size, float eps, float pair_thresh, int flags,
+                                           int texel_layout, mr_stream_t stream) {
+    if (batch_size < 0 || (batch_size & 1) || num_faces < 0 || num_verts < 0 || image_size <= 0 || !texel_layout_ok(texel_layout))
+        return MR_ERR_BADARG;
+    if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
+    if (batch_size == 0 || num_verts == 0) return MR_OK;
+    if (!flows || !image_ref || !image || !jitter_ref || !jitter || !sums || !grad_loss_fwd || !mask_pre || !mask_x_lo ||
+        !mask_x_hi || !occl || !grad_flow_scratch || !tile_hit)
+        return MR_ERR_BADARG;
+    if (jitter_channels != 1 && jitter_channels != 3) return MR_ERR_BADARG;
+    if (height <= 0 || width < 2 || height > image_size || width > image_size || (int64_t)height * width > (1LL << 29))
+        return MR_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!(flags & MR_FLAG_OUTPUT_ZEROED)) {
+        hipError_t e = hipMemsetAsync(grad_vcolors, 0, (size_t)batch_size * num_verts * 3 * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (num_faces == 0) return MR_OK;
+    if (!face_index_map || !weight_map || !vertex_id_map || !(eps >= 1e-6f)) return MR_ERR_BADARG;
+    const int64_t table_bytes = (((int64_t)num_verts * 2 + 1) / 2) * 16;
+    if (image_size % 4 != 0 || table_bytes > SV_MAX_TABLE_BYTES ||
+        (int64_t)((image_size + ST_TW - 1) / ST_TW) * ((image_size + ST_TH - 1) / ST_TH) > ST_MAX_TILES)
+        return MR_ERR_NOTIMPL;
+    ScatterTilesParams sp{};
+    sp.g = GatherVCParams{nullptr, nullptr, face_index_map, nullptr, grad_vcolors, batch_size, num_verts, num_faces,
+                          fill_back, image_size, eps, flags >> 8, texel_layout};
+    sp.weight = weight_map; sp.tile_hit = tile_hit; sp.vid_map = vertex_id_map;
+    sp.m_pre = mask_pre; sp.m_x_lo = mask_x_lo; sp.m_x_hi = mask_x_hi; sp.occl = occl;
+    sp.split = batch_size / 2; sp.H = height; sp.W = width;
+    sp.tiles_x = (image_size + ST_TW - 1) / ST_TW; sp.tiles_y = (image_size + ST_TH - 1) / ST_TH;
+    sp.groups = ST_G;
+    switch ((flags >> 12) & 7) { case 1: sp.groups = 2; break; case 2: sp.groups = 4; break; case 3: sp.groups = 16; break; case 4: sp.groups = 32; break; default: break; }
+    sp.stash = grad_flow_scratch; sp.flow = flows; sp.image_ref = image_ref; sp.image = image; sp.jitter_ref = jitter_ref;
+    sp.jitter = jitter; sp.Cj = jitter_channels; sp.sums = sums; sp.gl_fwd = grad_loss_fwd; sp.gl_bwd = grad_loss_bwd;
+    sp.pair_thresh = pair_thresh;
+    const int64_t blocks = (int64_t)batch_size * sp.groups;
+    if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(pair_scatter_tiles_kernel, dim3((unsigned)blocks), dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

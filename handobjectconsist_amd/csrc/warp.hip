@@ -22,200 +22,9 @@
 #include <algorithm>
 
 #include "mr_common.hpp"
+#include "warp_device.hpp"
 
 namespace mr {
-
-struct Taps {
-    int x0, y0;            // north-west tap
-    float nw, ne, sw, se;  // bilinear weights
-    float ix, iy;
-};
-
-__device__ __forceinline__ void sample_pos(float x, float y, float u, float v, int W, int H, float& ix,
-                                           float& iy) {
-    const float gx = x + u, gy = y + v;
-    const float vx = 2.0f * gx / (float)max(W - 1, 1) - 1.0f;
-    const float vy = 2.0f * gy / (float)max(H - 1, 1) - 1.0f;
-    ix = ((vx + 1.0f) * (float)W - 1.0f) / 2.0f;
-    iy = ((vy + 1.0f) * (float)H - 1.0f) / 2.0f;
-}
-
-__device__ __forceinline__ Taps make_taps(float ix, float iy) {
-    Taps t;
-    t.ix = ix; t.iy = iy;
-    const float fx = floorf(ix), fy = floorf(iy);
-    // clamp before the int conversion so that huge / non-finite positions are simply out of bounds
-    t.x0 = (int)fminf(fmaxf(fx, -4.0f), 1.0e9f);
-    t.y0 = (int)fminf(fmaxf(fy, -4.0f), 1.0e9f);
-    if (!(fx == fx)) t.x0 = -4;
-    if (!(fy == fy)) t.y0 = -4;
-    const float ix_se = fx + 1.0f, iy_se = fy + 1.0f;
-    t.nw = (ix_se - ix) * (iy_se - iy);
-    t.ne = (ix - fx) * (iy_se - iy);
-    t.sw = (ix_se - ix) * (iy - fy);
-    t.se = (ix - fx) * (iy - fy);
-    return t;
-}
-
-__device__ __forceinline__ bool inb(int x, int y, int W, int H) { return x >= 0 && x < W && y >= 0 && y < H; }
-
-// bilinear sample of one channel plane (zeros padding), accumulation order nw, ne, sw, se.
-// The four loads are unconditional (clamped addresses) so they issue back to back; a tap that
-// is out of bounds leaves the accumulator untouched, exactly like the skipped branch of the
-// reference implementation.
-struct TapAddr {
-    int64_t a_nw, a_ne, a_sw, a_se;
-    bool b_nw, b_ne, b_sw, b_se;
-};
-
-__device__ __forceinline__ TapAddr tap_addr(const Taps& t, int W, int H) {
-    TapAddr a;
-    a.b_nw = inb(t.x0, t.y0, W, H);
-    a.b_ne = inb(t.x0 + 1, t.y0, W, H);
-    a.b_sw = inb(t.x0, t.y0 + 1, W, H);
-    a.b_se = inb(t.x0 + 1, t.y0 + 1, W, H);
-    const int xc0 = min(max(t.x0, 0), W - 1), xc1 = min(max(t.x0 + 1, 0), W - 1);
-    const int yc0 = min(max(t.y0, 0), H - 1), yc1 = min(max(t.y0 + 1, 0), H - 1);
-    a.a_nw = (int64_t)yc0 * W + xc0;
-    a.a_ne = (int64_t)yc0 * W + xc1;
-    a.a_sw = (int64_t)yc1 * W + xc0;
-    a.a_se = (int64_t)yc1 * W + xc1;
-    return a;
-}
-
-__device__ __forceinline__ float bilin(const float* __restrict__ plane, const Taps& t, const TapAddr& a) {
-    const float v_nw = plane[a.a_nw], v_ne = plane[a.a_ne], v_sw = plane[a.a_sw], v_se = plane[a.a_se];
-    float acc = 0.0f;
-    acc = a.b_nw ? acc + v_nw * t.nw : acc;
-    acc = a.b_ne ? acc + v_ne * t.ne : acc;
-    acc = a.b_sw ? acc + v_sw * t.sw : acc;
-    acc = a.b_se ? acc + v_se * t.se : acc;
-    return acc;
-}
-
-__device__ __forceinline__ float bilin(const float* __restrict__ plane, const Taps& t, int W, int H) {
-    return bilin(plane, t, tap_addr(t, W, H));
-}
-
-// bilinear sample of an all-ones image = sum of the in-bounds weights, binarised as
-// imgflowarp.py:52-53 (mask[mask < thresh] = 0; mask[mask > 0] = 1)
-__device__ __forceinline__ float valid_mask(const Taps& t, int W, int H, float thresh) {
-    float acc = 0.0f;
-    if (inb(t.x0, t.y0, W, H)) acc += t.nw;
-    if (inb(t.x0 + 1, t.y0, W, H)) acc += t.ne;
-    if (inb(t.x0, t.y0 + 1, W, H)) acc += t.sw;
-    if (inb(t.x0 + 1, t.y0 + 1, W, H)) acc += t.se;
-    if (acc < thresh) acc = 0.0f;
-    if (acc > 0.0f) acc = 1.0f;
-    return acc;
-}
-
-// d(sample)/d(ix), d(sample)/d(iy) of one channel plane
-__device__ __forceinline__ void bilin_grad(const float* __restrict__ plane, const Taps& t, const TapAddr& a,
-                                           float& gix, float& giy) {
-    const float fx = (float)t.x0, fy = (float)t.y0;
-    const float ix_se = fx + 1.0f, iy_se = fy + 1.0f;
-    const float v_nw = plane[a.a_nw], v_ne = plane[a.a_ne], v_sw = plane[a.a_sw], v_se = plane[a.a_se];
-    gix = 0.0f; giy = 0.0f;
-    if (a.b_nw) { gix -= v_nw * (iy_se - t.iy); giy -= v_nw * (ix_se - t.ix); }
-    if (a.b_ne) { gix += v_ne * (iy_se - t.iy); giy -= v_ne * (t.ix - fx); }
-    if (a.b_sw) { gix -= v_sw * (t.iy - fy); giy += v_sw * (ix_se - t.ix); }
-    if (a.b_se) { gix += v_se * (t.iy - fy); giy += v_se * (t.ix - fx); }
-}
-
-__device__ __forceinline__ void bilin_grad(const float* __restrict__ plane, const Taps& t, int W, int H,
-                                           float& gix, float& giy) {
-    bilin_grad(plane, t, tap_addr(t, W, H), gix, giy);
-}
-
-// Raw values of the four taps of one channel plane.  Loading them into a Quad first and pinning
-// them with `pin()` keeps the loads UNCONDITIONAL and back to back: otherwise the compiler sinks
-// each load into the branch of its in-bounds select and waits for it there (one exposed HBM
-// round trip per tap instead of one per batch).
-struct Quad {
-    float nw, ne, sw, se;
-};
-__device__ __forceinline__ Quad load_quad(const float* __restrict__ plane, const TapAddr& a) {
-    Quad q;
-    q.nw = plane[a.a_nw]; q.ne = plane[a.a_ne]; q.sw = plane[a.a_sw]; q.se = plane[a.a_se];
-    return q;
-}
-__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void pin(Quad& q) { pin(q.nw); pin(q.ne); pin(q.sw); pin(q.se); }
-template <typename A>
-__device__ __forceinline__ float bilin_q(const Quad& q, const Taps& t, const A& a) {
-    float acc = 0.0f;
-    acc = a.b_nw ? acc + q.nw * t.nw : acc;
-    acc = a.b_ne ? acc + q.ne * t.ne : acc;
-    acc = a.b_sw ? acc + q.sw * t.sw : acc;
-    acc = a.b_se ? acc + q.se * t.se : acc;
-    return acc;
-}
-template <typename A>
-__device__ __forceinline__ void bilin_grad_q(const Quad& q, const Taps& t, const A& a, float& gix, float& giy) {
-    const float fx = (float)t.x0, fy = (float)t.y0;
-    const float ix_se = fx + 1.0f, iy_se = fy + 1.0f;
-    gix = 0.0f; giy = 0.0f;
-    if (a.b_nw) { gix -= q.nw * (iy_se - t.iy); giy -= q.nw * (ix_se - t.ix); }
-    if (a.b_ne) { gix += q.ne * (iy_se - t.iy); giy -= q.ne * (t.ix - fx); }
-    if (a.b_sw) { gix -= q.sw * (t.iy - fy); giy += q.sw * (ix_se - t.ix); }
-    if (a.b_se) { gix += q.se * (t.iy - fy); giy += q.se * (t.ix - fx); }
-}
-
-// Row-pair addressing (W >= 2): the west / east taps of a row are adjacent in memory, so ONE
-// 8-byte load per row fetches both -- half the load instructions of four scalar taps, which is
-// what bounds the fused pair kernels.  The pair starts at column clamp(x0, 0, W - 2); when that
-// differs from x0 the in-bounds tap sits in the other half (x0 == -1: east tap = first element;
-// x0 == W - 1: west tap = second element); taps that are out of bounds are never used.
-// Offsets are 32-bit BYTE offsets from a wave-uniform plane pointer (global_load saddr form).
-struct PairAddr {
-    unsigned o_n, o_s;  // byte offsets of the pairs in rows y0 and y0 + 1 (both clamped)
-    bool shl, shr;      // pair shifted right of x0 (x0 < 0) / left of x0 (x0 > W - 2)
-    bool b_nw, b_ne, b_sw, b_se;
-};
-__device__ __forceinline__ PairAddr pair_addr(const Taps& t, int W, int H) {
-    PairAddr a;
-    a.b_nw = inb(t.x0, t.y0, W, H);
-    a.b_ne = inb(t.x0 + 1, t.y0, W, H);
-    a.b_sw = inb(t.x0, t.y0 + 1, W, H);
-    a.b_se = inb(t.x0 + 1, t.y0 + 1, W, H);
-    const int xs = min(max(t.x0, 0), W - 2);
-    const int yc0 = min(max(t.y0, 0), H - 1), yc1 = min(max(t.y0 + 1, 0), H - 1);
-    a.o_n = ((unsigned)yc0 * (unsigned)W + (unsigned)xs) * 4u;
-    a.o_s = ((unsigned)yc1 * (unsigned)W + (unsigned)xs) * 4u;
-    a.shl = t.x0 < 0;
-    a.shr = t.x0 > W - 2;
-    return a;
-}
-struct __attribute__((packed, aligned(4))) F2 {
-    float x, y;
-};
-struct Quad2 {
-    F2 n, s;
-};
-__device__ __forceinline__ Quad2 load_quad2(const float* __restrict__ plane, const PairAddr& a) {
-    const char* base = reinterpret_cast<const char*>(plane);
-    Quad2 q;
-    q.n = *reinterpret_cast<const F2*>(base + a.o_n);
-    q.s = *reinterpret_cast<const F2*>(base + a.o_s);
-    return q;
-}
-__device__ __forceinline__ void pin(Quad2& q) {
-    asm volatile("" : "+v"(q.n.x)); asm volatile("" : "+v"(q.n.y));
-    asm volatile("" : "+v"(q.s.x)); asm volatile("" : "+v"(q.s.y));
-}
-__device__ __forceinline__ Quad quad_of(const Quad2& q, const PairAddr& a) {
-    Quad r;
-    r.nw = a.shr ? q.n.y : q.n.x; r.ne = a.shl ? q.n.x : q.n.y;
-    r.sw = a.shr ? q.s.y : q.s.x; r.se = a.shl ? q.s.x : q.s.y;
-    return r;
-}
-
-__device__ __forceinline__ void nearest_idx(float ix, float iy, int& xn, int& yn) {
-    const float rx = rintf(ix), ry = rintf(iy);  // round half to even, as nearbyint
-    xn = (rx == rx) ? (int)fminf(fmaxf(rx, -4.0f), 1.0e9f) : -4;
-    yn = (ry == ry) ? (int)fminf(fmaxf(ry, -4.0f), 1.0e9f) : -4;
-}
 
 // ---------------------------------------------------------------------------------------
 // warp
@@ -318,75 +127,6 @@ __global__ void __launch_bounds__(256) warp_backward_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------
 // forward-backward occlusion check
 // ---------------------------------------------------------------------------------------
-// One direction: occl_a(p) from (mask_a, mask_b, flow_ab, flow_ba).
-//   grid_a = [x/W, y/H, mask_a, mask_a]
-//   warp_ab(q)  = nearest(grid_a; q + flow_ba(q)) * mask_b(q)            (imgflowarp.py:132,134)
-//   warp_aba(p) = nearest(warp_ab; p + flow_ab(p)) * mask_a(p)           (:136,138)
-//   occl_a = occlusion_mask_from_warped_grid(grid_a, warp_aba)           (:145)
-// Coverage bytes of mr_render_flow_forward ([tiles_y, tiles_x, 4], RASTER orientation, one byte per 32 x 8 tile and row
-// pair; the planes read here are in IMAGE orientation): 0 = nothing covered there -- with MR_FLAG_SPARSE_TILES the
-// render did not even write those pixels, so every read of a rendered plane is guarded by this test.
-__device__ __forceinline__ bool tile_covered(const uint8_t* __restrict__ hit, int tiles_x, int H, int x, int y) {
-    if (!hit) return true;
-    const int ry = H - 1 - y;
-    return hit[((ry >> 3) * tiles_x + (x >> 5)) * 4 + ((ry & 7) >> 1)] != 0;
-}
-
-__device__ __forceinline__ float occl_one(const float* __restrict__ mask_a, const float* __restrict__ mask_b,
-                                          const float* __restrict__ flow_ab,
-                                          const float* __restrict__ flow_ba, const float* __restrict__ scale_ab,
-                                          const float* __restrict__ scale_ba, int64_t hw, int H, int W,
-                                          int xx, int yy, float dist_thresh, float wthresh,
-                                          const uint8_t* __restrict__ hit_a = nullptr,
-                                          const uint8_t* __restrict__ hit_b = nullptr, int tiles_x = 0) {
-    const int64_t pix = (int64_t)yy * W + xx;
-    if (!tile_covered(hit_a, tiles_x, H, xx, yy)) return 0.0f;
-    const float ma_p = mask_a[pix];
-    // The result is mask_a(p) * (...) * motion with finite factors (masks are 0 / 1 or a rendered alpha): a pixel
-    // outside its own mask -- 90 % of a hand + object frame -- is 0 without any of the dependent gathers below.
-    if (ma_p == 0.0f) return 0.0f;
-    // second warp: sample warp_ab at p + flow_ab(p)   (flow = raw flow * scale when a scale map is given)
-    float ix, iy;
-    const float sa = scale_ab ? scale_ab[pix] : 1.0f;
-    sample_pos((float)xx, (float)yy, scale_ab ? flow_ab[pix] * sa : flow_ab[pix],
-               scale_ab ? flow_ab[hw + pix] * sa : flow_ab[hw + pix], W, H, ix, iy);
-    int qx, qy;
-    nearest_idx(ix, iy, qx, qy);
-    float wg[3] = {0.0f, 0.0f, 0.0f};  // channels x, y, mask of warp_ab at q
-    float m2 = inb(qx, qy, W, H) ? 1.0f : 0.0f;
-    if (m2 < wthresh) m2 = 0.0f;
-    if (m2 > 0.0f) {
-        const int64_t qpix = (int64_t)qy * W + qx;
-        // nothing rendered around q: mask_b(q) = 0 zeroes the warped grid, hence the result
-        if (!tile_covered(hit_b, tiles_x, H, qx, qy)) return 0.0f;
-        // first warp: sample grid_a at q + flow_ba(q)
-        float jx, jy;
-        const float sb = scale_ba ? scale_ba[qpix] : 1.0f;
-        sample_pos((float)qx, (float)qy, scale_ba ? flow_ba[qpix] * sb : flow_ba[qpix],
-                   scale_ba ? flow_ba[hw + qpix] * sb : flow_ba[hw + qpix], W, H, jx, jy);
-        int rx, ry;
-        nearest_idx(jx, jy, rx, ry);
-        float m1 = inb(rx, ry, W, H) ? 1.0f : 0.0f;
-        if (m1 < wthresh) m1 = 0.0f;
-        if (m1 > 0.0f) {
-            const float mb_q = mask_b[qpix];
-            const float ma_r = tile_covered(hit_a, tiles_x, H, rx, ry) ? mask_a[(int64_t)ry * W + rx] : 0.0f;
-            wg[0] = ((float)rx / (float)W) * m1 * mb_q;
-            wg[1] = ((float)ry / (float)H) * m1 * mb_q;
-            wg[2] = ma_r * m1 * mb_q;
-        }
-    }
-    float w3[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) w3[k] = wg[k] * m2 * ma_p;
-    const float g0 = (float)xx / (float)W, g1 = (float)yy / (float)H;
-    const float mask = ma_p * w3[2];
-    const float dx = (w3[0] - g0) * mask, dy = (w3[1] - g1) * mask;
-    const float displ = sqrtf(dx * dx + dy * dy);
-    const float motion = (displ < dist_thresh) ? 1.0f : 0.0f;
-    return mask * motion;
-}
-
 __global__ void __launch_bounds__(256) occlusion_kernel(const float* __restrict__ mask1,
                                                         const float* __restrict__ mask2,
                                                         const float* __restrict__ flow12,
@@ -548,110 +288,6 @@ struct PairParams {
     const uint8_t* hit21;
     int hit_is, hit_tiles_x, hit_stride;  // raster size, tiles per raster row, bytes per image
 };
-
-// one direction at one pixel: warp `src` with `flow`, gate with the jitter mask `jwarp`
-// warped by the same flow and with `jdirect` at the pixel, compare with `tgt`.
-struct DirOut {
-    float s[3];      // warped source * warp mask
-    float m;         // warp mask (before the jitter gate)
-    float wm[3];     // warp mask after the jitter gate, per jitter channel
-    bool valid;
-};
-
-// One direction at one pixel, in three steps so that every global load of the pixel is in
-// flight before anything waits:  pair_taps (flow -> tap addresses),  pair_load (raw tap values of
-// the 3 source channels and of the jitter mask, the target pixel, the direct jitter value),
-// pair_eval (masks, warped values).
-struct DirTaps {
-    Taps t;
-    PairAddr a;
-    float2 uv;
-};
-struct DirRaw2 {  // as loaded: one 8-byte pair per tap row
-    Quad2 src[3];
-    Quad2 jit[3];
-    float tgt[3];
-    float jd;
-};
-struct DirRaw {
-    Quad src[3];
-    Quad jit[3];
-    float tgt[3];
-    float jd;
-};
-
-__device__ __forceinline__ float2 pair_flow(const float* __restrict__ flow, int b, int xx, int yy, int H, int W) {
-    return *reinterpret_cast<const float2*>(flow + ((int64_t)b * H * W + (int64_t)yy * W + xx) * 2);
-}
-// ... guarded by the coverage bytes of the flow's render (hit == NULL: dense)
-__device__ __forceinline__ float2 pair_flow(const float* __restrict__ flow, const uint8_t* __restrict__ hit, int hit_is,
-                                            int hit_tiles_x, int hit_stride, int b, int xx, int yy, int H, int W) {
-    if (hit && !tile_covered(hit + (int64_t)b * hit_stride, hit_tiles_x, hit_is, xx, yy)) return make_float2(0.0f, 0.0f);
-    return pair_flow(flow, b, xx, yy, H, W);
-}
-
-__device__ __forceinline__ DirTaps pair_taps(float2 uv, int xx, int yy, int H, int W) {
-    DirTaps d;
-    d.uv = uv;
-    float ix, iy;
-    sample_pos((float)xx, (float)yy, d.uv.x, d.uv.y, W, H, ix, iy);
-    d.t = make_taps(ix, iy);
-    d.a = pair_addr(d.t, W, H);
-    return d;
-}
-
-__device__ __forceinline__ void pair_load(const DirTaps& d, const float* __restrict__ src,
-                                          const float* __restrict__ tgt, const float* __restrict__ jwarp,
-                                          const float* __restrict__ jdirect, int Cj, bool all_jitter_channels,
-                                          int b, int64_t pix, int64_t hw, DirRaw2& r) {
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        r.src[c] = load_quad2(src + ((int64_t)b * 3 + c) * hw, d.a);
-        r.tgt[c] = tgt[((int64_t)b * 3 + c) * hw + pix];
-    }
-    // channels 1, 2 only when the per-channel masks are requested (pair_eval then reads them; otherwise it
-    // uses channel 0 three times -- no copies of loaded values here, they would wait for the loads)
-    r.jit[0] = load_quad2(jwarp + (int64_t)b * Cj * hw, d.a);
-    const F2 z{0.0f, 0.0f};
-    r.jit[1].n = z; r.jit[1].s = z; r.jit[2].n = z; r.jit[2].s = z;
-    if (all_jitter_channels && Cj == 3) {
-        r.jit[1] = load_quad2(jwarp + ((int64_t)b * Cj + 1) * hw, d.a);
-        r.jit[2] = load_quad2(jwarp + ((int64_t)b * Cj + 2) * hw, d.a);
-    }
-    r.jd = jdirect[(int64_t)b * Cj * hw + pix];
-}
-
-__device__ __forceinline__ void pin(DirRaw2& r) {
-#pragma unroll
-    for (int c = 0; c < 3; c++) { pin(r.src[c]); pin(r.jit[c]); pin(r.tgt[c]); }
-    pin(r.jd);
-}
-
-__device__ __forceinline__ DirRaw unpack(const DirRaw2& r2, const PairAddr& a) {
-    DirRaw r;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        r.src[c] = quad_of(r2.src[c], a);
-        r.jit[c] = quad_of(r2.jit[c], a);
-        r.tgt[c] = r2.tgt[c];
-    }
-    r.jd = r2.jd;
-    return r;
-}
-
-__device__ __forceinline__ DirOut pair_eval(const DirTaps& d, const DirRaw& r, int H, int W, float thresh,
-                                            bool three_jitter_channels) {
-    DirOut o;
-    o.m = valid_mask(d.t, W, H, thresh);
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        o.s[c] = bilin_q(r.src[c], d.t, d.a) * o.m;
-        const float js = bilin_q(three_jitter_channels ? r.jit[c] : r.jit[0], d.t, d.a) * o.m;
-        o.wm[c] = o.m * ((js == 1.0f) ? 1.0f : 0.0f);
-    }
-    o.valid = (o.wm[0] != 0.0f) && (d.uv.x != 0.0f) && (r.jd == 1.0f);
-    return o;
-}
 
 // 64 x 4 pixel tiles (one 256-B row per wave); logical tile id -> (sample, tile) with the XCD-aware remap so that
 // vertically adjacent tiles (which share bilinear taps) run behind the same L2.
@@ -824,26 +460,6 @@ struct PairBwdParams {
     unsigned* grad_max;    // nullable: [2B] float bits, zero on entry: max |grad_flow12[b]| at [b], |grad_flow21[b]| at [B + b]
 };
 
-__device__ __forceinline__ float2 pair_grad(const DirTaps& d, const DirRaw& r, const DirOut& o, int H, int W,
-                                             float coef) {
-    float gu = 0.0f, gv = 0.0f;
-    if (o.valid && coef != 0.0f) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float gix, giy;
-            bilin_grad_q(r.src[c], d.t, d.a, gix, giy);
-            const float res = o.s[c] - r.tgt[c];
-            const float sg = (res > 0.0f) ? 1.0f : ((res < 0.0f) ? -1.0f : 0.0f);
-            const float g = sg * coef * o.m;
-            gu += g * gix;
-            gv += g * giy;
-        }
-        gu = gu * ((float)W / 2.0f) * (2.0f / (float)max(W - 1, 1));
-        gv = gv * ((float)H / 2.0f) * (2.0f / (float)max(H - 1, 1));
-    }
-    return make_float2(gu, gv);
-}
-
 __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParams p) {
     const int64_t hw = (int64_t)p.H * p.W;
     const unsigned total = (unsigned)p.ntiles * (unsigned)p.B;
@@ -930,32 +546,6 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
 // word is non-zero gets all its pixels (inside the crop) written; tiles with a zero word -- listed or not -- get
 // NOTHING, and no reader may look there.  Same XCD slices as the render's tile kernel (list_slice): what it wrote for
 // a tile is read back behind the same L2.
-struct ListArgs {
-    const TileList* tlist;
-    const uint4* ids;
-    unsigned cap;
-};
-
-struct TileAt {
-    int img, dir, b, tile, x, ry, y;  // image of the stack, direction (0: frame 1's grid, 1: frame 2's), pair, raster tile,
-    uint32_t word;                    // pixel column, raster row, image row of this thread; the tile's coverage word
-    bool row_covered;                 // this thread's row pair holds a covered pixel (the planes are defined there)
-};
-__device__ __forceinline__ TileAt tile_at(unsigned gtile, int B, int tiles_x, int T, int is, const uint8_t* __restrict__ hit_lo,
-                                          const uint8_t* __restrict__ hit_hi) {
-    TileAt t;
-    t.img = (int)(gtile / (unsigned)T);
-    t.tile = (int)(gtile % (unsigned)T);
-    t.dir = t.img >= B ? 1 : 0;
-    t.b = t.img - t.dir * B;
-    t.word = *reinterpret_cast<const uint32_t*>((t.dir ? hit_hi : hit_lo) + ((int64_t)t.b * T + t.tile) * 4);
-    t.x = (t.tile % tiles_x) * 32 + (int)(threadIdx.x & 31u);
-    t.ry = (t.tile / tiles_x) * 8 + (int)(threadIdx.x >> 5);
-    t.y = is - 1 - t.ry;
-    t.row_covered = ((t.word >> (8 * ((t.ry & 7) >> 1))) & 0xffu) != 0u;
-    return t;
-}
-
 struct OcclTilesParams {
     const float* mask[2];    // mask_flow1 / mask_flow2  [B,is,is]
     const float* flow[2];    // flow12 / flow21 planes (batch stride fbstride)
@@ -1078,6 +668,92 @@ __global__ void __launch_bounds__(256, 6) pair_consist_forward_tiles_kernel(Pair
             float* o = p.partial + ((int64_t)t.img * T + t.tile) * 2;
             o[0] = red[slot][0][0] + red[slot][1][0] + red[slot][2][0] + red[slot][3][0];
             o[1] = red[slot][0][1] + red[slot][1][1] + red[slot][2][1] + red[slot][3][1];
+        }
+    }
+}
+
+// occlusion_flow_tiles_kernel + pair_consist_forward_tiles_kernel in ONE pass (mr_flow_pair_forward_tiles): the thread that
+// has just formed its pixel's final flow is the one that warps the image with it.  Same arithmetic, same per-tile partial
+// sums (bit-identical losses); what disappears is the second kernel's chain of dependent loads (list counters -> entry ->
+// coverage word -> flow) in front of its taps, and a launch.  The pixel's own image values (target, direct jitter) do
+// not depend on the flow: they are requested before the occlusion check's gathers and have arrived when the taps go out.
+struct FlowPairFwdParams {
+    OcclTilesParams o;
+    const float* image_ref;   // [B,3,H,W], H = o.crop_h, W = o.crop_w
+    const float* image;
+    const float* jitter_ref;  // [B,Cj,H,W]
+    const float* jitter;
+    int Cj;
+    float* partial;           // [2B, T, 2]
+    float thresh;
+};
+
+__global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFwdParams q) {
+    __shared__ float red[2][4][2];
+    const OcclTilesParams& p = q.o;
+    unsigned j;
+    const ListSlice sl = list_slice(p.list.tlist->n_heavy, p.list.tlist->n_light, j);
+    const int T = p.tiles_x * p.tiles_y, is = p.is, H = p.crop_h, W = p.crop_w;
+    const int64_t hw = (int64_t)is * is, hw_img = (int64_t)H * W;
+    unsigned round = 0;
+    for (; j < sl.n_local; j += sl.stride, round++) {
+        const TileAt t = tile_at(p.list.ids[sl.slot(j, p.list.cap)].x, p.B, p.tiles_x, T, is, p.hit[0], p.hit[1]);
+        if (t.word == 0u) continue;  // (uniform)
+        float sum = 0.0f, cnt = 0.0f;
+        if (t.x < is && t.ry < is) {
+            const int a = t.dir, o_ = 1 - t.dir;
+            const float* ma = p.mask[a] + (int64_t)t.b * hw;
+            const float* mb = p.mask[o_] + (int64_t)t.b * hw;
+            const float* fab = p.flow[a] + (int64_t)t.b * p.fbstride;
+            const float* fba = p.flow[o_] + (int64_t)t.b * p.fbstride;
+            const float* sab = p.scale[a] ? p.scale[a] + (int64_t)t.b * hw : nullptr;
+            const float* sba = p.scale[o_] ? p.scale[o_] + (int64_t)t.b * hw : nullptr;
+            const uint8_t* ha = p.hit[a] + (int64_t)t.b * T * 4;
+            const uint8_t* hb = p.hit[o_] + (int64_t)t.b * T * 4;
+            const int64_t pix = (int64_t)t.y * is + t.x;
+            const bool in_crop = t.y < H && t.x < W;
+            const int64_t pixc = (int64_t)t.y * W + t.x;
+            // direction 0 = frame 1's grid: flow12 warps `image` towards image_ref, gated by jitter_ref; direction 1: the reverse
+            const float* src = t.dir ? q.image_ref : q.image;
+            const float* tgt = t.dir ? q.image : q.image_ref;
+            const float* jit = t.dir ? q.jitter : q.jitter_ref;
+            DirRaw2 raw{};
+            if (in_crop && t.row_covered) pair_load_own(tgt, jit, q.Cj, t.b, pixc, hw_img, raw);
+            float o = 0.0f;
+            if (t.row_covered) o = occl_one(ma, mb, fab, fba, sab, sba, hw, is, is, t.x, t.y, p.dist_thresh, p.wthresh, ha, hb, p.tiles_x);
+            p.occl[a][(int64_t)t.b * hw + pix] = o;
+            if (in_crop) {
+                const float sc = (o != 0.0f && sab) ? sab[pix] : 1.0f;
+                const float post = o != 0.0f ? ma[pix] * o : 0.0f;
+                float2 r = make_float2(0.0f, 0.0f);
+                if (post != 0.0f && sc != 0.0f) r = make_float2((fab[pix] * sc) * post, (fab[hw + pix] * sc) * post);
+                *reinterpret_cast<float2*>(p.out[a] + ((int64_t)t.b * hw_img + pixc) * 2) = r;
+#pragma unroll
+                for (int c = 0; c < 3; c++) pin(raw.tgt[c]);
+                pin(raw.jd);
+                if (r.x != 0.0f) {  // (a zero x component: invalid whatever the images hold, imgflowarp.py:93-100)
+                    const DirTaps tp = pair_taps(r, t.x, t.y, H, W);
+                    pair_load_taps(tp, src, jit, q.Cj, t.b, hw_img, raw);
+                    pin(raw);
+                    const DirRaw rr = unpack(raw, tp.a);
+                    const DirOut e = pair_eval(tp, rr, H, W, q.thresh, false);
+                    if (e.valid) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) sum += fabsf(e.s[c] - rr.tgt[c]);
+                        cnt = 3.0f;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { sum += __shfl_xor(sum, off); cnt += __shfl_xor(cnt, off); }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = round & 1u;
+        if (lane == 0) { red[slot][wave][0] = sum; red[slot][wave][1] = cnt; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* out = q.partial + ((int64_t)t.img * T + t.tile) * 2;
+            out[0] = red[slot][0][0] + red[slot][1][0] + red[slot][2][0] + red[slot][3][0];
+            out[1] = red[slot][0][1] + red[slot][1][1] + red[slot][2][1] + red[slot][3][1];
         }
     }
 }
@@ -1455,6 +1131,44 @@ extern "C" int mr_pair_consist_backward_tiles(const float* flow12, const float* 
     p.grad_max = reinterpret_cast<unsigned*>(grad_max);
     hipLaunchKernelGGL(pair_consist_backward_tiles_kernel, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
                        (hipStream_t)stream, p);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+
+extern "C" int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                                          const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                                          const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
+                                          float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2,
+                                          const float* image_ref, const float* image, const float* jitter_ref,
+                                          const float* jitter, int jitter_channels, void* workspace, int64_t workspace_bytes,
+                                          float* sums, float* loss_fwd, float* loss_bwd, int batch_size, int image_size,
+                                          int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
+                                          const void* list_header, const void* list_entries, int64_t list_capacity,
+                                          int64_t tile_bound, mr_stream_t stream) {
+    if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2 || !flow_out12 || !flow_out21)
+        return MR_ERR_BADARG;
+    if (batch_size < 0 || image_size <= 0 || flow_bstride < 2LL * image_size * image_size) return MR_ERR_BADARG;
+    const int rc = pair_tiles_args_ok(flow_out12, flow_out21, image_ref, image, jitter_ref, jitter, jitter_channels, batch_size,
+                                      height, width, tile_hit1, tile_hit2, image_size, list_header, list_entries, list_capacity);
+    if (rc != MR_OK) return rc;
+    if (!workspace || !sums || workspace_bytes < mr_pair_consist_tiles_workspace_bytes(batch_size, image_size))
+        return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    const int tiles_x = (image_size + 31) / 32, tiles_y = (image_size + 7) / 8;
+    FlowPairFwdParams q{};
+    q.o = OcclTilesParams{{mask_flow1, mask_flow2}, {flow12, flow21}, {flow12_scale, flow21_scale}, {occl1, occl2},
+                          {flow_out12, flow_out21}, {tile_hit1, tile_hit2}, flow_bstride, batch_size, image_size, height,
+                          width, tiles_x, tiles_y, distance_thresh, warp_thresh,
+                          {(const TileList*)list_header, (const uint4*)list_entries, (unsigned)list_capacity}};
+    q.image_ref = image_ref; q.image = image; q.jitter_ref = jitter_ref; q.jitter = jitter; q.Cj = jitter_channels;
+    q.partial = (float*)workspace; q.thresh = pair_thresh;
+    hipLaunchKernelGGL(flow_pair_forward_tiles_kernel, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
+                       (hipStream_t)stream, q);
+    MR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(64), 0, (hipStream_t)stream,
+                       (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit1),
+                       reinterpret_cast<const uint32_t*>(tile_hit2), batch_size, tiles_x * tiles_y, sums, loss_fwd, loss_bwd);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

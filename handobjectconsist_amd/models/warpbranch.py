@@ -54,6 +54,31 @@ def _frame_meshes(samples, all_results, hand_face, gt_refs, first_only):
     return frames, faces
 
 
+def _fused_pairs(samples, verts_world, all_faces, renderer, image_size, hand_ignore_faces, use_backward):
+    """The "loss" mode of ``forward`` with every (frame 0, frame k) pair as ONE fused node (opticalflow.flow_pair_loss:
+    render, then occlusion + epilogue + pair loss in one pass, one backward launch); None when the node does not apply."""
+    cams = [_q(sample, "camintr").cuda() for sample in samples]
+    ref_image, ref_jitter = _q(samples[0], "image").cuda(), _q(samples[0], "jittermask").cuda()
+    losses, flows = [], []
+    for k in range(1, len(samples)):
+        res = opticalflow.flow_pair_loss([verts_world[0], verts_world[k]], all_faces, [cams[0], cams[k]], renderer, image_size,
+                                         ref_image, _q(samples[k], "image").cuda(), ref_jitter,
+                                         _q(samples[k], "jittermask").cuda(), ignore_face_idxs=hand_ignore_faces)
+        if res is None:
+            return None if k == 1 else _raise_mixed()
+        loss_fwd, loss_bwd, pair_flows = res
+        losses.append(loss_bwd + loss_fwd if use_backward else loss_fwd)
+        flows.append(pair_flows)
+    diff_losses = torch.stack(losses)
+    none = [None] * len(losses)
+    return diff_losses.mean(), {"masks": none, "warps": list(none), "recons_flows": flows, "diffs": list(none),
+                                "diff_losses": diff_losses}
+
+
+def _raise_mixed():
+    raise RuntimeError("the fused pair node applied to the first frame pair of a sequence but not to a later one")
+
+
 def forward(
     samples,
     all_results,
@@ -81,6 +106,10 @@ def forward(
         (mean pair loss, {"masks", "warps", "recons_flows", "diffs", "diff_losses"})
     """
     verts_world, all_faces = _frame_meshes(samples, all_results, hand_face, gt_refs, first_only)
+    if pair_outputs == "loss" and imgflowarp._is_fused_l1(criterion):
+        fused = _fused_pairs(samples, verts_world, all_faces, renderer, image_size, hand_ignore_faces, use_backward)
+        if fused is not None:
+            return fused
     recons_flows = opticalflow.get_opticalflows(
         verts_world,
         all_faces,

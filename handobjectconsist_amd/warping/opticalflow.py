@@ -301,6 +301,56 @@ def _fused_epilogue_stacked(ro, orig_img_size, ignore_face_idxs):
     return [flows[:B], flows[B:]]
 
 
+def _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, want_grad):
+    """The flow-mode render of the 2B stacked meshes of a frame pair (mr_render_flow_forward): what both training nodes
+    (_StackedFlowFunction, _FlowPairLossFunction) start with.  Returns the buffers by name."""
+    from handobjectconsist_amd.neurender import rasterize
+
+    _lib.check_cuda(ndc, faces2, cols, lut)
+    if not (float(eps) >= 1e-6):
+        raise ValueError("vertex-colour rendering needs eps >= 1e-6")
+    verts, fidx, c = _lib.contig(ndc.detach()), faces2, _lib.contig(cols.detach())
+    dev = verts.device
+    B2, V = verts.shape[:2]
+    F0, is_ = fidx.shape[1], int(image_size)
+    if (fidx.dtype != torch.int32 or not fidx.is_contiguous() or B2 % 2 or fidx.shape != (B2, F0, 3)
+            or verts.shape != (B2, V, 3) or c.shape != (B2, V, 3)):
+        raise ValueError("expected stacked vertices / colours [2B,V,3] and contiguous int32 faces [2B,F,3]")
+    f32 = dict(dtype=torch.float32, device=dev)
+    bg, bg_stride = rasterize._background_tensor(background_color, dev, B2)
+    if DEBUG_POISON_RENDER_OUTPUTS:
+        new_f = lambda *shape: torch.full(shape, float("nan"), **f32)
+        new_i = lambda *shape: torch.full(shape, -2 ** 31, dtype=torch.int32, device=dev)
+    else:
+        new_f = lambda *shape: torch.empty(shape, **f32)
+        new_i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    rgb = new_f(B2, 3, is_, is_)
+    alpha, mask = new_f(B2, is_, is_), new_f(B2, is_, is_)
+    # the backward's inputs, valid at covered pixels only: sampling weights + vertex ids, or barycentrics + depth
+    depth = None if USE_PIXEL_RECORDS else new_f(B2, is_, is_)
+    vid = new_i(B2, is_, is_, 3) if USE_PIXEL_RECORDS else None
+    wmap = new_f(B2, is_, is_, 3)
+    fim = new_i(B2, is_, is_)
+    tile_hit = torch.empty((B2, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=dev)
+    F = 2 * F0 if fill_back else F0
+    wbytes = int(_lib.load().mr_render_workspace_bytes(B2, F, is_))
+    work = torch.empty((max(wbytes, 8),), dtype=torch.uint8, device=dev)
+    st = _lib.stream_ptr(dev)
+    bound, count_word = _tile_bound(dev, B2, is_) if (USE_SPARSE_TILES and USE_TILE_LIST) else (0, None)
+    # the backward's output buffer is cleared by the render's binning pass on its way (its own clearing would be a
+    # launch on the backward pass's critical path); a second backward through this node clears its own
+    grad_buf = torch.empty((B2, V, 3), **f32) if want_grad else None
+    _lib.call("mr_render_flow_forward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(c), _lib.ptr(bg), bg_stride,
+              _lib.ptr(lut), int(lut.numel()) if lut is not None else 0, 0.99999, _lib.ptr(rgb), _lib.ptr(alpha),
+              _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(wmap), _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(work), wbytes,
+              B2, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps),
+              _lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0, _lib.ptr(vid), bound, _lib.ptr(count_word), _lib.ptr(grad_buf),
+              int(grad_buf.numel()) if grad_buf is not None else 0, textutils.texel_layout_code(), st)
+    return dict(verts=verts, fidx=fidx, rgb=rgb, alpha=alpha, mask=mask, depth=depth, vid=vid, wmap=wmap, fim=fim,
+                tile_hit=tile_hit, work=work, bound=bound, grad_buf=grad_buf, new_f=new_f, f32=f32, dev=dev, st=st, B2=B2, V=V,
+                F=F, F0=F0, is_=is_)
+
+
 class _StackedFlowFunction(torch.autograd.Function):
     """The whole training-path body of ``get_opticalflow`` after the vertex stage as ONE autograd node:
     (ndc[2B,V,3], faces[2B,F0,3] int32, cols[2B,V,3]) -> flows[2B,H,W,2] (first half flow12, second half flow21).
@@ -320,49 +370,14 @@ class _StackedFlowFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, height, width,
                 sparse=False):
-        from handobjectconsist_amd.neurender import rasterize
-
         ctx.set_materialize_grads(False)
-        _lib.check_cuda(ndc, faces2, cols, lut)
-        if not (float(eps) >= 1e-6):
-            raise ValueError("vertex-colour rendering needs eps >= 1e-6")
-        verts, fidx, c = _lib.contig(ndc.detach()), faces2, _lib.contig(cols.detach())
-        dev = verts.device
-        B2, V = verts.shape[:2]
-        B, F0, is_ = B2 // 2, fidx.shape[1], int(image_size)
-        if (fidx.dtype != torch.int32 or not fidx.is_contiguous() or B2 % 2 or fidx.shape != (B2, F0, 3)
-                or verts.shape != (B2, V, 3) or c.shape != (B2, V, 3)):
-            raise ValueError("expected stacked vertices / colours [2B,V,3] and contiguous int32 faces [2B,F,3]")
-        f32 = dict(dtype=torch.float32, device=dev)
-        bg, bg_stride = rasterize._background_tensor(background_color, dev, B2)
-        if DEBUG_POISON_RENDER_OUTPUTS:
-            new_f = lambda *shape: torch.full(shape, float("nan"), **f32)
-            new_i = lambda *shape: torch.full(shape, -2 ** 31, dtype=torch.int32, device=dev)
-        else:
-            new_f = lambda *shape: torch.empty(shape, **f32)
-            new_i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
-        rgb = new_f(B2, 3, is_, is_)
-        alpha, mask = new_f(B2, is_, is_), new_f(B2, is_, is_)
-        # the backward's inputs, valid at covered pixels only: sampling weights + vertex ids, or barycentrics + depth
-        depth = None if USE_PIXEL_RECORDS else new_f(B2, is_, is_)
-        vid = new_i(B2, is_, is_, 3) if USE_PIXEL_RECORDS else None
-        wmap = new_f(B2, is_, is_, 3)
-        fim = new_i(B2, is_, is_)
-        tile_hit = torch.empty((B2, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=dev)
-        F = 2 * F0 if fill_back else F0
-        wbytes = int(_lib.load().mr_render_workspace_bytes(B2, F, is_))
-        work = torch.empty((max(wbytes, 8),), dtype=torch.uint8, device=dev)
-        st = _lib.stream_ptr(dev)
-        bound, count_word = _tile_bound(dev, B2, is_) if (USE_SPARSE_TILES and USE_TILE_LIST) else (0, None)
-        # the backward's output buffer is cleared by the render's binning pass on its way (its own clearing would be a
-        # launch on the backward pass's critical path); a second backward through this node clears its own
-        grad_buf = torch.empty((B2, V, 3), **f32) if ctx.needs_input_grad[2] else None
-        _lib.call("mr_render_flow_forward", _lib.ptr(verts), _lib.ptr(fidx), _lib.ptr(c), _lib.ptr(bg), bg_stride,
-                  _lib.ptr(lut), int(lut.numel()) if lut is not None else 0, 0.99999, _lib.ptr(rgb), _lib.ptr(alpha),
-                  _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(wmap), _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(work), wbytes,
-                  B2, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps),
-                  _lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0, _lib.ptr(vid), bound, _lib.ptr(count_word), _lib.ptr(grad_buf),
-                  int(grad_buf.numel()) if grad_buf is not None else 0, textutils.texel_layout_code(), st)
+        r = _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color,
+                                 ctx.needs_input_grad[2])
+        verts, fidx, rgb, alpha, mask, depth, vid, wmap, fim, tile_hit, work, bound, grad_buf = (
+            r["verts"], r["fidx"], r["rgb"], r["alpha"], r["mask"], r["depth"], r["vid"], r["wmap"], r["fim"], r["tile_hit"],
+            r["work"], r["bound"], r["grad_buf"])
+        new_f, f32, dev, st = r["new_f"], r["f32"], r["dev"], r["st"]
+        B2, V, B, F, is_ = r["B2"], r["V"], r["B2"] // 2, r["F"], r["is_"]
         # the render's tile list, for callers that accept flows defined under the covered tiles only
         tiles = None
         if sparse and USE_TILE_LIST_WARP and bound != 0:
@@ -416,6 +431,117 @@ class _StackedFlowFunction(torch.autograd.Function):
                   _lib.FLAG_OUTPUT_ZEROED if zeroed else 0, _lib.ptr(vid), textutils.texel_layout_code(), _lib.ptr(bound),
                   _lib.stream_ptr(verts.device))
         return (None, None, grad_cols) + (None,) * 10
+
+
+# The consistency term of a frame pair as ONE autograd node (warpbranch's "loss" mode): flow render, then occlusion check +
+# flow epilogue + pair loss in one pass over the render's tile list (mr_flow_pair_forward_tiles), and ONE backward launch in
+# which the pair loss's backward, the epilogue's adjoint and the scatter to the vertex colours run per covered tile
+# (mr_flow_pair_backward_tiles: the flow gradient never exists as a tensor).  False: get_opticalflow -> pair_consist, the
+# same kernels' arithmetic in five launches (same losses bit for bit, gradients to fp32 rounding).
+USE_FUSED_PAIR_NODE = True
+
+
+class _FlowPairLossFunction(torch.autograd.Function):
+    """(ndc[2B,V,3], faces[2B,F0,3] int32, cols[2B,V,3]; image_ref, image [B,3,H,W], jitter masks [B,Cj,H,W]) ->
+    (loss_fwd[B], loss_bwd[B], flows[2B,H,W,2], tile_hit): opticalflow.py:98-154 + imgflowarp.py:58-115 +
+    pyramidloss.py:56-62 + lossutils.py:1-8 for one frame pair.  Differentiable w.r.t. ``cols`` only (the training
+    setting: detach_renders=True, images are data).  ``flows`` are defined under the covered tiles only."""
+
+    @staticmethod
+    def forward(ctx, ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, height, width,
+                image_ref, image, jitter_ref, jitter, thresh):
+        ctx.set_materialize_grads(False)
+        _lib.check_cuda(image_ref, image, jitter_ref, jitter)
+        r = _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color,
+                                 ctx.needs_input_grad[2])
+        B2, B, is_, dev, st, new_f, f32 = r["B2"], r["B2"] // 2, r["is_"], r["dev"], r["st"], r["new_f"], r["f32"]
+        where = _lib.tile_list(r["work"], B2, r["F"], is_) if r["bound"] != 0 else None
+        if where is None or r["vid"] is None:
+            raise RuntimeError("the fused pair node needs the render's tile list and per-pixel records")
+        im_ref, im, jm_ref, jm = (_lib.contig(x) for x in (image_ref, image, jitter_ref, jitter))
+        Cj = jm.shape[1]
+        if (im.shape != (B, 3, height, width) or im_ref.shape != im.shape or Cj not in (1, 3)
+                or jm.shape != (B, Cj, height, width) or jm_ref.shape != jm.shape or width < 2):
+            raise ValueError("images must be [B,3,H,W] and jitter masks [B,1 or 3,H,W] of the flows' size")
+        rgb, alpha, mask, tile_hit = r["rgb"], r["alpha"], r["mask"], r["tile_hit"]
+        occl, flow = new_f(B2, is_, is_), new_f(B2, height, width, 2)
+        wbytes = int(_lib.load().mr_pair_consist_tiles_workspace_bytes(B, is_))
+        work = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
+        sums, loss_fwd, loss_bwd = torch.empty((B, 4), **f32), torch.empty((B,), **f32), torch.empty((B,), **f32)
+        _lib.call("mr_flow_pair_forward_tiles", _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(rgb[:B]), _lib.ptr(rgb[B:]),
+                  3 * is_ * is_, _lib.ptr(mask[:B]), _lib.ptr(mask[B:]), _lib.ptr(occl[:B]), _lib.ptr(occl[B:]),
+                  _lib.ptr(flow[:B]), _lib.ptr(flow[B:]), _lib.ptr(tile_hit[:B]), _lib.ptr(tile_hit[B:]), _lib.ptr(im_ref),
+                  _lib.ptr(im), _lib.ptr(jm_ref), _lib.ptr(jm), Cj, _lib.ptr(work), wbytes, _lib.ptr(sums), _lib.ptr(loss_fwd),
+                  _lib.ptr(loss_bwd), B, is_, height, width, 0.03, 0.99999, float(thresh), where[0], where[1], where[2],
+                  int(r["bound"]), st)
+        ctx.cfg = (is_, float(eps), bool(fill_back), height, width, float(thresh), int(r["F0"]), int(r["V"]))
+        ctx.save_for_backward(r["fim"], tile_hit, r["wmap"], r["vid"], mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums)
+        ctx.grad_buf = r["grad_buf"]
+        ctx.mark_non_differentiable(flow, tile_hit)
+        return loss_fwd, loss_bwd, flow, tile_hit
+
+    @staticmethod
+    def backward(ctx, g_fwd, g_bwd, _g_flow=None, _g_hit=None):
+        fim, tile_hit, wmap, vid, mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums = ctx.saved_tensors
+        is_, eps, fill_back, height, width, thresh, F0, V = ctx.cfg
+        if not ctx.needs_input_grad[2] or (g_fwd is None and g_bwd is None):
+            return (None,) * 17
+        B2 = fim.shape[0]
+        B, dev = B2 // 2, fim.device
+        if g_fwd is None:
+            g_fwd = torch.zeros((B,), dtype=torch.float32, device=dev)
+        g_fwd, g_bwd = _lib.contig(g_fwd), (_lib.contig(g_bwd) if g_bwd is not None else None)
+        grad_cols, ctx.grad_buf = ctx.grad_buf, None
+        zeroed = grad_cols is not None
+        if not zeroed:
+            grad_cols = torch.empty((B2, V, 3), dtype=torch.float32, device=dev)
+        # scratch of the launch: the masked flow gradient of a workgroup's tiles between its two passes
+        scratch = (torch.full((B2, height, width, 2), float("nan"), dtype=torch.float32, device=dev) if DEBUG_POISON_RENDER_OUTPUTS
+                   else torch.empty((B2, height, width, 2), dtype=torch.float32, device=dev))
+        _lib.call("mr_flow_pair_backward_tiles", _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(wmap), _lib.ptr(vid), _lib.ptr(flow),
+                  _lib.ptr(im_ref), _lib.ptr(im), _lib.ptr(jm_ref), _lib.ptr(jm), int(jm.shape[1]), _lib.ptr(sums), _lib.ptr(g_fwd),
+                  _lib.ptr(g_bwd), _lib.ptr(mask), _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(occl), _lib.ptr(scratch),
+                  height, width, _lib.ptr(grad_cols), B2, V, F0, int(fill_back), is_, eps, thresh,
+                  _lib.FLAG_OUTPUT_ZEROED if zeroed else 0, textutils.texel_layout_code(), _lib.stream_ptr(dev))
+        return (None, None, grad_cols) + (None,) * 14
+
+
+def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image_ref, image, jitter_mask_ref, jitter_mask,
+                   ignore_face_idxs=None):
+    """``get_opticalflow(verts_cam, ..., detach_textures=False, detach_renders=True)`` followed by
+    ``pair_consist(flows, image_ref, image, jitter_mask_ref, jitter_mask, PyramidCriterion("l1"))`` for ONE frame pair, as a
+    single fused node (no counterpart function in the reference: opticalflow.py:51-156 + imgflowarp.py:58-115 composed).
+
+    Returns ``(loss_fwd[B], loss_bwd[B], [flow12, flow21])`` -- ``pair_consist``'s ``warp_loss`` is ``loss_fwd`` (+
+    ``loss_bwd`` with ``use_backward``); the flows are defined under their renders' covered tiles only -- or ``None`` when the
+    fused node does not apply (renderer settings, raster size, tensors off the GPU): callers then compose the two functions."""
+    v1, v2 = verts_cam
+    if not (USE_FUSED_PAIR_NODE and USE_FUSED_VERTEX_STAGE and USE_FUSED_EPILOGUE and USE_SPARSE_TILES and USE_TILE_LIST
+            and USE_PIXEL_RECORDS and USE_TILE_LIST_WARP and _vertex_color_path(neurenderer, True)
+            and hasattr(neurenderer, "render_projected_vertex_colors") and v1.is_cuda and v1.dtype == torch.float32
+            and v2.shape == v1.shape and _stacked_flow_node_ok(neurenderer, v1.shape[1]) and image.is_cuda
+            and image.dtype == torch.float32 and image.dim() == 4 and image.shape[1] == 3 and image.shape[-1] >= 2
+            and jitter_mask.dim() == 4 and jitter_mask.shape[1] in (1, 3)):
+        return None
+    dev = v1.device
+    is_ = int(neurenderer.image_size)
+    W, H = (orig_img_size[0], orig_img_size[1]) if orig_img_size is not None else (is_, is_)
+    H, W = min(int(H), is_), min(int(W), is_)
+    if tuple(image.shape[2:]) != (H, W) or image_ref.shape != image.shape:
+        return None
+    F = faces.shape[1] * (2 if neurenderer.fill_back else 1)
+    if not _lib.has_tile_list(2 * v1.shape[0], F, is_):
+        return None
+    ndc, cols = _FlowVertexStage.apply(
+        v1, v2, camintrs[0].to(dev), camintrs[1].to(dev), neurenderer.R.to(dev), neurenderer.t.to(dev),
+        neurenderer.dist_coeffs.to(dev), neurenderer.orig_size)
+    lut = _keep_lut(ignore_face_idxs, dev) if ignore_face_idxs is not None else None
+    loss_fwd, loss_bwd, flows, tile_hit = _FlowPairLossFunction.apply(
+        ndc, _stacked_faces(faces), cols, lut, neurenderer.fill_back, is_, neurenderer.near, neurenderer.far,
+        neurenderer.rasterizer_eps, neurenderer.background_color, H, W, image_ref, image, jitter_mask_ref, jitter_mask, 0.99999)
+    B = v1.shape[0]
+    flows._hoc_coverage = (tile_hit, is_, flows._version, None)
+    return loss_fwd, loss_bwd, [flows[:B], flows[B:]]
 
 
 def _stacked_flow_node_ok(neurenderer, num_verts):

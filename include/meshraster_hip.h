@@ -65,7 +65,8 @@ typedef void* mr_stream_t;
  * 3: mr_render_flow_forward tile_bound / tile_count_out / zero_fill, MR_FLAG_OUTPUT_ZEROED, texel_layout of the four
  *    vertex-colour entry points;
  * 4: mr_render_tile_list, mr_occlusion_flow_tiles, mr_pair_consist_{forward,backward}_tiles, mr_pair_consist_tiles_workspace_bytes
- *    (the warp half of the training path over the render's tile list: the sparse contract, round 4). */
+ *    (the warp half of the training path over the render's tile list: the sparse contract, round 4),
+ *    mr_flow_pair_{forward,backward}_tiles (the same fused into one forward and one backward launch). */
 #define MR_ABI_VERSION 4
 MR_API int mr_abi_version(void);
 /* 1 if the calling thread's CURRENT HIP device is a gfx950, else 0.
@@ -511,6 +512,39 @@ MR_API int mr_pair_consist_backward_tiles(const float* flow12, const float* flow
                                           const uint8_t* tile_hit12, const uint8_t* tile_hit21, int hit_image_size,
                                           float* grad_max, const void* list_header, const void* list_entries,
                                           int64_t list_capacity, int64_t tile_bound, mr_stream_t stream);
+
+/* The consistency term of a frame pair in two launches (+ the render).
+ * mr_flow_pair_forward_tiles = mr_occlusion_flow_tiles + mr_pair_consist_forward_tiles in ONE pass over the tile list: the
+ * thread that has formed its pixel's final flow warps the image with it.  Arguments: those of mr_occlusion_flow_tiles
+ * (crop = height x width = the images' size) followed by those of mr_pair_consist_forward_tiles; outputs occl1 / occl2,
+ * flow_out12 / flow_out21 (sparse contract) and sums / loss_fwd / loss_bwd -- bit-identical to the two calls.
+ * mr_flow_pair_backward_tiles = mr_pair_consist_backward_tiles + mr_render_flow_backward (flow-space form, per-pixel
+ * records) in ONE launch over the stacked pair (batch_size = 2B images, split = B): every workgroup computes the pair
+ * loss's flow gradient of its tiles itself, times the epilogue masks, and scatters it to grad_vcolors [2B,V,3]; the flow
+ * gradient never exists as a tensor.  flows [2B,height,width,2]: the stacked final flows the forward wrote;
+ * grad_flow_scratch [2B,height,width,2]: scratch of the launch (contents unspecified afterwards); mask_pre / mask_x_lo /
+ * mask_x_hi / occl as for mr_render_flow_backward; sums / grad_loss_fwd / grad_loss_bwd as for mr_pair_consist_backward
+ * (grad_loss_bwd nullable); flags: MR_FLAG_OUTPUT_ZEROED.  Same products as the two calls; the fixed-point scale of the
+ * per-workgroup sums comes from the workgroup's own largest gradient. */
+MR_API int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                                      const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                                      const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
+                                      float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2,
+                                      const float* image_ref, const float* image, const float* jitter_ref,
+                                      const float* jitter, int jitter_channels, void* workspace, int64_t workspace_bytes,
+                                      float* sums, float* loss_fwd, float* loss_bwd, int batch_size, int image_size,
+                                      int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
+                                      const void* list_header, const void* list_entries, int64_t list_capacity,
+                                      int64_t tile_bound, mr_stream_t stream);
+MR_API int mr_flow_pair_backward_tiles(const int32_t* face_index_map, const uint32_t* tile_hit, const float* weight_map,
+                                       const int32_t* vertex_id_map, const float* flows, const float* image_ref,
+                                       const float* image, const float* jitter_ref, const float* jitter,
+                                       int jitter_channels, const float* sums, const float* grad_loss_fwd,
+                                       const float* grad_loss_bwd, const float* mask_pre, const float* mask_x_lo,
+                                       const float* mask_x_hi, const float* occl, float* grad_flow_scratch, int height,
+                                       int width, float* grad_vcolors, int batch_size, int num_verts, int num_faces,
+                                       int fill_back, int image_size, float eps, float pair_thresh, int flags,
+                                       int texel_layout, mr_stream_t stream);
 
 /* ---- dataset pipeline: decoded frames -> network-input batch ------------------------------
  * One launch for a whole batch of what meshreg/datasets/handobjset.py:361-379 does per sample on the

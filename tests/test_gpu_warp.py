@@ -719,3 +719,68 @@ def test_sparse_warp_half_equals_dense(cuda, monkeypatch, B, is_, H, Wd, bound):
                                         [t(s["K1"], cuda), t(s["K2"], cuda)], ren, orig_img_size=(Wd, H), sparse_flows=True)
     with pytest.raises(ValueError, match="sparse_flows"):
         imgflowarp.pair_consist(flows, im_ref, im, jm_ref, jm, crit, use_backward=True, outputs="full")
+
+
+@pytest.mark.parametrize("B,is_,H,Wd,bound", [(3, 256, 256, 256, None), (2, 96, 64, 96, 8), (2, 480, 270, 480, None),
+                                              (5, 64, 64, 64, 10 ** 6)])
+def test_fused_pair_node_equals_the_composed_path(cuda, monkeypatch, B, is_, H, Wd, bound):
+    """opticalflow.flow_pair_loss -- render, ONE pass for occlusion + epilogue + pair loss (mr_flow_pair_forward_tiles), ONE
+    backward launch for the pair loss's backward + the epilogue's adjoint + the scatter to the vertices
+    (mr_flow_pair_backward_tiles) -- against get_opticalflow(sparse_flows=True) -> pair_consist(outputs="loss"), the same
+    arithmetic in separate launches: losses and flows (under the covered tiles) bit for bit, vertex gradients of both frames
+    to fp32 rounding of the per-workgroup sums; on NaN-poisoned buffers, with per-sample loss weights on both terms."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import imgflowarp, opticalflow
+
+    s = synth.random_scene(B, seed=9, image_size=is_)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
+                   no_light=True, light_intensity_ambient=0.8)
+    im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, H, Wd, 6)]
+    crit = PyramidCriterion(criterion="l1")
+    wf, wb = torch.linspace(0.5, 1.5, B, device=cuda), torch.linspace(2.0, 0.25, B, device=cuda)
+    monkeypatch.setattr(opticalflow, "DEBUG_POISON_RENDER_OUTPUTS", True)
+    monkeypatch.setattr(imgflowarp, "DEBUG_POISON_SPARSE_GRADS", True)
+    if bound is not None:
+        real_bound = opticalflow._tile_bound
+        monkeypatch.setattr(opticalflow, "_tile_bound", lambda dev, B2, size: (bound, real_bound(dev, B2, size)[1]))
+    calls = []
+    real_call = imgflowarp._lib.call
+    monkeypatch.setattr(imgflowarp._lib, "call", lambda name, *a: (calls.append(name), real_call(name, *a))[1])
+    args = lambda v1, v2: ([v1, v2], t(s["faces"], cuda), [t(s["K1"], cuda), t(s["K2"], cuda)], ren)  # noqa: E731
+
+    def composed(only_fwd):
+        v1, v2 = t(s["verts1"], cuda).requires_grad_(True), t(s["verts2"], cuda).requires_grad_(True)
+        flows = opticalflow.get_opticalflow(*args(v1, v2), orig_img_size=(Wd, H), detach_textures=False, detach_renders=True,
+                                            ignore_face_idxs=synth.HAND_IGNORE_FACES, sparse_flows=True)
+        res = imgflowarp._PairConsistFunction.apply(flows[0]._base, None, im_ref, im, jm_ref, jm, 0.99999, False,
+                                                    *imgflowarp._coverage_of(flows[0]._base), imgflowarp._tiles_of(flows[0]._base))
+        lf, lb = res[0], res[1]
+        ((lf * wf).sum() if only_fwd else (lf * wf).sum() + (lb * wb).sum()).backward()
+        return lf.detach(), lb.detach(), flows[0]._base.detach().clone(), flows[0]._base._hoc_coverage[0], v1.grad, v2.grad
+
+    def fused(only_fwd):
+        v1, v2 = t(s["verts1"], cuda).requires_grad_(True), t(s["verts2"], cuda).requires_grad_(True)
+        res = opticalflow.flow_pair_loss(*args(v1, v2), (Wd, H), im_ref, im, jm_ref, jm, ignore_face_idxs=synth.HAND_IGNORE_FACES)
+        assert res is not None, "the fused node must apply to this configuration"
+        lf, lb, flows = res
+        ((lf * wf).sum() if only_fwd else (lf * wf).sum() + (lb * wb).sum()).backward()
+        return lf.detach(), lb.detach(), flows[0]._base.detach().clone(), flows[0]._base._hoc_coverage[0], v1.grad, v2.grad
+
+    for only_fwd in (False, True):
+        ref = composed(only_fwd)
+        del calls[:]
+        got = fused(only_fwd)
+        assert "mr_flow_pair_forward_tiles" in calls and "mr_flow_pair_backward_tiles" in calls
+        assert not any(n in calls for n in ("mr_pair_consist_backward_tiles", "mr_render_flow_backward", "mr_occlusion_flow_tiles"))
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), "losses"
+        assert float(ref[0].abs().sum()) > 0 and float(ref[1].abs().sum()) > 0
+        assert torch.equal(got[3], ref[3]), "coverage bytes"
+        words = ref[3].contiguous().view(torch.int32).view(2 * B, (is_ + 7) // 8, (is_ + 31) // 32).cpu().numpy() != 0
+        yy, xx = np.mgrid[0:H, 0:Wd]
+        defined = torch.from_numpy(words[:, (is_ - 1 - yy) >> 3, xx >> 5]).to(cuda)
+        assert torch.equal(got[2][defined], ref[2][defined]) and torch.isnan(got[2][~defined]).all(), "flows"
+        for a, b_, what in ((got[4], ref[4], "d/d vertices of frame 1"), (got[5], ref[5], "d/d vertices of frame 2")):
+            assert torch.isfinite(a).all() and float(b_.abs().sum()) > 0, what
+            close(a.cpu().numpy(), b_.cpu().numpy(), 1e-5, 1e-6 * float(b_.abs().max()), what)
