@@ -66,6 +66,9 @@ def parse():
     p.add_argument("--roofline-only", action="store_true",
                    help="launch only the two roofline kernels a few times (what the in-run PMC passes profile)")
     p.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic")
+    p.add_argument("--step-only", action="store_true",
+                   help="only the timed training steps (no hot-path / stock-trunk / kernel / CPU legs): what the in-run "
+                        "rocprofv3 --kernel-trace pass behind roofline.frac_in_step profiles")
     p.add_argument("--reducer-ab", type=int, default=0, metavar="PAIRS",
                    help="A/B inside ONE process (one model, one set of MIOpen / TunableOp solver choices): PAIRS x "
                         "(--steps plain steps, then --steps steps through the RCCL process group + bucketed gradient "
@@ -102,22 +105,30 @@ def event_time_ms(fn, iters, warmup=5, flush=None):
     return total / iters
 
 
-ROOF_BWD = "render_flow_backward(train,E+epilogue adjoint,2B)"
+# The raster backward AS THE TRAINING STEP LAUNCHES IT since round 4: one launch in which every workgroup computes the pair
+# loss's flow gradient of its covered tiles, applies the epilogue adjoint and scatters to the vertex colours
+# (mr_flow_pair_backward_tiles).  ROOF_BWD_PLAIN: the scatter alone on a given flow gradient (mr_render_flow_backward, rounds 2-3).
+ROOF_BWD = "flow_pair_backward_tiles(train: pair-loss bwd + epilogue adjoint + E scatter,2B)"
+ROOF_BWD_PLAIN = "render_flow_backward(train,E+epilogue adjoint,2B)"
 ROOF_FWD = "render_flow_forward(train outputs,both frames=2B)"
-# the device kernels behind the two groups (names as rocprofv3 prints them)
-ROOF_KERNELS = {ROOF_BWD: ["scatter_tiles_kernel<true, true>"],
+FUSED_FWD = "flow_pair_forward_tiles(train: occlusion + epilogue + pair loss, sparse)"
+# the device kernels behind the groups (names as rocprofv3 prints them)
+ROOF_KERNELS = {ROOF_BWD: ["pair_scatter_tiles_kernel"], ROOF_BWD_PLAIN: ["scatter_tiles_kernel<true, true>"],
                 ROOF_FWD: ["face_records_kernel<true>", "bin_boxes_kernel", "raster_tile_kernel<true, true>"]}
-WARP_TILES_KERNELS = ("occlusion_flow_tiles_kernel", "pair_consist_forward_tiles_kernel", "pair_consist_backward_tiles_kernel")
+WARP_TILES_KERNELS = ("occlusion_flow_tiles_kernel", "pair_consist_forward_tiles_kernel", "pair_consist_backward_tiles_kernel",
+                      "flow_pair_forward_tiles_kernel")
 
 
 ROOF_OPTIONAL = ()
 # the warp half over the render's tile list (round 4) and what one pixel of a covered tile makes each pass move
 WARP_TILES = ("occlusion_flow_tiles(train: occlusion + flow epilogue, sparse)", "pair_consist_forward_tiles(train, sparse)",
-              "pair_consist_backward_tiles(train, sparse)")
-WARP_TILES_BYTES = (44, 40, 48)
+              "pair_consist_backward_tiles(train, sparse)", FUSED_FWD)
+WARP_TILES_BYTES = (44, 40, 48, 76)
 WARP_TILES_WHAT = ("per pixel of a covered tile: own mask 4 + scale 4 + flow 8, gathered flow 8 + scale 4 + mask 4, out occl 4 + flow 8",
                    "per pixel of a covered tile: flow 8 + source 12 + target 12 + two jitter values 8 (each image pixel counted once)",
-                   "per pixel of a covered tile: flow 8 + source 12 + target 12 + two jitter values 8, out grad_flow 8")
+                   "per pixel of a covered tile: flow 8 + source 12 + target 12 + two jitter values 8, out grad_flow 8",
+                   "per pixel of a covered tile: the occlusion pass's 44 + source 12 + target 12 + two jitter values 8 (the flow it "
+                   "warps with never leaves the thread)")
 
 
 def kernel_bench(dev, B, is_, iters, only=None):
@@ -304,6 +315,20 @@ def kernel_bench(dev, B, is_, iters, only=None):
                   P(gl), P(g12), P(g21), B, is_, is_, 0.99999, P(ptile_hit[:B]), P(ptile_hit[B:]), is_,
                   P(pgmax) if os.environ.get("HOC_GRAD_BOUND", "1") == "1" else None, tlist[0], tlist[1], tlist[2], tl_bound, st)
 
+    def flow_pair_fwd_tiles():  # the step's forward launch: occlusion + epilogue + pair loss, one pass over the list
+        _lib.call("mr_flow_pair_forward_tiles", P(pmask[:B]), P(palpha[B:]), P(prgb[:B]), P(prgb[B:]), 3 * is_ * is_, P(pmask[:B]),
+                  P(pmask[B:]), P(pocc[:B]), P(pocc[B:]), P(pflows[:B]), P(pflows[B:]), P(ptile_hit[:B]), P(ptile_hit[B:]),
+                  P(im_ref), P(im), P(jm_ref), P(jm), 3, P(ptwork), ptbytes, P(sums), P(lf), P(lb), B, is_, is_, is_, 0.03, 0.99999,
+                  0.99999, tlist[0], tlist[1], tlist[2], tl_bound, st)
+
+    pscratch = torch.empty((B2, is_, is_, 2), **f32)
+
+    def flow_pair_bwd_tiles():  # the step's backward launch (output cleared by the forward's binning pass, as in the step)
+        _lib.call("mr_flow_pair_backward_tiles", P(pfim), P(ptile_hit), P(pwrec), P(pvid), P(pflows), P(im_ref), P(im), P(jm_ref),
+                  P(jm), 3, P(sums), P(gl), P(gl), P(pmask), P(pmask[:B]), P(palpha[B:]), P(pocc), P(pscratch), is_, is_,
+                  P(pg_cols), B2, pv.shape[1], F0, 1, is_, 1e-3, 0.99999,
+                  _lib.FLAG_OUTPUT_ZEROED | (int(os.environ.get("HOC_FLOW_BWD_DBG", "0")) << 8), 0, st)
+
     m1, m2 = alpha.unsqueeze(1).contiguous(), alpha.unsqueeze(1).contiguous()
     o1, o2 = torch.empty((B, is_, is_), **f32), torch.empty((B, is_, is_), **f32)
 
@@ -383,6 +408,9 @@ def kernel_bench(dev, B, is_, iters, only=None):
         (WARP_TILES[0], occlusion_flow_tiles, (8 + 16 + 8 + 16) * npx),
         (WARP_TILES[1], pair_fwd_tiles, 48 * npx),
         (WARP_TILES[2], pair_bwd_tiles, 64 * npx),
+        # ... and fused, as the training step launches them now: SURVEY 8(d)'s bytes of the passes each replaces
+        (FUSED_FWD, flow_pair_fwd_tiles, (8 + 16 + 8 + 16) * npx + 48 * npx),
+        (ROOF_BWD, flow_pair_bwd_tiles, 64 * npx + 2 * ((12 + 4 + 12 + 4) * npx + (36 + 96) * BF)),
         ("occlusion_mask", occlusion, (8 + 16 + 8) * npx),
         # + the two final flows written in the same pass (16 B per pixel)
         ("occlusion_flow(train: occlusion + flow epilogue)", occlusion_flow, (8 + 16 + 8 + 16) * npx),
@@ -419,6 +447,17 @@ def kernel_bench(dev, B, is_, iters, only=None):
                       "compulsory_frac_hbm_peak": round(comp / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "compulsory_frac_hbm_peak_cache_warm": round(comp / (k["ms_cache_warm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     if ROOF_BWD in out:
+        # the fused launch: per pixel of a covered tile face index 4 + vertex ids 12 + sampling weights 12 + three masks 12
+        # + final flow 8 + source 12 + target 12 + two jitter values 8 = 80 B (its scratch stays in the L2 of the
+        # workgroup that writes and re-reads it), the coverage bytes and the [2B,V,3] output
+        comp = covered_words * 32 * 8 * 80 + ptile_hit.numel() + pg_cols.numel() * 4
+        k = out[ROOF_BWD]
+        k.update({"covered_tiles": covered_words, "tiles": int(ptile_hit.numel() // 4), "compulsory_bytes": int(comp),
+                  "compulsory_per_pixel": 80,
+                  "compulsory_GBps": round(comp / (k["ms"] * 1e-3) / 1e9, 1),
+                  "compulsory_frac_hbm_peak": round(comp / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "compulsory_frac_hbm_peak_cache_warm": round(comp / (k["ms_cache_warm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    if ROOF_BWD_PLAIN in out:
         # What the raster backward of the training path HAS to move, at least once, for this scene: per tile the forward
         # reports as covered (coverage bytes) the 256 pixels of face_index_map 4 + vertex ids 12 + sampling weights 12 +
         # flow gradient 8 + three masks 12 = 48 B, the coverage bytes themselves and the [2B,V,3] output.  The SURVEY 8(d)
@@ -428,8 +467,9 @@ def kernel_bench(dev, B, is_, iters, only=None):
         # `frac_algorithmic`.
         covered = int((ptile_hit.view(torch.int32) != 0).sum())
         comp = covered * 32 * 8 * 48 + ptile_hit.numel() + pg_cols.numel() * 4
-        k = out[ROOF_BWD]
+        k = out[ROOF_BWD_PLAIN]
         k.update({"covered_tiles": covered, "tiles": int(ptile_hit.numel() // 4), "compulsory_bytes": int(comp),
+                  "compulsory_per_pixel": 48,
                   "compulsory_GBps": round(comp / (k["ms"] * 1e-3) / 1e9, 1),
                   "compulsory_frac_hbm_peak": round(comp / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                   "compulsory_frac_hbm_peak_cache_warm": round(comp / (k["ms_cache_warm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
@@ -525,7 +565,47 @@ def pmc_traffic_in_run(args, timeout=420):
     return out
 
 
-def roofline_block(name, k, pmc, units):
+def in_step_durations(args, timeout=420):
+    """Durations of this build's kernels INSIDE training steps: one `rocprofv3 --kernel-trace` pass over
+    `bench.py --step-only` (a few steps of the same workload, nothing else in the process), median per kernel name in
+    microseconds.  MIOpen's measured solver search and TunableOp are off in that subprocess (it only has to reach the
+    steady state quickly; the render / warp kernels do not depend on them).  {} when rocprofv3 is missing or the pass fails."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}
+    tmp = tempfile.mkdtemp(prefix="hoc_step_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+           "--step-only", "--steps", "6", "--warmup", "3", "--batch", str(args.batch), "--image-size", str(args.image_size)]
+    if args.image_height:
+        cmd += ["--image-height", str(args.image_height)]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", HOC_CUDNN_BENCHMARK="0", HOC_TUNABLEOP="0"),
+                       timeout=timeout, capture_output=True, check=True)
+        files = glob.glob(os.path.join(tmp, "**", "p_kernel_trace.csv"), recursive=True)
+        per = {}
+        with open(files[0]) as fh:
+            for row in csv.DictReader(fh):
+                name = row["Kernel_Name"]
+                if "mr::" not in name:
+                    continue
+                key = name.split("(")[0].replace("void ", "").replace("mr::", "")
+                per.setdefault(key, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+        return {k: {"median_us": round(statistics.median(v), 2), "min_us": round(min(v), 2), "dispatches": len(v)} for k, v in per.items()}
+    except Exception as e:  # noqa: BLE001 -- informational
+        sys.stderr.write(f"[bench] in-step kernel-trace pass failed: {e}\n")
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def roofline_block(name, k, pmc, units, in_step=None):
     """`frac` = bytes / HIP-event duration with cold caches / peak, where bytes = the kernel's own COMPULSORY traffic when
     the kernel bench states it (the raster backward: covered tiles only -- cannot exceed 1 by construction) and SURVEY
     8(d)'s algorithmic bytes otherwise; `frac_algorithmic` always carries the SURVEY 8(d) figure; `dram_frac` = the bytes
@@ -535,12 +615,17 @@ def roofline_block(name, k, pmc, units):
             "unit": "GB/s", "frac": k["compulsory_frac_hbm_peak"] if own else k["frac_hbm_peak"],
             "frac_cache_warm": k["compulsory_frac_hbm_peak_cache_warm"] if own else k["frac_hbm_peak_cache_warm"],
             "bytes": k["compulsory_bytes"] if own else k["algorithmic_bytes"],
-            "bytes_are": ("compulsory traffic of this launch: 48 B per pixel of the %d covered tiles of %d + coverage bytes + "
-                          "output" % (k["covered_tiles"], k["tiles"])) if own else "algorithmic bytes of SURVEY 8(d)",
+            "bytes_are": ("compulsory traffic of this launch: %d B per pixel of the %d covered tiles of %d + coverage bytes + "
+                          "output" % (k["compulsory_per_pixel"], k["covered_tiles"], k["tiles"])) if own else "algorithmic bytes of SURVEY 8(d)",
             "traffic": None, "algorithmic_bytes": k["algorithmic_bytes"], "achieved_algorithmic": k["GBps"],
             "frac_algorithmic": k["frac_hbm_peak"], "frac_algorithmic_cache_warm": k["frac_hbm_peak_cache_warm"],
             "launch_ms": k["ms"], "launch_ms_cache_warm": k["ms_cache_warm"],
             "units_per_launch": units, "device_kernels": ROOF_KERNELS[name]}
+    if in_step and all(d in in_step for d in ROOF_KERNELS[name]):
+        us = sum(in_step[d]["median_us"] for d in ROOF_KERNELS[name])
+        roof.update({"in_step_us": round(us, 2), "frac_in_step": round(roof["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "in_step_source": "median duration of the kernel(s) inside training steps, rocprofv3 --kernel-trace pass "
+                                       "over `bench.py --step-only` run by this process"})
     found = [pmc[d] for d in ROOF_KERNELS[name] if d in pmc]
     if len(found) >= len([d for d in ROOF_KERNELS[name] if d not in ROOF_OPTIONAL]):
         hi, lo = sum(f["hbm_bytes"] for f in found), sum(f["hbm_bytes_low"] for f in found)
@@ -635,7 +720,7 @@ def main():
 
     assert _lib.load().mr_device_ok() == 1, "libmeshraster_hip.so: no gfx950 device"
     if args.kernels_only or args.roofline_only:
-        only = (ROOF_BWD, ROOF_FWD) + WARP_TILES if args.roofline_only else None
+        only = (ROOF_BWD, ROOF_BWD_PLAIN, ROOF_FWD) + WARP_TILES if args.roofline_only else None
         if os.environ.get("HOC_KERNEL_GROUPS"):  # profiling aid: group names of kernel_bench, separated by ";"
             only = tuple(os.environ["HOC_KERNEL_GROUPS"].split(";"))
         os.write(real_stdout, (json.dumps(kernel_bench(dev, args.batch, args.image_size, args.kernel_iters, only), indent=1) + "\n").encode())
@@ -754,6 +839,13 @@ def main():
 
     # hot path alone (2 renders, flows, occlusion, pair loss, backward to the vertices)
     hot_ms = None
+    if args.step_only:
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 3), "steps": args.steps}) + "\n").encode())
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if rank == 0:
         from handobjectconsist_amd.models import warpbranch
 
@@ -829,16 +921,18 @@ def main():
             _sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark = saved
         torch.cuda.empty_cache()
 
-    kernels, roof, roof_fwd, cpu, warp_tiles = None, None, None, None, None
+    kernels, roof, roof_fwd, cpu, warp_tiles, in_step_line = None, None, None, None, None, None
     if rank == 0 and not args.no_kernel_bench:
         kernels = kernel_bench(dev, B, is_, args.kernel_iters)
         pmc = {} if (args.no_pmc or world > 1) else pmc_traffic_in_run(args)
+        in_step = {} if (args.no_pmc or world > 1) else in_step_durations(args)
         units = f"{2 * B} renders of {is_}x{is_}, 7104 faces"
         # the raster backward (north star) in the shape the training step launches it: one launch for both frames of
-        # the pair, the adjoint of the flow epilogue folded in
-        roof = roofline_block(ROOF_BWD, kernels[ROOF_BWD], pmc, units)
+        # the pair, the pair loss's backward and the adjoint of the flow epilogue folded in
+        roof = roofline_block(ROOF_BWD, kernels[ROOF_BWD], pmc, units, in_step)
+        roof["scatter_alone"] = roofline_block(ROOF_BWD_PLAIN, kernels[ROOF_BWD_PLAIN], pmc, units)
         # ... and the forward of the same launch shape: the hot-path kernel that takes the most time
-        roof_fwd = roofline_block(ROOF_FWD, kernels[ROOF_FWD], pmc, units)
+        roof_fwd = roofline_block(ROOF_FWD, kernels[ROOF_FWD], pmc, units, in_step)
         # the warp half of the step (launched over the render's tile list): compulsory-bytes fractions + PMC traffic
         warp_tiles = {}
         for name, dk in zip(WARP_TILES, WARP_TILES_KERNELS):
@@ -850,7 +944,11 @@ def main():
             if dk in pmc:
                 w.update({"traffic": pmc[dk]["hbm_bytes"], "traffic_low": pmc[dk]["hbm_bytes_low"],
                           "write_bytes": int(pmc[dk]["WRITE_SIZE_KB"] * 1024), "fetch_bytes_as_reported": int(pmc[dk]["FETCH_SIZE_KB"] * 1024)})
+            if dk in in_step:
+                w.update({"in_step_us": in_step[dk]["median_us"],
+                          "frac_in_step": round(w["bytes"] / (in_step[dk]["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
             warp_tiles[name] = w
+        in_step_line = in_step or None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_sample, is_, B)
         if (os.cpu_count() or 1) > 8:  # the figure that lines up with BASELINE.md's 8-thread reference measurement
@@ -879,7 +977,8 @@ def main():
                         "epilogue, pair loss, their backward passes)",
                 "device_ms_graph_replay": None if hot_graph_ms is None else round(hot_graph_ms, 3),
                 "eager_ms_host_bound": round(hot_eager_ms, 3)},
-            "ranks": ranks, "stock_trunk": stock, "roofline": roof, "roofline_forward": roof_fwd, "warp_tiles": warp_tiles, "kernels": kernels, "cpu_baseline": cpu,
+            "ranks": ranks, "stock_trunk": stock, "roofline": roof, "roofline_forward": roof_fwd, "warp_tiles": warp_tiles,
+            "in_step_kernels_us": in_step_line, "kernels": kernels, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
