@@ -14,6 +14,7 @@ ABI_VERSION = 4  # MR_ABI_VERSION of include/meshraster_hip.h
 FLAG_REFERENCE_ALGO = 1
 FLAG_SPARSE_TILES = 2
 FLAG_OUTPUT_ZEROED = 4
+FLAG_TILE_PER_WORKGROUP = 8
 
 _c = ctypes
 _P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64

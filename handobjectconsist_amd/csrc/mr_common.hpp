@@ -447,7 +447,8 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
 struct TileList {
     unsigned n_heavy;  // tiles with at least HEAVY_RECS candidate records, all images: dispatched FIRST; entries [0, n_heavy)
     unsigned n_light;  // the other tiles with at least one candidate record; entries [cap, cap + n_light)
-    unsigned pad[62];
+    unsigned n_bg;     // dense launches: the tiles WITHOUT candidates (pure background), listed in a separate id array
+    unsigned pad[61];
 };
 
 // A workgroup's place in a listed launch.  The dispatcher puts workgroup i on XCD i % 8, and every XCD has its own L2:

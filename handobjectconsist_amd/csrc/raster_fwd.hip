@@ -48,6 +48,8 @@
 // z-buffer key (depth, face index) makes the depth test a commutative minimum.
 // HBM traffic: faces 36 B + 48 B + ~3 x 16 B records per live face, outputs written exactly once; no
 // per-pixel memset, no sampling maps, no separate flip / permute / alpha / background pass.
+#include <algorithm>
+
 #include "mr_common.hpp"
 
 namespace mr {
@@ -121,6 +123,7 @@ struct BinParams {
                              // count of the bin's records, length of the image's large list}, grouped by image: everything
                              // a tile's workgroup needs to start on its records after ONE scalar load
     uint8_t* tile_hit;       // [B, tiles, 4]: the binning pass writes the (zero) coverage bytes of the other tiles
+    uint32_t* bg_ids;        // nullable (dense launches): [B * tiles] receives the global ids of the tiles WITHOUT candidates
     float* zero_fill;        // nullable: cleared by the binning pass (the matching backward's gradient buffer)
     int64_t zero_count;
 };
@@ -134,7 +137,7 @@ template <bool VC>
 __global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
     const int b = blockIdx.y;
     const int f0 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p.tlist && b == 0 && f0 == 0) { p.tlist->n_heavy = 0u; p.tlist->n_light = 0u; }  // (this launch precedes the binning pass)
+    if (p.tlist && b == 0 && f0 == 0) { p.tlist->n_heavy = 0u; p.tlist->n_light = 0u; p.tlist->n_bg = 0u; }  // (this launch precedes the binning pass)
     if (f0 >= p.F0) return;
     const int is = p.is;
     float f[9];
@@ -201,7 +204,7 @@ __device__ unsigned long long mr_dbg_bin[1024 * 8];  // profiling builds: phase 
 __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     MR_BIN_STAMP(0);
     extern __shared__ int bin_smem[];
-    __shared__ int s_large, s_nlarge, s_lbase, s_hbase;
+    __shared__ int s_large, s_nlarge, s_lbase, s_hbase, s_bbase;
     __shared__ unsigned long long wsum[BIN_TPB / MR_WAVE];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbins = p.nbx * p.nby;
@@ -276,6 +279,7 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         const unsigned n_ne = (unsigned)(total64 >> 32) & 0xffffu, n_hv = (unsigned)(total64 >> 48);
         s_hbase = (int)atomicAdd(&p.tlist->n_heavy, n_hv);
         s_lbase = (int)atomicAdd(&p.tlist->n_light, n_ne - n_hv);
+        if (p.bg_ids) s_bbase = (int)atomicAdd(&p.tlist->n_bg, (unsigned)nbins - n_ne);
     }
     BinHdr* bh = p.bins + (int64_t)b * nbins;
     unsigned livebits = 0u;  // (per <= MAX_BINS / BIN_TPB = 8 bins per thread)
@@ -296,6 +300,7 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         const unsigned hv_before = (unsigned)(base64 >> 48), ne_before = (unsigned)(base64 >> 32) & 0xffffu;
         unsigned at_h = (unsigned)s_hbase + hv_before;                                   // heavy part: from the front
         unsigned at_l = (unsigned)p.tile_cap + (unsigned)s_lbase + (ne_before - hv_before);  // light part: second half
+        unsigned at_b = p.bg_ids ? (unsigned)s_bbase + ((unsigned)i0 - ne_before) : 0u;     // tiles without candidates
         uint32_t* hit32 = reinterpret_cast<uint32_t*>(p.tile_hit) + (int64_t)b * nbins;
         const unsigned nlarge = (unsigned)s_nlarge;
         for (int i = i0; i < i1; i++) {
@@ -305,6 +310,7 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
             const uint4 ent = make_uint4((unsigned)(b * nbins + i), off, end - off, nlarge);
             if (live && end - off + nlarge >= HEAVY_RECS) p.tile_ids[at_h++] = ent;
             else if (live) p.tile_ids[at_l++] = ent;
+            else if (p.bg_ids) p.bg_ids[at_b++] = (unsigned)(b * nbins + i);
             else hit32[i] = 0u;
         }
         __syncthreads();  // (pass 2 moves the cursors)
@@ -387,6 +393,8 @@ struct FwdParams {
     const TileList* tlist;
     const uint4* tile_ids;           // heavy entries [0, n_heavy), light entries [tile_cap, tile_cap + n_light)
     unsigned tile_cap;
+    const uint32_t* bg_ids;          // dense listed launches: ids of the tlist->n_bg tiles without candidates, which the
+                                     // workgroups of the launch stream as background between them (grid stride)
     uint32_t* tile_count_out;        // nullable, any device-writable address (e.g. pinned host memory): the list
                                      // length of this launch, for the caller's next grid-size guess
     // vertex-colour mode (VC): indexed geometry + per-vertex colours, fill-back done by index
@@ -451,6 +459,40 @@ __device__ __forceinline__ void zbuf_min(unsigned long long* zb, int idx, float 
 __device__ unsigned long long mr_dbg_times[65536 * 4];
 #endif
 
+// A tile no face can touch is pure background: every requested plane streamed with 16-byte stores (full tiles of rasters
+// whose side is a multiple of 4; one 128-B row segment = 8 float4 of a scalar plane / 24 float4 of weight_map).
+__device__ __forceinline__ void stream_background_tile(const FwdParams& p, int b, int t, int tx0, int ty0) {
+    const int tid = threadIdx.x, is = p.is;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    // one 128-B row segment = 8 float4 (scalar planes) / 24 float4 (weight_map, 3 floats per pixel)
+    const int64_t plane = (int64_t)is * is;
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (tid < TILE_H * 8) {
+        const int row = tid >> 3, seg = tid & 7;
+        const int64_t ro = ((int64_t)b * is + ty0 + row) * is + tx0;            // raster orientation
+        const int64_t io = ((int64_t)b * is + (is - 1 - ty0 - row)) * is + tx0;  // image orientation
+        const int m1 = -1;
+        const float fm1 = __int_as_float(m1);
+        reinterpret_cast<float4*>(p.fim + ro)[seg] = make_float4(fm1, fm1, fm1, fm1);
+        if (p.depth && !p.sparse_wd) reinterpret_cast<float4*>(p.depth + io)[seg] = make_float4(p.far_, p.far_, p.far_, p.far_);
+        if (p.alpha) reinterpret_cast<float4*>(p.alpha + io)[seg] = zero4;
+        if (p.mask) reinterpret_cast<float4*>(p.mask + io)[seg] = zero4;
+        if (p.rgb) {
+            const float* bg = p.background + (int64_t)b * p.bg_stride;
+            const int64_t o = ((int64_t)b * 3 * is + (is - 1 - ty0 - row)) * is + tx0;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (c < p.rgb_channels)
+                    reinterpret_cast<float4*>(p.rgb + o + c * plane)[seg] = make_float4(bg[c], bg[c], bg[c], bg[c]);
+        }
+    }
+    if (p.tile_hit && tid == 0) reinterpret_cast<uint32_t*>(p.tile_hit)[(int64_t)b * tiles_per_img + t] = 0u;
+    if (p.weight && !p.sparse_wd && tid < TILE_H * 24) {
+        const int row = tid / 24, seg = tid % 24;
+        reinterpret_cast<float4*>(p.weight + (((int64_t)b * is + ty0 + row) * is + tx0) * 3)[seg] = zero4;
+    }
+}
+
 // One screen tile `lid` (= image * tiles per image + tile): candidates -> z-buffer -> resolve (design at the top).
 // `ent` (listed launches): the tile's list entry {lid, record offset, record count, large-list length}; else nullptr
 template <bool FUSED, bool VC>
@@ -496,33 +538,7 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             return;
         }
         if (FUSED && n_rec == 0 && (is & 3) == 0 && tx0 + TILE_W <= is && ty0 + TILE_H <= is && !p.face_inv_map) {
-            // one 128-B row segment = 8 float4 (scalar planes) / 24 float4 (weight_map, 3 floats per pixel)
-            const int64_t plane = (int64_t)is * is;
-            const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (tid < TILE_H * 8) {
-                const int row = tid >> 3, seg = tid & 7;
-                const int64_t ro = ((int64_t)b * is + ty0 + row) * is + tx0;            // raster orientation
-                const int64_t io = ((int64_t)b * is + (is - 1 - ty0 - row)) * is + tx0;  // image orientation
-                const int m1 = -1;
-                const float fm1 = __int_as_float(m1);
-                reinterpret_cast<float4*>(p.fim + ro)[seg] = make_float4(fm1, fm1, fm1, fm1);
-                if (p.depth && !p.sparse_wd) reinterpret_cast<float4*>(p.depth + io)[seg] = make_float4(p.far_, p.far_, p.far_, p.far_);
-                if (p.alpha) reinterpret_cast<float4*>(p.alpha + io)[seg] = zero4;
-                if (p.mask) reinterpret_cast<float4*>(p.mask + io)[seg] = zero4;
-                if (p.rgb) {
-                    const float* bg = p.background + (int64_t)b * p.bg_stride;
-                    const int64_t o = ((int64_t)b * 3 * is + (is - 1 - ty0 - row)) * is + tx0;
-#pragma unroll
-                    for (int c = 0; c < 3; c++)
-                        if (c < p.rgb_channels)
-                            reinterpret_cast<float4*>(p.rgb + o + c * plane)[seg] = make_float4(bg[c], bg[c], bg[c], bg[c]);
-                }
-            }
-            if (p.tile_hit && tid == 0) reinterpret_cast<uint32_t*>(p.tile_hit)[(int64_t)b * tiles_per_img + t] = 0u;
-            if (p.weight && !p.sparse_wd && tid < TILE_H * 24) {
-                const int row = tid / 24, seg = tid % 24;
-                reinterpret_cast<float4*>(p.weight + (((int64_t)b * is + ty0 + row) * is + tx0) * 3)[seg] = zero4;
-            }
+            stream_background_tile(p, b, t, tx0, ty0);
             return;
         }
     }
@@ -958,9 +974,26 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(7, 8))
         sl = list_slice(n_heavy, n_light, j);
         have = j < sl.n_local;
         if (have) ent = p.tile_ids[sl.slot(j, p.tile_cap)];
+        if (FUSED && p.bg_ids) {
+            // dense launch: this workgroup's share of the tiles no face touches -- stores only, in flight while the
+            // tile's own candidates are worked on (the write stream of the empty four fifths of the screen rides on
+            // the workgroups that have instructions to issue, instead of 13 000 workgroups of its own)
+            // ... except those with a HEAVY tile: they are the launch's critical path (dispatched first for that reason)
+            const unsigned n_bg = p.tlist->n_bg;
+            const int tpi = p.tiles_x * p.tiles_y;
+            const unsigned nx = (gridDim.x & 7u) ? 1u : 8u, nh_max = (n_heavy + nx - 1u) / nx;
+            const bool few_heavy = nh_max * 2u <= sl.stride;  // (else: everybody helps)
+            const unsigned k0 = few_heavy ? (j >= nh_max ? (j - nh_max) * nx + blockIdx.x % nx : n_bg) : blockIdx.x;
+            const unsigned kstep = few_heavy ? (sl.stride - nh_max) * nx : gridDim.x;
+            for (unsigned k = k0; k < n_bg; k += kstep) {
+                const unsigned g = p.bg_ids[k];
+                const int bt = (int)(g % (unsigned)tpi);
+                stream_background_tile(p, (int)(g / (unsigned)tpi), bt, (bt % p.tiles_x) * TILE_W, (bt / p.tiles_x) * TILE_H);
+            }
+        }
     }
     if (have) raster_one_tile<FUSED, VC>(p, ent.x, listed ? &ent : nullptr);
-    if (FUSED && VC && listed && sl.n_local > sl.stride)  // (uniform per slice; false whenever the guess held)
+    if (FUSED && listed && sl.n_local > sl.stride)  // (uniform per slice; false whenever the guess held)
         // (the kernel's own argument block, in the kernarg segment: C cast out of address space 4; the intrinsic is
         // only valid in the kernel itself -- inside the callee it read as a null pointer)
         raster_overflow_tiles<FUSED, VC>((const FwdParams*)__builtin_amdgcn_kernarg_segment_ptr(), sl, j + sl.stride);
@@ -1055,7 +1088,7 @@ __global__ void __launch_bounds__(256) face_inv_map_kernel(const float* __restri
 // | TileList | [B * tiles] tile ids    (every byte the tile kernel reads is written by the two setup kernels: no memset)
 struct WorkLayout {
     int nbx, nby, ysh;
-    size_t off_bins, off_boxes, off_recs, off_rverts, off_tlist, off_tile_ids, total;
+    size_t off_bins, off_boxes, off_recs, off_rverts, off_tlist, off_tile_ids, off_bg, total;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1073,19 +1106,27 @@ static WorkLayout work_layout(int B, int F, int is) {
     w.off_rverts = w.off_recs + align256((size_t)B * REC_CAP * F * sizeof(FaceRec));
     w.off_tlist = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (VC needs F / 2 of it with fill-back)
     w.off_tile_ids = w.off_tlist + align256(sizeof(TileList));
-    w.total = w.off_tile_ids + align256((size_t)2 * B * tiles_x * tiles_y * sizeof(uint4));  // heavy part | light part
+    w.off_bg = w.off_tile_ids + align256((size_t)2 * B * tiles_x * tiles_y * sizeof(uint4));  // heavy part | light part
+    w.total = w.off_bg + align256((size_t)B * tiles_x * tiles_y * sizeof(uint32_t));  // dense listed launches: ids of the tiles off the list
     return w;
 }
 
 // per-face records + boxes (pass A), bin lists (pass B); fills the record-source fields of `fp`
 // `tile_hit` != nullptr asks for the tile list too (sparse-tile launches of rasters whose bins are tiles): fp.tlist is
 // set when one is built
+// `dense_list`: build the list for a DENSE launch (every pixel written): the tiles without candidates are listed too, in
+// an id array of their own, instead of getting zero coverage bytes
 template <bool VC>
 static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int F, int is, hipStream_t s,
-                       uint8_t* tile_hit = nullptr) {
+                       uint8_t* tile_hit = nullptr, bool dense_list = false) {
     const WorkLayout w = work_layout(B, F, is);
     if (w.nbx > MAX_BINS) return MR_ERR_BADARG;  // (image_size <= 16384 keeps a row of bins within the counters)
     char* base = (char*)workspace;
+    if (dense_list) {
+        bp.bg_ids = (uint32_t*)(base + w.off_bg);
+        fp.bg_ids = bp.bg_ids;
+        tile_hit = (uint8_t*)bp.bg_ids;  // (not written in this mode: any non-null value asks for the list)
+    }
     if (tile_hit && w.ysh == 0 && (int64_t)B * w.nbx * w.nby <= 0x7fffffffLL) {
         bp.tlist = (TileList*)(base + w.off_tlist);
         bp.tile_ids = (uint4*)(base + w.off_tile_ids);
@@ -1145,12 +1186,12 @@ static int launch_tiles(FwdParams& p, hipStream_t s, int64_t tile_bound = 0) {
         // is walked afterwards by the same workgroups (raster_overflow_tiles).
         if (tile_bound <= 0) tile_bound = (nblocks + 3) / 4;
         const int64_t bound = std::min<int64_t>(nblocks, std::max<int64_t>((tile_bound + 7) & ~(int64_t)7, 8));
-        if constexpr (FUSED && VC) {
+        if constexpr (FUSED) {
             hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC>), dim3((unsigned)bound), dim3(TPB), 0, s, p);
             MR_CHECK_LAUNCH();
             return MR_OK;
         }
-        return MR_ERR_NOTIMPL;  // (lists are built for the flow-mode render only)
+        return MR_ERR_NOTIMPL;  // (no lists for the five-entry-point compatible path)
     }
     hipLaunchKernelGGL((raster_tile_kernel<FUSED, VC>), dim3((unsigned)nblocks), dim3(TPB), 0, s, p);
     MR_CHECK_LAUNCH();
@@ -1170,6 +1211,23 @@ __global__ void __launch_bounds__(256) selftest_division_kernel(const float* __r
 }  // namespace mr
 
 using namespace mr;
+
+// Can a dense launch (every requested plane written for every pixel) go over the tile list?  Full tiles with 16-byte rows,
+// no per-pixel inverse map (the background stream does not write one), a raster whose bins are tiles.
+static bool dense_list_ok(int B, int F, int is, const float* face_inv_map, int flags) {
+    if ((flags & (MR_FLAG_REFERENCE_ALGO | MR_FLAG_TILE_PER_WORKGROUP)) || face_inv_map) return false;
+    if ((is % TILE_W) != 0 || (is % TILE_H) != 0) return false;
+    const WorkLayout w = work_layout(B, F, is);
+    return w.ysh == 0 && (int64_t)B * w.nbx * w.nby <= 0x7fffffffLL;
+}
+
+// ... over the tile list: a quarter of the screen as the grid (a longer list is walked in rounds, surplus workgroups leave
+// after their share of the background), every workgroup streams its share of the tiles off the list first
+template <bool VC>
+static int launch_dense_listed(FwdParams& p, hipStream_t s) {
+    if (!p.bg_ids) return MR_ERR_BADARG;
+    return launch_tiles<true, VC>(p, s, -1);
+}
 
 extern "C" int mr_selftest_division(const float* a, const float* b, float* refined, float* plain, int64_t n,
                                     mr_stream_t stream) {
@@ -1273,8 +1331,9 @@ extern "C" int mr_render_forward(const float* faces, const float* textures, cons
     FwdParams p{};
     BinParams bp{};
     bp.faces = faces; bp.F0 = num_faces;
+    const bool dense_list = dense_list_ok(batch_size, num_faces, image_size, face_inv_map, flags);
     int rc = (flags & MR_FLAG_REFERENCE_ALGO) ? MR_OK
-                                              : launch_bins<false>(bp, p, workspace, batch_size, num_faces, image_size, s);
+                                              : launch_bins<false>(bp, p, workspace, batch_size, num_faces, image_size, s, nullptr, dense_list);
     if (rc != MR_OK) return rc;
     p.faces = faces;
     p.textures = textures; p.background = background;
@@ -1301,6 +1360,7 @@ extern "C" int mr_render_forward(const float* faces, const float* textures, cons
         if (rc == MR_OK && e != hipSuccess) rc = (int)e;
         return rc;
     }
+    if (p.tlist) return launch_dense_listed<false>(p, s);
     return launch_tiles<true, false>(p, s);
 }
 
@@ -1339,7 +1399,8 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
     bp.verts = verts; bp.fidx = faces_idx; bp.V = num_verts; bp.F0 = num_faces; bp.fill_back = fill_back;
     bp.dbg = flags >> 24;
     if (batch_size > 65535) return MR_ERR_BADARG;
-    const int rc = launch_bins<true>(bp, p, workspace, batch_size, F, image_size, s);
+    const bool dense_list = dense_list_ok(batch_size, F, image_size, nullptr, flags);
+    const int rc = launch_bins<true>(bp, p, workspace, batch_size, F, image_size, s, nullptr, dense_list);
     if (rc != MR_OK) return rc;
     p.background = background; p.bg_stride = bg_stride;
     p.rgb = return_rgb ? rgb_img : nullptr;
@@ -1352,6 +1413,7 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
     p.texel = texel_layout;
     p.dbg = (flags >> 8) & 0xffff;  // profiling experiments (scripts/fwd_vc_variants.py)
     if (p.dbg & 128) return MR_OK;  // ... binning pass alone
+    if (p.tlist) return launch_dense_listed<true>(p, s);
     return launch_tiles<true, true>(p, s);
 }
 

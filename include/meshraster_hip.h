@@ -44,6 +44,10 @@ extern "C" {
 /* mr_render_flow_backward: grad_vcolors holds zeros on entry (mr_render_flow_forward's zero_fill wrote them, or the
  * caller did): the call does not clear it again -- one launch and 12 B per vertex less on the backward's critical path. */
 #define MR_FLAG_OUTPUT_ZEROED 4
+/* mr_render_forward / mr_render_vc_forward: one workgroup per screen tile in screen order (rounds 1-3) instead of the
+ * tile list + background stream these entry points use since round 4 where the raster allows it.  Same outputs, bit for
+ * bit; A/B profiling and tests only. */
+#define MR_FLAG_TILE_PER_WORKGROUP 8
 
 /* texel_layout argument of the vertex-colour entry points (mr_render_vc_*, mr_render_flow_*): which vertex's colour the
  * three non-zero texels of the 2x2x2 texture of libyana's batch_vertex_textures hold -- two bits per texel axis,

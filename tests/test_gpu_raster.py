@@ -1002,3 +1002,55 @@ def test_cyclic_face_padding_is_invisible(cuda):
     for k in ("rgb", "alpha", "depth", "weight_map", "face_index_map"):
         assert torch.equal(a[k], b[k]), k
     assert int(b["face_index_map"].max()) < F
+
+
+@pytest.mark.parametrize("B,is_,outs", [(3, 96, (1, 1, 1)), (2, 256, (1, 1, 1)), (5, 64, (1, 0, 1)), (2, 128, (0, 1, 0))])
+def test_dense_forwards_over_the_tile_list_equal_one_workgroup_per_tile(cuda, B, is_, outs):
+    """mr_render_forward / mr_render_vc_forward launch the tiles that hold candidates from the binning pass's list and
+    stream the background of all others with a separate kernel (round 4); MR_FLAG_TILE_PER_WORKGROUP keeps the launch of
+    rounds 1-3.  Every output byte must be the same, on poisoned buffers (every pixel of every requested plane is
+    written by exactly one of the two kernels), for every combination of requested planes."""
+    from handobjectconsist_amd import _lib
+    from handobjectconsist_amd.neurender import nr_ops
+    from handobjectconsist_amd.utils import textutils
+
+    d = _vc_abi_case(cuda, B, is_, 41)
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    f32 = dict(dtype=torch.float32, device=cuda)
+    V, F0 = d["V"], d["F0"]
+    bg = torch.tensor([0.25, -0.5, 0.75], **f32)
+    rr, ra, rd = outs
+    # materialised faces / textures of the same scene for the generic entry point (fill-back by concatenation)
+    fidx64 = d["fidx"].long()
+    tex = textutils.batch_vertex_textures(fidx64, d["cols"])
+    faces = nr_ops.vertices_to_faces(d["v"], torch.cat((fidx64, fidx64.flip(-1)), 1)).contiguous()
+    tex2 = torch.cat((tex, tex.permute(0, 1, 4, 3, 2, 5)), 1).contiguous()
+    F = faces.shape[1]
+    wbytes = int(_lib.load().mr_render_workspace_bytes(B, F, is_))
+
+    def planes():
+        return (torch.full((B, 3, is_, is_), float("nan"), **f32), torch.full((B, is_, is_), float("nan"), **f32),
+                torch.full((B, is_, is_), float("nan"), **f32), torch.full((B, is_, is_), -7, dtype=torch.int32, device=cuda),
+                torch.full((B, is_, is_, 3), float("nan"), **f32))
+
+    def run(vc, flags):
+        rgb, alpha, depth, fim, wmap = planes()
+        work = torch.full((wbytes,), 0xAB, dtype=torch.uint8, device=cuda)
+        if vc:
+            _lib.call("mr_render_vc_forward", P(d["v"]), P(d["fidx"]), P(d["cols"]), P(bg), 0, P(rgb), P(alpha), P(depth), P(fim),
+                      P(wmap), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, rr, ra, rd, flags, 0, st)
+        else:
+            _lib.call("mr_render_forward", P(faces), P(tex2), P(bg), 0, P(rgb), P(alpha), P(depth), P(fim), P(wmap), None, P(work),
+                      wbytes, B, F, is_, 2, 0.1, 100.0, 1e-3, rr, ra, rd, flags, st)
+        torch.cuda.synchronize()
+        return [x.view(torch.int32) for x in (rgb, alpha, depth, fim, wmap)]
+
+    for vc in (True, False):
+        old = run(vc, _lib.FLAG_TILE_PER_WORKGROUP)
+        new = run(vc, 0)
+        for a, b_, name, wanted in zip(old, new, ("rgb", "alpha", "depth", "face_index_map", "weight_map"), (rr, ra, rd, 1, 1)):
+            assert torch.equal(a, b_), f"{name} differs (vertex colours: {vc})"
+            if wanted:  # ... and nothing of a requested plane kept its poison
+                poison = -7 if name == "face_index_map" else torch.tensor(float("nan")).view(torch.int32).item()
+                assert int((b_ == poison).sum()) == 0, f"{name}: unwritten pixels (vertex colours: {vc})"
+        assert int((new[3] >= 0).sum()) > 100
