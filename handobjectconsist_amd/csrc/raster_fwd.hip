@@ -204,7 +204,9 @@ __device__ unsigned long long mr_dbg_bin[1024 * 8];  // profiling builds: phase 
 __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     MR_BIN_STAMP(0);
     extern __shared__ int bin_smem[];
-    __shared__ int s_large, s_nlarge, s_lbase, s_hbase, s_bbase;
+    __shared__ int s_large, s_nlarge, s_lbase, s_hbase, s_bbase, s_everywhere;
+    // listed launches: bit 30 of a bin's counter = "a face of the image's large list overlaps this bin" (counts stay far below)
+    constexpr int LARGE_BIT = 1 << 30, CNT_MASK = LARGE_BIT - 1;
     __shared__ unsigned long long wsum[BIN_TPB / MR_WAVE];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbins = p.nbx * p.nby;
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     const FaceBox* box_b = p.boxes + (int64_t)b * p.F;
 
     for (int i = tid; i < nbins; i += BIN_TPB) cnt[i] = 0;
-    if (tid == 0) { s_large = 0; s_nlarge = 0; }
+    if (tid == 0) { s_large = 0; s_nlarge = 0; s_everywhere = 0; }
     if (p.zero_fill)
         for (int64_t i = (int64_t)b * BIN_TPB + tid; i < p.zero_count; i += (int64_t)gridDim.x * BIN_TPB) p.zero_fill[i] = 0.0f;
     __syncthreads();
@@ -236,7 +238,16 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
             const int bx0 = bx.x0 / TILE_W, bx1 = bx.x1 / TILE_W;
             const int by0 = bx.y0 >> (3 + p.ysh), by1 = bx.y1 >> (3 + p.ysh);
             if ((bx1 - bx0 + 1) * (by1 - by0 + 1) > SMALL_MAX_BINS) {  // large list (filled in pass 2)
-                if (p.tlist) atomicAdd(&s_nlarge, 1);
+                if (p.tlist) {
+                    // ... which only the tiles under the face's box have to walk (round 4; until then one large face made
+                    // every tile of its image a listed tile that walks the whole large list -- at 640 x 640, where the 28
+                    // wrist-closing faces of a hand span more than 8 bins, 86 000 listed tiles instead of 19 000)
+                    atomicAdd(&s_nlarge, 1);
+                    if ((bx1 - bx0 + 1) * (by1 - by0 + 1) * 4 > nbins) s_everywhere = 1;  // (degenerate faces: full-screen boxes)
+                    else
+                        for (int y = by0; y <= by1; y++)
+                            for (int x = bx0; x <= bx1; x++) atomicOr(&cnt[y * p.nbx + x], LARGE_BIT);
+                }
                 continue;
             }
             for (int y = by0; y <= by1; y++)
@@ -251,13 +262,14 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     // if the image has a large list): the places of the image's entries in the launch's tile list.
     const int per = (nbins + BIN_TPB - 1) / BIN_TPB;
     const int i0 = min(tid * per, nbins), i1 = min(i0 + per, nbins);
-    const bool all_live = p.tlist && s_nlarge > 0;
+    const bool all_large = p.tlist && s_nlarge > 0 && s_everywhere != 0;
     unsigned long long local = 0;
     for (int i = i0; i < i1; i++) {
-        const int c = cnt[i];
+        const int raw = cnt[i], c = raw & CNT_MASK;
+        const bool lg = all_large || (raw & LARGE_BIT);  // this bin's tile walks the large list
         // (bits 32-47: bins that hold candidates, bits 48-63: those of them that are heavy; at most 8192 bins per image)
-        const unsigned nrec_i = (unsigned)c + (unsigned)s_nlarge;
-        local += (unsigned long long)(unsigned)c | ((unsigned long long)((c > 0 || all_live) ? 1u : 0u) << 32) |
+        const unsigned nrec_i = (unsigned)c + (lg ? (unsigned)s_nlarge : 0u);
+        local += (unsigned long long)(unsigned)c | ((unsigned long long)((c > 0 || lg) ? 1u : 0u) << 32) |
                  ((unsigned long long)((p.tlist && nrec_i >= HEAVY_RECS) ? 1u : 0u) << 48);
     }
     unsigned long long incl = local;
@@ -282,15 +294,17 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         if (p.bg_ids) s_bbase = (int)atomicAdd(&p.tlist->n_bg, (unsigned)nbins - n_ne);
     }
     BinHdr* bh = p.bins + (int64_t)b * nbins;
-    unsigned livebits = 0u;  // (per <= MAX_BINS / BIN_TPB = 8 bins per thread)
+    unsigned livebits = 0u, lgbits = 0u;  // (per <= MAX_BINS / BIN_TPB = 8 bins per thread)
     for (int i = i0; i < i1; i++) {
-        const int c = cnt[i];
+        const int raw = cnt[i], c = raw & CNT_MASK;
+        const bool lg = all_large || (raw & LARGE_BIT);
         BinHdr h;
         h.off = (unsigned)base; h.cnt = (unsigned)c;
         bh[i] = h;
         cnt[i] = base;
         base += c;
-        livebits |= (c > 0 ? 1u : 0u) << (i - i0);
+        livebits |= ((c > 0 || lg) ? 1u : 0u) << (i - i0);
+        lgbits |= (lg ? 1u : 0u) << (i - i0);
     }
     __syncthreads();
     MR_BIN_STAMP(3);
@@ -302,9 +316,9 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         unsigned at_l = (unsigned)p.tile_cap + (unsigned)s_lbase + (ne_before - hv_before);  // light part: second half
         unsigned at_b = p.bg_ids ? (unsigned)s_bbase + ((unsigned)i0 - ne_before) : 0u;     // tiles without candidates
         uint32_t* hit32 = reinterpret_cast<uint32_t*>(p.tile_hit) + (int64_t)b * nbins;
-        const unsigned nlarge = (unsigned)s_nlarge;
         for (int i = i0; i < i1; i++) {
-            const bool live = all_live || ((livebits >> (i - i0)) & 1u);
+            const bool live = (livebits >> (i - i0)) & 1u;
+            const unsigned nlarge = ((lgbits >> (i - i0)) & 1u) ? (unsigned)s_nlarge : 0u;
             // (cnt[] holds the bins' fill cursors = record offsets until pass 2 starts; `base` is the end of this run)
             const unsigned off = (unsigned)cnt[i], end = (unsigned)(i + 1 < i1 ? cnt[i + 1] : base);
             const uint4 ent = make_uint4((unsigned)(b * nbins + i), off, end - off, nlarge);

@@ -758,29 +758,25 @@ __global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFw
     }
 }
 
-// per-sample fixed-order reduction of the tile partials, read only where the coverage words say a workgroup wrote one
-__global__ void __launch_bounds__(64) pair_consist_finalize_tiles_kernel(const float* __restrict__ partial,
-                                                                         const uint32_t* __restrict__ hit12,
-                                                                         const uint32_t* __restrict__ hit21, int B, int T,
-                                                                         float* __restrict__ sums, float* __restrict__ loss_fwd,
-                                                                         float* __restrict__ loss_bwd) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+// per-sample fixed-order reduction of the tile partials, counted only where the coverage words say a workgroup wrote one
+// (the words and the partials of a tile are requested together: whatever an unwritten partial holds is discarded)
+__global__ void __launch_bounds__(256) pair_consist_finalize_tiles_kernel(const float* __restrict__ partial,
+                                                                          const uint32_t* __restrict__ hit12,
+                                                                          const uint32_t* __restrict__ hit21, int B, int T,
+                                                                          float* __restrict__ sums, float* __restrict__ loss_fwd,
+                                                                          float* __restrict__ loss_bwd) {
+    __shared__ float red[4][4];
+    const int b = blockIdx.x;
     float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int t = lane; t < T; t += 64) {
-        if (hit21[(int64_t)b * T + t] != 0u) {
-            const float2 v = *reinterpret_cast<const float2*>(partial + ((int64_t)(B + b) * T + t) * 2);
-            a[0] += v.x; a[1] += v.y;
-        }
-        if (hit12[(int64_t)b * T + t] != 0u) {
-            const float2 v = *reinterpret_cast<const float2*>(partial + ((int64_t)b * T + t) * 2);
-            a[2] += v.x; a[3] += v.y;
-        }
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const uint32_t h21 = hit21[(int64_t)b * T + t], h12 = hit12[(int64_t)b * T + t];
+        const float2 v1 = *reinterpret_cast<const float2*>(partial + ((int64_t)(B + b) * T + t) * 2);
+        const float2 v2 = *reinterpret_cast<const float2*>(partial + ((int64_t)b * T + t) * 2);
+        if (h21 != 0u) { a[0] += v1.x; a[1] += v1.y; }
+        if (h12 != 0u) { a[2] += v2.x; a[3] += v2.y; }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-#pragma unroll
-        for (int k = 0; k < 4; k++) a[k] += __shfl_xor(a[k], off);
-    if (lane == 0) {
+    block_sum4(a, red);
+    if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 4; k++) sums[b * 4 + k] = a[k];
         const float n1 = (a[1] == 0.0f) ? 1.0f : a[1], n2 = (a[3] == 0.0f) ? 1.0f : a[3];
@@ -1098,7 +1094,7 @@ extern "C" int mr_pair_consist_forward_tiles(const float* flow12, const float* f
     hipLaunchKernelGGL(pair_consist_forward_tiles_kernel, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
                        (hipStream_t)stream, p);
     MR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit12),
                        reinterpret_cast<const uint32_t*>(tile_hit21), batch_size, p.tiles_x * p.tiles_y, sums, loss_fwd, loss_bwd);
     MR_CHECK_LAUNCH();
@@ -1166,7 +1162,7 @@ extern "C" int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* 
     hipLaunchKernelGGL(flow_pair_forward_tiles_kernel, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
                        (hipStream_t)stream, q);
     MR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit1),
                        reinterpret_cast<const uint32_t*>(tile_hit2), batch_size, tiles_x * tiles_y, sums, loss_fwd, loss_bwd);
     MR_CHECK_LAUNCH();
