@@ -211,3 +211,21 @@ def test_baseline_configs_3_and_5_full_steps(cuda, name, extra, dtype):
     assert line["dtype"].startswith(dtype) and ("bf16-autocast" in line["config"]["workload"]) == (dtype == "bf16")
     assert line["hot_path_ms"] > 0
     _keep(f"bench_{name}.json", line)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,size,floor", [(32, 640, 0.4), (8, 480, 0.25)])
+def test_forward_roofline_at_the_raster_sizes_of_configs_3_and_5(cuda, batch, size, floor):
+    """The flow-mode forward of the training step at the raster sizes of BASELINE configs 5 (640 x 640, B = 32) and 3
+    (480 x 480, B = 8): fraction of the 8 TB/s roofline on SURVEY 8(d)'s algorithmic bytes, cold caches.  640: >= 0.4 (0.64
+    measured; 0.31 before round 4, when one face spanning more than eight bins made every tile of its image a listed tile).
+    480 at B = 8 is 16 renders -- a launch too small to fill 256 compute units (0.30 measured: 30 of its 62 us are the two
+    latency-bound set-up kernels, 16 workgroups of the binning pass among them); the floor there only guards against a
+    regression."""
+    env = dict(os.environ, HOC_KERNEL_GROUPS="render_flow_forward(train outputs,both frames=2B)")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--kernels-only", "--batch", str(batch), "--image-size",
+                          str(size), "--kernel-iters", "20"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    k = json.loads(res.stdout)["render_flow_forward(train outputs,both frames=2B)"]
+    _keep(f"forward_roofline_{size}.json", k)
+    assert k["frac_hbm_peak"] >= floor, k
