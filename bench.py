@@ -972,6 +972,10 @@ def main():
                                    f"object 1002v/2000f (7104 faces after fill-back), ResNet-18 {('fp32' if args.encoder_dtype == 'f32' else 'bf16-autocast') + ' (MIOpen convolutions, channels-last, + fused HIP BatchNorm/ReLU/residual/max-pool kernels)'}, Adam",
                        "global_batch": B * world, "image_size": is_, "parallelism": f"dp{world}"},
             "hot_path_ms": None if hot_ms is None else round(hot_ms, 3),
+            # (what the scalar above is, so that lines of different rounds are not compared blindly: rounds 1-2 reported the
+            # eager, host-bound figure under this key; roofline.frac is on the kernel's compulsory bytes since round 3,
+            # SURVEY 8(d)'s algorithmic figure rides along as roofline.frac_algorithmic)
+            "hot_path_ms_is": "hot_path.device_ms_graph_replay" if hot_graph_ms is not None else "hot_path.eager_ms_host_bound",
             "hot_path": None if hot_ms is None else {
                 "what": "render + warp hot path, forward + backward to the vertices (vertex stage, 2B-mesh flow render, occlusion + "
                         "epilogue, pair loss, their backward passes)",

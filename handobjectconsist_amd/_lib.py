@@ -41,6 +41,9 @@ SIGNATURES = {
     "mr_render_flow_forward": (_I, [_P, _P, _P, _P, _I, _P, _I, _F] + [_P] * 8 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _P, _I, _P, _P, _L, _I, _P]),
     "mr_flow_vertices_forward": (_I, [_P] * 7 + [_I, _F] + [_P] * 4 + [_I, _I, _P]),
     "mr_flow_vertices_backward": (_I, [_P] * 8 + [_I, _I, _P]),
+    "mr_flow_vertices_parts_forward": (_I, [_P] * 4 + [_I, _I] + [_P] * 5 + [_I, _F] + [_P] * 4 + [_I, _P]),
+    "mr_flow_vertices_parts_backward": (_I, [_P] * 4 + [_I, _I] + [_P] * 8 + [_I, _P]),
+    "mr_stack_pair_faces": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "mr_mano_workspace_floats": (_L, [_I]),
     "mr_mano_forward": (_I, [_P] * 12 + [_I, _I] + [_P] * 3 + [_I, _P]),
     "mr_mano_backward": (_I, [_P] * 10 + [_I, _I] + [_P] * 5 + [_I, _P]),

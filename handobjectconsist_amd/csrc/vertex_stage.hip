@@ -15,8 +15,11 @@
 namespace mr {
 
 struct VertexStageParams {
-    const float* verts1;  // [B,V,3] camera frame
+    const float* verts1;  // [B,V,3] camera frame -- or, with part B given, the first `split` vertices [B,split,3]
     const float* verts2;
+    const float* verts1b; // nullable: vertices split .. V - 1 of every mesh [B,V-split,3] (hand | object: the concatenation
+    const float* verts2b; //           torch.cat([hand, obj], 1) of warpbranch.py:49-55 done by index instead of by a copy)
+    int split;
     const float* K1;      // [B,3,3]
     const float* K2;
     const float* R;       // [Bc,3,3]  (Bc = 1 or B)
@@ -81,8 +84,13 @@ __global__ void __launch_bounds__(256) flow_vertices_forward_kernel(VertexStageP
 #pragma unroll
     for (int k = 0; k < 5; k++) d[k] = p.dist[(int64_t)b * p.cam_bstride * 5 + k];
     const int64_t o = ((int64_t)b * p.V + vi) * 3;
-    const float v1[3] = {p.verts1[o], p.verts1[o + 1], p.verts1[o + 2]};
-    const float v2[3] = {p.verts2[o], p.verts2[o + 1], p.verts2[o + 2]};
+    const bool second = p.verts1b != nullptr && vi >= p.split;
+    const float* s1 = second ? p.verts1b + ((int64_t)b * (p.V - p.split) + (vi - p.split)) * 3
+                             : p.verts1 + ((int64_t)b * (p.verts1b ? p.split : p.V) + vi) * 3;
+    const float* s2 = second ? p.verts2b + ((int64_t)b * (p.V - p.split) + (vi - p.split)) * 3
+                             : p.verts2 + ((int64_t)b * (p.verts2b ? p.split : p.V) + vi) * 3;
+    const float v1[3] = {s1[0], s1[1], s1[2]};
+    const float v2[3] = {s2[0], s2[1], s2[2]};
     float h[3], a[2], c[2];
     proj2d(K1, v1, h, a[0], a[1]);
     proj2d(K2, v2, h, c[0], c[1]);
@@ -96,6 +104,7 @@ __global__ void __launch_bounds__(256) flow_vertices_forward_kernel(VertexStageP
 }
 
 // adjoint of (verts1, verts2) -> (cols12, cols21); grad_verts* may be NULL
+// (two-part meshes: verts*b / grad_verts*b hold the vertices from `split` on; a NULL gradient pointer = not wanted)
 __global__ void __launch_bounds__(256) flow_vertices_backward_kernel(const float* __restrict__ verts1,
                                                                      const float* __restrict__ verts2,
                                                                      const float* __restrict__ K1g,
@@ -103,21 +112,27 @@ __global__ void __launch_bounds__(256) flow_vertices_backward_kernel(const float
                                                                      const float* __restrict__ g12,
                                                                      const float* __restrict__ g21,
                                                                      float* __restrict__ grad_verts1,
-                                                                     float* __restrict__ grad_verts2, int B, int V) {
+                                                                     float* __restrict__ grad_verts2, int B, int V,
+                                                                     const float* __restrict__ verts1b,
+                                                                     const float* __restrict__ verts2b,
+                                                                     float* __restrict__ grad_verts1b,
+                                                                     float* __restrict__ grad_verts2b, int split) {
     const int b = blockIdx.y;
     const int vi = blockIdx.x * blockDim.x + threadIdx.x;
     if (vi >= V) return;
     const int64_t o = ((int64_t)b * V + vi) * 3;
+    const bool parts = verts1b != nullptr, second = parts && vi >= split;
+    const int64_t op = second ? ((int64_t)b * (V - split) + (vi - split)) * 3 : ((int64_t)b * (parts ? split : V) + vi) * 3;
     // d loss / d p1 = g21 - g12,  d loss / d p2 = g12 - g21  (x, y components; the constant 1 has no gradient)
     float ga[2] = {0.0f, 0.0f};
     if (g12) { ga[0] += g12[o]; ga[1] += g12[o + 1]; }
     if (g21) { ga[0] -= g21[o]; ga[1] -= g21[o + 1]; }
 #pragma unroll
     for (int f = 0; f < 2; f++) {
-        float* out = f == 0 ? grad_verts1 : grad_verts2;
+        float* out = f == 0 ? (second ? grad_verts1b : grad_verts1) : (second ? grad_verts2b : grad_verts2);
         if (!out) continue;
         const float* K = (f == 0 ? K1g : K2g) + b * 9;
-        const float* vp = (f == 0 ? verts1 : verts2) + o;
+        const float* vp = (f == 0 ? (second ? verts1b : verts1) : (second ? verts2b : verts2)) + op;
         const float v[3] = {vp[0], vp[1], vp[2]};
         const float sgn = f == 0 ? -1.0f : 1.0f;  // p1 enters cols12 with a minus sign
         const float gp[2] = {sgn * ga[0], sgn * ga[1]};
@@ -127,8 +142,24 @@ __global__ void __launch_bounds__(256) flow_vertices_backward_kernel(const float
         // p = (h0 / h2, h1 / h2)
         const float gh[3] = {gp[0] / h[2], gp[1] / h[2], -(gp[0] * h[0] + gp[1] * h[1]) / (h[2] * h[2])};
 #pragma unroll
-        for (int j = 0; j < 3; j++) out[o + j] = K[j] * gh[0] + K[3 + j] * gh[1] + K[6 + j] * gh[2];
+        for (int j = 0; j < 3; j++) out[op + j] = K[j] * gh[0] + K[3 + j] * gh[1] + K[6 + j] * gh[2];
     }
+}
+
+// faces of the concatenated hand + object mesh of a frame pair, as the stacked render takes them: int32 [2B, Fh + Fo, 3],
+// rows [0, B) and [B, 2B) identical (both frames of a pair share the faces, warpbranch.py:49-55), object indices offset
+// by the hand's vertex count -- hand_face.repeat + (obj_faces + Vh) + cat + cat + dtype conversion in one pass
+__global__ void __launch_bounds__(256) stack_pair_faces_kernel(const int64_t* __restrict__ hand_faces, int64_t hand_bstride,
+                                                               const int64_t* __restrict__ obj_faces, int offset,
+                                                               int32_t* __restrict__ out, int B, int Fh, int Fo) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = (Fh + Fo) * 3;
+    if (i >= n) return;
+    const int f3h = Fh * 3;
+    const int64_t v = i < f3h ? hand_faces[(int64_t)b * hand_bstride + i] : obj_faces[(int64_t)b * Fo * 3 + (i - f3h)] + offset;
+    out[(int64_t)b * n + i] = (int32_t)v;
+    out[((int64_t)B + b) * n + i] = (int32_t)v;
 }
 
 }  // namespace mr
@@ -144,7 +175,7 @@ extern "C" int mr_flow_vertices_forward(const float* verts1, const float* verts2
     if (!verts1 || !verts2 || !K1 || !K2 || !R || !t || !dist_coeffs || !ndc1 || !ndc2 || !cols12 || !cols21)
         return MR_ERR_BADARG;
     if (batch_size > 65535) return MR_ERR_BADARG;
-    VertexStageParams p{verts1, verts2, K1, K2, R, t, dist_coeffs, cam_batched ? 1 : 0, orig_size,
+    VertexStageParams p{verts1, verts2, nullptr, nullptr, num_verts, K1, K2, R, t, dist_coeffs, cam_batched ? 1 : 0, orig_size,
                         ndc1, ndc2, cols12, cols21, batch_size, num_verts};
     hipLaunchKernelGGL(flow_vertices_forward_kernel, dim3((unsigned)((num_verts + 255) / 256), (unsigned)batch_size),
                        dim3(256), 0, (hipStream_t)stream, p);
@@ -161,7 +192,60 @@ extern "C" int mr_flow_vertices_backward(const float* verts1, const float* verts
     if (batch_size > 65535) return MR_ERR_BADARG;
     hipLaunchKernelGGL(flow_vertices_backward_kernel, dim3((unsigned)((num_verts + 255) / 256), (unsigned)batch_size),
                        dim3(256), 0, (hipStream_t)stream, verts1, verts2, K1, K2, grad_cols12, grad_cols21, grad_verts1,
-                       grad_verts2, batch_size, num_verts);
+                       grad_verts2, batch_size, num_verts, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, num_verts);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_flow_vertices_parts_forward(const float* verts1a, const float* verts1b, const float* verts2a,
+                                              const float* verts2b, int num_verts_a, int num_verts_b, const float* K1,
+                                              const float* K2, const float* R, const float* t, const float* dist_coeffs,
+                                              int cam_batched, float orig_size, float* ndc1, float* ndc2, float* cols12,
+                                              float* cols21, int batch_size, mr_stream_t stream) {
+    if (batch_size < 0 || num_verts_a < 0 || num_verts_b <= 0 || !(orig_size > 0.0f)) return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    if (!verts1b || !verts2b || ((!verts1a || !verts2a) && num_verts_a > 0) || !K1 || !K2 || !R || !t || !dist_coeffs ||
+        !ndc1 || !ndc2 || !cols12 || !cols21)
+        return MR_ERR_BADARG;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    const int V = num_verts_a + num_verts_b;
+    VertexStageParams p{verts1a, verts2a, verts1b, verts2b, num_verts_a, K1, K2, R, t, dist_coeffs, cam_batched ? 1 : 0,
+                        orig_size, ndc1, ndc2, cols12, cols21, batch_size, V};
+    hipLaunchKernelGGL(flow_vertices_forward_kernel, dim3((unsigned)((V + 255) / 256), (unsigned)batch_size), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_flow_vertices_parts_backward(const float* verts1a, const float* verts1b, const float* verts2a,
+                                               const float* verts2b, int num_verts_a, int num_verts_b, const float* K1,
+                                               const float* K2, const float* grad_cols12, const float* grad_cols21,
+                                               float* grad_verts1a, float* grad_verts1b, float* grad_verts2a,
+                                               float* grad_verts2b, int batch_size, mr_stream_t stream) {
+    if (batch_size < 0 || num_verts_a < 0 || num_verts_b <= 0) return MR_ERR_BADARG;
+    if (batch_size == 0 || (!grad_verts1a && !grad_verts1b && !grad_verts2a && !grad_verts2b)) return MR_OK;
+    if (!verts1b || !verts2b || ((!verts1a || !verts2a) && num_verts_a > 0) || !K1 || !K2) return MR_ERR_BADARG;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    const int V = num_verts_a + num_verts_b;
+    hipLaunchKernelGGL(flow_vertices_backward_kernel, dim3((unsigned)((V + 255) / 256), (unsigned)batch_size), dim3(256), 0,
+                       (hipStream_t)stream, verts1a, verts2a, K1, K2, grad_cols12, grad_cols21, grad_verts1a, grad_verts2a,
+                       batch_size, V, verts1b, verts2b, grad_verts1b, grad_verts2b, num_verts_a);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_stack_pair_faces(const int64_t* hand_faces, int hand_batched, const int64_t* obj_faces, int vertex_offset,
+                                   int32_t* faces_out, int batch_size, int num_hand_faces, int num_obj_faces,
+                                   mr_stream_t stream) {
+    if (batch_size < 0 || num_hand_faces < 0 || num_obj_faces < 0 || vertex_offset < 0) return MR_ERR_BADARG;
+    const int n = (num_hand_faces + num_obj_faces) * 3;
+    if (batch_size == 0 || n == 0) return MR_OK;
+    if (!faces_out || (!hand_faces && num_hand_faces > 0) || (!obj_faces && num_obj_faces > 0)) return MR_ERR_BADARG;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(stack_pair_faces_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)batch_size), dim3(256), 0,
+                       (hipStream_t)stream, hand_faces, hand_batched ? (int64_t)num_hand_faces * 3 : (int64_t)0, obj_faces,
+                       vertex_offset, faces_out, batch_size, num_hand_faces, num_obj_faces);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

@@ -54,14 +54,28 @@ def _frame_meshes(samples, all_results, hand_face, gt_refs, first_only):
     return frames, faces
 
 
-def _fused_pairs(samples, verts_world, all_faces, renderer, image_size, hand_ignore_faces, use_backward):
+def _frame_parts(samples, all_results, gt_refs, first_only):
+    """(hand, object) vertices per frame as ``_frame_meshes`` selects them, NOT concatenated."""
+    frames = []
+    for k, (sample, result) in enumerate(zip(samples, all_results)):
+        annotated = gt_refs and k > 0
+        hand = _q(sample, "handverts3d").cuda() if annotated else result["recov_handverts3d"]
+        obj = _q(sample, "objverts3d").cuda() if annotated else result["recov_objverts3d"]
+        frames.append((hand.detach(), obj.detach()) if (first_only and k > 0) else (hand, obj))
+    return frames
+
+
+def _fused_pairs(samples, all_results, hand_face, gt_refs, first_only, renderer, image_size, hand_ignore_faces, use_backward):
     """The "loss" mode of ``forward`` with every (frame 0, frame k) pair as ONE fused node (opticalflow.flow_pair_loss:
-    render, then occlusion + epilogue + pair loss in one pass, one backward launch); None when the node does not apply."""
+    render, then occlusion + epilogue + pair loss in one pass, one backward launch; hand and object go in as separate
+    tensors, concatenated by index inside the kernels); None when the node does not apply."""
     cams = [_q(sample, "camintr").cuda() for sample in samples]
     ref_image, ref_jitter = _q(samples[0], "image").cuda(), _q(samples[0], "jittermask").cuda()
+    parts = _frame_parts(samples, all_results, gt_refs, first_only)
+    faces = (hand_face.cuda(), _q(samples[-1], "objfaces").cuda())  # (the LAST frame's faces, warpbranch.py:49-55)
     losses, flows = [], []
     for k in range(1, len(samples)):
-        res = opticalflow.flow_pair_loss([verts_world[0], verts_world[k]], all_faces, [cams[0], cams[k]], renderer, image_size,
+        res = opticalflow.flow_pair_loss([parts[0], parts[k]], faces, [cams[0], cams[k]], renderer, image_size,
                                          ref_image, _q(samples[k], "image").cuda(), ref_jitter,
                                          _q(samples[k], "jittermask").cuda(), ignore_face_idxs=hand_ignore_faces)
         if res is None:
@@ -105,11 +119,12 @@ def forward(
     Returns:
         (mean pair loss, {"masks", "warps", "recons_flows", "diffs", "diff_losses"})
     """
-    verts_world, all_faces = _frame_meshes(samples, all_results, hand_face, gt_refs, first_only)
     if pair_outputs == "loss" and imgflowarp._is_fused_l1(criterion):
-        fused = _fused_pairs(samples, verts_world, all_faces, renderer, image_size, hand_ignore_faces, use_backward)
+        fused = _fused_pairs(samples, all_results, hand_face, gt_refs, first_only, renderer, image_size, hand_ignore_faces,
+                             use_backward)
         if fused is not None:
             return fused
+    verts_world, all_faces = _frame_meshes(samples, all_results, hand_face, gt_refs, first_only)
     recons_flows = opticalflow.get_opticalflows(
         verts_world,
         all_faces,

@@ -159,6 +159,64 @@ class _FlowVertexStage(torch.autograd.Function):
         return gv1, gv2, None, None, None, None, None, None
 
 
+class _FlowVertexStageParts(torch.autograd.Function):
+    """_FlowVertexStage for meshes handed over as (hand, object) vertex tensors per frame: the concatenation
+    ``torch.cat([hand, obj], 1)`` of warpbranch.py:49-55 happens by index inside the kernel (and the split of the
+    gradient in its backward) -- two copies and their autograd nodes less per pair."""
+
+    @staticmethod
+    def forward(ctx, v1a, v1b, v2a, v2b, K1, K2, R, t, dist, orig_size):
+        ctx.set_materialize_grads(False)
+        parts = [_lib.contig(x.detach()) for x in (v1a, v1b, v2a, v2b)]
+        k1, k2 = _lib.contig(K1.detach()), _lib.contig(K2.detach())
+        B, Va, Vb = parts[0].shape[0], parts[0].shape[1], parts[1].shape[1]
+        Rc = _lib.contig(R.detach().reshape(-1, 3, 3))
+        tc = _lib.contig(t.detach().reshape(-1, 3))
+        dc = _lib.contig(dist.detach().reshape(-1, 5))
+        nb = Rc.shape[0]
+        if (parts[2].shape != parts[0].shape or parts[3].shape != parts[1].shape or parts[1].shape[0] != B or k1.shape != (B, 3, 3)
+                or k2.shape != (B, 3, 3) or nb not in (1, B) or tc.shape[0] != nb or dc.shape[0] != nb or Vb == 0):
+            raise ValueError("expected vertex parts [B,Va,3] / [B,Vb,3], intrinsics [B,3,3] and R / t / dist_coeffs with batch 1 or B")
+        ndc = torch.empty((2 * B, Va + Vb, 3), dtype=torch.float32, device=parts[0].device)
+        cols = torch.empty_like(ndc)
+        _lib.call("mr_flow_vertices_parts_forward", *[_lib.ptr(x) for x in parts], Va, Vb, _lib.ptr(k1), _lib.ptr(k2),
+                  _lib.ptr(Rc), _lib.ptr(tc), _lib.ptr(dc), int(nb == B and B > 1), float(orig_size), _lib.ptr(ndc[:B]),
+                  _lib.ptr(ndc[B:]), _lib.ptr(cols[:B]), _lib.ptr(cols[B:]), B, _lib.stream_ptr(parts[0].device))
+        ctx.save_for_backward(*parts, k1, k2)
+        ctx.mark_non_differentiable(ndc)
+        return ndc, cols
+
+    @staticmethod
+    def backward(ctx, _g_ndc, g_cols):
+        v1a, v1b, v2a, v2b, k1, k2 = ctx.saved_tensors
+        B, Va, Vb = v1a.shape[0], v1a.shape[1], v1b.shape[1]
+        want = ctx.needs_input_grad[:4]
+        if g_cols is None or not any(want):
+            return (None,) * 10
+        grads = [torch.empty_like(x) if w else None for x, w in zip((v1a, v1b, v2a, v2b), want)]
+        g = _lib.contig(g_cols)
+        _lib.call("mr_flow_vertices_parts_backward", _lib.ptr(v1a), _lib.ptr(v1b), _lib.ptr(v2a), _lib.ptr(v2b), Va, Vb,
+                  _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(g[:B]), _lib.ptr(g[B:]), *[_lib.ptr(x) for x in grads], B,
+                  _lib.stream_ptr(v1a.device))
+        return tuple(grads) + (None,) * 6
+
+
+def _stack_pair_faces(hand_face, obj_faces, num_hand_verts):
+    """int32 [2B, Fh + Fo, 3]: the faces of the concatenated hand + object mesh (object indices offset by the hand's
+    vertex count, warpbranch.py:36, 49-55), twice -- what the stacked render of a frame pair takes -- in one launch."""
+    hf = _lib.contig(hand_face, torch.int64)
+    of = _lib.contig(obj_faces, torch.int64)
+    B, Fo = of.shape[:2]
+    batched = hf.dim() == 3 and hf.shape[0] == B and B > 1
+    if hf.dim() == 3 and not batched:
+        hf = hf[0]
+    Fh = hf.shape[-2]
+    out = torch.empty((2 * B, Fh + Fo, 3), dtype=torch.int32, device=of.device)
+    _lib.call("mr_stack_pair_faces", _lib.ptr(hf), int(batched), _lib.ptr(of), int(num_hand_verts), _lib.ptr(out), B, Fh, Fo,
+              _lib.stream_ptr(of.device))
+    return out
+
+
 def _vertex_color_path(neurenderer, detach_renders):
     return (USE_VERTEX_COLOR_RENDER and detach_renders and hasattr(neurenderer, "render_vertex_colors")
             and getattr(neurenderer, "no_light", False) and getattr(neurenderer, "camera_mode", "") == "projection")
@@ -512,10 +570,27 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
     ``pair_consist(flows, image_ref, image, jitter_mask_ref, jitter_mask, PyramidCriterion("l1"))`` for ONE frame pair, as a
     single fused node (no counterpart function in the reference: opticalflow.py:51-156 + imgflowarp.py:58-115 composed).
 
+    ``verts_cam`` = two [B,V,3] tensors and ``faces`` = [B,F,3], as for ``get_opticalflow`` -- or, to spare the copies of
+    warpbranch.py:49-55, two ``(hand [B,Vh,3], object [B,Vo,3])`` tuples and ``faces`` = ``(hand_faces [Fh,3] or [B,Fh,3],
+    object_faces [B,Fo,3])`` (object indices WITHOUT the hand offset): concatenation and offset then happen inside the kernels.
+
     Returns ``(loss_fwd[B], loss_bwd[B], [flow12, flow21])`` -- ``pair_consist``'s ``warp_loss`` is ``loss_fwd`` (+
     ``loss_bwd`` with ``use_backward``); the flows are defined under their renders' covered tiles only -- or ``None`` when the
     fused node does not apply (renderer settings, raster size, tensors off the GPU): callers then compose the two functions."""
-    v1, v2 = verts_cam
+    parts = isinstance(verts_cam[0], (tuple, list))  # (hand, object) vertex tensors per frame + (hand, object) faces
+    if parts:
+        (h1, o1), (h2, o2) = verts_cam
+        hand_face, obj_faces = faces
+        if not (h1.is_cuda and o1.is_cuda and h2.shape == h1.shape and o2.shape == o1.shape and o1.dtype == torch.float32
+                and h2.dtype == torch.float32 and o2.dtype == torch.float32 and obj_faces.is_cuda and hand_face.is_cuda
+                and obj_faces.dim() == 3 and obj_faces.shape[0] == h1.shape[0]):
+            return None
+        # (a stand-in view with the concatenated mesh's shape / dtype / device for the checks below; never read)
+        v1 = v2 = h1.detach()[:1, :1, :1].expand(h1.shape[0], h1.shape[1] + o1.shape[1], 3)
+        num_faces0 = (hand_face.shape[-2] + obj_faces.shape[1])
+    else:
+        v1, v2 = verts_cam
+        num_faces0 = faces.shape[1]
     if not (USE_FUSED_PAIR_NODE and USE_FUSED_VERTEX_STAGE and USE_FUSED_EPILOGUE and USE_SPARSE_TILES and USE_TILE_LIST
             and USE_PIXEL_RECORDS and USE_TILE_LIST_WARP and _vertex_color_path(neurenderer, True)
             and hasattr(neurenderer, "render_projected_vertex_colors") and v1.is_cuda and v1.dtype == torch.float32
@@ -529,15 +604,20 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
     H, W = min(int(H), is_), min(int(W), is_)
     if tuple(image.shape[2:]) != (H, W) or image_ref.shape != image.shape:
         return None
-    F = faces.shape[1] * (2 if neurenderer.fill_back else 1)
+    F = num_faces0 * (2 if neurenderer.fill_back else 1)
     if not _lib.has_tile_list(2 * v1.shape[0], F, is_):
         return None
-    ndc, cols = _FlowVertexStage.apply(
-        v1, v2, camintrs[0].to(dev), camintrs[1].to(dev), neurenderer.R.to(dev), neurenderer.t.to(dev),
-        neurenderer.dist_coeffs.to(dev), neurenderer.orig_size)
+    cam = (camintrs[0].to(dev), camintrs[1].to(dev), neurenderer.R.to(dev), neurenderer.t.to(dev), neurenderer.dist_coeffs.to(dev),
+           neurenderer.orig_size)
+    if parts:
+        ndc, cols = _FlowVertexStageParts.apply(h1, o1, h2, o2, *cam)
+        faces2 = _stack_pair_faces(hand_face, obj_faces, h1.shape[1])
+    else:
+        ndc, cols = _FlowVertexStage.apply(v1, v2, *cam)
+        faces2 = _stacked_faces(faces)
     lut = _keep_lut(ignore_face_idxs, dev) if ignore_face_idxs is not None else None
     loss_fwd, loss_bwd, flows, tile_hit = _FlowPairLossFunction.apply(
-        ndc, _stacked_faces(faces), cols, lut, neurenderer.fill_back, is_, neurenderer.near, neurenderer.far,
+        ndc, faces2, cols, lut, neurenderer.fill_back, is_, neurenderer.near, neurenderer.far,
         neurenderer.rasterizer_eps, neurenderer.background_color, H, W, image_ref, image, jitter_mask_ref, jitter_mask, 0.99999)
     B = v1.shape[0]
     flows._hoc_coverage = (tile_hit, is_, flows._version, None)

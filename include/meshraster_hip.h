@@ -305,6 +305,27 @@ MR_API int mr_flow_vertices_backward(const float* verts1, const float* verts2, c
                                      float* grad_verts2, int batch_size, int num_verts,
                                      mr_stream_t stream);
 
+/* The same for meshes handed over in TWO parts (hand | object): vertices [0, num_verts_a) of every mesh come from
+ * verts*a [B,num_verts_a,3], the rest from verts*b [B,num_verts_b,3] -- the concatenation of warpbranch.py:49-55 done by
+ * index instead of by a copy (and a split in the backward).  Outputs as above over V = num_verts_a + num_verts_b; any
+ * gradient pointer may be NULL (not wanted). */
+MR_API int mr_flow_vertices_parts_forward(const float* verts1a, const float* verts1b, const float* verts2a,
+                                          const float* verts2b, int num_verts_a, int num_verts_b, const float* K1,
+                                          const float* K2, const float* R, const float* t, const float* dist_coeffs,
+                                          int cam_batched, float orig_size, float* ndc1, float* ndc2, float* cols12,
+                                          float* cols21, int batch_size, mr_stream_t stream);
+MR_API int mr_flow_vertices_parts_backward(const float* verts1a, const float* verts1b, const float* verts2a,
+                                           const float* verts2b, int num_verts_a, int num_verts_b, const float* K1,
+                                           const float* K2, const float* grad_cols12, const float* grad_cols21,
+                                           float* grad_verts1a, float* grad_verts1b, float* grad_verts2a,
+                                           float* grad_verts2b, int batch_size, mr_stream_t stream);
+/* Faces of the concatenated hand + object mesh of a frame pair as the stacked render takes them: faces_out int32
+ * [2B, Fh + Fo, 3], rows b and B + b = hand_faces (shared [Fh,3], or per sample [B,Fh,3] with hand_batched) followed by
+ * obj_faces[b] + vertex_offset (warpbranch.py:36, 49-55: repeat, offset, cat) -- one pass instead of five launches. */
+MR_API int mr_stack_pair_faces(const int64_t* hand_faces, int hand_batched, const int64_t* obj_faces, int vertex_offset,
+                               int32_t* faces_out, int batch_size, int num_hand_faces, int num_obj_faces,
+                               mr_stream_t stream);
+
 /* MANO linear-blend skinning (manopth ManoLayer.forward as called at
  * manobranch.py:130-136, PCA pose space, arithmetic of SURVEY appendix B.10) and its adjoint.
  *   pose_coeffs[B, 3 + ncomps] (global axis-angle + PCA coefficients), betas[B,10]
