@@ -596,7 +596,9 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
             and hasattr(neurenderer, "render_projected_vertex_colors") and v1.is_cuda and v1.dtype == torch.float32
             and v2.shape == v1.shape and _stacked_flow_node_ok(neurenderer, v1.shape[1]) and image.is_cuda
             and image.dtype == torch.float32 and image.dim() == 4 and image.shape[1] == 3 and image.shape[-1] >= 2
-            and jitter_mask.dim() == 4 and jitter_mask.shape[1] in (1, 3)):
+            and jitter_mask.dim() == 4 and jitter_mask.shape[1] in (1, 3)
+            # (the node differentiates w.r.t. the vertices only: images that want a gradient take the composed path)
+            and not (image.requires_grad or image_ref.requires_grad or jitter_mask.requires_grad or jitter_mask_ref.requires_grad)):
         return None
     dev = v1.device
     is_ = int(neurenderer.image_size)

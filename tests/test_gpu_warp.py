@@ -784,3 +784,62 @@ def test_fused_pair_node_equals_the_composed_path(cuda, monkeypatch, B, is_, H, 
         for a, b_, what in ((got[4], ref[4], "d/d vertices of frame 1"), (got[5], ref[5], "d/d vertices of frame 2")):
             assert torch.isfinite(a).all() and float(b_.abs().sum()) > 0, what
             close(a.cpu().numpy(), b_.cpu().numpy(), 1e-5, 1e-6 * float(b_.abs().max()), what)
+
+
+@pytest.mark.parametrize("B,is_,H,Wd,Cj", [(1, 72, 72, 72, 1), (3, 104, 56, 100, 1), (2, 136, 136, 136, 3)])
+def test_fused_pair_node_on_ragged_rasters_and_as_parts(cuda, B, is_, H, Wd, Cj):
+    """Rasters that are no multiple of the 32 x 8 tile (border tiles hang over the raster), a single pair, crops narrower
+    than the raster, one-channel jitter masks -- and the mesh handed over as (hand, object) vertex tensors + (hand, object)
+    faces: concatenation and index offset inside the kernels (mr_flow_vertices_parts_*, mr_stack_pair_faces) must give what
+    torch.cat of the parts gives, bit for bit (losses, flows) / to fp32 rounding (gradients of BOTH parts of frame 1).
+    The composed dense path is the reference throughout."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import imgflowarp, opticalflow
+
+    s = synth.random_scene(B, seed=17, image_size=is_)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
+                   no_light=True, light_intensity_ambient=0.8)
+    im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, H, Wd, 8)]
+    jm_ref, jm = jm_ref[:, :Cj].contiguous(), jm[:, :Cj].contiguous()
+    Ks = [t(s["K1"], cuda), t(s["K2"], cuda)]
+    Vh = s["hand_verts1"].shape[1]
+    hand_faces = t(s["hand_faces"].astype(np.int64), cuda)                              # [Fh,3], shared by the batch
+    obj_faces = t(s["obj_faces"].astype(np.int64)[None].repeat(B, 0), cuda)             # [B,Fo,3] WITHOUT the hand offset
+    assert int(hand_faces.max()) < Vh and int(obj_faces.min()) >= 0
+
+    def dense():
+        v1 = t(s["verts1"], cuda).requires_grad_(True)
+        flows = opticalflow.get_opticalflow([v1, t(s["verts2"], cuda)], t(s["faces"], cuda), Ks, ren, orig_img_size=(Wd, H),
+                                            ignore_face_idxs=synth.HAND_IGNORE_FACES)
+        loss = imgflowarp.pair_consist(flows, im_ref, im, jm_ref, jm, PyramidCriterion("l1"), use_backward=True, outputs="loss")[0]
+        loss.sum().backward()
+        return loss.detach(), flows[0]._base.detach().clone(), v1.grad
+
+    def fused(parts):
+        if parts:
+            h1, o1 = t(s["hand_verts1"], cuda).requires_grad_(True), t(s["obj_verts1"], cuda).requires_grad_(True)
+            verts = [(h1, o1), (t(s["hand_verts2"], cuda), t(s["obj_verts2"], cuda))]
+            faces = (hand_faces, obj_faces)
+        else:
+            v1 = t(s["verts1"], cuda).requires_grad_(True)
+            verts, faces = [v1, t(s["verts2"], cuda)], t(s["faces"], cuda)
+        res = opticalflow.flow_pair_loss(verts, faces, Ks, ren, (Wd, H), im_ref, im, jm_ref, jm, ignore_face_idxs=synth.HAND_IGNORE_FACES)
+        assert res is not None
+        (res[0] + res[1]).sum().backward()
+        grad = torch.cat([h1.grad, o1.grad], 1) if parts else v1.grad
+        return (res[0] + res[1]).detach(), res[2][0]._base.detach().clone(), res[2][0]._base._hoc_coverage[0], grad
+
+    assert np.array_equal(np.concatenate([s["hand_verts1"], s["obj_verts1"]], 1), s["verts1"])
+    loss_d, flow_d, grad_d = dense()
+    assert float(loss_d.abs().sum()) > 0 and float(grad_d.abs().sum()) > 0
+    for parts in (False, True):
+        loss_f, flow_f, hit, grad_f = fused(parts)
+        close(loss_f.cpu().numpy(), loss_d.cpu().numpy(), 2e-6, 1e-9, f"loss (parts: {parts})")
+        words = hit.contiguous().view(torch.int32).view(2 * B, (is_ + 7) // 8, (is_ + 31) // 32).cpu().numpy() != 0
+        yy, xx = np.mgrid[0:H, 0:Wd]
+        defined = torch.from_numpy(words[:, (is_ - 1 - yy) >> 3, xx >> 5]).to(cuda)
+        assert torch.equal(flow_f[defined], flow_d[defined]), f"flows (parts: {parts})"
+        assert float(flow_d[~defined].abs().sum()) == 0.0  # (the dense flows are exactly zero where nothing is written)
+        close(grad_f.cpu().numpy(), grad_d.cpu().numpy(), 1e-5, 1e-6 * float(grad_d.abs().max()), f"vertex gradient (parts: {parts})")
