@@ -1306,9 +1306,12 @@ __device__ __forceinline__ float pm_term(float dg, float c, float fd1, float d1_
     return dg * __builtin_amdgcn_rcpf(dist);
 }
 // owns[b * F + face] = 1 for every face that won a pixel (four pixels per thread)
+// (`zero` / `n_zero`: a word array cleared on the way -- the strip weights of kernel D, which the next kernel adds into)
 __global__ void __launch_bounds__(256) mark_owners_kernel(const int32_t* __restrict__ fim, uint8_t* __restrict__ owns,
-                                                          int64_t npx4, int64_t px_per_image, int F) {
+                                                          int64_t npx4, int64_t px_per_image, int F,
+                                                          unsigned* __restrict__ zero, int64_t n_zero) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_zero) zero[i] = 0u;
     if (i >= npx4) return;
     const int4 f = reinterpret_cast<const int4*>(fim)[i];
     uint8_t* o = owns + ((i * 4) / px_per_image) * F;
@@ -1320,8 +1323,10 @@ __global__ void __launch_bounds__(256) mark_owners_kernel(const int32_t* __restr
 
 __global__ void __launch_bounds__(256) mark_owners_scalar_kernel(const int32_t* __restrict__ fim,
                                                                  uint8_t* __restrict__ owns, int64_t npx,
-                                                                 int64_t px_per_image, int F) {
+                                                                 int64_t px_per_image, int F,
+                                                                 unsigned* __restrict__ zero, int64_t n_zero) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_zero) zero[i] = 0u;
     if (i >= npx) return;
     const int f = fim[i];
     if (f >= 0) owns[(i / px_per_image) * F + f] = 1;
@@ -1365,9 +1370,15 @@ constexpr int CO_TPB = 1024, CO_PER = 4;
 __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p, const uint8_t* __restrict__ owns,
                                                                 unsigned* __restrict__ counter, uint32_t* __restrict__ list,
                                                                 unsigned* __restrict__ img_count, float4* __restrict__ img_recs,
-                                                                int chunks) {
+                                                                int chunks, unsigned* __restrict__ strip_w, int strip_l,
+                                                                int strips_axis) {
     __shared__ unsigned s_cnt, s_base, s_icnt, s_ibase, s_range[4];
     __shared__ uint8_t s_own[CO_TPB * CO_PER];
+    constexpr int CO_WMAX = 2048;         // strip weights of the image gathered in LDS first (2 * strips_axis <= CO_WMAX)
+    __shared__ unsigned s_w[CO_WMAX];
+    const bool lds_w = strip_w != nullptr && 2 * strips_axis <= CO_WMAX;
+    if (lds_w)
+        for (int q = threadIdx.x; q < 2 * strips_axis; q += CO_TPB) s_w[q] = 0u;
     const int b = blockIdx.x / chunks, fc0 = (blockIdx.x % chunks) * (CO_TPB * CO_PER);
     const int nf = min(CO_TPB * CO_PER, p.F - fc0);  // faces of this workgroup
     const int64_t f0 = (int64_t)b * p.F + fc0;
@@ -1411,7 +1422,15 @@ __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p
                 const float q0 = pxy[k][axis], q1 = pxy[k][2 + axis], q2 = pxy[k][4 + axis];
                 const int from = (int)fmaxf(ceilf(fminf(fminf(q0, q1), q2)), 0.0f);
                 const int to = (int)fminf(fmaxf(fmaxf(q0, q1), q2), fis - 1.0f);
-                if (iown[k] && from <= to) { hi[axis] = (float)(to + 1); lo[axis] = (float)(p.is - from); }
+                if (iown[k] && from <= to) {
+                    hi[axis] = (float)(to + 1); lo[axis] = (float)(p.is - from);
+                    // ... and, strip by strip, how many owners have crossings there: the strips' weights (strip_list_kernel)
+                    if (strip_w)
+                        for (int sx = from / strip_l; sx <= to / strip_l; sx++) {
+                            if (lds_w) atomicAdd(&s_w[axis * strips_axis + sx], 1u);
+                            else atomicAdd(&strip_w[((int64_t)b * 2 + axis) * strips_axis + sx], 1u);
+                        }
+                }
             }
             const unsigned long long mi = __ballot(iown[k]);
             if (mi) {  // (wave-uniform)
@@ -1432,6 +1451,9 @@ __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p
         if (img_recs) s_ibase = atomicAdd(&img_count[b], s_icnt);
     }
     if (img_recs && tid < 4 && s_range[tid]) atomicMax(&img_count[p.B + 4 * b + tid], s_range[tid]);
+    if (lds_w)
+        for (int q = tid; q < 2 * strips_axis; q += CO_TPB)
+            if (s_w[q]) atomicAdd(&strip_w[(int64_t)b * 2 * strips_axis + q], s_w[q]);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < CO_PER; k++)
@@ -1521,9 +1543,51 @@ static int64_t strip_lds_bytes(int is, int L) {
            (PS_T / MR_WAVE) * (PS_TASKS * 2LL + MR_WAVE * 8LL);
 }
 
+// The strips that have work, XCD by XCD (image b runs on XCD b % 8: all strips of an image behind one L2), HEAVIEST FIRST.
+// One workgroup per XCD reads the weights compact_owners_kernel left (owners with crossings per strip), and lists the
+// strips with a non-zero weight in three classes -- at least half / a quarter of the largest weight, the rest.  The
+// strip kernel takes workgroup i = entry i / 8 of XCD i % 8: no workgroup for the 57 % of the strips outside their image's
+// line range (each used to hold one of the chip's 768 slots for a microsecond or two), and the strips through the middle
+// of the meshes (up to 100 us each) start first instead of wherever the image order put them (workgroup timeline,
+// scripts/dstrip_timeline.py: last start 265 us into a 315 us launch, 650-700 working strips resident of 768).
+constexpr int SL_T = 1024;
+__global__ void __launch_bounds__(SL_T) strip_list_kernel(const unsigned* __restrict__ strip_w, unsigned* __restrict__ lists,
+                                                          unsigned* __restrict__ counts, int B, int S, int cap) {
+    __shared__ unsigned s_max, s_n[3], s_at[3];
+    const int x = blockIdx.x, tid = threadIdx.x;
+    const int n_img = (B - x + 7) / 8;  // images x, x + 8, ...
+    const int total = n_img * S;
+    if (tid == 0) { s_max = 0u; s_n[0] = s_n[1] = s_n[2] = 0u; }
+    __syncthreads();
+    unsigned mx = 0u;
+    for (int i = tid; i < total; i += SL_T) mx = max(mx, strip_w[(int64_t)((i / S) * 8 + x) * S + i % S]);
+    if (mx) atomicMax(&s_max, mx);
+    __syncthreads();
+    const unsigned hi = s_max / 2u, mid = s_max / 4u;
+    auto cls = [&](unsigned w) { return w > hi ? 0 : (w > mid ? 1 : 2); };
+    for (int i = tid; i < total; i += SL_T) {
+        const unsigned w = strip_w[(int64_t)((i / S) * 8 + x) * S + i % S];
+        if (w) atomicAdd(&s_n[cls(w)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        s_at[0] = 0u; s_at[1] = s_n[0]; s_at[2] = s_n[0] + s_n[1];
+        counts[x] = s_n[0] + s_n[1] + s_n[2];
+    }
+    __syncthreads();
+    unsigned* out = lists + (int64_t)x * cap;
+    for (int i = tid; i < total; i += SL_T) {
+        const int b = (i / S) * 8 + x;
+        const unsigned w = strip_w[(int64_t)b * S + i % S];
+        if (w) out[atomicAdd(&s_at[cls(w)], 1u)] = (unsigned)(b * S + i % S);
+    }
+}
+
 template <bool IMG, int L>
 __global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p, const unsigned* __restrict__ img_count,
-                                                               const float4* __restrict__ img_recs, int strips_axis) {
+                                                               const float4* __restrict__ img_recs, int strips_axis,
+                                                               const unsigned* __restrict__ strip_lists,
+                                                               const unsigned* __restrict__ strip_counts, int list_cap) {
     extern __shared__ float4 ps_lds[];
     __shared__ unsigned s_qn, s_next;
 #ifdef MR_WG_TIMELINE
@@ -1539,16 +1603,14 @@ __global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p,
     unsigned* queue = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(fimL) + ((L * stride * 4 + 15) & ~15));
     unsigned* sweeps = queue + PS_QCAP;  // (the task lists and the per-item sums of the waves)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // blockIdx -> XCD blockIdx % 8: every strip of an image on the same XCD
+    // blockIdx -> XCD blockIdx % 8: every strip of an image on the same XCD; entry blockIdx / 8 of that XCD's list of
+    // working strips (heaviest first), `b * S + axis * strips_axis + strip`
     const unsigned S = 2u * (unsigned)strips_axis, xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-    const int b = (int)((j / S) * 8u + xcd);
-    if (b >= p.B) return;
-    const unsigned sidx = j % S;
-    const int axis = (int)(sidx & 1u), l0 = (int)(sidx >> 1) * L;
-    {   // no owner of this image has a crossing on these lines: nothing to add
-        const unsigned hi1 = img_count[p.B + 4 * b + 2 * axis], lo1 = img_count[p.B + 4 * b + 2 * axis + 1];
-        if ((int)hi1 <= l0 || is - (int)lo1 > l0 + L - 1) return;
-    }
+    if (j >= strip_counts[xcd]) return;
+    const unsigned ent = strip_lists[(int64_t)xcd * list_cap + j];
+    const int b = (int)(ent / S);
+    const unsigned sidx = ent % S;
+    const int axis = (int)(sidx / (unsigned)strips_axis), l0 = (int)(sidx % (unsigned)strips_axis) * L;
     const int nl = min(L, is - l0);
     const bool ra = p.return_alpha != 0, rr = p.return_rgb != 0;
     const float fis = (float)is, two_over_is = 2.0f / fis;
@@ -1902,20 +1964,49 @@ static OwnerList owner_list(void* workspace, int B, int F) {
     return o;
 }
 // flags -> lists (+ zero rows); the workspace's flags and counts must have been cleared (ol.clear_bytes) and marked
-static int launch_compact(const PixelMapParams& q, const OwnerList& ol, bool per_image, hipStream_t s) {
+static int launch_compact(const PixelMapParams& q, const OwnerList& ol, bool per_image, hipStream_t s,
+                          unsigned* strip_w = nullptr, int strip_l = 1, int strips_axis = 0) {
     const int chunks = (q.F + CO_TPB * CO_PER - 1) / (CO_TPB * CO_PER);
     const int64_t blocks = (int64_t)q.B * chunks;
     if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
     if (blocks == 0) return MR_OK;
     hipLaunchKernelGGL(compact_owners_kernel, dim3((unsigned)blocks), dim3(CO_TPB), 0, s, q, (const uint8_t*)ol.owns, ol.counter,
-                       ol.list, per_image ? ol.img_count : (unsigned*)nullptr, per_image ? ol.img_recs : (float4*)nullptr, chunks);
+                       ol.list, per_image ? ol.img_count : (unsigned*)nullptr, per_image ? ol.img_recs : (float4*)nullptr, chunks,
+                       strip_w, strip_l, strips_axis);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
 
+// ... + kernel D's strip bookkeeping behind it: weights [B][2 strips_axis], per-XCD lists [8][cap], their lengths [8]
+struct StripLists {
+    unsigned* weights;
+    unsigned* lists;
+    unsigned* counts;
+    int strips_axis, cap;
+    int64_t n_weights;
+};
+static int strip_lines(int is);
+static int64_t strip_list_bytes(int B, int is) {
+    const int L = strip_lines(is);
+    if (L == 0) return 0;
+    const int64_t sa = (is + L - 1) / L, S = 2 * sa, cap = (int64_t)((B + 7) / 8) * S;
+    return round256((int64_t)B * S * 4) + round256(8 * cap * 4) + 256;
+}
+static StripLists strip_lists(void* workspace, int B, int F, int is) {
+    StripLists sl{};
+    const int L = strip_lines(is);
+    sl.strips_axis = (is + L - 1) / L;
+    const int64_t S = 2LL * sl.strips_axis;
+    sl.cap = (int)(((B + 7) / 8) * S);
+    sl.n_weights = (int64_t)B * S;
+    char* base = (char*)workspace + owner_list_bytes(B, F);
+    sl.weights = (unsigned*)base;
+    sl.lists = (unsigned*)(base + round256(sl.n_weights * 4));
+    sl.counts = (unsigned*)(base + round256(sl.n_weights * 4) + round256(8LL * sl.cap * 4));
+    return sl;
+}
 static int64_t pixel_map_workspace_bytes(int B, int F, int is) {
-    (void)is;
-    return owner_list_bytes(B, F);
+    return owner_list_bytes(B, F) + strip_list_bytes(B, is);
 }
 
 // kernel D by strips needs the workspace, a raster whose lines fit LDS and 24-bit owner numbers
@@ -1937,20 +2028,25 @@ static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t wo
     hipError_t e0 = hipMemsetAsync(ol0.owns, 0, ol0.clear_bytes, s);  // flags and the counts behind them
     if (e0 != hipSuccess) return (int)e0;
     const int64_t ppi = (int64_t)p.is * p.is, npx = ppi * p.B;
-    int rc = (ppi % 4 == 0) ? launch1d(mark_owners_kernel, npx / 4, s, p.fim, ol0.owns, npx / 4, ppi, p.F)
-                            : launch1d(mark_owners_scalar_kernel, npx, s, p.fim, ol0.owns, npx, ppi, p.F);
+    const StripLists sl = strip_lists(workspace, p.B, p.F, p.is);
+    if (sl.n_weights > npx / 4) return MR_ERR_BADARG;  // (the marking pass clears the weights, one word per thread: 2 B is / L <= B is^2 / 4)
+    int rc = (ppi % 4 == 0) ? launch1d(mark_owners_kernel, npx / 4, s, p.fim, ol0.owns, npx / 4, ppi, p.F, sl.weights, sl.n_weights)
+                            : launch1d(mark_owners_scalar_kernel, npx, s, p.fim, ol0.owns, npx, ppi, p.F, sl.weights, sl.n_weights);
     if (rc != MR_OK || nfaces == 0) return rc;
     PixelMapParams q = p;
     q.zero_owner_rows = 1;
-    rc = launch_compact(q, ol0, true, s);
+    rc = launch_compact(q, ol0, true, s, sl.weights, strip_l, sl.strips_axis);
     if (rc != MR_OK) return rc;
-    const int strips_axis = (p.is + strip_l - 1) / strip_l;
-    const int64_t grid = 8LL * 2 * strips_axis * ((p.B + 7) / 8);
+    const int strips_axis = sl.strips_axis;
+    hipLaunchKernelGGL(strip_list_kernel, dim3(8), dim3(SL_T), 0, s, (const unsigned*)sl.weights, sl.lists, sl.counts, p.B,
+                       2 * strips_axis, sl.cap);
+    MR_CHECK_LAUNCH();
+    const int64_t grid = 8LL * sl.cap;
     if (grid > 0x7fffffffLL) return MR_ERR_BADARG;
     const size_t lds = (size_t)strip_lds_bytes(p.is, strip_l);
     auto kernel = strip_l == 4 ? pixel_map_strip_kernel<IMG, 4> : (strip_l == 2 ? pixel_map_strip_kernel<IMG, 2> : pixel_map_strip_kernel<IMG, 1>);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PS_T), lds, s, p, (const unsigned*)ol0.img_count,
-                       (const float4*)ol0.img_recs, strips_axis);
+                       (const float4*)ol0.img_recs, strips_axis, (const unsigned*)sl.lists, (const unsigned*)sl.counts, sl.cap);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -2067,8 +2163,8 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
         hipError_t e = hipMemsetAsync(ol.owns, 0, ol.clear_bytes, s);  // flags and the counts behind them
         if (e != hipSuccess) return (int)e;
         const int64_t ppi = (int64_t)image_size * image_size;
-        if (ppi % 4 == 0) rc = launch1d(mark_owners_kernel, npx / 4, s, face_index_map, ol.owns, npx / 4, ppi, num_faces);
-        else rc = launch1d(mark_owners_scalar_kernel, npx, s, face_index_map, ol.owns, npx, ppi, num_faces);
+        if (ppi % 4 == 0) rc = launch1d(mark_owners_kernel, npx / 4, s, face_index_map, ol.owns, npx / 4, ppi, num_faces, (unsigned*)nullptr, (int64_t)0);
+        else rc = launch1d(mark_owners_scalar_kernel, npx, s, face_index_map, ol.owns, npx, ppi, num_faces, (unsigned*)nullptr, (int64_t)0);
         if (rc != MR_OK) return rc;
         PixelMapParams q{};
         q.faces = faces; q.grad_faces = grad_faces; q.B = batch_size; q.F = num_faces; q.is = image_size;
