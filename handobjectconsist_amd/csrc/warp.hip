@@ -719,14 +719,23 @@ __global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFw
             const float* jit = t.dir ? q.jitter : q.jitter_ref;
             DirRaw2 raw{};
             if (in_crop && t.row_covered) pair_load_own(tgt, jit, q.Cj, t.b, pixc, hw_img, raw);
+            // the pixel's own rendered values, all requested at once (the planes are defined wherever the row pair holds
+            // a covered pixel): mask, scale, the two displacement planes
+            float ma_p = 0.0f, sc = 1.0f, f0 = 0.0f, f1 = 0.0f;
+            if (t.row_covered) {
+                ma_p = ma[pix];
+                if (sab) sc = sab[pix];
+                f0 = fab[pix]; f1 = fab[hw + pix];
+            }
             float o = 0.0f;
-            if (t.row_covered) o = occl_one(ma, mb, fab, fba, sab, sba, hw, is, is, t.x, t.y, p.dist_thresh, p.wthresh, ha, hb, p.tiles_x);
+            if (t.row_covered && ma_p != 0.0f)
+                o = occl_from_own(ma_p, sab ? f0 * sc : f0, sab ? f1 * sc : f1, ma, mb, fba, sba, hw, is, is, t.x, t.y,
+                                  p.dist_thresh, p.wthresh, ha, hb, p.tiles_x);
             p.occl[a][(int64_t)t.b * hw + pix] = o;
             if (in_crop) {
-                const float sc = (o != 0.0f && sab) ? sab[pix] : 1.0f;
-                const float post = o != 0.0f ? ma[pix] * o : 0.0f;
+                const float post = o != 0.0f ? ma_p * o : 0.0f;
                 float2 r = make_float2(0.0f, 0.0f);
-                if (post != 0.0f && sc != 0.0f) r = make_float2((fab[pix] * sc) * post, (fab[hw + pix] * sc) * post);
+                if (post != 0.0f && sc != 0.0f) r = make_float2((f0 * sc) * post, (f1 * sc) * post);
                 *reinterpret_cast<float2*>(p.out[a] + ((int64_t)t.b * hw_img + pixc) * 2) = r;
 #pragma unroll
                 for (int c = 0; c < 3; c++) pin(raw.tgt[c]);

@@ -217,6 +217,12 @@ __device__ __forceinline__ bool tile_covered(const uint8_t* __restrict__ hit, in
     return hit[((ry >> 3) * tiles_x + (x >> 5)) * 4 + ((ry & 7) >> 1)] != 0;
 }
 
+__device__ __forceinline__ float occl_from_own(float ma_p, float fx, float fy, const float* __restrict__ mask_a,
+                                               const float* __restrict__ mask_b, const float* __restrict__ flow_ba,
+                                               const float* __restrict__ scale_ba, int64_t hw, int H, int W, int xx, int yy,
+                                               float dist_thresh, float wthresh, const uint8_t* __restrict__ hit_a,
+                                               const uint8_t* __restrict__ hit_b, int tiles_x);
+
 __device__ __forceinline__ float occl_one(const float* __restrict__ mask_a, const float* __restrict__ mask_b,
                                           const float* __restrict__ flow_ab,
                                           const float* __restrict__ flow_ba, const float* __restrict__ scale_ab,
@@ -231,10 +237,20 @@ __device__ __forceinline__ float occl_one(const float* __restrict__ mask_a, cons
     // outside its own mask -- 90 % of a hand + object frame -- is 0 without any of the dependent gathers below.
     if (ma_p == 0.0f) return 0.0f;
     // second warp: sample warp_ab at p + flow_ab(p)   (flow = raw flow * scale when a scale map is given)
-    float ix, iy;
     const float sa = scale_ab ? scale_ab[pix] : 1.0f;
-    sample_pos((float)xx, (float)yy, scale_ab ? flow_ab[pix] * sa : flow_ab[pix],
-               scale_ab ? flow_ab[hw + pix] * sa : flow_ab[hw + pix], W, H, ix, iy);
+    return occl_from_own(ma_p, scale_ab ? flow_ab[pix] * sa : flow_ab[pix], scale_ab ? flow_ab[hw + pix] * sa : flow_ab[hw + pix],
+                         mask_a, mask_b, flow_ba, scale_ba, hw, H, W, xx, yy, dist_thresh, wthresh, hit_a, hit_b, tiles_x);
+}
+
+// ... from the pixel's OWN values (mask_a(p) != 0 and the scaled flow_ab(p)) on: callers that can request those values
+// without waiting for the mask test (the listed kernels: one dependent round trip less per workgroup)
+__device__ __forceinline__ float occl_from_own(float ma_p, float fx, float fy, const float* __restrict__ mask_a,
+                                               const float* __restrict__ mask_b, const float* __restrict__ flow_ba,
+                                               const float* __restrict__ scale_ba, int64_t hw, int H, int W, int xx, int yy,
+                                               float dist_thresh, float wthresh, const uint8_t* __restrict__ hit_a,
+                                               const uint8_t* __restrict__ hit_b, int tiles_x) {
+    float ix, iy;
+    sample_pos((float)xx, (float)yy, fx, fy, W, H, ix, iy);
     int qx, qy;
     nearest_idx(ix, iy, qx, qy);
     float wg[3] = {0.0f, 0.0f, 0.0f};  // channels x, y, mask of warp_ab at q
