@@ -850,13 +850,17 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
             if (x >= sp.W || ry >= is || y >= sp.H) continue;
             const int64_t pixc = (int64_t)y * sp.W + x;
             float2 gq = make_float2(0.0f, 0.0f);
+            // the coverage word, the flow and the epilogue masks of the pixel are requested TOGETHER (all inside their
+            // allocations; what an uncovered row pair holds there is never used): the taps are the only dependent trip
             const uint32_t word = sp.tile_hit[(int64_t)b * T + t];
+            const int64_t o = ((int64_t)b * is + y) * is + x;
+            float2 uv = *reinterpret_cast<const float2*>(sp.flow + ((int64_t)b * hw_img + pixc) * 2);
+            float a = sp.m_pre[o];
+            float mxo = (b < sp.split ? sp.m_x_lo[o] : sp.m_x_hi[o - (int64_t)sp.split * is * is]), oc = sp.occl[o];
+            pin(uv.x); pin(uv.y); pin(a); pin(mxo); pin(oc);
             if (coef != 0.0f && ((word >> (8 * ((ry & 7) >> 1))) & 0xffu) != 0u) {
-                const float2 uv = *reinterpret_cast<const float2*>(sp.flow + ((int64_t)b * hw_img + pixc) * 2);
                 if (uv.x != 0.0f) {
-                    const int64_t o = ((int64_t)b * is + y) * is + x;
-                    const float a = sp.m_pre[o];
-                    const float post = (b < sp.split ? sp.m_x_lo[o] : sp.m_x_hi[o - (int64_t)sp.split * is * is]) * sp.occl[o];
+                    const float post = mxo * oc;
                     const DirTaps tp = pair_taps(uv, x, y, sp.H, sp.W);
                     DirRaw2 q{};
                     pair_load(tp, src, tgt, jit, jit, sp.Cj, false, pb, pixc, hw_img, q);
