@@ -794,7 +794,10 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
     const GatherVCParams& p = sp.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G = sp.groups;
-    const int b = blockIdx.x / G, part = blockIdx.x % G;
+    // PAIR: an image's workgroups on the XCD whose L2 holds what the forward launches just wrote for it (their tile lists are
+    // image-major and every XCD takes a contiguous eighth: images [x B / 8, (x + 1) B / 8) on XCD x, more or less)
+    const unsigned lidx = PAIR ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int b = (int)(lidx / (unsigned)G), part = (int)(lidx % (unsigned)G);
     const int is = p.is;
     const int T = sp.tiles_x * sp.tiles_y;
     const int r = lane >> 3, x4 = (lane & 7) * 4;  // the lane's pixel quad inside a tile
