@@ -796,7 +796,7 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
     const int G = sp.groups;
     // PAIR: an image's workgroups on the XCD whose L2 holds what the forward launches just wrote for it (their tile lists are
     // image-major and every XCD takes a contiguous eighth: images [x B / 8, (x + 1) B / 8) on XCD x, more or less)
-    const unsigned lidx = PAIR ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned lidx = (PAIR || FLOWGRAD) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int b = (int)(lidx / (unsigned)G), part = (int)(lidx % (unsigned)G);
     const int is = p.is;
     const int T = sp.tiles_x * sp.tiles_y;
