@@ -505,6 +505,8 @@ class _FlowPairLossFunction(torch.autograd.Function):
     pyramidloss.py:56-62 + lossutils.py:1-8 for one frame pair.  Differentiable w.r.t. ``cols`` only (the training
     setting: detach_renders=True, images are data).  ``flows`` are defined under the covered tiles only."""
 
+    last_tiles = None
+
     @staticmethod
     def forward(ctx, ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, height, width,
                 image_ref, image, jitter_ref, jitter, thresh):
@@ -532,6 +534,8 @@ class _FlowPairLossFunction(torch.autograd.Function):
                   _lib.ptr(im), _lib.ptr(jm_ref), _lib.ptr(jm), Cj, _lib.ptr(work), wbytes, _lib.ptr(sums), _lib.ptr(loss_fwd),
                   _lib.ptr(loss_bwd), B, is_, height, width, 0.03, 0.99999, float(thresh), where[0], where[1], where[2],
                   int(r["bound"]), st)
+        # (the flows are defined under the covered tiles only: the list rides along with them, as for get_opticalflow(sparse_flows=True))
+        _FlowPairLossFunction.last_tiles = (where[0], where[1], where[2], int(r["bound"]), r["work"])
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width, float(thresh), int(r["F0"]), int(r["V"]))
         ctx.save_for_backward(r["fim"], tile_hit, r["wmap"], r["vid"], mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums)
         ctx.grad_buf = r["grad_buf"]
@@ -581,33 +585,32 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
     if parts:
         (h1, o1), (h2, o2) = verts_cam
         hand_face, obj_faces = faces
-        if not (h1.is_cuda and o1.is_cuda and h2.shape == h1.shape and o2.shape == o1.shape and o1.dtype == torch.float32
-                and h2.dtype == torch.float32 and o2.dtype == torch.float32 and obj_faces.is_cuda and hand_face.is_cuda
-                and obj_faces.dim() == 3 and obj_faces.shape[0] == h1.shape[0]):
-            return None
-        # (a stand-in view with the concatenated mesh's shape / dtype / device for the checks below; never read)
-        v1 = v2 = h1.detach()[:1, :1, :1].expand(h1.shape[0], h1.shape[1] + o1.shape[1], 3)
-        num_faces0 = (hand_face.shape[-2] + obj_faces.shape[1])
+        tensors_ok = (all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 for x in (h1, o1, h2, o2))
+                      and h2.shape == h1.shape and o2.shape == o1.shape and o1.shape[0] == h1.shape[0] and obj_faces.is_cuda
+                      and hand_face.is_cuda and obj_faces.dim() == 3 and obj_faces.shape[0] == h1.shape[0])
+        B, V, dev = h1.shape[0], h1.shape[1] + (o1.shape[1] if tensors_ok else 0), h1.device
+        num_faces0 = (hand_face.shape[-2] + obj_faces.shape[1]) if tensors_ok else 0
     else:
         v1, v2 = verts_cam
+        tensors_ok = v1.is_cuda and v1.dtype == torch.float32 and v2.shape == v1.shape and v1.dim() == 3
+        B, V, dev = v1.shape[0], v1.shape[1], v1.device
         num_faces0 = faces.shape[1]
     if not (USE_FUSED_PAIR_NODE and USE_FUSED_VERTEX_STAGE and USE_FUSED_EPILOGUE and USE_SPARSE_TILES and USE_TILE_LIST
             and USE_PIXEL_RECORDS and USE_TILE_LIST_WARP and _vertex_color_path(neurenderer, True)
-            and hasattr(neurenderer, "render_projected_vertex_colors") and v1.is_cuda and v1.dtype == torch.float32
-            and v2.shape == v1.shape and _stacked_flow_node_ok(neurenderer, v1.shape[1]) and image.is_cuda
+            and hasattr(neurenderer, "render_projected_vertex_colors") and tensors_ok
+            and _stacked_flow_node_ok(neurenderer, V) and image.is_cuda
             and image.dtype == torch.float32 and image.dim() == 4 and image.shape[1] == 3 and image.shape[-1] >= 2
             and jitter_mask.dim() == 4 and jitter_mask.shape[1] in (1, 3)
             # (the node differentiates w.r.t. the vertices only: images that want a gradient take the composed path)
             and not (image.requires_grad or image_ref.requires_grad or jitter_mask.requires_grad or jitter_mask_ref.requires_grad)):
         return None
-    dev = v1.device
     is_ = int(neurenderer.image_size)
     W, H = (orig_img_size[0], orig_img_size[1]) if orig_img_size is not None else (is_, is_)
     H, W = min(int(H), is_), min(int(W), is_)
     if tuple(image.shape[2:]) != (H, W) or image_ref.shape != image.shape:
         return None
     F = num_faces0 * (2 if neurenderer.fill_back else 1)
-    if not _lib.has_tile_list(2 * v1.shape[0], F, is_):
+    if not _lib.has_tile_list(2 * B, F, is_):
         return None
     cam = (camintrs[0].to(dev), camintrs[1].to(dev), neurenderer.R.to(dev), neurenderer.t.to(dev), neurenderer.dist_coeffs.to(dev),
            neurenderer.orig_size)
@@ -621,8 +624,8 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
     loss_fwd, loss_bwd, flows, tile_hit = _FlowPairLossFunction.apply(
         ndc, faces2, cols, lut, neurenderer.fill_back, is_, neurenderer.near, neurenderer.far,
         neurenderer.rasterizer_eps, neurenderer.background_color, H, W, image_ref, image, jitter_mask_ref, jitter_mask, 0.99999)
-    B = v1.shape[0]
-    flows._hoc_coverage = (tile_hit, is_, flows._version, None)
+    tiles, _FlowPairLossFunction.last_tiles = _FlowPairLossFunction.last_tiles, None
+    flows._hoc_coverage = (tile_hit, is_, flows._version, tiles)
     return loss_fwd, loss_bwd, [flows[:B], flows[B:]]
 
 
