@@ -365,3 +365,34 @@ def test_general_flow_path_keeps_the_second_alpha_out_of_autograd(monkeypatch):
         grads.append((v1.grad.clone(), v2.grad.clone(), f12.detach(), f21.detach()))
     for a, b in zip(*grads):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), float((a - b).abs().max())
+
+
+def test_bench_plain_script_with_gpus_n_becomes_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` without RANK / WORLD_SIZE re-executes itself under torch.distributed.run with N ranks on
+    127.0.0.1 and the original arguments; with fewer devices than N it exits with a one-line message (no traceback)."""
+    import sys
+
+    import bench
+
+    launched = {}
+    monkeypatch.setattr(bench.os, "execv", lambda exe, cmd: launched.update(exe=exe, cmd=list(cmd)))
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("HOC_SHARE_GPU", raising=False)
+    args = bench.parse()
+    bench.self_launch(args)
+    cmd = launched["cmd"]
+    assert launched["exe"] == sys.executable and cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    script = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    # too few devices: a message, not an assertion
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 2)
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(args)
+    assert "--gpus 8 asks for 8 devices, this node shows 2" in str(e.value)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 0)
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(args)
+    assert "needs a GPU" in str(e.value)
