@@ -105,30 +105,43 @@ def event_time_ms(fn, iters, warmup=5, flush=None):
     return total / iters
 
 
-# The raster backward AS THE TRAINING STEP LAUNCHES IT since round 4: one launch in which every workgroup computes the pair
-# loss's flow gradient of its covered tiles, applies the epilogue adjoint and scatters to the vertex colours
-# (mr_flow_pair_backward_tiles).  ROOF_BWD_PLAIN: the scatter alone on a given flow gradient (mr_render_flow_backward, rounds 2-3).
-ROOF_BWD = "flow_pair_backward_tiles(train: pair-loss bwd + epilogue adjoint + E scatter,2B)"
+# The raster backward AS THE TRAINING STEP LAUNCHES IT (round 4, ABI 5): the scatter of the pair loss's gradient to the vertex
+# colours, the gradient itself -- for a unit coefficient, epilogue masks applied -- having been left by the FORWARD launch
+# that held its taps in registers (mr_flow_pair_forward_grad_tiles -> mr_flow_pair_backward_unit_tiles).
+# ROOF_BWD_R4A: the first round-4 form, one launch that recomputes the pair loss's backward in front of the scatter
+# (mr_flow_pair_backward_tiles; what `roofline` described until this change).  ROOF_BWD_PLAIN: the scatter alone on a given
+# flow gradient with the epilogue adjoint applied on the fly (mr_render_flow_backward, rounds 2-3).
+ROOF_BWD = "flow_pair_backward_unit_tiles(train: E scatter of the forward's unit gradient x coefficient,2B)"
+ROOF_BWD_R4A = "flow_pair_backward_tiles(train: pair-loss bwd + epilogue adjoint + E scatter,2B)"
 ROOF_BWD_PLAIN = "render_flow_backward(train,E+epilogue adjoint,2B)"
 ROOF_FWD = "render_flow_forward(train outputs,both frames=2B)"
-FUSED_FWD = "flow_pair_forward_tiles(train: occlusion + epilogue + pair loss, sparse)"
+FUSED_FWD = "flow_pair_forward_grad_tiles(train: occlusion + epilogue + pair loss + unit gradient, sparse)"
+FUSED_FWD_PLAIN = "flow_pair_forward_tiles(occlusion + epilogue + pair loss, sparse)"
 # the device kernels behind the groups (names as rocprofv3 prints them)
-ROOF_KERNELS = {ROOF_BWD: ["pair_scatter_tiles_kernel"], ROOF_BWD_PLAIN: ["scatter_tiles_kernel<true, true>"],
+ROOF_KERNELS = {ROOF_BWD: ["unit_scatter_tiles_kernel"], ROOF_BWD_R4A: ["pair_scatter_tiles_kernel"],
+                ROOF_BWD_PLAIN: ["scatter_tiles_kernel<true, true>"],
                 ROOF_FWD: ["face_records_kernel<true>", "bin_boxes_kernel", "raster_tile_kernel<true, true>"]}
+# compulsory bytes per pixel of a covered tile: face index 4 + vertex ids 12 + sampling weights 12 + ...
+ROOF_BWD_PER_PIXEL = {ROOF_BWD: (36, "... + unit gradient 8"),
+                      ROOF_BWD_R4A: (80, "... + three masks 12 + final flow 8 + source 12 + target 12 + two jitter values 8 (its scratch "
+                                         "stays in the L2 of the workgroup that writes and re-reads it)"),
+                      ROOF_BWD_PLAIN: (48, "... + flow gradient 8 + three masks 12")}
 WARP_TILES_KERNELS = ("occlusion_flow_tiles_kernel", "pair_consist_forward_tiles_kernel", "pair_consist_backward_tiles_kernel",
-                      "flow_pair_forward_tiles_kernel")
+                      "flow_pair_forward_tiles_kernel<false>", "flow_pair_forward_tiles_kernel<true>")
 
 
 ROOF_OPTIONAL = ()
 # the warp half over the render's tile list (round 4) and what one pixel of a covered tile makes each pass move
 WARP_TILES = ("occlusion_flow_tiles(train: occlusion + flow epilogue, sparse)", "pair_consist_forward_tiles(train, sparse)",
-              "pair_consist_backward_tiles(train, sparse)", FUSED_FWD)
-WARP_TILES_BYTES = (44, 40, 48, 76)
+              "pair_consist_backward_tiles(train, sparse)", FUSED_FWD_PLAIN, FUSED_FWD)
+WARP_TILES_BYTES = (44, 40, 48, 76, 84)
 WARP_TILES_WHAT = ("per pixel of a covered tile: own mask 4 + scale 4 + flow 8, gathered flow 8 + scale 4 + mask 4, out occl 4 + flow 8",
                    "per pixel of a covered tile: flow 8 + source 12 + target 12 + two jitter values 8 (each image pixel counted once)",
                    "per pixel of a covered tile: flow 8 + source 12 + target 12 + two jitter values 8, out grad_flow 8",
                    "per pixel of a covered tile: the occlusion pass's 44 + source 12 + target 12 + two jitter values 8 (the flow it "
-                   "warps with never leaves the thread)")
+                   "warps with never leaves the thread)",
+                   "per pixel of a covered tile: the occlusion pass's 44 + source 12 + target 12 + two jitter values 8 + out unit "
+                   "gradient 8 (the step's forward launch when the vertices want a gradient)")
 
 
 def kernel_bench(dev, B, is_, iters, only=None):
@@ -321,6 +334,19 @@ def kernel_bench(dev, B, is_, iters, only=None):
                   P(im_ref), P(im), P(jm_ref), P(jm), 3, P(ptwork), ptbytes, P(sums), P(lf), P(lb), B, is_, is_, is_, 0.03, 0.99999,
                   0.99999, tlist[0], tlist[1], tlist[2], tl_bound, st)
 
+    punit, punit_max = torch.empty((B2, is_, is_, 2), **f32), torch.empty((B2,), **f32)
+
+    def flow_pair_fwd_grad_tiles():  # ... and as the step launches it when the vertices want a gradient (they do)
+        _lib.call("mr_flow_pair_forward_grad_tiles", P(pmask[:B]), P(palpha[B:]), P(prgb[:B]), P(prgb[B:]), 3 * is_ * is_,
+                  P(pmask[:B]), P(pmask[B:]), P(pocc[:B]), P(pocc[B:]), P(pflows[:B]), P(pflows[B:]), P(ptile_hit[:B]),
+                  P(ptile_hit[B:]), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(ptwork), ptbytes, P(sums), P(lf), P(lb), B, is_, is_,
+                  is_, 0.03, 0.99999, 0.99999, tlist[0], tlist[1], tlist[2], tl_bound, P(punit), P(punit_max), st)
+
+    def flow_pair_bwd_unit_tiles():  # the step's backward launch (output cleared by the forward's binning pass, as in the step)
+        _lib.call("mr_flow_pair_backward_unit_tiles", P(pfim), P(ptile_hit), P(pwrec), P(pvid), P(punit), P(punit_max), P(sums),
+                  P(gl), P(gl), is_, is_, P(pg_cols), B2, pv.shape[1], F0, 1, is_, 1e-3,
+                  _lib.FLAG_OUTPUT_ZEROED | (int(os.environ.get("HOC_FLOW_BWD_DBG", "0")) << 8), 0, st)
+
     pscratch = torch.empty((B2, is_, is_, 2), **f32)
 
     def flow_pair_bwd_tiles():  # the step's backward launch (output cleared by the forward's binning pass, as in the step)
@@ -409,8 +435,12 @@ def kernel_bench(dev, B, is_, iters, only=None):
         (WARP_TILES[1], pair_fwd_tiles, 48 * npx),
         (WARP_TILES[2], pair_bwd_tiles, 64 * npx),
         # ... and fused, as the training step launches them now: SURVEY 8(d)'s bytes of the passes each replaces
-        (FUSED_FWD, flow_pair_fwd_tiles, (8 + 16 + 8 + 16) * npx + 48 * npx),
-        (ROOF_BWD, flow_pair_bwd_tiles, 64 * npx + 2 * ((12 + 4 + 12 + 4) * npx + (36 + 96) * BF)),
+        (FUSED_FWD_PLAIN, flow_pair_fwd_tiles, (8 + 16 + 8 + 16) * npx + 48 * npx),
+        (ROOF_BWD_R4A, flow_pair_bwd_tiles, 64 * npx + 2 * ((12 + 4 + 12 + 4) * npx + (36 + 96) * BF)),
+        # ... and with the pair loss's backward moved into the forward launch: the pair forward + the pair backward's bytes
+        # there, kernel E's here
+        (FUSED_FWD, flow_pair_fwd_grad_tiles, (8 + 16 + 8 + 16) * npx + 48 * npx + 64 * npx),
+        (ROOF_BWD, flow_pair_bwd_unit_tiles, 2 * ((12 + 4 + 12 + 4) * npx + (36 + 96) * BF)),
         ("occlusion_mask", occlusion, (8 + 16 + 8) * npx),
         # + the two final flows written in the same pass (16 B per pixel)
         ("occlusion_flow(train: occlusion + flow epilogue)", occlusion_flow, (8 + 16 + 8 + 16) * npx),
@@ -446,33 +476,21 @@ def kernel_bench(dev, B, is_, iters, only=None):
                       "compulsory_GBps": round(comp / (k["ms"] * 1e-3) / 1e9, 1),
                       "compulsory_frac_hbm_peak": round(comp / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "compulsory_frac_hbm_peak_cache_warm": round(comp / (k["ms_cache_warm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-    if ROOF_BWD in out:
-        # the fused launch: per pixel of a covered tile face index 4 + vertex ids 12 + sampling weights 12 + three masks 12
-        # + final flow 8 + source 12 + target 12 + two jitter values 8 = 80 B (its scratch stays in the L2 of the
-        # workgroup that writes and re-reads it), the coverage bytes and the [2B,V,3] output
-        comp = covered_words * 32 * 8 * 80 + ptile_hit.numel() + pg_cols.numel() * 4
-        k = out[ROOF_BWD]
-        k.update({"covered_tiles": covered_words, "tiles": int(ptile_hit.numel() // 4), "compulsory_bytes": int(comp),
-                  "compulsory_per_pixel": 80,
-                  "compulsory_GBps": round(comp / (k["ms"] * 1e-3) / 1e9, 1),
-                  "compulsory_frac_hbm_peak": round(comp / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                  "compulsory_frac_hbm_peak_cache_warm": round(comp / (k["ms_cache_warm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-    if ROOF_BWD_PLAIN in out:
-        # What the raster backward of the training path HAS to move, at least once, for this scene: per tile the forward
-        # reports as covered (coverage bytes) the 256 pixels of face_index_map 4 + vertex ids 12 + sampling weights 12 +
-        # flow gradient 8 + three masks 12 = 48 B, the coverage bytes themselves and the [2B,V,3] output.  The SURVEY 8(d)
-        # figure (`algorithmic_bytes`: 32 B for every pixel of the raster + 132 B per face) describes upstream's kernel E,
-        # which this kernel replaces without touching a [B,F,...] tensor or the 83 % of the screen that is empty: dividing
-        # THAT by the launch time gives an effective rate that can exceed the chip's bandwidth and is kept only as
-        # `frac_algorithmic`.
-        covered = int((ptile_hit.view(torch.int32) != 0).sum())
-        comp = covered * 32 * 8 * 48 + ptile_hit.numel() + pg_cols.numel() * 4
-        k = out[ROOF_BWD_PLAIN]
-        k.update({"covered_tiles": covered, "tiles": int(ptile_hit.numel() // 4), "compulsory_bytes": int(comp),
-                  "compulsory_per_pixel": 48,
-                  "compulsory_GBps": round(comp / (k["ms"] * 1e-3) / 1e9, 1),
-                  "compulsory_frac_hbm_peak": round(comp / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                  "compulsory_frac_hbm_peak_cache_warm": round(comp / (k["ms_cache_warm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    # What the raster backward of the training path HAS to move, at least once, for this scene: per tile the forward reports
+    # as covered (coverage bytes) the 256 pixels of ROOF_BWD_PER_PIXEL's bytes, the coverage bytes themselves and the
+    # [2B,V,3] output.  The SURVEY 8(d) figure (`algorithmic_bytes`: 32 B for every pixel of the raster + 132 B per face)
+    # describes upstream's kernel E, which these kernels replace without touching a [B,F,...] tensor or the 83 % of the
+    # screen that is empty: dividing THAT by the launch time gives an effective rate that can exceed the chip's bandwidth
+    # and is kept only as `frac_algorithmic`.
+    for name, (per_px, _what) in ROOF_BWD_PER_PIXEL.items():
+        if name in out:
+            comp = covered_words * 32 * 8 * per_px + ptile_hit.numel() + pg_cols.numel() * 4
+            k = out[name]
+            k.update({"covered_tiles": covered_words, "tiles": int(ptile_hit.numel() // 4), "compulsory_bytes": int(comp),
+                      "compulsory_per_pixel": per_px,
+                      "compulsory_GBps": round(comp / (k["ms"] * 1e-3) / 1e9, 1),
+                      "compulsory_frac_hbm_peak": round(comp / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "compulsory_frac_hbm_peak_cache_warm": round(comp / (k["ms_cache_warm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     return out
 
 
@@ -615,8 +633,10 @@ def roofline_block(name, k, pmc, units, in_step=None):
             "unit": "GB/s", "frac": k["compulsory_frac_hbm_peak"] if own else k["frac_hbm_peak"],
             "frac_cache_warm": k["compulsory_frac_hbm_peak_cache_warm"] if own else k["frac_hbm_peak_cache_warm"],
             "bytes": k["compulsory_bytes"] if own else k["algorithmic_bytes"],
-            "bytes_are": ("compulsory traffic of this launch: %d B per pixel of the %d covered tiles of %d + coverage bytes + "
-                          "output" % (k["compulsory_per_pixel"], k["covered_tiles"], k["tiles"])) if own else "algorithmic bytes of SURVEY 8(d)",
+            "bytes_are": ("compulsory traffic of this launch: %d B per pixel of the %d covered tiles of %d (face index 4 + vertex ids "
+                          "12 + sampling weights 12 %s) + coverage bytes + output"
+                          % (k["compulsory_per_pixel"], k["covered_tiles"], k["tiles"], ROOF_BWD_PER_PIXEL[name][1])) if own
+                         else "algorithmic bytes of SURVEY 8(d)",
             "traffic": None, "algorithmic_bytes": k["algorithmic_bytes"], "achieved_algorithmic": k["GBps"],
             "frac_algorithmic": k["frac_hbm_peak"], "frac_algorithmic_cache_warm": k["frac_hbm_peak_cache_warm"],
             "launch_ms": k["ms"], "launch_ms_cache_warm": k["ms_cache_warm"],
@@ -720,7 +740,7 @@ def main():
 
     assert _lib.load().mr_device_ok() == 1, "libmeshraster_hip.so: no gfx950 device"
     if args.kernels_only or args.roofline_only:
-        only = (ROOF_BWD, ROOF_BWD_PLAIN, ROOF_FWD) + WARP_TILES if args.roofline_only else None
+        only = (ROOF_BWD, ROOF_BWD_R4A, ROOF_BWD_PLAIN, ROOF_FWD) + WARP_TILES if args.roofline_only else None
         if os.environ.get("HOC_KERNEL_GROUPS"):  # profiling aid: group names of kernel_bench, separated by ";"
             only = tuple(os.environ["HOC_KERNEL_GROUPS"].split(";"))
         os.write(real_stdout, (json.dumps(kernel_bench(dev, args.batch, args.image_size, args.kernel_iters, only), indent=1) + "\n").encode())
@@ -930,6 +950,11 @@ def main():
         # the raster backward (north star) in the shape the training step launches it: one launch for both frames of
         # the pair, the pair loss's backward and the adjoint of the flow epilogue folded in
         roof = roofline_block(ROOF_BWD, kernels[ROOF_BWD], pmc, units, in_step)
+        roof["note"] = ("the pair loss's backward runs inside the step's FORWARD launch since ABI 5 (warp_tiles: " + FUSED_FWD + "); "
+                        "this launch is the scatter to the vertex colours alone.  `recomputing_form`: the launch it replaced "
+                        "(pair-loss backward recomputed in front of the scatter), `scatter_alone`: the round-3 launch on a given "
+                        "flow gradient")
+        roof["recomputing_form"] = roofline_block(ROOF_BWD_R4A, kernels[ROOF_BWD_R4A], pmc, units)
         roof["scatter_alone"] = roofline_block(ROOF_BWD_PLAIN, kernels[ROOF_BWD_PLAIN], pmc, units)
         # ... and the forward of the same launch shape: the hot-path kernel that takes the most time
         roof_fwd = roofline_block(ROOF_FWD, kernels[ROOF_FWD], pmc, units, in_step)

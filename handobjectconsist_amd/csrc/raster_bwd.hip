@@ -736,19 +736,24 @@ struct ScatterTilesParams {
     const float* gl_fwd;      // [split] incoming gradients of loss_fwd / loss_bwd (gl_bwd nullable)
     const float* gl_bwd;
     float pair_thresh;
+    // UNIT (mr_flow_pair_backward_unit_tiles): the forward (mr_flow_pair_forward_grad_tiles) left the pair loss's gradient for
+    // a coefficient of 1, masks applied; this launch multiplies by grad_loss / count of the image -- no taps, no pass 1
+    const float* unit_grad;   // [B,H,W,2]
+    const float* unit_max;    // [B] largest |unit gradient| per image (an upper bound is enough)
 };
 
-template <bool FLOWGRAD, bool PAIR = false>
-__device__ __forceinline__ void st_load_grad(const ScatterTilesParams& sp, int b, int yi, int x, float (*g)[3]) {
+template <bool FLOWGRAD, bool PAIR = false, bool UNIT = false>
+__device__ __forceinline__ void st_load_grad(const ScatterTilesParams& sp, int b, int yi, int x, float (*g)[3], float ucoef = 0.0f) {
     const GatherVCParams& p = sp.g;
     const int is = p.is;
     const int yimg = is - 1 - yi;
-    if (PAIR) {  // pass 1 of this workgroup left the gradient, masks applied, in the stash
+    if (PAIR || UNIT) {  // pass 1 of this workgroup (UNIT: the forward launch) left the gradient, masks applied
+        const float* st = UNIT ? sp.unit_grad : sp.stash;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float2 gf = make_float2(0.0f, 0.0f);
-            if (yimg < sp.H && x + j < sp.W) gf = *reinterpret_cast<const float2*>(sp.stash + (((int64_t)b * sp.H + yimg) * sp.W + x + j) * 2);
-            g[j][0] = gf.x; g[j][1] = gf.y; g[j][2] = 0.0f;
+            if (yimg < sp.H && x + j < sp.W) gf = *reinterpret_cast<const float2*>(st + (((int64_t)b * sp.H + yimg) * sp.W + x + j) * 2);
+            g[j][0] = UNIT ? gf.x * ucoef : gf.x; g[j][1] = UNIT ? gf.y * ucoef : gf.y; g[j][2] = 0.0f;
         }
     } else if (!FLOWGRAD) {
 #pragma unroll
@@ -783,7 +788,7 @@ __device__ unsigned long long mr_dbg_st[4096 * 8];  // profiling builds: phase s
 #define MR_ST_STAMP(k) do { } while (0)
 #endif
 
-template <bool FLOWGRAD, bool REC, bool PAIR>
+template <bool FLOWGRAD, bool REC, bool PAIR, bool UNIT = false>
 __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp) {
     MR_ST_STAMP(0);
     extern __shared__ long long vtab[];  // [V * NCH] rounded up to an even count
@@ -828,8 +833,19 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
 
     // pass 1: largest |gradient| over the workgroup's covered tiles, as float bits -- or the caller's bound for the image
     unsigned mx = 0u;
-    const bool bounded = PAIR || (FLOWGRAD && sp.grad_bound != nullptr);
-    if (bounded && !PAIR) mx = __float_as_uint(sp.grad_bound[b]) & 0x7fffffffu;
+    const bool bounded = PAIR || UNIT || (FLOWGRAD && sp.grad_bound != nullptr);
+    if (bounded && !PAIR && !UNIT) mx = __float_as_uint(sp.grad_bound[b]) & 0x7fffffffu;
+    float ucoef = 0.0f;
+    if constexpr (UNIT) {
+        // the image's coefficient (pair_consist_backward_tiles_kernel's): every gradient of the image is unit * ucoef, and
+        // |unit| <= unit_max rounds to at most fl(unit_max * |ucoef|) (rounding is monotone): the bound of the fixed point.
+        // A zero coefficient leaves the image without a gradient whatever the unit gradient holds.
+        const int dir = b >= sp.split ? 1 : 0, pb = b - dir * sp.split;
+        const float cnt = sp.sums[pb * 4 + (dir ? 1 : 3)];
+        const float* gl = dir ? sp.gl_fwd : sp.gl_bwd;
+        ucoef = gl ? gl[pb] / ((cnt == 0.0f) ? 1.0f : cnt) : 0.0f;
+        if (ucoef != 0.0f) mx = __float_as_uint(sp.unit_max[b] * ucoef) & 0x7fffffffu;
+    }
     if constexpr (PAIR) {
         // ... PAIR: the pair loss's backward for the workgroup's tiles (pair_consist_backward_tiles_kernel's arithmetic, one
         // pixel per thread, two tiles at a time), times the epilogue masks as st_load_grad forms them, into the stash;
@@ -931,7 +947,7 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
             for (int k = 0; k < 3; k++) { g[j][k] = 0.0f; w[j][k] = 0.0f; }
         }
         if (inside) {
-            st_load_grad<FLOWGRAD, PAIR>(sp, b, yi, x, g);
+            st_load_grad<FLOWGRAD, PAIR, UNIT>(sp, b, yi, x, g, ucoef);
             const float4* wq = reinterpret_cast<const float4*>(sp.weight + (((int64_t)b * is + yi) * is + x) * 3);
             const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2];
             w[0][0] = w0.x; w[0][1] = w0.y; w[0][2] = w0.z; w[1][0] = w0.w; w[1][1] = w1.x; w[1][2] = w1.y;
@@ -1029,6 +1045,12 @@ __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) scatter_tiles_kernel(Scatt
 __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) __attribute__((amdgpu_waves_per_eu(8, 8)))
 pair_scatter_tiles_kernel(ScatterTilesParams sp) {
     scatter_tiles_body<true, true, true>(sp);
+}
+
+// ... and with the pair loss's gradient already formed by the forward launch (mr_flow_pair_backward_unit_tiles): the
+// scatter alone, its gradient = unit gradient x the image's coefficient, its bound = the forward's maximum x |coefficient|
+__global__ void __launch_bounds__(ST_WAVES * MR_WAVE) unit_scatter_tiles_kernel(ScatterTilesParams sp) {
+    scatter_tiles_body<true, true, false, true>(sp);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2036,9 +2058,10 @@ static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t wo
     if (e0 != hipSuccess) return (int)e0;
     const int64_t ppi = (int64_t)p.is * p.is, npx = ppi * p.B;
     const StripLists sl = strip_lists(workspace, p.B, p.F, p.is);
-    if (sl.n_weights > npx / 4) return MR_ERR_BADARG;  // (the marking pass clears the weights, one word per thread: 2 B is / L <= B is^2 / 4)
-    int rc = (ppi % 4 == 0) ? launch1d(mark_owners_kernel, npx / 4, s, p.fim, ol0.owns, npx / 4, ppi, p.F, sl.weights, sl.n_weights)
-                            : launch1d(mark_owners_scalar_kernel, npx, s, p.fim, ol0.owns, npx, ppi, p.F, sl.weights, sl.n_weights);
+    // (the marking pass clears the weights, one word per thread: 2 B is / L words -- more than B is^2 / 4 pixel quads for
+    // rasters of one or two pixels, found by tests/fuzz_parity.py: the launch then covers the weights, the kernels guard)
+    int rc = (ppi % 4 == 0) ? launch1d(mark_owners_kernel, std::max(npx / 4, sl.n_weights), s, p.fim, ol0.owns, npx / 4, ppi, p.F, sl.weights, sl.n_weights)
+                            : launch1d(mark_owners_scalar_kernel, std::max(npx, sl.n_weights), s, p.fim, ol0.owns, npx, ppi, p.F, sl.weights, sl.n_weights);
     if (rc != MR_OK || nfaces == 0) return rc;
     PixelMapParams q = p;
     q.zero_owner_rows = 1;
@@ -2336,6 +2359,46 @@ extern "C" int mr_flow_pair_backward_tiles(const int32_t* face_index_map, const 
     const int64_t blocks = (int64_t)batch_size * sp.groups;
     if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
     hipLaunchKernelGGL(pair_scatter_tiles_kernel, dim3((unsigned)blocks), dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, const uint32_t* tile_hit,
+                                                const float* weight_map, const int32_t* vertex_id_map, const float* unit_grad,
+                                                const float* unit_grad_max, const float* sums, const float* grad_loss_fwd,
+                                                const float* grad_loss_bwd, int height, int width, float* grad_vcolors,
+                                                int batch_size, int num_verts, int num_faces, int fill_back, int image_size,
+                                                float eps, int flags, int texel_layout, mr_stream_t stream) {
+    if (batch_size < 0 || (batch_size & 1) || num_faces < 0 || num_verts < 0 || image_size <= 0 || !texel_layout_ok(texel_layout))
+        return MR_ERR_BADARG;
+    if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
+    if (batch_size == 0 || num_verts == 0) return MR_OK;
+    if (!unit_grad || !unit_grad_max || !sums || !grad_loss_fwd || !tile_hit) return MR_ERR_BADARG;
+    if (height <= 0 || width < 2 || height > image_size || width > image_size || (int64_t)height * width > (1LL << 29))
+        return MR_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!(flags & MR_FLAG_OUTPUT_ZEROED)) {
+        hipError_t e = hipMemsetAsync(grad_vcolors, 0, (size_t)batch_size * num_verts * 3 * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (num_faces == 0) return MR_OK;
+    if (!face_index_map || !weight_map || !vertex_id_map || !(eps >= 1e-6f)) return MR_ERR_BADARG;
+    const int64_t table_bytes = (((int64_t)num_verts * 2 + 1) / 2) * 16;
+    if (image_size % 4 != 0 || table_bytes > SV_MAX_TABLE_BYTES ||
+        (int64_t)((image_size + ST_TW - 1) / ST_TW) * ((image_size + ST_TH - 1) / ST_TH) > ST_MAX_TILES)
+        return MR_ERR_NOTIMPL;
+    ScatterTilesParams sp{};
+    sp.g = GatherVCParams{nullptr, nullptr, face_index_map, nullptr, grad_vcolors, batch_size, num_verts, num_faces,
+                          fill_back, image_size, eps, flags >> 8, texel_layout};
+    sp.weight = weight_map; sp.tile_hit = tile_hit; sp.vid_map = vertex_id_map;
+    sp.split = batch_size / 2; sp.H = height; sp.W = width;
+    sp.tiles_x = (image_size + ST_TW - 1) / ST_TW; sp.tiles_y = (image_size + ST_TH - 1) / ST_TH;
+    sp.groups = ST_G;
+    switch ((flags >> 12) & 7) { case 1: sp.groups = 2; break; case 2: sp.groups = 4; break; case 3: sp.groups = 16; break; case 4: sp.groups = 32; break; default: break; }
+    sp.unit_grad = unit_grad; sp.unit_max = unit_grad_max; sp.sums = sums; sp.gl_fwd = grad_loss_fwd; sp.gl_bwd = grad_loss_bwd;
+    const int64_t blocks = (int64_t)batch_size * sp.groups;
+    if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(unit_scatter_tiles_kernel, dim3((unsigned)blocks), dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

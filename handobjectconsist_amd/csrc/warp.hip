@@ -686,10 +686,17 @@ struct FlowPairFwdParams {
     int Cj;
     float* partial;           // [2B, T, 2]
     float thresh;
+    // GRAD (mr_flow_pair_forward_grad_tiles): the thread holds everything the pair loss's backward needs -- taps, masks, the
+    // epilogue's factors -- so it leaves d(sum of |residuals|) / d(rendered displacement) of its pixel, the "unit gradient"
+    // (the backward multiplies by grad_loss / count, one scalar per image), and the tile's largest magnitude
+    float* unit_grad;         // [2B, H, W, 2] (written under the covered tiles)
+    unsigned* tile_max;       // [2B, T] float bits
 };
 
+template <bool GRAD>
 __global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFwdParams q) {
     __shared__ float red[2][4][2];
+    __shared__ unsigned redm[2][4];
     const OcclTilesParams& p = q.o;
     unsigned j;
     const ListSlice sl = list_slice(p.list.tlist->n_heavy, p.list.tlist->n_light, j);
@@ -700,6 +707,7 @@ __global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFw
         const TileAt t = tile_at(p.list.ids[sl.slot(j, p.list.cap)].x, p.B, p.tiles_x, T, is, p.hit[0], p.hit[1]);
         if (t.word == 0u) continue;  // (uniform)
         float sum = 0.0f, cnt = 0.0f;
+        unsigned gmx = 0u;
         if (t.x < is && t.ry < is) {
             const int a = t.dir, o_ = 1 - t.dir;
             const float* ma = p.mask[a] + (int64_t)t.b * hw;
@@ -740,6 +748,7 @@ __global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFw
 #pragma unroll
                 for (int c = 0; c < 3; c++) pin(raw.tgt[c]);
                 pin(raw.jd);
+                float2 gq = make_float2(0.0f, 0.0f);
                 if (r.x != 0.0f) {  // (a zero x component: invalid whatever the images hold, imgflowarp.py:93-100)
                     const DirTaps tp = pair_taps(r, t.x, t.y, H, W);
                     pair_load_taps(tp, src, jit, q.Cj, t.b, hw_img, raw);
@@ -751,18 +760,33 @@ __global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFw
                         for (int c = 0; c < 3; c++) sum += fabsf(e.s[c] - rr.tgt[c]);
                         cnt = 3.0f;
                     }
+                    if (GRAD) {
+                        // pair_consist_backward_tiles_kernel's gradient with coefficient 1, times the epilogue's factors as
+                        // the raster backward applies them: (g * (mask_x * occl)) * mask_pre
+                        const float2 gp = pair_grad(tp, rr, e, H, W, 1.0f);
+                        gq = make_float2((gp.x * post) * sc, (gp.y * post) * sc);
+                    }
+                }
+                if (GRAD) {
+                    *reinterpret_cast<float2*>(q.unit_grad + ((int64_t)t.img * hw_img + pixc) * 2) = gq;
+                    gmx = max(__float_as_uint(gq.x) & 0x7fffffffu, __float_as_uint(gq.y) & 0x7fffffffu);
                 }
             }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { sum += __shfl_xor(sum, off); cnt += __shfl_xor(cnt, off); }
+        if (GRAD) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) gmx = max(gmx, (unsigned)__shfl_xor((int)gmx, off));
+        }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = round & 1u;
-        if (lane == 0) { red[slot][wave][0] = sum; red[slot][wave][1] = cnt; }
+        if (lane == 0) { red[slot][wave][0] = sum; red[slot][wave][1] = cnt; if (GRAD) redm[slot][wave] = gmx; }
         __syncthreads();
         if (threadIdx.x == 0) {
             float* out = q.partial + ((int64_t)t.img * T + t.tile) * 2;
             out[0] = red[slot][0][0] + red[slot][1][0] + red[slot][2][0] + red[slot][3][0];
             out[1] = red[slot][0][1] + red[slot][1][1] + red[slot][2][1] + red[slot][3][1];
+            if (GRAD) q.tile_max[(int64_t)t.img * T + t.tile] = max(max(redm[slot][0], redm[slot][1]), max(redm[slot][2], redm[slot][3]));
         }
     }
 }
@@ -773,18 +797,36 @@ __global__ void __launch_bounds__(256) pair_consist_finalize_tiles_kernel(const 
                                                                           const uint32_t* __restrict__ hit12,
                                                                           const uint32_t* __restrict__ hit21, int B, int T,
                                                                           float* __restrict__ sums, float* __restrict__ loss_fwd,
-                                                                          float* __restrict__ loss_bwd) {
+                                                                          float* __restrict__ loss_bwd,
+                                                                          const unsigned* __restrict__ tile_max,
+                                                                          unsigned* __restrict__ image_max) {
     __shared__ float red[4][4];
+    __shared__ unsigned redm[4][2];
     const int b = blockIdx.x;
     float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned m12 = 0u, m21 = 0u;  // largest unit-gradient magnitude (float bits) of stack images b and B + b
     for (int t = threadIdx.x; t < T; t += 256) {
         const uint32_t h21 = hit21[(int64_t)b * T + t], h12 = hit12[(int64_t)b * T + t];
         const float2 v1 = *reinterpret_cast<const float2*>(partial + ((int64_t)(B + b) * T + t) * 2);
         const float2 v2 = *reinterpret_cast<const float2*>(partial + ((int64_t)b * T + t) * 2);
-        if (h21 != 0u) { a[0] += v1.x; a[1] += v1.y; }
-        if (h12 != 0u) { a[2] += v2.x; a[3] += v2.y; }
+        unsigned t21 = 0u, t12 = 0u;
+        if (tile_max) { t21 = tile_max[(int64_t)(B + b) * T + t]; t12 = tile_max[(int64_t)b * T + t]; }
+        if (h21 != 0u) { a[0] += v1.x; a[1] += v1.y; m21 = max(m21, t21); }
+        if (h12 != 0u) { a[2] += v2.x; a[3] += v2.y; m12 = max(m12, t12); }
     }
-    block_sum4(a, red);
+    if (image_max) {  // (uniform)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            m12 = max(m12, (unsigned)__shfl_xor((int)m12, off));
+            m21 = max(m21, (unsigned)__shfl_xor((int)m21, off));
+        }
+        if ((threadIdx.x & 63) == 0) { redm[threadIdx.x >> 6][0] = m12; redm[threadIdx.x >> 6][1] = m21; }
+    }
+    block_sum4(a, red);  // (its barrier also publishes redm)
+    if (threadIdx.x == 0 && image_max) {
+        image_max[b] = max(max(redm[0][0], redm[1][0]), max(redm[2][0], redm[3][0]));
+        image_max[B + b] = max(max(redm[0][1], redm[1][1]), max(redm[2][1], redm[3][1]));
+    }
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 4; k++) sums[b * 4 + k] = a[k];
@@ -1060,7 +1102,8 @@ extern "C" int mr_occlusion_flow_tiles(const float* mask_flow1, const float* mas
 
 extern "C" int64_t mr_pair_consist_tiles_workspace_bytes(int batch_size, int hit_image_size) {
     if (batch_size < 0 || hit_image_size <= 0) return MR_ERR_BADARG;
-    return 2LL * batch_size * ((hit_image_size + 31) / 32) * ((hit_image_size + 7) / 8) * 2 * (int64_t)sizeof(float);
+    // per tile of the 2B stacked images: {sum, count} of the pair loss + (mr_flow_pair_forward_grad_tiles) the largest unit gradient
+    return 2LL * batch_size * ((hit_image_size + 31) / 32) * ((hit_image_size + 7) / 8) * 3 * (int64_t)sizeof(float);
 }
 
 static int pair_tiles_args_ok(const float* flow12, const float* flow21, const float* image_ref, const float* image,
@@ -1105,7 +1148,8 @@ extern "C" int mr_pair_consist_forward_tiles(const float* flow12, const float* f
     MR_CHECK_LAUNCH();
     hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit12),
-                       reinterpret_cast<const uint32_t*>(tile_hit21), batch_size, p.tiles_x * p.tiles_y, sums, loss_fwd, loss_bwd);
+                       reinterpret_cast<const uint32_t*>(tile_hit21), batch_size, p.tiles_x * p.tiles_y, sums, loss_fwd, loss_bwd,
+                       (const unsigned*)nullptr, (unsigned*)nullptr);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1141,16 +1185,16 @@ extern "C" int mr_pair_consist_backward_tiles(const float* flow12, const float* 
 }
 
 
-extern "C" int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
-                                          const float* flow21, int64_t flow_bstride, const float* flow12_scale,
-                                          const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
-                                          float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2,
-                                          const float* image_ref, const float* image, const float* jitter_ref,
-                                          const float* jitter, int jitter_channels, void* workspace, int64_t workspace_bytes,
-                                          float* sums, float* loss_fwd, float* loss_bwd, int batch_size, int image_size,
-                                          int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
-                                          const void* list_header, const void* list_entries, int64_t list_capacity,
-                                          int64_t tile_bound, mr_stream_t stream) {
+static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                                   const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                                   const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
+                                   float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2,
+                                   const float* image_ref, const float* image, const float* jitter_ref,
+                                   const float* jitter, int jitter_channels, void* workspace, int64_t workspace_bytes,
+                                   float* sums, float* loss_fwd, float* loss_bwd, int batch_size, int image_size,
+                                   int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
+                                   const void* list_header, const void* list_entries, int64_t list_capacity,
+                                   int64_t tile_bound, float* unit_grad, float* unit_grad_max, mr_stream_t stream) {
     if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2 || !flow_out12 || !flow_out21)
         return MR_ERR_BADARG;
     if (batch_size < 0 || image_size <= 0 || flow_bstride < 2LL * image_size * image_size) return MR_ERR_BADARG;
@@ -1168,12 +1212,56 @@ extern "C" int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* 
                           {(const TileList*)list_header, (const uint4*)list_entries, (unsigned)list_capacity}};
     q.image_ref = image_ref; q.image = image; q.jitter_ref = jitter_ref; q.jitter = jitter; q.Cj = jitter_channels;
     q.partial = (float*)workspace; q.thresh = pair_thresh;
-    hipLaunchKernelGGL(flow_pair_forward_tiles_kernel, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
-                       (hipStream_t)stream, q);
+    q.unit_grad = unit_grad;
+    q.tile_max = reinterpret_cast<unsigned*>(q.partial + 2LL * batch_size * tiles_x * tiles_y * 2);
+    if (unit_grad)
+        hipLaunchKernelGGL(flow_pair_forward_tiles_kernel<true>, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
+                           (hipStream_t)stream, q);
+    else
+        hipLaunchKernelGGL(flow_pair_forward_tiles_kernel<false>, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
+                           (hipStream_t)stream, q);
     MR_CHECK_LAUNCH();
     hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit1),
-                       reinterpret_cast<const uint32_t*>(tile_hit2), batch_size, tiles_x * tiles_y, sums, loss_fwd, loss_bwd);
+                       reinterpret_cast<const uint32_t*>(tile_hit2), batch_size, tiles_x * tiles_y, sums, loss_fwd, loss_bwd,
+                       unit_grad ? (const unsigned*)q.tile_max : (const unsigned*)nullptr,
+                       unit_grad ? reinterpret_cast<unsigned*>(unit_grad_max) : (unsigned*)nullptr);
     MR_CHECK_LAUNCH();
     return MR_OK;
+}
+
+extern "C" int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                                          const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                                          const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
+                                          float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2,
+                                          const float* image_ref, const float* image, const float* jitter_ref,
+                                          const float* jitter, int jitter_channels, void* workspace, int64_t workspace_bytes,
+                                          float* sums, float* loss_fwd, float* loss_bwd, int batch_size, int image_size,
+                                          int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
+                                          const void* list_header, const void* list_entries, int64_t list_capacity,
+                                          int64_t tile_bound, mr_stream_t stream) {
+    return flow_pair_forward_tiles(mask_flow1, mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2,
+                                   flow_out12, flow_out21, tile_hit1, tile_hit2, image_ref, image, jitter_ref, jitter,
+                                   jitter_channels, workspace, workspace_bytes, sums, loss_fwd, loss_bwd, batch_size, image_size,
+                                   height, width, distance_thresh, warp_thresh, pair_thresh, list_header, list_entries,
+                                   list_capacity, tile_bound, nullptr, nullptr, stream);
+}
+
+extern "C" int mr_flow_pair_forward_grad_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                                               const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                                               const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
+                                               float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2,
+                                               const float* image_ref, const float* image, const float* jitter_ref,
+                                               const float* jitter, int jitter_channels, void* workspace,
+                                               int64_t workspace_bytes, float* sums, float* loss_fwd, float* loss_bwd,
+                                               int batch_size, int image_size, int height, int width, float distance_thresh,
+                                               float warp_thresh, float pair_thresh, const void* list_header,
+                                               const void* list_entries, int64_t list_capacity, int64_t tile_bound,
+                                               float* unit_grad, float* unit_grad_max, mr_stream_t stream) {
+    if (!unit_grad || !unit_grad_max) return MR_ERR_BADARG;
+    return flow_pair_forward_tiles(mask_flow1, mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2,
+                                   flow_out12, flow_out21, tile_hit1, tile_hit2, image_ref, image, jitter_ref, jitter,
+                                   jitter_channels, workspace, workspace_bytes, sums, loss_fwd, loss_bwd, batch_size, image_size,
+                                   height, width, distance_thresh, warp_thresh, pair_thresh, list_header, list_entries,
+                                   list_capacity, tile_bound, unit_grad, unit_grad_max, stream);
 }

@@ -497,6 +497,11 @@ class _StackedFlowFunction(torch.autograd.Function):
 # (mr_flow_pair_backward_tiles: the flow gradient never exists as a tensor).  False: get_opticalflow -> pair_consist, the
 # same kernels' arithmetic in five launches (same losses bit for bit, gradients to fp32 rounding).
 USE_FUSED_PAIR_NODE = True
+# ... with the pair loss's gradient formed by the forward launch, where its taps and masks already sit in registers
+# (mr_flow_pair_forward_grad_tiles: 8 B per covered pixel more to write), the backward launch being the scatter alone on
+# (that gradient) x (grad_loss / count) (mr_flow_pair_backward_unit_tiles): no image, mask or flow is read twice.
+# False: mr_flow_pair_forward_tiles + mr_flow_pair_backward_tiles (the backward recomputes the taps).
+USE_UNIT_GRADIENT = True
 
 
 class _FlowPairLossFunction(torch.autograd.Function):
@@ -528,26 +533,36 @@ class _FlowPairLossFunction(torch.autograd.Function):
         wbytes = int(_lib.load().mr_pair_consist_tiles_workspace_bytes(B, is_))
         work = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
         sums, loss_fwd, loss_bwd = torch.empty((B, 4), **f32), torch.empty((B,), **f32), torch.empty((B,), **f32)
-        _lib.call("mr_flow_pair_forward_tiles", _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(rgb[:B]), _lib.ptr(rgb[B:]),
-                  3 * is_ * is_, _lib.ptr(mask[:B]), _lib.ptr(mask[B:]), _lib.ptr(occl[:B]), _lib.ptr(occl[B:]),
-                  _lib.ptr(flow[:B]), _lib.ptr(flow[B:]), _lib.ptr(tile_hit[:B]), _lib.ptr(tile_hit[B:]), _lib.ptr(im_ref),
-                  _lib.ptr(im), _lib.ptr(jm_ref), _lib.ptr(jm), Cj, _lib.ptr(work), wbytes, _lib.ptr(sums), _lib.ptr(loss_fwd),
-                  _lib.ptr(loss_bwd), B, is_, height, width, 0.03, 0.99999, float(thresh), where[0], where[1], where[2],
-                  int(r["bound"]), st)
+        unit = ctx.needs_input_grad[2] and USE_UNIT_GRADIENT
+        args = (_lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(rgb[:B]), _lib.ptr(rgb[B:]),
+                3 * is_ * is_, _lib.ptr(mask[:B]), _lib.ptr(mask[B:]), _lib.ptr(occl[:B]), _lib.ptr(occl[B:]),
+                _lib.ptr(flow[:B]), _lib.ptr(flow[B:]), _lib.ptr(tile_hit[:B]), _lib.ptr(tile_hit[B:]), _lib.ptr(im_ref),
+                _lib.ptr(im), _lib.ptr(jm_ref), _lib.ptr(jm), Cj, _lib.ptr(work), wbytes, _lib.ptr(sums), _lib.ptr(loss_fwd),
+                _lib.ptr(loss_bwd), B, is_, height, width, 0.03, 0.99999, float(thresh), where[0], where[1], where[2],
+                int(r["bound"]))
+        if unit:
+            unit_grad, unit_max = new_f(B2, height, width, 2), torch.empty((B2,), **f32)
+            _lib.call("mr_flow_pair_forward_grad_tiles", *args, _lib.ptr(unit_grad), _lib.ptr(unit_max), st)
+        else:
+            _lib.call("mr_flow_pair_forward_tiles", *args, st)
         # (the flows are defined under the covered tiles only: the list rides along with them, as for get_opticalflow(sparse_flows=True))
         _FlowPairLossFunction.last_tiles = (where[0], where[1], where[2], int(r["bound"]), r["work"])
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width, float(thresh), int(r["F0"]), int(r["V"]))
-        ctx.save_for_backward(r["fim"], tile_hit, r["wmap"], r["vid"], mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums)
+        ctx.unit = unit
+        if unit:
+            ctx.save_for_backward(r["fim"], tile_hit, r["wmap"], r["vid"], unit_grad, unit_max, sums)
+        else:
+            ctx.save_for_backward(r["fim"], tile_hit, r["wmap"], r["vid"], mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums)
         ctx.grad_buf = r["grad_buf"]
         ctx.mark_non_differentiable(flow, tile_hit)
         return loss_fwd, loss_bwd, flow, tile_hit
 
     @staticmethod
     def backward(ctx, g_fwd, g_bwd, _g_flow=None, _g_hit=None):
-        fim, tile_hit, wmap, vid, mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums = ctx.saved_tensors
         is_, eps, fill_back, height, width, thresh, F0, V = ctx.cfg
         if not ctx.needs_input_grad[2] or (g_fwd is None and g_bwd is None):
             return (None,) * 17
+        fim = ctx.saved_tensors[0]
         B2 = fim.shape[0]
         B, dev = B2 // 2, fim.device
         if g_fwd is None:
@@ -557,6 +572,14 @@ class _FlowPairLossFunction(torch.autograd.Function):
         zeroed = grad_cols is not None
         if not zeroed:
             grad_cols = torch.empty((B2, V, 3), dtype=torch.float32, device=dev)
+        if ctx.unit:
+            fim, tile_hit, wmap, vid, unit_grad, unit_max, sums = ctx.saved_tensors
+            _lib.call("mr_flow_pair_backward_unit_tiles", _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(wmap), _lib.ptr(vid),
+                      _lib.ptr(unit_grad), _lib.ptr(unit_max), _lib.ptr(sums), _lib.ptr(g_fwd), _lib.ptr(g_bwd), height, width,
+                      _lib.ptr(grad_cols), B2, V, F0, int(fill_back), is_, eps, _lib.FLAG_OUTPUT_ZEROED if zeroed else 0,
+                      textutils.texel_layout_code(), _lib.stream_ptr(dev))
+            return (None, None, grad_cols) + (None,) * 14
+        fim, tile_hit, wmap, vid, mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums = ctx.saved_tensors
         # scratch of the launch: the masked flow gradient of a workgroup's tiles between its two passes
         scratch = (torch.full((B2, height, width, 2), float("nan"), dtype=torch.float32, device=dev) if DEBUG_POISON_RENDER_OUTPUTS
                    else torch.empty((B2, height, width, 2), dtype=torch.float32, device=dev))

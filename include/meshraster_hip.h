@@ -71,7 +71,7 @@ typedef void* mr_stream_t;
  * 4: mr_render_tile_list, mr_occlusion_flow_tiles, mr_pair_consist_{forward,backward}_tiles, mr_pair_consist_tiles_workspace_bytes
  *    (the warp half of the training path over the render's tile list: the sparse contract, round 4),
  *    mr_flow_pair_{forward,backward}_tiles (the same fused into one forward and one backward launch). */
-#define MR_ABI_VERSION 4
+#define MR_ABI_VERSION 5
 MR_API int mr_abi_version(void);
 /* 1 if the calling thread's CURRENT HIP device is a gfx950, else 0.
  * Device contract of every entry point below: kernels are launched on the calling thread's current HIP
@@ -570,6 +570,38 @@ MR_API int mr_flow_pair_backward_tiles(const int32_t* face_index_map, const uint
                                        int width, float* grad_vcolors, int batch_size, int num_verts, int num_faces,
                                        int fill_back, int image_size, float eps, float pair_thresh, int flags,
                                        int texel_layout, mr_stream_t stream);
+
+/* The same pair with the pair loss's gradient formed where its inputs already sit in registers -- in the FORWARD launch
+ * (round 4, ABI 5): the training path of opticalflow.flow_pair_loss when the vertices want a gradient.
+ * mr_flow_pair_forward_grad_tiles = mr_flow_pair_forward_tiles (same arguments, same outputs bit for bit) + two outputs:
+ *   unit_grad [2B,height,width,2]: per pixel of a covered tile, d(sum of |residuals| of its direction) / d(final flow)
+ *     -- mr_pair_consist_backward_tiles' gradient for a coefficient grad_loss / count of 1 -- times the epilogue's factors
+ *     ((g * (mask_x * occl)) * mask_pre, as mr_render_flow_backward applies them): the gradient w.r.t. the RENDERED
+ *     displacement planes up to one scalar per image (sparse contract: untouched under uncovered tiles);
+ *   unit_grad_max [2B]: largest |component| of unit_grad per stack image (float; NaN / Inf propagate as such).
+ *   workspace: mr_pair_consist_tiles_workspace_bytes(B, image_size) as for the plain call.
+ * mr_flow_pair_backward_unit_tiles = the scatter half of mr_flow_pair_backward_tiles on that gradient: every covered pixel's
+ *   unit_grad x (grad_loss_{fwd,bwd}[b] / count of the image's direction, from sums) goes to the vertex colours behind its
+ *   three sampling weights (per-pixel records of mr_render_flow_forward); no image, mask or flow is read again.  The
+ *   fixed-point scale of the per-workgroup sums is unit_grad_max[b] x |coefficient| (an upper bound, rounding is monotone).
+ *   A zero coefficient leaves the image's rows zero whatever unit_grad holds.  flags: MR_FLAG_OUTPUT_ZEROED.
+ * Results equal mr_flow_pair_backward_tiles' up to fp32 rounding (the coefficient multiplies last instead of first). */
+MR_API int mr_flow_pair_forward_grad_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
+                                           const float* flow21, int64_t flow_bstride, const float* flow12_scale,
+                                           const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
+                                           float* flow_out21, const uint8_t* tile_hit1, const uint8_t* tile_hit2,
+                                           const float* image_ref, const float* image, const float* jitter_ref,
+                                           const float* jitter, int jitter_channels, void* workspace, int64_t workspace_bytes,
+                                           float* sums, float* loss_fwd, float* loss_bwd, int batch_size, int image_size,
+                                           int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
+                                           const void* list_header, const void* list_entries, int64_t list_capacity,
+                                           int64_t tile_bound, float* unit_grad, float* unit_grad_max, mr_stream_t stream);
+MR_API int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, const uint32_t* tile_hit, const float* weight_map,
+                                            const int32_t* vertex_id_map, const float* unit_grad, const float* unit_grad_max,
+                                            const float* sums, const float* grad_loss_fwd, const float* grad_loss_bwd,
+                                            int height, int width, float* grad_vcolors, int batch_size, int num_verts,
+                                            int num_faces, int fill_back, int image_size, float eps, int flags,
+                                            int texel_layout, mr_stream_t stream);
 
 /* ---- dataset pipeline: decoded frames -> network-input batch ------------------------------
  * One launch for a whole batch of what meshreg/datasets/handobjset.py:361-379 does per sample on the

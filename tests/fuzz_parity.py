@@ -467,3 +467,75 @@ for case in range(min(n_cases, 200)):
         bad7 += 1
         print(f"seed {seed} N={N} src {Hs}x{Ws} -> {Ho}x{Wo}: mismatch")
 print(f"sweep 7 (frames -> batch): {min(n_cases, 200)} cases, {bad7} with mismatches")
+
+# ---- eighth sweep: the pair as ONE fused node (opticalflow.flow_pair_loss: the path training takes since round 4) against
+# ---- the CPU oracle (flows, both loss terms) and against the composed get_opticalflow + pair_consist path (vertex
+# ---- gradient), whole meshes and (hand, object) parts, random raster sizes / crops / jitter borders / loss weights
+bad8, skipped8 = 0, 0
+for case in range(min(n_cases, 300)):
+    seed = seed0 + 700000 + case
+    rng = np.random.default_rng(seed)
+    B, is_ = int(rng.integers(1, 5)), 4 * int(rng.integers(6, 56))  # (the node's backward reads pixel quads: rasters of 4 k pixels)
+    H, Wd = (is_, is_) if rng.random() < 0.3 else (int(rng.integers(8, is_ + 1)), int(rng.integers(8, is_ + 1)))
+    s = synth.random_scene(B, seed=seed, image_size=is_)
+    if rng.random() < 0.2:  # a frame far off to the side / nothing rendered in one of the frames
+        s["verts2"] = s["verts2"] + np.float32(rng.choice([0.3, 3.0]))
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=dev)[None], t=torch.zeros(1, 3, device=dev), K=torch.ones(1, 3, 3, device=dev),
+                   orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1, no_light=True)
+    im_ref, im, jm_ref, jm = synth.random_images(B, H, Wd, seed)
+    if rng.random() < 0.3: jm_ref, jm = jm_ref[:, :1], jm[:, :1]  # one-channel jitter masks
+    gl = rng.standard_normal((2, B)).astype(np.float32)
+    if rng.random() < 0.2: gl[1] = 0  # no gradient through the backward term
+    msg = []
+    v1 = t(s["verts1"]).requires_grad_(True)
+    flows = opticalflow.get_opticalflow([v1, t(s["verts2"])], t(s["faces"]), [t(s["K1"]), t(s["K2"])], ren, orig_img_size=(Wd, H),
+                                        ignore_face_idxs=synth.HAND_IGNORE_FACES)
+    lc = imgflowarp.pair_consist(flows, t(im_ref), t(im), t(jm_ref), t(jm), PyramidCriterion("l1"), use_backward=True, outputs="loss")
+    # (pair_consist's loss = forward + backward term; the node returns them separately: compare through two weightings)
+    parts = bool(rng.random() < 0.5)
+    if parts:
+        nh = 778
+        h1, o1 = t(s["verts1"][:, :nh]).requires_grad_(True), t(s["verts1"][:, nh:]).requires_grad_(True)
+        vf = [(h1, o1), (t(s["verts2"][:, :nh]), t(s["verts2"][:, nh:]))]
+        fh = s["faces"][0, :1552]
+        assert (s["faces"][:, :1552] == fh).all() and s["faces"][:, 1552:].min() >= nh
+        ff = (t(fh), t(s["faces"][:, 1552:] - nh))
+    else:
+        v1f = t(s["verts1"]).requires_grad_(True)
+        vf, ff = [v1f, t(s["verts2"])], t(s["faces"])
+    fused = opticalflow.flow_pair_loss(vf, ff, [t(s["K1"]), t(s["K2"])], ren, (Wd, H), t(im_ref), t(im), t(jm_ref), t(jm),
+                                       ignore_face_idxs=synth.HAND_IGNORE_FACES)
+    if fused is None:
+        skipped8 += 1
+        continue
+    kw8 = dict(KW, orig_size=is_, image_size=is_, anti_aliasing=False, near=0.1, far=100, eps=1e-3)
+    ref_flows = W.get_opticalflow(R, [s["verts1"], s["verts2"]], s["faces"], [s["K1"], s["K2"]], kw8, orig_img_size=(Wd, H),
+                                  ignore_face_idxs=synth.HAND_IGNORE_FACES)
+    ref_fwd = W.pair_consist(ref_flows, im_ref, im, jm_ref, jm, False)[0]
+    ref_both = W.pair_consist(ref_flows, im_ref, im, jm_ref, jm, True)[0]
+    lf, lb = fused[0].detach().cpu().numpy(), fused[1].detach().cpu().numpy()
+    for got, want, name in ((lf, ref_fwd, "loss_fwd"), (lf + lb, ref_both, "loss_fwd + loss_bwd")):
+        e = np.abs(got - want).max()
+        if e > 2e-5 * max(1.0, np.abs(want).max()): msg.append(f"{name} vs ORACLE err {e:.2e}")
+    # the node's flows: defined under covered tiles, equal to the oracle's there; the oracle's flow is zero elsewhere
+    tiles = getattr(fused[2][0], "_hoc_coverage", None)
+    for i in (0, 1):
+        a, r_ = fused[2][i].detach().cpu().numpy(), ref_flows[i]
+        cov = r_[..., 0] != 0
+        e = float(np.abs(a - r_)[cov].max()) if cov.any() else 0.0
+        if e > 1e-4 * max(float(np.abs(r_).max()), 1.0): msg.append(f"flow{i} under the render vs ORACLE err {e:.2e}")
+    # gradient: (gl[0] . loss_fwd + gl[1] . loss_bwd) -- the composed path needs the two terms apart
+    l_fwd_c = imgflowarp.pair_consist(flows, t(im_ref), t(im), t(jm_ref), t(jm), PyramidCriterion("l1"), use_backward=False, outputs="loss")[0]
+    l_bwd_c = lc[0] - l_fwd_c
+    ((l_fwd_c * t(gl[0])).sum() + (l_bwd_c * t(gl[1])).sum()).backward()
+    ((fused[0] * t(gl[0])).sum() + (fused[1] * t(gl[1])).sum()).backward()
+    gc = v1.grad
+    gf = torch.cat([h1.grad, o1.grad], 1) if parts else v1f.grad
+    if not torch.isfinite(gf).all(): msg.append("vertex gradient non-finite")
+    e, sc = float((gf - gc).abs().max()), float(gc.abs().max())
+    if e > 2e-4 * sc + 1e-12: msg.append(f"vertex gradient vs composed path err {e:.2e} (scale {sc:.2e})")
+    if msg:
+        bad8 += 1
+        print(f"seed {seed} B={B} is={is_} crop {H}x{Wd} parts={parts}: " + "; ".join(msg))
+print(f"sweep 8 (fused pair node vs oracle / composed path): {min(n_cases, 300)} cases, {skipped8} not applicable, {bad8} with mismatches")
+sys.exit(1 if (bad or bad2 or bad3 or bad4 or bad5 or bad6 or bad7 or bad8) else 0)

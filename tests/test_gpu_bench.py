@@ -44,13 +44,14 @@ def test_bench_single_process_line(cuda):
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert abs(roof["achieved"] - roof["bytes"] / (roof["launch_ms"] * 1e-3) / 1e9) <= 0.02 * roof["achieved"]
-    # the raster backward as the step launches it: the pair loss's backward + epilogue adjoint + scatter in one kernel
-    assert roof["device_kernels"] == ["pair_scatter_tiles_kernel"] and 0 < roof["frac_cache_warm"]
+    # the raster backward as the step launches it: the scatter of the unit gradient the step's forward launch left
+    assert roof["device_kernels"] == ["unit_scatter_tiles_kernel"] and 0 < roof["frac_cache_warm"]
+    assert roof["recomputing_form"]["device_kernels"] == ["pair_scatter_tiles_kernel"] and 0 < roof["recomputing_form"]["frac"] < 1
     assert roof["scatter_alone"]["device_kernels"] == ["scatter_tiles_kernel<true, true>"] and 0 < roof["scatter_alone"]["frac"] < 1
     assert roof["in_step_us"] > 0 and abs(roof["frac_in_step"] - roof["bytes"] / (roof["in_step_us"] * 1e-6) / 1e9 / roof["peak"]) < 1e-3
     for name, w in line["warp_tiles"].items():
         assert 0 < w["frac"] < 1 and w["launch_ms"] > 0, name
-    assert line["warp_tiles"]["flow_pair_forward_tiles(train: occlusion + epilogue + pair loss, sparse)"]["in_step_us"] > 0
+    assert line["warp_tiles"]["flow_pair_forward_grad_tiles(train: occlusion + epilogue + pair loss + unit gradient, sparse)"]["in_step_us"] > 0
     # the backward's fraction is on its own compulsory traffic (covered tiles), below 1 by construction; the SURVEY 8(d)
     # figure rides along
     assert 0 < roof["frac"] < 1 and roof["bytes"] < roof["algorithmic_bytes"] and roof["frac_algorithmic"] > roof["frac"]

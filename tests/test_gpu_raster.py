@@ -39,7 +39,8 @@ def big_faces(B, image_size, seed, n=24):
 
 
 def t(a, dev):
-    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # (a copy, not ascontiguousarray: a reversed axis of length 1 counts as contiguous and keeps its negative stride)
+    return torch.from_numpy(np.array(a, copy=True, order="C")).to(dev)
 
 
 def assert_close(a, b, rtol, atol, what):
@@ -236,6 +237,25 @@ def test_fused_backward_few_faces(cuda, n):
     assert np.abs(gf_ref).max() > 0
     assert_close(x_t.grad.cpu().numpy(), gt_ref, 1e-4, 1e-5 * np.abs(gt_ref).max(), "grad_textures")
     assert_close(f_t.grad.cpu().numpy(), gf_ref, 1e-4, 1e-5 * np.abs(gf_ref).max(), "grad_faces")
+
+
+@pytest.mark.parametrize("is_", [1, 2, 3, 5, 8])
+def test_fused_backward_on_rasters_of_a_few_pixels(cuda, is_):
+    """Kernel D's strip bookkeeping (2 B is / L weight words, cleared by the marking pass) has more words than the image has
+    pixel quads at 1 x 1 and 2 x 2 pixels: the call refused such rasters ("bad argument"; found by tests/fuzz_parity.py)."""
+    from handobjectconsist_amd.neurender import rasterize
+
+    faces, tex = big_faces(3, is_, 70 + is_, n=6)
+    ref = R.rasterize_rgbad(faces, tex, is_, False, 0.1, 100, 1e-3, (0.1, 0.2, 0.3), num_threads=8, keep_saved=True)
+    saved = ref["_saved"]
+    raster_g, img_g = _img_grads(saved, is_)
+    gf_ref, gt_ref = R.rasterize_backward(saved, *raster_g, num_threads=8)
+    f_t, x_t = t(faces, cuda).requires_grad_(True), t(tex, cuda).requires_grad_(True)
+    out = rasterize.rasterize_rgbad(f_t, x_t, is_, False, 0.1, 100, 1e-3, (0.1, 0.2, 0.3))
+    assert (out["face_index_map"].cpu().numpy() == ref["face_index_map"]).all()
+    torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]], [t(g, cuda) for g in img_g])
+    assert_close(x_t.grad.cpu().numpy(), gt_ref, 1e-4, 1e-5 * max(np.abs(gt_ref).max(), 1e-30), "grad_textures")
+    assert_close(f_t.grad.cpu().numpy(), gf_ref, 2e-4, 1e-5 * max(np.abs(gf_ref).max(), 1e-30), "grad_faces")
 
 
 @pytest.mark.parametrize("B,is_,sparse", [(2, 64, False), (3, 96, True), (2, 256, True)])
