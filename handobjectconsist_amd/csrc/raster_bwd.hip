@@ -1841,7 +1841,7 @@ __global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p,
                         for (int it0 = 0; it0 < ((p.dbg & 8) ? 0 : CH); it0 += 2 * PG) {
                             request(y, it0 + PG);
                             work(x);
-                            if (it0 + 2 * PG < CH) request(x, it0 + 2 * PG);
+                            request(x, it0 + 2 * PG);  // (behind the last step: positions wrap inside the chunk, the values are not used)
                             work(y);
                         }
                     } else {
@@ -1868,7 +1868,7 @@ __global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p,
                         for (int it0 = 0; it0 < ((p.dbg & 8) ? 0 : CH); it0 += 2 * PG) {
                             request(y, it0 + PG);
                             work(x);
-                            if (it0 + 2 * PG < CH) request(x, it0 + 2 * PG);
+                            request(x, it0 + 2 * PG);  // (behind the last step: positions wrap inside the chunk, the values are not used)
                             work(y);
                         }
                     }

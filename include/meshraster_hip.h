@@ -70,7 +70,9 @@ typedef void* mr_stream_t;
  *    vertex-colour entry points;
  * 4: mr_render_tile_list, mr_occlusion_flow_tiles, mr_pair_consist_{forward,backward}_tiles, mr_pair_consist_tiles_workspace_bytes
  *    (the warp half of the training path over the render's tile list: the sparse contract, round 4),
- *    mr_flow_pair_{forward,backward}_tiles (the same fused into one forward and one backward launch). */
+ *    mr_flow_pair_{forward,backward}_tiles (the same fused into one forward and one backward launch);
+ * 5: mr_flow_pair_forward_grad_tiles / mr_flow_pair_backward_unit_tiles (the pair loss's gradient formed by the forward
+ *    launch); mr_pair_consist_tiles_workspace_bytes grows to three words per tile. */
 #define MR_ABI_VERSION 5
 MR_API int mr_abi_version(void);
 /* 1 if the calling thread's CURRENT HIP device is a gfx950, else 0.

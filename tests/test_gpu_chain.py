@@ -411,10 +411,13 @@ def test_flow_finalize_backward_against_reference_glue(cuda):
 # ---------------------------------------------------------------------------------------------------
 
 
+@pytest.mark.parametrize("mode", ["full", "loss"])
 @pytest.mark.parametrize("keys", ["enum", "string"])
-def test_warpbranch_forward_against_reference_glue(cuda, keys):
+def test_warpbranch_forward_against_reference_glue(cuda, keys, mode):
     """warpbranch.forward (warpbranch.py:9-96): GT-reference substitution, detach of frames > 0
-    (first_only), per-pair pair_consist, stack().mean(), and d loss / d predicted vertices of every frame."""
+    (first_only), per-pair pair_consist, stack().mean(), and d loss / d predicted vertices of every frame.
+    ``mode`` "loss" = the trainer's setting (pair_outputs="loss": fused pair nodes, flows defined under their renders only,
+    no per-pixel outputs): same losses and gradients as the reference's run."""
     from handobjectconsist_amd.datasets.queries import BaseQueries as BQ
     from handobjectconsist_amd.datasets.queries import TransQueries as TQ
     from handobjectconsist_amd.models import warpbranch
@@ -437,11 +440,17 @@ def test_warpbranch_forward_against_reference_glue(cuda, keys):
         loss, pair = warpbranch.forward(
             samples, results, t(z["hand_face"], cuda)[None], _training_renderer(is_, cuda), crop,
             PyramidCriterion("l1"), gt_refs=m["gt_refs"], first_only=m["first_only"],
-            hand_ignore_faces=m["hand_ignore_faces"], use_backward=m["use_backward"])
+            hand_ignore_faces=m["hand_ignore_faces"], use_backward=m["use_backward"], pair_outputs=mode)
         loss.backward()
         sup = 0
         for p in range(m["frames"] - 1):
             for d in (0, 1):
+                if mode == "loss":  # flows: wherever the reference's are non-zero (unspecified memory elsewhere)
+                    got, want = n(pair["recons_flows"][p][d]), z[f"{k}_p{p}_flow{d}"]
+                    on = want[..., 0] != 0
+                    assert on.sum() > 20 and np.abs(got[on] - want[on]).max() < 5e-3, (k, p, d, np.abs(got[on] - want[on]).max())
+                    assert np.median(np.abs(got[on] - want[on])) < 1e-5, (k, p, d)
+                    continue
                 sup += _flow_check(n(pair["recons_flows"][p][d]), z[f"{k}_p{p}_flow{d}"], (k, p, d))
                 assert sup == 0, (k, p, d, "the training path must reproduce the support of the reference's flows")
                 fm = n(pair["masks"][p][d]["full_mask"]).astype(bool)

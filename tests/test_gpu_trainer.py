@@ -137,6 +137,53 @@ def test_metric_workload_warpbranch_against_reference_glue(cuda):
         assert results[1][name].grad is None, "the annotated frame must not receive a gradient"
 
 
+@pytest.mark.parametrize("unit", [True, False])
+def test_metric_workload_training_mode_against_the_reference(cuda, monkeypatch, unit):
+    """The same reference run against warpbranch.forward AS THE TRAINER CALLS IT (pair_outputs="loss"): the pair is one
+    fused node (opticalflow.flow_pair_loss) -- with the pair loss's gradient formed by the forward launch (``unit``, what
+    training runs) or recomputed by the backward launch -- on NaN-poisoned buffers.  Loss, per-sample pair losses and
+    d loss / d predicted vertices of frame 0 are the reference's; the flows are, wherever the reference's are non-zero."""
+    from handobjectconsist_amd import _lib
+    from handobjectconsist_amd.models import warpbranch
+    from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import opticalflow
+
+    z, m = load("chain_metric.npz")
+    B, is_ = m["batch"], m["image_size"]
+    s, images, jitters = _metric_scene(z, m)
+    monkeypatch.setattr(opticalflow, "USE_UNIT_GRADIENT", unit)
+    monkeypatch.setattr(opticalflow, "DEBUG_POISON_RENDER_OUTPUTS", True)
+    calls = []
+    real_call = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), real_call(name, *a))[1])
+    samples, results = [], []
+    for k in (0, 1):
+        f = "12"[k]
+        samples.append({"image": t(images[k], cuda), "jittermask": t(jitters[k], cuda), "camintr": t(s["K" + f], cuda),
+                        "objfaces": t(s["obj_faces"][None].repeat(B, 0), cuda), "objverts3d": t(s["obj_verts" + f], cuda),
+                        "handverts3d": t(s["hand_verts" + f], cuda)})
+    results.append({"recov_handverts3d": t(s["hand_verts1"], cuda, True), "recov_objverts3d": t(s["obj_verts1"], cuda, True)})
+    results.append({"recov_handverts3d": t(z["pred1_hand"], cuda, True), "recov_objverts3d": t(z["pred1_obj"], cuda, True)})
+    loss, pair = warpbranch.forward(samples, results, t(s["hand_faces"], cuda)[None], _renderer(is_, cuda), (is_, is_),
+                                    PyramidCriterion("l1"), gt_refs=True, first_only=True,
+                                    hand_ignore_faces=m["hand_ignore_faces"], use_backward=True, pair_outputs="loss")
+    loss.backward()
+    fwd, bwd = (("mr_flow_pair_forward_grad_tiles", "mr_flow_pair_backward_unit_tiles") if unit
+                else ("mr_flow_pair_forward_tiles", "mr_flow_pair_backward_tiles"))
+    assert fwd in calls and bwd in calls, "the trainer's setting must take the fused pair node"
+    assert all(x is None for x in pair["masks"]) and all(x is None for x in pair["warps"])  # nothing per-pixel in this mode
+    for d in (0, 1):
+        got = n(pair["recons_flows"][0][d]).reshape(-1, 2)
+        idx, want = z[f"wb_flow{d}_idx"], z[f"wb_flow{d}_sample"]
+        on = want[:, 0] != 0  # (defined under the covered tiles only; the reference's flow is zero elsewhere)
+        assert on.any() and np.abs(got[idx][on] - want[on]).max() <= 1e-6 * max(np.abs(want).max(), 1.0), ("flow", d)
+    assert norm_rel(n(pair["diff_losses"]), z["wb_diff_losses"]) < 1e-5
+    assert abs(float(loss) - float(z["wb_loss"])) < 1e-5 * abs(float(z["wb_loss"]))
+    for name, key in (("recov_handverts3d", "wb_grad_hand0"), ("recov_objverts3d", "wb_grad_obj0")):
+        assert norm_rel(n(results[0][name].grad), z[key]) < 1e-4, (key, norm_rel(n(results[0][name].grad), z[key]))
+        assert results[1][name].grad is None, "the annotated frame must not receive a gradient"
+
+
 # ---------------------------------------------------------------------------------------------------
 # WarpRegNet.forward and epoch_pass
 # ---------------------------------------------------------------------------------------------------
