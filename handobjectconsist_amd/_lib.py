@@ -44,6 +44,7 @@ SIGNATURES = {
     "mr_flow_vertices_parts_forward": (_I, [_P] * 4 + [_I, _I] + [_P] * 5 + [_I, _F] + [_P] * 4 + [_I, _P]),
     "mr_flow_vertices_parts_backward": (_I, [_P] * 4 + [_I, _I] + [_P] * 8 + [_I, _P]),
     "mr_stack_pair_faces": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    "mr_flow_pair_prologue_parts": (_I, [_P] * 4 + [_I, _I] + [_P] * 5 + [_I, _F] + [_P] * 5 + [_I, _P, _P, _I, _I, _I, _P]),
     "mr_mano_workspace_floats": (_L, [_I]),
     "mr_mano_forward": (_I, [_P] * 12 + [_I, _I] + [_P] * 3 + [_I, _P]),
     "mr_mano_backward": (_I, [_P] * 10 + [_I, _I] + [_P] * 5 + [_I, _P]),
@@ -66,7 +67,7 @@ SIGNATURES = {
     "mr_pair_consist_backward_tiles": (_I, [_P] * 6 + [_I] + [_P] * 5 + [_I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _L, _L, _P]),
     "mr_flow_pair_forward_tiles": (_I, [_P] * 4 + [_L] + [_P] * 12 + [_I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _L, _L, _P]),
     "mr_flow_pair_backward_tiles": (_I, [_P] * 9 + [_I] + [_P] * 8 + [_I, _I, _P, _I, _I, _I, _I, _I, _F, _F, _I, _I, _P]),
-    "mr_flow_pair_forward_grad_tiles": (_I, [_P] * 4 + [_L] + [_P] * 12 + [_I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _L, _L, _P, _P, _P]),
+    "mr_flow_pair_forward_grad_tiles": (_I, [_P] * 4 + [_L] + [_P] * 12 + [_I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _L, _L, _P, _P, _P, _P]),
     "mr_flow_pair_backward_unit_tiles": (_I, [_P] * 9 + [_I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "mr_frames_to_batch_workspace_bytes": (_L, [_I, _I, _I]),
     "mr_frames_to_batch": (_I, [_P] * 3 + [_F] * 6 + [_P, _L, _P, _P] + [_I] * 6 + [_P]),

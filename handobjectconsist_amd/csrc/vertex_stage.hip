@@ -69,9 +69,9 @@ __device__ __forceinline__ void ndc_project(const float* K, const float* R, cons
     out[2] = z;
 }
 
-__global__ void __launch_bounds__(256) flow_vertices_forward_kernel(VertexStageParams p) {
+__device__ __forceinline__ void flow_vertices_forward_body(const VertexStageParams& p, int bx) {
     const int b = blockIdx.y;
-    const int vi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int vi = bx * blockDim.x + threadIdx.x;
     if (vi >= p.V) return;
     float K1[9], K2[9], R[9], t[3], d[5];
 #pragma unroll
@@ -102,6 +102,8 @@ __global__ void __launch_bounds__(256) flow_vertices_forward_kernel(VertexStageP
     ndc_project(K2, R, t, d, p.orig_size, v2, n);
     p.ndc2[o] = n[0]; p.ndc2[o + 1] = n[1]; p.ndc2[o + 2] = n[2];
 }
+
+__global__ void __launch_bounds__(256) flow_vertices_forward_kernel(VertexStageParams p) { flow_vertices_forward_body(p, blockIdx.x); }
 
 // adjoint of (verts1, verts2) -> (cols12, cols21); grad_verts* may be NULL
 // (two-part meshes: verts*b / grad_verts*b hold the vertices from `split` on; a NULL gradient pointer = not wanted)
@@ -149,17 +151,31 @@ __global__ void __launch_bounds__(256) flow_vertices_backward_kernel(const float
 // faces of the concatenated hand + object mesh of a frame pair, as the stacked render takes them: int32 [2B, Fh + Fo, 3],
 // rows [0, B) and [B, 2B) identical (both frames of a pair share the faces, warpbranch.py:49-55), object indices offset
 // by the hand's vertex count -- hand_face.repeat + (obj_faces + Vh) + cat + cat + dtype conversion in one pass
-__global__ void __launch_bounds__(256) stack_pair_faces_kernel(const int64_t* __restrict__ hand_faces, int64_t hand_bstride,
-                                                               const int64_t* __restrict__ obj_faces, int offset,
-                                                               int32_t* __restrict__ out, int B, int Fh, int Fo) {
+struct StackFacesParams {
+    const int64_t* hand_faces;
+    int64_t hand_bstride;
+    const int64_t* obj_faces;
+    int offset;
+    int32_t* out;
+    int B, Fh, Fo;
+};
+__device__ __forceinline__ void stack_pair_faces_body(const StackFacesParams& q, int bx) {
     const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = (Fh + Fo) * 3;
+    const int i = bx * blockDim.x + threadIdx.x;
+    const int n = (q.Fh + q.Fo) * 3;
     if (i >= n) return;
-    const int f3h = Fh * 3;
-    const int64_t v = i < f3h ? hand_faces[(int64_t)b * hand_bstride + i] : obj_faces[(int64_t)b * Fo * 3 + (i - f3h)] + offset;
-    out[(int64_t)b * n + i] = (int32_t)v;
-    out[((int64_t)B + b) * n + i] = (int32_t)v;
+    const int f3h = q.Fh * 3;
+    const int64_t v = i < f3h ? q.hand_faces[(int64_t)b * q.hand_bstride + i] : q.obj_faces[(int64_t)b * q.Fo * 3 + (i - f3h)] + q.offset;
+    q.out[(int64_t)b * n + i] = (int32_t)v;
+    q.out[((int64_t)q.B + b) * n + i] = (int32_t)v;
+}
+__global__ void __launch_bounds__(256) stack_pair_faces_kernel(StackFacesParams q) { stack_pair_faces_body(q, blockIdx.x); }
+
+// both set-up steps of a frame pair in ONE launch (mr_flow_pair_prologue_parts): the first `vertex_blocks` workgroups of a
+// row project vertices, the others stack faces -- the two do not depend on each other
+__global__ void __launch_bounds__(256) pair_prologue_kernel(VertexStageParams p, StackFacesParams q, int vertex_blocks) {
+    if ((int)blockIdx.x < vertex_blocks) flow_vertices_forward_body(p, blockIdx.x);
+    else stack_pair_faces_body(q, (int)blockIdx.x - vertex_blocks);
 }
 
 }  // namespace mr
@@ -243,9 +259,37 @@ extern "C" int mr_stack_pair_faces(const int64_t* hand_faces, int hand_batched, 
     if (batch_size == 0 || n == 0) return MR_OK;
     if (!faces_out || (!hand_faces && num_hand_faces > 0) || (!obj_faces && num_obj_faces > 0)) return MR_ERR_BADARG;
     if (batch_size > 65535) return MR_ERR_BADARG;
+    const StackFacesParams q{hand_faces, hand_batched ? (int64_t)num_hand_faces * 3 : (int64_t)0, obj_faces, vertex_offset, faces_out,
+                             batch_size, num_hand_faces, num_obj_faces};
     hipLaunchKernelGGL(stack_pair_faces_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)batch_size), dim3(256), 0,
-                       (hipStream_t)stream, hand_faces, hand_batched ? (int64_t)num_hand_faces * 3 : (int64_t)0, obj_faces,
-                       vertex_offset, faces_out, batch_size, num_hand_faces, num_obj_faces);
+                       (hipStream_t)stream, q);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_flow_pair_prologue_parts(const float* verts1a, const float* verts1b, const float* verts2a, const float* verts2b,
+                                           int num_verts_a, int num_verts_b, const float* K1, const float* K2, const float* R,
+                                           const float* t, const float* dist_coeffs, int cam_batched, float orig_size,
+                                           float* ndc1, float* ndc2, float* cols12, float* cols21, const int64_t* hand_faces,
+                                           int hand_batched, const int64_t* obj_faces, int32_t* faces_out, int num_hand_faces,
+                                           int num_obj_faces, int batch_size, mr_stream_t stream) {
+    if (batch_size < 0 || num_verts_a < 0 || num_verts_b <= 0 || !(orig_size > 0.0f) || num_hand_faces < 0 || num_obj_faces < 0)
+        return MR_ERR_BADARG;
+    if (batch_size == 0) return MR_OK;
+    if (!verts1b || !verts2b || ((!verts1a || !verts2a) && num_verts_a > 0) || !K1 || !K2 || !R || !t || !dist_coeffs ||
+        !ndc1 || !ndc2 || !cols12 || !cols21)
+        return MR_ERR_BADARG;
+    const int n = (num_hand_faces + num_obj_faces) * 3;
+    if (n > 0 && (!faces_out || (!hand_faces && num_hand_faces > 0) || (!obj_faces && num_obj_faces > 0))) return MR_ERR_BADARG;
+    if (batch_size > 65535) return MR_ERR_BADARG;
+    const int V = num_verts_a + num_verts_b;
+    const VertexStageParams p{verts1a, verts2a, verts1b, verts2b, num_verts_a, K1, K2, R, t, dist_coeffs, cam_batched ? 1 : 0,
+                              orig_size, ndc1, ndc2, cols12, cols21, batch_size, V};
+    const StackFacesParams q{hand_faces, hand_batched ? (int64_t)num_hand_faces * 3 : (int64_t)0, obj_faces, num_verts_a, faces_out,
+                             batch_size, num_hand_faces, num_obj_faces};
+    const int vb = (V + 255) / 256, fb = (n + 255) / 256;
+    hipLaunchKernelGGL(pair_prologue_kernel, dim3((unsigned)(vb + fb), (unsigned)batch_size), dim3(256), 0, (hipStream_t)stream,
+                       p, q, vb);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

@@ -799,7 +799,8 @@ __global__ void __launch_bounds__(256) pair_consist_finalize_tiles_kernel(const 
                                                                           float* __restrict__ sums, float* __restrict__ loss_fwd,
                                                                           float* __restrict__ loss_bwd,
                                                                           const unsigned* __restrict__ tile_max,
-                                                                          unsigned* __restrict__ image_max) {
+                                                                          unsigned* __restrict__ image_max,
+                                                                          float* __restrict__ loss_sum) {
     __shared__ float red[4][4];
     __shared__ unsigned redm[4][2];
     const int b = blockIdx.x;
@@ -833,6 +834,7 @@ __global__ void __launch_bounds__(256) pair_consist_finalize_tiles_kernel(const 
         const float n1 = (a[1] == 0.0f) ? 1.0f : a[1], n2 = (a[3] == 0.0f) ? 1.0f : a[3];
         if (loss_fwd) loss_fwd[b] = a[0] / n1;
         if (loss_bwd) loss_bwd[b] = a[2] / n2;
+        if (loss_sum) loss_sum[b] = a[2] / n2 + a[0] / n1;  // pair_consist's warp_loss with use_backward (imgflowarp.py:104-113)
     }
 }
 
@@ -1149,7 +1151,7 @@ extern "C" int mr_pair_consist_forward_tiles(const float* flow12, const float* f
     hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit12),
                        reinterpret_cast<const uint32_t*>(tile_hit21), batch_size, p.tiles_x * p.tiles_y, sums, loss_fwd, loss_bwd,
-                       (const unsigned*)nullptr, (unsigned*)nullptr);
+                       (const unsigned*)nullptr, (unsigned*)nullptr, (float*)nullptr);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1194,7 +1196,8 @@ static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_fl
                                    float* sums, float* loss_fwd, float* loss_bwd, int batch_size, int image_size,
                                    int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
                                    const void* list_header, const void* list_entries, int64_t list_capacity,
-                                   int64_t tile_bound, float* unit_grad, float* unit_grad_max, mr_stream_t stream) {
+                                   int64_t tile_bound, float* unit_grad, float* unit_grad_max, float* loss_sum,
+                                   mr_stream_t stream) {
     if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2 || !flow_out12 || !flow_out21)
         return MR_ERR_BADARG;
     if (batch_size < 0 || image_size <= 0 || flow_bstride < 2LL * image_size * image_size) return MR_ERR_BADARG;
@@ -1225,7 +1228,7 @@ static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_fl
                        (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit1),
                        reinterpret_cast<const uint32_t*>(tile_hit2), batch_size, tiles_x * tiles_y, sums, loss_fwd, loss_bwd,
                        unit_grad ? (const unsigned*)q.tile_max : (const unsigned*)nullptr,
-                       unit_grad ? reinterpret_cast<unsigned*>(unit_grad_max) : (unsigned*)nullptr);
+                       unit_grad ? reinterpret_cast<unsigned*>(unit_grad_max) : (unsigned*)nullptr, loss_sum);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1244,7 +1247,7 @@ extern "C" int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* 
                                    flow_out12, flow_out21, tile_hit1, tile_hit2, image_ref, image, jitter_ref, jitter,
                                    jitter_channels, workspace, workspace_bytes, sums, loss_fwd, loss_bwd, batch_size, image_size,
                                    height, width, distance_thresh, warp_thresh, pair_thresh, list_header, list_entries,
-                                   list_capacity, tile_bound, nullptr, nullptr, stream);
+                                   list_capacity, tile_bound, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int mr_flow_pair_forward_grad_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
@@ -1257,11 +1260,12 @@ extern "C" int mr_flow_pair_forward_grad_tiles(const float* mask_flow1, const fl
                                                int batch_size, int image_size, int height, int width, float distance_thresh,
                                                float warp_thresh, float pair_thresh, const void* list_header,
                                                const void* list_entries, int64_t list_capacity, int64_t tile_bound,
-                                               float* unit_grad, float* unit_grad_max, mr_stream_t stream) {
+                                               float* unit_grad, float* unit_grad_max, float* loss_sum,
+                                               mr_stream_t stream) {
     if (!unit_grad || !unit_grad_max) return MR_ERR_BADARG;
     return flow_pair_forward_tiles(mask_flow1, mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2,
                                    flow_out12, flow_out21, tile_hit1, tile_hit2, image_ref, image, jitter_ref, jitter,
                                    jitter_channels, workspace, workspace_bytes, sums, loss_fwd, loss_bwd, batch_size, image_size,
                                    height, width, distance_thresh, warp_thresh, pair_thresh, list_header, list_entries,
-                                   list_capacity, tile_bound, unit_grad, unit_grad_max, stream);
+                                   list_capacity, tile_bound, unit_grad, unit_grad_max, loss_sum, stream);
 }

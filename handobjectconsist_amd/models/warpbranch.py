@@ -77,13 +77,14 @@ def _fused_pairs(samples, all_results, hand_face, gt_refs, first_only, renderer,
     for k in range(1, len(samples)):
         res = opticalflow.flow_pair_loss([parts[0], parts[k]], faces, [cams[0], cams[k]], renderer, image_size,
                                          ref_image, _q(samples[k], "image").cuda(), ref_jitter,
-                                         _q(samples[k], "jittermask").cuda(), ignore_face_idxs=hand_ignore_faces)
+                                         _q(samples[k], "jittermask").cuda(), ignore_face_idxs=hand_ignore_faces, with_sum=True)
         if res is None:
             return None if k == 1 else _raise_mixed()
-        loss_fwd, loss_bwd, pair_flows = res
-        losses.append(loss_bwd + loss_fwd if use_backward else loss_fwd)
+        loss_fwd, loss_bwd, pair_flows, loss_sum = res
+        losses.append(loss_sum if use_backward else loss_fwd)  # (loss_sum = loss_bwd + loss_fwd, formed by the node itself)
         flows.append(pair_flows)
-    diff_losses = torch.stack(losses)
+    # (one pair -- the trainer's setting --: the stack is a view, not a copy launch)
+    diff_losses = losses[0].unsqueeze(0) if len(losses) == 1 else torch.stack(losses)
     none = [None] * len(losses)
     return diff_losses.mean(), {"masks": none, "warps": list(none), "recons_flows": flows, "diffs": list(none),
                                 "diff_losses": diff_losses}

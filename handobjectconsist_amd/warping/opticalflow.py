@@ -165,7 +165,9 @@ class _FlowVertexStageParts(torch.autograd.Function):
     gradient in its backward) -- two copies and their autograd nodes less per pair."""
 
     @staticmethod
-    def forward(ctx, v1a, v1b, v2a, v2b, K1, K2, R, t, dist, orig_size):
+    def forward(ctx, v1a, v1b, v2a, v2b, K1, K2, R, t, dist, orig_size, hand_face=None, obj_faces=None):
+        """``hand_face`` / ``obj_faces`` given: the stacked int32 faces of the pair (``_stack_pair_faces``) come out of the SAME
+        launch as a third output (mr_flow_pair_prologue_parts)."""
         ctx.set_materialize_grads(False)
         parts = [_lib.contig(x.detach()) for x in (v1a, v1b, v2a, v2b)]
         k1, k2 = _lib.contig(K1.detach()), _lib.contig(K2.detach())
@@ -179,37 +181,54 @@ class _FlowVertexStageParts(torch.autograd.Function):
             raise ValueError("expected vertex parts [B,Va,3] / [B,Vb,3], intrinsics [B,3,3] and R / t / dist_coeffs with batch 1 or B")
         ndc = torch.empty((2 * B, Va + Vb, 3), dtype=torch.float32, device=parts[0].device)
         cols = torch.empty_like(ndc)
-        _lib.call("mr_flow_vertices_parts_forward", *[_lib.ptr(x) for x in parts], Va, Vb, _lib.ptr(k1), _lib.ptr(k2),
-                  _lib.ptr(Rc), _lib.ptr(tc), _lib.ptr(dc), int(nb == B and B > 1), float(orig_size), _lib.ptr(ndc[:B]),
-                  _lib.ptr(ndc[B:]), _lib.ptr(cols[:B]), _lib.ptr(cols[B:]), B, _lib.stream_ptr(parts[0].device))
+        head = (*[_lib.ptr(x) for x in parts], Va, Vb, _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(Rc), _lib.ptr(tc), _lib.ptr(dc),
+                int(nb == B and B > 1), float(orig_size), _lib.ptr(ndc[:B]), _lib.ptr(ndc[B:]), _lib.ptr(cols[:B]), _lib.ptr(cols[B:]))
         ctx.save_for_backward(*parts, k1, k2)
-        ctx.mark_non_differentiable(ndc)
-        return ndc, cols
+        ctx.with_faces = obj_faces is not None
+        if obj_faces is None:
+            _lib.call("mr_flow_vertices_parts_forward", *head, B, _lib.stream_ptr(parts[0].device))
+            ctx.mark_non_differentiable(ndc)
+            return ndc, cols
+        hf, of, batched = _pair_face_parts(hand_face, obj_faces)
+        if of.shape[0] != B:
+            raise ValueError("expected object faces [B,Fo,3]")
+        Fh, Fo = hf.shape[-2], of.shape[1]
+        faces2 = torch.empty((2 * B, Fh + Fo, 3), dtype=torch.int32, device=parts[0].device)
+        _lib.call("mr_flow_pair_prologue_parts", *head, _lib.ptr(hf), int(batched), _lib.ptr(of), _lib.ptr(faces2), Fh, Fo, B,
+                  _lib.stream_ptr(parts[0].device))
+        ctx.mark_non_differentiable(ndc, faces2)
+        return ndc, cols, faces2
 
     @staticmethod
-    def backward(ctx, _g_ndc, g_cols):
+    def backward(ctx, _g_ndc, g_cols, _g_faces=None):
         v1a, v1b, v2a, v2b, k1, k2 = ctx.saved_tensors
         B, Va, Vb = v1a.shape[0], v1a.shape[1], v1b.shape[1]
         want = ctx.needs_input_grad[:4]
         if g_cols is None or not any(want):
-            return (None,) * 10
+            return (None,) * 12
         grads = [torch.empty_like(x) if w else None for x, w in zip((v1a, v1b, v2a, v2b), want)]
         g = _lib.contig(g_cols)
         _lib.call("mr_flow_vertices_parts_backward", _lib.ptr(v1a), _lib.ptr(v1b), _lib.ptr(v2a), _lib.ptr(v2b), Va, Vb,
                   _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(g[:B]), _lib.ptr(g[B:]), *[_lib.ptr(x) for x in grads], B,
                   _lib.stream_ptr(v1a.device))
-        return tuple(grads) + (None,) * 6
+        return tuple(grads) + (None,) * 8
+
+
+def _pair_face_parts(hand_face, obj_faces):
+    """(contiguous int64 hand faces [Fh,3] or [B,Fh,3], object faces [B,Fo,3], hand faces batched?)"""
+    hf = _lib.contig(hand_face, torch.int64)
+    of = _lib.contig(obj_faces, torch.int64)
+    batched = hf.dim() == 3 and hf.shape[0] == of.shape[0] and of.shape[0] > 1
+    if hf.dim() == 3 and not batched:
+        hf = hf[0]
+    return hf, of, batched
 
 
 def _stack_pair_faces(hand_face, obj_faces, num_hand_verts):
     """int32 [2B, Fh + Fo, 3]: the faces of the concatenated hand + object mesh (object indices offset by the hand's
     vertex count, warpbranch.py:36, 49-55), twice -- what the stacked render of a frame pair takes -- in one launch."""
-    hf = _lib.contig(hand_face, torch.int64)
-    of = _lib.contig(obj_faces, torch.int64)
+    hf, of, batched = _pair_face_parts(hand_face, obj_faces)
     B, Fo = of.shape[:2]
-    batched = hf.dim() == 3 and hf.shape[0] == B and B > 1
-    if hf.dim() == 3 and not batched:
-        hf = hf[0]
     Fh = hf.shape[-2]
     out = torch.empty((2 * B, Fh + Fo, 3), dtype=torch.int32, device=of.device)
     _lib.call("mr_stack_pair_faces", _lib.ptr(hf), int(batched), _lib.ptr(of), int(num_hand_verts), _lib.ptr(out), B, Fh, Fo,
@@ -506,7 +525,7 @@ USE_UNIT_GRADIENT = True
 
 class _FlowPairLossFunction(torch.autograd.Function):
     """(ndc[2B,V,3], faces[2B,F0,3] int32, cols[2B,V,3]; image_ref, image [B,3,H,W], jitter masks [B,Cj,H,W]) ->
-    (loss_fwd[B], loss_bwd[B], flows[2B,H,W,2], tile_hit): opticalflow.py:98-154 + imgflowarp.py:58-115 +
+    (loss_fwd[B], loss_bwd[B], loss_bwd + loss_fwd, flows[2B,H,W,2], tile_hit): opticalflow.py:98-154 + imgflowarp.py:58-115 +
     pyramidloss.py:56-62 + lossutils.py:1-8 for one frame pair.  Differentiable w.r.t. ``cols`` only (the training
     setting: detach_renders=True, images are data).  ``flows`` are defined under the covered tiles only."""
 
@@ -541,10 +560,11 @@ class _FlowPairLossFunction(torch.autograd.Function):
                 _lib.ptr(loss_bwd), B, is_, height, width, 0.03, 0.99999, float(thresh), where[0], where[1], where[2],
                 int(r["bound"]))
         if unit:
-            unit_grad, unit_max = new_f(B2, height, width, 2), torch.empty((B2,), **f32)
-            _lib.call("mr_flow_pair_forward_grad_tiles", *args, _lib.ptr(unit_grad), _lib.ptr(unit_max), st)
+            unit_grad, unit_max, loss_sum = new_f(B2, height, width, 2), torch.empty((B2,), **f32), torch.empty((B,), **f32)
+            _lib.call("mr_flow_pair_forward_grad_tiles", *args, _lib.ptr(unit_grad), _lib.ptr(unit_max), _lib.ptr(loss_sum), st)
         else:
             _lib.call("mr_flow_pair_forward_tiles", *args, st)
+            loss_sum = loss_bwd + loss_fwd
         # (the flows are defined under the covered tiles only: the list rides along with them, as for get_opticalflow(sparse_flows=True))
         _FlowPairLossFunction.last_tiles = (where[0], where[1], where[2], int(r["bound"]), r["work"])
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width, float(thresh), int(r["F0"]), int(r["V"]))
@@ -555,11 +575,14 @@ class _FlowPairLossFunction(torch.autograd.Function):
             ctx.save_for_backward(r["fim"], tile_hit, r["wmap"], r["vid"], mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums)
         ctx.grad_buf = r["grad_buf"]
         ctx.mark_non_differentiable(flow, tile_hit)
-        return loss_fwd, loss_bwd, flow, tile_hit
+        return loss_fwd, loss_bwd, loss_sum, flow, tile_hit
 
     @staticmethod
-    def backward(ctx, g_fwd, g_bwd, _g_flow=None, _g_hit=None):
+    def backward(ctx, g_fwd, g_bwd, g_sum=None, _g_flow=None, _g_hit=None):
         is_, eps, fill_back, height, width, thresh, F0, V = ctx.cfg
+        if g_sum is not None:  # d/d(loss_bwd + loss_fwd) goes to both terms (the same tensor for both when only the sum is used)
+            g_fwd = g_sum if g_fwd is None else g_fwd + g_sum
+            g_bwd = g_sum if g_bwd is None else g_bwd + g_sum
         if not ctx.needs_input_grad[2] or (g_fwd is None and g_bwd is None):
             return (None,) * 17
         fim = ctx.saved_tensors[0]
@@ -592,7 +615,7 @@ class _FlowPairLossFunction(torch.autograd.Function):
 
 
 def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image_ref, image, jitter_mask_ref, jitter_mask,
-                   ignore_face_idxs=None):
+                   ignore_face_idxs=None, with_sum=False):
     """``get_opticalflow(verts_cam, ..., detach_textures=False, detach_renders=True)`` followed by
     ``pair_consist(flows, image_ref, image, jitter_mask_ref, jitter_mask, PyramidCriterion("l1"))`` for ONE frame pair, as a
     single fused node (no counterpart function in the reference: opticalflow.py:51-156 + imgflowarp.py:58-115 composed).
@@ -603,7 +626,9 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
 
     Returns ``(loss_fwd[B], loss_bwd[B], [flow12, flow21])`` -- ``pair_consist``'s ``warp_loss`` is ``loss_fwd`` (+
     ``loss_bwd`` with ``use_backward``); the flows are defined under their renders' covered tiles only -- or ``None`` when the
-    fused node does not apply (renderer settings, raster size, tensors off the GPU): callers then compose the two functions."""
+    fused node does not apply (renderer settings, raster size, tensors off the GPU): callers then compose the two functions.
+    ``with_sum``: a fourth element, ``loss_bwd + loss_fwd`` as the node's own output (the finalize launch writes it: one
+    element-wise launch less each way for callers that want the sum)."""
     parts = isinstance(verts_cam[0], (tuple, list))  # (hand, object) vertex tensors per frame + (hand, object) faces
     if parts:
         (h1, o1), (h2, o2) = verts_cam
@@ -638,17 +663,18 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
     cam = (camintrs[0].to(dev), camintrs[1].to(dev), neurenderer.R.to(dev), neurenderer.t.to(dev), neurenderer.dist_coeffs.to(dev),
            neurenderer.orig_size)
     if parts:
-        ndc, cols = _FlowVertexStageParts.apply(h1, o1, h2, o2, *cam)
-        faces2 = _stack_pair_faces(hand_face, obj_faces, h1.shape[1])
+        ndc, cols, faces2 = _FlowVertexStageParts.apply(h1, o1, h2, o2, *cam, hand_face, obj_faces)  # (+ the stacked faces)
     else:
         ndc, cols = _FlowVertexStage.apply(v1, v2, *cam)
         faces2 = _stacked_faces(faces)
     lut = _keep_lut(ignore_face_idxs, dev) if ignore_face_idxs is not None else None
-    loss_fwd, loss_bwd, flows, tile_hit = _FlowPairLossFunction.apply(
+    loss_fwd, loss_bwd, loss_sum, flows, tile_hit = _FlowPairLossFunction.apply(
         ndc, faces2, cols, lut, neurenderer.fill_back, is_, neurenderer.near, neurenderer.far,
         neurenderer.rasterizer_eps, neurenderer.background_color, H, W, image_ref, image, jitter_mask_ref, jitter_mask, 0.99999)
     tiles, _FlowPairLossFunction.last_tiles = _FlowPairLossFunction.last_tiles, None
     flows._hoc_coverage = (tile_hit, is_, flows._version, tiles)
+    if with_sum:
+        return loss_fwd, loss_bwd, [flows[:B], flows[B:]], loss_sum
     return loss_fwd, loss_bwd, [flows[:B], flows[B:]]
 
 

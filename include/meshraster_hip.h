@@ -327,6 +327,14 @@ MR_API int mr_flow_vertices_parts_backward(const float* verts1a, const float* ve
 MR_API int mr_stack_pair_faces(const int64_t* hand_faces, int hand_batched, const int64_t* obj_faces, int vertex_offset,
                                int32_t* faces_out, int batch_size, int num_hand_faces, int num_obj_faces,
                                mr_stream_t stream);
+/* mr_flow_vertices_parts_forward + mr_stack_pair_faces (vertex_offset = num_verts_a) in ONE launch: the two set-up steps of
+ * a frame pair do not depend on each other (ABI 5). */
+MR_API int mr_flow_pair_prologue_parts(const float* verts1a, const float* verts1b, const float* verts2a, const float* verts2b,
+                                       int num_verts_a, int num_verts_b, const float* K1, const float* K2, const float* R,
+                                       const float* t, const float* dist_coeffs, int cam_batched, float orig_size,
+                                       float* ndc1, float* ndc2, float* cols12, float* cols21, const int64_t* hand_faces,
+                                       int hand_batched, const int64_t* obj_faces, int32_t* faces_out, int num_hand_faces,
+                                       int num_obj_faces, int batch_size, mr_stream_t stream);
 
 /* MANO linear-blend skinning (manopth ManoLayer.forward as called at
  * manobranch.py:130-136, PCA pose space, arithmetic of SURVEY appendix B.10) and its adjoint.
@@ -580,7 +588,8 @@ MR_API int mr_flow_pair_backward_tiles(const int32_t* face_index_map, const uint
  *     -- mr_pair_consist_backward_tiles' gradient for a coefficient grad_loss / count of 1 -- times the epilogue's factors
  *     ((g * (mask_x * occl)) * mask_pre, as mr_render_flow_backward applies them): the gradient w.r.t. the RENDERED
  *     displacement planes up to one scalar per image (sparse contract: untouched under uncovered tiles);
- *   unit_grad_max [2B]: largest |component| of unit_grad per stack image (float; NaN / Inf propagate as such).
+ *   unit_grad_max [2B]: largest |component| of unit_grad per stack image (float; NaN / Inf propagate as such);
+ *   loss_sum [B] (nullable): loss_bwd + loss_fwd, pair_consist's warp_loss with use_backward (one element-wise launch less).
  *   workspace: mr_pair_consist_tiles_workspace_bytes(B, image_size) as for the plain call.
  * mr_flow_pair_backward_unit_tiles = the scatter half of mr_flow_pair_backward_tiles on that gradient: every covered pixel's
  *   unit_grad x (grad_loss_{fwd,bwd}[b] / count of the image's direction, from sums) goes to the vertex colours behind its
@@ -597,7 +606,8 @@ MR_API int mr_flow_pair_forward_grad_tiles(const float* mask_flow1, const float*
                                            float* sums, float* loss_fwd, float* loss_bwd, int batch_size, int image_size,
                                            int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
                                            const void* list_header, const void* list_entries, int64_t list_capacity,
-                                           int64_t tile_bound, float* unit_grad, float* unit_grad_max, mr_stream_t stream);
+                                           int64_t tile_bound, float* unit_grad, float* unit_grad_max, float* loss_sum,
+                                           mr_stream_t stream);
 MR_API int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, const uint32_t* tile_hit, const float* weight_map,
                                             const int32_t* vertex_id_map, const float* unit_grad, const float* unit_grad_max,
                                             const float* sums, const float* grad_loss_fwd, const float* grad_loss_bwd,

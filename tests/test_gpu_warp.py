@@ -794,6 +794,29 @@ def test_fused_pair_node_equals_the_composed_path(cuda, monkeypatch, B, is_, H, 
             close(a.cpu().numpy(), b_.cpu().numpy(), 1e-5, 1e-6 * float(b_.abs().max()), what)
 
 
+@pytest.mark.parametrize("B,batched_hand", [(1, False), (3, False), (2, True)])
+def test_pair_prologue_equals_its_two_launches(cuda, B, batched_hand):
+    """mr_flow_pair_prologue_parts (vertex stage of the (hand, object) parts + the stacked int32 faces in ONE launch, what
+    flow_pair_loss issues) against mr_flow_vertices_parts_forward and mr_stack_pair_faces: bit for bit."""
+    from handobjectconsist_amd.warping import opticalflow
+
+    s = synth.random_scene(B, seed=23, image_size=96)
+    Ks = [t(s["K1"], cuda), t(s["K2"], cuda)]
+    cam = (Ks[0], Ks[1], torch.eye(3, device=cuda)[None], torch.zeros(1, 3, device=cuda), torch.zeros(1, 5, device=cuda), 96)
+    parts = [t(s[k], cuda) for k in ("hand_verts1", "obj_verts1", "hand_verts2", "obj_verts2")]
+    hand_faces = t(s["hand_faces"].astype(np.int64), cuda)
+    if batched_hand:
+        hand_faces = hand_faces[None].repeat(B, 1, 1).contiguous()
+    obj_faces = t(s["obj_faces"].astype(np.int64)[None].repeat(B, 0), cuda)
+    ndc0, cols0 = opticalflow._FlowVertexStageParts.apply(*parts, *cam)
+    faces0 = opticalflow._stack_pair_faces(hand_faces, obj_faces, parts[0].shape[1])
+    ndc1, cols1, faces1 = opticalflow._FlowVertexStageParts.apply(*parts, *cam, hand_faces, obj_faces)
+    assert torch.equal(ndc0, ndc1) and torch.equal(cols0, cols1) and torch.equal(faces0, faces1)
+    want = np.concatenate([np.broadcast_to(s["hand_faces"], (B,) + s["hand_faces"].shape),
+                           np.broadcast_to(s["obj_faces"] + parts[0].shape[1], (B,) + s["obj_faces"].shape)], 1)
+    assert faces1.dtype == torch.int32 and np.array_equal(faces1.cpu().numpy(), np.concatenate([want, want], 0))
+
+
 @pytest.mark.parametrize("B,is_,H,Wd,Cj", [(1, 72, 72, 72, 1), (3, 104, 56, 100, 1), (2, 136, 136, 136, 3)])
 def test_fused_pair_node_on_ragged_rasters_and_as_parts(cuda, B, is_, H, Wd, Cj):
     """Rasters that are no multiple of the 32 x 8 tile (border tiles hang over the raster), a single pair, crops narrower
