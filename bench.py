@@ -334,13 +334,13 @@ def kernel_bench(dev, B, is_, iters, only=None):
                   P(im_ref), P(im), P(jm_ref), P(jm), 3, P(ptwork), ptbytes, P(sums), P(lf), P(lb), B, is_, is_, is_, 0.03, 0.99999,
                   0.99999, tlist[0], tlist[1], tlist[2], tl_bound, st)
 
-    punit, punit_max = torch.empty((B2, is_, is_, 2), **f32), torch.empty((B2,), **f32)
+    punit, punit_max, lsum = torch.empty((B2, is_, is_, 2), **f32), torch.empty((B2,), **f32), torch.empty((B,), **f32)
 
     def flow_pair_fwd_grad_tiles():  # ... and as the step launches it when the vertices want a gradient (they do)
         _lib.call("mr_flow_pair_forward_grad_tiles", P(pmask[:B]), P(palpha[B:]), P(prgb[:B]), P(prgb[B:]), 3 * is_ * is_,
                   P(pmask[:B]), P(pmask[B:]), P(pocc[:B]), P(pocc[B:]), P(pflows[:B]), P(pflows[B:]), P(ptile_hit[:B]),
                   P(ptile_hit[B:]), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(ptwork), ptbytes, P(sums), P(lf), P(lb), B, is_, is_,
-                  is_, 0.03, 0.99999, 0.99999, tlist[0], tlist[1], tlist[2], tl_bound, P(punit), P(punit_max), st)
+                  is_, 0.03, 0.99999, 0.99999, tlist[0], tlist[1], tlist[2], tl_bound, P(punit), P(punit_max), P(lsum), st)
 
     def flow_pair_bwd_unit_tiles():  # the step's backward launch (output cleared by the forward's binning pass, as in the step)
         _lib.call("mr_flow_pair_backward_unit_tiles", P(pfim), P(ptile_hit), P(pwrec), P(pvid), P(punit), P(punit_max), P(sums),
