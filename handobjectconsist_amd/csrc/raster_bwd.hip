@@ -2393,8 +2393,11 @@ extern "C" int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, c
     sp.weight = weight_map; sp.tile_hit = tile_hit; sp.vid_map = vertex_id_map;
     sp.split = batch_size / 2; sp.H = height; sp.W = width;
     sp.tiles_x = (image_size + ST_TW - 1) / ST_TW; sp.tiles_y = (image_size + ST_TH - 1) / ST_TH;
+    // workgroups per image: a wave takes a covered tile per round, and larger rasters have more of them per image (a sixth of
+    // 256 / 900 / 1600 tiles): 8 / 32 / 32 -- a 480 x 480 pair at B = 8: 30 -> 19 us, 640 x 640 at B = 32: 86 -> 74 us cold
     sp.groups = ST_G;
-    switch ((flags >> 12) & 7) { case 1: sp.groups = 2; break; case 2: sp.groups = 4; break; case 3: sp.groups = 16; break; case 4: sp.groups = 32; break; default: break; }
+    while (sp.groups < 32 && sp.tiles_x * sp.tiles_y > 48 * sp.groups) sp.groups *= 2;
+    switch ((flags >> 12) & 7) { case 1: sp.groups = 2; break; case 2: sp.groups = 4; break; case 3: sp.groups = 16; break; case 4: sp.groups = 32; break; case 5: sp.groups = 8; break; default: break; }
     sp.unit_grad = unit_grad; sp.unit_max = unit_grad_max; sp.sums = sums; sp.gl_fwd = grad_loss_fwd; sp.gl_bwd = grad_loss_bwd;
     const int64_t blocks = (int64_t)batch_size * sp.groups;
     if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
