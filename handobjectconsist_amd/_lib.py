@@ -15,6 +15,7 @@ FLAG_REFERENCE_ALGO = 1
 FLAG_SPARSE_TILES = 2
 FLAG_OUTPUT_ZEROED = 4
 FLAG_TILE_PER_WORKGROUP = 8
+FLAG_TILE_LIST_CLEARED = 16
 
 _c = ctypes
 _P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
@@ -44,7 +45,7 @@ SIGNATURES = {
     "mr_flow_vertices_parts_forward": (_I, [_P] * 4 + [_I, _I] + [_P] * 5 + [_I, _F] + [_P] * 4 + [_I, _P]),
     "mr_flow_vertices_parts_backward": (_I, [_P] * 4 + [_I, _I] + [_P] * 8 + [_I, _P]),
     "mr_stack_pair_faces": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
-    "mr_flow_pair_prologue_parts": (_I, [_P] * 4 + [_I, _I] + [_P] * 5 + [_I, _F] + [_P] * 5 + [_I, _P, _P, _I, _I, _I, _P]),
+    "mr_flow_pair_prologue_parts": (_I, [_P] * 4 + [_I, _I] + [_P] * 5 + [_I, _F] + [_P] * 5 + [_I, _P, _P, _I, _I, _I, _P, _P]),
     "mr_mano_workspace_floats": (_L, [_I]),
     "mr_mano_forward": (_I, [_P] * 12 + [_I, _I] + [_P] * 3 + [_I, _P]),
     "mr_mano_backward": (_I, [_P] * 10 + [_I, _I] + [_P] * 5 + [_I, _P]),

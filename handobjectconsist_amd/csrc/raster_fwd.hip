@@ -201,6 +201,11 @@ __device__ unsigned long long mr_dbg_bin[1024 * 8];  // profiling builds: phase 
 // padding the counter rows against LDS bank conflicts (32 bins per row = 32 banks), four predicated straight-line atomics
 // instead of the bin loops for faces within 2 x 2 bins.  What is left is memory latency at three dependent points
 // (boxes in, headers / records out) around ~2 x 2 us of atomics.
+// RECORDS (vertex-colour mode, boxes in LDS, tile list whose header the CALLER cleared -- MR_FLAG_TILE_LIST_CLEARED): the per-face
+// pass runs inside this kernel -- a thread computes the boxes of its real faces (and their reversed copies) straight into the LDS
+// copy and writes the faces' coordinates; the boxes never exist in global memory.  One launch and one dependent round trip (the
+// boxes' read-back) less per render: 14 + 17.5 -> 21 us for the 2B = 128 meshes of a training pair.
+template <bool RECORDS>
 __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     MR_BIN_STAMP(0);
     extern __shared__ int bin_smem[];
@@ -221,6 +226,50 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     __syncthreads();
     MR_BIN_STAMP(1);
 
+    if constexpr (RECORDS) {
+        // the per-face pass (face_records_kernel<true>'s arithmetic): indices of REC_PF faces per thread requested together,
+        // then their vertices, then the boxes of both orientations into the LDS copy
+        constexpr int REC_PF = 4;
+        const bool two = p.fill_back != 0;
+        for (int base = 0; base < p.F0; base += REC_PF * BIN_TPB) {
+            int id[REC_PF][3];
+#pragma unroll
+            for (int k = 0; k < REC_PF; k++) {
+                const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + min(base + k * BIN_TPB + tid, p.F0 - 1)) * 3;
+                id[k][0] = ix[0]; id[k][1] = ix[1]; id[k][2] = ix[2];
+            }
+            float f[REC_PF][9];
+#pragma unroll
+            for (int k = 0; k < REC_PF; k++)
+#pragma unroll
+                for (int v = 0; v < 3; v++) {
+                    const float* g = p.verts + ((int64_t)b * p.V + id[k][v]) * 3;
+                    f[k][3 * v] = g[0]; f[k][3 * v + 1] = g[1]; f[k][3 * v + 2] = g[2];
+                }
+#pragma unroll
+            for (int k = 0; k < REC_PF; k++) {
+                const int f0 = base + k * BIN_TPB + tid;
+                if (f0 >= p.F0) continue;
+                BoxShared sh;
+                face_box_shared(f[k], p.is, sh);
+                const FaceBox b0 = face_box_orient<false>(f[k], p.is, sh);
+                sbox[f0] = b0;
+                bool live = b0.x0 <= b0.x1;
+                if (two) {
+                    const FaceBox b1 = face_box_orient<true>(f[k], p.is, sh);
+                    sbox[f0 + p.F0] = b1;
+                    live = live || b1.x0 <= b1.x1;
+                }
+                if (live) {
+                    float4* rv = reinterpret_cast<float4*>(p.rverts + (int64_t)b * p.F0 + f0);
+                    rv[0] = make_float4(f[k][0], f[k][1], f[k][2], f[k][3]);
+                    rv[1] = make_float4(f[k][4], f[k][5], f[k][6], f[k][7]);
+                    rv[2] = make_float4(f[k][8], division_safe_face(f[k], p.is) ? 1.0f : 0.0f, 0.0f, 0.0f);
+                }
+            }
+        }
+        __syncthreads();
+    }
     // pass 1: records per bin.  The boxes of BIN_PF trips are requested together (unconditional loads from clamped
     // addresses): one load round trip per BIN_PF x 1024 faces instead of one per trip -- a hand + object mesh (7104
     // virtual faces) is seven trips, i.e. seven dependent round trips of the single workgroup an image has.
@@ -228,12 +277,15 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     for (int base = 0; base < p.F; base += BIN_PF * BIN_TPB) {
         FaceBox bxs[BIN_PF];
 #pragma unroll
-        for (int k = 0; k < BIN_PF; k++) bxs[k] = box_b[min(base + k * BIN_TPB + tid, p.F - 1)];
+        for (int k = 0; k < BIN_PF; k++) {
+            const int fc = min(base + k * BIN_TPB + tid, p.F - 1);
+            bxs[k] = RECORDS ? sbox[fc] : box_b[fc];
+        }
 #pragma unroll
         for (int k = 0; k < BIN_PF; k++) {
             const int fn = base + k * BIN_TPB + tid;
             const FaceBox bx = bxs[k];
-            if (fn < p.F && p.lds_boxes) sbox[fn] = bx;
+            if (!RECORDS && fn < p.F && p.lds_boxes) sbox[fn] = bx;
             if (fn >= p.F || bx.x0 > bx.x1) continue;
             const int bx0 = bx.x0 / TILE_W, bx1 = bx.x1 / TILE_W;
             const int by0 = bx.y0 >> (3 + p.ysh), by1 = bx.y1 >> (3 + p.ysh);
@@ -1132,7 +1184,7 @@ static WorkLayout work_layout(int B, int F, int is) {
 // an id array of their own, instead of getting zero coverage bytes
 template <bool VC>
 static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int F, int is, hipStream_t s,
-                       uint8_t* tile_hit = nullptr, bool dense_list = false) {
+                       uint8_t* tile_hit = nullptr, bool dense_list = false, bool list_cleared = false) {
     const WorkLayout w = work_layout(B, F, is);
     if (w.nbx > MAX_BINS) return MR_ERR_BADARG;  // (image_size <= 16384 keeps a row of bins within the counters)
     char* base = (char*)workspace;
@@ -1163,7 +1215,11 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     fp.nbx = w.nbx; fp.nby = w.nby; fp.ysh = w.ysh;
     if (B == 0) return MR_OK;
     if (B > 65535) return MR_ERR_BADARG;
-    if (bp.F0 > 0) {
+    // (list_cleared: the caller cleared the tile list's header on this stream -- what the per-face pass's first thread does)
+    const bool fused_records = VC && list_cleared && bp.tlist && bp.lds_boxes && bp.F0 > 0 && !(bp.dbg & 16);
+    if (fused_records) {
+        // nothing: the per-face pass runs inside the binning kernel
+    } else if (bp.F0 > 0) {
         hipLaunchKernelGGL((face_records_kernel<VC>), dim3((unsigned)((bp.F0 + 255) / 256), (unsigned)B), dim3(256), 0, s,
                            bp);
         MR_CHECK_LAUNCH();
@@ -1175,12 +1231,16 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     }
     static size_t allowed = 48 * 1024;  // dynamic LDS beyond the default limit is an opt-in, raised on demand
     if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_boxes_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_boxes_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_boxes_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) return (int)e;
         allowed = 152 * 1024;
     }
-    hipLaunchKernelGGL(bin_boxes_kernel, dim3((unsigned)B), dim3(BIN_TPB), lds, s, bp);
+    if (fused_records) hipLaunchKernelGGL(bin_boxes_kernel<true>, dim3((unsigned)B), dim3(BIN_TPB), lds, s, bp);
+    else hipLaunchKernelGGL(bin_boxes_kernel<false>, dim3((unsigned)B), dim3(BIN_TPB), lds, s, bp);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1471,7 +1531,8 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
     bp.zero_fill = zero_fill_count > 0 ? zero_fill : nullptr; bp.zero_count = zero_fill_count;
     if ((flags & MR_FLAG_SPARSE_TILES) && !tile_hit) return MR_ERR_BADARG;
     const bool listed = (flags & MR_FLAG_SPARSE_TILES) && tile_bound != 0;
-    const int rc = launch_bins<true>(bp, p, workspace, batch_size, F, image_size, s, listed ? tile_hit : nullptr);
+    const int rc = launch_bins<true>(bp, p, workspace, batch_size, F, image_size, s, listed ? tile_hit : nullptr, false,
+                                     (flags & MR_FLAG_TILE_LIST_CLEARED) != 0);
     if (rc != MR_OK) return rc;
     p.tile_count_out = p.tlist ? tile_count_out : nullptr;
     p.background = background; p.bg_stride = bg_stride;

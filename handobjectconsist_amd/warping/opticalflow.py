@@ -165,9 +165,10 @@ class _FlowVertexStageParts(torch.autograd.Function):
     gradient in its backward) -- two copies and their autograd nodes less per pair."""
 
     @staticmethod
-    def forward(ctx, v1a, v1b, v2a, v2b, K1, K2, R, t, dist, orig_size, hand_face=None, obj_faces=None):
+    def forward(ctx, v1a, v1b, v2a, v2b, K1, K2, R, t, dist, orig_size, hand_face=None, obj_faces=None, clear16=None):
         """``hand_face`` / ``obj_faces`` given: the stacked int32 faces of the pair (``_stack_pair_faces``) come out of the SAME
-        launch as a third output (mr_flow_pair_prologue_parts)."""
+        launch as a third output (mr_flow_pair_prologue_parts); ``clear16``: address of 16 bytes that launch clears (the header of
+        the tile list of the render that follows on this stream, ``_lib.FLAG_TILE_LIST_CLEARED``)."""
         ctx.set_materialize_grads(False)
         parts = [_lib.contig(x.detach()) for x in (v1a, v1b, v2a, v2b)]
         k1, k2 = _lib.contig(K1.detach()), _lib.contig(K2.detach())
@@ -195,7 +196,7 @@ class _FlowVertexStageParts(torch.autograd.Function):
         Fh, Fo = hf.shape[-2], of.shape[1]
         faces2 = torch.empty((2 * B, Fh + Fo, 3), dtype=torch.int32, device=parts[0].device)
         _lib.call("mr_flow_pair_prologue_parts", *head, _lib.ptr(hf), int(batched), _lib.ptr(of), _lib.ptr(faces2), Fh, Fo, B,
-                  _lib.stream_ptr(parts[0].device))
+                  clear16, _lib.stream_ptr(parts[0].device))
         ctx.mark_non_differentiable(ndc, faces2)
         return ndc, cols, faces2
 
@@ -205,13 +206,13 @@ class _FlowVertexStageParts(torch.autograd.Function):
         B, Va, Vb = v1a.shape[0], v1a.shape[1], v1b.shape[1]
         want = ctx.needs_input_grad[:4]
         if g_cols is None or not any(want):
-            return (None,) * 12
+            return (None,) * 13
         grads = [torch.empty_like(x) if w else None for x, w in zip((v1a, v1b, v2a, v2b), want)]
         g = _lib.contig(g_cols)
         _lib.call("mr_flow_vertices_parts_backward", _lib.ptr(v1a), _lib.ptr(v1b), _lib.ptr(v2a), _lib.ptr(v2b), Va, Vb,
                   _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(g[:B]), _lib.ptr(g[B:]), *[_lib.ptr(x) for x in grads], B,
                   _lib.stream_ptr(v1a.device))
-        return tuple(grads) + (None,) * 8
+        return tuple(grads) + (None,) * 9
 
 
 def _pair_face_parts(hand_face, obj_faces):
@@ -378,9 +379,12 @@ def _fused_epilogue_stacked(ro, orig_img_size, ignore_face_idxs):
     return [flows[:B], flows[B:]]
 
 
-def _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, want_grad):
+def _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, want_grad,
+                         cleared_work=None):
     """The flow-mode render of the 2B stacked meshes of a frame pair (mr_render_flow_forward): what both training nodes
-    (_StackedFlowFunction, _FlowPairLossFunction) start with.  Returns the buffers by name."""
+    (_StackedFlowFunction, _FlowPairLossFunction) start with.  Returns the buffers by name.
+    ``cleared_work``: the render's workspace, allocated by the caller, the header of its tile list cleared on this stream
+    (the pair prologue does that): the render then runs its per-face pass inside the binning pass."""
     from handobjectconsist_amd.neurender import rasterize
 
     _lib.check_cuda(ndc, faces2, cols, lut)
@@ -411,9 +415,12 @@ def _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, fa
     tile_hit = torch.empty((B2, (is_ + 7) // 8, (is_ + 31) // 32, 4), dtype=torch.uint8, device=dev)
     F = 2 * F0 if fill_back else F0
     wbytes = int(_lib.load().mr_render_workspace_bytes(B2, F, is_))
-    work = torch.empty((max(wbytes, 8),), dtype=torch.uint8, device=dev)
+    if cleared_work is not None and (cleared_work.numel() < wbytes or cleared_work.device != dev):
+        raise ValueError("the render's workspace is too small or on another device")
+    work = cleared_work if cleared_work is not None else torch.empty((max(wbytes, 8),), dtype=torch.uint8, device=dev)
     st = _lib.stream_ptr(dev)
     bound, count_word = _tile_bound(dev, B2, is_) if (USE_SPARSE_TILES and USE_TILE_LIST) else (0, None)
+    render_flags = (_lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0) | (_lib.FLAG_TILE_LIST_CLEARED if cleared_work is not None else 0)
     # the backward's output buffer is cleared by the render's binning pass on its way (its own clearing would be a
     # launch on the backward pass's critical path); a second backward through this node clears its own
     grad_buf = torch.empty((B2, V, 3), **f32) if want_grad else None
@@ -421,7 +428,7 @@ def _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, fa
               _lib.ptr(lut), int(lut.numel()) if lut is not None else 0, 0.99999, _lib.ptr(rgb), _lib.ptr(alpha),
               _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(wmap), _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(work), wbytes,
               B2, V, F0, int(bool(fill_back)), is_, float(near), float(far), float(eps),
-              _lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0, _lib.ptr(vid), bound, _lib.ptr(count_word), _lib.ptr(grad_buf),
+              render_flags, _lib.ptr(vid), bound, _lib.ptr(count_word), _lib.ptr(grad_buf),
               int(grad_buf.numel()) if grad_buf is not None else 0, textutils.texel_layout_code(), st)
     return dict(verts=verts, fidx=fidx, rgb=rgb, alpha=alpha, mask=mask, depth=depth, vid=vid, wmap=wmap, fim=fim,
                 tile_hit=tile_hit, work=work, bound=bound, grad_buf=grad_buf, new_f=new_f, f32=f32, dev=dev, st=st, B2=B2, V=V,
@@ -521,6 +528,9 @@ USE_FUSED_PAIR_NODE = True
 # (that gradient) x (grad_loss / count) (mr_flow_pair_backward_unit_tiles): no image, mask or flow is read twice.
 # False: mr_flow_pair_forward_tiles + mr_flow_pair_backward_tiles (the backward recomputes the taps).
 USE_UNIT_GRADIENT = True
+# ... and with the render's per-face pass folded into its binning pass (the pair prologue clears the tile list's header, which
+# the per-face pass's first thread does otherwise): one launch and one dependent round trip less per pair.
+USE_FUSED_RECORDS = True
 
 
 class _FlowPairLossFunction(torch.autograd.Function):
@@ -533,11 +543,11 @@ class _FlowPairLossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, height, width,
-                image_ref, image, jitter_ref, jitter, thresh):
+                image_ref, image, jitter_ref, jitter, thresh, cleared_work=None):
         ctx.set_materialize_grads(False)
         _lib.check_cuda(image_ref, image, jitter_ref, jitter)
         r = _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color,
-                                 ctx.needs_input_grad[2])
+                                 ctx.needs_input_grad[2], cleared_work)
         B2, B, is_, dev, st, new_f, f32 = r["B2"], r["B2"] // 2, r["is_"], r["dev"], r["st"], r["new_f"], r["f32"]
         where = _lib.tile_list(r["work"], B2, r["F"], is_) if r["bound"] != 0 else None
         if where is None or r["vid"] is None:
@@ -584,7 +594,7 @@ class _FlowPairLossFunction(torch.autograd.Function):
             g_fwd = g_sum if g_fwd is None else g_fwd + g_sum
             g_bwd = g_sum if g_bwd is None else g_bwd + g_sum
         if not ctx.needs_input_grad[2] or (g_fwd is None and g_bwd is None):
-            return (None,) * 17
+            return (None,) * 18
         fim = ctx.saved_tensors[0]
         B2 = fim.shape[0]
         B, dev = B2 // 2, fim.device
@@ -601,7 +611,7 @@ class _FlowPairLossFunction(torch.autograd.Function):
                       _lib.ptr(unit_grad), _lib.ptr(unit_max), _lib.ptr(sums), _lib.ptr(g_fwd), _lib.ptr(g_bwd), height, width,
                       _lib.ptr(grad_cols), B2, V, F0, int(fill_back), is_, eps, _lib.FLAG_OUTPUT_ZEROED if zeroed else 0,
                       textutils.texel_layout_code(), _lib.stream_ptr(dev))
-            return (None, None, grad_cols) + (None,) * 14
+            return (None, None, grad_cols) + (None,) * 15
         fim, tile_hit, wmap, vid, mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums = ctx.saved_tensors
         # scratch of the launch: the masked flow gradient of a workgroup's tiles between its two passes
         scratch = (torch.full((B2, height, width, 2), float("nan"), dtype=torch.float32, device=dev) if DEBUG_POISON_RENDER_OUTPUTS
@@ -611,7 +621,7 @@ class _FlowPairLossFunction(torch.autograd.Function):
                   _lib.ptr(g_bwd), _lib.ptr(mask), _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(occl), _lib.ptr(scratch),
                   height, width, _lib.ptr(grad_cols), B2, V, F0, int(fill_back), is_, eps, thresh,
                   _lib.FLAG_OUTPUT_ZEROED if zeroed else 0, textutils.texel_layout_code(), _lib.stream_ptr(dev))
-        return (None, None, grad_cols) + (None,) * 14
+        return (None, None, grad_cols) + (None,) * 15
 
 
 def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image_ref, image, jitter_mask_ref, jitter_mask,
@@ -662,15 +672,28 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
         return None
     cam = (camintrs[0].to(dev), camintrs[1].to(dev), neurenderer.R.to(dev), neurenderer.t.to(dev), neurenderer.dist_coeffs.to(dev),
            neurenderer.orig_size)
+    cleared_work = None
     if parts:
-        ndc, cols, faces2 = _FlowVertexStageParts.apply(h1, o1, h2, o2, *cam, hand_face, obj_faces)  # (+ the stacked faces)
+        # the render's workspace is allocated here so that the prologue launch can clear the header of its tile list: the
+        # render's per-face pass (whose first thread does that otherwise) then runs inside its binning pass
+        clear16 = None
+        if USE_FUSED_RECORDS and USE_SPARSE_TILES and USE_TILE_LIST:
+            wbytes = int(_lib.load().mr_render_workspace_bytes(2 * B, F, is_))
+            cleared_work = torch.empty((max(wbytes, 8),), dtype=torch.uint8, device=dev)
+            where = _lib.tile_list(cleared_work, 2 * B, F, is_)
+            if where is None:
+                cleared_work = None
+            else:
+                clear16 = where[0]
+        ndc, cols, faces2 = _FlowVertexStageParts.apply(h1, o1, h2, o2, *cam, hand_face, obj_faces, clear16)  # (+ the stacked faces)
     else:
         ndc, cols = _FlowVertexStage.apply(v1, v2, *cam)
         faces2 = _stacked_faces(faces)
     lut = _keep_lut(ignore_face_idxs, dev) if ignore_face_idxs is not None else None
     loss_fwd, loss_bwd, loss_sum, flows, tile_hit = _FlowPairLossFunction.apply(
         ndc, faces2, cols, lut, neurenderer.fill_back, is_, neurenderer.near, neurenderer.far,
-        neurenderer.rasterizer_eps, neurenderer.background_color, H, W, image_ref, image, jitter_mask_ref, jitter_mask, 0.99999)
+        neurenderer.rasterizer_eps, neurenderer.background_color, H, W, image_ref, image, jitter_mask_ref, jitter_mask, 0.99999,
+        cleared_work)
     tiles, _FlowPairLossFunction.last_tiles = _FlowPairLossFunction.last_tiles, None
     flows._hoc_coverage = (tile_hit, is_, flows._version, tiles)
     if with_sum:

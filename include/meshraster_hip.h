@@ -48,6 +48,10 @@ extern "C" {
  * tile list + background stream these entry points use since round 4 where the raster allows it.  Same outputs, bit for
  * bit; A/B profiling and tests only. */
 #define MR_FLAG_TILE_PER_WORKGROUP 8
+/* mr_render_flow_forward: the caller has cleared the 16-byte header of the tile list (mr_render_tile_list's list_header, pure
+ * address arithmetic on the workspace pointer) on the same stream before the call -- mr_flow_pair_prologue_parts does it on
+ * request.  The per-face pass, whose first thread clears it otherwise, then runs inside the binning pass (one launch less). */
+#define MR_FLAG_TILE_LIST_CLEARED 16
 
 /* texel_layout argument of the vertex-colour entry points (mr_render_vc_*, mr_render_flow_*): which vertex's colour the
  * three non-zero texels of the 2x2x2 texture of libyana's batch_vertex_textures hold -- two bits per texel axis,
@@ -328,13 +332,14 @@ MR_API int mr_stack_pair_faces(const int64_t* hand_faces, int hand_batched, cons
                                int32_t* faces_out, int batch_size, int num_hand_faces, int num_obj_faces,
                                mr_stream_t stream);
 /* mr_flow_vertices_parts_forward + mr_stack_pair_faces (vertex_offset = num_verts_a) in ONE launch: the two set-up steps of
- * a frame pair do not depend on each other (ABI 5). */
+ * a frame pair do not depend on each other (ABI 5).  clear16 (nullable, 16-byte aligned): 16 bytes the launch clears -- the
+ * header of the tile list of the render that follows (MR_FLAG_TILE_LIST_CLEARED). */
 MR_API int mr_flow_pair_prologue_parts(const float* verts1a, const float* verts1b, const float* verts2a, const float* verts2b,
                                        int num_verts_a, int num_verts_b, const float* K1, const float* K2, const float* R,
                                        const float* t, const float* dist_coeffs, int cam_batched, float orig_size,
                                        float* ndc1, float* ndc2, float* cols12, float* cols21, const int64_t* hand_faces,
                                        int hand_batched, const int64_t* obj_faces, int32_t* faces_out, int num_hand_faces,
-                                       int num_obj_faces, int batch_size, mr_stream_t stream);
+                                       int num_obj_faces, int batch_size, void* clear16, mr_stream_t stream);
 
 /* MANO linear-blend skinning (manopth ManoLayer.forward as called at
  * manobranch.py:130-136, PCA pose space, arithmetic of SURVEY appendix B.10) and its adjoint.

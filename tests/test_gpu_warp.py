@@ -794,6 +794,71 @@ def test_fused_pair_node_equals_the_composed_path(cuda, monkeypatch, B, is_, H, 
             close(a.cpu().numpy(), b_.cpu().numpy(), 1e-5, 1e-6 * float(b_.abs().max()), what)
 
 
+@pytest.mark.parametrize("B,is_", [(2, 96), (3, 256), (1, 480)])
+def test_per_face_pass_inside_the_binning_pass(cuda, monkeypatch, B, is_):
+    """flow_pair_loss on (hand, object) parts: the pair prologue clears the header of the render's tile list and the render
+    (MR_FLAG_TILE_LIST_CLEARED) computes the face boxes inside its binning kernel instead of a launch of their own -- same
+    losses, flows and coverage bytes bit for bit (vertex gradients to the order of the backward's fp32 atomics) as with the
+    separate per-face pass; the workspace is
+    filled with 0xff bytes first (the list counters must come from the prologue, not from whatever the allocation held)."""
+    from handobjectconsist_amd import _lib
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.warping import opticalflow
+
+    s = synth.random_scene(B, seed=31, image_size=is_)
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
+                   no_light=True, light_intensity_ambient=0.8)
+    im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, is_, is_, 9)]
+    Ks = [t(s["K1"], cuda), t(s["K2"], cuda)]
+    hand_faces = t(s["hand_faces"].astype(np.int64), cuda)
+    obj_faces = t(s["obj_faces"].astype(np.int64)[None].repeat(B, 0), cuda)
+    real_empty = torch.empty
+
+    def dirty_empty(*a, **k):  # uint8 workspaces come back full of 0xff
+        out = real_empty(*a, **k)
+        if out.dtype == torch.uint8 and out.numel() > 4096:
+            out.fill_(255)
+        return out
+
+    flags_seen = []
+    real_call = _lib.call
+
+    def spy(name, *a):
+        if name == "mr_render_flow_forward":  # (`flags` follows the last float argument, eps)
+            flags_seen.append(a[max(i for i, x in enumerate(a) if isinstance(x, float)) + 1])
+        return real_call(name, *a)
+
+    monkeypatch.setattr(_lib, "call", spy)
+
+    def run(fused_records):
+        monkeypatch.setattr(opticalflow, "USE_FUSED_RECORDS", fused_records)
+        monkeypatch.setattr(torch, "empty", dirty_empty)
+        try:
+            h1, o1 = t(s["hand_verts1"], cuda).requires_grad_(True), t(s["obj_verts1"], cuda).requires_grad_(True)
+            res = opticalflow.flow_pair_loss([(h1, o1), (t(s["hand_verts2"], cuda), t(s["obj_verts2"], cuda))], (hand_faces, obj_faces),
+                                             Ks, ren, (is_, is_), im_ref, im, jm_ref, jm, ignore_face_idxs=synth.HAND_IGNORE_FACES)
+            assert res is not None
+            (res[0] * 1.5 + res[1]).sum().backward()
+        finally:
+            monkeypatch.setattr(torch, "empty", real_empty)
+        base = res[2][0]._base
+        hit = base._hoc_coverage[0]
+        words = hit.contiguous().view(torch.int32).view(2 * B, (is_ + 7) // 8, (is_ + 31) // 32).cpu().numpy() != 0
+        yy, xx = np.mgrid[0:is_, 0:is_]
+        defined = torch.from_numpy(words[:, (is_ - 1 - yy) >> 3, xx >> 5]).to(cuda)
+        return res[0].detach(), res[1].detach(), base.detach()[defined], hit.clone(), h1.grad, o1.grad
+
+    a, b_ = run(True), run(False)
+    assert len(flags_seen) == 2 and flags_seen[0] & _lib.FLAG_TILE_LIST_CLEARED and not flags_seen[1] & _lib.FLAG_TILE_LIST_CLEARED
+    for x, y, what in zip(a[:4], b_[:4], ("loss_fwd", "loss_bwd", "flows", "coverage bytes")):
+        assert torch.equal(x, y), what
+    for x, y, what in zip(a[4:], b_[4:], ("d/d hand vertices", "d/d object vertices")):
+        # (the eight workgroups of an image add their table sums to the vertex rows with fp32 atomics: order-dependent last bits)
+        close(x.cpu().numpy(), y.cpu().numpy(), 1e-5, 1e-6 * float(y.abs().max()), what)
+    assert float(a[0].abs().sum()) > 0 and float(a[4].abs().sum()) > 0
+
+
 @pytest.mark.parametrize("B,batched_hand", [(1, False), (3, False), (2, True)])
 def test_pair_prologue_equals_its_two_launches(cuda, B, batched_hand):
     """mr_flow_pair_prologue_parts (vertex stage of the (hand, object) parts + the stacked int32 faces in ONE launch, what
