@@ -120,7 +120,10 @@ FUSED_FWD_PLAIN = "flow_pair_forward_tiles(occlusion + epilogue + pair loss, spa
 # the device kernels behind the groups (names as rocprofv3 prints them)
 ROOF_KERNELS = {ROOF_BWD: ["unit_scatter_tiles_kernel"], ROOF_BWD_R4A: ["pair_scatter_tiles_kernel"],
                 ROOF_BWD_PLAIN: ["scatter_tiles_kernel<true, true>"],
-                ROOF_FWD: ["face_records_kernel<true>", "bin_boxes_kernel", "raster_tile_kernel<true, true>"]}
+                ROOF_FWD: ["face_records_kernel<true>", "bin_boxes_kernel<false>", "raster_tile_kernel<true, true>"]}
+# ... and as the training step launches the same render: the pair prologue has cleared the tile list's header, the per-face
+# pass runs inside the binning kernel (MR_FLAG_TILE_LIST_CLEARED)
+ROOF_KERNELS_IN_STEP = {ROOF_FWD: ["bin_boxes_kernel<true>", "raster_tile_kernel<true, true>"]}
 # compulsory bytes per pixel of a covered tile: face index 4 + vertex ids 12 + sampling weights 12 + ...
 ROOF_BWD_PER_PIXEL = {ROOF_BWD: (36, "... + unit gradient 8"),
                       ROOF_BWD_R4A: (80, "... + three masks 12 + final flow 8 + source 12 + target 12 + two jitter values 8 (its scratch "
@@ -643,9 +646,13 @@ def roofline_block(name, k, pmc, units, in_step=None):
             "frac_algorithmic": k["frac_hbm_peak"], "frac_algorithmic_cache_warm": k["frac_hbm_peak_cache_warm"],
             "launch_ms": k["ms"], "launch_ms_cache_warm": k["ms_cache_warm"],
             "units_per_launch": units, "device_kernels": ROOF_KERNELS[name]}
-    if in_step and all(d in in_step for d in ROOF_KERNELS[name]):
-        us = sum(in_step[d]["median_us"] for d in ROOF_KERNELS[name])
+    step_names = ROOF_KERNELS_IN_STEP.get(name, ROOF_KERNELS[name])
+    if in_step and not all(d in in_step for d in step_names):
+        step_names = ROOF_KERNELS[name]
+    if in_step and all(d in in_step for d in step_names):
+        us = sum(in_step[d]["median_us"] for d in step_names)
         roof.update({"in_step_us": round(us, 2), "frac_in_step": round(roof["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "in_step_kernels": step_names,
                      "in_step_source": "median duration of the kernel(s) inside training steps, rocprofv3 --kernel-trace pass "
                                        "over `bench.py --step-only` run by this process"})
     found = [pmc[d] for d in ROOF_KERNELS[name] if d in pmc]
