@@ -692,6 +692,16 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
+_T0 = time.perf_counter()
+
+
+def _phase(name):
+    """Wall-clock note on stderr (rank 0): how long each leg of a default run takes."""
+    if os.environ.get("RANK", "0") == "0":
+        sys.stderr.write(f"[bench] {time.perf_counter() - _T0:7.1f} s  {name}\n")
+        sys.stderr.flush()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -827,6 +837,7 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
         dist.destroy_process_group()
         return
+    _phase("model built; warm-up steps")
     for i in range(0 if args.hot_only else args.warmup):
         train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan, reducer=reducer)
     torch.cuda.synchronize()
@@ -893,6 +904,7 @@ def main():
             # `l.backward()` would add five device-to-device copies into the leaves' .grad, 12 us that no step contains)
             return torch.autograd.grad(l, hot_leaves, allow_unused=True)
 
+        _phase("timed steps done; hot path")
         hot_ms = event_time_ms(hot, 10, 3)
         # The eager loop above is bound by the HOST once the kernels are this short (~0.58 ms of Python + launch calls per
         # pass against ~0.33 ms of device work; inside a training step the host issues this section while the device is
@@ -921,6 +933,7 @@ def main():
     # the same step with the trunk exactly as stock PyTorch-ROCm runs it (nn.BatchNorm2d / ReLU / MaxPool2d modules,
     # NCHW, MIOpen's default solver choice): what this build's trunk glue kernels + channels-last layout are worth.
     # Informational (single GPU only); `value` above is the default configuration.
+    _phase("hot path done; stock trunk")
     stock = None
     if rank == 0 and world == 1 and not use_dist and not args.hot_only and not args.no_stock_trunk \
             and args.encoder_dtype == "f32":
@@ -956,9 +969,13 @@ def main():
 
     kernels, roof, roof_fwd, cpu, warp_tiles, in_step_line = None, None, None, None, None, None
     if rank == 0 and not args.no_kernel_bench:
+        _phase("stock trunk done; kernel bench")
         kernels = kernel_bench(dev, B, is_, args.kernel_iters)
+        _phase("kernel bench done; PMC passes")
         pmc = {} if (args.no_pmc or world > 1) else pmc_traffic_in_run(args)
+        _phase("PMC passes done; in-step kernel trace")
         in_step = {} if (args.no_pmc or world > 1) else in_step_durations(args)
+        _phase("in-step trace done")
         units = f"{2 * B} renders of {is_}x{is_}, 7104 faces"
         # the raster backward (north star) in the shape the training step launches it: one launch for both frames of
         # the pair, the pair loss's backward and the adjoint of the flow epilogue folded in
@@ -988,6 +1005,7 @@ def main():
             warp_tiles[name] = w
         in_step_line = in_step or None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        _phase("CPU baseline")
         cpu = cpu_baseline(args.cpu_sample, is_, B)
         if (os.cpu_count() or 1) > 8:  # the figure that lines up with BASELINE.md's 8-thread reference measurement
             c8 = cpu_baseline(max(args.cpu_sample // 4, 2), is_, B, threads=8)
