@@ -1,7 +1,8 @@
 """Randomised parity sweeps of the HIP path against the CPU oracle (not collected by pytest: a bug hunt to run
 on the GPU box).  Usage: python tests/fuzz_parity.py [n_cases] [first_seed]  (HOC_FUZZ_RASTER_ONLY=1: the first sweep
 alone; HOC_FUZZ_DEBUG=1: details of non-finite gradients).  Found the NaN-depth point-face bug
-and the collinear-face bounding-box bug; 24 000+ cases clean since."""
+and the collinear-face bounding-box bug, in round 4 that kernel D's strip bookkeeping refused rasters of one or two pixels;
+30 000+ cases clean since (the final build of round 4: 2 500 + 2 500 + 300 ... cases of seed 960000 on, all eight sweeps)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
