@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmeshraster_hip.so")
-ABI_VERSION = 5  # MR_ABI_VERSION of include/meshraster_hip.h
+ABI_VERSION = 6  # MR_ABI_VERSION of include/meshraster_hip.h
 FLAG_REFERENCE_ALGO = 1
 FLAG_SPARSE_TILES = 2
 FLAG_OUTPUT_ZEROED = 4
@@ -45,7 +45,7 @@ SIGNATURES = {
     "mr_flow_vertices_parts_forward": (_I, [_P] * 4 + [_I, _I] + [_P] * 5 + [_I, _F] + [_P] * 4 + [_I, _P]),
     "mr_flow_vertices_parts_backward": (_I, [_P] * 4 + [_I, _I] + [_P] * 8 + [_I, _P]),
     "mr_stack_pair_faces": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
-    "mr_flow_pair_prologue_parts": (_I, [_P] * 4 + [_I, _I] + [_P] * 5 + [_I, _F] + [_P] * 5 + [_I, _P, _P, _I, _I, _I, _P, _P]),
+    "mr_flow_pair_prologue_parts": (_I, [_P] * 4 + [_I, _I] + [_P] * 5 + [_I, _F] + [_P] * 5 + [_I, _P, _P, _I, _I, _I, _P, _L, _P]),
     "mr_mano_workspace_floats": (_L, [_I]),
     "mr_mano_forward": (_I, [_P] * 12 + [_I, _I] + [_P] * 3 + [_I, _P]),
     "mr_mano_backward": (_I, [_P] * 10 + [_I, _I] + [_P] * 5 + [_I, _P]),
@@ -62,6 +62,7 @@ SIGNATURES = {
     "mr_pair_consist_forward": (_I, [_P] * 6 + [_I, _P, _L] + [_P] * 11 + [_I, _I, _I, _F, _P, _P, _I, _P]),
     "mr_pair_consist_backward": (_I, [_P] * 6 + [_I] + [_P] * 5 + [_I, _I, _I, _F, _P, _P, _I, _P, _P]),
     "mr_render_tile_list": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "mr_render_clear_bytes": (_L, [_I, _I, _I]),
     "mr_occlusion_flow_tiles": (_I, [_P] * 4 + [_L] + [_P] * 8 + [_I, _I, _I, _I, _F, _F, _P, _P, _L, _L, _P]),
     "mr_pair_consist_tiles_workspace_bytes": (_L, [_I, _I]),
     "mr_pair_consist_forward_tiles": (_I, [_P] * 6 + [_I, _P, _L, _P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P, _P, _L, _L, _P]),

@@ -126,6 +126,10 @@ struct BinParams {
     uint32_t* bg_ids;        // nullable (dense launches): [B * tiles] receives the global ids of the tiles WITHOUT candidates
     float* zero_fill;        // nullable: cleared by the binning pass (the matching backward's gradient buffer)
     int64_t zero_count;
+    // round 5: `parts` workgroups per image, each binning a contiguous range of the image's faces (see bin_boxes_kernel)
+    int B, parts;
+    int* part_cnt;           // [B, parts, nbins + 4]: a part's raw bin counters + {its large faces, its "everywhere" flag}
+    unsigned* arrive;        // [B] arrival counters of the images' parts; ZERO on entry (per-face pass / the caller's clear)
 };
 
 // Pass A, one thread per REAL face, grid = (ceil(F0 / 256), B): back-face cull + conservative pixel bbox of the
@@ -138,6 +142,7 @@ __global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
     const int b = blockIdx.y;
     const int f0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (p.tlist && b == 0 && f0 == 0) { p.tlist->n_heavy = 0u; p.tlist->n_light = 0u; p.tlist->n_bg = 0u; }  // (this launch precedes the binning pass)
+    if (p.parts > 1 && f0 == 0) p.arrive[b] = 0u;
     if (f0 >= p.F0) return;
     const int is = p.is;
     float f[9];
@@ -205,24 +210,50 @@ __device__ unsigned long long mr_dbg_bin[1024 * 8];  // profiling builds: phase 
 // pass runs inside this kernel -- a thread computes the boxes of its real faces (and their reversed copies) straight into the LDS
 // copy and writes the faces' coordinates; the boxes never exist in global memory.  One launch and one dependent round trip (the
 // boxes' read-back) less per render: 14 + 17.5 -> 21 us for the 2B = 128 meshes of a training pair.
+// PARTS (round 5).  One workgroup per image leaves half the chip idle at the 2B = 128 renders of a training pair and 15 of 16
+// compute units at config 3's 16 renders.  An image is therefore binned by `parts` workgroups, each taking a contiguous range
+// of its faces through the per-face pass, the counting pass and the fill pass; between counting and filling the parts of an
+// image exchange their bin counters through global memory (a part's place in a bin's list = the bin's offset + what the
+// lower parts hold in it), behind a barrier on the image's arrival counter.  All parts of all images are co-resident by
+// construction (launch_bins: B x parts <= compute units, one workgroup fits a compute unit on its own), so the barrier cannot
+// starve; a part that waits for more than ~2 s traps instead of hanging the queue.  The parts of an image run on ONE XCD
+// (workgroup i goes to XCD i % 8): the exchange is L2 traffic.  Part 0 writes the bin headers and the image's tile-list
+// entries; the order of the records inside a bin's list differs from the one-workgroup order -- as it already does from run
+// to run (LDS atomics) -- and the image does not depend on it (z-buffer keys).
 template <bool RECORDS>
 __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     MR_BIN_STAMP(0);
     extern __shared__ int bin_smem[];
-    __shared__ int s_large, s_nlarge, s_lbase, s_hbase, s_bbase, s_everywhere;
+    __shared__ int s_large, s_nlarge, s_lbase, s_hbase, s_bbase, s_everywhere, s_large_before;
     // listed launches: bit 30 of a bin's counter = "a face of the image's large list overlaps this bin" (counts stay far below)
     constexpr int LARGE_BIT = 1 << 30, CNT_MASK = LARGE_BIT - 1;
     __shared__ unsigned long long wsum[BIN_TPB / MR_WAVE];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nbins = p.nbx * p.nby;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.parts;
+    if (p.zero_fill)
+        for (int64_t i = (int64_t)blockIdx.x * BIN_TPB + tid; i < p.zero_count; i += (int64_t)gridDim.x * BIN_TPB) p.zero_fill[i] = 0.0f;
+    int b = blockIdx.x, part = 0;
+    if (K > 1) {  // workgroup -> (image, part): the parts of image b on XCD b % 8
+        const unsigned q = blockIdx.x >> 3;
+        part = (int)(q % (unsigned)K);
+        b = (int)(q / (unsigned)K) * 8 + (int)(blockIdx.x & 7u);
+        if (b >= p.B) return;
+    }
+    const int nbins = p.nbx * p.nby, nbins4 = (nbins + 3) & ~3;
     int* cnt = bin_smem;
-    FaceBox* sbox = reinterpret_cast<FaceBox*>(bin_smem + ((nbins + 3) & ~3));
+    int* before = bin_smem + nbins4;  // K > 1: records the lower parts hold in a bin
+    FaceBox* sbox = reinterpret_cast<FaceBox*>(bin_smem + (K > 1 ? 2 : 1) * nbins4);
     const FaceBox* box_b = p.boxes + (int64_t)b * p.F;
+    // this part's faces: real faces [r0, r0 + nr) and (RECORDS with fill-back) their reversed copies F0 + [r0, r0 + nr), or
+    // (!RECORDS) virtual faces [r0, r0 + nr); local index j < nv -> face fn_of(j)
+    const int nsplit = RECORDS ? p.F0 : p.F;
+    const int r0 = (int)((int64_t)nsplit * part / K), nr = (int)((int64_t)nsplit * (part + 1) / K) - r0;
+    const bool two = RECORDS && p.fill_back != 0;
+    const int nv = two ? 2 * nr : nr;
+    auto fn_of = [&](int j) { return j < nr ? r0 + j : p.F0 + r0 + (j - nr); };
 
     for (int i = tid; i < nbins; i += BIN_TPB) cnt[i] = 0;
-    if (tid == 0) { s_large = 0; s_nlarge = 0; s_everywhere = 0; }
-    if (p.zero_fill)
-        for (int64_t i = (int64_t)b * BIN_TPB + tid; i < p.zero_count; i += (int64_t)gridDim.x * BIN_TPB) p.zero_fill[i] = 0.0f;
+    if (tid == 0) { s_large = 0; s_nlarge = 0; s_everywhere = 0; s_large_before = 0; }
     __syncthreads();
     MR_BIN_STAMP(1);
 
@@ -230,12 +261,11 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         // the per-face pass (face_records_kernel<true>'s arithmetic): indices of REC_PF faces per thread requested together,
         // then their vertices, then the boxes of both orientations into the LDS copy
         constexpr int REC_PF = 4;
-        const bool two = p.fill_back != 0;
-        for (int base = 0; base < p.F0; base += REC_PF * BIN_TPB) {
+        for (int base = 0; base < nr; base += REC_PF * BIN_TPB) {
             int id[REC_PF][3];
 #pragma unroll
             for (int k = 0; k < REC_PF; k++) {
-                const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + min(base + k * BIN_TPB + tid, p.F0 - 1)) * 3;
+                const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + r0 + min(base + k * BIN_TPB + tid, nr - 1)) * 3;
                 id[k][0] = ix[0]; id[k][1] = ix[1]; id[k][2] = ix[2];
             }
             float f[REC_PF][9];
@@ -248,20 +278,20 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
                 }
 #pragma unroll
             for (int k = 0; k < REC_PF; k++) {
-                const int f0 = base + k * BIN_TPB + tid;
-                if (f0 >= p.F0) continue;
+                const int j = base + k * BIN_TPB + tid;
+                if (j >= nr) continue;
                 BoxShared sh;
                 face_box_shared(f[k], p.is, sh);
                 const FaceBox b0 = face_box_orient<false>(f[k], p.is, sh);
-                sbox[f0] = b0;
+                sbox[j] = b0;
                 bool live = b0.x0 <= b0.x1;
                 if (two) {
                     const FaceBox b1 = face_box_orient<true>(f[k], p.is, sh);
-                    sbox[f0 + p.F0] = b1;
+                    sbox[nr + j] = b1;
                     live = live || b1.x0 <= b1.x1;
                 }
                 if (live) {
-                    float4* rv = reinterpret_cast<float4*>(p.rverts + (int64_t)b * p.F0 + f0);
+                    float4* rv = reinterpret_cast<float4*>(p.rverts + (int64_t)b * p.F0 + r0 + j);
                     rv[0] = make_float4(f[k][0], f[k][1], f[k][2], f[k][3]);
                     rv[1] = make_float4(f[k][4], f[k][5], f[k][6], f[k][7]);
                     rv[2] = make_float4(f[k][8], division_safe_face(f[k], p.is) ? 1.0f : 0.0f, 0.0f, 0.0f);
@@ -274,27 +304,27 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     // addresses): one load round trip per BIN_PF x 1024 faces instead of one per trip -- a hand + object mesh (7104
     // virtual faces) is seven trips, i.e. seven dependent round trips of the single workgroup an image has.
     constexpr int BIN_PF = 8;
-    for (int base = 0; base < p.F; base += BIN_PF * BIN_TPB) {
+    for (int base = 0; base < nv; base += BIN_PF * BIN_TPB) {
         FaceBox bxs[BIN_PF];
 #pragma unroll
         for (int k = 0; k < BIN_PF; k++) {
-            const int fc = min(base + k * BIN_TPB + tid, p.F - 1);
-            bxs[k] = RECORDS ? sbox[fc] : box_b[fc];
+            const int jc = min(base + k * BIN_TPB + tid, nv - 1);
+            bxs[k] = RECORDS ? sbox[jc] : box_b[r0 + jc];
         }
 #pragma unroll
         for (int k = 0; k < BIN_PF; k++) {
-            const int fn = base + k * BIN_TPB + tid;
+            const int j = base + k * BIN_TPB + tid;
             const FaceBox bx = bxs[k];
-            if (!RECORDS && fn < p.F && p.lds_boxes) sbox[fn] = bx;
-            if (fn >= p.F || bx.x0 > bx.x1) continue;
+            if (!RECORDS && j < nv && p.lds_boxes) sbox[j] = bx;
+            if (j >= nv || bx.x0 > bx.x1) continue;
             const int bx0 = bx.x0 / TILE_W, bx1 = bx.x1 / TILE_W;
             const int by0 = bx.y0 >> (3 + p.ysh), by1 = bx.y1 >> (3 + p.ysh);
             if ((bx1 - bx0 + 1) * (by1 - by0 + 1) > SMALL_MAX_BINS) {  // large list (filled in pass 2)
+                atomicAdd(&s_nlarge, 1);
                 if (p.tlist) {
                     // ... which only the tiles under the face's box have to walk (round 4; until then one large face made
                     // every tile of its image a listed tile that walks the whole large list -- at 640 x 640, where the 28
                     // wrist-closing faces of a hand span more than 8 bins, 86 000 listed tiles instead of 19 000)
-                    atomicAdd(&s_nlarge, 1);
                     if ((bx1 - bx0 + 1) * (by1 - by0 + 1) * 4 > nbins) s_everywhere = 1;  // (degenerate faces: full-screen boxes)
                     else
                         for (int y = by0; y <= by1; y++)
@@ -309,11 +339,56 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     __syncthreads();
     MR_BIN_STAMP(2);
 
+    const int per = (nbins + BIN_TPB - 1) / BIN_TPB;
+    const int i0 = min(tid * per, nbins), i1 = min(i0 + per, nbins);
+    if (K > 1) {
+        // exchange: publish this part's counters, wait for the image's other parts, turn cnt[] into the image's totals
+        // and before[] into what the lower parts hold in each bin
+        const int pstride = nbins + 4;
+        int* pub = p.part_cnt + ((int64_t)b * K + part) * pstride;
+        for (int i = tid; i < nbins; i += BIN_TPB) pub[i] = cnt[i];
+        if (tid == 0) { pub[nbins] = s_nlarge; pub[nbins + 1] = s_everywhere; }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(&p.arrive[b], 1u);
+            unsigned spins = 0;
+            while (__hip_atomic_load(&p.arrive[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)K) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 24)) __builtin_trap();  // (~2 s: a part that never arrives is a bug, not a wait)
+            }
+        }
+        __syncthreads();
+        __threadfence();
+        const int* all = p.part_cnt + (int64_t)b * K * pstride;
+        for (int i = i0; i < i1; i++) {
+            int tot = 0, lg = 0, bef = 0;
+            for (int k = 0; k < K; k++) {
+                const int raw = __hip_atomic_load(all + (int64_t)k * pstride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tot += raw & CNT_MASK;
+                lg |= raw & LARGE_BIT;
+                bef += k < part ? (raw & CNT_MASK) : 0;
+            }
+            cnt[i] = tot | lg;
+            before[i] = bef;
+        }
+        if (tid == 0) {
+            int nl = 0, ev = 0, lb = 0;
+            for (int k = 0; k < K; k++) {
+                const int n = __hip_atomic_load(all + (int64_t)k * pstride + nbins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ev |= __hip_atomic_load(all + (int64_t)k * pstride + nbins + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                nl += n;
+                lb += k < part ? n : 0;
+            }
+            s_nlarge = nl; s_everywhere = ev; s_large_before = lb;
+        }
+        __syncthreads();
+    }
+    const bool lead = part == 0;  // writes what the image has once: bin headers, tile-list entries, the image header
+
     // exclusive scan of the bin counts (each thread owns a run of consecutive bins); headers out, counters
     // become fill cursors.  The high half of the scanned value counts the bins that hold candidates (every bin,
     // if the image has a large list): the places of the image's entries in the launch's tile list.
-    const int per = (nbins + BIN_TPB - 1) / BIN_TPB;
-    const int i0 = min(tid * per, nbins), i1 = min(i0 + per, nbins);
     const bool all_large = p.tlist && s_nlarge > 0 && s_everywhere != 0;
     unsigned long long local = 0;
     for (int i = i0; i < i1; i++) {
@@ -339,7 +414,7 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         total64 += ws;
     }
     int base = (int)(unsigned)(base64 & 0xffffffffull);
-    if (p.tlist && tid == 0) {
+    if (p.tlist && lead && tid == 0) {
         const unsigned n_ne = (unsigned)(total64 >> 32) & 0xffffu, n_hv = (unsigned)(total64 >> 48);
         s_hbase = (int)atomicAdd(&p.tlist->n_heavy, n_hv);
         s_lbase = (int)atomicAdd(&p.tlist->n_light, n_ne - n_hv);
@@ -350,9 +425,11 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     for (int i = i0; i < i1; i++) {
         const int raw = cnt[i], c = raw & CNT_MASK;
         const bool lg = all_large || (raw & LARGE_BIT);
-        BinHdr h;
-        h.off = (unsigned)base; h.cnt = (unsigned)c;
-        bh[i] = h;
+        if (lead) {
+            BinHdr h;
+            h.off = (unsigned)base; h.cnt = (unsigned)c;
+            bh[i] = h;
+        }
         cnt[i] = base;
         base += c;
         livebits |= ((c > 0 || lg) ? 1u : 0u) << (i - i0);
@@ -360,7 +437,7 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     }
     __syncthreads();
     MR_BIN_STAMP(3);
-    if (p.tlist) {
+    if (p.tlist && lead) {
         // the image's tiles with candidates go to the launch's tile list (a bin IS a tile here: ysh == 0), the
         // others get their (zero) coverage bytes now -- no workgroup is dispatched for them
         const unsigned hv_before = (unsigned)(base64 >> 48), ne_before = (unsigned)(base64 >> 32) & 0xffffu;
@@ -371,7 +448,7 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         for (int i = i0; i < i1; i++) {
             const bool live = (livebits >> (i - i0)) & 1u;
             const unsigned nlarge = ((lgbits >> (i - i0)) & 1u) ? (unsigned)s_nlarge : 0u;
-            // (cnt[] holds the bins' fill cursors = record offsets until pass 2 starts; `base` is the end of this run)
+            // (cnt[] holds the bins' offsets until pass 2 starts; `base` is the end of this run)
             const unsigned off = (unsigned)cnt[i], end = (unsigned)(i + 1 < i1 ? cnt[i + 1] : base);
             const uint4 ent = make_uint4((unsigned)(b * nbins + i), off, end - off, nlarge);
             if (live && end - off + nlarge >= HEAVY_RECS) p.tile_ids[at_h++] = ent;
@@ -379,14 +456,19 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
             else if (p.bg_ids) p.bg_ids[at_b++] = (unsigned)(b * nbins + i);
             else hit32[i] = 0u;
         }
+    }
+    if (p.tlist || K > 1) {
         __syncthreads();  // (pass 2 moves the cursors)
+        if (K > 1)
+            for (int i = i0; i < i1; i++) cnt[i] += before[i];  // this part's place inside each bin's list
+        if (K > 1) __syncthreads();
     }
     MR_BIN_STAMP(4);
     if (p.dbg & 2) return;
 
     // pass 2: fill
     FaceRec* recs_b = p.recs + (int64_t)b * REC_CAP * p.F;
-    FaceRec* large_b = recs_b + (int64_t)SMALL_MAX_BINS * p.F;
+    FaceRec* large_b = recs_b + (int64_t)SMALL_MAX_BINS * p.F + s_large_before;
     auto fill_face = [&](const int fn, const FaceBox bx) __attribute__((always_inline)) {
         if (bx.x0 > bx.x1) return;
         FaceRec rec;
@@ -403,18 +485,17 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
                 for (int x = bx0; x <= bx1; x++) recs_b[atomicAdd(&cnt[y * p.nbx + x], 1)] = rec;
         }
     };
-    // (two loops, not one over `lds_boxes ? sbox[fn] : box_b[fn]`: the merged pointer is a generic one, and every box
+    // (two loops, not one over `lds_boxes ? sbox[j] : box_b[fn]`: the merged pointer is a generic one, and every box
     // then costs two dependent FLAT loads with a full wait each, also when it sits in LDS)
     if (p.lds_boxes) {
-        for (int fn = tid; fn < p.F; fn += BIN_TPB) fill_face(fn, sbox[fn]);
+        for (int j = tid; j < nv; j += BIN_TPB) fill_face(fn_of(j), sbox[j]);
     } else {
-        for (int fn = tid; fn < p.F; fn += BIN_TPB) fill_face(fn, box_b[fn]);
+        for (int j = tid; j < nv; j += BIN_TPB) fill_face(fn_of(j), box_b[fn_of(j)]);
     }
-    __syncthreads();
     MR_BIN_STAMP(5);
-    if (tid == 0) {
+    if (lead && tid == 0) {
         ImageHdr h;
-        h.n_live = 0; h.n_large = s_large;
+        h.n_live = 0; h.n_large = s_nlarge;
 #pragma unroll
         for (int k = 0; k < 6; k++) h.pad[k] = 0;
         p.hdrs[b] = h;
@@ -1154,8 +1235,29 @@ __global__ void __launch_bounds__(256) face_inv_map_kernel(const float* __restri
 // | TileList | [B * tiles] tile ids    (every byte the tile kernel reads is written by the two setup kernels: no memset)
 struct WorkLayout {
     int nbx, nby, ysh;
-    size_t off_bins, off_boxes, off_recs, off_rverts, off_tlist, off_tile_ids, off_bg, total;
+    int parts;  // workgroups per image of the binning pass (bin_boxes_kernel, PARTS)
+    size_t off_bins, off_boxes, off_recs, off_rverts, off_tlist, off_arrive, off_tile_ids, off_bg, off_part_cnt, total;
 };
+
+// Workgroups per image of the binning pass: the largest power of two (<= 16) that keeps B x parts within the device's
+// compute units -- every workgroup of the launch resident at once, which the parts' barrier relies on -- and leaves a part
+// at least 256 faces.
+static int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
+    }
+    return cus[dev] > 0 ? cus[dev] : 0;
+}
+constexpr int MAX_PARTS = 16, MAX_PART_CUS = 256;
+static int bin_parts(int B, int F, int cus) {
+    int k = 1;
+    while (k < MAX_PARTS && (int64_t)B * k * 2 <= cus && F / (k * 2) >= 256) k *= 2;
+    return k;
+}
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -1171,9 +1273,14 @@ static WorkLayout work_layout(int B, int F, int is) {
     w.off_recs = w.off_boxes + align256((size_t)B * F * sizeof(FaceBox));
     w.off_rverts = w.off_recs + align256((size_t)B * REC_CAP * F * sizeof(FaceRec));
     w.off_tlist = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (VC needs F / 2 of it with fill-back)
-    w.off_tile_ids = w.off_tlist + align256(sizeof(TileList));
+    // (the images' arrival counters sit right behind the list header: ONE region for the caller of MR_FLAG_TILE_LIST_CLEARED to clear)
+    w.off_arrive = w.off_tlist + align256(sizeof(TileList));
+    w.off_tile_ids = w.off_arrive + align256((size_t)B * sizeof(unsigned));
     w.off_bg = w.off_tile_ids + align256((size_t)2 * B * tiles_x * tiles_y * sizeof(uint4));  // heavy part | light part
-    w.total = w.off_bg + align256((size_t)B * tiles_x * tiles_y * sizeof(uint32_t));  // dense listed launches: ids of the tiles off the list
+    w.off_part_cnt = w.off_bg + align256((size_t)B * tiles_x * tiles_y * sizeof(uint32_t));  // dense listed launches: ids of the tiles off the list
+    // (sized for a 256-CU device, the most launch_bins assumes: the layout must not depend on the device at hand)
+    w.parts = bin_parts(B, F, MAX_PART_CUS);
+    w.total = w.off_part_cnt + (w.parts > 1 ? align256((size_t)B * w.parts * (w.nbx * w.nby + 4) * sizeof(int)) : 0);
     return w;
 }
 
@@ -1207,8 +1314,15 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     bp.rverts = (RecVerts*)(base + w.off_rverts);
     bp.F = F; bp.is = is; bp.nbx = w.nbx; bp.nby = w.nby; bp.ysh = w.ysh;
     const int nbins = w.nbx * w.nby;
-    size_t lds = (size_t)((nbins + 3) & ~3) * sizeof(int);
-    const size_t box_lds = (size_t)F * sizeof(FaceBox);
+    // parts per image (bin_boxes_kernel, PARTS): B x parts workgroups, all resident at once; dbg 32: one workgroup per image
+    int parts = (bp.dbg & 32) ? 1 : bin_parts(B, F, std::min(device_cus(), MAX_PART_CUS));
+    if (parts > w.parts) parts = w.parts;
+    bp.B = B; bp.parts = parts;
+    bp.part_cnt = (int*)(base + w.off_part_cnt);
+    bp.arrive = (unsigned*)(base + w.off_arrive);
+    size_t lds = (size_t)((nbins + 3) & ~3) * sizeof(int) * (parts > 1 ? 2 : 1);
+    // (boxes of the largest part: its share of the real faces in both orientations, or of the virtual faces)
+    const size_t box_lds = (size_t)((F + parts - 1) / parts + 2) * sizeof(FaceBox);
     bp.lds_boxes = (lds + box_lds <= 152 * 1024) ? 1 : 0;
     if (bp.lds_boxes) lds += box_lds;
     fp.hdrs = bp.hdrs; fp.bins = bp.bins; fp.recs = bp.recs; fp.rverts = bp.rverts;
@@ -1239,8 +1353,10 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
         if (e != hipSuccess) return (int)e;
         allowed = 152 * 1024;
     }
-    if (fused_records) hipLaunchKernelGGL(bin_boxes_kernel<true>, dim3((unsigned)B), dim3(BIN_TPB), lds, s, bp);
-    else hipLaunchKernelGGL(bin_boxes_kernel<false>, dim3((unsigned)B), dim3(BIN_TPB), lds, s, bp);
+    // (parts > 1: workgroup i = part (i / 8) % parts of image (i / 8 / parts) * 8 + i % 8 -- an image's parts on one XCD)
+    const unsigned grid = parts > 1 ? (unsigned)((B + 7) / 8) * 8u * (unsigned)parts : (unsigned)B;
+    if (fused_records) hipLaunchKernelGGL(bin_boxes_kernel<true>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
+    else hipLaunchKernelGGL(bin_boxes_kernel<false>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1317,6 +1433,12 @@ extern "C" int mr_selftest_division(const float* a, const float* b, float* refin
 extern "C" int64_t mr_render_workspace_bytes(int batch_size, int num_faces, int image_size) {
     if (batch_size < 0 || num_faces < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
     return (int64_t)work_layout(batch_size, num_faces, image_size).total;
+}
+
+extern "C" int64_t mr_render_clear_bytes(int batch_size, int num_faces, int image_size) {
+    if (batch_size < 0 || num_faces < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
+    const WorkLayout w = work_layout(batch_size, num_faces, image_size);
+    return (int64_t)(w.off_tile_ids - w.off_tlist);  // list header + the images' arrival counters (a multiple of 256)
 }
 
 extern "C" int mr_render_tile_list(const void* workspace, int batch_size, int num_faces, int image_size,
@@ -1405,6 +1527,7 @@ extern "C" int mr_render_forward(const float* faces, const float* textures, cons
     FwdParams p{};
     BinParams bp{};
     bp.faces = faces; bp.F0 = num_faces;
+    bp.dbg = (flags >> 24) & 0xff;
     const bool dense_list = dense_list_ok(batch_size, num_faces, image_size, face_inv_map, flags);
     int rc = (flags & MR_FLAG_REFERENCE_ALGO) ? MR_OK
                                               : launch_bins<false>(bp, p, workspace, batch_size, num_faces, image_size, s, nullptr, dense_list);
@@ -1471,7 +1594,7 @@ extern "C" int mr_render_vc_forward(const float* verts, const int32_t* faces_idx
     FwdParams p{};
     BinParams bp{};
     bp.verts = verts; bp.fidx = faces_idx; bp.V = num_verts; bp.F0 = num_faces; bp.fill_back = fill_back;
-    bp.dbg = flags >> 24;
+    bp.dbg = (flags >> 24) & 0xff;
     if (batch_size > 65535) return MR_ERR_BADARG;
     const bool dense_list = dense_list_ok(batch_size, F, image_size, nullptr, flags);
     const int rc = launch_bins<true>(bp, p, workspace, batch_size, F, image_size, s, nullptr, dense_list);
@@ -1527,7 +1650,7 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
     FwdParams p{};
     BinParams bp{};
     bp.verts = verts; bp.fidx = faces_idx; bp.V = num_verts; bp.F0 = num_faces; bp.fill_back = fill_back;
-    bp.dbg = flags >> 24;
+    bp.dbg = (flags >> 24) & 0xff;
     bp.zero_fill = zero_fill_count > 0 ? zero_fill : nullptr; bp.zero_count = zero_fill_count;
     if ((flags & MR_FLAG_SPARSE_TILES) && !tile_hit) return MR_ERR_BADARG;
     const bool listed = (flags & MR_FLAG_SPARSE_TILES) && tile_bound != 0;

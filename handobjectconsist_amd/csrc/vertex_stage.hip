@@ -174,9 +174,11 @@ __global__ void __launch_bounds__(256) stack_pair_faces_kernel(StackFacesParams 
 // both set-up steps of a frame pair in ONE launch (mr_flow_pair_prologue_parts): the first `vertex_blocks` workgroups of a
 // row project vertices, the others stack faces -- the two do not depend on each other
 __global__ void __launch_bounds__(256) pair_prologue_kernel(VertexStageParams p, StackFacesParams q, int vertex_blocks,
-                                                            uint4* __restrict__ clear16) {
-    // (the header of the render's tile list, for MR_FLAG_TILE_LIST_CLEARED: the render that follows on this stream adds to it)
-    if (clear16 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *clear16 = make_uint4(0u, 0u, 0u, 0u);
+                                                            uint4* __restrict__ clear16, int clear_words) {
+    // (the header of the render's tile list and the arrival counters behind it, for MR_FLAG_TILE_LIST_CLEARED: the render
+    // that follows on this stream adds to them)
+    if (clear16 && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < clear_words; i += blockDim.x) clear16[i] = make_uint4(0u, 0u, 0u, 0u);
     if ((int)blockIdx.x < vertex_blocks) flow_vertices_forward_body(p, blockIdx.x);
     else stack_pair_faces_body(q, (int)blockIdx.x - vertex_blocks);
 }
@@ -275,7 +277,8 @@ extern "C" int mr_flow_pair_prologue_parts(const float* verts1a, const float* ve
                                            const float* t, const float* dist_coeffs, int cam_batched, float orig_size,
                                            float* ndc1, float* ndc2, float* cols12, float* cols21, const int64_t* hand_faces,
                                            int hand_batched, const int64_t* obj_faces, int32_t* faces_out, int num_hand_faces,
-                                           int num_obj_faces, int batch_size, void* clear16, mr_stream_t stream) {
+                                           int num_obj_faces, int batch_size, void* clear16, int64_t clear_bytes,
+                                           mr_stream_t stream) {
     if (batch_size < 0 || num_verts_a < 0 || num_verts_b <= 0 || !(orig_size > 0.0f) || num_hand_faces < 0 || num_obj_faces < 0)
         return MR_ERR_BADARG;
     if (batch_size == 0) return MR_OK;
@@ -291,9 +294,9 @@ extern "C" int mr_flow_pair_prologue_parts(const float* verts1a, const float* ve
     const StackFacesParams q{hand_faces, hand_batched ? (int64_t)num_hand_faces * 3 : (int64_t)0, obj_faces, num_verts_a, faces_out,
                              batch_size, num_hand_faces, num_obj_faces};
     const int vb = (V + 255) / 256, fb = (n + 255) / 256;
-    if (((uintptr_t)clear16 & 15u) != 0) return MR_ERR_BADARG;
+    if (((uintptr_t)clear16 & 15u) != 0 || clear_bytes < 0 || (clear_bytes & 15) != 0 || clear_bytes > (1 << 24)) return MR_ERR_BADARG;
     hipLaunchKernelGGL(pair_prologue_kernel, dim3((unsigned)(vb + fb), (unsigned)batch_size), dim3(256), 0, (hipStream_t)stream,
-                       p, q, vb, (uint4*)clear16);
+                       p, q, vb, clear_bytes > 0 ? (uint4*)clear16 : nullptr, (int)(clear_bytes / 16));
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

@@ -167,8 +167,9 @@ class _FlowVertexStageParts(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v1a, v1b, v2a, v2b, K1, K2, R, t, dist, orig_size, hand_face=None, obj_faces=None, clear16=None):
         """``hand_face`` / ``obj_faces`` given: the stacked int32 faces of the pair (``_stack_pair_faces``) come out of the SAME
-        launch as a third output (mr_flow_pair_prologue_parts); ``clear16``: address of 16 bytes that launch clears (the header of
-        the tile list of the render that follows on this stream, ``_lib.FLAG_TILE_LIST_CLEARED``)."""
+        launch as a third output (mr_flow_pair_prologue_parts); ``clear16``: ``(address, bytes)`` of a region that launch clears
+        (the header of the tile list of the render that follows on this stream + the arrival counters of its binning pass:
+        ``mr_render_clear_bytes``, ``_lib.FLAG_TILE_LIST_CLEARED``)."""
         ctx.set_materialize_grads(False)
         parts = [_lib.contig(x.detach()) for x in (v1a, v1b, v2a, v2b)]
         k1, k2 = _lib.contig(K1.detach()), _lib.contig(K2.detach())
@@ -195,8 +196,9 @@ class _FlowVertexStageParts(torch.autograd.Function):
             raise ValueError("expected object faces [B,Fo,3]")
         Fh, Fo = hf.shape[-2], of.shape[1]
         faces2 = torch.empty((2 * B, Fh + Fo, 3), dtype=torch.int32, device=parts[0].device)
+        clear_ptr, clear_bytes = clear16 if clear16 is not None else (None, 0)
         _lib.call("mr_flow_pair_prologue_parts", *head, _lib.ptr(hf), int(batched), _lib.ptr(of), _lib.ptr(faces2), Fh, Fo, B,
-                  clear16, _lib.stream_ptr(parts[0].device))
+                  clear_ptr, int(clear_bytes), _lib.stream_ptr(parts[0].device))
         ctx.mark_non_differentiable(ndc, faces2)
         return ndc, cols, faces2
 
@@ -684,7 +686,7 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
             if where is None:
                 cleared_work = None
             else:
-                clear16 = where[0]
+                clear16 = (where[0], int(_lib.load().mr_render_clear_bytes(2 * B, F, is_)))
         ndc, cols, faces2 = _FlowVertexStageParts.apply(h1, o1, h2, o2, *cam, hand_face, obj_faces, clear16)  # (+ the stacked faces)
     else:
         ndc, cols = _FlowVertexStage.apply(v1, v2, *cam)

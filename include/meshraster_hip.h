@@ -48,9 +48,9 @@ extern "C" {
  * tile list + background stream these entry points use since round 4 where the raster allows it.  Same outputs, bit for
  * bit; A/B profiling and tests only. */
 #define MR_FLAG_TILE_PER_WORKGROUP 8
-/* mr_render_flow_forward: the caller has cleared the 16-byte header of the tile list (mr_render_tile_list's list_header, pure
- * address arithmetic on the workspace pointer) on the same stream before the call -- mr_flow_pair_prologue_parts does it on
- * request.  The per-face pass, whose first thread clears it otherwise, then runs inside the binning pass (one launch less). */
+/* mr_render_flow_forward: the caller has cleared the first mr_render_clear_bytes(...) bytes at the tile list's header
+ * (mr_render_tile_list's list_header, pure address arithmetic on the workspace pointer: the list counters and the arrival
+ * counters of the binning pass) on the same stream before the call -- mr_flow_pair_prologue_parts does it on request.  The per-face pass, whose first thread clears it otherwise, then runs inside the binning pass (one launch less). */
 #define MR_FLAG_TILE_LIST_CLEARED 16
 
 /* texel_layout argument of the vertex-colour entry points (mr_render_vc_*, mr_render_flow_*): which vertex's colour the
@@ -76,8 +76,10 @@ typedef void* mr_stream_t;
  *    (the warp half of the training path over the render's tile list: the sparse contract, round 4),
  *    mr_flow_pair_{forward,backward}_tiles (the same fused into one forward and one backward launch);
  * 5: mr_flow_pair_forward_grad_tiles / mr_flow_pair_backward_unit_tiles (the pair loss's gradient formed by the forward
- *    launch); mr_pair_consist_tiles_workspace_bytes grows to three words per tile. */
-#define MR_ABI_VERSION 5
+ *    launch); mr_pair_consist_tiles_workspace_bytes grows to three words per tile;
+ * 6: mr_render_clear_bytes; MR_FLAG_TILE_LIST_CLEARED covers that many bytes (list header + the arrival counters of the
+ *    binning pass's workgroups, several per image since round 5); mr_flow_pair_prologue_parts takes clear_bytes. */
+#define MR_ABI_VERSION 6
 MR_API int mr_abi_version(void);
 /* 1 if the calling thread's CURRENT HIP device is a gfx950, else 0.
  * Device contract of every entry point below: kernels are launched on the calling thread's current HIP
@@ -332,14 +334,16 @@ MR_API int mr_stack_pair_faces(const int64_t* hand_faces, int hand_batched, cons
                                int32_t* faces_out, int batch_size, int num_hand_faces, int num_obj_faces,
                                mr_stream_t stream);
 /* mr_flow_vertices_parts_forward + mr_stack_pair_faces (vertex_offset = num_verts_a) in ONE launch: the two set-up steps of
- * a frame pair do not depend on each other (ABI 5).  clear16 (nullable, 16-byte aligned): 16 bytes the launch clears -- the
- * header of the tile list of the render that follows (MR_FLAG_TILE_LIST_CLEARED). */
+ * a frame pair do not depend on each other (ABI 5).  clear16 (nullable, 16-byte aligned) / clear_bytes (a
+ * multiple of 16): a region the launch clears -- mr_render_clear_bytes at the header of the tile list of the render that
+ * follows (MR_FLAG_TILE_LIST_CLEARED). */
 MR_API int mr_flow_pair_prologue_parts(const float* verts1a, const float* verts1b, const float* verts2a, const float* verts2b,
                                        int num_verts_a, int num_verts_b, const float* K1, const float* K2, const float* R,
                                        const float* t, const float* dist_coeffs, int cam_batched, float orig_size,
                                        float* ndc1, float* ndc2, float* cols12, float* cols21, const int64_t* hand_faces,
                                        int hand_batched, const int64_t* obj_faces, int32_t* faces_out, int num_hand_faces,
-                                       int num_obj_faces, int batch_size, void* clear16, mr_stream_t stream);
+                                       int num_obj_faces, int batch_size, void* clear16, int64_t clear_bytes,
+                                       mr_stream_t stream);
 
 /* MANO linear-blend skinning (manopth ManoLayer.forward as called at
  * manobranch.py:130-136, PCA pose space, arithmetic of SURVEY appendix B.10) and its adjoint.
@@ -529,6 +533,8 @@ MR_API int mr_pair_consist_backward(const float* flow12, const float* flow21, co
  * entry point's (32 x 8 instead of 64 x 4 blocks): sums agree to fp32 rounding, not bit for bit.  No debug outputs. */
 MR_API int mr_render_tile_list(const void* workspace, int batch_size, int num_faces, int image_size,
                                const void** list_header, const void** list_entries, int64_t* list_capacity);
+/* Bytes at list_header a caller of MR_FLAG_TILE_LIST_CLEARED has to clear (a multiple of 16; sizes only, no device). */
+MR_API int64_t mr_render_clear_bytes(int batch_size, int num_faces, int image_size);
 MR_API int mr_occlusion_flow_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
                                    const float* flow21, int64_t flow_bstride, const float* flow12_scale,
                                    const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,

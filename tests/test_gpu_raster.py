@@ -1074,3 +1074,64 @@ def test_dense_forwards_over_the_tile_list_equal_one_workgroup_per_tile(cuda, B,
                 poison = -7 if name == "face_index_map" else torch.tensor(float("nan")).view(torch.int32).item()
                 assert int((b_ == poison).sum()) == 0, f"{name}: unwritten pixels (vertex colours: {vc})"
         assert int((new[3] >= 0).sum()) > 100
+
+
+FLAG_ONE_WORKGROUP_PER_IMAGE = 32 << 24  # (profiling / A-B bit of the binning pass: raster_fwd.hip, launch_bins)
+
+
+@pytest.mark.parametrize("B,is_", [(2, 256), (13, 96), (40, 64), (3, 480)])
+def test_binning_pass_in_parts_equals_one_workgroup_per_image(cuda, B, is_):
+    """Round 5: an image is binned by several workgroups (a contiguous range of its faces each; they exchange their bin
+    counters behind a barrier on the image's arrival counter).  Every output byte of the listed flow-mode render, of the
+    dense vertex-colour render and of the generic render and the reported tile-list length equal the one-workgroup-per-image pass, on workspaces full of 0xff (the arrival counters must come from
+    the per-face pass, not from the allocation); batch sizes that are no multiple of 8 leave surplus workgroups."""
+    from handobjectconsist_amd import _lib
+    from handobjectconsist_amd.neurender import nr_ops
+    from handobjectconsist_amd.utils import textutils
+
+    d = _vc_abi_case(cuda, B, is_, 57)
+    P, st = _lib.ptr, _lib.stream_ptr(cuda)
+    f32 = dict(dtype=torch.float32, device=cuda)
+    V, F0 = d["V"], d["F0"]
+    assert 2 * F0 >= 512  # (enough faces for more than one part)
+    bg = torch.tensor([0.25, -0.5, 0.75], **f32)
+    wbytes = int(_lib.load().mr_render_workspace_bytes(B, 2 * F0, is_))
+    word = torch.zeros(1, dtype=torch.int32).pin_memory()
+    fidx64 = d["fidx"].long()
+    tex = textutils.batch_vertex_textures(fidx64, d["cols"])
+    faces = nr_ops.vertices_to_faces(d["v"], torch.cat((fidx64, fidx64.flip(-1)), 1)).contiguous()
+    tex2 = torch.cat((tex, tex.permute(0, 1, 4, 3, 2, 5)), 1).contiguous()
+
+    def run(kind, flags):
+        rgb = torch.full((B, 3, is_, is_), float("nan"), **f32)
+        alpha, mask, depth = (torch.full((B, is_, is_), float("nan"), **f32) for _ in range(3))
+        wmap = torch.full((B, is_, is_, 3), float("nan"), **f32)
+        fim = torch.full((B, is_, is_), -7, dtype=torch.int32, device=cuda)
+        vid = torch.full((B, is_, is_, 3), -7, dtype=torch.int32, device=cuda)
+        hit = torch.full((B, (is_ + 7) // 8, (is_ + 31) // 32, 4), 9, dtype=torch.uint8, device=cuda)
+        work = torch.full((wbytes,), 0xFF, dtype=torch.uint8, device=cuda)
+        word[0] = -1
+        if kind == "flow":
+            _lib.call("mr_render_flow_forward", P(d["v"]), P(d["fidx"]), P(d["cols"]), P(bg), 0, None, 0, 0.99999, P(rgb), P(alpha),
+                      P(mask), None, P(wmap), P(fim), P(hit), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3,
+                      _lib.FLAG_SPARSE_TILES | flags, P(vid), -1, P(word), None, 0, 0, st)
+        elif kind == "vc":
+            _lib.call("mr_render_vc_forward", P(d["v"]), P(d["fidx"]), P(d["cols"]), P(bg), 0, P(rgb), P(alpha), P(depth), P(fim),
+                      P(wmap), P(work), wbytes, B, V, F0, 1, is_, 0.1, 100.0, 1e-3, 1, 1, 1, flags, 0, st)
+        else:
+            _lib.call("mr_render_forward", P(faces), P(tex2), P(bg), 0, P(rgb), P(alpha), P(depth), P(fim), P(wmap), None, P(work),
+                      wbytes, B, 2 * F0, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, flags, st)
+        torch.cuda.synchronize()
+        outs = [x.view(torch.int32) if x.dtype == torch.float32 else x for x in (rgb, alpha, mask, depth, wmap, fim, vid, hit)]
+        return outs, int(word[0])
+
+    for kind in ("flow", "vc", "generic"):
+        one, n_one = run(kind, FLAG_ONE_WORKGROUP_PER_IMAGE)
+        for _ in range(2):  # (twice: the second call finds the first one's counters in a REUSED allocation)
+            parts, n_parts = run(kind, 0)
+            for a, b_, name in zip(one, parts, ("rgb", "alpha", "mask", "depth", "weights", "face_index_map", "vertex ids", "coverage")):
+                assert torch.equal(a, b_), f"{name} differs ({kind})"
+            assert n_one == n_parts
+        assert int((one[5] >= 0).sum()) > 100
+        if kind == "flow":
+            assert n_one > 8
