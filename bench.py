@@ -58,7 +58,8 @@ def parse():
                         "autocast, heads / MANO / render / warp stay fp32 -- reported with dtype 'bf16+f32'")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-bench", action="store_true")
-    p.add_argument("--no-stock-trunk", action="store_true", help="skip the informational run with the stock trunk modules")
+    p.add_argument("--no-stock-trunk", action="store_true", help="skip the run with the stock trunk modules (the north-star-conformant figure)")
+    p.add_argument("--stock-trunk-nchw", action="store_true", help="also time the stock modules in NCHW without solver search (rounds 1-4's leg)")
     p.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample")
     p.add_argument("--kernel-iters", type=int, default=50)
     p.add_argument("--kernels-only", action="store_true", help="only the per-kernel benchmark (profiling aid)")
@@ -69,6 +70,8 @@ def parse():
     p.add_argument("--step-only", action="store_true",
                    help="only the timed training steps (no hot-path / stock-trunk / kernel / CPU legs): what the in-run "
                         "rocprofv3 --kernel-trace pass behind roofline.frac_in_step profiles")
+    p.add_argument("--eager-step", action="store_true",
+                   help="issue every step's launches from the host (rounds 1-4) instead of replaying the captured step (hipGraph)")
     p.add_argument("--reducer-ab", type=int, default=0, metavar="PAIRS",
                    help="A/B inside ONE process (one model, one set of MIOpen / TunableOp solver choices): PAIRS x "
                         "(--steps plain steps, then --steps steps through the RCCL process group + bucketed gradient "
@@ -503,41 +506,56 @@ def cpu_baseline(B_sample, is_, B_full, threads=None):
     """The CPU oracle (oracle/, a port -- the reference has no CPU render path) on a
     bounded sample of the hot path: 2 renders + flow masks + occlusion + pair loss forward, and
     the texture / flow backward; extrapolated linearly in the batch size (images are independent).
-    The rasteriser (kernels A, B, C, E) is C + OpenMP over batch x rows with `threads` threads; the warp /
-    occlusion / pair-loss half is single-threaded numpy (oracle/warp_ref.py)."""
+    BOTH halves use the stated threads (round 5): the sample is cut into per-image tasks run by a thread pool (numpy and
+    the ctypes calls release the GIL); inside a task the rasteriser (kernels A, B, C, E: C + OpenMP over rows) gets
+    threads // tasks OpenMP threads, the warp / occlusion / pair-loss half (oracle/warp_ref.py) is numpy on the task's
+    thread.  `cores` = tasks x OpenMP threads per task, the threads that actually work."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from handobjectconsist_amd.utils import synth
     from oracle import raster_ref as R
     from oracle import warp_ref as W
 
     threads = threads or os.cpu_count() or 1
+    n_tasks = max(1, min(B_sample, threads))
+    omp = max(1, threads // n_tasks)
     s = synth.random_scene(B_sample, seed=0, image_size=is_)
-    kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
-              dist_coeffs=np.zeros((1, 5), np.float32), orig_size=is_, image_size=is_, anti_aliasing=False,
-              near=0.1, far=100, eps=1e-3, num_threads=threads)
     im_ref, im, jm_ref, jm = synth.random_images(B_sample, is_, is_, 0)
     R.lib()
-    kw["keep_saved"] = True
+    bounds = [B_sample * i // n_tasks for i in range(n_tasks + 1)]
+
+    def task(i):
+        sl = slice(bounds[i], bounds[i + 1])
+        kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
+                  dist_coeffs=np.zeros((1, 5), np.float32), orig_size=is_, image_size=is_, anti_aliasing=False,
+                  near=0.1, far=100, eps=1e-3, num_threads=omp, keep_saved=True)
+        flows, renders = W.get_opticalflow(R, [s["verts1"][sl], s["verts2"][sl]], s["faces"][sl], [s["K1"][sl], s["K2"][sl]], kw,
+                                           orig_img_size=(is_, is_), ignore_face_idxs=synth.HAND_IGNORE_FACES,
+                                           return_renders=True)
+        W.pair_consist(flows, im_ref[sl], im[sl], jm_ref[sl], jm[sl], True)
+        gl = np.full((bounds[i + 1] - bounds[i],), 1.0 / B_sample, np.float32)
+        gflows = W.pair_consist_grad(flows, im_ref[sl], im[sl], jm_ref[sl], jm[sl], gl, True)
+        # texture backward of the two renders (kernel E; training mode = detach_renders)
+        for ro, g in zip(renders, gflows):
+            sv = ro["_saved"]
+            g_rgb = np.zeros_like(sv["rgb_map"])
+            g_rgb[..., :2] = g[:, ::-1]
+            R.backward_textures(sv["face_index_map"], sv["sampling_weight_map"], sv["sampling_index_map"], g_rgb,
+                                sv["faces"].shape[1], 2)
+
     t0 = time.perf_counter()
-    flows, renders = W.get_opticalflow(R, [s["verts1"], s["verts2"]], s["faces"], [s["K1"], s["K2"]], kw,
-                                       orig_img_size=(is_, is_), ignore_face_idxs=synth.HAND_IGNORE_FACES,
-                                       return_renders=True)
-    W.pair_consist(flows, im_ref, im, jm_ref, jm, True)
-    gl = np.full((B_sample,), 1.0 / B_sample, np.float32)
-    gflows = W.pair_consist_grad(flows, im_ref, im, jm_ref, jm, gl, True)
-    # texture backward of the two renders (kernel E; training mode = detach_renders)
-    for ro, g in zip(renders, gflows):
-        sv = ro["_saved"]
-        g_rgb = np.zeros_like(sv["rgb_map"])
-        g_rgb[..., :2] = g[:, ::-1]
-        R.backward_textures(sv["face_index_map"], sv["sampling_weight_map"], sv["sampling_index_map"], g_rgb,
-                            sv["faces"].shape[1], 2)
+    if n_tasks == 1:
+        task(0)
+    else:
+        with ThreadPoolExecutor(max_workers=n_tasks) as pool:
+            list(pool.map(task, range(n_tasks)))
     dt = time.perf_counter() - t0
     sec_per_iter = dt * (B_full / B_sample)
-    return {"value": round(1.0 / sec_per_iter, 6), "unit": "iters/s", "cores": threads, "kind": "port",
+    return {"value": round(1.0 / sec_per_iter, 6), "unit": "iters/s", "cores": n_tasks * omp, "kind": "port",
             "sample": f"hot path only (2 renders fwd, flow masks, occlusion, pair loss fwd+bwd, texture bwd; encoder "
                       f"and optimiser excluded), B={B_sample} of {B_full} at {is_}x{is_}, {dt:.1f} s measured, "
-                      f"extrapolated x{B_full // B_sample}; rasteriser = C/OpenMP on {threads} threads, warp / occlusion / "
-                      f"pair loss = single-threaded numpy"}
+                      f"extrapolated x{B_full / B_sample:g}; {n_tasks} per-image tasks on a thread pool x {omp} OpenMP threads in "
+                      f"the C rasteriser; warp / occlusion / pair loss = numpy inside the tasks"}
 
 
 def pmc_traffic_in_run(args, timeout=420):
@@ -605,7 +623,8 @@ def in_step_durations(args, timeout=420):
         return {}
     tmp = tempfile.mkdtemp(prefix="hoc_step_", dir="/tmp")
     cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-           "--step-only", "--steps", "6", "--warmup", "3", "--batch", str(args.batch), "--image-size", str(args.image_size)]
+           "--step-only", "--eager-step", "--steps", "6", "--warmup", "3", "--batch", str(args.batch), "--image-size",
+           str(args.image_size)]  # (eager: the kernels are the replayed step's, and every profiler version lists them)
     if args.image_height:
         cmd += ["--image-height", str(args.image_height)]
     try:
@@ -793,7 +812,13 @@ def main():
     # trainmeshwarp.py's optimiser (Adam, lr 5e-5).  fused=True is stock PyTorch's single-pass kernel for the
     # same update (A/B on one MI355X: 46.05 -> 45.10 ms per step); HOC_FUSED_ADAM=0 selects the foreach default
     params = [p for p in model.parameters() if p.requires_grad]
-    optimizer = torch.optim.Adam(params, lr=5e-5, fused=os.environ.get("HOC_FUSED_ADAM", "1") == "1")
+    # One step = ONE hipGraph launch (netscripts/epochpassconsist.GraphedTrainStep: train_step captured per device-resident
+    # batch set and replayed) on a single GPU; data-parallel runs issue their launches eagerly (no collective has run inside
+    # a capture on hardware here).  --eager-step / HOC_GRAPH_STEP=0: the eager loop of rounds 1-4.
+    fused_adam = os.environ.get("HOC_FUSED_ADAM", "1") == "1"
+    graph_step = (not args.eager_step and os.environ.get("HOC_GRAPH_STEP", "1") == "1" and not use_dist and fused_adam
+                  and not args.hot_only)
+    optimizer = torch.optim.Adam(params, lr=5e-5, fused=fused_adam, capturable=graph_step)
     loader = SyntheticConsistLoader(B, is_, seed=rank, device=dev, pool=2, image_height=ih_)
 
     def barrier():
@@ -838,15 +863,25 @@ def main():
         dist.destroy_process_group()
         return
     _phase("model built; warm-up steps")
-    for i in range(0 if args.hot_only else args.warmup):
-        train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan, reducer=reducer)
+    from handobjectconsist_amd.netscripts.epochpassconsist import GraphedTrainStep
+
+    def make_step(pre, opt):
+        if not graph_step:
+            return lambda batches: train_step(batches, pre, opt, check_nan=check_nan, reducer=reducer)
+        return GraphedTrainStep(pre, opt, check_nan=check_nan)
+
+    step_fn = make_step(premodel, optimizer)
+    # (graph replay: a batch set's first call runs eagerly, its second captures -- both inside the warm-up)
+    n_warm = max(args.warmup, 2 * len(loader.batches)) if graph_step else args.warmup
+    for i in range(0 if args.hot_only else n_warm):
+        step_fn(loader.step_batches(i))
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = torch.zeros(1)
     for i in range(0 if args.hot_only else args.steps):
-        loss, _ = train_step(loader.step_batches(i), premodel, optimizer, check_nan=check_nan, reducer=reducer)
+        loss, _ = step_fn(loader.step_batches(n_warm + i))
     if check_nan:
         raise_pending_nan(optimizer)  # the last step's device-side NaN flag (train_step's contract), inside the timed region
     torch.cuda.synchronize()
@@ -930,47 +965,60 @@ def main():
             os.write(real_stdout, (json.dumps({"hot_path_ms": hot_ms}) + "\n").encode())
             return
 
-    # the same step with the trunk exactly as stock PyTorch-ROCm runs it (nn.BatchNorm2d / ReLU / MaxPool2d modules,
-    # NCHW, MIOpen's default solver choice): what this build's trunk glue kernels + channels-last layout are worth.
-    # Informational (single GPU only); `value` above is the default configuration.
+    # The north-star-CONFORMANT figure ("the ResNet-18 encoder and regression heads stay on stock PyTorch-ROCm"): the same
+    # step with the trunk's BatchNorm2d / ReLU / MaxPool2d as the stock nn modules.  It differs from `value` in ONE thing --
+    # the module substitution; memory format (channels-last), MIOpen's measured solver search (cudnn.benchmark) and TunableOp
+    # are stock PyTorch features and stay as `value` has them.  `--stock-trunk-nchw` adds the round-1..4 leg (NCHW, solver
+    # search off) as stock_trunk_nchw.  Single GPU only.
     _phase("hot path done; stock trunk")
-    stock = None
+    stock, stock_nchw = None, None
     if rank == 0 and world == 1 and not use_dist and not args.hot_only and not args.no_stock_trunk \
             and args.encoder_dtype == "f32":
         from handobjectconsist_amd.models import synthnet as _sn
 
-        saved = (_sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark)
-        _sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark = False, False, False
-        try:
-            torch.manual_seed(rank)
-            model_s = SynthMeshRegNet().to(dev)
-            model_s.eval()
-            pre_s = WarpRegNet((is_, ih_), model_s, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
-                               progressive_steps=1000, use_backward=True, mano_faces=model_s.mano_layer.th_faces,
-                               pair_outputs="loss").to(dev)
-            pre_s.step_count = 1000
-            opt_s = torch.optim.Adam([p for p in model_s.parameters() if p.requires_grad], lr=5e-5,
-                                     fused=os.environ.get("HOC_FUSED_ADAM", "1") == "1")
-            for i in range(max(args.warmup, 2)):
-                train_step(loader.step_batches(i), pre_s, opt_s, check_nan=check_nan)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                train_step(loader.step_batches(i), pre_s, opt_s, check_nan=check_nan)
-            torch.cuda.synchronize()
-            dt_s = time.perf_counter() - t1
-            stock = {"what": "same step, trunk on stock PyTorch-ROCm modules (BatchNorm2d / ReLU / MaxPool2d, NCHW, "
-                             "cudnn.benchmark off); render + warp + MANO + heads unchanged",
-                     "ms_per_step": round(dt_s / args.steps * 1e3, 3), "value": round(args.steps / dt_s, 4)}
-            del model_s, pre_s, opt_s
-        finally:
-            _sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark = saved
-        torch.cuda.empty_cache()
+        def stock_leg(channels_last, solver_search, what):
+            saved = (_sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark)
+            _sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark = False, channels_last, solver_search
+            try:
+                torch.manual_seed(rank)
+                model_s = SynthMeshRegNet().to(dev)
+                model_s.eval()
+                pre_s = WarpRegNet((is_, ih_), model_s, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
+                                   progressive_steps=1000, use_backward=True, mano_faces=model_s.mano_layer.th_faces,
+                                   pair_outputs="loss").to(dev)
+                pre_s.step_count = 1000
+                opt_s = torch.optim.Adam([p for p in model_s.parameters() if p.requires_grad], lr=5e-5, fused=fused_adam,
+                                         capturable=graph_step)
+                step_s = make_step(pre_s, opt_s)
+                for i in range(max(n_warm, 2)):
+                    step_s(loader.step_batches(i))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    step_s(loader.step_batches(max(n_warm, 2) + i))
+                if check_nan:
+                    raise_pending_nan(opt_s)
+                torch.cuda.synchronize()
+                dt_s = time.perf_counter() - t1
+                del model_s, pre_s, opt_s, step_s
+                return {"what": what, "ms_per_step": round(dt_s / args.steps * 1e3, 3), "value": round(args.steps / dt_s, 4)}
+            finally:
+                _sn.USE_HIP_BN, _sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark = saved
+                torch.cuda.empty_cache()
+
+        stock = stock_leg(_sn.USE_CHANNELS_LAST, torch.backends.cudnn.benchmark,
+                          "same step, same settings (channels-last, cudnn.benchmark and TunableOp as in `value`), trunk on the STOCK "
+                          "PyTorch-ROCm modules (nn.BatchNorm2d / ReLU / MaxPool2d): differs from `value` in the module substitution "
+                          "only; render + warp + MANO + heads unchanged")
+        if args.stock_trunk_nchw:
+            stock_nchw = stock_leg(False, False, "stock modules, NCHW, cudnn.benchmark off (the stock_trunk leg of rounds 1-4)")
 
     kernels, roof, roof_fwd, cpu, warp_tiles, in_step_line = None, None, None, None, None, None
     if rank == 0 and not args.no_kernel_bench:
         _phase("stock trunk done; kernel bench")
-        kernels = kernel_bench(dev, B, is_, args.kernel_iters)
+        # (N > 1: the other ranks sit in the final barrier meanwhile -- the roofline groups only, a few launches each)
+        kernels = kernel_bench(dev, B, is_, args.kernel_iters) if world == 1 else \
+            kernel_bench(dev, B, is_, min(args.kernel_iters, 10), (ROOF_BWD, ROOF_BWD_R4A, ROOF_BWD_PLAIN, ROOF_FWD) + WARP_TILES)
         _phase("kernel bench done; PMC passes")
         pmc = {} if (args.no_pmc or world > 1) else pmc_traffic_in_run(args)
         _phase("PMC passes done; in-step kernel trace")
@@ -1004,9 +1052,18 @@ def main():
                           "frac_in_step": round(w["bytes"] / (in_step[dk]["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
             warp_tiles[name] = w
         in_step_line = in_step or None
+        # what the driver's record keeps of this line is `roofline` / `cpu_baseline`: the figures a reader needs ride inside
+        roof["forward"] = {k: roof_fwd.get(k) for k in ("kernel", "device_kernels", "launch_ms", "launch_ms_cache_warm", "bytes",
+                                                       "bytes_are", "frac", "frac_cache_warm", "in_step_us", "frac_in_step",
+                                                       "in_step_kernels", "traffic")}
+        roof["hot_path_device_ms"] = None if hot_graph_ms is None else round(hot_graph_ms, 3)
+        roof["hot_path_eager_ms_host_bound"] = None if hot_ms is None else round(hot_eager_ms, 3)
+        roof["stock_trunk_it_s"] = None if stock is None else stock["value"]
+        roof["stock_trunk_is"] = None if stock is None else "north-star-conformant step (stock BatchNorm2d / ReLU / MaxPool2d modules; everything else as `value`)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _phase("CPU baseline")
-        cpu = cpu_baseline(args.cpu_sample, is_, B)
+        ncpu = os.cpu_count() or 1
+        cpu = cpu_baseline(min(B, max(args.cpu_sample, min(ncpu, 64))), is_, B)  # (a task per image: enough images for the cores)
         if (os.cpu_count() or 1) > 8:  # the figure that lines up with BASELINE.md's 8-thread reference measurement
             c8 = cpu_baseline(max(args.cpu_sample // 4, 2), is_, B, threads=8)
             cpu["at_8_threads"] = {"value": c8["value"], "sample": c8["sample"]}
@@ -1014,13 +1071,16 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         line = {
-            "metric": "trainmeshwarp iters/sec (render+warp, B=64, 256x256)",
+            "metric": f"trainmeshwarp iters/sec (render+warp, B={B}, {is_}x{ih_})",
+            "headline": bool(B == 64 and is_ == 256 and ih_ == 256 and args.encoder_dtype == "f32"),  # BASELINE.json's metric config
             "value": round(world * args.steps / dt, 4),
             "unit": "iters/s (each: 1 data batch + 1 consist batch of B per GPU, one optimizer step; the figure with the encoder "
-                    "entirely on stock PyTorch-ROCm modules, as the north star words it, is stock_trunk.value -- `value` adds this "
-                    "build's fused BatchNorm/ReLU/residual/max-pool kernels between the stock convolutions; render + warp itself "
-                    "is hot_path.device_ms_graph_replay ms of the step)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                    "entirely on stock PyTorch-ROCm modules, as the north star words it, is stock_trunk.value = roofline.stock_trunk_it_s "
+                    "(same layout / solver search / TunableOp as `value`: the ONLY difference is that `value` substitutes this build's "
+                    "fused BatchNorm/ReLU/residual/max-pool kernels between the stock convolutions); render + warp itself is "
+                    "roofline.hot_path_device_ms of the step)",
+            "n_gpus": world, "steps": args.steps, "warmup": n_warm, "ms_per_step": round(ms, 3),
+            "step_mode": "hipGraph replay of the captured train_step (one launch per step)" if graph_step else "eager launches",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
             "data": "synthetic",
@@ -1037,7 +1097,7 @@ def main():
                         "epilogue, pair loss, their backward passes)",
                 "device_ms_graph_replay": None if hot_graph_ms is None else round(hot_graph_ms, 3),
                 "eager_ms_host_bound": round(hot_eager_ms, 3)},
-            "ranks": ranks, "stock_trunk": stock, "roofline": roof, "roofline_forward": roof_fwd, "warp_tiles": warp_tiles,
+            "ranks": ranks, "stock_trunk": stock, "stock_trunk_nchw": stock_nchw, "roofline": roof, "roofline_forward": roof_fwd, "warp_tiles": warp_tiles,
             "in_step_kernels_us": in_step_line, "kernels": kernels, "cpu_baseline": cpu,
         }
         sys.stdout.flush()

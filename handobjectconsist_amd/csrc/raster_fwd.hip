@@ -101,6 +101,7 @@ constexpr int BIN_TPB = 1024;         // bin_boxes_kernel: one workgroup per ima
 constexpr int MAX_BINS = 8192;        // LDS counters (32 KB)
 constexpr int SMALL_MAX_BINS = 8;     // a face overlapping more bins goes to the image's large list
 constexpr int REC_CAP = SMALL_MAX_BINS + 1;  // record capacity per image, in units of F: 8 F binned + F large
+constexpr int MAX_PARTS_DEV = 16;            // most workgroups per image of the binning pass (= MAX_PARTS of launch_bins)
 
 struct BinParams {
     const float* faces;      // !VC: [B,F,3,3]
@@ -343,23 +344,30 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     const int i0 = min(tid * per, nbins), i1 = min(i0 + per, nbins);
     if (K > 1) {
         // exchange: publish this part's counters, wait for the image's other parts, turn cnt[] into the image's totals
-        // and before[] into what the lower parts hold in each bin
-        const int pstride = nbins + 4;
+        // and before[] into what the lower parts hold in each bin.  The parts of an image share an XCD and therefore an L2
+        // (launch_bins' workgroup -> image map; checked below): plain stores that the L2 has acknowledged, a flag counted
+        // by L2 atomics (workgroup scope: no trip to the memory side) and loads that bypass the compute unit's L1 are
+        // coherent there -- no device-scope fence.  (A release + acquire fence pair per wave -- L2 write-back and
+        // invalidate, 32 per workgroup -- made this kernel 142 us; one pair per workgroup still cost 5 us of barrier.)
+        const int pstride = (nbins + 4 + 31) & ~31;  // (a part's counters start on a 128-byte line of their own)
         int* pub = p.part_cnt + ((int64_t)b * K + part) * pstride;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 15u;
         for (int i = tid; i < nbins; i += BIN_TPB) pub[i] = cnt[i];
-        if (tid == 0) { pub[nbins] = s_nlarge; pub[nbins + 1] = s_everywhere; }
-        __threadfence();
-        __syncthreads();
+        if (tid == 0) { pub[nbins] = s_nlarge; pub[nbins + 1] = s_everywhere; pub[nbins + 2] = (int)xcc; }
+        __syncthreads();  // (the workgroup's stores are performed: s_waitcnt vmcnt(0) in front of the barrier)
+        MR_BIN_STAMP(6);
         if (tid == 0) {
-            atomicAdd(&p.arrive[b], 1u);
+            __hip_atomic_fetch_add(&p.arrive[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             unsigned spins = 0;
-            while (__hip_atomic_load(&p.arrive[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)K) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 24)) __builtin_trap();  // (~2 s: a part that never arrives is a bug, not a wait)
+            while (__hip_atomic_fetch_add(&p.arrive[b], 0u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)K) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 25)) __builtin_trap();  // (seconds: a part that never arrives is a bug, not a wait)
             }
         }
         __syncthreads();
-        __threadfence();
+        MR_BIN_STAMP(7);
         const int* all = p.part_cnt + (int64_t)b * K * pstride;
         for (int i = i0; i < i1; i++) {
             int tot = 0, lg = 0, bef = 0;
@@ -372,15 +380,21 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
             cnt[i] = tot | lg;
             before[i] = bef;
         }
-        if (tid == 0) {
-            int nl = 0, ev = 0, lb = 0;
-            for (int k = 0; k < K; k++) {
-                const int n = __hip_atomic_load(all + (int64_t)k * pstride + nbins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ev |= __hip_atomic_load(all + (int64_t)k * pstride + nbins + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                nl += n;
-                lb += k < part ? n : 0;
+        if (tid < MR_WAVE) {  // (wave 0; lane k < K: part k's scalars)
+            int n = 0, ev = 0;
+            if (tid < K) {
+                const int* q = all + (int64_t)tid * pstride + nbins;
+                n = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ev = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned their = (unsigned)__hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (their != xcc) __builtin_trap();  // an image's parts on two XCDs: the exchange above would not be coherent
             }
-            s_nlarge = nl; s_everywhere = ev; s_large_before = lb;
+            int nl = n, lb = tid < part ? n : 0, e = ev;
+#pragma unroll
+            for (int off = 1; off < MAX_PARTS_DEV; off <<= 1) {
+                nl += __shfl_xor(nl, off); lb += __shfl_xor(lb, off); e |= __shfl_xor(e, off);
+            }
+            if (tid == 0) { s_nlarge = nl; s_everywhere = e; s_large_before = lb; }
         }
         __syncthreads();
     }
@@ -1239,9 +1253,12 @@ struct WorkLayout {
     size_t off_bins, off_boxes, off_recs, off_rverts, off_tlist, off_arrive, off_tile_ids, off_bg, off_part_cnt, total;
 };
 
-// Workgroups per image of the binning pass: the largest power of two (<= 16) that keeps B x parts within the device's
-// compute units -- every workgroup of the launch resident at once, which the parts' barrier relies on -- and leaves a part
-// at least 256 faces.
+// Workgroups per image of the binning pass: the largest power of two (<= 16) that keeps B x parts within HALF the device's
+// compute units and leaves a part at least 256 faces.  Every workgroup of the launch is then resident at once, which the
+// parts' barrier relies on.  Why half: the exchange costs a part ~6 us of dependent L2 round trips (phase stamps,
+// scripts/wg_timeline.py), what two parts save each other at the 128 images of a training pair -- one workgroup per image
+// 22.3 us, two 23-29 us -- so parts are for the launches that leave most of the chip idle: 16 renders of config 3 (the
+// reference's default batch size) ran their set-up on 16 of 256 compute units.
 static int device_cus() {
     static int cus[64] = {0};
     int dev = 0;
@@ -1252,10 +1269,10 @@ static int device_cus() {
     }
     return cus[dev] > 0 ? cus[dev] : 0;
 }
-constexpr int MAX_PARTS = 16, MAX_PART_CUS = 256;
+constexpr int MAX_PARTS = MAX_PARTS_DEV, MAX_PART_CUS = 256;
 static int bin_parts(int B, int F, int cus) {
     int k = 1;
-    while (k < MAX_PARTS && (int64_t)B * k * 2 <= cus && F / (k * 2) >= 256) k *= 2;
+    while (k < MAX_PARTS && (int64_t)B * k * 2 * 2 <= cus && F / (k * 2) >= 256) k *= 2;
     return k;
 }
 
@@ -1280,7 +1297,7 @@ static WorkLayout work_layout(int B, int F, int is) {
     w.off_part_cnt = w.off_bg + align256((size_t)B * tiles_x * tiles_y * sizeof(uint32_t));  // dense listed launches: ids of the tiles off the list
     // (sized for a 256-CU device, the most launch_bins assumes: the layout must not depend on the device at hand)
     w.parts = bin_parts(B, F, MAX_PART_CUS);
-    w.total = w.off_part_cnt + (w.parts > 1 ? align256((size_t)B * w.parts * (w.nbx * w.nby + 4) * sizeof(int)) : 0);
+    w.total = w.off_part_cnt + (w.parts > 1 ? align256((size_t)B * w.parts * ((w.nbx * w.nby + 4 + 31) & ~31) * sizeof(int)) : 0);
     return w;
 }
 

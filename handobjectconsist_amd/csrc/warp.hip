@@ -634,7 +634,7 @@ __global__ void __launch_bounds__(256, 6) pair_consist_forward_tiles_kernel(Pair
     const int T = p.tiles_x * p.tiles_y;
     const int64_t hw = (int64_t)p.H * p.W;
     unsigned round = 0;
-    for (; j < sl.n_local; j += sl.stride, round++) {
+    for (; j < sl.n_local; j += sl.stride) {
         const TileAt t = tile_at(p.list.ids[sl.slot(j, p.list.cap)].x, p.B, p.tiles_x, T, p.is, p.hit[0], p.hit[1]);
         if (t.word == 0u) continue;
         float sum = 0.0f, cnt = 0.0f;
@@ -661,7 +661,9 @@ __global__ void __launch_bounds__(256, 6) pair_consist_forward_tiles_kernel(Pair
         // between rounds so that a round needs ONE barrier
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { sum += __shfl_xor(sum, off); cnt += __shfl_xor(cnt, off); }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = round & 1u;
+        // (`round` counts EXECUTED rounds -- tiles with a zero coverage word `continue` above: two consecutive executed rounds
+        // must not share a slot, or a wave of the next round could overwrite it while thread 0 still reads)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = round++ & 1u;
         if (lane == 0) { red[slot][wave][0] = sum; red[slot][wave][1] = cnt; }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -703,7 +705,7 @@ __global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFw
     const int T = p.tiles_x * p.tiles_y, is = p.is, H = p.crop_h, W = p.crop_w;
     const int64_t hw = (int64_t)is * is, hw_img = (int64_t)H * W;
     unsigned round = 0;
-    for (; j < sl.n_local; j += sl.stride, round++) {
+    for (; j < sl.n_local; j += sl.stride) {
         const TileAt t = tile_at(p.list.ids[sl.slot(j, p.list.cap)].x, p.B, p.tiles_x, T, is, p.hit[0], p.hit[1]);
         if (t.word == 0u) continue;  // (uniform)
         float sum = 0.0f, cnt = 0.0f;
@@ -779,7 +781,7 @@ __global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFw
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) gmx = max(gmx, (unsigned)__shfl_xor((int)gmx, off));
         }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = round & 1u;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = round++ & 1u;  // (executed rounds only: see above)
         if (lane == 0) { red[slot][wave][0] = sum; red[slot][wave][1] = cnt; if (GRAD) redm[slot][wave] = gmx; }
         __syncthreads();
         if (threadIdx.x == 0) {

@@ -72,6 +72,10 @@ class WarpRegNet(torch.nn.Module):
         self.lambda_data, self.lambda_consist = lambda_data, lambda_consist
         self.progressive_consist, self.progressive_steps = progressive_consist, progressive_steps
         self.step_count = 0
+        # graph replay (netscripts/epochpassconsist.GraphedTrainStep): the two weights as a DEVICE tensor [lambda_data,
+        # lambda_consist] that the caller refreshes before every step -- a Python float would be frozen into the capture
+        self.lambda_tensors = None
+        self._lambda_host = None
 
         side = max(image_size)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -107,6 +111,25 @@ class WarpRegNet(torch.nn.Module):
             sample["_post"] = chunk
         return True
 
+    def refresh_lambda_tensors(self, device=None):
+        """(Create and) fill ``lambda_tensors`` with the weights ``forward`` would compute from ``step_count`` now: the same
+        fp32 values the Python floats round to inside the multiplications, so the losses are bit-identical.  Two ``fill_``
+        launches (the value travels as a kernel argument: no host buffer a later step could overwrite while this one is
+        still queued), and none once the ramp is over and the weights stop changing."""
+        if self.lambda_tensors is None:
+            device = device if device is not None else self.th_faces.device
+            self.lambda_tensors = torch.zeros(2, dtype=torch.float32, device=device)
+            self._lambda_host = None
+        now = consist_lambdas(self.step_count, self.lambda_data, self.lambda_consist, self.progressive_consist,
+                              self.progressive_steps)
+        now = (float(now[0]), float(now[1]))
+        if now != self._lambda_host:
+            with torch.no_grad():
+                self.lambda_tensors[0].fill_(now[0])
+                self.lambda_tensors[1].fill_(now[1])
+            self._lambda_host = now
+        return self.lambda_tensors
+
     def forward(self, batch):
         samples, supervision = batch["data"], batch["supervision"]
         outputs = [self.model(sample) for sample in samples]  # (loss, results, losses) per frame
@@ -116,6 +139,8 @@ class WarpRegNet(torch.nn.Module):
         aggregate_losses = _mean_over_samples(all_losses)
         lambda_data, lambda_consist = consist_lambdas(
             self.step_count, self.lambda_data, self.lambda_consist, self.progressive_consist, self.progressive_steps)
+        if self.lambda_tensors is not None:
+            lambda_data, lambda_consist = self.lambda_tensors[0], self.lambda_tensors[1]
 
         loss, pair_results = 0, None
         if "data" in supervision:

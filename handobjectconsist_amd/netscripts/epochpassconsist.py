@@ -79,6 +79,9 @@ def train_step(batches, premodel, optimizer, check_nan=True, reducer=None):
     nan_flag = torch.isnan(loss.detach()) if check_nan else None
     optimizer.zero_grad(set_to_none=True)
     if loss.requires_grad:
+        if reducer is not None and getattr(optimizer, "_hoc_reducer_checked", None) is not reducer:
+            reducer.check_optimizer(optimizer)  # (once per optimiser / reducer pair)
+            optimizer._hoc_reducer_checked = reducer
         if reducer is not None and check_nan:
             reducer.set_flag(nan_flag)  # travels with the last gradient bucket
         if reducer is not None and reducer.loss_scale != 1.0:
@@ -107,6 +110,78 @@ def train_step(batches, premodel, optimizer, check_nan=True, reducer=None):
     elif check_nan and bool(nan_flag):
         raise ValueError("Loss became nan!")
     return loss.detach(), logs
+
+
+class GraphedTrainStep:
+    """``train_step`` captured ONCE per set of device-resident batches into a hipGraph and replayed ("host
+    overhead dominates once kernels are fast").  A step of the metric workload is 333 launches; between the end of the
+    encoder's forward and the first large kernel of its backward lie ~170 launches of a few microseconds (heads, MANO,
+    losses, render + warp, the start of backward) that the autograd engine cannot issue as fast as the device retires them:
+    1.0 ms of a 27.3 ms step is idle there (profiles/r04_step_sequence.txt), and at the reference's default batch size
+    (B = 8, trainmeshwarp.py:372) the host binds the whole step.  One graph launch per step removes the host from it.
+
+    What the capture holds: ``prepare`` + the forwards of the step's batches + ``zero_grad`` + ``backward`` + the fused
+    optimiser update with its device-side NaN guard (``found_inf``) -- i.e. ``train_step`` itself, called under
+    ``torch.cuda.graph``.  What stays outside: ``raise_pending_nan`` (the host reads step k's flag when step k + 1 starts,
+    as in the eager path), the lambda ramp (``WarpRegNet.refresh_lambda_tensors``: a device tensor refreshed before the
+    replay, nothing once the ramp is over) and the step counter.  The graph READS THE BATCH TENSORS IN PLACE: a batch set
+    is identified by its dict objects, whose tensors must keep their storage and may be refilled in place between steps (a
+    frame pipeline writing into fixed buffers -- ``mr_frames_to_batch`` -- or a device-resident pool as
+    ``SyntheticConsistLoader``).  The first call with a new batch set runs eagerly (solver searches, TunableOp, the tile-list
+    guess), the second captures and replays, later ones replay.
+
+    Requirements: a CUDA optimiser built with ``capturable=True`` (stock fused Adam), no ``reducer`` (data-parallel runs
+    stay eager: a collective inside a capture has not run on hardware here), ``check_nan`` handled on the device."""
+
+    def __init__(self, premodel, optimizer, check_nan=True, max_graphs=8):
+        if not _device_guarded(optimizer) or not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise ValueError("GraphedTrainStep needs a fused optimiser built with capturable=True")
+        self.premodel, self.optimizer, self.check_nan, self.max_graphs = premodel, optimizer, check_nan, max_graphs
+        self._entries = {}
+        self.replays = 0
+
+    def __call__(self, batches):
+        key = tuple(id(b) for b in batches)
+        entry = self._entries.get(key)
+        if self.check_nan:
+            raise_pending_nan(self.optimizer)
+        if entry is None:
+            if len(self._entries) >= self.max_graphs:
+                raise RuntimeError("GraphedTrainStep: more batch sets than max_graphs -- refill the batch tensors in place "
+                                   "instead of handing over new ones")
+            self._entries[key] = {"batches": batches, "graph": None}
+            self.premodel.refresh_lambda_tensors()  # (the eager step reads the same device tensor the captures will)
+            return train_step(batches, self.premodel, self.optimizer, check_nan=self.check_nan)
+        pm = self.premodel
+        pm.refresh_lambda_tensors()
+        if entry["graph"] is None:
+            self._capture(entry)
+        entry["graph"].replay()
+        self.replays += 1
+        pm.step_count += entry["consist_batches"]
+        if self.check_nan:
+            self.optimizer._hoc_pending_nan = entry["nan_flag"]
+        return entry["loss"], entry["logs"]
+
+    def _capture(self, entry):
+        pm, opt = self.premodel, self.optimizer
+        tunable = getattr(torch.cuda, "tunable", None)
+        was_tuning = bool(tunable and tunable.is_enabled() and tunable.tuning_is_enabled())
+        if was_tuning:
+            tunable.tuning_enable(False)  # (every GEMM shape of the step was tuned by the eager call; no timing runs in a capture)
+        count0 = pm.step_count
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                loss, logs = train_step(entry["batches"], pm, opt, check_nan=self.check_nan)
+                flag = getattr(opt, "_hoc_pending_nan", None)
+        finally:
+            if was_tuning:
+                tunable.tuning_enable(True)
+        opt._hoc_pending_nan = None
+        entry.update(graph=graph, loss=loss, logs=logs, nan_flag=flag, consist_batches=pm.step_count - count0)
+        pm.step_count = count0  # (nothing ran yet: the replay that follows is the step)
 
 
 def epoch_pass(loader, premodel, optimizer, loader_nb=2, check_nan=True, reducer=None):

@@ -34,7 +34,9 @@ communicated: 30.1-30.7 ms per step against 26.6 ms without the wrapper, 430 aga
 All ranks must train the same parameter set.  A parameter that received no gradient on a rank contributes zeros
 and ends up with a zero (not ``None``) gradient: under Adam without weight decay (trainmeshwarp.py's optimiser)
 such a parameter does not move while its moments are zero, but unlike the single-process path its step counter
-advances.
+advances; ``check_optimizer`` (called by ``train_step``) refuses weight decay / momentum, under which it WOULD move.
+The flag slot takes the last bucket's dtype (fp32 for this trainer; a 16-bit last bucket still carries 0 / non-zero
+for up to 2048 ranks) and is re-zeroed by the last bucket's launch in steps that do not call ``set_flag``.
 
 The same code runs for every world size, including 1 (no short cut: the one-rank run is how the cost of the
 path is measured on a one-GPU box).
@@ -103,6 +105,7 @@ class BucketedGradReducer:
         self.buckets.append(_Bucket(cur, extra=1))
         self._flag = self.buckets[-1].flat[-1:]  # rides through the last bucket's all-reduce (sum over the ranks)
         self._next = 0  # index of the first bucket not yet issued in this step
+        self._flag_set = False  # set_flag called since the last finish()
         self._handles = []
         for b in self.buckets:
             for p in b.params:
@@ -143,6 +146,15 @@ class BucketedGradReducer:
                 self._flag.copy_(flag.reshape(1).to(self._flag.dtype))
             else:
                 self._flag.fill_(float(bool(flag)))
+        self._flag_set = True
+
+    def check_optimizer(self, optimizer):
+        """A parameter without a gradient gets ZEROS here (every rank must reduce the same buckets), not ``None``: with
+        weight decay or momentum the optimiser would move it, unlike the single-process path.  Refuse such settings."""
+        for g in optimizer.param_groups:
+            if g.get("weight_decay", 0) or g.get("momentum", 0):
+                raise ValueError("BucketedGradReducer hands zero (not None) gradients to parameters without a gradient: "
+                                 "weight_decay / momentum != 0 would move them; not supported")
 
     def flag(self):
         """After ``finish()``: 0-dim bool tensor on the parameters' device, identical on every rank."""
@@ -151,6 +163,8 @@ class BucketedGradReducer:
     # ------------------------------------------------------------------ per step
     def _launch(self, b):
         with torch.no_grad():
+            if b is self.buckets[-1] and not self._flag_set:
+                self._flag.zero_()  # (a step without set_flag must not re-send the previous step's rank sum)
             have = [(v, p.grad) for v, p in zip(b.views, b.params)
                     if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
             if have:
@@ -171,6 +185,7 @@ class BucketedGradReducer:
             b.work.wait()
             b.work, b.launched, b.pending = None, False, len(b.params)
         self._next = 0
+        self._flag_set = False
 
     def remove(self):
         for h in self._handles:

@@ -9,7 +9,7 @@ from handobjectconsist_amd import _lib
 from handobjectconsist_amd.neurender import nr_ops
 from handobjectconsist_amd.utils import synth
 dev = torch.device("cuda:0")
-B, is_ = 64, 256
+B, is_ = int(os.environ.get("HOC_TL_BATCH", "64")), int(os.environ.get("HOC_TL_SIZE", "256"))
 s = synth.random_scene(B, seed=0, image_size=is_)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 eye, z3, z5 = torch.eye(3, device=dev)[None], torch.zeros(1, 3, device=dev), torch.zeros(1, 5, device=dev)
@@ -28,7 +28,14 @@ wbytes = int(lib.mr_render_workspace_bytes(B2, 2 * F0, is_)); work = torch.empty
 bg = torch.zeros(3, **f32)
 lut = torch.ones(2 * F0 + 2, **f32)
 flush = torch.zeros(768 * 1024 * 1024 // 4, **f32)
-fn = lambda: _lib.call("mr_render_flow_forward", P(pv), P(pf), P(cols), P(bg), 0, P(lut), int(lut.numel()), 0.99999, P(rgb), P(alpha), P(mask), P(depth), P(wmap), P(fim), P(hit), P(work), wbytes, B2, V, F0, 1, is_, 0.1, 100.0, 1e-3, _lib.FLAG_SPARSE_TILES, None, -1, None, None, 0, 0, st)
+FUSED = os.environ.get("HOC_FUSED_RECORDS", "1") == "1"  # as the training step launches it: per-face pass inside the binning kernel
+hdr_off = _lib.tile_list(work, B2, 2 * F0, is_)[0].value - work.data_ptr()
+clear = work[hdr_off:hdr_off + int(lib.mr_render_clear_bytes(B2, 2 * F0, is_))]
+XFLAGS = int(os.environ.get("HOC_FWD_FLAGS", "0"))
+def fn():
+    if FUSED:
+        clear.zero_()
+    _lib.call("mr_render_flow_forward", P(pv), P(pf), P(cols), P(bg), 0, P(lut), int(lut.numel()), 0.99999, P(rgb), P(alpha), P(mask), P(depth), P(wmap), P(fim), P(hit), P(work), wbytes, B2, V, F0, 1, is_, 0.1, 100.0, 1e-3, _lib.FLAG_SPARSE_TILES | (_lib.FLAG_TILE_LIST_CLEARED if FUSED else 0) | XFLAGS, None, -1, None, None, 0, 0, st)
 print("cold %.1f us" % (bench.event_time_ms(fn, 10, flush=flush) * 1e3))
 flush.add_(1.0); torch.cuda.synchronize()
 fn(); torch.cuda.synchronize()
@@ -36,10 +43,18 @@ fn(); torch.cuda.synchronize()
 bb = np.zeros(1024 * 8, dtype=np.uint64)
 lib.mr_debug_bin_times.argtypes = [ctypes.c_void_p, ctypes.c_long]
 assert lib.mr_debug_bin_times(bb.ctypes.data, bb.nbytes) == 0
-bt = bb.reshape(1024, 8)[:B2, :6].astype(np.int64)
-names = ["zero counters (+ zero_fill)", "pass 1: count", "scan + bin headers", "tile list", "pass 2: fill"]
-print("binning pass, per image (us):", {n_: round(float((bt[:, k + 1] - bt[:, k]).mean()) * 0.01, 2) for k, n_ in enumerate(names)},
-      "total %.2f" % (float((bt[:, 5] - bt[:, 0]).mean()) * 0.01), "first start -> last end %.2f" % ((bt[:, 5].max() - bt[:, 0].min()) * 0.01))
+bt_all = bb.reshape(1024, 8).astype(np.int64)
+bt_all = bt_all[bt_all[:, 5] > 0]  # workgroups of the last launch (parts per image since round 5; surplus ones leave at once)
+exch = bool((bt_all[:, 6] > 0).any())
+# stamps in time order: 0 start, 1 counters zeroed, 2 (per-face pass +) counting pass done, [6 counters published, 7 barrier
+# passed,] 3 scan + headers done, 4 tile list written, 5 fill pass done
+order = [0, 1, 2, 6, 7, 3, 4, 5] if exch else [0, 1, 2, 3, 4, 5]
+names = (["zero counters (+ zero_fill)", "(per-face pass +) count", "publish counters", "barrier", "read parts + scan + bin headers",
+          "tile list (part 0)", "pass 2: fill"] if exch else
+         ["zero counters (+ zero_fill)", "(per-face pass +) count", "scan + bin headers", "tile list", "pass 2: fill"])
+bt = bt_all[:, order]
+print("binning pass: %d workgroups; per workgroup (us):" % len(bt), {n_: round(float((bt[:, k + 1] - bt[:, k]).mean()) * 0.01, 2) for k, n_ in enumerate(names)},
+      "total %.2f" % (float((bt[:, -1] - bt[:, 0]).mean()) * 0.01), "first start -> last end %.2f" % ((bt[:, -1].max() - bt[:, 0].min()) * 0.01))
 n = 32768
 buf = np.zeros(n * 4, dtype=np.uint64)
 lib.mr_debug_times.argtypes = [ctypes.c_void_p, ctypes.c_long]

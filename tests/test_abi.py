@@ -46,6 +46,30 @@ def test_header_prototype_arity_matches_ctypes_table():
         assert len(params) == len(argtypes), f"{name}: header has {len(params)} parameters, ctypes {len(argtypes)}"
 
 
+def test_header_prototype_types_match_ctypes_table():
+    """... and position by position the KIND of every parameter: pointer / int / int64 / float (a swapped int and float
+    would pass the arity check and reinterpret bits at run time), plus the return type."""
+    from handobjectconsist_amd import _lib
+
+    def kind(decl):
+        decl = decl.strip()
+        if "*" in decl or re.search(r"\bmr_stream_t\b", decl):
+            return ctypes.c_void_p
+        words = decl.split()
+        base = [w for w in words[:-1] if w not in ("const", "unsigned")] or words  # (last word = the parameter's name)
+        t = base[0]
+        return {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float}[t]
+
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (res, argtypes) in _lib.SIGNATURES.items():
+        m = re.search(r"MR_API\s+(int64_t|int)\s+" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        assert res is {"int": ctypes.c_int, "int64_t": ctypes.c_int64}[m.group(1)], f"{name}: return type"
+        params = [p for p in m.group(2).split(",") if p.strip() and p.strip() != "void"]
+        for i, (decl, want) in enumerate(zip(params, argtypes)):
+            assert kind(decl) is want, f"{name}: parameter {i} `{' '.join(decl.split())}` is bound as {want.__name__}"
+
+
 def test_argument_validation_needs_no_device():
     from handobjectconsist_amd import _lib
 

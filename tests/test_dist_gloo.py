@@ -166,3 +166,109 @@ def test_nan_on_one_rank_stops_every_rank_in_the_same_step(tmp_path):
             assert all(s == 1.0 for s in r[fused]["steps"])
             assert r[fused]["probe"] == 2.0
         assert torch.equal(per_rank[0][fused]["w"], per_rank[1][fused]["w"])
+
+
+def _worker_many(rank, world, port, out):
+    """World sizes the node will be asked for (4, 8): a tiny model in several buckets, a rank whose gradients complete in
+    another order than everybody else's, a NaN on one rank in a later step."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from handobjectconsist_amd.netscripts import epochpassconsist as E
+    from handobjectconsist_amd.netscripts.gradreduce import BucketedGradReducer
+
+    late_rank, nan_rank = world - 1, min(5, world - 2)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(6, 40)
+            self.b = torch.nn.Linear(40, 40)
+            self.c = torch.nn.Linear(40, 1)
+            self.bad = False
+
+        def forward(self, batch):
+            x = batch["x"]
+            if rank == late_rank:
+                # `c` (next to the loss: its gradients complete FIRST everywhere else) also enters at the very start of this
+                # rank's graph, so here its gradients complete LAST -- with a zero weight, so that the value is unchanged
+                x = x + 0.0 * self.c.weight[:, :6].sum() + 0.0 * self.c.bias.sum()
+            loss = self.c(torch.tanh(self.b(torch.tanh(self.a(x))))).mean().reshape(1)
+            if self.bad:
+                loss = loss * float("nan")
+            return loss, {}, None, None
+
+    torch.manual_seed(100 + rank)  # replicas start different; the reducer's broadcast makes them rank 0's
+    net = Net()
+    reducer = BucketedGradReducer(net.parameters(), bucket_mb=0.0005)  # ~0.5 KB: c, then b in pieces, then a
+    nb = len(reducer.buckets)
+    assert nb >= 4
+    order, ready = [], []
+    launch = reducer._launch
+    reducer._launch = lambda b: (order.append(reducer.buckets.index(b)), launch(b))[1]
+    seen = [0] * nb
+
+    def note(bi, n):  # (the order the buckets' gradients become complete in)
+        def hook(_p):
+            seen[bi] += 1
+            if seen[bi] == n:
+                ready.append(bi)
+        return hook
+
+    for bi, b in enumerate(reducer.buckets):
+        for p in b.params:
+            p.register_post_accumulate_grad_hook(note(bi, len(b.params)))
+    opt = torch.optim.Adam(net.parameters(), lr=0.05, fused=False)
+    torch.manual_seed(rank)
+    batch = {"data": [{}], "x": torch.randn(4, 6)}
+    shard_grads = None
+    for step in range(3):
+        order.clear(); ready.clear()
+        seen[:] = [0] * nb
+        E.train_step([batch], net, opt, reducer=reducer)
+        assert order == list(range(nb)), (rank, order)
+        if step == 0:
+            g = torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+            shard_grads = g
+    ready_first = list(ready)
+    w_ok = torch.cat([p.detach().flatten() for p in net.parameters()]).clone()
+    net.bad = rank == nan_rank
+    raised = []
+    try:
+        E.train_step([batch], net, opt, reducer=reducer)  # synchronous check: raises on EVERY rank in this step
+    except ValueError as e:
+        raised.append(str(e))
+    w_after = torch.cat([p.detach().flatten() for p in net.parameters()])
+    probe = torch.ones(1)
+    dist.all_reduce(probe)
+    res = {"rank": rank, "raised": raised, "same": bool(torch.equal(w_ok, w_after)), "w": w_after, "g": shard_grads,
+           "probe": float(probe), "ready": ready_first, "buckets": nb}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_ranks(tmp_path, world):
+    """The rank counts of the scaling runs (1 / 2 / 4 / 8): every rank issues its buckets in index order although
+    one rank's gradients complete in another order, the averaged gradient and the replicas are identical everywhere after
+    three steps, and a NaN on ONE rank (rank 5 of 8) stops all of them in the same step with the group still usable."""
+    out = str(tmp_path / f"many{world}.pt")
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker_many, args=(world, port, out), nprocs=world, join=True)
+    per_rank = torch.load(out, weights_only=False)
+    assert sorted(r["rank"] for r in per_rank) == list(range(world))
+    for r in per_rank:
+        assert torch.equal(r["w"], per_rank[0]["w"]), f"replica {r['rank']} diverged"
+        assert torch.equal(r["g"], per_rank[0]["g"]), f"rank {r['rank']} holds another averaged gradient"
+        assert len(r["raised"]) == 1 and "nan" in r["raised"][0].lower()
+        assert r["same"], "the diverged step touched the parameters of a rank"
+        assert r["probe"] == float(world)
+    # the hold was exercised: the late rank's first bucket completes last, everybody else's first
+    late = per_rank[world - 1]["ready"]
+    assert late.index(0) > late.index(per_rank[0]["buckets"] - 1), late
+    assert per_rank[0]["ready"].index(0) < per_rank[0]["ready"].index(per_rank[0]["buckets"] - 1)

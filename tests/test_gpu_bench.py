@@ -126,6 +126,34 @@ def test_bench_gpus_2_as_a_plain_script_starts_its_own_ranks(cuda):
 
 
 @pytest.mark.gpu
+def test_bench_gpus_8_as_a_plain_script(cuda):
+    """The command the scaling run will one day issue -- ``python bench.py --gpus 8`` -- executed once before a node with 8
+    devices exists: 8 ranks started by bench.py itself, sharing this box's GPU(s) over gloo; 8 seeds / loaders, the
+    in-order buckets on 8 ranks, the `ranks` block with 8 rows, the global batch of 8 shards, replicas bit-identical
+    (HOC_CHECK_REPLICAS), rank 0's reduced kernel bench while the others wait.  Wall time bounded."""
+    import time
+
+    env = dict(os.environ, HOC_SHARE_GPU="1", HOC_DIST_BACKEND="gloo", HOC_CHECK_REPLICAS="1", HOC_TUNABLEOP="0", HOC_CUDNN_BENCHMARK="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "2", "--image-size", "64", "--steps", "2",
+           "--warmup", "1", "--no-kernel-bench", "--no-cpu-baseline"]
+    t0 = time.time()
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    wall = time.time() - t0
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = _json_line(res.stdout)
+    for k in CONTRACT:
+        assert k in line, k
+    assert line["n_gpus"] == 8 and line["value"] > 0 and line["config"]["parallelism"] == "dp8"
+    assert line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
+    assert line["ranks"]["world_size"] == 8 and sorted(r["rank"] for r in line["ranks"]["per_rank"]) == list(range(8))
+    assert all(r["ms_per_step"] > 0 for r in line["ranks"]["per_rank"])
+    assert line["cpu_baseline"] is None and line["stock_trunk"] is None  # (N = 1 legs only)
+    assert wall < 300, f"bench.py --gpus 8 took {wall:.0f} s"
+
+
+@pytest.mark.gpu
 def test_one_rank_rccl_step_costs_what_the_plain_step_costs(cuda):
     """The data-parallel code path must not tax the step before a byte is communicated (round 2 measured torch's
     DistributedDataParallel wrapper at +13-15 % on one rank).  Headline workload (B = 64, 256 x 256).  Both loops run
