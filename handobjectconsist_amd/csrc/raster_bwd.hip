@@ -795,7 +795,6 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
     constexpr int NCH = FLOWGRAD ? 2 : 3;  // (the flow-space gradient has no third channel)
     __shared__ unsigned wmax[ST_WAVES];
     __shared__ unsigned short hits[ST_MAX_TILES];  // the image's covered tiles, ascending
-    __shared__ int wcnt[ST_WAVES];
     const GatherVCParams& p = sp.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G = sp.groups;
@@ -810,8 +809,21 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
     const float* verts_b = p.verts + (int64_t)b * p.V * 3;
     const int32_t* fidx_b = p.fidx + (int64_t)b * p.F0 * 3;
 
-    // the list of covered tiles (block-wide compaction of the coverage bytes); the 16 waves that share an image
-    // then take them round-robin: every wave gets its share whatever part of the screen the mesh sits in
+    // UNIT: the image's scalars (count, incoming loss gradient, bound of the unit gradient) are requested NOW, in front of
+    // the coverage words, not behind the list they do not depend on (one cold round trip less on the workgroup's chain)
+    float u_cnt = 1.0f, u_gl = 0.0f, u_max = 0.0f;
+    if constexpr (UNIT) {
+        const int dir = b >= sp.split ? 1 : 0, pb = b - dir * sp.split;
+        const float* gl = dir ? sp.gl_fwd : sp.gl_bwd;
+        u_cnt = sp.sums[pb * 4 + (dir ? 1 : 3)];
+        u_gl = gl ? gl[pb] : 0.0f;
+        u_max = sp.unit_max[b];
+    }
+    // the list of covered tiles (block-wide compaction of the coverage bytes); the waves that share an image then take
+    // them round-robin: every wave gets its share whatever part of the screen the mesh sits in.  (All coverage words
+    // requested up front and compacted behind one barrier -- eight predicated rounds unrolled -- measured SLOWER than
+    // this loop at 1024 tiles per image: 1.98 against 1.54 us.)
+    __shared__ int wcnt[ST_WAVES];
     int n_hits = 0;
     for (int t0 = 0; t0 < T; t0 += blockDim.x) {
         const int t = t0 + threadIdx.x;
@@ -840,11 +852,9 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
         // the image's coefficient (pair_consist_backward_tiles_kernel's): every gradient of the image is unit * ucoef, and
         // |unit| <= unit_max rounds to at most fl(unit_max * |ucoef|) (rounding is monotone): the bound of the fixed point.
         // A zero coefficient leaves the image without a gradient whatever the unit gradient holds.
-        const int dir = b >= sp.split ? 1 : 0, pb = b - dir * sp.split;
-        const float cnt = sp.sums[pb * 4 + (dir ? 1 : 3)];
-        const float* gl = dir ? sp.gl_fwd : sp.gl_bwd;
-        ucoef = gl ? gl[pb] / ((cnt == 0.0f) ? 1.0f : cnt) : 0.0f;
-        if (ucoef != 0.0f) mx = __float_as_uint(sp.unit_max[b] * ucoef) & 0x7fffffffu;
+        const float* gl = (b >= sp.split) ? sp.gl_fwd : sp.gl_bwd;
+        ucoef = gl ? u_gl / ((u_cnt == 0.0f) ? 1.0f : u_cnt) : 0.0f;
+        if (ucoef != 0.0f) mx = __float_as_uint(u_max * ucoef) & 0x7fffffffu;
     }
     if constexpr (PAIR) {
         // ... PAIR: the pair loss's backward for the workgroup's tiles (pair_consist_backward_tiles_kernel's arithmetic, one
@@ -978,6 +988,11 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
 #pragma unroll
                 for (int k = 0; k < 3; k++) vz[j][k] = fn[j] >= 0 ? verts_b[(int64_t)vid[j][k] * 3 + 2] : 1.0f;
         }
+        // (Measured and dropped in round 5: forming the fixed-point value from the float's bits with 64-bit integer shifts
+        // instead of the double-precision ldexp + conversion -- main pass 5.2 -> 7.6 us per workgroup, the 64-bit shifts and
+        // selects are slower than the conversion sequence; summing a lane's consecutive pixels of one face in registers
+        // before the LDS atomic -- exact, a third fewer atomics, but 54 -> 82 vector registers: three workgroups per compute
+        // unit instead of four, or 92 bytes of scratch when capped.)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (fn[j] < 0) continue;

@@ -102,6 +102,7 @@ constexpr int MAX_BINS = 8192;        // LDS counters (32 KB)
 constexpr int SMALL_MAX_BINS = 8;     // a face overlapping more bins goes to the image's large list
 constexpr int REC_CAP = SMALL_MAX_BINS + 1;  // record capacity per image, in units of F: 8 F binned + F large
 constexpr int MAX_PARTS_DEV = 16;            // most workgroups per image of the binning pass (= MAX_PARTS of launch_bins)
+constexpr int ARRIVE_STRIDE = 32;            // words between the arrival counters of two images
 
 struct BinParams {
     const float* faces;      // !VC: [B,F,3,3]
@@ -129,8 +130,11 @@ struct BinParams {
     int64_t zero_count;
     // round 5: `parts` workgroups per image, each binning a contiguous range of the image's faces (see bin_boxes_kernel)
     int B, parts;
+    int poll_add;            // always 0: the addend of the polling RMWs (a literal 0 lets the compiler turn them into loads, which may
+                             // be served from the compute unit's L1 for ever)
     int* part_cnt;           // [B, parts, nbins + 4]: a part's raw bin counters + {its large faces, its "everywhere" flag}
-    unsigned* arrive;        // [B] arrival counters of the images' parts; ZERO on entry (per-face pass / the caller's clear)
+    unsigned* arrive;        // [B * ARRIVE_STRIDE] arrival counters of the images' parts, a 128-byte line each (an image's
+                             // parts count on it with atomics of their XCD's L2); ZERO on entry (per-face pass / the caller's clear)
 };
 
 // Pass A, one thread per REAL face, grid = (ceil(F0 / 256), B): back-face cull + conservative pixel bbox of the
@@ -143,7 +147,7 @@ __global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
     const int b = blockIdx.y;
     const int f0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (p.tlist && b == 0 && f0 == 0) { p.tlist->n_heavy = 0u; p.tlist->n_light = 0u; p.tlist->n_bg = 0u; }  // (this launch precedes the binning pass)
-    if (p.parts > 1 && f0 == 0) p.arrive[b] = 0u;
+    if (p.parts > 1 && f0 == 0) p.arrive[(int64_t)b * ARRIVE_STRIDE] = 0u;
     if (f0 >= p.F0) return;
     const int is = p.is;
     float f[9];
@@ -359,23 +363,31 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         __syncthreads();  // (the workgroup's stores are performed: s_waitcnt vmcnt(0) in front of the barrier)
         MR_BIN_STAMP(6);
         if (tid == 0) {
-            __hip_atomic_fetch_add(&p.arrive[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            unsigned* arr = p.arrive + (int64_t)b * ARRIVE_STRIDE;
+            __hip_atomic_fetch_add(arr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             unsigned spins = 0;
-            while (__hip_atomic_fetch_add(&p.arrive[b], 0u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)K) {
+            while (__hip_atomic_fetch_add(arr, (unsigned)p.poll_add, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)K) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 25)) __builtin_trap();  // (seconds: a part that never arrives is a bug, not a wait)
+                if (++spins > (1u << 22)) __builtin_trap();  // (a second or so: a part that never arrives is a bug, not a wait)
             }
         }
         __syncthreads();
         MR_BIN_STAMP(7);
+        // (Loads WITHOUT a device scope -- streaming hint only: they miss this compute unit's L1 -- nothing of these lines was
+        // read here before, the L1 is write-through and is invalidated when a kernel starts -- and hit the XCD's L2, where
+        // the partners' stores sit.  A device-scope load (sc1) goes PAST the L2 and returns what memory held before the
+        // partner's store: measured, the XCD check below trapped on it.)
         const int* all = p.part_cnt + (int64_t)b * K * pstride;
         for (int i = i0; i < i1; i++) {
+            int raw[MAX_PARTS_DEV];  // (all parts' counters of the bin in flight together)
+#pragma unroll
+            for (int k = 0; k < MAX_PARTS_DEV; k++) raw[k] = k < K ? __builtin_nontemporal_load(all + (int64_t)k * pstride + i) : 0;
             int tot = 0, lg = 0, bef = 0;
-            for (int k = 0; k < K; k++) {
-                const int raw = __hip_atomic_load(all + (int64_t)k * pstride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tot += raw & CNT_MASK;
-                lg |= raw & LARGE_BIT;
-                bef += k < part ? (raw & CNT_MASK) : 0;
+#pragma unroll
+            for (int k = 0; k < MAX_PARTS_DEV; k++) {
+                tot += raw[k] & CNT_MASK;
+                lg |= raw[k] & LARGE_BIT;
+                bef += k < part ? (raw[k] & CNT_MASK) : 0;
             }
             cnt[i] = tot | lg;
             before[i] = bef;
@@ -383,10 +395,11 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         if (tid < MR_WAVE) {  // (wave 0; lane k < K: part k's scalars)
             int n = 0, ev = 0;
             if (tid < K) {
-                const int* q = all + (int64_t)tid * pstride + nbins;
-                n = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ev = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned their = (unsigned)__hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (the three scalars of part `tid` through L2 atomics: coherent whatever an L1 holds)
+                int* q = p.part_cnt + ((int64_t)b * K + tid) * pstride + nbins;
+                n = __hip_atomic_fetch_add(q, p.poll_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ev = __hip_atomic_fetch_add(q + 1, p.poll_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned their = (unsigned)__hip_atomic_fetch_add(q + 2, p.poll_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (their != xcc) __builtin_trap();  // an image's parts on two XCDs: the exchange above would not be coherent
             }
             int nl = n, lb = tid < part ? n : 0, e = ev;
@@ -1253,12 +1266,11 @@ struct WorkLayout {
     size_t off_bins, off_boxes, off_recs, off_rverts, off_tlist, off_arrive, off_tile_ids, off_bg, off_part_cnt, total;
 };
 
-// Workgroups per image of the binning pass: the largest power of two (<= 16) that keeps B x parts within HALF the device's
-// compute units and leaves a part at least 256 faces.  Every workgroup of the launch is then resident at once, which the
-// parts' barrier relies on.  Why half: the exchange costs a part ~6 us of dependent L2 round trips (phase stamps,
-// scripts/wg_timeline.py), what two parts save each other at the 128 images of a training pair -- one workgroup per image
-// 22.3 us, two 23-29 us -- so parts are for the launches that leave most of the chip idle: 16 renders of config 3 (the
-// reference's default batch size) ran their set-up on 16 of 256 compute units.
+// Workgroups per image of the binning pass: the largest power of two (<= 16) that keeps B x parts within the device's
+// compute units -- every workgroup of the launch resident at once, which the parts' barrier relies on -- and leaves a part
+// at least 256 faces.  Phase stamps (scripts/wg_timeline.py, profiles/r05_binning_parts.txt): the exchange costs a part
+// ~2.5 us (publish 0.4, barrier 0.8, the other parts' counters 1.4) once it stays inside the XCD's L2; 16 renders of 480 x 480
+// (config 3, the reference's default batch size) 19.5 -> 13.9 us per workgroup, 64 renders 19.6 -> 16.6, 128 renders 21.7 -> ~19.
 static int device_cus() {
     static int cus[64] = {0};
     int dev = 0;
@@ -1272,7 +1284,7 @@ static int device_cus() {
 constexpr int MAX_PARTS = MAX_PARTS_DEV, MAX_PART_CUS = 256;
 static int bin_parts(int B, int F, int cus) {
     int k = 1;
-    while (k < MAX_PARTS && (int64_t)B * k * 2 * 2 <= cus && F / (k * 2) >= 256) k *= 2;
+    while (k < MAX_PARTS && (int64_t)B * k * 2 <= cus && F / (k * 2) >= 256) k *= 2;
     return k;
 }
 
@@ -1292,7 +1304,7 @@ static WorkLayout work_layout(int B, int F, int is) {
     w.off_tlist = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (VC needs F / 2 of it with fill-back)
     // (the images' arrival counters sit right behind the list header: ONE region for the caller of MR_FLAG_TILE_LIST_CLEARED to clear)
     w.off_arrive = w.off_tlist + align256(sizeof(TileList));
-    w.off_tile_ids = w.off_arrive + align256((size_t)B * sizeof(unsigned));
+    w.off_tile_ids = w.off_arrive + align256((size_t)B * ARRIVE_STRIDE * sizeof(unsigned));
     w.off_bg = w.off_tile_ids + align256((size_t)2 * B * tiles_x * tiles_y * sizeof(uint4));  // heavy part | light part
     w.off_part_cnt = w.off_bg + align256((size_t)B * tiles_x * tiles_y * sizeof(uint32_t));  // dense listed launches: ids of the tiles off the list
     // (sized for a 256-CU device, the most launch_bins assumes: the layout must not depend on the device at hand)
@@ -1334,7 +1346,7 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     // parts per image (bin_boxes_kernel, PARTS): B x parts workgroups, all resident at once; dbg 32: one workgroup per image
     int parts = (bp.dbg & 32) ? 1 : bin_parts(B, F, std::min(device_cus(), MAX_PART_CUS));
     if (parts > w.parts) parts = w.parts;
-    bp.B = B; bp.parts = parts;
+    bp.B = B; bp.parts = parts; bp.poll_add = 0;
     bp.part_cnt = (int*)(base + w.off_part_cnt);
     bp.arrive = (unsigned*)(base + w.off_arrive);
     size_t lds = (size_t)((nbins + 3) & ~3) * sizeof(int) * (parts > 1 ? 2 : 1);

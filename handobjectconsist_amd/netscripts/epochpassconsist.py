@@ -69,7 +69,9 @@ def train_step(batches, premodel, optimizer, check_nan=True, reducer=None):
         for batch in batches:
             loss, all_losses, _results, _pair_results = premodel.forward(batch)
             losses.append(loss.flatten())
-            logs.update({k: v for k, v in all_losses.items() if v is not None})
+            # (detached: a log entry that kept its grad_fn would keep this step's autograd graph -- and the parameters'
+            # AccumulateGrad nodes, bound to the stream they were created on -- alive in the caller's hands)
+            logs.update({k: (v.detach() if torch.is_tensor(v) else v) for k, v in all_losses.items() if v is not None})
     finally:
         for batch in batches:  # the prepared tensors belong to this step's autograd graph
             for sample in batch["data"]:
@@ -139,6 +141,12 @@ class GraphedTrainStep:
         self.premodel, self.optimizer, self.check_nan, self.max_graphs = premodel, optimizer, check_nan, max_graphs
         self._entries = {}
         self.replays = 0
+        self.last_grads = None  # gradient tensors of the last replayed step, in the optimiser's parameter order
+        # The eager first call of a batch set and the capture run on ONE side stream: autograd binds a parameter's
+        # AccumulateGrad node to the stream it is created on, and a node left over from a default-stream backward inside a
+        # capture on another stream breaks the capture (PyTorch's whole-network capture recipe warms up on a side stream
+        # for that reason; on ROCm the broken capture ends in a segmentation fault in hipStreamEndCapture).
+        self._stream = torch.cuda.Stream()
 
     def __call__(self, batches):
         key = tuple(id(b) for b in batches)
@@ -151,13 +159,18 @@ class GraphedTrainStep:
                                    "instead of handing over new ones")
             self._entries[key] = {"batches": batches, "graph": None}
             self.premodel.refresh_lambda_tensors()  # (the eager step reads the same device tensor the captures will)
-            return train_step(batches, self.premodel, self.optimizer, check_nan=self.check_nan)
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                out = train_step(batches, self.premodel, self.optimizer, check_nan=self.check_nan)
+            torch.cuda.current_stream().wait_stream(self._stream)
+            return out
         pm = self.premodel
         pm.refresh_lambda_tensors()
         if entry["graph"] is None:
             self._capture(entry)
         entry["graph"].replay()
         self.replays += 1
+        self.last_grads = entry["grads"]
         pm.step_count += entry["consist_batches"]
         if self.check_nan:
             self.optimizer._hoc_pending_nan = entry["nan_flag"]
@@ -173,14 +186,16 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=self._stream):
                 loss, logs = train_step(entry["batches"], pm, opt, check_nan=self.check_nan)
                 flag = getattr(opt, "_hoc_pending_nan", None)
         finally:
             if was_tuning:
                 tunable.tuning_enable(True)
         opt._hoc_pending_nan = None
-        entry.update(graph=graph, loss=loss, logs=logs, nan_flag=flag, consist_batches=pm.step_count - count0)
+        # (the gradient tensors the replay writes: `p.grad` points at them until somebody else resets the gradients)
+        grads = [p.grad for g in opt.param_groups for p in g["params"]]
+        entry.update(graph=graph, loss=loss, logs=logs, nan_flag=flag, consist_batches=pm.step_count - count0, grads=grads)
         pm.step_count = count0  # (nothing ran yet: the replay that follows is the step)
 
 

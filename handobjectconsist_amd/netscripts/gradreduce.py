@@ -181,8 +181,15 @@ class BucketedGradReducer:
         ``p.grad`` = the rank-summed gradient of the pre-scaled loss = the mean gradient (a view into the bucket's flat buffer)."""
         for b in self.buckets[self._next:]:
             self._launch(b)
+        if self.backend == "nccl":
+            # RCCL runs a group's collectives on ONE stream in issue order: the last bucket's completion implies the others'.
+            # One cross-stream wait instead of one per bucket (each is a barrier packet the compute queue stalls on: nine of
+            # them were most of the 0.65 ms this path cost a one-rank step, profiles/r04_one_rank_reducer_vs_plain.json)
+            self.buckets[-1].work.wait()
+        else:
+            for b in self.buckets:
+                b.work.wait()
         for b in self.buckets:
-            b.work.wait()
             b.work, b.launched, b.pending = None, False, len(b.params)
         self._next = 0
         self._flag_set = False

@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 export HOC_HIPCC_FLAGS=-DMR_WG_TIMELINE
-python handobjectconsist_amd/build.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+timeout 600 python handobjectconsist_amd/build.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
 timeout 300 python scripts/wg_timeline.py > $OUT/wg_timeline.txt 2>&1
 HOC_FWD_FLAGS=$((32 << 24)) timeout 300 python scripts/wg_timeline.py > $OUT/wg_timeline_one_wg_per_image.txt 2>&1
 HOC_TL_BATCH=8 HOC_TL_SIZE=480 timeout 300 python scripts/wg_timeline.py > $OUT/wg_timeline_480.txt 2>&1

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _build(dev, B, is_, seed, capturable):
+def _build(dev, B, is_, seed, capturable, lr=5e-5, pool=2):
     from handobjectconsist_amd.models.synthnet import SynthMeshRegNet
     from handobjectconsist_amd.models.warpreg import WarpRegNet
     from handobjectconsist_amd.netscripts.epochpassconsist import SyntheticConsistLoader
@@ -18,37 +18,78 @@ def _build(dev, B, is_, seed, capturable):
     model.eval()
     pre = WarpRegNet((is_, is_), model, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
                      progressive_steps=6, use_backward=True, mano_faces=model.mano_layer.th_faces, pair_outputs="loss").to(dev)
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, fused=True, capturable=capturable)
-    loader = SyntheticConsistLoader(B, is_, seed=3, device=dev, pool=2)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr, fused=True, capturable=capturable)
+    loader = SyntheticConsistLoader(B, is_, seed=3, device=dev, pool=pool)
     return model, pre, opt, loader
 
 
+def _grads(model):
+    return torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]).double()
+
+
 def test_graph_replay_equals_the_eager_step(cuda):
+    """ONE model, learning rate 0 (the parameters stay put): every step is done twice from the same lambda-ramp position,
+    eagerly and through GraphedTrainStep (two batch sets: one eager call each, then capture + replays) -- loss, every log
+    entry and the gradients agree (the forward is deterministic: equal to fp32 rounding of the loss sums; the gradients to
+    the order of the render backward's fp32 atomics), the ramp is followed (progressive_steps = 6), the counters advance."""
     from handobjectconsist_amd.netscripts.epochpassconsist import GraphedTrainStep, raise_pending_nan, train_step
 
     B, is_, steps = 4, 64, 9
-    m_e, pre_e, opt_e, ld_e = _build(cuda, B, is_, 11, False)
-    m_g, pre_g, opt_g, ld_g = _build(cuda, B, is_, 11, True)
-    for a, b_ in zip(m_e.parameters(), m_g.parameters()):
-        assert torch.equal(a, b_)
-    step_g = GraphedTrainStep(pre_g, opt_g)
-    losses_e, losses_g = [], []
+    model, pre, opt, loader = _build(cuda, B, is_, 11, True, lr=0.0)
+    step_g = GraphedTrainStep(pre, opt)
+    losses_g = []
     for i in range(steps):
-        le, logs_e = train_step(ld_e.step_batches(i), pre_e, opt_e)
-        lg, logs_g = step_g(ld_g.step_batches(i))
-        losses_e.append(float(le)); losses_g.append(float(lg))
+        pre.step_count = i
+        le, logs_e = train_step(loader.step_batches(i), pre, opt)
+        grads_e = [p.grad.detach().clone() for g in opt.param_groups for p in g["params"]]
+        assert pre.step_count == i + 1
+        pre.step_count = i
+        lg, logs_g = step_g(loader.step_batches(i))
+        assert pre.step_count == i + 1
+        losses_g.append(float(lg))
+        np.testing.assert_allclose(float(lg), float(le), rtol=1e-5, atol=1e-9, err_msg=f"loss at step {i}")
         assert set(logs_e) == set(logs_g)
-    raise_pending_nan(opt_e); raise_pending_nan(opt_g)
-    assert step_g.replays == steps - 2, "two batch sets: one eager call each, then replays"
-    assert pre_e.step_count == pre_g.step_count == steps
-    # the ramp (progressive_steps = 6) moves the weights during the first steps: frozen weights would show here
-    np.testing.assert_allclose(losses_g, losses_e, rtol=2e-5, atol=1e-7)
-    for (name, a), b_ in zip(m_e.named_parameters(), m_g.parameters()):
-        if a.requires_grad:
-            scale = float(a.abs().max()) + 1e-8
-            assert float((a - b_).abs().max()) <= 2e-5 * scale + 2e-7, name
-    sd_e, sd_g = opt_e.state_dict()["state"], opt_g.state_dict()["state"]
-    assert all(float(sd_e[k]["step"]) == float(sd_g[k]["step"]) == steps for k in sd_e)
+        for k in logs_e:
+            # (the consistency term of a RANDOM-INIT network: two eager calls already differ by ~5e-5 -- the heads' GEMMs and
+            # the trunk's convolutions are not bit-reproducible from call to call, and the renderer's barycentrics amplify
+            # a last-bit change of a few-pixel face by 10^3 (DESIGN.md section 2))
+            tol = 5e-4 if k == "warp_consist" else 2e-5
+            np.testing.assert_allclose(float(logs_g[k]), float(logs_e[k]), rtol=tol, atol=1e-9, err_msg=f"{k} at step {i}")
+        if i >= 2:  # a replayed step: its gradients live in the capture's own tensors
+            assert step_g.replays == i - 1
+            ge = torch.cat([g.flatten() for g in grads_e]).double()
+            gg = torch.cat([g.flatten() for g in step_g.last_grads]).double()
+            assert float((ge - gg).norm() / ge.norm()) < 1e-4, f"gradients at step {i}"
+    raise_pending_nan(opt)
+    # the ramp is followed: the same batch set gives another loss while the weights still move (steps 0 / 2 / 4) ...
+    assert abs(losses_g[0] - losses_g[2]) > 1e-7 and abs(losses_g[2] - losses_g[4]) > 1e-7
+    assert abs(losses_g[6] - losses_g[8]) <= 1e-5 * abs(losses_g[8])  # ... and the same one once it is over
+    assert all(float(st["step"]) == 2 * steps for st in opt.state_dict()["state"].values())
+
+
+def test_replayed_update_equals_the_eager_update(cuda):
+    """... and with trainmeshwarp.py's learning rate: from identical states one eager step, then one step -- replayed on
+    one side, eager on the other -- moves the parameters by the same amounts (to the noise of the fp32 atomics in the
+    gradients, which Adam's normalisation passes on: 2 % of the mean update)."""
+    from handobjectconsist_amd.netscripts.epochpassconsist import GraphedTrainStep, train_step
+
+    B, is_ = 4, 64
+    m_e, pre_e, opt_e, ld_e = _build(cuda, B, is_, 21, False, pool=1)
+    m_g, pre_g, opt_g, ld_g = _build(cuda, B, is_, 21, True, pool=1)
+    step_g = GraphedTrainStep(pre_g, opt_g)
+    train_step(ld_e.step_batches(0), pre_e, opt_e)
+    step_g(ld_g.step_batches(0))
+    before = [p.detach().clone() for p in m_g.parameters()]
+    train_step(ld_e.step_batches(1), pre_e, opt_e)
+    step_g(ld_g.step_batches(1))
+    assert step_g.replays == 1
+    torch.cuda.synchronize()
+    num = den = 0.0
+    for p_e, p_g, p0 in zip(m_e.parameters(), m_g.parameters(), before):
+        if p_e.requires_grad:
+            d_e, d_g = (p_e - p0).double(), (p_g - p0).double()
+            num += float((d_e - d_g).detach().abs().sum()); den += float(d_e.detach().abs().sum())
+    assert den > 0 and num / den < 0.02, num / den
 
 
 def test_graph_replay_stops_a_nan_on_the_device(cuda):
