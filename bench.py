@@ -871,7 +871,8 @@ def main():
         return GraphedTrainStep(pre, opt, check_nan=check_nan)
 
     step_fn = make_step(premodel, optimizer)
-    # (graph replay: a batch set's first call runs eagerly, its second captures -- both inside the warm-up)
+    # (graph replay: a batch set's first call runs eagerly, its second captures -- both untimed; when the W warm-up steps asked
+    # for do not cover them, the missing ones run in front as set-up and the line says so in `graph_setup_steps`)
     n_warm = max(args.warmup, 2 * len(loader.batches)) if graph_step else args.warmup
     for i in range(0 if args.hot_only else n_warm):
         step_fn(loader.step_batches(i))
@@ -1079,7 +1080,8 @@ def main():
                     "(same layout / solver search / TunableOp as `value`: the ONLY difference is that `value` substitutes this build's "
                     "fused BatchNorm/ReLU/residual/max-pool kernels between the stock convolutions); render + warp itself is "
                     "roofline.hot_path_device_ms of the step)",
-            "n_gpus": world, "steps": args.steps, "warmup": n_warm, "ms_per_step": round(ms, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "graph_setup_steps": n_warm - args.warmup,
+            "ms_per_step": round(ms, 3),
             "step_mode": "hipGraph replay of the captured train_step (one launch per step)" if graph_step else "eager launches",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
