@@ -192,7 +192,7 @@ def kernel_bench(dev, B, is_, iters, only=None):
 
     def render_bwd_train():  # detach_renders=True: textures only (kernel E), as neurender.rasterize launches it
         _lib.call("mr_render_backward", P(faces), P(tex2), P(fim), P(rgb), P(alpha), P(g_rgb), None, None, None,
-                  P(grad_tex), P(bl_work), bl_bytes, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, 0, st)
+                  P(grad_tex), P(bl_work), bl_bytes, B, F, is_, 2, 0.1, 100.0, 1e-3, 1, 1, 1, int(os.environ.get("HOC_BWD_FLAGS", "0")), st)
 
     bw_bytes = int(lib.mr_render_backward_workspace_bytes(B, F, is_))
     bw_work = torch.empty((bw_bytes,), dtype=torch.uint8, device=dev)
@@ -341,17 +341,18 @@ def kernel_bench(dev, B, is_, iters, only=None):
                   0.99999, tlist[0], tlist[1], tlist[2], tl_bound, st)
 
     punit, punit_max, lsum = torch.empty((B2, is_, is_, 2), **f32), torch.empty((B2,), **f32), torch.empty((B,), **f32)
+    pswork = torch.empty((int(_lib.load().mr_flow_pair_scatter_work_bytes(B, is_)),), dtype=torch.uint8, device=dev)
 
     def flow_pair_fwd_grad_tiles():  # ... and as the step launches it when the vertices want a gradient (they do)
         _lib.call("mr_flow_pair_forward_grad_tiles", P(pmask[:B]), P(palpha[B:]), P(prgb[:B]), P(prgb[B:]), 3 * is_ * is_,
                   P(pmask[:B]), P(pmask[B:]), P(pocc[:B]), P(pocc[B:]), P(pflows[:B]), P(pflows[B:]), P(ptile_hit[:B]),
                   P(ptile_hit[B:]), P(im_ref), P(im), P(jm_ref), P(jm), 3, P(ptwork), ptbytes, P(sums), P(lf), P(lb), B, is_, is_,
-                  is_, 0.03, 0.99999, 0.99999, tlist[0], tlist[1], tlist[2], tl_bound, P(punit), P(punit_max), P(lsum), st)
+                  is_, 0.03, 0.99999, 0.99999, tlist[0], tlist[1], tlist[2], tl_bound, P(punit), P(punit_max), P(lsum), P(pswork), st)
 
     def flow_pair_bwd_unit_tiles():  # the step's backward launch (output cleared by the forward's binning pass, as in the step)
         _lib.call("mr_flow_pair_backward_unit_tiles", P(pfim), P(ptile_hit), P(pwrec), P(pvid), P(punit), P(punit_max), P(sums),
                   P(gl), P(gl), is_, is_, P(pg_cols), B2, pv.shape[1], F0, 1, is_, 1e-3,
-                  _lib.FLAG_OUTPUT_ZEROED | (int(os.environ.get("HOC_FLOW_BWD_DBG", "0")) << 8), 0, st)
+                  _lib.FLAG_OUTPUT_ZEROED | (int(os.environ.get("HOC_FLOW_BWD_DBG", "0")) << 8), 0, P(pswork), st)
 
     pscratch = torch.empty((B2, is_, is_, 2), **f32)
 

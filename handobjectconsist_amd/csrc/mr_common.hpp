@@ -434,6 +434,25 @@ __device__ __forceinline__ void rodrigues_bwd(const float* r, const float* gR, f
     for (int k = 0; k < 3; k++) gr[k] = g_ax[k] / angle + g_angle * a[k] / angle;
 }
 
+// Covered-tile lists of the 2B stack images of a frame pair (round 5, ABI 7): mr_flow_pair_forward_grad_tiles' finalize
+// launch compacts the coverage words it reads anyway, mr_flow_pair_backward_unit_tiles hands out its workgroups over them in
+// proportion to the images' covered tiles (raster_bwd.hip, scatter_tiles_body WORK).  Layout of the buffer:
+//   int n_cov[2B] (padded to 256 bytes) | uint16 cov[2B][tiles per image]  (ids of the image's covered tiles, ascending)
+struct ScatterWork {
+    int* n_cov;
+    unsigned short* cov;
+};
+__host__ __device__ inline int64_t scatter_work_cov_offset(int images) { return ((int64_t)images * 4 + 255) & ~(int64_t)255; }
+__host__ __device__ inline int64_t scatter_work_bytes(int images, int tiles) {
+    return scatter_work_cov_offset(images) + (((int64_t)images * tiles * 2 + 255) & ~(int64_t)255);
+}
+__host__ __device__ inline ScatterWork scatter_work_at(void* buf, int images) {
+    ScatterWork w;
+    w.n_cov = reinterpret_cast<int*>(buf);
+    w.cov = buf ? reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(buf) + scatter_work_cov_offset(images)) : nullptr;
+    return w;
+}
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a
 // contiguous range of logical ids so the tiles / faces of one image share one L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {

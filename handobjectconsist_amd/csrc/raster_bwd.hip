@@ -60,6 +60,7 @@ struct GatherParams {
     // others were zeroed when the list was built
     const uint32_t* owners;
     const unsigned* n_owners;
+    int dbg_rows;             // profiling: 1 = the row-walking form of the small-face path
 };
 
 template <bool IMG, bool TEX, bool DEPTH>
@@ -210,15 +211,43 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
         Face f;
         load_face(p.faces + i * 9, f, is);
         const int32_t* fim_b = p.fim + (int64_t)b * is * is;
-        for (int yi = bx.y0 + sub; yi <= bx.y1; yi += GGL)
-            for (int xi = bx.x0; xi <= bx.x1; xi += 4) {
-                int hit[4];  // four probes in flight
+        if (p.dbg_rows) {  // (profiling: the round-4 form -- every lane evaluates the pixels of its own rows)
+            for (int yi = bx.y0 + sub; yi <= bx.y1; yi += GGL)
+                for (int xi = bx.x0; xi <= bx.x1; xi += 4) {
+                    int hit[4];  // four probes in flight
 #pragma unroll
-                for (int u = 0; u < 4; u++) hit[u] = fim_b[yi * is + min(xi + u, (int)bx.x1)];
+                    for (int u = 0; u < 4; u++) hit[u] = fim_b[yi * is + min(xi + u, (int)bx.x1)];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (xi + u <= bx.x1 && hit[u] == fn) gather_pixel<IMG, TEX, DEPTH>(p, f, b, xi + u, yi, gt, gf);
-            }
+                    for (int u = 0; u < 4; u++)
+                        if (xi + u <= bx.x1 && hit[u] == fn) gather_pixel<IMG, TEX, DEPTH>(p, f, b, xi + u, yi, gt, gf);
+                }
+        } else {
+            // Round 5.  The face's box goes by chunks of GGL rows x 4 columns: lane `sub` probes row `sub` of the chunk (four
+            // probes in flight), the group ORs its lanes' results into one 32-bit mask, and the pixels the face WON are then
+            // dealt out over the group's lanes by rank -- the few-pixel faces of a dense mesh win 4.6 of the 14 pixels of
+            // their box, so one trip through the ~250 instructions of a pixel serves a whole face at more than half of the
+            // lanes, where "every lane walks its own row" ran four trips (one per column) at a sixth of them.
+            for (int yc = bx.y0; yc <= bx.y1; yc += GGL)
+                for (int xc = bx.x0; xc <= bx.x1; xc += 4) {
+                    const int yi = yc + sub;
+                    const int yl = min(yi, (int)bx.y1);
+                    int hit[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) hit[u] = fim_b[yl * is + min(xc + u, (int)bx.x1)];
+                    unsigned gm = 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) gm |= (yi <= bx.y1 && xc + u <= bx.x1 && hit[u] == fn) ? (1u << (sub * 4 + u)) : 0u;
+#pragma unroll
+                    for (int off = 1; off < GGL; off <<= 1) gm |= (unsigned)__shfl_xor((int)gm, off);
+                    const int won = __popc(gm);
+                    for (int r = sub; r < won; r += GGL) {
+                        unsigned m = gm;
+                        for (int k = 0; k < r; k++) m &= m - 1u;  // drop the r lowest set bits
+                        const int pos = __ffs((int)m) - 1;
+                        gather_pixel<IMG, TEX, DEPTH>(p, f, b, xc + (pos & 3), yc + (pos >> 2), gt, gf);
+                    }
+                }
+        }
     }
     // quad reduction: afterwards every lane of the quad holds the face's sums
 #pragma unroll
@@ -705,6 +734,9 @@ constexpr int ST_G = 8;       // workgroups per image (sp.groups; profiling: fla
 constexpr int ST_WAVES = 8;   // waves per workgroup
 constexpr int ST_TW = 32, ST_TH = 8;  // the forward's tile
 constexpr int ST_MAX_TILES = 4096;    // tiles per image the covered-tile list in LDS can hold (1024 x 1024 pixels)
+// fixed point of the per-workgroup sums: terms below 2^ST_FIX_BITS in magnitude (2^-37 of the workgroup's largest gradient
+// per term: 13 bits below the last bit of an fp32 value of that size), sums below 2^ST_SUM_BITS (see scatter_tiles_body)
+constexpr int ST_FIX_BITS = 37, ST_SUM_BITS = 50;
 
 struct ScatterTilesParams {
     GatherVCParams g;
@@ -740,6 +772,8 @@ struct ScatterTilesParams {
     // a coefficient of 1, masks applied; this launch multiplies by grad_loss / count of the image -- no taps, no pass 1
     const float* unit_grad;   // [B,H,W,2]
     const float* unit_max;    // [B] largest |unit gradient| per image (an upper bound is enough)
+    // WORK (round 5): the images' covered-tile lists the forward's finalize launch left (mr_common.hpp, ScatterWork)
+    ScatterWork work;
 };
 
 template <bool FLOWGRAD, bool PAIR = false, bool UNIT = false>
@@ -788,22 +822,113 @@ __device__ unsigned long long mr_dbg_st[4096 * 8];  // profiling builds: phase s
 #define MR_ST_STAMP(k) do { } while (0)
 #endif
 
-template <bool FLOWGRAD, bool REC, bool PAIR, bool UNIT = false>
+// inclusive sum over the lanes of a wave (int): row shifts and the two row broadcasts of the gfx9 DPP unit -- six vector
+// instructions, no LDS crossbar (a lane without a source adds 0)
+__device__ __forceinline__ int wave_incl_sum(int v, int lane) {
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+    return v;
+}
+
+template <bool FLOWGRAD, bool REC, bool PAIR, bool UNIT = false, bool WORK = false>
 __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp) {
     MR_ST_STAMP(0);
     extern __shared__ long long vtab[];  // [V * NCH] rounded up to an even count
     constexpr int NCH = FLOWGRAD ? 2 : 3;  // (the flow-space gradient has no third channel)
     __shared__ unsigned wmax[ST_WAVES];
-    __shared__ unsigned short hits[ST_MAX_TILES];  // the image's covered tiles, ascending
+    __shared__ unsigned short hits[WORK ? 1 : ST_MAX_TILES];  // the image's covered tiles, ascending
     const GatherVCParams& p = sp.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int G = sp.groups;
+    int G = sp.groups;
     // PAIR: an image's workgroups on the XCD whose L2 holds what the forward launches just wrote for it (their tile lists are
     // image-major and every XCD takes a contiguous eighth: images [x B / 8, (x + 1) B / 8) on XCD x, more or less)
     const unsigned lidx = (PAIR || FLOWGRAD) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    const int b = (int)(lidx / (unsigned)G), part = (int)(lidx % (unsigned)G);
+    int b = (int)(lidx / (unsigned)G), part = (int)(lidx % (unsigned)G);
     const int is = p.is;
     const int T = sp.tiles_x * sp.tiles_y;
+    int n_hits = 0;
+    // WORK: the table is zeroed FIRST (it needs nothing but V), so that the barrier behind it can wait where the first LDS
+    // atomic is about to be issued -- behind the tile's loads instead of in front of them
+    if constexpr (WORK)
+        for (int k = threadIdx.x; k < (p.V * NCH + 1) >> 1; k += blockDim.x) reinterpret_cast<int4*>(vtab)[k] = make_int4(0, 0, 0, 0);
+    const unsigned short* cov_b = nullptr;  // WORK: this workgroup's share of the forward's list of the image's covered tiles
+    int t_first = 0;
+    auto tile_at = [&](int h) -> int { return WORK ? (h == wave ? t_first : (int)cov_b[h]) : (int)hits[h]; };
+    if constexpr (WORK) {
+        // WORK (round 5): the launch's workgroups are handed out over the images IN PROPORTION TO THEIR COVERED TILES.  With a
+        // fixed number per image the images that cover more than G x ST_WAVES tiles need a second round of their waves while
+        // the waves of the others idle: on the bench scene (45 covered tiles per image on average, 8 x 8 waves) a third of the
+        // workgroups ran two rounds and the launch ended at 18.8 us with the average workgroup done at 12.5
+        // (profiles/r05_bwd_timeline_before.txt).  Every wave derives the split from the per-image counts the forward's
+        // finalize launch left: q = tiles per workgroup (at least one per wave) such that sum ceil(n_b / q) fits the grid,
+        // image b gets ceil(n_b / q) workgroups sharing its n_b tiles evenly, and the workgroups in use are spread over the
+        // logical index range so that every XCD gets the same share.  No listing pass, no LDS list.
+        const int B2 = p.B, grid = (int)gridDim.x;
+        const int* ncov = sp.work.n_cov;
+        // (every quantity below is the same in all lanes: readlane keeps it in scalar registers; the scans are DPP row shifts,
+        // six vector instructions each, no LDS crossbar)
+        // First try: one tile per wave (q = ST_WAVES) -- it fits whenever the scene leaves the grid some room, and then ONE pass
+        // over the counts gives everything; else q = ceil(N / room) and a second pass.
+        int q = ST_WAVES, used = 0, N = 0;
+        for (int c = 0; c < B2; c += MR_WAVE) {
+            const int n = c + lane < B2 ? ncov[c + lane] : 0;
+            N += __builtin_amdgcn_readlane(wave_incl_sum(n, lane), MR_WAVE - 1);
+            used += __builtin_amdgcn_readlane(wave_incl_sum((n + ST_WAVES - 1) / ST_WAVES, lane), MR_WAVE - 1);
+        }
+        if (used > grid) {
+            const int room = max(grid - B2, 1);  // (sum ceil(n_b / q) <= N / q + B2)
+            q = max(ST_WAVES, (N + room - 1) / room);
+            used = 0;
+            for (int c = 0; c < B2; c += MR_WAVE) {
+                const int n = c + lane < B2 ? ncov[c + lane] : 0;
+                used += __builtin_amdgcn_readlane(wave_incl_sum((n + q - 1) / q, lane), MR_WAVE - 1);
+            }
+            if (used > grid) used = grid;  // (grid <= images: cannot be; the surplus images would go without a gradient)
+        }
+        // logical index -> slot k of the `used` workgroups with work.  xcd_remap gave XCD x the logical indices [x grid / 8,
+        // (x + 1) grid / 8): it takes the slots [x used / 8, (x + 1) used / 8) with the first of them -- every XCD the same share
+        // of the work, images in list order (as the forward's tile list hands them to the XCDs), divisions by 8 only
+        int k;
+        if ((grid & 7) == 0) {
+            const int per = grid >> 3, x = (int)lidx / per, j = (int)lidx - x * per;
+            const int k0 = (int)(((long long)x * used) >> 3), k1 = (int)(((long long)(x + 1) * used) >> 3);
+            if (j >= k1 - k0) return;
+            k = k0 + j;
+        } else {
+            if ((int)lidx >= used) return;
+            k = (int)lidx;
+        }
+        int base = 0, nb = 0, pb = 1;
+        b = -1;
+        for (int c = 0; c < B2 && b < 0; c += MR_WAVE) {
+            const int n = c + lane < B2 ? ncov[c + lane] : 0;
+            const int parts = (n + q - 1) / q;
+            const int incl = wave_incl_sum(parts, lane);
+            const unsigned long long mine = __ballot(k >= base + incl - parts && k < base + incl);
+            if (mine != 0ull) {
+                const int src = __ffsll((long long)mine) - 1;
+                b = c + src;
+                part = k - (base + __builtin_amdgcn_readlane(incl - parts, src));
+                nb = __builtin_amdgcn_readlane(n, src);
+                pb = __builtin_amdgcn_readlane(parts, src);
+            }
+            base += __builtin_amdgcn_readlane(incl, MR_WAVE - 1);
+        }
+        if (b < 0) return;  // (cannot happen: k < used)
+        // this workgroup's share of the image's list: tiles [first, first + n_hits); its waves take them round-robin
+        const int each = nb / pb, rem = nb % pb;
+        const int first = part * each + min(part, rem);
+        n_hits = each + (part < rem ? 1 : 0);
+        cov_b = sp.work.cov + (int64_t)b * T + first;
+        part = 0; G = 1;
+        // (the wave's first tile id is requested now: its round trip runs beside the image's scalars and the table zeroing)
+        t_first = wave < n_hits ? (int)cov_b[wave] : 0;
+    }
     const int r = lane >> 3, x4 = (lane & 7) * 4;  // the lane's pixel quad inside a tile
     const int32_t* fim_b = p.fim + (int64_t)b * is * is;
     const float* verts_b = p.verts + (int64_t)b * p.V * 3;
@@ -824,8 +949,7 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
     // requested up front and compacted behind one barrier -- eight predicated rounds unrolled -- measured SLOWER than
     // this loop at 1024 tiles per image: 1.98 against 1.54 us.)
     __shared__ int wcnt[ST_WAVES];
-    int n_hits = 0;
-    for (int t0 = 0; t0 < T; t0 += blockDim.x) {
+    for (int t0 = 0; t0 < T && !WORK; t0 += blockDim.x) {
         const int t = t0 + threadIdx.x;
         const bool hit = t < T && (sp.tile_hit ? sp.tile_hit[(int64_t)b * T + t] != 0u : true);
         const unsigned long long m = __ballot(hit);
@@ -841,7 +965,7 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
     MR_ST_STAMP(1);
     if (part * ST_WAVES >= n_hits) return;  // fewer covered tiles than waves before this workgroup: nothing to do
     const int n2 = (p.V * NCH + 1) >> 1;
-    for (int k = threadIdx.x; k < n2; k += blockDim.x) reinterpret_cast<int4*>(vtab)[k] = make_int4(0, 0, 0, 0);
+    for (int k = threadIdx.x; k < n2 && !WORK; k += blockDim.x) reinterpret_cast<int4*>(vtab)[k] = make_int4(0, 0, 0, 0);
 
     // pass 1: largest |gradient| over the workgroup's covered tiles, as float bits -- or the caller's bound for the image
     unsigned mx = 0u;
@@ -873,7 +997,7 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
         const float* jit = dir ? sp.jitter : sp.jitter_ref;
         const int64_t hw_img = (int64_t)sp.H * sp.W;
         for (int m = half; m < n_mine; m += 2) {
-            const int t = hits[part * ST_WAVES + (m % ST_WAVES) + (m / ST_WAVES) * G * ST_WAVES];
+            const int t = tile_at(part * ST_WAVES + (m % ST_WAVES) + (m / ST_WAVES) * G * ST_WAVES);
             const int x = (t % sp.tiles_x) * ST_TW + (tid & 31), ry = (t / sp.tiles_x) * ST_TH + (tid >> 5);
             const int y = is - 1 - ry;
             if (x >= sp.W || ry >= is || y >= sp.H) continue;
@@ -906,7 +1030,7 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
         __threadfence_block();  // the stash is read back by other waves of this workgroup after the barrier below
     }
     for (int h = part * ST_WAVES + wave; h < n_hits && !bounded; h += G * ST_WAVES) {
-        const int t = hits[h];
+        const int t = tile_at(h);
         const int yi = (t / sp.tiles_x) * ST_TH + r, x = (t % sp.tiles_x) * ST_TW + x4;
         if (yi >= is || x >= is) continue;  // partial tile at the image border (rows are multiples of 4 wide)
         float g[4][3];
@@ -916,30 +1040,44 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) mx = max(mx, __float_as_uint(g[j][ch]) & 0x7fffffffu);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
-    if (lane == 0) wmax[wave] = mx;
-    __syncthreads();  // table zeroed, maxima visible
-    MR_ST_STAMP(2);
     unsigned bm = 0u;
+    bool synced = !WORK;  // WORK: the barrier behind the table zeroing waits in front of the first LDS atomic (pass 2)
+    if constexpr (UNIT) {
+        if (!WORK) __syncthreads();  // table zeroed
+        MR_ST_STAMP(2);
+        bm = mx;          // (the image's bound: the same in every lane of the workgroup, nothing to reduce)
+    } else {
 #pragma unroll
-    for (int k = 0; k < ST_WAVES; k++) bm = max(bm, wmax[k]);
+        for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+        if (lane == 0) wmax[wave] = mx;
+        __syncthreads();  // table zeroed, maxima visible
+        MR_ST_STAMP(2);
+#pragma unroll
+        for (int k = 0; k < ST_WAVES; k++) bm = max(bm, wmax[k]);
+    }
     if (bm == 0u) return;                  // every gradient is +-0: nothing to add (block-uniform)
     const bool finite = bm < 0x7f800000u;  // else: fp32 global atomics, Inf / NaN propagate
     // A table cell receives at most 3 terms per pixel (a face may name one vertex three times) of every tile this
-    // workgroup walks, each below 2^SV_FIX_BITS in magnitude: 2^13 terms fit an int64.  A workgroup with more
-    // (beyond ten covered tiles: large rasters, screen-filling meshes) gives up one bit of the 50 per doubling -- at
-    // the 256 tiles the list can hold per workgroup that is still 2^-45 of the largest gradient per term.
+    // workgroup walks, each below 2^ST_FIX_BITS in magnitude: 2^13 of them fit the 51-bit field of the sums.  A workgroup
+    // with more (beyond ten covered tiles: large rasters, screen-filling meshes) gives up one bit of the 37 per doubling
+    // -- at 256 tiles per workgroup that is still 2^-32 of the largest gradient per term.
     const int rem = n_hits - part * ST_WAVES;
     const long long terms = 3LL * ST_TW * ST_TH * ((rem / (G * ST_WAVES)) * ST_WAVES + min(rem % (G * ST_WAVES), ST_WAVES));
     int headroom = 0;
-    while ((terms >> headroom) >= (1LL << (63 - SV_FIX_BITS))) headroom++;
-    const int shift = SV_FIX_BITS - headroom - ((int)(bm >> 23) - 126);
+    while ((terms >> headroom) >= (1LL << (ST_SUM_BITS - ST_FIX_BITS))) headroom++;
+    const int shift = ST_FIX_BITS - headroom - ((int)(bm >> 23) - 126);
+    // Round 5: float -> fixed point by the "magic number" addition, two double-precision instructions per value instead of
+    // eight (cvt, ldexp, trunc, ldexp, floor, fma, two conversions: the main pass was bound by them -- 24 values per lane, 8
+    // waves per SIMD): v 2^shift + 1.5 x 2^52, rounded to an integer by that very addition, has v's fixed-point value in two's
+    // complement in the low 51 bits of its mantissa field and a CONSTANT above them; the raw bit patterns are summed by the
+    // 64-bit LDS atomics, the constants pile up above bit 50 and are dropped at the flush (sign extension from bit 50).
+    // |terms| < 2^ST_FIX_BITS and at most 2^(ST_SUM_BITS - ST_FIX_BITS) of them per cell: the sum stays inside the field.
+    const double fix_scale = ldexp(1.0, shift);
     float* out = p.grad_vcolors + (int64_t)b * p.V * 3;
 
     // pass 2
     for (int h = part * ST_WAVES + wave; h < n_hits; h += G * ST_WAVES) {
-        const int t = hits[h];
+        const int t = tile_at(h);
         const int yi = (t / sp.tiles_x) * ST_TH + r, x = (t % sp.tiles_x) * ST_TW + x4;
         const bool inside = yi < is && x < is;
         int4 f4 = make_int4(-1, -1, -1, -1);
@@ -993,6 +1131,10 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
         // selects are slower than the conversion sequence; summing a lane's consecutive pixels of one face in registers
         // before the LDS atomic -- exact, a third fewer atomics, but 54 -> 82 vector registers: three workgroups per compute
         // unit instead of four, or 92 bytes of scratch when capped.)
+        if (!synced) {  // (every wave passes exactly one of these: here in its first trip, or behind the loop)
+            __syncthreads();
+            synced = true;
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (fn[j] < 0) continue;
@@ -1029,19 +1171,20 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
                     const int vtx = REC ? vid[j][k] : sel3(vid[j][0], vid[j][1], vid[j][2], texel_vertex(p.texel, k, fn[j] >= p.F0));
                     const int cell = vtx * NCH + ch;
                     if (finite) {
-                        const long long q = (long long)ldexp((double)v, shift);
-                        if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&vtab[cell]), (unsigned long long)q);
+                        const double d = __builtin_fma((double)v, fix_scale, 6755399441055744.0);
+                        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&vtab[cell]), (unsigned long long)__double_as_longlong(d));
                     } else if (v != 0.0f) {
                         atomicAdd(&out[vtx * 3 + ch], v);
                     }
                 }
         }
     }
+    if (!synced) __syncthreads();  // (a wave without a tile)
     if (!finite) return;  // block-uniform
     __syncthreads();
     MR_ST_STAMP(3);
     for (int k = threadIdx.x; k < p.V * NCH; k += blockDim.x) {
-        const long long tsum = vtab[k];
+        const long long tsum = (long long)((unsigned long long)vtab[k] << (64 - ST_SUM_BITS - 1)) >> (64 - ST_SUM_BITS - 1);
         if (tsum != 0) {
             const float v = (float)ldexp((double)tsum, -shift);
             if (v != 0.0f) atomicAdd(&out[(k / NCH) * 3 + k % NCH], v);
@@ -1064,8 +1207,12 @@ pair_scatter_tiles_kernel(ScatterTilesParams sp) {
 
 // ... and with the pair loss's gradient already formed by the forward launch (mr_flow_pair_backward_unit_tiles): the
 // scatter alone, its gradient = unit gradient x the image's coefficient, its bound = the forward's maximum x |coefficient|
+__global__ void __launch_bounds__(ST_WAVES * MR_WAVE) unit_scatter_listing_kernel(ScatterTilesParams sp) {
+    scatter_tiles_body<true, true, false, true, false>(sp);
+}
+// ... and with the workgroups handed out over the forward's covered-tile lists (WORK; what the step launches since round 5)
 __global__ void __launch_bounds__(ST_WAVES * MR_WAVE) unit_scatter_tiles_kernel(ScatterTilesParams sp) {
-    scatter_tiles_body<true, true, false, true>(sp);
+    scatter_tiles_body<true, true, false, true, true>(sp);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1887,9 +2034,36 @@ __global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p,
                             work(y);
                         }
                     }
-                    if (mine) {
-                        if (t_use0 && ww.x != 0.0f) unsafeAtomicAdd(&acc[src].x, ww.x);
-                        if (t_use1 && ww.y != 0.0f) unsafeAtomicAdd(&acc[src].y, ww.y);
+                    // The chunks of an item are CONSECUTIVE tasks (at most 16): their sums are added up over the lanes of the
+                    // segment and its first lane adds the total to the item's slot with a plain LDS read-modify-write -- an
+                    // item has one segment per round, and the rounds of a wave run one behind the other.  (Round 5: these were
+                    // two LDS float atomics per round; ds_add_f32 costs ~12 cycles PER ACTIVE LANE on gfx950 -- 770 cycles for
+                    // a full wave whatever the addresses, 30 x a ds_add_u64, profiles/r05_valu_rate_probe.txt -- i.e. as much
+                    // as the sixteen terms of the chunks themselves.)
+                    if (p.dbg & 16) {
+                        if (mine) {
+                            if (t_use0 && ww.x != 0.0f) unsafeAtomicAdd(&acc[src].x, ww.x);
+                            if (t_use1 && ww.y != 0.0f) unsafeAtomicAdd(&acc[src].y, ww.y);
+                        }
+                    } else {
+                        float sx = (mine && t_use0) ? ww.x : 0.0f, sy = (mine && t_use1) ? ww.y : 0.0f;
+                        const int seg = mine ? src : -1 - lane;
+#pragma unroll
+                        for (int off = 1; off < 16; off <<= 1) {
+                            // (every shuffle in full-wave control flow: a lane that is masked off hands out zeros)
+                            const float ox = __shfl_down(sx, off), oy = __shfl_down(sy, off);
+                            const int os = __shfl_down(seg, off);
+                            const bool same = lane + off < MR_WAVE && os == seg;
+                            sx += same ? ox : 0.0f;
+                            sy += same ? oy : 0.0f;
+                        }
+                        const int prev = __shfl_up(seg, 1);
+                        const bool head = mine && (lane == 0 || prev != seg);
+                        if (head && (sx != 0.0f || sy != 0.0f)) {
+                            float2 a = acc[src];
+                            a.x += sx; a.y += sy;
+                            acc[src] = a;
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();  // (the next kind / batch overwrites the task list)
@@ -2235,6 +2409,7 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
         g.grad_textures = gather_tex ? grad_textures : nullptr;
         g.B = batch_size; g.F = num_faces; g.is = image_size; g.eps = eps;
         g.accumulate_faces = want_d ? 1 : 0;
+        g.dbg_rows = (flags >> 8) & 32 ? 1 : 0;
         if (use_list) {
             const OwnerList ol = owner_list(workspace, batch_size, num_faces);
             g.owners = ol.list; g.n_owners = ol.counter;
@@ -2383,7 +2558,8 @@ extern "C" int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, c
                                                 const float* unit_grad_max, const float* sums, const float* grad_loss_fwd,
                                                 const float* grad_loss_bwd, int height, int width, float* grad_vcolors,
                                                 int batch_size, int num_verts, int num_faces, int fill_back, int image_size,
-                                                float eps, int flags, int texel_layout, mr_stream_t stream) {
+                                                float eps, int flags, int texel_layout, const void* scatter_work,
+                                                mr_stream_t stream) {
     if (batch_size < 0 || (batch_size & 1) || num_faces < 0 || num_verts < 0 || image_size <= 0 || !texel_layout_ok(texel_layout))
         return MR_ERR_BADARG;
     if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
@@ -2416,7 +2592,13 @@ extern "C" int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, c
     sp.unit_grad = unit_grad; sp.unit_max = unit_grad_max; sp.sums = sums; sp.gl_fwd = grad_loss_fwd; sp.gl_bwd = grad_loss_bwd;
     const int64_t blocks = (int64_t)batch_size * sp.groups;
     if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
-    hipLaunchKernelGGL(unit_scatter_tiles_kernel, dim3((unsigned)blocks), dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
+    // (the covered-tile lists need the workgroup split's head room: grid > images; profiling bit 15 of flags: the listing form)
+    if (scatter_work && sp.groups >= 2 && !(flags & (1 << 15))) {
+        sp.work = scatter_work_at(const_cast<void*>(scatter_work), batch_size);
+        hipLaunchKernelGGL(unit_scatter_tiles_kernel, dim3((unsigned)blocks), dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
+    } else {
+        hipLaunchKernelGGL(unit_scatter_listing_kernel, dim3((unsigned)blocks), dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
+    }
     MR_CHECK_LAUNCH();
     return MR_OK;
 }

@@ -802,20 +802,55 @@ __global__ void __launch_bounds__(256) pair_consist_finalize_tiles_kernel(const 
                                                                           float* __restrict__ loss_bwd,
                                                                           const unsigned* __restrict__ tile_max,
                                                                           unsigned* __restrict__ image_max,
-                                                                          float* __restrict__ loss_sum) {
+                                                                          float* __restrict__ loss_sum, ScatterWork work) {
     __shared__ float red[4][4];
     __shared__ unsigned redm[4][2];
+    __shared__ int wcov[2][4];
     const int b = blockIdx.x;
     float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     unsigned m12 = 0u, m21 = 0u;  // largest unit-gradient magnitude (float bits) of stack images b and B + b
-    for (int t = threadIdx.x; t < T; t += 256) {
-        const uint32_t h21 = hit21[(int64_t)b * T + t], h12 = hit12[(int64_t)b * T + t];
-        const float2 v1 = *reinterpret_cast<const float2*>(partial + ((int64_t)(B + b) * T + t) * 2);
-        const float2 v2 = *reinterpret_cast<const float2*>(partial + ((int64_t)b * T + t) * 2);
-        unsigned t21 = 0u, t12 = 0u;
-        if (tile_max) { t21 = tile_max[(int64_t)(B + b) * T + t]; t12 = tile_max[(int64_t)b * T + t]; }
-        if (h21 != 0u) { a[0] += v1.x; a[1] += v1.y; m21 = max(m21, t21); }
-        if (h12 != 0u) { a[2] += v2.x; a[3] += v2.y; m12 = max(m12, t12); }
+    if (work.cov) {
+        // ... and the ids of the covered tiles of stack images b and B + b, compacted (ascending) for the raster backward's
+        // launch (ScatterWork, mr_common.hpp): this workgroup holds the coverage words of both anyway
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int base12 = 0, base21 = 0;
+        for (int t0 = 0; t0 < T; t0 += 256) {
+            const int t = t0 + (int)threadIdx.x;
+            const bool in = t < T;
+            const int tc = in ? t : T - 1;
+            const uint32_t h21 = hit21[(int64_t)b * T + tc], h12 = hit12[(int64_t)b * T + tc];
+            const float2 v1 = *reinterpret_cast<const float2*>(partial + ((int64_t)(B + b) * T + tc) * 2);
+            const float2 v2 = *reinterpret_cast<const float2*>(partial + ((int64_t)b * T + tc) * 2);
+            unsigned t21 = 0u, t12 = 0u;
+            if (tile_max) { t21 = tile_max[(int64_t)(B + b) * T + tc]; t12 = tile_max[(int64_t)b * T + tc]; }
+            const bool c21 = in && h21 != 0u, c12 = in && h12 != 0u;
+            if (c21) { a[0] += v1.x; a[1] += v1.y; m21 = max(m21, t21); }
+            if (c12) { a[2] += v2.x; a[3] += v2.y; m12 = max(m12, t12); }
+            const unsigned long long k12 = __ballot(c12), k21 = __ballot(c21);
+            if (lane == 0) { wcov[0][wave] = __popcll(k12); wcov[1][wave] = __popcll(k21); }
+            __syncthreads();
+            int o12 = base12, o21 = base21;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                o12 += w < wave ? wcov[0][w] : 0; o21 += w < wave ? wcov[1][w] : 0;
+                base12 += wcov[0][w]; base21 += wcov[1][w];
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (c12) work.cov[(int64_t)b * T + o12 + __popcll(k12 & below)] = (unsigned short)t;
+            if (c21) work.cov[(int64_t)(B + b) * T + o21 + __popcll(k21 & below)] = (unsigned short)t;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { work.n_cov[b] = base12; work.n_cov[B + b] = base21; }
+    } else {
+        for (int t = threadIdx.x; t < T; t += 256) {
+            const uint32_t h21 = hit21[(int64_t)b * T + t], h12 = hit12[(int64_t)b * T + t];
+            const float2 v1 = *reinterpret_cast<const float2*>(partial + ((int64_t)(B + b) * T + t) * 2);
+            const float2 v2 = *reinterpret_cast<const float2*>(partial + ((int64_t)b * T + t) * 2);
+            unsigned t21 = 0u, t12 = 0u;
+            if (tile_max) { t21 = tile_max[(int64_t)(B + b) * T + t]; t12 = tile_max[(int64_t)b * T + t]; }
+            if (h21 != 0u) { a[0] += v1.x; a[1] += v1.y; m21 = max(m21, t21); }
+            if (h12 != 0u) { a[2] += v2.x; a[3] += v2.y; m12 = max(m12, t12); }
+        }
     }
     if (image_max) {  // (uniform)
 #pragma unroll
@@ -1110,6 +1145,11 @@ extern "C" int64_t mr_pair_consist_tiles_workspace_bytes(int batch_size, int hit
     return 2LL * batch_size * ((hit_image_size + 31) / 32) * ((hit_image_size + 7) / 8) * 3 * (int64_t)sizeof(float);
 }
 
+extern "C" int64_t mr_flow_pair_scatter_work_bytes(int batch_size, int image_size) {
+    if (batch_size < 0 || image_size <= 0) return MR_ERR_BADARG;
+    return scatter_work_bytes(2 * batch_size, ((image_size + 31) / 32) * ((image_size + 7) / 8));
+}
+
 static int pair_tiles_args_ok(const float* flow12, const float* flow21, const float* image_ref, const float* image,
                               const float* jitter_ref, const float* jitter, int jitter_channels, int batch_size, int height,
                               int width, const uint8_t* tile_hit12, const uint8_t* tile_hit21, int hit_image_size,
@@ -1153,7 +1193,7 @@ extern "C" int mr_pair_consist_forward_tiles(const float* flow12, const float* f
     hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit12),
                        reinterpret_cast<const uint32_t*>(tile_hit21), batch_size, p.tiles_x * p.tiles_y, sums, loss_fwd, loss_bwd,
-                       (const unsigned*)nullptr, (unsigned*)nullptr, (float*)nullptr);
+                       (const unsigned*)nullptr, (unsigned*)nullptr, (float*)nullptr, ScatterWork{nullptr, nullptr});
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1199,7 +1239,7 @@ static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_fl
                                    int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
                                    const void* list_header, const void* list_entries, int64_t list_capacity,
                                    int64_t tile_bound, float* unit_grad, float* unit_grad_max, float* loss_sum,
-                                   mr_stream_t stream) {
+                                   void* scatter_work, mr_stream_t stream) {
     if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2 || !flow_out12 || !flow_out21)
         return MR_ERR_BADARG;
     if (batch_size < 0 || image_size <= 0 || flow_bstride < 2LL * image_size * image_size) return MR_ERR_BADARG;
@@ -1230,7 +1270,8 @@ static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_fl
                        (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit1),
                        reinterpret_cast<const uint32_t*>(tile_hit2), batch_size, tiles_x * tiles_y, sums, loss_fwd, loss_bwd,
                        unit_grad ? (const unsigned*)q.tile_max : (const unsigned*)nullptr,
-                       unit_grad ? reinterpret_cast<unsigned*>(unit_grad_max) : (unsigned*)nullptr, loss_sum);
+                       unit_grad ? reinterpret_cast<unsigned*>(unit_grad_max) : (unsigned*)nullptr, loss_sum,
+                       scatter_work_at(unit_grad ? scatter_work : nullptr, 2 * batch_size));
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1249,7 +1290,7 @@ extern "C" int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* 
                                    flow_out12, flow_out21, tile_hit1, tile_hit2, image_ref, image, jitter_ref, jitter,
                                    jitter_channels, workspace, workspace_bytes, sums, loss_fwd, loss_bwd, batch_size, image_size,
                                    height, width, distance_thresh, warp_thresh, pair_thresh, list_header, list_entries,
-                                   list_capacity, tile_bound, nullptr, nullptr, nullptr, stream);
+                                   list_capacity, tile_bound, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int mr_flow_pair_forward_grad_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
@@ -1263,11 +1304,11 @@ extern "C" int mr_flow_pair_forward_grad_tiles(const float* mask_flow1, const fl
                                                float warp_thresh, float pair_thresh, const void* list_header,
                                                const void* list_entries, int64_t list_capacity, int64_t tile_bound,
                                                float* unit_grad, float* unit_grad_max, float* loss_sum,
-                                               mr_stream_t stream) {
+                                               void* scatter_work, mr_stream_t stream) {
     if (!unit_grad || !unit_grad_max) return MR_ERR_BADARG;
     return flow_pair_forward_tiles(mask_flow1, mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2,
                                    flow_out12, flow_out21, tile_hit1, tile_hit2, image_ref, image, jitter_ref, jitter,
                                    jitter_channels, workspace, workspace_bytes, sums, loss_fwd, loss_bwd, batch_size, image_size,
                                    height, width, distance_thresh, warp_thresh, pair_thresh, list_header, list_entries,
-                                   list_capacity, tile_bound, unit_grad, unit_grad_max, loss_sum, stream);
+                                   list_capacity, tile_bound, unit_grad, unit_grad_max, loss_sum, scatter_work, stream);
 }

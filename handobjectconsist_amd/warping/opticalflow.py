@@ -530,6 +530,9 @@ USE_FUSED_PAIR_NODE = True
 # (that gradient) x (grad_loss / count) (mr_flow_pair_backward_unit_tiles): no image, mask or flow is read twice.
 # False: mr_flow_pair_forward_tiles + mr_flow_pair_backward_tiles (the backward recomputes the taps).
 USE_UNIT_GRADIENT = True
+# ... and with the backward's workgroups handed out over the covered-tile lists the forward's finalize launch compacts (ABI 7):
+# workgroups per image in proportion to its covered tiles.  False: a fixed number per image, each listing the image's tiles.
+USE_SCATTER_WORK = True
 # ... and with the render's per-face pass folded into its binning pass (the pair prologue clears the tile list's header, which
 # the per-face pass's first thread does otherwise): one launch and one dependent round trip less per pair.
 USE_FUSED_RECORDS = True
@@ -573,7 +576,11 @@ class _FlowPairLossFunction(torch.autograd.Function):
                 int(r["bound"]))
         if unit:
             unit_grad, unit_max, loss_sum = new_f(B2, height, width, 2), torch.empty((B2,), **f32), torch.empty((B,), **f32)
-            _lib.call("mr_flow_pair_forward_grad_tiles", *args, _lib.ptr(unit_grad), _lib.ptr(unit_max), _lib.ptr(loss_sum), st)
+            # the images' covered-tile lists: the finalize launch writes them, the backward hands out its workgroups over them
+            scatter_work = (torch.empty((int(_lib.load().mr_flow_pair_scatter_work_bytes(B, is_)),), dtype=torch.uint8, device=dev)
+                            if USE_SCATTER_WORK else None)
+            _lib.call("mr_flow_pair_forward_grad_tiles", *args, _lib.ptr(unit_grad), _lib.ptr(unit_max), _lib.ptr(loss_sum),
+                      _lib.ptr(scatter_work), st)
         else:
             _lib.call("mr_flow_pair_forward_tiles", *args, st)
             loss_sum = loss_bwd + loss_fwd
@@ -582,7 +589,7 @@ class _FlowPairLossFunction(torch.autograd.Function):
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width, float(thresh), int(r["F0"]), int(r["V"]))
         ctx.unit = unit
         if unit:
-            ctx.save_for_backward(r["fim"], tile_hit, r["wmap"], r["vid"], unit_grad, unit_max, sums)
+            ctx.save_for_backward(r["fim"], tile_hit, r["wmap"], r["vid"], unit_grad, unit_max, sums, scatter_work)
         else:
             ctx.save_for_backward(r["fim"], tile_hit, r["wmap"], r["vid"], mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums)
         ctx.grad_buf = r["grad_buf"]
@@ -608,11 +615,11 @@ class _FlowPairLossFunction(torch.autograd.Function):
         if not zeroed:
             grad_cols = torch.empty((B2, V, 3), dtype=torch.float32, device=dev)
         if ctx.unit:
-            fim, tile_hit, wmap, vid, unit_grad, unit_max, sums = ctx.saved_tensors
+            fim, tile_hit, wmap, vid, unit_grad, unit_max, sums, scatter_work = ctx.saved_tensors
             _lib.call("mr_flow_pair_backward_unit_tiles", _lib.ptr(fim), _lib.ptr(tile_hit), _lib.ptr(wmap), _lib.ptr(vid),
                       _lib.ptr(unit_grad), _lib.ptr(unit_max), _lib.ptr(sums), _lib.ptr(g_fwd), _lib.ptr(g_bwd), height, width,
                       _lib.ptr(grad_cols), B2, V, F0, int(fill_back), is_, eps, _lib.FLAG_OUTPUT_ZEROED if zeroed else 0,
-                      textutils.texel_layout_code(), _lib.stream_ptr(dev))
+                      textutils.texel_layout_code(), _lib.ptr(scatter_work), _lib.stream_ptr(dev))
             return (None, None, grad_cols) + (None,) * 15
         fim, tile_hit, wmap, vid, mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums = ctx.saved_tensors
         # scratch of the launch: the masked flow gradient of a workgroup's tiles between its two passes

@@ -78,8 +78,10 @@ typedef void* mr_stream_t;
  * 5: mr_flow_pair_forward_grad_tiles / mr_flow_pair_backward_unit_tiles (the pair loss's gradient formed by the forward
  *    launch); mr_pair_consist_tiles_workspace_bytes grows to three words per tile;
  * 6: mr_render_clear_bytes; MR_FLAG_TILE_LIST_CLEARED covers that many bytes (list header + the arrival counters of the
- *    binning pass's workgroups, several per image since round 5); mr_flow_pair_prologue_parts takes clear_bytes. */
-#define MR_ABI_VERSION 6
+ *    binning pass's workgroups, several per image since round 5); mr_flow_pair_prologue_parts takes clear_bytes;
+ * 7: scatter_work of mr_flow_pair_forward_grad_tiles / mr_flow_pair_backward_unit_tiles (the covered-tile lists the
+ *    backward's workgroups are handed out over), mr_flow_pair_scatter_work_bytes. */
+#define MR_ABI_VERSION 7
 MR_API int mr_abi_version(void);
 /* 1 if the calling thread's CURRENT HIP device is a gfx950, else 0.
  * Device contract of every entry point below: kernels are launched on the calling thread's current HIP
@@ -607,7 +609,15 @@ MR_API int mr_flow_pair_backward_tiles(const int32_t* face_index_map, const uint
  *   three sampling weights (per-pixel records of mr_render_flow_forward); no image, mask or flow is read again.  The
  *   fixed-point scale of the per-workgroup sums is unit_grad_max[b] x |coefficient| (an upper bound, rounding is monotone).
  *   A zero coefficient leaves the image's rows zero whatever unit_grad holds.  flags: MR_FLAG_OUTPUT_ZEROED.
- * Results equal mr_flow_pair_backward_tiles' up to fp32 rounding (the coefficient multiplies last instead of first). */
+ * Results equal mr_flow_pair_backward_tiles' up to fp32 rounding (the coefficient multiplies last instead of first).
+ * scatter_work (ABI 7, nullable in both calls; mr_flow_pair_scatter_work_bytes(B, image_size) bytes, contents need no
+ *   initialisation): the forward call's finalize launch leaves, per stack image, the number and the ids of its covered tiles
+ *   there -- it reads every coverage word anyway; the backward call, given the SAME buffer, hands out its workgroups over the
+ *   images in proportion to their covered tiles instead of a fixed number per image (no listing pass; a third of the images of
+ *   a hand + object pair otherwise need a second round of their waves while the others' idle).  Null in the backward call:
+ *   the listing form (a fixed number of workgroups per image, each compacting the image's coverage words itself).  Same
+ *   sums either way up to the order of the final fp32 atomics. */
+MR_API int64_t mr_flow_pair_scatter_work_bytes(int batch_size, int image_size);
 MR_API int mr_flow_pair_forward_grad_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,
                                            const float* flow21, int64_t flow_bstride, const float* flow12_scale,
                                            const float* flow21_scale, float* occl1, float* occl2, float* flow_out12,
@@ -618,13 +628,13 @@ MR_API int mr_flow_pair_forward_grad_tiles(const float* mask_flow1, const float*
                                            int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
                                            const void* list_header, const void* list_entries, int64_t list_capacity,
                                            int64_t tile_bound, float* unit_grad, float* unit_grad_max, float* loss_sum,
-                                           mr_stream_t stream);
+                                           void* scatter_work, mr_stream_t stream);
 MR_API int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, const uint32_t* tile_hit, const float* weight_map,
                                             const int32_t* vertex_id_map, const float* unit_grad, const float* unit_grad_max,
                                             const float* sums, const float* grad_loss_fwd, const float* grad_loss_bwd,
                                             int height, int width, float* grad_vcolors, int batch_size, int num_verts,
                                             int num_faces, int fill_back, int image_size, float eps, int flags,
-                                            int texel_layout, mr_stream_t stream);
+                                            int texel_layout, const void* scatter_work, mr_stream_t stream);
 
 /* ---- dataset pipeline: decoded frames -> network-input batch ------------------------------
  * One launch for a whole batch of what meshreg/datasets/handobjset.py:361-379 does per sample on the

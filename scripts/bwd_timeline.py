@@ -23,6 +23,13 @@ names = ["covered-tile list", "zero table + maximum pass", "main pass", "flush"]
 w = t[worked]
 print("per working workgroup (us):", {n: round(float((w[:, k + 1] - w[:, k]).mean()) * 0.01, 2) for k, n in enumerate(names)},
       "total %.2f" % (float((w[:, 4] - w[:, 0]).mean()) * 0.01))
+for k, n in enumerate(names):
+    d = (w[:, k + 1] - w[:, k]) * 0.01
+    print("  %-28s p10 %.2f  p50 %.2f  p90 %.2f  p99 %.2f  max %.2f" % (n, *np.percentile(d, [10, 50, 90, 99]), d.max()))
+e = (w[:, 4] - t0) * 0.01
+print("  end of a working workgroup   p10 %.2f  p50 %.2f  p90 %.2f  p99 %.2f  max %.2f" % (*np.percentile(e, [10, 50, 90, 99]), e.max()))
+st = (w[:, 0] - t0) * 0.01
+print("  start of a working workgroup p10 %.2f  p50 %.2f  p90 %.2f  p99 %.2f  max %.2f" % (*np.percentile(st, [10, 50, 90, 99]), st.max()))
 idle = t[~worked]
 if len(idle):
     print("idle workgroups: list %.2f us" % (float((idle[:, 1] - idle[:, 0]).mean()) * 0.01))

@@ -794,6 +794,67 @@ def test_fused_pair_node_equals_the_composed_path(cuda, monkeypatch, B, is_, H, 
             close(a.cpu().numpy(), b_.cpu().numpy(), 1e-5, 1e-6 * float(b_.abs().max()), what)
 
 
+@pytest.mark.parametrize("B,is_,shape", [(4, 256, "unbalanced"), (1, 64, "unbalanced"), (6, 256, "plain"), (3, 480, "unbalanced"),
+                                         (2, 640, "plain")])
+def test_scatter_work_lists_equal_the_listing_form(cuda, monkeypatch, B, is_, shape):
+    """mr_flow_pair_backward_unit_tiles over the covered-tile lists of the forward's finalize launch (ABI 7: workgroups handed out
+    in proportion to the images' covered tiles) against its listing form (a fixed number of workgroups per image, each
+    compacting the coverage words itself): the same vertex gradients up to the order of the final fp32 atomics.  "unbalanced":
+    one pair zoomed until the meshes fill the screen (hundreds of covered tiles, several rounds per wave), one pushed off
+    screen (no covered tile at all, in either frame).  The list buffer comes back full of 0xff bytes: nothing of it may be
+    assumed initialised."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.warping import opticalflow
+
+    s = synth.random_scene(B, seed=77, image_size=is_)
+    if shape == "unbalanced":
+        for k in ("K1", "K2"):
+            s[k][0, 0, 0] *= 5.0
+            s[k][0, 1, 1] *= 5.0
+        if B > 1:
+            for k in ("verts1", "verts2"):
+                s[k][B - 1, :, 0] += 50.0
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
+                   no_light=True, light_intensity_ambient=0.8)
+    im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, is_, is_, 4)]
+    wf, wb = torch.linspace(0.5, 1.5, B, device=cuda), torch.linspace(2.0, 0.25, B, device=cuda)
+    real_empty = torch.empty
+
+    def dirty_empty(*a, **k):  # uint8 scratch buffers come back full of 0xff
+        out = real_empty(*a, **k)
+        if out.dtype == torch.uint8 and out.numel() > 64:
+            out.fill_(255)
+        return out
+
+    monkeypatch.setattr(torch, "empty", dirty_empty)
+    calls = []
+    real_call = opticalflow._lib.call
+    monkeypatch.setattr(opticalflow._lib, "call", lambda name, *a: (calls.append((name, a)), real_call(name, *a))[1])
+
+    def run(work):
+        monkeypatch.setattr(opticalflow, "USE_SCATTER_WORK", work)
+        v1, v2 = t(s["verts1"], cuda).requires_grad_(True), t(s["verts2"], cuda).requires_grad_(True)
+        res = opticalflow.flow_pair_loss([v1, v2], t(s["faces"], cuda), [t(s["K1"], cuda), t(s["K2"], cuda)], ren, (is_, is_),
+                                         im_ref, im, jm_ref, jm, ignore_face_idxs=synth.HAND_IGNORE_FACES)
+        assert res is not None
+        lf, lb, _ = res
+        del calls[:]
+        ((lf * wf).sum() + (lb * wb).sum()).backward()
+        bwd = [a for n_, a in calls if n_ == "mr_flow_pair_backward_unit_tiles"]
+        assert len(bwd) == 1 and (bwd[0][-2] is not None) == work, "the scatter_work argument of the backward call"
+        return lf.detach(), lb.detach(), v1.grad, v2.grad
+
+    ref = run(False)
+    got = run(True)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    for a, b_ in ((got[2], ref[2]), (got[3], ref[3])):
+        assert torch.isfinite(a).all() and float(b_.abs().sum()) > 0
+        close(a.cpu().numpy(), b_.cpu().numpy(), 1e-5, 2e-6 * float(b_.abs().max()), "vertex gradient")
+        if shape == "unbalanced" and B > 1:
+            assert float(a[B - 1].abs().sum()) == 0.0, "an off-screen mesh has no gradient"
+
+
 @pytest.mark.parametrize("B,is_", [(2, 96), (3, 256), (1, 480)])
 def test_per_face_pass_inside_the_binning_pass(cuda, monkeypatch, B, is_):
     """flow_pair_loss on (hand, object) parts: the pair prologue clears the header of the render's tile list and the render
