@@ -25,6 +25,8 @@
 #include "mr_common.hpp"
 #include "warp_device.hpp"
 #include <algorithm>
+#include <functional>
+#include <mutex>
 #include <type_traits>
 
 namespace mr {
@@ -110,7 +112,10 @@ __device__ __forceinline__ void gather_pixel(const GatherParams& p, const Face& 
 // the partial sums are combined with shuffles inside the lane group (fixed order: deterministic).  Faces whose bbox
 // exceeds GATHER_BIG pixels are walked by the whole wave instead.
 constexpr int GLPF = 4;
-constexpr int GGL = 8;   // lanes per face of the generic gather (E: 74 -> 64 us, E + F: 105 -> 93 us against 4; 16: 70 / 101)
+#ifndef MR_GGL
+#define MR_GGL 8
+#endif
+constexpr int GGL = MR_GGL;   // lanes per face of the generic gather (E: 74 -> 64 us, E + F: 105 -> 93 us against 4; 16: 70 / 101)
 constexpr int GATHER_BIG = 128;          // vertex-colour gather: bbox area above which the whole wave probes
 constexpr int GATHER_BIG_GENERIC = 256;  // generic gather (direct accumulation on the wave-cooperative path)
 
@@ -122,26 +127,43 @@ __device__ __forceinline__ void gather_store(const GatherParams& p, int64_t i, c
         for (int k = 0; k < 6; k++) o[k] = make_float4(gt[4 * k], gt[4 * k + 1], gt[4 * k + 2], gt[4 * k + 3]);
     }
     if (p.grad_faces) {
+        if (p.accumulate_faces) {
+            // (kernel D's sums are in the row already: ADD to them with fire-and-forget atomics -- a load + add + store would
+            // put one more dependent round trip at the end of every wave; one writer per element here, the order of the two
+            // kernels' contributions is the stream's)
+            if (DEPTH)
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const float v = DEPTH ? gf[k] : 0.0f;
-            p.grad_faces[i * 9 + k] = p.accumulate_faces ? p.grad_faces[i * 9 + k] + v : v;
+                for (int k = 0; k < 9; k++)
+                    if (gf[k] != 0.0f) unsafeAtomicAdd(&p.grad_faces[i * 9 + k], gf[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; k++) p.grad_faces[i * 9 + k] = DEPTH ? gf[k] : 0.0f;
         }
     }
 }
 
+#ifdef MR_GATHER_WPE
+#define MR_GATHER_ATTR __attribute__((amdgpu_waves_per_eu(MR_GATHER_WPE, MR_GATHER_WPE)))
+#else
+#define MR_GATHER_ATTR
+#endif
 template <bool IMG, bool TEX, bool DEPTH>
-__global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
+__global__ void __launch_bounds__(256) MR_GATHER_ATTR gather_kernel(GatherParams p) {
     constexpr int NT = TEX ? 24 : 1, NF = DEPTH ? 9 : 1;
-    const int64_t total = p.owners ? (int64_t)*p.n_owners : (int64_t)p.B * p.F;
     // (owner list: the entries in use are the first ones -- plain block order, so that they spread over the XCDs)
     const int64_t gid = (int64_t)(p.owners ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
-    if ((gid - threadIdx.x) / GGL >= total) return;  // block-uniform: nothing left in the list
     const int64_t slot = gid / GGL;
     const int sub = (int)(gid % GGL);
     const int lane = threadIdx.x & 63;
+    // (the list entry is requested TOGETHER with the list's length, not behind the test on it: the list has room for every
+    // face, the entry is inside the allocation whatever the length turns out to be -- one dependent round trip less)
+    uint32_t own = 0u;
+    if (p.owners) own = p.owners[slot];
+    const int64_t total = p.owners ? (int64_t)*p.n_owners : (int64_t)p.B * p.F;
+    asm volatile("" : "+v"(own));  // (keeps the load in front of the branch)
+    if ((gid - threadIdx.x) / GGL >= total) return;  // block-uniform: nothing left in the list
     const bool valid = slot < total;
-    const int64_t i = p.owners ? (valid ? (int64_t)p.owners[slot] : 0) : slot;
+    const int64_t i = p.owners ? (valid ? (int64_t)own : 0) : slot;
     const int b = valid ? (int)(i / p.F) : 0;
     const int fn = valid ? (int)(i % p.F) : 0;
     const int is = p.is;
@@ -162,7 +184,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
 
     // very large faces first: the whole wave walks the bbox, lane per pixel, butterfly-reduce,
     // the owner lane stores the result straight away
-    unsigned long long m_big = __ballot(big && sub == 0);
+    unsigned long long m_big = (p.dbg_rows & 2) ? 0ull : __ballot(big && sub == 0);  // (profiling: 2 = big faces skipped)
     while (m_big) {
         const int src = __ffsll((long long)m_big) - 1;
         m_big &= m_big - 1;
@@ -1557,7 +1579,10 @@ __device__ __forceinline__ float wave_max_last(float v) {
 // coordinates, 0.5 * (v * is + is - 1) as kernel D computes them, and the face number -- with the counts in
 // img_count[b] and the range of lines their crossings can fall on in img_count[B + 4 b ..]: kernel D by strips walks
 // the owners of ONE image and reads nothing else of a face).
-constexpr int CO_TPB = 1024, CO_PER = 4;
+#ifndef MR_CO_PER
+#define MR_CO_PER 4
+#endif
+constexpr int CO_TPB = 1024, CO_PER = MR_CO_PER;
 __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p, const uint8_t* __restrict__ owns,
                                                                 unsigned* __restrict__ counter, uint32_t* __restrict__ list,
                                                                 unsigned* __restrict__ img_count, float4* __restrict__ img_recs,
@@ -2235,9 +2260,11 @@ static bool strips_apply(int B, int F, int is, const void* workspace, int64_t wo
 
 // kernel D: by strips when a workspace of pixel_map_workspace_bytes is available (leaves the owner list for the gather
 // behind), else the plane-reading per-face walk (same results up to the order of the fp32 additions)
+// `after_compact` (nullable): called once the owner lists stand (behind compact_owners_kernel on `s`) and before the strip
+// kernels are launched -- mr_render_backward forks its E / F gather onto a second stream there
 template <bool IMG>
 static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t workspace_bytes, int flags,
-                            hipStream_t s) {
+                            hipStream_t s, const std::function<int()>* after_compact = nullptr) {
     const int64_t nfaces = (int64_t)p.B * p.F;
     if (!strips_apply(p.B, p.F, p.is, workspace, workspace_bytes, flags))
         return launch1d(pixel_map_kernel<IMG>, nfaces * MR_WAVE, s, p);
@@ -2256,6 +2283,10 @@ static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t wo
     q.zero_owner_rows = 1;
     rc = launch_compact(q, ol0, true, s, sl.weights, strip_l, sl.strips_axis);
     if (rc != MR_OK) return rc;
+    if (after_compact) {
+        rc = (*after_compact)();
+        if (rc != MR_OK) return rc;
+    }
     const int strips_axis = sl.strips_axis;
     hipLaunchKernelGGL(strip_list_kernel, dim3(8), dim3(SL_T), 0, s, (const unsigned*)sl.weights, sl.lists, sl.counts, p.B,
                        2 * strips_axis, sl.cap);
@@ -2268,6 +2299,35 @@ static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t wo
                        (const float4*)ol0.img_recs, strips_axis, (const unsigned*)sl.lists, (const unsigned*)sl.counts, sl.cap);
     MR_CHECK_LAUNCH();
     return MR_OK;
+}
+
+// A second stream per device for launches that may run BESIDE the caller's stream (mr_render_backward: the E / F gather next to
+// kernel D), with the two events of the fork and the join.  Created at the first use on a device, never destroyed.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static SideStream* side_stream() {
+    static std::mutex mu;
+    static SideStream cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    SideStream& c = cache[dev];
+    if (!c.stream) {
+        int lo = 0, hi = 0;  // (numerically lower = higher priority; the side stream's short launches go first)
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        hipStream_t st = nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        c.stream = st; c.fork = a; c.join = b;
+    }
+    return &c;
 }
 
 }  // namespace mr
@@ -2370,12 +2430,57 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
     const bool use_list = want_d ? strips_d
                                  : (workspace && workspace_bytes >= owner_list_bytes(batch_size, num_faces) &&
                                     !(flags & MR_FLAG_REFERENCE_ALGO) && nfaces <= 0xffffffffLL);
+    // the E / F gather of the faces that own a pixel (or of all of them without a list)
+    auto launch_gather = [&](hipStream_t gs) -> int {
+        GatherParams g{};
+        g.faces = faces; g.fim = face_index_map;
+        g.grad_rgb = gather_tex ? grad_rgb_img : nullptr;
+        g.grad_depth = want_f ? grad_depth_img : nullptr;
+        g.grad_faces = grad_faces;
+        g.grad_textures = gather_tex ? grad_textures : nullptr;
+        g.B = batch_size; g.F = num_faces; g.is = image_size; g.eps = eps;
+        g.accumulate_faces = want_d ? 1 : 0;
+        g.dbg_rows = ((flags >> 8) & 32 ? 1 : 0) | ((flags >> 8) & 64 ? 2 : 0);
+        if (use_list) {
+            const OwnerList ol = owner_list(workspace, batch_size, num_faces);
+            g.owners = ol.list; g.n_owners = ol.counter;
+        }
+        const int64_t nthreads = nfaces * GGL;
+        if (gather_tex && want_f) return launch1d(gather_kernel<true, true, true>, nthreads, gs, g);
+        if (gather_tex) return launch1d(gather_kernel<true, true, false>, nthreads, gs, g);
+        if (want_f) return launch1d(gather_kernel<true, false, true>, nthreads, gs, g);
+        return launch1d(gather_kernel<true, false, false>, nthreads, gs, g);
+    };
+    bool gathered = false;
     if (want_d) {
         const int rr = return_rgb && grad_rgb_img && rgb_img, ra = return_alpha && grad_alpha_img && alpha_img;
         PixelMapParams p{faces, face_index_map, rgb_img, alpha_img, grad_rgb_img, grad_alpha_img,
                          grad_faces, batch_size, num_faces, image_size, eps, rr, ra, 1, flags >> 8};
         p.zero_textures = (use_list && run_gather && gather_tex) ? grad_textures : nullptr;
-        rc = launch_pixel_map<true>(p, workspace, workspace_bytes, flags, s);
+        // Round 5: kernel D's walk and the E / F gather are independent once the owner lists stand -- D adds to grad_faces' x / y
+        // with atomics, the gather adds its depth terms to the same rows with atomics (commutative) and writes grad_textures,
+        // which D never touches.  The gather is a latency chain of short workgroups (owner -> face -> probes -> gradients, ~100
+        // us one behind the other), the walk 200+ us of vector arithmetic at three waves per SIMD: the gather goes to a second,
+        // higher-priority stream behind the compaction pass and runs in the slots the walk's workgroups leave as they retire
+        // (profiling switch flags >> 8 & 128: one stream, one behind the other, as before).
+        SideStream* side = (use_list && strips_d && run_gather && !((flags >> 8) & 128)) ? side_stream() : nullptr;
+        bool forked = false;
+        std::function<int()> fork = [&]() -> int {
+            if (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return MR_OK;  // (no fork: the gather follows on the caller's stream below)
+            }
+            forked = true;
+            const int grc = launch_gather(side->stream);
+            // (the join is recorded whatever the launch returned: the side stream must not stay forked off a capture)
+            if (hipEventRecord(side->join, side->stream) != hipSuccess) { (void)hipGetLastError(); return MR_ERR_BADARG; }
+            return grc;
+        };
+        rc = launch_pixel_map<true>(p, workspace, workspace_bytes, flags, s, side ? &fork : nullptr);
+        if (forked) {
+            if (hipStreamWaitEvent(s, side->join, 0) != hipSuccess) { (void)hipGetLastError(); return MR_ERR_BADARG; }
+            gathered = true;
+        }
         if (rc != MR_OK) return rc;
     } else if (use_list && run_gather) {
         const OwnerList ol = owner_list(workspace, batch_size, num_faces);
@@ -2400,26 +2505,7 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
                       grad_textures, npx, num_faces, image_size, texture_size, eps);
         if (rc != MR_OK) return rc;
     }
-    if (run_gather) {
-        GatherParams g{};
-        g.faces = faces; g.fim = face_index_map;
-        g.grad_rgb = gather_tex ? grad_rgb_img : nullptr;
-        g.grad_depth = want_f ? grad_depth_img : nullptr;
-        g.grad_faces = grad_faces;
-        g.grad_textures = gather_tex ? grad_textures : nullptr;
-        g.B = batch_size; g.F = num_faces; g.is = image_size; g.eps = eps;
-        g.accumulate_faces = want_d ? 1 : 0;
-        g.dbg_rows = (flags >> 8) & 32 ? 1 : 0;
-        if (use_list) {
-            const OwnerList ol = owner_list(workspace, batch_size, num_faces);
-            g.owners = ol.list; g.n_owners = ol.counter;
-        }
-        const int64_t nthreads = nfaces * GGL;
-        if (gather_tex && want_f) rc = launch1d(gather_kernel<true, true, true>, nthreads, s, g);
-        else if (gather_tex) rc = launch1d(gather_kernel<true, true, false>, nthreads, s, g);
-        else if (want_f) rc = launch1d(gather_kernel<true, false, true>, nthreads, s, g);
-        else rc = launch1d(gather_kernel<true, false, false>, nthreads, s, g);
-    }
+    if (run_gather && !gathered) rc = launch_gather(s);
     return rc;
 }
 
