@@ -137,6 +137,9 @@ WARP_TILES_KERNELS = ("occlusion_flow_tiles_kernel", "pair_consist_forward_tiles
 
 
 ROOF_OPTIONAL = ()
+# vector wave-instructions of one D + E + F launch (pixel_map_strip_kernel 90.97 M + gather_kernel<true, true, true> 14.55 M), per
+# (B, image size) of the kernel bench's scene: rocprofv3 --pmc SQ_INSTS_VALU, profiles/r05_kernel_d_pmc.txt
+DEF_VALU_WAVE_INSTS = {(64, 256): (90.97e6 + 14.55e6, "profiles/r05_kernel_d_pmc.txt")}
 # the warp half over the render's tile list (round 4) and what one pixel of a covered tile makes each pass move
 WARP_TILES = ("occlusion_flow_tiles(train: occlusion + flow epilogue, sparse)", "pair_consist_forward_tiles(train, sparse)",
               "pair_consist_backward_tiles(train, sparse)", FUSED_FWD_PLAIN, FUSED_FWD)
@@ -475,6 +478,16 @@ def kernel_bench(dev, B, is_, iters, only=None):
                      "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                      "frac_hbm_peak_cache_warm": round(nbytes / (ms_warm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del flush
+    full = "render_backward_full(D+E+F)"
+    if full in out and (B, is_) in DEF_VALU_WAVE_INSTS:
+        # D + E + F is bound by vector-instruction issue, not by HBM: the bound next to the HBM fraction.
+        # Wave-instruction counts per launch from the PMC pass committed under profiles/ (SQ_INSTS_VALU of the strip kernel +
+        # of the gather), 1024 SIMDs issuing one wave-instruction per 4 cycles at 2.4 GHz.
+        insts, src = DEF_VALU_WAVE_INSTS[(B, is_)]
+        bound_ms = insts * 4 / (1024 * 2.4e9) * 1e3
+        out[full].update({"valu_wave_insts": int(insts), "valu_wave_insts_source": src, "valu_bound_ms": round(bound_ms, 4),
+                          "frac_of_valu_bound": round(bound_ms / out[full]["ms"], 4),
+                          "frac_of_valu_bound_cache_warm": round(bound_ms / out[full]["ms_cache_warm"], 4)})
     covered_words = int((ptile_hit.view(torch.int32) != 0).sum())
     for name, per_px, what in zip(WARP_TILES, WARP_TILES_BYTES, WARP_TILES_WHAT):
         if name in out:

@@ -1574,13 +1574,15 @@ __device__ __forceinline__ float wave_max_last(float v) {
 }
 
 // The faces that own a pixel (typically a fifth of them), compacted into a list for the gather / the walk kernel; the
-// others get their zero rows here.  One workgroup per image and 4096 faces of it, ONE global atomic each (two with
+// others get their zero rows here.  One workgroup per image and CO_TPB * CO_PER faces of it, ONE global atomic each (two with
 // `img_recs`: the front-facing ones once more image by image, [B][F] records of two float4 -- the vertices in pixel
 // coordinates, 0.5 * (v * is + is - 1) as kernel D computes them, and the face number -- with the counts in
 // img_count[b] and the range of lines their crossings can fall on in img_count[B + 4 b ..]: kernel D by strips walks
 // the owners of ONE image and reads nothing else of a face).
+// faces per thread: 1 -- seven workgroups per image of the bench meshes instead of two; most of this kernel's time is the zero
+// rows it writes (60 MB per launch at the metric config), which 128 workgroups do not stream at the chip's rate: 17.8 -> 13.8 us
 #ifndef MR_CO_PER
-#define MR_CO_PER 4
+#define MR_CO_PER 1
 #endif
 constexpr int CO_TPB = 1024, CO_PER = MR_CO_PER;
 __global__ void __launch_bounds__(CO_TPB) compact_owners_kernel(PixelMapParams p, const uint8_t* __restrict__ owns,
