@@ -133,11 +133,17 @@ class GraphedTrainStep:
     guess), the second captures and replays, later ones replay.
 
     Requirements: a CUDA optimiser built with ``capturable=True`` (stock fused Adam), no ``reducer`` (data-parallel runs
-    stay eager: a collective inside a capture has not run on hardware here), ``check_nan`` handled on the device."""
+    stay eager: a collective inside a capture has not run on hardware here), ``check_nan`` handled on the device, and an
+    fp32 trunk: with the encoder under bf16 autocast replayed runs flagged NaN head losses that eager runs never showed
+    (round 5, 640 x 480, not root-caused) -- ``allow_autocast=True`` overrides the refusal."""
 
-    def __init__(self, premodel, optimizer, check_nan=True, max_graphs=8):
+    def __init__(self, premodel, optimizer, check_nan=True, max_graphs=8, allow_autocast=False):
         if not _device_guarded(optimizer) or not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainStep needs a fused optimiser built with capturable=True")
+        enc_dtype = getattr(getattr(premodel, "model", None), "encoder_dtype", None)
+        if enc_dtype not in (None, torch.float32) and not allow_autocast:
+            raise ValueError("GraphedTrainStep is validated for an fp32 trunk only (see the class docstring); "
+                             "pass allow_autocast=True to capture an autocast step anyway")
         self.premodel, self.optimizer, self.check_nan, self.max_graphs = premodel, optimizer, check_nan, max_graphs
         self._entries = {}
         self.replays = 0

@@ -9,6 +9,8 @@ the occlusion block).
 """
 from typing import List
 
+import os
+
 import torch
 
 from handobjectconsist_amd import _lib
@@ -532,7 +534,7 @@ USE_FUSED_PAIR_NODE = True
 USE_UNIT_GRADIENT = True
 # ... and with the backward's workgroups handed out over the covered-tile lists the forward's finalize launch compacts (ABI 7):
 # workgroups per image in proportion to its covered tiles.  False: a fixed number per image, each listing the image's tiles.
-USE_SCATTER_WORK = True
+USE_SCATTER_WORK = os.environ.get("HOC_SCATTER_WORK", "1") != "0"
 # ... and with the render's per-face pass folded into its binning pass (the pair prologue clears the tile list's header, which
 # the per-face pass's first thread does otherwise): one launch and one dependent round trip less per pair.
 USE_FUSED_RECORDS = True
