@@ -70,8 +70,10 @@ def parse():
     p.add_argument("--step-only", action="store_true",
                    help="only the timed training steps (no hot-path / stock-trunk / kernel / CPU legs): what the in-run "
                         "rocprofv3 --kernel-trace pass behind roofline.frac_in_step profiles")
-    p.add_argument("--eager-step", action="store_true",
-                   help="issue every step's launches from the host (rounds 1-4) instead of replaying the captured step (hipGraph)")
+    p.add_argument("--eager-step", action="store_true", help="(the default since the end of round 5; kept for old command lines)")
+    p.add_argument("--graph-step", action="store_true",
+                   help="replay the captured train_step (one hipGraph launch per step) instead of issuing its launches from the "
+                        "host; switches MIOpen's solver search off for the run (see the note at graph_step in main)")
     p.add_argument("--reducer-ab", type=int, default=0, metavar="PAIRS",
                    help="A/B inside ONE process (one model, one set of MIOpen / TunableOp solver choices): PAIRS x "
                         "(--steps plain steps, then --steps steps through the RCCL process group + bucketed gradient "
@@ -828,15 +830,19 @@ def main():
     # trainmeshwarp.py's optimiser (Adam, lr 5e-5).  fused=True is stock PyTorch's single-pass kernel for the
     # same update (A/B on one MI355X: 46.05 -> 45.10 ms per step); HOC_FUSED_ADAM=0 selects the foreach default
     params = [p for p in model.parameters() if p.requires_grad]
-    # One step = ONE hipGraph launch (netscripts/epochpassconsist.GraphedTrainStep: train_step captured per device-resident
-    # batch set and replayed) on a single GPU; data-parallel runs issue their launches eagerly (no collective has run inside
-    # a capture on hardware here).  --eager-step / HOC_GRAPH_STEP=0: the eager loop of rounds 1-4.
+    # --graph-step: one step = ONE hipGraph launch (netscripts/epochpassconsist.GraphedTrainStep: train_step captured per
+    # device-resident batch set and replayed).  NOT the default, and never together with MIOpen's solver search: with
+    # torch.backends.cudnn.benchmark on, a replayed step now and then (1 in 8 in scripts/r5_graph_grad_debug2.py) comes back with
+    # garbage in the weight gradients of the trunk's convolutions -- 2e5 x the gradient's norm in conv1 / layer1, losses
+    # unchanged -- which eager steps and replays under MIOpen's default solver choice never showed; the NaN head losses of the
+    # bf16 configuration under replay were the same thing one step later.  Measured (profiles/r05_graph_vs_eager.txt): the metric
+    # config gains 0.4 % from the replay (device-bound), config 3 (B = 8) 6 %.  Data-parallel runs issue their launches eagerly
+    # (no collective has run inside a capture on hardware here).
     fused_adam = os.environ.get("HOC_FUSED_ADAM", "1") == "1"
-    # (the graph-replayed step is validated for the fp32 trunk only: with the trunk under bf16 autocast -- BASELINE config 5 --
-    # 5 of 9 replayed runs at 640 x 480 flagged a NaN in the DATA term's head losses within 30 steps while eager runs and the
-    # fp32 replay never did (gpurun_out of round 5; not root-caused, the hot path is not involved): that configuration steps eagerly)
-    graph_step = (not args.eager_step and os.environ.get("HOC_GRAPH_STEP", "1") == "1" and not use_dist and fused_adam
-                  and not args.hot_only and (args.encoder_dtype == "f32" or os.environ.get("HOC_GRAPH_STEP_BF16") == "1"))
+    graph_step = (args.graph_step and not args.eager_step and not use_dist and fused_adam and not args.hot_only
+                  and args.encoder_dtype == "f32")
+    if graph_step:
+        torch.backends.cudnn.benchmark = False
     optimizer = torch.optim.Adam(params, lr=5e-5, fused=fused_adam, capturable=graph_step)
     loader = SyntheticConsistLoader(B, is_, seed=rank, device=dev, pool=2, image_height=ih_)
 
@@ -1122,7 +1128,7 @@ def main():
                     "roofline.hot_path_device_ms of the step)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "graph_setup_steps": n_warm - args.warmup,
             "ms_per_step": round(ms, 3),
-            "step_mode": graph_fell_back or ("hipGraph replay of the captured train_step (one launch per step)" if graph_step else "eager launches"),
+            "step_mode": graph_fell_back or ("hipGraph replay of the captured train_step (one launch per step; MIOpen's solver search off)" if graph_step else "eager launches"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
             "data": "synthetic",

@@ -25,8 +25,6 @@
 #include "mr_common.hpp"
 #include "warp_device.hpp"
 #include <algorithm>
-#include <functional>
-#include <mutex>
 #include <type_traits>
 
 namespace mr {
@@ -147,11 +145,13 @@ __device__ __forceinline__ void gather_store(const GatherParams& p, int64_t i, c
 #else
 #define MR_GATHER_ATTR
 #endif
+// (`vbid` of `vgrid`: the workgroup's place in the gather's own grid -- blockIdx.x of gridDim.x when it is launched alone,
+// a virtual index when its workgroups are interleaved with kernel D's strips in one launch, strip_gather_kernel)
 template <bool IMG, bool TEX, bool DEPTH>
-__global__ void __launch_bounds__(256) MR_GATHER_ATTR gather_kernel(GatherParams p) {
+__device__ __forceinline__ void gather_body(const GatherParams& p, const unsigned vbid, const unsigned vgrid) {
     constexpr int NT = TEX ? 24 : 1, NF = DEPTH ? 9 : 1;
     // (owner list: the entries in use are the first ones -- plain block order, so that they spread over the XCDs)
-    const int64_t gid = (int64_t)(p.owners ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
+    const int64_t gid = (int64_t)(p.owners ? vbid : xcd_remap(vbid, vgrid)) * blockDim.x + threadIdx.x;
     const int64_t slot = gid / GGL;
     const int sub = (int)(gid % GGL);
     const int lane = threadIdx.x & 63;
@@ -282,6 +282,10 @@ __global__ void __launch_bounds__(256) MR_GATHER_ATTR gather_kernel(GatherParams
             for (int k = 0; k < NF; k++) gf[k] += __shfl_xor(gf[k], off);
     }
     if (valid && sub == 0 && !big) gather_store<TEX, DEPTH>(p, i, gt, gf);
+}
+template <bool IMG, bool TEX, bool DEPTH>
+__global__ void __launch_bounds__(256) MR_GATHER_ATTR gather_kernel(GatherParams p) {
+    gather_body<IMG, TEX, DEPTH>(p, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1802,10 +1806,10 @@ __global__ void __launch_bounds__(SL_T) strip_list_kernel(const unsigned* __rest
 }
 
 template <bool IMG, int L>
-__global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p, const unsigned* __restrict__ img_count,
-                                                               const float4* __restrict__ img_recs, int strips_axis,
-                                                               const unsigned* __restrict__ strip_lists,
-                                                               const unsigned* __restrict__ strip_counts, int list_cap) {
+__device__ __forceinline__ void strip_body(const PixelMapParams& p, const unsigned* __restrict__ img_count,
+                                           const float4* __restrict__ img_recs, int strips_axis,
+                                           const unsigned* __restrict__ strip_lists,
+                                           const unsigned* __restrict__ strip_counts, int list_cap, const unsigned vbid) {
     extern __shared__ float4 ps_lds[];
     __shared__ unsigned s_qn, s_next;
 #ifdef MR_WG_TIMELINE
@@ -1823,7 +1827,8 @@ __global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p,
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // blockIdx -> XCD blockIdx % 8: every strip of an image on the same XCD; entry blockIdx / 8 of that XCD's list of
     // working strips (heaviest first), `b * S + axis * strips_axis + strip`
-    const unsigned S = 2u * (unsigned)strips_axis, xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    // (vbid: blockIdx.x, or the strip's virtual index when the launch also carries the gather's workgroups -- same residue mod 8)
+    const unsigned S = 2u * (unsigned)strips_axis, xcd = vbid & 7u, j = vbid >> 3;
     if (j >= strip_counts[xcd]) return;
     const unsigned ent = strip_lists[(int64_t)xcd * list_cap + j];
     const int b = (int)(ent / S);
@@ -2172,6 +2177,45 @@ __global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p,
 #endif
 }
 
+template <bool IMG, int L>
+__global__ void __launch_bounds__(PS_T) pixel_map_strip_kernel(PixelMapParams p, const unsigned* __restrict__ img_count,
+                                                               const float4* __restrict__ img_recs, int strips_axis,
+                                                               const unsigned* __restrict__ strip_lists,
+                                                               const unsigned* __restrict__ strip_counts, int list_cap) {
+    strip_body<IMG, L>(p, img_count, img_recs, strips_axis, strip_lists, strip_counts, list_cap, blockIdx.x);
+}
+
+// Kernel D's strips and the E / F gather in ONE launch (round 5).  The two are independent once the owner lists stand -- D adds
+// to grad_faces' x / y with atomics, the gather adds its depth terms to the same rows with atomics and writes grad_textures,
+// which D never touches -- and they complement each other: the walk is 200+ us of vector arithmetic at three waves per SIMD,
+// the gather a latency chain of short workgroups (owner -> face -> probes -> gradients) that waits on memory half of its
+// time.  Groups of eight workgroups (one per XCD: the strips' XCD residue is kept) alternate between the two grids while both
+// last; a gather workgroup reserves the strips' LDS and registers, which costs it nothing (144 registers: three workgroups
+// per compute unit either way).  A first version ran the gather on a second, higher-priority stream (fork / join events):
+// 0.375 -> 0.334 ms in a process with two queues, but 0.47 ms inside bench.py's full run -- with the five or more queues that
+// process has, every cross-queue dependency waited for a ~50 us scheduling quantum (profiles/r05_def_two_streams_trace.txt).
+template <bool IMG, int L, bool TEX, bool DEPTH>
+__global__ void __launch_bounds__(PS_T) strip_gather_kernel(PixelMapParams p, const unsigned* __restrict__ img_count,
+                                                            const float4* __restrict__ img_recs, int strips_axis,
+                                                            const unsigned* __restrict__ strip_lists,
+                                                            const unsigned* __restrict__ strip_counts, int list_cap,
+                                                            GatherParams g, unsigned gather_groups, unsigned strip_groups) {
+    const unsigned grp = blockIdx.x >> 3, r = blockIdx.x & 7u;
+    bool gather;
+    unsigned vg;
+    if (p.dbg & 256) {         // (profiling: the two grids alternate group by group while both last)
+        const unsigned pairs = min(gather_groups, strip_groups);
+        if (grp < 2u * pairs) { gather = (grp & 1u) != 0u; vg = grp >> 1; }
+        else { gather = gather_groups > strip_groups; vg = pairs + (grp - 2u * pairs); }
+    } else if (p.dbg & 512) {  // (profiling: the strips first)
+        gather = grp >= strip_groups; vg = gather ? grp - strip_groups : grp;
+    } else {                   // the gather's workgroups first: short, and its few long ones (faces with large boxes) start early
+        gather = grp < gather_groups; vg = gather ? grp : grp - gather_groups;
+    }
+    if (gather) gather_body<IMG, TEX, DEPTH>(g, vg * 8u + r, gather_groups * 8u);
+    else strip_body<IMG, L>(p, img_count, img_recs, strips_axis, strip_lists, strip_counts, list_cap, vg * 8u + r);
+}
+
 
 template <typename K, typename... A>
 static int launch1d(K kernel, int64_t n, hipStream_t s, A... args) {
@@ -2262,11 +2306,16 @@ static bool strips_apply(int B, int F, int is, const void* workspace, int64_t wo
 
 // kernel D: by strips when a workspace of pixel_map_workspace_bytes is available (leaves the owner list for the gather
 // behind), else the plane-reading per-face walk (same results up to the order of the fp32 additions)
-// `after_compact` (nullable): called once the owner lists stand (behind compact_owners_kernel on `s`) and before the strip
-// kernels are launched -- mr_render_backward forks its E / F gather onto a second stream there
+// `fused` (nullable): the E / F gather of the same call, to go out INSIDE the strip kernel's launch (strip_gather_kernel);
+// *fused_done says whether it did (not when the walk takes the plane-reading kernel)
+struct FusedGather {
+    GatherParams g;
+    bool tex, depth;
+    int64_t threads;
+};
 template <bool IMG>
 static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t workspace_bytes, int flags,
-                            hipStream_t s, const std::function<int()>* after_compact = nullptr) {
+                            hipStream_t s, const FusedGather* fused = nullptr, bool* fused_done = nullptr) {
     const int64_t nfaces = (int64_t)p.B * p.F;
     if (!strips_apply(p.B, p.F, p.is, workspace, workspace_bytes, flags))
         return launch1d(pixel_map_kernel<IMG>, nfaces * MR_WAVE, s, p);
@@ -2285,10 +2334,6 @@ static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t wo
     q.zero_owner_rows = 1;
     rc = launch_compact(q, ol0, true, s, sl.weights, strip_l, sl.strips_axis);
     if (rc != MR_OK) return rc;
-    if (after_compact) {
-        rc = (*after_compact)();
-        if (rc != MR_OK) return rc;
-    }
     const int strips_axis = sl.strips_axis;
     hipLaunchKernelGGL(strip_list_kernel, dim3(8), dim3(SL_T), 0, s, (const unsigned*)sl.weights, sl.lists, sl.counts, p.B,
                        2 * strips_axis, sl.cap);
@@ -2296,40 +2341,37 @@ static int launch_pixel_map(const PixelMapParams& p, void* workspace, int64_t wo
     const int64_t grid = 8LL * sl.cap;
     if (grid > 0x7fffffffLL) return MR_ERR_BADARG;
     const size_t lds = (size_t)strip_lds_bytes(p.is, strip_l);
+    if (fused && (fused->tex || fused->depth)) {
+        const int64_t gblocks = (fused->threads + PS_T - 1) / PS_T;
+        const int64_t ggroups = (gblocks + 7) / 8, total = (ggroups + sl.cap) * 8;
+        if (total <= 0x7fffffffLL && ggroups <= 0x0fffffffLL) {
+            const GatherParams g = fused->g;
+#define MR_SG_LAUNCH(L_, T_, D_)                                                                                          \
+            hipLaunchKernelGGL((strip_gather_kernel<IMG, L_, T_, D_>), dim3((unsigned)total), dim3(PS_T), lds, s, p,      \
+                               (const unsigned*)ol0.img_count, (const float4*)ol0.img_recs, strips_axis,                  \
+                               (const unsigned*)sl.lists, (const unsigned*)sl.counts, sl.cap, g, (unsigned)ggroups,       \
+                               (unsigned)sl.cap)
+#define MR_SG_PICK(L_)                                                                                                    \
+            do {                                                                                                          \
+                if (fused->tex && fused->depth) MR_SG_LAUNCH(L_, true, true);                                             \
+                else if (fused->tex) MR_SG_LAUNCH(L_, true, false);                                                       \
+                else MR_SG_LAUNCH(L_, false, true);                                                                       \
+            } while (0)
+            if (strip_l == 4) MR_SG_PICK(4);
+            else if (strip_l == 2) MR_SG_PICK(2);
+            else MR_SG_PICK(1);
+#undef MR_SG_PICK
+#undef MR_SG_LAUNCH
+            MR_CHECK_LAUNCH();
+            if (fused_done) *fused_done = true;
+            return MR_OK;
+        }
+    }
     auto kernel = strip_l == 4 ? pixel_map_strip_kernel<IMG, 4> : (strip_l == 2 ? pixel_map_strip_kernel<IMG, 2> : pixel_map_strip_kernel<IMG, 1>);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PS_T), lds, s, p, (const unsigned*)ol0.img_count,
                        (const float4*)ol0.img_recs, strips_axis, (const unsigned*)sl.lists, (const unsigned*)sl.counts, sl.cap);
     MR_CHECK_LAUNCH();
     return MR_OK;
-}
-
-// A second stream per device for launches that may run BESIDE the caller's stream (mr_render_backward: the E / F gather next to
-// kernel D), with the two events of the fork and the join.  Created at the first use on a device, never destroyed.
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-static SideStream* side_stream() {
-    static std::mutex mu;
-    static SideStream cache[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    SideStream& c = cache[dev];
-    if (!c.stream) {
-        int lo = 0, hi = 0;  // (numerically lower = higher priority; the side stream's short launches go first)
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        hipStream_t st = nullptr;
-        hipEvent_t a = nullptr, b = nullptr;
-        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        c.stream = st; c.fork = a; c.join = b;
-    }
-    return &c;
 }
 
 }  // namespace mr
@@ -2433,25 +2475,25 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
                                  : (workspace && workspace_bytes >= owner_list_bytes(batch_size, num_faces) &&
                                     !(flags & MR_FLAG_REFERENCE_ALGO) && nfaces <= 0xffffffffLL);
     // the E / F gather of the faces that own a pixel (or of all of them without a list)
+    GatherParams g{};
+    g.faces = faces; g.fim = face_index_map;
+    g.grad_rgb = gather_tex ? grad_rgb_img : nullptr;
+    g.grad_depth = want_f ? grad_depth_img : nullptr;
+    g.grad_faces = grad_faces;
+    g.grad_textures = gather_tex ? grad_textures : nullptr;
+    g.B = batch_size; g.F = num_faces; g.is = image_size; g.eps = eps;
+    g.accumulate_faces = want_d ? 1 : 0;
+    g.dbg_rows = ((flags >> 8) & 32 ? 1 : 0) | ((flags >> 8) & 64 ? 2 : 0);
+    if (use_list) {
+        const OwnerList ol = owner_list(workspace, batch_size, num_faces);
+        g.owners = ol.list; g.n_owners = ol.counter;
+    }
+    const int64_t gather_threads = nfaces * GGL;
     auto launch_gather = [&](hipStream_t gs) -> int {
-        GatherParams g{};
-        g.faces = faces; g.fim = face_index_map;
-        g.grad_rgb = gather_tex ? grad_rgb_img : nullptr;
-        g.grad_depth = want_f ? grad_depth_img : nullptr;
-        g.grad_faces = grad_faces;
-        g.grad_textures = gather_tex ? grad_textures : nullptr;
-        g.B = batch_size; g.F = num_faces; g.is = image_size; g.eps = eps;
-        g.accumulate_faces = want_d ? 1 : 0;
-        g.dbg_rows = ((flags >> 8) & 32 ? 1 : 0) | ((flags >> 8) & 64 ? 2 : 0);
-        if (use_list) {
-            const OwnerList ol = owner_list(workspace, batch_size, num_faces);
-            g.owners = ol.list; g.n_owners = ol.counter;
-        }
-        const int64_t nthreads = nfaces * GGL;
-        if (gather_tex && want_f) return launch1d(gather_kernel<true, true, true>, nthreads, gs, g);
-        if (gather_tex) return launch1d(gather_kernel<true, true, false>, nthreads, gs, g);
-        if (want_f) return launch1d(gather_kernel<true, false, true>, nthreads, gs, g);
-        return launch1d(gather_kernel<true, false, false>, nthreads, gs, g);
+        if (gather_tex && want_f) return launch1d(gather_kernel<true, true, true>, gather_threads, gs, g);
+        if (gather_tex) return launch1d(gather_kernel<true, true, false>, gather_threads, gs, g);
+        if (want_f) return launch1d(gather_kernel<true, false, true>, gather_threads, gs, g);
+        return launch1d(gather_kernel<true, false, false>, gather_threads, gs, g);
     };
     bool gathered = false;
     if (want_d) {
@@ -2459,30 +2501,11 @@ extern "C" int mr_render_backward(const float* faces, const float* textures,
         PixelMapParams p{faces, face_index_map, rgb_img, alpha_img, grad_rgb_img, grad_alpha_img,
                          grad_faces, batch_size, num_faces, image_size, eps, rr, ra, 1, flags >> 8};
         p.zero_textures = (use_list && run_gather && gather_tex) ? grad_textures : nullptr;
-        // Round 5: kernel D's walk and the E / F gather are independent once the owner lists stand -- D adds to grad_faces' x / y
-        // with atomics, the gather adds its depth terms to the same rows with atomics (commutative) and writes grad_textures,
-        // which D never touches.  The gather is a latency chain of short workgroups (owner -> face -> probes -> gradients, ~100
-        // us one behind the other), the walk 200+ us of vector arithmetic at three waves per SIMD: the gather goes to a second,
-        // higher-priority stream behind the compaction pass and runs in the slots the walk's workgroups leave as they retire
-        // (profiling switch flags >> 8 & 128: one stream, one behind the other, as before).
-        SideStream* side = (use_list && strips_d && run_gather && !((flags >> 8) & 128)) ? side_stream() : nullptr;
-        bool forked = false;
-        std::function<int()> fork = [&]() -> int {
-            if (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                return MR_OK;  // (no fork: the gather follows on the caller's stream below)
-            }
-            forked = true;
-            const int grc = launch_gather(side->stream);
-            // (the join is recorded whatever the launch returned: the side stream must not stay forked off a capture)
-            if (hipEventRecord(side->join, side->stream) != hipSuccess) { (void)hipGetLastError(); return MR_ERR_BADARG; }
-            return grc;
-        };
-        rc = launch_pixel_map<true>(p, workspace, workspace_bytes, flags, s, side ? &fork : nullptr);
-        if (forked) {
-            if (hipStreamWaitEvent(s, side->join, 0) != hipSuccess) { (void)hipGetLastError(); return MR_ERR_BADARG; }
-            gathered = true;
-        }
+        // Round 5: kernel D's walk and the E / F gather go out as ONE launch when both run over the owner lists
+        // (strip_gather_kernel; profiling switch flags >> 8 & 128: two launches, one behind the other, as before)
+        FusedGather fg{g, gather_tex, want_f, gather_threads};
+        const bool fuse = use_list && strips_d && run_gather && (gather_tex || want_f) && !((flags >> 8) & 128);
+        rc = launch_pixel_map<true>(p, workspace, workspace_bytes, flags, s, fuse ? &fg : nullptr, &gathered);
         if (rc != MR_OK) return rc;
     } else if (use_list && run_gather) {
         const OwnerList ol = owner_list(workspace, batch_size, num_faces);

@@ -140,6 +140,10 @@ class WarpRegNet(torch.nn.Module):
         lambda_data, lambda_consist = consist_lambdas(
             self.step_count, self.lambda_data, self.lambda_consist, self.progressive_consist, self.progressive_steps)
         if self.lambda_tensors is not None:
+            # (a premodel that has been through GraphedTrainStep reads its weights from the device tensor also when it is
+            # stepped eagerly again: bring the tensor up to this step first -- inside a capture the caller has done so)
+            if not torch.cuda.is_current_stream_capturing():
+                self.refresh_lambda_tensors()
             lambda_data, lambda_consist = self.lambda_tensors[0], self.lambda_tensors[1]
 
         loss, pair_results = 0, None

@@ -134,12 +134,20 @@ class GraphedTrainStep:
 
     Requirements: a CUDA optimiser built with ``capturable=True`` (stock fused Adam), no ``reducer`` (data-parallel runs
     stay eager: a collective inside a capture has not run on hardware here), ``check_nan`` handled on the device, and an
-    fp32 trunk: with the encoder under bf16 autocast replayed runs flagged NaN head losses that eager runs never showed
-    (round 5, 640 x 480, not root-caused) -- ``allow_autocast=True`` overrides the refusal."""
+    fp32 trunk with MIOpen's DEFAULT solver choice: with ``torch.backends.cudnn.benchmark = True`` a replayed step now and then
+    returns garbage weight gradients of the trunk's convolutions (1 step in 8 at 128 x 128: 2e5 x the gradient's norm, losses
+    unchanged; never with the search off, never eagerly), which is also what the NaN head losses of replayed bf16 runs came
+    from (round 5) -- ``allow_autocast=True`` overrides both refusals (measurements only).  A premodel that goes through this
+    class should not be stepped eagerly on another stream in between (its AccumulateGrad nodes are bound to the stream of
+    their first backward pass)."""
 
     def __init__(self, premodel, optimizer, check_nan=True, max_graphs=8, allow_autocast=False):
         if not _device_guarded(optimizer) or not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainStep needs a fused optimiser built with capturable=True")
+        if torch.backends.cudnn.benchmark and not allow_autocast:
+            raise ValueError("GraphedTrainStep with torch.backends.cudnn.benchmark = True: replayed steps intermittently return "
+                             "garbage weight gradients of the trunk's convolutions under MIOpen's searched solvers (round 5, "
+                             "scripts/r5_graph_grad_debug2.py); switch the search off or step eagerly")
         enc_dtype = getattr(getattr(premodel, "model", None), "encoder_dtype", None)
         if enc_dtype not in (None, torch.float32) and not allow_autocast:
             raise ValueError("GraphedTrainStep is validated for an fp32 trunk only (see the class docstring); "

@@ -6,12 +6,12 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 COMMON="--no-kernel-bench --no-cpu-baseline --no-stock-trunk"
-timeout 500 python bench.py $COMMON > $OUT/graph_256.json 2> $OUT/graph_256.err
-timeout 500 python bench.py $COMMON --eager-step > $OUT/eager_256.json 2> $OUT/eager_256.err
-timeout 500 python bench.py $COMMON --batch 8 --image-size 480 --image-height 270 > $OUT/graph_480.json 2> $OUT/graph_480.err
-timeout 500 python bench.py $COMMON --batch 8 --image-size 480 --image-height 270 --eager-step > $OUT/eager_480.json 2> $OUT/eager_480.err
-timeout 500 python bench.py $COMMON --batch 32 --image-size 640 --image-height 480 --encoder-dtype bf16 > $OUT/graph_640.json 2> $OUT/graph_640.err
-timeout 500 python bench.py $COMMON --batch 32 --image-size 640 --image-height 480 --encoder-dtype bf16 --eager-step > $OUT/eager_640.json 2> $OUT/eager_640.err
+timeout 500 python bench.py $COMMON --graph-step > $OUT/graph_256.json 2> $OUT/graph_256.err
+timeout 500 python bench.py $COMMON > $OUT/eager_256.json 2> $OUT/eager_256.err
+timeout 500 python bench.py $COMMON --batch 8 --image-size 480 --image-height 270 --graph-step > $OUT/graph_480.json 2> $OUT/graph_480.err
+timeout 500 python bench.py $COMMON --batch 8 --image-size 480 --image-height 270 > $OUT/eager_480.json 2> $OUT/eager_480.err
+timeout 500 python bench.py $COMMON --batch 32 --image-size 640 --image-height 480 --encoder-dtype bf16 --graph-step > $OUT/graph_640.json 2> $OUT/graph_640.err
+timeout 500 python bench.py $COMMON --batch 32 --image-size 640 --image-height 480 --encoder-dtype bf16 > $OUT/eager_640.json 2> $OUT/eager_640.err
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("$OUT/*_*.json")):

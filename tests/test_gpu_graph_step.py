@@ -8,6 +8,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _default_solvers():
+    """GraphedTrainStep refuses MIOpen's solver search (torch.backends.cudnn.benchmark): see its docstring."""
+    saved = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
+    yield
+    torch.backends.cudnn.benchmark = saved
+
+
 def _build(dev, B, is_, seed, capturable, lr=5e-5, pool=2):
     from handobjectconsist_amd.models.synthnet import SynthMeshRegNet
     from handobjectconsist_amd.models.warpreg import WarpRegNet
@@ -28,52 +37,50 @@ def _grads(model):
 
 
 def test_graph_replay_equals_the_eager_step(cuda):
-    """ONE model, learning rate 0 (the parameters stay put): every step is done twice from the same lambda-ramp position,
-    eagerly and through GraphedTrainStep (two batch sets: one eager call each, then capture + replays) -- loss, every log
-    entry and the gradients agree (the forward is deterministic: equal to fp32 rounding of the loss sums; the gradients to
-    the order of the render backward's fp32 atomics), the ramp is followed (progressive_steps = 6), the counters advance."""
+    """Two identical models, learning rate 0 (the parameters stay put): every step is done eagerly on one (``train_step``) and
+    through GraphedTrainStep on the other (two batch sets: one eager call each, then capture + replays) -- loss, every log
+    entry and the gradients agree (the forward is deterministic up to the trunk's / heads' GEMM rounding, which the renderer
+    amplifies for the consistency term; the gradients to the order of the render backward's fp32 atomics on top), the ramp is
+    followed (progressive_steps = 6), the counters advance.  (One model per side: a premodel that has been through
+    GraphedTrainStep keeps its AccumulateGrad nodes bound to that class's stream -- eager backward passes on the default
+    stream in between would move them.)"""
     from handobjectconsist_amd.netscripts.epochpassconsist import GraphedTrainStep, raise_pending_nan, train_step
 
     B, is_, steps = 4, 128, 9
-    model, pre, opt, loader = _build(cuda, B, is_, 11, True, lr=0.0)
+    _, pre_e, opt_e, loader_e = _build(cuda, B, is_, 11, True, lr=0.0)
+    _, pre, opt, loader = _build(cuda, B, is_, 11, True, lr=0.0)
     step_g = GraphedTrainStep(pre, opt)
     losses_g = []
     for i in range(steps):
-        pre.step_count = i
-        le, logs_e = train_step(loader.step_batches(i), pre, opt)
-        grads_e = [p.grad.detach().clone() for g in opt.param_groups for p in g["params"]]
-        assert pre.step_count == i + 1
-        pre.step_count = i
+        assert pre_e.step_count == i and pre.step_count == i
+        le, logs_e = train_step(loader_e.step_batches(i), pre_e, opt_e)
+        grads_e = [p.grad.detach().clone() for g in opt_e.param_groups for p in g["params"]]
         lg, logs_g = step_g(loader.step_batches(i))
-        assert pre.step_count == i + 1
+        assert pre.step_count == i + 1 and pre_e.step_count == i + 1
         losses_g.append(float(lg))
         assert set(logs_e) == set(logs_g)
-        # (the total: equal up to the consistency term's run-to-run scatter -- see below -- at its largest weight, 0.001)
+        # (the consistency term of a RANDOM-INIT network: two eager calls differ by up to ~1e-3 -- the heads' GEMMs and the
+        # trunk's convolutions are not bit-reproducible from call to call, the renderer's barycentrics amplify a last-bit change
+        # of a few-pixel face by 10^3 (DESIGN.md section 2), and a pixel that changes sides of a validity threshold is 1e-3
+        # of the masked mean of a small frame; its weight in the total is at most 0.001)
         consist_e = abs(float(logs_e["warp_consist"])) if "warp_consist" in logs_e else 0.0
-        assert abs(float(lg) - float(le)) <= 1e-5 * abs(float(le)) + 0.001 * 0.3 * consist_e + 1e-9, f"loss at step {i}"
+        assert abs(float(lg) - float(le)) <= 1e-5 * abs(float(le)) + 0.001 * 1e-2 * consist_e + 1e-9, f"loss at step {i}"
         for k in logs_e:
-            # (the consistency term of a RANDOM-INIT network: two EAGER calls already differ by 5e-5 ... 8e-4 (seen at step 0,
-            # where both calls are eager) -- the heads' GEMMs and the trunk's convolutions are not bit-reproducible from call
-            # to call, the renderer's barycentrics amplify a last-bit change of a few-pixel face by 10^3 (DESIGN.md section
-            # 2), and at 64 x 64 a pixel that changes sides of a validity threshold is 1e-3 of the masked mean)
-            # A 64 x 64 frame of a random-init network holds a few hundred valid pixels: one of them changing sides moves the
-            # masked mean by several per cent (14 % seen once), so this entry is a sanity check only here; the kernels behind
-            # it are compared bit for bit elsewhere (tests/test_gpu_warp.py, tests/test_gpu_trainer.py).
-            tol = 0.3 if k == "warp_consist" else 2e-5
+            tol = 1e-2 if k == "warp_consist" else 2e-5
             np.testing.assert_allclose(float(logs_g[k]), float(logs_e[k]), rtol=tol, atol=1e-9, err_msg=f"{k} at step {i}")
         if i >= 2:  # a replayed step: its gradients live in the capture's own tensors
             assert step_g.replays == i - 1
             ge = torch.cat([g.flatten() for g in grads_e]).double()
             gg = torch.cat([g.flatten() for g in step_g.last_grads]).double()
-            # (the consistency term's share, as above: at 64 x 64 the two gradients were 2.3 % apart once with losses equal to
-            # 1e-5 -- a handful of pixels changing sides moves that term's gradient by a tenth; a stale or missing gradient
-            # would show as a difference of order one)
-            assert float((ge - gg).norm() / ge.norm()) < 3e-2, f"gradients at step {i}"
+            # (two eager calls on this workload: up to 3e-3 apart, the consistency term's share; a stale or missing
+            # gradient shows as a difference of order one)
+            assert float((ge - gg).norm() / ge.norm()) < 2e-2, f"gradients at step {i}"
     raise_pending_nan(opt)
+    raise_pending_nan(opt_e)
     # the ramp is followed: the same batch set gives another loss while the weights still move (steps 0 / 2 / 4) ...
     assert abs(losses_g[0] - losses_g[2]) > 1e-7 and abs(losses_g[2] - losses_g[4]) > 1e-7
     assert abs(losses_g[6] - losses_g[8]) <= 1e-5 * abs(losses_g[8])  # ... and the same one once it is over
-    assert all(float(st["step"]) == 2 * steps for st in opt.state_dict()["state"].values())
+    assert all(float(st["step"]) == steps for st in opt.state_dict()["state"].values())
 
 
 def test_replayed_update_equals_the_eager_update(cuda):
