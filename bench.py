@@ -72,8 +72,8 @@ def parse():
                         "rocprofv3 --kernel-trace pass behind roofline.frac_in_step profiles")
     p.add_argument("--eager-step", action="store_true", help="(the default since the end of round 5; kept for old command lines)")
     p.add_argument("--graph-step", action="store_true",
-                   help="replay the captured train_step (one hipGraph launch per step) instead of issuing its launches from the "
-                        "host; switches MIOpen's solver search off for the run (see the note at graph_step in main)")
+                   help="EXPERIMENTAL, timing only: replay the captured train_step (one hipGraph launch per step) instead of issuing "
+                        "its launches from the host (see the note at graph_step in main)")
     p.add_argument("--reducer-ab", type=int, default=0, metavar="PAIRS",
                    help="A/B inside ONE process (one model, one set of MIOpen / TunableOp solver choices): PAIRS x "
                         "(--steps plain steps, then --steps steps through the RCCL process group + bucketed gradient "
@@ -831,18 +831,14 @@ def main():
     # same update (A/B on one MI355X: 46.05 -> 45.10 ms per step); HOC_FUSED_ADAM=0 selects the foreach default
     params = [p for p in model.parameters() if p.requires_grad]
     # --graph-step: one step = ONE hipGraph launch (netscripts/epochpassconsist.GraphedTrainStep: train_step captured per
-    # device-resident batch set and replayed).  NOT the default, and never together with MIOpen's solver search: with
-    # torch.backends.cudnn.benchmark on, a replayed step now and then (1 in 8 in scripts/r5_graph_grad_debug2.py) comes back with
-    # garbage in the weight gradients of the trunk's convolutions -- 2e5 x the gradient's norm in conv1 / layer1, losses
-    # unchanged -- which eager steps and replays under MIOpen's default solver choice never showed; the NaN head losses of the
-    # bf16 configuration under replay were the same thing one step later.  Measured (profiles/r05_graph_vs_eager.txt): the metric
-    # config gains 0.4 % from the replay (device-bound), config 3 (B = 8) 6 %.  Data-parallel runs issue their launches eagerly
-    # (no collective has run inside a capture on hardware here).
+    # device-resident batch set and replayed).  EXPERIMENTAL, for timing only, never the default: a replayed step now and then
+    # comes back with garbage in the weight gradients of the trunk's convolutions (2e5 x the gradient's norm in conv1 / layer1,
+    # losses unchanged; scripts/r5_graph_grad_debug2.py, tests of round 5) -- eager steps never.  Measured
+    # (profiles/r05_graph_vs_eager.txt): with the same (searched) solvers the metric config gains 0.4 % from the replay
+    # (device-bound), config 3 (B = 8) 6 %.
     fused_adam = os.environ.get("HOC_FUSED_ADAM", "1") == "1"
     graph_step = (args.graph_step and not args.eager_step and not use_dist and fused_adam and not args.hot_only
                   and args.encoder_dtype == "f32")
-    if graph_step:
-        torch.backends.cudnn.benchmark = False
     optimizer = torch.optim.Adam(params, lr=5e-5, fused=fused_adam, capturable=graph_step)
     loader = SyntheticConsistLoader(B, is_, seed=rank, device=dev, pool=2, image_height=ih_)
 
@@ -893,7 +889,7 @@ def main():
     def make_step(pre, opt):
         if not graph_step:
             return lambda batches: train_step(batches, pre, opt, check_nan=check_nan, reducer=reducer)
-        return GraphedTrainStep(pre, opt, check_nan=check_nan)
+        return GraphedTrainStep(pre, opt, check_nan=check_nan, experimental=True)
 
     step_fn = make_step(premodel, optimizer)
     # (graph replay: a batch set's first call runs eagerly, its second captures -- both untimed; when the W warm-up steps asked
@@ -1128,7 +1124,7 @@ def main():
                     "roofline.hot_path_device_ms of the step)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "graph_setup_steps": n_warm - args.warmup,
             "ms_per_step": round(ms, 3),
-            "step_mode": graph_fell_back or ("hipGraph replay of the captured train_step (one launch per step; MIOpen's solver search off)" if graph_step else "eager launches"),
+            "step_mode": graph_fell_back or ("EXPERIMENTAL hipGraph replay of the captured train_step (one launch per step; replays are known to return garbage convolution weight gradients now and then: timing only)" if graph_step else "eager launches"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
             "data": "synthetic",

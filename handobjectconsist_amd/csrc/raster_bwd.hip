@@ -115,7 +115,10 @@ constexpr int GLPF = 4;
 #endif
 constexpr int GGL = MR_GGL;   // lanes per face of the generic gather (E: 74 -> 64 us, E + F: 105 -> 93 us against 4; 16: 70 / 101)
 constexpr int GATHER_BIG = 128;          // vertex-colour gather: bbox area above which the whole wave probes
-constexpr int GATHER_BIG_GENERIC = 256;  // generic gather (direct accumulation on the wave-cooperative path)
+#ifndef MR_GATHER_BIG
+#define MR_GATHER_BIG 256
+#endif
+constexpr int GATHER_BIG_GENERIC = MR_GATHER_BIG;  // generic gather (direct accumulation on the wave-cooperative path)
 
 template <bool TEX, bool DEPTH>
 __device__ __forceinline__ void gather_store(const GatherParams& p, int64_t i, const float* gt, const float* gf) {

@@ -132,22 +132,26 @@ class GraphedTrainStep:
     ``SyntheticConsistLoader``).  The first call with a new batch set runs eagerly (solver searches, TunableOp, the tile-list
     guess), the second captures and replays, later ones replay.
 
-    Requirements: a CUDA optimiser built with ``capturable=True`` (stock fused Adam), no ``reducer`` (data-parallel runs
-    stay eager: a collective inside a capture has not run on hardware here), ``check_nan`` handled on the device, and an
-    fp32 trunk with MIOpen's DEFAULT solver choice: with ``torch.backends.cudnn.benchmark = True`` a replayed step now and then
-    returns garbage weight gradients of the trunk's convolutions (1 step in 8 at 128 x 128: 2e5 x the gradient's norm, losses
-    unchanged; never with the search off, never eagerly), which is also what the NaN head losses of replayed bf16 runs came
-    from (round 5) -- ``allow_autocast=True`` overrides both refusals (measurements only).  A premodel that goes through this
-    class should not be stepped eagerly on another stream in between (its AccumulateGrad nodes are bound to the stream of
-    their first backward pass)."""
+    **EXPERIMENTAL -- NOT RELIABLE, measurements only** (round 5).  A twin-model test (one model stepped eagerly, its twin through
+    the replay, learning rate 0) shows that a replayed step NOW AND THEN returns garbage in the weight gradients of the trunk's
+    convolutions -- 2e5 x the gradient's norm in conv1 / layer1, losses unchanged: 1 step in 8 at 128 x 128 with MIOpen's
+    solver search on, step 8 of 9 in another run with it off; eager steps never.  Not root-caused (MIOpen's split-K
+    weight-gradient kernels under capture are the suspects); the NaN head losses of replayed bf16 runs came from it.  The
+    constructor therefore refuses to build unless ``experimental=True``; ``train_step`` (eager) is the product's step, and the
+    host never binds it by the 0.8 rule (issue / device time 0.21 at the metric config, 0.65 at B = 8, 0.33 at config 5:
+    profiles/r05_host_timeline.txt).
 
-    def __init__(self, premodel, optimizer, check_nan=True, max_graphs=8, allow_autocast=False):
+    Requirements: a CUDA optimiser built with ``capturable=True`` (stock fused Adam), no ``reducer`` (no collective has run
+    inside a capture on hardware here), ``check_nan`` handled on the device.  A premodel that goes through this class should not
+    be stepped eagerly on another stream in between (its AccumulateGrad nodes are bound to the stream of their first backward
+    pass)."""
+
+    def __init__(self, premodel, optimizer, check_nan=True, max_graphs=8, experimental=False, allow_autocast=False):
+        if not experimental:
+            raise ValueError("GraphedTrainStep is experimental: replayed steps return garbage convolution weight gradients now "
+                             "and then (see the class docstring); pass experimental=True for timing measurements only")
         if not _device_guarded(optimizer) or not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainStep needs a fused optimiser built with capturable=True")
-        if torch.backends.cudnn.benchmark and not allow_autocast:
-            raise ValueError("GraphedTrainStep with torch.backends.cudnn.benchmark = True: replayed steps intermittently return "
-                             "garbage weight gradients of the trunk's convolutions under MIOpen's searched solvers (round 5, "
-                             "scripts/r5_graph_grad_debug2.py); switch the search off or step eagerly")
         enc_dtype = getattr(getattr(premodel, "model", None), "encoder_dtype", None)
         if enc_dtype not in (None, torch.float32) and not allow_autocast:
             raise ValueError("GraphedTrainStep is validated for an fp32 trunk only (see the class docstring); "

@@ -25,7 +25,7 @@ def build(capturable):
 if two:
     me, pe, oe, le = build(False)
 mg, pg, og, lg = build(True)
-step = E.GraphedTrainStep(pg, og)
+step = E.GraphedTrainStep(pg, og, experimental=True)
 for i in range(6):
     if two:
         E.train_step(le.step_batches(i), pe, oe)

@@ -89,7 +89,7 @@ for name, spans in r[3].items():
 # the same step as ONE graph launch
 pre.forward = real_forward
 torch.Tensor.backward = real_backward
-step = E.GraphedTrainStep(pre, opt, allow_autocast=True)  # (bf16: measured here, not used by bench.py -- see its note)
+step = E.GraphedTrainStep(pre, opt, experimental=True, allow_autocast=True)  # (bf16: measured here, not used by bench.py -- see its note)
 for i in range(6):
     step(loader.step_batches(i))
 torch.cuda.synchronize()

@@ -20,7 +20,7 @@ pre = WarpRegNet((is_, ih_), model, lambda_consist=0.001, lambda_data=0.999, cri
 pre.step_count = 1000
 opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, fused=True, capturable=True)
 loader = E.SyntheticConsistLoader(B, is_, seed=0, device=dev, pool=2, image_height=ih_ if ih_ != is_ else None)
-step = E.GraphedTrainStep(pre, opt, allow_autocast=True) if graph else (lambda b: E.train_step(b, pre, opt))
+step = E.GraphedTrainStep(pre, opt, experimental=True, allow_autocast=True) if graph else (lambda b: E.train_step(b, pre, opt))
 bad = None
 for i in range(steps):
     try:

@@ -11,7 +11,7 @@ if len(sys.argv) > 1:
     pre.lambda_consist = float(sys.argv[1])
 names = [n for n, p in model.named_parameters() if p.requires_grad]
 params = [p for g in opt.param_groups for p in g["params"]]
-step_g = GraphedTrainStep(pre, opt)
+step_g = GraphedTrainStep(pre, opt, experimental=True)
 def grads(): return [p.grad.detach().clone() for p in params]
 for i in range(6):
     pre.step_count = i

@@ -13,7 +13,7 @@ m_e, pre_e, opt_e, ld_e = _build(dev, B, is_, 11, True, lr=0.0)
 m_g, pre_g, opt_g, ld_g = _build(dev, B, is_, 11, True, lr=0.0)
 names = [n for n, p in m_e.named_parameters() if p.requires_grad]
 pe = [p for g in opt_e.param_groups for p in g["params"]]
-step_g = GraphedTrainStep(pre_g, opt_g)
+step_g = GraphedTrainStep(pre_g, opt_g, experimental=True)
 for i in range(8):
     le, _ = train_step(ld_e.step_batches(i), pre_e, opt_e)
     ge = [p.grad.detach().clone() for p in pe]
