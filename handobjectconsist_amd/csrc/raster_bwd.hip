@@ -115,8 +115,11 @@ constexpr int GLPF = 4;
 #endif
 constexpr int GGL = MR_GGL;   // lanes per face of the generic gather (E: 74 -> 64 us, E + F: 105 -> 93 us against 4; 16: 70 / 101)
 constexpr int GATHER_BIG = 128;          // vertex-colour gather: bbox area above which the whole wave probes
+// (256 until round 5: the 114 faces of the bench scene with boxes of 256-500 pixels then took the whole-wave path ONE BEHIND THE
+// OTHER inside the wave that holds them -- consecutive wrist faces -- while as ordinary lane groups they advance side by side: E
+// alone 93.7 -> 90.4 us at 256 x 256, 263 -> 230 at 640 x 640; 8192: no further gain at 256, slower at 640)
 #ifndef MR_GATHER_BIG
-#define MR_GATHER_BIG 256
+#define MR_GATHER_BIG 1024
 #endif
 constexpr int GATHER_BIG_GENERIC = MR_GATHER_BIG;  // generic gather (direct accumulation on the wave-cooperative path)
 
