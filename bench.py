@@ -812,7 +812,7 @@ def main():
     if use_dist and torch_ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
 
-        net = DDP(model, device_ids=[dev_index], bucket_cap_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "8")),
+        net = DDP(model, device_ids=[dev_index], bucket_cap_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "16")),
                   broadcast_buffers=False, gradient_as_bucket_view=os.environ.get("HOC_DDP_BUCKET_VIEW", "1") == "1")
     elif use_dist and not args.reducer_ab:
         from handobjectconsist_amd.netscripts.gradreduce import BucketedGradReducer
@@ -820,7 +820,7 @@ def main():
         # the model is NOT wrapped: 8 MB buckets, filled by one multi-tensor copy each from inside backward(), one
         # asynchronous RCCL all-reduce (average) per bucket overlapping the encoder backward; frozen BN statistics
         # -> no buffer exchange (netscripts/gradreduce.py)
-        reducer = BucketedGradReducer(model.parameters(), bucket_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "8")))
+        reducer = BucketedGradReducer(model.parameters(), bucket_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "16")))
     ih_ = args.image_height or is_
     assert ih_ <= is_, "--image-height must not exceed --image-size (the raster is the square of the longer side)"
     premodel = WarpRegNet((is_, ih_), net, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
@@ -870,7 +870,7 @@ def main():
         plain_ms, red_ms, nb = [], [], 0
         for _ in range(args.reducer_ab):
             plain_ms.append(round(block(None), 4))
-            red = BucketedGradReducer(model.parameters(), bucket_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "8")))
+            red = BucketedGradReducer(model.parameters(), bucket_mb=int(os.environ.get("HOC_DDP_BUCKET_MB", "16")))
             nb = len(red.buckets)
             red_ms.append(round(block(red), 4))
             red.remove()
@@ -944,7 +944,7 @@ def main():
         ranks = {"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "world_size": world,
                  "per_rank": [{"rank": int(r_[0]), "device": int(r_[1]), "ms_per_step": round(float(r_[2]), 3)} for r_ in allr],
                  "grad_allreduce_MB": round(sum(p_.numel() for p_ in model.parameters() if p_.requires_grad) * 4 / 1e6, 1),
-                 "bucket_MB": int(os.environ.get("HOC_DDP_BUCKET_MB", "8")),
+                 "bucket_MB": int(os.environ.get("HOC_DDP_BUCKET_MB", "16")),
                  "reducer": "torch DistributedDataParallel (HOC_TORCH_DDP=1)" if torch_ddp else
                             f"gradreduce.BucketedGradReducer, {len(reducer.buckets)} buckets, all-reduce issued from backward"}
     assert torch.isfinite(loss).all(), "loss is not finite"

@@ -11,7 +11,9 @@ communicated: 30.1-30.7 ms per step against 26.6 ms without the wrapper, 430 aga
 
 * the model is NOT wrapped -- forwards cost what they cost without data parallelism;
 * parameters are grouped, in reverse registration order (the order their gradients become ready in), into
-  buckets of ``bucket_mb`` (xGMI is point-to-point: 8 MB keeps a ring step per link well above its latency);
+  buckets of ``bucket_mb`` (xGMI is point-to-point: a bucket must keep a ring step per link well above its latency; 16 MB since
+  round 5 -- four buckets for this trainer: one-rank cost 2.2 % with nine 8 MB buckets, 1.8 % with four or two,
+  profiles/r05_reducer_bucket_sizes.txt);
   each bucket owns ONE flat buffer and per-parameter views of it with the parameter's own (dense) strides;
 * a post-accumulate hook per parameter counts the bucket down; the hook of the LAST gradient of a bucket copies
   the bucket's gradients into the flat buffer with one multi-tensor copy, points ``p.grad`` at the views and
@@ -82,7 +84,7 @@ class BucketedGradReducer:
     backward per ``finish()`` -- the step structure of epochpassconsist.py:57-68).  ``process_group=None`` = the
     default group."""
 
-    def __init__(self, params, process_group=None, bucket_mb=8, broadcast_from=0):
+    def __init__(self, params, process_group=None, bucket_mb=16, broadcast_from=0):
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.backend = dist.get_backend(process_group)
