@@ -1139,6 +1139,29 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
                 const int4 v0 = vq[0], v1 = vq[1], v2 = vq[2];
                 vid[0][0] = v0.x; vid[0][1] = v0.y; vid[0][2] = v0.z; vid[1][0] = v0.w; vid[1][1] = v1.x; vid[1][2] = v1.y;
                 vid[2][0] = v1.z; vid[2][1] = v1.w; vid[2][2] = v2.x; vid[3][0] = v2.y; vid[3][1] = v2.z; vid[3][2] = v2.w;
+                // Round 5: the three (vertex, weight) pairs of a pixel are ROTATED by the lane's row in the tile (mod 3).  A
+                // face spans three or four rows, so the lanes above one another hold the same three vertex ids, and the LDS
+                // atomics of step k below all hit the same table cell -- 65 % of this kernel's LDS-active cycles were such
+                // collisions (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r05_pmc_summary.txt), the LDS pipe the
+                // longest phase of a workgroup.  Rotated, neighbouring rows add to DIFFERENT vertices of the face in the same
+                // step (the sum does not care about the order).  SQ_LDS_BANK_CONFLICT 1.59 -> 1.27 M per launch.  dbg & 4: off.
+                if (!(p.dbg & 4)) {
+                    // (by row AND column: horizontally adjacent lanes share a face where it straddles their four-pixel groups.
+                    // 640 x 640, B = 32, warm: 43.9 us unrotated, 36.7 by row, 33.1 by row + column; at 256 x 256, one tile per
+                    // wave, the launch is not bound by its LDS pipe and does not change.  dbg & 8: by row only)
+                    const int rot = (p.dbg & 8) ? r % 3 : (r + (lane & 7)) % 3;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int a0 = vid[j][0], a1 = vid[j][1], a2 = vid[j][2];
+                        const float b0 = w[j][0], b1 = w[j][1], b2 = w[j][2];
+                        vid[j][0] = rot == 0 ? a0 : (rot == 1 ? a1 : a2);
+                        vid[j][1] = rot == 0 ? a1 : (rot == 1 ? a2 : a0);
+                        vid[j][2] = rot == 0 ? a2 : (rot == 1 ? a0 : a1);
+                        w[j][0] = rot == 0 ? b0 : (rot == 1 ? b1 : b2);
+                        w[j][1] = rot == 0 ? b1 : (rot == 1 ? b2 : b0);
+                        w[j][2] = rot == 0 ? b2 : (rot == 1 ? b0 : b1);
+                    }
+                }
             } else {
                 const float4 d4 = *reinterpret_cast<const float4*>(sp.depth + ((int64_t)b * is + (is - 1 - yi)) * is + x);
                 zp[0] = d4.x; zp[1] = d4.y; zp[2] = d4.z; zp[3] = d4.w;
