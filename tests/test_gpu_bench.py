@@ -159,7 +159,7 @@ def test_one_rank_rccl_step_costs_what_the_plain_step_costs(cuda):
     DistributedDataParallel wrapper at +13-15 % on one rank).  Headline workload (B = 64, 256 x 256).  Both loops run
     in ONE process (``bench.py --reducer-ab``): one model, one set of MIOpen solver / TunableOp choices -- round 3
     compared two processes, whose separate solver searches alone moved a pair by up to 5 % -- so every pair counts: the
-    reducer's real cost on one rank is 2.5 % (its bucket copies and nine one-rank all-reduce launches; pairs of this round:
+    reducer's real cost on one rank is 1.8-2.5 % (its bucket copies and four -- nine until round 5 -- one-rank all-reduce launches; pairs of round 4:
     1.025, 1.026, 1.025, 1.032), so with +-0.5 % of block-to-block noise a bound of 1.03 on EACH of two pairs fails one run in
     a few.  Three pairs: the MEDIAN ratio <= 1.03 and no pair above 1.045 (not the minimum of the pairs, which round 3 used)."""
     bench = os.path.join(ROOT, "bench.py")
@@ -168,7 +168,7 @@ def test_one_rank_rccl_step_costs_what_the_plain_step_costs(cuda):
     assert res.returncode == 0, res.stderr[-2000:]
     line = _json_line(res.stdout)
     _keep("one_rank_reducer_vs_plain.json", line)
-    assert line["backend"] == "rccl" and line["buckets"] >= 5 and len(line["ratios"]) == 3
+    assert line["backend"] == "rccl" and line["buckets"] >= 3 and len(line["ratios"]) == 3
     ratios = sorted(red / plain for plain, red in zip(line["plain_ms"], line["one_rank_rccl_ms"]))
     assert ratios[1] <= 1.03 and ratios[2] <= 1.045, line
 
