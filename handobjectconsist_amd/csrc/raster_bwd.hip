@@ -905,9 +905,20 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
         // (every quantity below is the same in all lanes: readlane keeps it in scalar registers; the scans are DPP row shifts,
         // six vector instructions each, no LDS crossbar)
         // First try: one tile per wave (q = ST_WAVES) -- it fits whenever the scene leaves the grid some room, and then ONE pass
-        // over the counts gives everything; else q = ceil(N / room) and a second pass.
+        // over the counts gives everything; else q = ceil(N / room) and a second pass.  The counts of the first 4 x 64 images
+        // are requested TOGETHER and stay in registers for all passes (one round trip; further images: read again, from L1).
+        constexpr int NC = 4;
+        int nreg[NC];
+#pragma unroll
+        for (int i = 0; i < NC; i++) nreg[i] = i * MR_WAVE + lane < B2 ? ncov[i * MR_WAVE + lane] : 0;
         int q = ST_WAVES, used = 0, N = 0;
-        for (int c = 0; c < B2; c += MR_WAVE) {
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            if (i * MR_WAVE >= B2) break;
+            N += __builtin_amdgcn_readlane(wave_incl_sum(nreg[i], lane), MR_WAVE - 1);
+            used += __builtin_amdgcn_readlane(wave_incl_sum((nreg[i] + ST_WAVES - 1) / ST_WAVES, lane), MR_WAVE - 1);
+        }
+        for (int c = NC * MR_WAVE; c < B2; c += MR_WAVE) {
             const int n = c + lane < B2 ? ncov[c + lane] : 0;
             N += __builtin_amdgcn_readlane(wave_incl_sum(n, lane), MR_WAVE - 1);
             used += __builtin_amdgcn_readlane(wave_incl_sum((n + ST_WAVES - 1) / ST_WAVES, lane), MR_WAVE - 1);
@@ -916,7 +927,12 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
             const int room = max(grid - B2, 1);  // (sum ceil(n_b / q) <= N / q + B2)
             q = max(ST_WAVES, (N + room - 1) / room);
             used = 0;
-            for (int c = 0; c < B2; c += MR_WAVE) {
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                if (i * MR_WAVE >= B2) break;
+                used += __builtin_amdgcn_readlane(wave_incl_sum((nreg[i] + q - 1) / q, lane), MR_WAVE - 1);
+            }
+            for (int c = NC * MR_WAVE; c < B2; c += MR_WAVE) {
                 const int n = c + lane < B2 ? ncov[c + lane] : 0;
                 used += __builtin_amdgcn_readlane(wave_incl_sum((n + q - 1) / q, lane), MR_WAVE - 1);
             }
@@ -938,7 +954,9 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
         int base = 0, nb = 0, pb = 1;
         b = -1;
         for (int c = 0; c < B2 && b < 0; c += MR_WAVE) {
-            const int n = c + lane < B2 ? ncov[c + lane] : 0;
+            const int ci = c / MR_WAVE;
+            const int n = ci == 0 ? nreg[0] : ci == 1 ? nreg[1] : ci == 2 ? nreg[2] : ci == 3 ? nreg[3]
+                                                                                         : (c + lane < B2 ? ncov[c + lane] : 0);
             const int parts = (n + q - 1) / q;
             const int incl = wave_incl_sum(parts, lane);
             const unsigned long long mine = __ballot(k >= base + incl - parts && k < base + incl);
