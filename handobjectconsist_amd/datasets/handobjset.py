@@ -14,7 +14,8 @@ sampling) re-cut for a GPU-side image path:
 ``pose_dataset`` is any object with the accessor protocol of the reference's dataset classes
 (ho3dv2.py / fhbhands.py): get_image, get_center_scale, get_camintr, get_joints3d, get_hand_verts3d,
 get_obj_verts_trans, get_obj_faces, get_obj_verts_can, get_sides, get_dist_idx.  Colour jitter and blur
-(libyana colortrans + PIL filters on the host, handobjset.py:339-358) are a pluggable host callable."""
+(libyana colortrans + PIL filters on the host, handobjset.py:339-358) are a host callable: ``datasets/coloraugm.py``
+by default (blur pinned by a fixture, jitter restated), ``color_fn=None`` switches them off."""
 import random
 import traceback
 
@@ -41,7 +42,7 @@ class HandObjSet(Dataset):
     def __init__(self, pose_dataset, center_idx=9, inp_res=(256, 256), max_rot=np.pi, normalize_img=False,
                  split="train", scale_jittering=0.3, center_jittering=0.2, train=True, hue=0.15, saturation=0.5,
                  contrast=0.5, brightness=0.5, blur_radius=0.5, spacing=2, queries=DEFAULT_QUERIES, sides="both",
-                 block_rot=False, sample_nb=None, has_dist2strong=False, color_fn=None):
+                 block_rot=False, sample_nb=None, has_dist2strong=False, color_fn="reference"):
         self.pose_dataset = pose_dataset
         self.center_idx, self.inp_res = center_idx, tuple(inp_res)
         self.normalize_img, self.sides = normalize_img, sides
@@ -52,6 +53,10 @@ class HandObjSet(Dataset):
         self.train, self.scale_jittering, self.center_jittering = train, scale_jittering, center_jittering
         self.queries = tuple(queries)
         self.has_dist2strong = has_dist2strong
+        if color_fn == "reference":  # the reference's own augmentation (handobjset.py:339-358)
+            from handobjectconsist_amd.datasets import coloraugm
+
+            color_fn = coloraugm.make_color_fn(jitter=True)
         self.color_fn = color_fn  # (frame_u8, dataset, color_augm | None, blur_radius) -> (frame_u8, color_augm)
 
     def __len__(self):
@@ -99,7 +104,12 @@ class HandObjSet(Dataset):
                 # their colour parameters (handobjset.py:341): part of how far a sample advances torch's RNG stream
                 blur_radius = Uniform(low=0, high=1).sample().item() * self.blur_radius
                 if self.color_fn is not None:
-                    frame, color_augm = self.color_fn(frame, self, color_augm, blur_radius)
+                    # (the reference blurs the MIRRORED image, handobjset.py:120-122 before :341; the frame travels unmirrored
+                    # to the GPU kernel, which flips on the fly: mirror, augment, mirror back -- PIL's box-blur passes are
+                    # not symmetric to the last bit)
+                    view = frame[:, ::-1] if flip else frame
+                    view, color_augm = self.color_fn(view, self, color_augm, blur_radius)
+                    frame = view[:, ::-1] if flip else view
             sample["color_augm"] = color_augm if self.train else None
             sample["frame"] = np.ascontiguousarray(frame)
             sample["flip"] = bool(flip)

@@ -49,5 +49,8 @@ CONFIGS = [
     ("val_single_nocenter", dict(center_idx=None, sides="both", train=False, sample_nb=None), 14, [2, 5]),
     ("train_mid_center", dict(center_idx=-1, sides="right", block_rot=False, max_rot=1.0, sample_nb=2, spacing=0,
                               scale_jittering=0.1, center_jittering=0.4), 15, [4, 1]),
+    # Gaussian blur (handobjset.py:340-341: PIL's filter on the mirrored frame, a radius drawn per frame), both hand sides
+    ("train_pair_blur", dict(center_idx=9, sides="right", block_rot=False, max_rot=0.3, sample_nb=2, spacing=1, blur_radius=2.0),
+     16, [0, 1, 3]),
 ]
 INP_RES = (64, 64)

@@ -98,8 +98,8 @@ def main():
         ds = dataset_fake.FakePoseDataset(pil=True)
         # (TransQueries.CENTER3D with center_idx=None reads an unassigned local in the reference, handobjset.py:333-334)
         cfg_queries = [q for q in queries if not (q is T.CENTER3D and kw.get("center_idx", 9) is None)]
-        hs = handobjset.HandObjSet(ds, inp_res=dataset_fake.INP_RES, queries=cfg_queries, blur_radius=0.0,
-                                   **{"train": True, **kw})
+        hs = handobjset.HandObjSet(ds, inp_res=dataset_fake.INP_RES, queries=cfg_queries,
+                                   **{"train": True, "blur_radius": 0.0, **kw})
         # (1) get_sample alone: the augmentation it drew, for the first index
         torch.manual_seed(seed)
         first = hs.get_sample(idxs[0])

@@ -26,10 +26,11 @@ def decode_image(level, offset):
 
 
 def build(kw):
-    from handobjectconsist_amd.datasets import handobjset
+    from handobjectconsist_amd.datasets import coloraugm, handobjset
 
     ds = dataset_fake.FakePoseDataset(pil=False)
-    return ds, handobjset.HandObjSet(ds, inp_res=dataset_fake.INP_RES, queries=QUERIES, blur_radius=0.0, **{"train": True, **kw})
+    return ds, handobjset.HandObjSet(ds, inp_res=dataset_fake.INP_RES, queries=QUERIES,
+                                   color_fn=coloraugm.make_color_fn(jitter=False), **{"train": True, "blur_radius": 0.0, **kw})
 
 
 @pytest.fixture(scope="module")
