@@ -115,7 +115,8 @@ def forward(
         use_backward: also compare the warp of the unannotated frame with the annotated image
         pair_outputs: "full" (masks / warps / diffs as the reference returns them) or "loss" (the trainer's setting:
             masks / warps / diffs are None and ``recons_flows`` hold defined values only where their renders cover
-            something -- ``flow._base._hoc_coverage`` -- everything else is unspecified memory)
+            something -- ``flow._base._hoc_coverage`` -- everything else is unspecified memory;
+            ``opticalflow.dense_flows(pair_flows)`` returns zero-filled copies for logging or visualisation)
 
     Returns:
         (mean pair loss, {"masks", "warps", "recons_flows", "diffs", "diff_losses"})

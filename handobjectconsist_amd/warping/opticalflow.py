@@ -451,13 +451,12 @@ class _StackedFlowFunction(torch.autograd.Function):
               skipped on the coverage bytes.
     Differentiable w.r.t. ``cols`` only (detach_renders=True).
     ``sparse``: the occlusion / epilogue pass runs over the render's tile list and writes ``flow`` / ``occl`` under the
-    covered tiles only (mr_occlusion_flow_tiles); ``last_tiles`` hands the list to ``get_opticalflow``."""
-
-    last_tiles = None
+    covered tiles only (mr_occlusion_flow_tiles); the list goes back to ``get_opticalflow`` in ``tile_out`` (a list the caller
+    owns: nothing is kept on the class, calls may nest or run from several threads)."""
 
     @staticmethod
     def forward(ctx, ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, height, width,
-                sparse=False):
+                sparse=False, tile_out=None):
         ctx.set_materialize_grads(False)
         r = _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color,
                                  ctx.needs_input_grad[2])
@@ -472,7 +471,8 @@ class _StackedFlowFunction(torch.autograd.Function):
             where = _lib.tile_list(work, B2, F, is_)
             if where is not None:
                 tiles = (where[0], where[1], where[2], int(bound), work)  # (`work` rides along: the list lives in it)
-        _StackedFlowFunction.last_tiles = tiles
+        if tile_out is not None:
+            tile_out.append(tiles)
         occl = new_f(B2, is_, is_) if tiles else torch.empty((B2, is_, is_), **f32)
         flow = new_f(B2, height, width, 2) if tiles else torch.empty((B2, height, width, 2), **f32)
         # occlusion check + crop / permute / mask products of both directions in one pass.  mask_flow2 is the RAW
@@ -501,7 +501,7 @@ class _StackedFlowFunction(torch.autograd.Function):
         depth, vid = (None, depth_or_vid) if ctx.records else (depth_or_vid, None)
         is_, eps, fill_back, height, width = ctx.cfg
         if grad_flow is None or not ctx.needs_input_grad[2]:
-            return (None,) * 13
+            return (None,) * 14
         B2, V = verts.shape[:2]
         B = B2 // 2
         g = _lib.contig(grad_flow)
@@ -518,7 +518,7 @@ class _StackedFlowFunction(torch.autograd.Function):
                   _lib.ptr(occl), height, width, _lib.ptr(grad_cols), B2, V, int(fidx.shape[1]), int(fill_back), is_, eps,
                   _lib.FLAG_OUTPUT_ZEROED if zeroed else 0, _lib.ptr(vid), textutils.texel_layout_code(), _lib.ptr(bound),
                   _lib.stream_ptr(verts.device))
-        return (None, None, grad_cols) + (None,) * 10
+        return (None, None, grad_cols) + (None,) * 11
 
 
 # The consistency term of a frame pair as ONE autograd node (warpbranch's "loss" mode): flow render, then occlusion check +
@@ -544,13 +544,12 @@ class _FlowPairLossFunction(torch.autograd.Function):
     """(ndc[2B,V,3], faces[2B,F0,3] int32, cols[2B,V,3]; image_ref, image [B,3,H,W], jitter masks [B,Cj,H,W]) ->
     (loss_fwd[B], loss_bwd[B], loss_bwd + loss_fwd, flows[2B,H,W,2], tile_hit): opticalflow.py:98-154 + imgflowarp.py:58-115 +
     pyramidloss.py:56-62 + lossutils.py:1-8 for one frame pair.  Differentiable w.r.t. ``cols`` only (the training
-    setting: detach_renders=True, images are data).  ``flows`` are defined under the covered tiles only."""
-
-    last_tiles = None
+    setting: detach_renders=True, images are data).  ``flows`` are defined under the covered tiles only; the render's tile
+    list goes back to the caller in ``tile_out`` (a list the caller owns)."""
 
     @staticmethod
     def forward(ctx, ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color, height, width,
-                image_ref, image, jitter_ref, jitter, thresh, cleared_work=None):
+                image_ref, image, jitter_ref, jitter, thresh, cleared_work=None, tile_out=None):
         ctx.set_materialize_grads(False)
         _lib.check_cuda(image_ref, image, jitter_ref, jitter)
         r = _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, far, eps, background_color,
@@ -587,7 +586,8 @@ class _FlowPairLossFunction(torch.autograd.Function):
             _lib.call("mr_flow_pair_forward_tiles", *args, st)
             loss_sum = loss_bwd + loss_fwd
         # (the flows are defined under the covered tiles only: the list rides along with them, as for get_opticalflow(sparse_flows=True))
-        _FlowPairLossFunction.last_tiles = (where[0], where[1], where[2], int(r["bound"]), r["work"])
+        if tile_out is not None:
+            tile_out.append((where[0], where[1], where[2], int(r["bound"]), r["work"]))
         ctx.cfg = (is_, float(eps), bool(fill_back), height, width, float(thresh), int(r["F0"]), int(r["V"]))
         ctx.unit = unit
         if unit:
@@ -605,7 +605,7 @@ class _FlowPairLossFunction(torch.autograd.Function):
             g_fwd = g_sum if g_fwd is None else g_fwd + g_sum
             g_bwd = g_sum if g_bwd is None else g_bwd + g_sum
         if not ctx.needs_input_grad[2] or (g_fwd is None and g_bwd is None):
-            return (None,) * 18
+            return (None,) * 19
         fim = ctx.saved_tensors[0]
         B2 = fim.shape[0]
         B, dev = B2 // 2, fim.device
@@ -622,7 +622,7 @@ class _FlowPairLossFunction(torch.autograd.Function):
                       _lib.ptr(unit_grad), _lib.ptr(unit_max), _lib.ptr(sums), _lib.ptr(g_fwd), _lib.ptr(g_bwd), height, width,
                       _lib.ptr(grad_cols), B2, V, F0, int(fill_back), is_, eps, _lib.FLAG_OUTPUT_ZEROED if zeroed else 0,
                       textutils.texel_layout_code(), _lib.ptr(scatter_work), _lib.stream_ptr(dev))
-            return (None, None, grad_cols) + (None,) * 15
+            return (None, None, grad_cols) + (None,) * 16
         fim, tile_hit, wmap, vid, mask, alpha, occl, flow, im_ref, im, jm_ref, jm, sums = ctx.saved_tensors
         # scratch of the launch: the masked flow gradient of a workgroup's tiles between its two passes
         scratch = (torch.full((B2, height, width, 2), float("nan"), dtype=torch.float32, device=dev) if DEBUG_POISON_RENDER_OUTPUTS
@@ -632,7 +632,28 @@ class _FlowPairLossFunction(torch.autograd.Function):
                   _lib.ptr(g_bwd), _lib.ptr(mask), _lib.ptr(mask[:B]), _lib.ptr(alpha[B:]), _lib.ptr(occl), _lib.ptr(scratch),
                   height, width, _lib.ptr(grad_cols), B2, V, F0, int(fill_back), is_, eps, thresh,
                   _lib.FLAG_OUTPUT_ZEROED if zeroed else 0, textutils.texel_layout_code(), _lib.stream_ptr(dev))
-        return (None, None, grad_cols) + (None,) * 15
+        return (None, None, grad_cols) + (None,) * 16
+
+
+def dense_flows(pair_flows):
+    """The two flows of a pair with zeros wherever nothing was rendered, as the reference returns them (opticalflow.py:151-156).
+    For flows that ``flow_pair_loss`` / ``get_opticalflow(..., sparse_flows=True)`` wrote under their renders' covered tiles
+    only (unspecified memory elsewhere: warpbranch's "loss" mode): a masked COPY, made on request -- logging, visualisation,
+    reductions over whole flows.  Flows that are dense already come back as they are."""
+    base = getattr(pair_flows[0], "_base", None)
+    note = getattr(base, "_hoc_coverage", None) if base is not None else None
+    if note is None or len(note) < 4 or note[3] is None:
+        return list(pair_flows)
+    tile_hit, is_, version = note[0], int(note[1]), note[2]
+    if version != base._version:
+        raise RuntimeError("the flows were written in place after their renders: their coverage is no longer known")
+    B2, H, W, _ = base.shape
+    # one 4-byte coverage word per tile of 8 raster rows x 32 columns; a tile whose word is non-zero was written completely.
+    # Raster row r is image row is - 1 - r (the renderer's vertical flip).
+    on = tile_hit.view(torch.int32)[..., 0] != 0
+    on = on.repeat_interleave(8, 1)[:, :is_].flip(1).repeat_interleave(32, 2)[:, :H, :W]
+    dense = torch.where(on[..., None], base, torch.zeros((), dtype=base.dtype, device=base.device))
+    return [dense[:B2 // 2], dense[B2 // 2:]]
 
 
 def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image_ref, image, jitter_mask_ref, jitter_mask,
@@ -704,8 +725,8 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
     loss_fwd, loss_bwd, loss_sum, flows, tile_hit = _FlowPairLossFunction.apply(
         ndc, faces2, cols, lut, neurenderer.fill_back, is_, neurenderer.near, neurenderer.far,
         neurenderer.rasterizer_eps, neurenderer.background_color, H, W, image_ref, image, jitter_mask_ref, jitter_mask, 0.99999,
-        cleared_work)
-    tiles, _FlowPairLossFunction.last_tiles = _FlowPairLossFunction.last_tiles, None
+        cleared_work, tile_out := [])
+    tiles = tile_out[0]
     flows._hoc_coverage = (tile_hit, is_, flows._version, tiles)
     if with_sum:
         return loss_fwd, loss_bwd, [flows[:B], flows[B:]], loss_sum
@@ -780,8 +801,8 @@ def get_opticalflow(
             flows, tile_hit = _StackedFlowFunction.apply(
                 ndc, _stacked_faces(faces), cols, lut, neurenderer.fill_back, is_, neurenderer.near, neurenderer.far,
                 neurenderer.rasterizer_eps, neurenderer.background_color, min(int(H), is_), min(int(W), is_),
-                bool(sparse_flows))
-            tiles, _StackedFlowFunction.last_tiles = _StackedFlowFunction.last_tiles, None
+                bool(sparse_flows), tile_out := [])
+            tiles = tile_out[0]
             # the coverage bytes of the two renders ride along: a consumer that knows them (pair_consist) does not
             # even read the flows where nothing was rendered (they are exactly zero there -- or, with sparse_flows,
             # not even written: then the render's tile list rides along too)

@@ -413,7 +413,7 @@ def test_flow_finalize_backward_against_reference_glue(cuda):
 
 @pytest.mark.parametrize("mode", ["full", "loss"])
 @pytest.mark.parametrize("keys", ["enum", "string"])
-def test_warpbranch_forward_against_reference_glue(cuda, keys, mode):
+def test_warpbranch_forward_against_reference_glue(cuda, keys, mode, monkeypatch):
     """warpbranch.forward (warpbranch.py:9-96): GT-reference substitution, detach of frames > 0
     (first_only), per-pair pair_consist, stack().mean(), and d loss / d predicted vertices of every frame.
     ``mode`` "loss" = the trainer's setting (pair_outputs="loss": fused pair nodes, flows defined under their renders only,
@@ -422,7 +422,10 @@ def test_warpbranch_forward_against_reference_glue(cuda, keys, mode):
     from handobjectconsist_amd.datasets.queries import TransQueries as TQ
     from handobjectconsist_amd.models import warpbranch
     from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
+    from handobjectconsist_amd.warping import opticalflow
 
+    # "loss": render outputs start as NaN, so whatever the kernels leave unwritten shows (and dense_flows must mask it)
+    monkeypatch.setattr(opticalflow, "DEBUG_POISON_RENDER_OUTPUTS", mode == "loss")
     z, meta = load("chain_warpbranch.npz")
     names = {"image": TQ.IMAGE, "jittermask": TQ.JITTERMASK, "camintr": TQ.CAMINTR, "objfaces": BQ.OBJFACES,
              "objverts3d": BQ.OBJVERTS3D, "handverts3d": BQ.HANDVERTS3D}
@@ -450,6 +453,9 @@ def test_warpbranch_forward_against_reference_glue(cuda, keys, mode):
                     on = want[..., 0] != 0
                     assert on.sum() > 20 and np.abs(got[on] - want[on]).max() < 5e-3, (k, p, d, np.abs(got[on] - want[on]).max())
                     assert np.median(np.abs(got[on] - want[on])) < 1e-5, (k, p, d)
+                    # ... and on request as the reference returns them: zeros wherever nothing was rendered
+                    dense = n(opticalflow.dense_flows(pair["recons_flows"][p])[d])
+                    assert _flow_check(dense, want, (k, p, d)) == 0, (k, p, d, "support of the zero-filled flows")
                     continue
                 sup += _flow_check(n(pair["recons_flows"][p][d]), z[f"{k}_p{p}_flow{d}"], (k, p, d))
                 assert sup == 0, (k, p, d, "the training path must reproduce the support of the reference's flows")
