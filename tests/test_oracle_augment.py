@@ -183,3 +183,53 @@ def test_collated_sequence_batch_format():
         assert frame["affinetrans"].shape == (3, 3, 3) and frame["flip"].shape == (3,)
         assert frame["camintr"].shape == (3, 3, 3) and frame["objfaces"].shape == (3, 2000, 3)
         assert frame["handverts3d"].shape == (3, 778, 3) and frame["joints3d"].shape == (3, 21, 3)
+
+
+def test_default_color_fn_blurs_jitters_and_shares_parameters():
+    """datasets/coloraugm.py (handobjset.py:339-358): the first frame of a sequence draws the colour parameters, the others get
+    the SAME ones; the blur radius is drawn per frame from torch's generator; the jitter's draws are Python's ``random``."""
+    import random
+
+    from PIL import Image, ImageFilter
+
+    from handobjectconsist_amd.datasets import coloraugm
+
+    ds, hs = _dataset(sample_nb=2, spacing=1, block_rot=True)
+    assert hs.color_fn is not None, "train mode applies the reference's colour augmentation by default"
+    frame = np.ascontiguousarray(ds.get_image(0))
+    random.seed(3)
+    out, params = hs.color_fn(frame, hs, None, 0.7)
+    assert out.shape == frame.shape and out.dtype == np.uint8 and not np.array_equal(out, frame)
+    assert set(params) == {"sat", "bright", "contrast", "hue"}
+    assert 1 - hs.brightness <= params["bright"] <= 1 + hs.brightness and abs(params["hue"]) <= hs.hue
+    # handed-over parameters are used as they are (second frame of a sequence): no draw, same parameters back
+    state = random.getstate()
+    out2, params2 = hs.color_fn(frame, hs, params, 0.7)
+    assert params2 == params
+    # (the only draw left is the shuffle of the four operations)
+    random.setstate(state)
+    random.shuffle([0, 1, 2, 3])
+    after_shuffle = random.getstate()
+    random.setstate(state)
+    hs.color_fn(frame, hs, params, 0.7)
+    assert random.getstate() == after_shuffle
+    # jitter off = the fixtures' generator stub: PIL's blur alone, neutral parameters
+    plain, neutral = coloraugm.make_color_fn(jitter=False)(frame, hs, None, 0.7)
+    assert np.array_equal(plain, np.asarray(Image.fromarray(frame).filter(ImageFilter.GaussianBlur(0.7))))
+    assert neutral == {"sat": 1.0, "bright": 1.0, "contrast": 1.0, "hue": 0.0}
+    # neutral factors leave the image alone up to the HSV round trip of the hue step; None switches a step off
+    img = Image.fromarray(frame)
+    assert np.array_equal(np.asarray(coloraugm.apply_jitter(img, brightness=1.0, contrast=1.0, saturation=1.0)), frame)
+    assert np.array_equal(np.asarray(coloraugm.apply_jitter(img)), frame)
+    # the hue shift is cyclic: +0.5 and -0.5 of a turn meet (int(127.5) = 127 steps either way: 254 = -2 mod 256)
+    up, down = np.asarray(coloraugm.adjust_hue(img, 0.5), np.int32), np.asarray(coloraugm.adjust_hue(img, -0.5), np.int32)
+    assert np.abs(up - down).max() <= 16  # (two hue steps of 256 apart, on saturated pixels)
+    with pytest.raises(ValueError):
+        coloraugm.adjust_hue(img, 0.6)
+    # a whole sequence through the dataset: torch's stream is the only one that places the crop
+    torch.manual_seed(0)
+    a = hs[2]
+    random.seed(11)
+    torch.manual_seed(0)
+    b = hs[2]
+    assert np.array_equal(a[0]["affinetrans"], b[0]["affinetrans"]) and np.array_equal(a[1]["affinetrans"], b[1]["affinetrans"])
