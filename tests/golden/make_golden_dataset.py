@@ -17,8 +17,11 @@ What is stubbed (source NOT under /root/reference, packages absent from the imag
                                       UNPINNED); transform_img -> the REAL Pillow ``Image.transform(res, AFFINE, rows of
                                       the inverse)`` (Pillow is installed)
     libyana.transformutils.colortrans get_color_params -> fixed neutral parameters, apply_jitter -> identity (the colour
-                                      jitter is a host-side callable outside this build's scope; ASSUMED not to draw
-                                      from torch's RNG)
+                                      jitter is libyana's: the package restates it in datasets/coloraugm.py, unpinned;
+                                      ASSUMED not to draw from torch's RNG)
+The Gaussian blur in front of the jitter (:340-341) is the reference's own call on the REAL Pillow: the configurations run
+with ``blur_radius`` 0 except ``train_pair_blur`` (2.0), which pins the package's default ``color_fn`` blur (on the mirrored
+frame, a radius per frame from torch's generator).
     torchvision.transforms.functional to_tensor (uint8 HWC -> float CHW / 255), normalize ((x - mean) / std)
     torch._six                        container_abcs, string_classes, int_classes
 """
