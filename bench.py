@@ -57,10 +57,15 @@ def parse():
                    help="f32 = the reference's precision (headline); bf16 = BASELINE config 5: trunk under bf16 "
                         "autocast, heads / MANO / render / warp stay fp32 -- reported with dtype 'bf16+f32'")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--details-out", default=None, metavar="PATH",
+                   help="where the FULL record goes (every kernel group, warp_tiles, in-step durations, notes): a JSON file, "
+                        "default bench_details.json in the working directory; '-' = nowhere.  stdout carries the compact "
+                        "contract line only (<= 4 KB)")
     p.add_argument("--no-kernel-bench", action="store_true")
     p.add_argument("--no-stock-trunk", action="store_true", help="skip the run with the stock trunk modules (the north-star-conformant figure)")
     p.add_argument("--stock-trunk-nchw", action="store_true", help="also time the stock modules in NCHW without solver search (rounds 1-4's leg)")
-    p.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample")
+    p.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample (at least)")
+    p.add_argument("--cpu-sweep", action="store_true", help="cpu_baseline also at 16 ... 256 worker processes (details file)")
     p.add_argument("--kernel-iters", type=int, default=50)
     p.add_argument("--kernels-only", action="store_true", help="only the per-kernel benchmark (profiling aid)")
     p.add_argument("--hot-only", action="store_true", help="only the render+warp hot path fwd+bwd (profiling aid)")
@@ -70,10 +75,7 @@ def parse():
     p.add_argument("--step-only", action="store_true",
                    help="only the timed training steps (no hot-path / stock-trunk / kernel / CPU legs): what the in-run "
                         "rocprofv3 --kernel-trace pass behind roofline.frac_in_step profiles")
-    p.add_argument("--eager-step", action="store_true", help="(the default since the end of round 5; kept for old command lines)")
-    p.add_argument("--graph-step", action="store_true",
-                   help="EXPERIMENTAL, timing only: replay the captured train_step (one hipGraph launch per step) instead of issuing "
-                        "its launches from the host (see the note at graph_step in main)")
+    p.add_argument("--eager-step", action="store_true", help="(the only mode; kept for old command lines)")
     p.add_argument("--reducer-ab", type=int, default=0, metavar="PAIRS",
                    help="A/B inside ONE process (one model, one set of MIOpen / TunableOp solver choices): PAIRS x "
                         "(--steps plain steps, then --steps steps through the RCCL process group + bucketed gradient "
@@ -521,59 +523,47 @@ def kernel_bench(dev, B, is_, iters, only=None):
 
 
 def cpu_baseline(B_sample, is_, B_full, threads=None):
-    """The CPU oracle (oracle/, a port -- the reference has no CPU render path) on a
-    bounded sample of the hot path: 2 renders + flow masks + occlusion + pair loss forward, and
-    the texture / flow backward; extrapolated linearly in the batch size (images are independent).
-    BOTH halves use the stated threads (round 5): the sample is cut into per-image tasks run by a thread pool (numpy and
-    the ctypes calls release the GIL); inside a task the rasteriser (kernels A, B, C, E: C + OpenMP over rows) gets
-    threads // tasks OpenMP threads, the warp / occlusion / pair-loss half (oracle/warp_ref.py) is numpy on the task's
-    thread.  `cores` = tasks x OpenMP threads per task, the threads that actually work."""
-    from concurrent.futures import ThreadPoolExecutor
-
-    from handobjectconsist_amd.utils import synth
-    from oracle import raster_ref as R
-    from oracle import warp_ref as W
+    """The CPU oracle (oracle/, a port -- the reference has no CPU render path) on a bounded sample of the hot
+    path: 2 renders + flow masks + occlusion + pair loss forward, and the texture / flow backward; extrapolated linearly in
+    the batch size (images are independent).  One worker PROCESS per image (oracle/cpu_hot_path.py; round 5's thread pool
+    serialised on the GIL: 256 threads bought 1.06 x over 8): `threads` processes of one image each while the sample allows
+    (`B_sample` caps it; beyond that the rasteriser's OpenMP threads take the rest), all started and set up before a
+    common "go", timed until the last one is done.  `cores` = processes x OpenMP threads per process."""
+    import subprocess
 
     threads = threads or os.cpu_count() or 1
     n_tasks = max(1, min(B_sample, threads))
     omp = max(1, threads // n_tasks)
-    s = synth.random_scene(B_sample, seed=0, image_size=is_)
-    im_ref, im, jm_ref, jm = synth.random_images(B_sample, is_, is_, 0)
-    R.lib()
-    bounds = [B_sample * i // n_tasks for i in range(n_tasks + 1)]
-
-    def task(i):
-        sl = slice(bounds[i], bounds[i + 1])
-        kw = dict(R=np.eye(3, dtype=np.float32)[None], t=np.zeros((1, 3), np.float32),
-                  dist_coeffs=np.zeros((1, 5), np.float32), orig_size=is_, image_size=is_, anti_aliasing=False,
-                  near=0.1, far=100, eps=1e-3, num_threads=omp, keep_saved=True)
-        flows, renders = W.get_opticalflow(R, [s["verts1"][sl], s["verts2"][sl]], s["faces"][sl], [s["K1"][sl], s["K2"][sl]], kw,
-                                           orig_img_size=(is_, is_), ignore_face_idxs=synth.HAND_IGNORE_FACES,
-                                           return_renders=True)
-        W.pair_consist(flows, im_ref[sl], im[sl], jm_ref[sl], jm[sl], True)
-        gl = np.full((bounds[i + 1] - bounds[i],), 1.0 / B_sample, np.float32)
-        gflows = W.pair_consist_grad(flows, im_ref[sl], im[sl], jm_ref[sl], jm[sl], gl, True)
-        # texture backward of the two renders (kernel E; training mode = detach_renders)
-        for ro, g in zip(renders, gflows):
-            sv = ro["_saved"]
-            g_rgb = np.zeros_like(sv["rgb_map"])
-            g_rgb[..., :2] = g[:, ::-1]
-            R.backward_textures(sv["face_index_map"], sv["sampling_weight_map"], sv["sampling_index_map"], g_rgb,
-                                sv["faces"].shape[1], 2)
-
-    t0 = time.perf_counter()
-    if n_tasks == 1:
-        task(0)
-    else:
-        with ThreadPoolExecutor(max_workers=n_tasks) as pool:
-            list(pool.map(task, range(n_tasks)))
-    dt = time.perf_counter() - t0
+    counts = [B_sample * (i + 1) // n_tasks - B_sample * i // n_tasks for i in range(n_tasks)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(omp), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_hot_path", "--seed", str(i), "--count", str(c), "--size", str(is_),
+                               "--omp", str(omp)], cwd=ROOT, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+             for i, c in enumerate(counts)]
+    try:
+        for p_ in procs:
+            if p_.stdout.readline().strip() != "ready":
+                raise RuntimeError("cpu_baseline: a worker process did not come up (oracle/cpu_hot_path.py)")
+        t0 = time.perf_counter()
+        for p_ in procs:
+            p_.stdin.write("go\n")
+            p_.stdin.flush()
+        own = []
+        for p_ in procs:
+            word = p_.stdout.readline().split()
+            if len(word) != 2 or word[0] != "done":
+                raise RuntimeError("cpu_baseline: a worker process failed (oracle/cpu_hot_path.py)")
+            own.append(float(word[1]))
+        dt = time.perf_counter() - t0
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+            p_.wait()
     sec_per_iter = dt * (B_full / B_sample)
     return {"value": round(1.0 / sec_per_iter, 6), "unit": "iters/s", "cores": n_tasks * omp, "kind": "port",
-            "sample": f"hot path only (2 renders fwd, flow masks, occlusion, pair loss fwd+bwd, texture bwd; encoder "
-                      f"and optimiser excluded), B={B_sample} of {B_full} at {is_}x{is_}, {dt:.1f} s measured, "
-                      f"extrapolated x{B_full / B_sample:g}; {n_tasks} per-image tasks on a thread pool x {omp} OpenMP threads in "
-                      f"the C rasteriser; warp / occlusion / pair loss = numpy inside the tasks"}
+            "processes": n_tasks, "omp_threads_per_process": omp, "seconds_per_image_in_a_worker": round(sum(own) / len(own) / max(counts), 3),
+            "sample": f"hot path only (2 renders, masks, occlusion, pair loss fwd+bwd, texture bwd; no encoder), {B_sample} images "
+                      f"(B={B_full}) at {is_}x{is_}, {dt:.1f} s, x{B_full / B_sample:g}; {n_tasks} processes x {omp} OpenMP threads"}
 
 
 def pmc_traffic_in_run(args, timeout=420):
@@ -703,6 +693,77 @@ def roofline_block(name, k, pmc, units, in_step=None):
     return roof
 
 
+CONTRACT_LINE_MAX = 4096  # bytes: the driver's record keeps the tail of stdout and parses its LAST line (round 5's 21 KB line was lost)
+
+
+def _pick(d, keys):
+    return None if d is None else {k: d.get(k) for k in keys if k in d}
+
+
+def _short(text, n=200):
+    text = str(text)
+    return text if len(text) <= n else text[: n - 3] + "..."
+
+
+def contract_line(full):
+    """The ONE line stdout carries: the bench contract's fields + the `roofline` and `cpu_baseline` objects with the figures
+    a reader needs, no prose beyond <= 200-character strings, <= CONTRACT_LINE_MAX bytes whatever the run produced
+    (optional keys are dropped from the back until it fits).  Everything else -- every kernel group, the warp passes, the
+    in-step durations, notes -- is the details file (`--details-out`)."""
+    roof, fwd, kernels, cpu = full.get("roofline"), full.get("roofline_forward"), full.get("kernels") or {}, full.get("cpu_baseline")
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data", "config", "headline", "step_mode", "hot_path_ms")}
+    line["unit"] = _short(line["unit"])
+    line["step_mode"] = _short(line["step_mode"], 80)
+    line["config"] = dict(line["config"], workload=_short(line["config"]["workload"], 260))
+    r = None
+    if roof is not None:
+        r = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_cache_warm", "frac_in_step", "in_step_us",
+                         "bytes", "traffic", "traffic_low", "dram_frac", "algorithmic_bytes", "frac_algorithmic", "launch_ms",
+                         "launch_ms_cache_warm", "device_kernels"))
+        r["kernel"] = _short(r["kernel"], 120)
+        r["forward"] = _pick(fwd, ("frac", "frac_cache_warm", "frac_in_step", "launch_ms", "launch_ms_cache_warm", "in_step_us",
+                                   "bytes", "traffic", "device_kernels"))
+        full_k = kernels.get("render_backward_full(D+E+F)")
+        if full_k is not None:
+            r["d_e_f"] = {"ms": full_k["ms"], "ms_cache_warm": full_k["ms_cache_warm"], "frac": full_k["frac_hbm_peak"],
+                          "bytes": full_k["algorithmic_bytes"]}
+            for k in ("frac_of_algorithmic_issue", "algorithmic_issue_ms", "terms"):
+                if k in full_k:
+                    r["d_e_f"][k] = full_k[k]
+        fused = (full.get("warp_tiles") or {}).get(FUSED_FWD)
+        if fused is not None:
+            r["fused_warp_forward"] = _pick(fused, ("frac", "frac_cache_warm", "frac_in_step", "launch_ms", "in_step_us", "bytes"))
+        for k in ("hot_path_device_ms", "hot_path_eager_ms_host_bound", "stock_trunk_it_s"):
+            r[k] = roof.get(k)
+    line["roofline"] = r
+    c = None
+    if cpu is not None:
+        c = _pick(cpu, ("value", "unit", "cores", "kind", "sample"))
+        c["sample"] = _short(c["sample"])
+        if "at_8_threads" in cpu:
+            c["at_8_threads"] = {"value": cpu["at_8_threads"]["value"]}
+    line["cpu_baseline"] = c
+    ranks = full.get("ranks")
+    if ranks is not None:
+        line["ranks"] = {"backend": ranks["backend"], "world_size": ranks["world_size"], "reducer": _short(ranks["reducer"], 100),
+                         "grad_allreduce_MB": ranks["grad_allreduce_MB"], "bucket_MB": ranks["bucket_MB"],
+                         "ms_per_step_by_rank": [r_["ms_per_step"] for r_ in sorted(ranks["per_rank"], key=lambda r_: r_["rank"])],
+                         "device_by_rank": [r_["device"] for r_ in sorted(ranks["per_rank"], key=lambda r_: r_["rank"])]}
+    line["details"] = full.get("details")
+    # never more than the driver reads: shed optional keys, least important first
+    shed = [("roofline", "fused_warp_forward"), ("roofline", "device_kernels"), ("ranks", "device_by_rank"), ("details",),
+            ("roofline", "forward", "device_kernels"), ("step_mode",), ("ranks", "reducer"), ("roofline", "d_e_f"), ("ranks",)]
+    while len(json.dumps(line)) > CONTRACT_LINE_MAX and shed:
+        path = shed.pop(0)
+        d = line
+        for k in path[:-1]:
+            d = d.get(k) if isinstance(d, dict) else None
+        if isinstance(d, dict):
+            d.pop(path[-1], None)
+    return line
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` started as a PLAIN script (no RANK / WORLD_SIZE in the environment) with N > 1:
     become the launcher -- re-execute this very command line under ``python -m torch.distributed.run --nnodes=1
@@ -830,16 +891,10 @@ def main():
     # trainmeshwarp.py's optimiser (Adam, lr 5e-5).  fused=True is stock PyTorch's single-pass kernel for the
     # same update (A/B on one MI355X: 46.05 -> 45.10 ms per step); HOC_FUSED_ADAM=0 selects the foreach default
     params = [p for p in model.parameters() if p.requires_grad]
-    # --graph-step: one step = ONE hipGraph launch (netscripts/epochpassconsist.GraphedTrainStep: train_step captured per
-    # device-resident batch set and replayed).  EXPERIMENTAL, for timing only, never the default: a replayed step now and then
-    # comes back with garbage in the weight gradients of the trunk's convolutions (2e5 x the gradient's norm in conv1 / layer1,
-    # losses unchanged; scripts/r5_graph_grad_debug2.py, tests of round 5) -- eager steps never.  Measured
-    # (profiles/r05_graph_vs_eager.txt): with the same (searched) solvers the metric config gains 0.4 % from the replay
-    # (device-bound), config 3 (B = 8) 6 %.
+    # The step is issued eagerly.  (A hipGraph replay of the whole step was built in round 5, found to return garbage convolution
+    # weight gradients now and then, and lives in scripts/graph_step_experiment.py since round 6 -- not in the product.)
     fused_adam = os.environ.get("HOC_FUSED_ADAM", "1") == "1"
-    graph_step = (args.graph_step and not args.eager_step and not use_dist and fused_adam and not args.hot_only
-                  and args.encoder_dtype == "f32")
-    optimizer = torch.optim.Adam(params, lr=5e-5, fused=fused_adam, capturable=graph_step)
+    optimizer = torch.optim.Adam(params, lr=5e-5, fused=fused_adam)
     loader = SyntheticConsistLoader(B, is_, seed=rank, device=dev, pool=2, image_height=ih_)
 
     def barrier():
@@ -884,17 +939,12 @@ def main():
         dist.destroy_process_group()
         return
     _phase("model built; warm-up steps")
-    from handobjectconsist_amd.netscripts.epochpassconsist import GraphedTrainStep
 
     def make_step(pre, opt):
-        if not graph_step:
-            return lambda batches: train_step(batches, pre, opt, check_nan=check_nan, reducer=reducer)
-        return GraphedTrainStep(pre, opt, check_nan=check_nan, experimental=True)
+        return lambda batches: train_step(batches, pre, opt, check_nan=check_nan, reducer=reducer)
 
     step_fn = make_step(premodel, optimizer)
-    # (graph replay: a batch set's first call runs eagerly, its second captures -- both untimed; when the W warm-up steps asked
-    # for do not cover them, the missing ones run in front as set-up and the line says so in `graph_setup_steps`)
-    n_warm = max(args.warmup, 2 * len(loader.batches)) if graph_step else args.warmup
+    n_warm = args.warmup
     for i in range(0 if args.hot_only else n_warm):
         step_fn(loader.step_batches(i))
     torch.cuda.synchronize()
@@ -902,29 +952,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = torch.zeros(1)
-    graph_fell_back = None
-    i = 0
-    while i < (0 if args.hot_only else args.steps):
-        try:
-            loss, _ = step_fn(loader.step_batches(n_warm + i))
-            i += 1
-        except ValueError as exc:
-            if not graph_step or graph_fell_back is not None:
-                raise
-            # A replayed step flagged a NaN loss (its update was skipped on the device: the parameters are what they were).
-            # Say which entries of the capture's logs are not finite, then do the measurement over with eager steps: the
-            # line reports that in `step_mode`.  (Seen with the trunk under bf16 autocast only, which no longer replays.)
-            for key, ent in step_fn._entries.items():
-                logs = ent.get("logs") or {}
-                bad = {k: float(v) for k, v in logs.items() if torch.is_tensor(v) and v.numel() == 1 and not bool(torch.isfinite(v).all())}
-                sys.stderr.write(f"[bench] timed step {i}: batch set {key}: loss {float(ent['loss']) if ent.get('loss') is not None else None}, non-finite log entries {bad}\n")
-            graph_fell_back = f"eager launches (a graph-replayed run flagged a NaN loss at timed step {i}: {exc}; measured again eagerly)"
-            step_fn = lambda batches: train_step(batches, premodel, optimizer, check_nan=check_nan, reducer=reducer)  # noqa: E731
-            for w in range(max(args.warmup, 2)):
-                step_fn(loader.step_batches(w))
-            torch.cuda.synchronize()
-            i = 0
-            t0 = time.perf_counter()
+    for i in range(0 if args.hot_only else args.steps):
+        loss, _ = step_fn(loader.step_batches(n_warm + i))
     if check_nan:
         raise_pending_nan(optimizer)  # the last step's device-side NaN flag (train_step's contract), inside the timed region
     torch.cuda.synchronize()
@@ -1030,8 +1059,7 @@ def main():
                                    progressive_steps=1000, use_backward=True, mano_faces=model_s.mano_layer.th_faces,
                                    pair_outputs="loss").to(dev)
                 pre_s.step_count = 1000
-                opt_s = torch.optim.Adam([p for p in model_s.parameters() if p.requires_grad], lr=5e-5, fused=fused_adam,
-                                         capturable=graph_step)
+                opt_s = torch.optim.Adam([p for p in model_s.parameters() if p.requires_grad], lr=5e-5, fused=fused_adam)
                 step_s = make_step(pre_s, opt_s)
                 for i in range(max(n_warm, 2)):
                     step_s(loader.step_batches(i))
@@ -1106,10 +1134,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _phase("CPU baseline")
         ncpu = os.cpu_count() or 1
-        cpu = cpu_baseline(min(B, max(args.cpu_sample, min(ncpu, 64))), is_, B)  # (a task per image: enough images for the cores)
-        if (os.cpu_count() or 1) > 8:  # the figure that lines up with BASELINE.md's 8-thread reference measurement
-            c8 = cpu_baseline(max(args.cpu_sample // 4, 2), is_, B, threads=8)
+        # one image per process while the box has hardware threads for them: the sample grows with the box (at most 4 batches'
+        # worth -- ~2 s of work per image), so that the stated cores all work; --cpu-sample bounds it from below
+        n_img = max(args.cpu_sample if B >= args.cpu_sample else B, min(ncpu, 4 * B))
+        cpu = cpu_baseline(n_img, is_, B)
+        if ncpu > 8:  # the figure that lines up with BASELINE.md's 8-thread reference measurement
+            c8 = cpu_baseline(8 if B >= 8 else B, is_, B, threads=8)
             cpu["at_8_threads"] = {"value": c8["value"], "sample": c8["sample"]}
+        if args.cpu_sweep:  # where the figure stops improving (profiles/: the knee the stated core count rests on)
+            cpu["sweep"] = []
+            for t_ in (16, 32, 64, 128, 256):
+                if t_ < ncpu:
+                    c_ = cpu_baseline(min(t_, 4 * B), is_, B, threads=t_)
+                    cpu["sweep"].append({"threads": t_, "value": c_["value"], "s_per_image": c_["seconds_per_image_in_a_worker"]})
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -1117,14 +1154,11 @@ def main():
             "metric": f"trainmeshwarp iters/sec (render+warp, B={B}, {is_}x{ih_})",
             "headline": bool(B == 64 and is_ == 256 and ih_ == 256 and args.encoder_dtype == "f32"),  # BASELINE.json's metric config
             "value": round(world * args.steps / dt, 4),
-            "unit": "iters/s (each: 1 data batch + 1 consist batch of B per GPU, one optimizer step; the figure with the encoder "
-                    "entirely on stock PyTorch-ROCm modules, as the north star words it, is stock_trunk.value = roofline.stock_trunk_it_s "
-                    "(same layout / solver search / TunableOp as `value`: the ONLY difference is that `value` substitutes this build's "
-                    "fused BatchNorm/ReLU/residual/max-pool kernels between the stock convolutions); render + warp itself is "
-                    "roofline.hot_path_device_ms of the step)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "graph_setup_steps": n_warm - args.warmup,
+            "unit": "iters/s (one optimiser step = 1 data batch + 1 consist batch of B per GPU; roofline.stock_trunk_it_s = the same "
+                    "step with the trunk's BatchNorm/ReLU/max-pool on the stock nn modules)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3),
-            "step_mode": graph_fell_back or ("EXPERIMENTAL hipGraph replay of the captured train_step (one launch per step; replays are known to return garbage convolution weight gradients now and then: timing only)" if graph_step else "eager launches"),
+            "step_mode": "eager launches",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder + f32 render/warp (BASELINE config 5, not the headline)",
             "data": "synthetic",
@@ -1144,8 +1178,16 @@ def main():
             "ranks": ranks, "stock_trunk": stock, "stock_trunk_nchw": stock_nchw, "roofline": roof, "roofline_forward": roof_fwd, "warp_tiles": warp_tiles,
             "in_step_kernels_us": in_step_line, "kernels": kernels, "cpu_baseline": cpu,
         }
+        details = args.details_out or "bench_details.json"
+        if details != "-":
+            try:
+                with open(details, "w") as fh:
+                    fh.write(json.dumps(line, indent=1) + "\n")
+                line["details"] = details
+            except OSError as e:  # (a read-only working directory must not cost the run its line)
+                sys.stderr.write(f"[bench] could not write {details}: {e}\n")
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        os.write(real_stdout, (json.dumps(contract_line(line)) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

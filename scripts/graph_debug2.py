@@ -3,6 +3,10 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import faulthandler; faulthandler.enable()
 import torch
+
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from graph_step_experiment import GraphedTrainStep  # noqa: E402  (experiment, not product: see that file)
 from handobjectconsist_amd.models.synthnet import SynthMeshRegNet
 from handobjectconsist_amd.models.warpreg import WarpRegNet
 from handobjectconsist_amd.netscripts import epochpassconsist as E
@@ -25,7 +29,7 @@ def build(capturable):
 if two:
     me, pe, oe, le = build(False)
 mg, pg, og, lg = build(True)
-step = E.GraphedTrainStep(pg, og, experimental=True)
+step = GraphedTrainStep(pg, og, experimental=True)
 for i in range(6):
     if two:
         E.train_step(le.step_batches(i), pe, oe)

@@ -10,6 +10,10 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from graph_step_experiment import GraphedTrainStep  # noqa: E402  (experiment, not product: see that file)
+
 from handobjectconsist_amd.models.synthnet import SynthMeshRegNet
 from handobjectconsist_amd.models.warpreg import WarpRegNet
 from handobjectconsist_amd.netscripts import epochpassconsist as E
@@ -89,7 +93,7 @@ for name, spans in r[3].items():
 # the same step as ONE graph launch
 pre.forward = real_forward
 torch.Tensor.backward = real_backward
-step = E.GraphedTrainStep(pre, opt, experimental=True, allow_autocast=True)  # (bf16: measured here, not used by bench.py -- see its note)
+step = GraphedTrainStep(pre, opt, experimental=True, allow_autocast=True)  # (bf16: measured here, not used by bench.py -- see its note)
 for i in range(6):
     step(loader.step_batches(i))
 torch.cuda.synchronize()

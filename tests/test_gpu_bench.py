@@ -24,15 +24,19 @@ def _keep(name, line):
 
 
 def _json_line(out):
+    """stdout of bench.py: ONE line, the compact contract line -- and it is the last line, at most 4 KB (what the driver's
+    record keeps and parses; round 5's 21 KB line was lost there)."""
     lines = [l for l in out.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
+    assert out.strip().splitlines()[-1] == lines[0] and len(lines[0].encode()) <= 4096, len(lines[0])
     return json.loads(lines[0])
 
 
 @pytest.mark.gpu
-def test_bench_single_process_line(cuda):
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, capture_output=True,
-                         text=True, timeout=600, cwd=ROOT)
+def test_bench_single_process_line(cuda, tmp_path):
+    details = str(tmp_path / "details.json")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--details-out", details] + SMALL,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _json_line(res.stdout)
     for k in CONTRACT:
@@ -40,32 +44,43 @@ def test_bench_single_process_line(cuda):
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
     assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
     assert "workload" in line["config"] and line["data"] == "synthetic" and line["dtype"] == "f32"
+    assert len(line["unit"]) <= 200 and line["details"] == details
+    # --- the compact line: the figures the driver's record has to hold
     roof, cpu = line["roofline"], line["cpu_baseline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert abs(roof["achieved"] - roof["bytes"] / (roof["launch_ms"] * 1e-3) / 1e9) <= 0.02 * roof["achieved"]
-    # the raster backward as the step launches it: the scatter of the unit gradient the step's forward launch left
-    assert roof["device_kernels"] == ["unit_scatter_tiles_kernel"] and 0 < roof["frac_cache_warm"]
-    assert roof["recomputing_form"]["device_kernels"] == ["pair_scatter_tiles_kernel"] and 0 < roof["recomputing_form"]["frac"] < 1
-    assert roof["scatter_alone"]["device_kernels"] == ["scatter_tiles_kernel<true, true>"] and 0 < roof["scatter_alone"]["frac"] < 1
-    assert roof["in_step_us"] > 0 and abs(roof["frac_in_step"] - roof["bytes"] / (roof["in_step_us"] * 1e-6) / 1e9 / roof["peak"]) < 1e-3
-    for name, w in line["warp_tiles"].items():
-        assert 0 < w["frac"] < 1 and w["launch_ms"] > 0, name
-    assert line["warp_tiles"]["flow_pair_forward_grad_tiles(train: occlusion + epilogue + pair loss + unit gradient, sparse)"]["in_step_us"] > 0
-    # the backward's fraction is on its own compulsory traffic (covered tiles), below 1 by construction; the SURVEY 8(d)
-    # figure rides along
     assert 0 < roof["frac"] < 1 and roof["bytes"] < roof["algorithmic_bytes"] and roof["frac_algorithmic"] > roof["frac"]
-    fwd = line["roofline_forward"]
+    assert 0 < roof["frac_cache_warm"] and roof["in_step_us"] > 0
+    assert abs(roof["frac_in_step"] - roof["bytes"] / (roof["in_step_us"] * 1e-6) / 1e9 / roof["peak"]) < 1e-3
+    assert roof["traffic"] is not None and roof["traffic"] >= roof["traffic_low"] > 0, "in-run PMC passes failed on the GPU box"
+    assert roof["forward"]["frac"] > 0 and roof["forward"]["launch_ms"] > 0 and roof["forward"]["in_step_us"] > 0
+    assert roof["d_e_f"]["ms"] > 0 and 0 < roof["d_e_f"]["frac"] < 1
+    assert 0 < roof["d_e_f"]["frac_of_algorithmic_issue"] < 1 and roof["d_e_f"]["terms"] > 0
+    assert roof["hot_path_device_ms"] > 0 and roof["hot_path_eager_ms_host_bound"] > 0 and roof["stock_trunk_it_s"] > 0
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"] and len(cpu["sample"]) <= 200
+    # --- the details file: everything else
+    with open(details) as fh:
+        full = json.load(fh)
+    assert full["value"] == line["value"] and full["ms_per_step"] == line["ms_per_step"]
+    froof = full["roofline"]
+    # the raster backward as the step launches it: the scatter of the unit gradient the step's forward launch left
+    assert froof["device_kernels"] == ["unit_scatter_tiles_kernel"] and froof["frac"] == roof["frac"]
+    assert froof["recomputing_form"]["device_kernels"] == ["pair_scatter_tiles_kernel"] and 0 < froof["recomputing_form"]["frac"] < 1
+    assert froof["scatter_alone"]["device_kernels"] == ["scatter_tiles_kernel<true, true>"] and 0 < froof["scatter_alone"]["frac"] < 1
+    for name, w in full["warp_tiles"].items():
+        assert 0 < w["frac"] < 1 and w["launch_ms"] > 0, name
+    assert full["warp_tiles"]["flow_pair_forward_grad_tiles(train: occlusion + epilogue + pair loss + unit gradient, sparse)"]["in_step_us"] > 0
+    fwd = full["roofline_forward"]
     assert fwd["bound"] == "hbm" and "raster_tile_kernel<true, true>" in fwd["device_kernels"] and fwd["launch_ms"] > 0
     assert fwd["bytes"] == fwd["algorithmic_bytes"]
-    for r in (roof, fwd):  # HBM bytes from the PMC passes this very run made (None only if rocprofv3 is unavailable)
+    for r in (froof, fwd):  # HBM bytes from the PMC passes this very run made (None only if rocprofv3 is unavailable)
         if r["traffic"] is not None:
             assert r["traffic"] >= r["traffic_low"] > 0 and r["dram_frac"] > 0
             assert abs(r["dram_frac"] - r["traffic"] / (r["launch_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-3
-    assert roof["traffic"] is not None, "in-run PMC passes failed on the GPU box"
-    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
-    # the informational run of the same step with the stock trunk modules
-    assert line["stock_trunk"]["value"] > 0 and line["stock_trunk"]["ms_per_step"] > 0
+    assert full["cpu_baseline"]["processes"] >= 1
+    # the run of the same step with the stock trunk modules
+    assert full["stock_trunk"]["value"] > 0 and full["stock_trunk"]["ms_per_step"] > 0
 
 
 @pytest.mark.gpu
@@ -97,7 +112,7 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(cuda):
     line = _json_line(res.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["parallelism"] == "dp2"
     assert line["config"]["global_batch"] == 8 and line["cpu_baseline"] is None
-    assert line["ranks"]["world_size"] == 2 and len(line["ranks"]["per_rank"]) == 2
+    assert line["ranks"]["world_size"] == 2 and len(line["ranks"]["ms_per_step_by_rank"]) == 2
 
 
 @pytest.mark.gpu
@@ -115,7 +130,7 @@ def test_bench_gpus_2_as_a_plain_script_starts_its_own_ranks(cuda):
     for k in CONTRACT:
         assert k in line, k
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["parallelism"] == "dp2"
-    assert line["ranks"]["world_size"] == 2 and sorted(r["rank"] for r in line["ranks"]["per_rank"]) == [0, 1]
+    assert line["ranks"]["world_size"] == 2 and len(line["ranks"]["ms_per_step_by_rank"]) == 2
     assert "torch.distributed.run" in res.stderr  # the launcher line bench.py prints
     # without device sharing the same command must refuse with a message, not an assertion, on a one-GPU box
     import torch
@@ -147,9 +162,9 @@ def test_bench_gpus_8_as_a_plain_script(cuda):
         assert k in line, k
     assert line["n_gpus"] == 8 and line["value"] > 0 and line["config"]["parallelism"] == "dp8"
     assert line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
-    assert line["ranks"]["world_size"] == 8 and sorted(r["rank"] for r in line["ranks"]["per_rank"]) == list(range(8))
-    assert all(r["ms_per_step"] > 0 for r in line["ranks"]["per_rank"])
-    assert line["cpu_baseline"] is None and line["stock_trunk"] is None  # (N = 1 legs only)
+    assert line["ranks"]["world_size"] == 8 and len(line["ranks"]["ms_per_step_by_rank"]) == 8
+    assert all(ms > 0 for ms in line["ranks"]["ms_per_step_by_rank"])
+    assert line["cpu_baseline"] is None and line["roofline"] is None  # (N = 1 legs only; --no-kernel-bench)
     assert wall < 300, f"bench.py --gpus 8 took {wall:.0f} s"
 
 
@@ -188,8 +203,8 @@ def test_config4_per_gpu_workload_under_rccl_ddp(cuda):
     line = _json_line(res.stdout)
     assert line["config"]["global_batch"] == 32 and line["value"] > 0 and line["ms_per_step"] > 0
     ranks = line["ranks"]
-    assert ranks["backend"] == "rccl" and ranks["world_size"] == 1 and len(ranks["per_rank"]) == 1
-    assert ranks["per_rank"][0]["rank"] == 0 and ranks["per_rank"][0]["ms_per_step"] > 0
+    assert ranks["backend"] == "rccl" and ranks["world_size"] == 1 and len(ranks["ms_per_step_by_rank"]) == 1
+    assert ranks["ms_per_step_by_rank"][0] > 0 and ranks["device_by_rank"] == [0]
     assert 47.0 < ranks["grad_allreduce_MB"] < 49.0  # 11.98 M trainable fp32 parameters
 
 

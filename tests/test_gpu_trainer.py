@@ -278,3 +278,34 @@ def test_epoch_pass_accumulation_against_the_reference(cuda, fused_optimizer):
             train_step(batches[2 * step:2 * step + 2], pre, opt)
             assert norm_rel(n(model.w), want[step]) < 1e-4, (step, n(model.w), want[step])
     assert pre.step_count == int(z["ep_step_count_after"])
+
+
+def test_eager_step_follows_the_ramp_with_lambda_tensors(cuda):
+    """A premodel that carries the device-side lambda tensors (`refresh_lambda_tensors`: what a captured step reads its two
+    weights from -- scripts/graph_step_experiment.py) and is stepped eagerly must read the weights of ITS step: the eager
+    forward refreshes the tensor (warpreg.py:103-110's ramp, one value per step)."""
+    from handobjectconsist_amd.models.synthnet import SynthMeshRegNet
+    from handobjectconsist_amd.models.warpreg import WarpRegNet
+    from handobjectconsist_amd.netscripts.epochpassconsist import SyntheticConsistLoader, train_step
+
+    saved = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False  # (MIOpen's default solver choice for both twins)
+    try:
+        twins = []
+        for _ in range(2):
+            torch.manual_seed(7)
+            model = SynthMeshRegNet().to(cuda)
+            model.eval()
+            pre = WarpRegNet((64, 64), model, lambda_consist=0.001, lambda_data=0.999, criterion="l1", gt_refs=True,
+                             progressive_steps=6, use_backward=True, mano_faces=model.mano_layer.th_faces, pair_outputs="loss").to(cuda)
+            opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.0, fused=True)
+            twins.append((pre, opt, SyntheticConsistLoader(2, 64, seed=3, device=cuda, pool=2)))
+        (pre_a, opt_a, ld_a), (pre_b, opt_b, ld_b) = twins
+        pre_b.refresh_lambda_tensors()
+        for i in range(4):
+            la, _ = train_step(ld_a.step_batches(i), pre_a, opt_a)
+            lb, _ = train_step(ld_b.step_batches(i), pre_b, opt_b)
+            consist = 0.3  # (upper bound of the term at random init; its weight is at most 0.001 and it scatters by ~1e-3)
+            assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la)) + 0.001 * 1e-2 * consist, f"step {i}"
+    finally:
+        torch.backends.cudnn.benchmark = saved

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from handobjectconsist_amd.utils import synth
 from oracle import raster_ref as R
 
@@ -396,3 +398,72 @@ def test_bench_plain_script_with_gpus_n_becomes_a_launcher(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.self_launch(args)
     assert "needs a GPU" in str(e.value)
+
+
+def test_bench_contract_line_is_compact_whatever_the_run_produced():
+    """What bench.py prints on stdout is the contract line alone: <= 4096 bytes (round 5's 21 KB line was not parsed by the
+    driver), carrying roofline.frac and cpu_baseline.value, strings <= 200 characters -- on round 5's full record (the
+    committed details of that run) and on the same record inflated with prose, 8 ranks and 50 more kernel groups."""
+    import copy
+    import json
+
+    import bench
+
+    with open(os.path.join(ROOT, "profiles", "r05_bench_line.json")) as fh:
+        full = json.load(fh)
+    assert len(json.dumps(full)) > 20000
+    fat = copy.deepcopy(full)
+    fat["unit"] = fat["unit"] + " prose" * 400
+    fat["step_mode"] = "x" * 3000
+    fat["config"]["workload"] = fat["config"]["workload"] * 10
+    fat["cpu_baseline"]["sample"] = fat["cpu_baseline"]["sample"] * 10
+    fat["roofline"]["kernel"] = fat["roofline"]["kernel"] * 20
+    fat["roofline"]["device_kernels"] = ["k" * 60] * 30
+    fat["roofline_forward"]["device_kernels"] = ["k" * 60] * 30
+    fat["ranks"] = {"backend": "rccl", "world_size": 8, "reducer": "r" * 500, "grad_allreduce_MB": 47.9, "bucket_MB": 16,
+                    "per_rank": [{"rank": r, "device": r, "ms_per_step": 26.0 + r} for r in reversed(range(8))]}
+    for i in range(50):
+        fat["kernels"]["extra group %d" % i] = dict(next(iter(full["kernels"].values())))
+    for rec, name in ((full, "round 5"), (fat, "inflated")):
+        line = bench.contract_line(rec)
+        text = json.dumps(line)
+        assert len(text.encode()) <= bench.CONTRACT_LINE_MAX == 4096, (name, len(text))
+        back = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config"):
+            assert k in back, (name, k)
+        assert back["value"] == rec["value"] and back["ms_per_step"] == rec["ms_per_step"]
+        assert back["roofline"]["frac"] == rec["roofline"]["frac"] and back["roofline"]["bound"] == "hbm"
+        assert back["roofline"]["forward"]["frac"] == rec["roofline_forward"]["frac"]
+        assert back["roofline"]["traffic"] == rec["roofline"]["traffic"]
+        assert back["cpu_baseline"]["value"] == rec["cpu_baseline"]["value"] and back["cpu_baseline"]["cores"] == rec["cpu_baseline"]["cores"]
+        assert len(back["unit"]) <= 200 and len(back["cpu_baseline"]["sample"]) <= 200
+        assert "kernels" not in back and "warp_tiles" not in back and "in_step_kernels_us" not in back
+
+        def strings(o):
+            if isinstance(o, dict):
+                for v in o.values():
+                    yield from strings(v)
+            elif isinstance(o, list):
+                for v in o:
+                    yield from strings(v)
+            elif isinstance(o, str):
+                yield o
+        assert max(len(t) for t in strings(back)) <= 260, name
+    assert bench.contract_line(fat)["ranks"]["ms_per_step_by_rank"] == [26.0 + r for r in range(8)]
+    # legs that did not run (N > 1, --no-kernel-bench): nulls, not KeyErrors
+    bare = dict(full, roofline=None, roofline_forward=None, kernels=None, cpu_baseline=None, warp_tiles=None)
+    line = bench.contract_line(bare)
+    assert line["roofline"] is None and line["cpu_baseline"] is None and line["value"] == full["value"]
+
+
+def test_cpu_baseline_workers_are_processes_behind_a_common_start():
+    """bench.py's cpu_baseline: one worker process per image (oracle/cpu_hot_path.py), every one set up before the common
+    "go", the time taken until the last "done"; `cores` = processes x OpenMP threads, all of which work."""
+    import bench
+
+    c = bench.cpu_baseline(3, 32, 6, threads=2)  # 3 images on 2 processes (2 + 1), 32 x 32 rasters
+    assert c["processes"] == 2 and c["omp_threads_per_process"] == 1 and c["cores"] == 2 and c["kind"] == "port"
+    assert c["value"] > 0 and c["seconds_per_image_in_a_worker"] > 0 and len(c["sample"]) <= 200
+    c = bench.cpu_baseline(1, 32, 1, threads=4)  # fewer images than threads: the rasteriser's OpenMP threads take the rest
+    assert c["processes"] == 1 and c["omp_threads_per_process"] == 4 and c["cores"] == 4
