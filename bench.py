@@ -64,7 +64,7 @@ def parse():
     p.add_argument("--no-kernel-bench", action="store_true")
     p.add_argument("--no-stock-trunk", action="store_true", help="skip the run with the stock trunk modules (the north-star-conformant figure)")
     p.add_argument("--stock-trunk-nchw", action="store_true", help="also time the stock modules in NCHW without solver search (rounds 1-4's leg)")
-    p.add_argument("--cpu-sample", type=int, default=32, help="images in the CPU-baseline sample (at least)")
+    p.add_argument("--cpu-sample", type=int, default=32, help="(unused since round 6: the sample is one image per worker process)")
     p.add_argument("--cpu-sweep", action="store_true", help="cpu_baseline also at 16 ... 256 worker processes (details file)")
     p.add_argument("--kernel-iters", type=int, default=50)
     p.add_argument("--kernels-only", action="store_true", help="only the per-kernel benchmark (profiling aid)")
@@ -141,9 +141,7 @@ WARP_TILES_KERNELS = ("occlusion_flow_tiles_kernel", "pair_consist_forward_tiles
 
 
 ROOF_OPTIONAL = ()
-# vector wave-instructions of one D + E + F launch (pixel_map_strip_kernel 90.97 M + gather_kernel<true, true, true> 14.55 M), per
-# (B, image size) of the kernel bench's scene: rocprofv3 --pmc SQ_INSTS_VALU, profiles/r05_kernel_d_pmc.txt
-DEF_VALU_WAVE_INSTS = {(64, 256): (90.97e6 + 14.55e6, "profiles/r05_kernel_d_pmc.txt")}
+DEF_LANE_INSTS_PER_TERM = 10  # necessary lane-instructions per term of kernel D's walk (see kernel_bench)
 # the warp half over the render's tile list (round 4) and what one pixel of a covered tile makes each pass move
 WARP_TILES = ("occlusion_flow_tiles(train: occlusion + flow epilogue, sparse)", "pair_consist_forward_tiles(train, sparse)",
               "pair_consist_backward_tiles(train, sparse)", FUSED_FWD_PLAIN, FUSED_FWD)
@@ -485,15 +483,36 @@ def kernel_bench(dev, B, is_, iters, only=None):
                      "frac_hbm_peak_cache_warm": round(nbytes / (ms_warm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del flush
     full = "render_backward_full(D+E+F)"
-    if full in out and (B, is_) in DEF_VALU_WAVE_INSTS:
-        # D + E + F is bound by vector-instruction issue, not by HBM: the bound next to the HBM fraction.
-        # Wave-instruction counts per launch from the PMC pass committed under profiles/ (SQ_INSTS_VALU of the strip kernel +
-        # of the gather), 1024 SIMDs issuing one wave-instruction per 4 cycles at 2.4 GHz.
-        insts, src = DEF_VALU_WAVE_INSTS[(B, is_)]
-        bound_ms = insts * 4 / (1024 * 2.4e9) * 1e3
-        out[full].update({"valu_wave_insts": int(insts), "valu_wave_insts_source": src, "valu_bound_ms": round(bound_ms, 4),
-                          "frac_of_valu_bound": round(bound_ms / out[full]["ms"], 4),
-                          "frac_of_valu_bound_cache_warm": round(bound_ms / out[full]["ms_cache_warm"], 4)})
+    if full in out:
+        # D + E + F is bound by vector-instruction issue, not by HBM (DESIGN.md sections 11 / 12).  The bound is ALGORITHMIC: the
+        # number of terms of upstream's walk on this scene (counted by the strip kernel itself in one extra, untimed launch with
+        # the profiling switch flags >> 8 & 1024; include/meshraster_hip.h: mr_pixel_map_terms) x the lane-instructions a term
+        # cannot do without -- the difference-times-gradient sum over four channels 5, the distance 1, its reciprocal 3
+        # (v_rcp_f32 is a quarter-rate instruction), the accumulation 1 --
+        # on 1024 SIMDs that issue one wave-instruction (64 lanes) per 4 cycles at 2.4 GHz.  (Round 5 divided by the kernel's
+        # OWN measured SQ_INSTS_VALU: a kernel with twice the necessary instructions scored the same.)
+        import ctypes
+
+        word = ctypes.c_uint64(0)
+        lib.mr_pixel_map_terms(ctypes.byref(word), 1)
+        prev = os.environ.get("HOC_BWD_FLAGS")
+        os.environ["HOC_BWD_FLAGS"] = str(int(prev or "0") | (1024 << 8))
+        try:
+            render_bwd_full()
+        finally:
+            if prev is None:
+                del os.environ["HOC_BWD_FLAGS"]
+            else:
+                os.environ["HOC_BWD_FLAGS"] = prev
+        lib.mr_pixel_map_terms(ctypes.byref(word), 1)
+        terms = int(word.value)
+        if terms > 0:
+            issue_ms = terms * DEF_LANE_INSTS_PER_TERM / 64 * 4 / (1024 * 2.4e9) * 1e3
+            out[full].update({"terms": terms, "lane_insts_per_term": DEF_LANE_INSTS_PER_TERM,
+                              "lane_insts_per_term_are": "difference x gradient over 4 channels 5, distance 1, reciprocal 3, accumulate 1",
+                              "algorithmic_issue_ms": round(issue_ms, 4),
+                              "frac_of_algorithmic_issue": round(issue_ms / out[full]["ms"], 4),
+                              "frac_of_algorithmic_issue_cache_warm": round(issue_ms / out[full]["ms_cache_warm"], 4)})
     covered_words = int((ptile_hit.view(torch.int32) != 0).sum())
     for name, per_px, what in zip(WARP_TILES, WARP_TILES_BYTES, WARP_TILES_WHAT):
         if name in out:
@@ -562,8 +581,35 @@ def cpu_baseline(B_sample, is_, B_full, threads=None):
     sec_per_iter = dt * (B_full / B_sample)
     return {"value": round(1.0 / sec_per_iter, 6), "unit": "iters/s", "cores": n_tasks * omp, "kind": "port",
             "processes": n_tasks, "omp_threads_per_process": omp, "seconds_per_image_in_a_worker": round(sum(own) / len(own) / max(counts), 3),
-            "sample": f"hot path only (2 renders, masks, occlusion, pair loss fwd+bwd, texture bwd; no encoder), {B_sample} images "
-                      f"(B={B_full}) at {is_}x{is_}, {dt:.1f} s, x{B_full / B_sample:g}; {n_tasks} processes x {omp} OpenMP threads"}
+            "sample": f"render+warp hot path fwd+bwd (no encoder), {B_sample} images of B={B_full} at {is_}x{is_}, {dt:.1f} s x{B_full / B_sample:g}; "
+                      f"{n_tasks} processes x {omp} OpenMP threads"}
+
+
+def cpu_baseline_at_the_knee(is_, B_full, ncpu, sweep_all=False, gain=1.25, budget_s=60.0):
+    """`cpu_baseline` at 8, 16, 32, ... worker processes (one image each) up to the box's hardware threads, stopping at the first
+    doubling that buys less than `gain` (or when `budget_s` of CPU-leg wall time is spent): the figure reported is the BEST level's
+    and `cores` is that level's process count -- the count at which the figure stops improving, not `os.cpu_count()` (round 5's
+    GPU boxes report 256 hardware threads and give a container a fraction of them: 256 workers ran 33 x slower PER IMAGE than 8).
+    Every level measured rides along in `sweep`; `at_8_threads` lines up with BASELINE.md's 8-thread reference measurement."""
+    levels, t0 = [], time.perf_counter()
+    t_ = min(8, ncpu)
+    best = None
+    while True:
+        c_ = cpu_baseline(max(1, min(t_, 4 * B_full)), is_, B_full, threads=t_)
+        levels.append({"cores": c_["cores"], "value": c_["value"], "s_per_image": c_["seconds_per_image_in_a_worker"]})
+        improved = best is None or c_["value"] >= gain * best["value"]
+        if improved:  # (a level that buys less than `gain` over the best so far is past the knee: the best stays)
+            best = c_
+        if t_ >= ncpu or (not improved and not sweep_all) or time.perf_counter() - t0 > budget_s:
+            break
+        t_ = min(2 * t_, ncpu)
+    out = dict(best)
+    out["hardware_threads"] = ncpu
+    out["sweep"] = levels
+    out["sample"] += f"; cores = knee of sweep {[l['cores'] for l in levels]} ({ncpu} hw threads reported)"
+    if levels[0]["cores"] == min(8, ncpu):
+        out["at_8_threads"] = {"value": levels[0]["value"]}
+    return out
 
 
 def pmc_traffic_in_run(args, timeout=420):
@@ -1134,19 +1180,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _phase("CPU baseline")
         ncpu = os.cpu_count() or 1
-        # one image per process while the box has hardware threads for them: the sample grows with the box (at most 4 batches'
-        # worth -- ~2 s of work per image), so that the stated cores all work; --cpu-sample bounds it from below
-        n_img = max(args.cpu_sample if B >= args.cpu_sample else B, min(ncpu, 4 * B))
-        cpu = cpu_baseline(n_img, is_, B)
-        if ncpu > 8:  # the figure that lines up with BASELINE.md's 8-thread reference measurement
-            c8 = cpu_baseline(8 if B >= 8 else B, is_, B, threads=8)
-            cpu["at_8_threads"] = {"value": c8["value"], "sample": c8["sample"]}
-        if args.cpu_sweep:  # where the figure stops improving (profiles/: the knee the stated core count rests on)
-            cpu["sweep"] = []
-            for t_ in (16, 32, 64, 128, 256):
-                if t_ < ncpu:
-                    c_ = cpu_baseline(min(t_, 4 * B), is_, B, threads=t_)
-                    cpu["sweep"].append({"threads": t_, "value": c_["value"], "s_per_image": c_["seconds_per_image_in_a_worker"]})
+        cpu = cpu_baseline_at_the_knee(is_, B, ncpu, sweep_all=args.cpu_sweep)
 
     if rank == 0:
         ms = dt / args.steps * 1e3

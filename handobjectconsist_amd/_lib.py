@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmeshraster_hip.so")
-ABI_VERSION = 7  # MR_ABI_VERSION of include/meshraster_hip.h
+ABI_VERSION = 8  # MR_ABI_VERSION of include/meshraster_hip.h
 FLAG_REFERENCE_ALGO = 1
 FLAG_SPARSE_TILES = 2
 FLAG_OUTPUT_ZEROED = 4
@@ -36,6 +36,7 @@ SIGNATURES = {
     "mr_render_backward_workspace_bytes": (_L, [_I, _I, _I]),
     "mr_render_backward_list_workspace_bytes": (_L, [_I, _I]),
     "mr_render_backward": (_I, [_P] * 11 + [_L, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _P]),
+    "mr_pixel_map_terms": (_I, [_P, _I]),
     "mr_render_vc_forward": (_I, [_P, _P, _P, _P, _I] + [_P] * 6 + [_L, _I, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _I, _P]),
     "mr_render_vc_backward": (_I, [_P] * 7 + [_I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "mr_render_flow_backward": (_I, [_P] * 11 + [_I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P]),

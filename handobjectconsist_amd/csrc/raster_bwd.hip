@@ -1797,6 +1797,16 @@ __device__ __forceinline__ float ps_diff_grad(const float4 v, const float4 g, co
     return d.x + d.y;
 }
 __device__ __forceinline__ float ps_bound_k(float k) { return (k == k) ? fminf(fmaxf(k, -1e15f), 1e15f) : k; }
+// Terms of the walk (profiling switch flags >> 8 & 1024; read back by mr_pixel_map_terms): one term = one evaluation of upstream's
+// sweep body (rasterize.py:269-281 -> backward_pixel_map: every position of an "out" sweep, every position of an "in" sweep whose
+// pixel belongs to the face) -- the unit bench.py's `d_e_f.frac_of_algorithmic_issue` prices at 10 lane-instructions.
+__device__ unsigned long long mr_pixel_map_terms_counter;
+__device__ __forceinline__ void ps_count_terms(int n) {
+    int tot = n;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&mr_pixel_map_terms_counter, (unsigned long long)tot);
+}
 constexpr int PS_T = 256;
 constexpr int PS_QCAP = 1024;  // queued entries; a round of PS_T faces adds at most 3 * PS_T
 
@@ -1989,6 +1999,12 @@ __device__ __forceinline__ void strip_body(const PixelMapParams& p, const unsign
                     if (use1) g1 -= pm_term(dg, c1, (float)d1, d1_cross, two_over_is, p.eps);
                 }
             }
+            if (p.dbg & 1024) {  // (profiling: the terms of the short "in" sweeps)
+                int nt = 0;
+                if (valid && !long_in)
+                    for (int d1 = in_from; d1 <= in_to; d1++) nt += fimL[line * stride + d1] == fn ? 1 : 0;
+                ps_count_terms(nt);
+            }
             acc[lane] = make_float2(0.0f, 0.0f);  // the sums of this lane's item over its chunks (LDS atomics of the task lanes)
 
             // The "out" sweeps of the visible items and the long "in" sweeps, one LANE per chunk of CH positions.  A lane
@@ -2033,6 +2049,12 @@ __device__ __forceinline__ void strip_body(const PixelMapParams& p, const unsign
                     const int t_fn = __shfl(fn, src);
                     MR_PS_COUNT(1, 1);
                     MR_PS_COUNT(2, cnt);
+                    if (p.dbg & 1024) {  // (profiling: "out" sweeps count every position, long "in" sweeps the face's own pixels)
+                        int nt = kind == 0 ? cnt : 0;
+                        if (kind == 1)
+                            for (int q_ = 0; q_ < cnt; q_++) nt += fimL[base + q_] == t_fn ? 1 : 0;
+                        ps_count_terms(nt);
+                    }
                     f32x2 ww = {0.0f, 0.0f};
                     // an unused term gets the distance 1 and the weight 0
                     const f32x2 kk = {t_use0 ? t_k0 : 0.0f, t_use1 ? t_k1 : 0.0f};
@@ -2758,6 +2780,22 @@ extern "C" int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, c
         hipLaunchKernelGGL(unit_scatter_listing_kernel, dim3((unsigned)blocks), dim3(ST_WAVES * MR_WAVE), (size_t)table_bytes, s, sp);
     }
     MR_CHECK_LAUNCH();
+    return MR_OK;
+}
+
+extern "C" int mr_pixel_map_terms(uint64_t* terms_host, int reset) {
+    if (!terms_host) return MR_ERR_BADARG;
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
+    unsigned long long v = 0ull;
+    e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(mr::mr_pixel_map_terms_counter), sizeof(v), 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    *terms_host = (uint64_t)v;
+    if (reset) {
+        v = 0ull;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(mr::mr_pixel_map_terms_counter), &v, sizeof(v), 0, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return (int)e;
+    }
     return MR_OK;
 }
 

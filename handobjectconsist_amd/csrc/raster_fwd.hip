@@ -60,8 +60,9 @@ constexpr int NB = 32;                // faces per batch (stage S1: one lane per
                                       // batch per wave for the ~145 faces of a typical geometry tile): the larger face
                                       // cache costs occupancy (5 / 4 instead of 7 waves per SIMD) and the kernel gets slower
 constexpr int NBP2 = 32;              // next power of two
-constexpr int FC_STRIDE = 25;         // dwords per face-cache slot (odd: conflict-free ds_read_b32): v 9, inv 9, face index,
-                                      // box, refined reciprocals of the three depths, "division-safe" flag
+constexpr int FC_STRIDE = 31;         // dwords per face-cache slot (odd: conflict-free ds_read_b32): v 9, inv 9, face index,
+                                      // box, refined reciprocals of the three depths, "division-safe" flag, and (round 6) per edge
+                                      // the tile-local pixel column where it crosses the tile's first row + its step per row
 constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 4 * 64, power of 2)
 
 // Per-image header written by bin_faces_kernel.
@@ -130,11 +131,10 @@ struct BinParams {
     int64_t zero_count;
     // round 5: `parts` workgroups per image, each binning a contiguous range of the image's faces (see bin_boxes_kernel)
     int B, parts;
-    int poll_add;            // always 0: the addend of the polling RMWs (a literal 0 lets the compiler turn them into loads, which may
-                             // be served from the compute unit's L1 for ever)
+    int poll_add;            // (unused since round 6: the parts no longer poll)
     int* part_cnt;           // [B, parts, nbins + 4]: a part's raw bin counters + {its large faces, its "everywhere" flag}
-    unsigned* arrive;        // [B * ARRIVE_STRIDE] arrival counters of the images' parts, a 128-byte line each (an image's
-                             // parts count on it with atomics of their XCD's L2); ZERO on entry (per-face pass / the caller's clear)
+    unsigned* arrive;        // [B * ARRIVE_STRIDE] arrival counters of the images' parts, a 128-byte line each; ZERO on entry (per-face
+                             // pass / the caller's clear) and again on exit (the last part to arrive re-zeroes its image's)
 };
 
 // Pass A, one thread per REAL face, grid = (ceil(F0 / 256), B): back-face cull + conservative pixel bbox of the
@@ -215,21 +215,23 @@ __device__ unsigned long long mr_dbg_bin[1024 * 8];  // profiling builds: phase 
 // pass runs inside this kernel -- a thread computes the boxes of its real faces (and their reversed copies) straight into the LDS
 // copy and writes the faces' coordinates; the boxes never exist in global memory.  One launch and one dependent round trip (the
 // boxes' read-back) less per render: 14 + 17.5 -> 21 us for the 2B = 128 meshes of a training pair.
-// PARTS (round 5).  One workgroup per image leaves half the chip idle at the 2B = 128 renders of a training pair and 15 of 16
-// compute units at config 3's 16 renders.  An image is therefore binned by `parts` workgroups, each taking a contiguous range
-// of its faces through the per-face pass, the counting pass and the fill pass; between counting and filling the parts of an
-// image exchange their bin counters through global memory (a part's place in a bin's list = the bin's offset + what the
-// lower parts hold in it), behind a barrier on the image's arrival counter.  All parts of all images are co-resident by
-// construction (launch_bins: B x parts <= compute units, one workgroup fits a compute unit on its own), so the barrier cannot
-// starve; a part that waits for more than ~2 s traps instead of hanging the queue.  The parts of an image run on ONE XCD
-// (workgroup i goes to XCD i % 8): the exchange is L2 traffic.  Part 0 writes the bin headers and the image's tile-list
-// entries; the order of the records inside a bin's list differs from the one-workgroup order -- as it already does from run
-// to run (LDS atomics) -- and the image does not depend on it (z-buffer keys).
+// PARTS (round 5; round 6: no barrier).  One workgroup per image leaves half the chip idle at the 2B = 128 renders of a training
+// pair and 15 of 16 compute units at config 3's 16 renders.  An image is therefore binned by `parts` workgroups, each taking a
+// contiguous range of its faces through the per-face pass and the counting pass; a part then PUBLISHES its bin counters, its
+// boxes and its scalars in global memory, counts itself on the image's arrival counter and LEAVES -- except the part that arrives
+// last: it adds the parts' counters up, scans them, writes the bin headers and the image's tile-list entries and runs the fill
+// pass over ALL boxes of the image.  Nobody waits for anybody: no assumption about which workgroups are resident together, about
+// other kernels on the device or about the XCD a workgroup lands on (round 5's parts met at a spin barrier that needed all B x
+// parts workgroups co-resident and trapped after ~2 s otherwise).  What crosses workgroups does so in agent-scope
+// atomic stores / loads and one agent-scope atomic add per part (the "last block reduces" pattern; details at the exchange
+// below).  The last arriver also re-zeroes the counter for the next launch.
+// The order of the records inside a bin's list differs from the one-workgroup order -- as it already does from run to run (LDS
+// atomics) -- and the image does not depend on it (z-buffer keys).
 template <bool RECORDS>
 __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     MR_BIN_STAMP(0);
     extern __shared__ int bin_smem[];
-    __shared__ int s_large, s_nlarge, s_lbase, s_hbase, s_bbase, s_everywhere, s_large_before;
+    __shared__ int s_large, s_nlarge, s_lbase, s_hbase, s_bbase, s_everywhere, s_last;
     // listed launches: bit 30 of a bin's counter = "a face of the image's large list overlaps this bin" (counts stay far below)
     constexpr int LARGE_BIT = 1 << 30, CNT_MASK = LARGE_BIT - 1;
     __shared__ unsigned long long wsum[BIN_TPB / MR_WAVE];
@@ -246,9 +248,8 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     }
     const int nbins = p.nbx * p.nby, nbins4 = (nbins + 3) & ~3;
     int* cnt = bin_smem;
-    int* before = bin_smem + nbins4;  // K > 1: records the lower parts hold in a bin
-    FaceBox* sbox = reinterpret_cast<FaceBox*>(bin_smem + (K > 1 ? 2 : 1) * nbins4);
-    const FaceBox* box_b = p.boxes + (int64_t)b * p.F;
+    FaceBox* sbox = reinterpret_cast<FaceBox*>(bin_smem + nbins4);
+    FaceBox* box_b = p.boxes + (int64_t)b * p.F;
     // this part's faces: real faces [r0, r0 + nr) and (RECORDS with fill-back) their reversed copies F0 + [r0, r0 + nr), or
     // (!RECORDS) virtual faces [r0, r0 + nr); local index j < nv -> face fn_of(j)
     const int nsplit = RECORDS ? p.F0 : p.F;
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     auto fn_of = [&](int j) { return j < nr ? r0 + j : p.F0 + r0 + (j - nr); };
 
     for (int i = tid; i < nbins; i += BIN_TPB) cnt[i] = 0;
-    if (tid == 0) { s_large = 0; s_nlarge = 0; s_everywhere = 0; s_large_before = 0; }
+    if (tid == 0) { s_large = 0; s_nlarge = 0; s_everywhere = 0; s_last = 1; }
     __syncthreads();
     MR_BIN_STAMP(1);
 
@@ -347,71 +348,68 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     const int per = (nbins + BIN_TPB - 1) / BIN_TPB;
     const int i0 = min(tid * per, nbins), i1 = min(i0 + per, nbins);
     if (K > 1) {
-        // exchange: publish this part's counters, wait for the image's other parts, turn cnt[] into the image's totals
-        // and before[] into what the lower parts hold in each bin.  The parts of an image share an XCD and therefore an L2
-        // (launch_bins' workgroup -> image map; checked below): plain stores that the L2 has acknowledged, a flag counted
-        // by L2 atomics (workgroup scope: no trip to the memory side) and loads that bypass the compute unit's L1 are
-        // coherent there -- no device-scope fence.  (A release + acquire fence pair per wave -- L2 write-back and
-        // invalidate, 32 per workgroup -- made this kernel 142 us; one pair per workgroup still cost 5 us of barrier.)
+        // publish this part's counters, scalars and (RECORDS: they exist in LDS only) boxes; count it on the image's arrival
+        // counter; every part but the last one to arrive is done.  Everything that crosses workgroups here goes through
+        // AGENT-scope atomic stores / loads (sc1: written through to / read from the memory side, past the XCD's L2) and the
+        // arrival counter through an agent-scope atomic add: coherent whichever XCDs the parts run on, and without the L2
+        // write-back of a release FENCE (measured, the formal form -- plain stores, agent-scope release fence + acquire fence
+        // around the add -- took this kernel from 26.8 to 36.5 us in the step at 2B = 128: buffer_wbl2 flushes the ~2 MB of
+        // vertex records the XCD's workgroups have just written, which nobody in this kernel reads).  Order: a part's stores
+        // have completed (s_waitcnt vmcnt(0)) before its barrier, the add is issued behind the barrier.
         const int pstride = (nbins + 4 + 31) & ~31;  // (a part's counters start on a 128-byte line of their own)
         int* pub = p.part_cnt + ((int64_t)b * K + part) * pstride;
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        xcc &= 15u;
-        for (int i = tid; i < nbins; i += BIN_TPB) pub[i] = cnt[i];
-        if (tid == 0) { pub[nbins] = s_nlarge; pub[nbins + 1] = s_everywhere; pub[nbins + 2] = (int)xcc; }
-        __syncthreads();  // (the workgroup's stores are performed: s_waitcnt vmcnt(0) in front of the barrier)
+        for (int i = tid; i < nbins; i += BIN_TPB) __hip_atomic_store(&pub[i], cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(&pub[nbins], s_nlarge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pub[nbins + 1], s_everywhere, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        static_assert(sizeof(FaceBox) == 8, "boxes cross workgroups as 64-bit atomic words");
+        unsigned long long* box_w = reinterpret_cast<unsigned long long*>(box_b);
+        if (RECORDS)
+            for (int j = tid; j < nv; j += BIN_TPB)
+                __hip_atomic_store(&box_w[fn_of(j)], reinterpret_cast<const unsigned long long*>(sbox)[j], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         MR_BIN_STAMP(6);
         if (tid == 0) {
             unsigned* arr = p.arrive + (int64_t)b * ARRIVE_STRIDE;
-            __hip_atomic_fetch_add(arr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            unsigned spins = 0;
-            while (__hip_atomic_fetch_add(arr, (unsigned)p.poll_add, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)K) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22)) __builtin_trap();  // (a second or so: a part that never arrives is a bug, not a wait)
-            }
+            const unsigned old = __hip_atomic_fetch_add(arr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == (unsigned)K - 1u) ? 1 : 0;
+            if (s_last) __hip_atomic_store(arr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next launch counts from zero)
         }
         __syncthreads();
+        if (!s_last) return;
         MR_BIN_STAMP(7);
-        // (Loads WITHOUT a device scope -- streaming hint only: they miss this compute unit's L1 -- nothing of these lines was
-        // read here before, the L1 is write-through and is invalidated when a kernel starts -- and hit the XCD's L2, where
-        // the partners' stores sit.  A device-scope load (sc1) goes PAST the L2 and returns what memory held before the
-        // partner's store: measured, the XCD check below trapped on it.)
         const int* all = p.part_cnt + (int64_t)b * K * pstride;
         for (int i = i0; i < i1; i++) {
             int raw[MAX_PARTS_DEV];  // (all parts' counters of the bin in flight together)
 #pragma unroll
-            for (int k = 0; k < MAX_PARTS_DEV; k++) raw[k] = k < K ? __builtin_nontemporal_load(all + (int64_t)k * pstride + i) : 0;
-            int tot = 0, lg = 0, bef = 0;
+            for (int k = 0; k < MAX_PARTS_DEV; k++)
+                raw[k] = k < K ? __hip_atomic_load(all + (int64_t)k * pstride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            int tot = 0, lg = 0;
 #pragma unroll
             for (int k = 0; k < MAX_PARTS_DEV; k++) {
                 tot += raw[k] & CNT_MASK;
                 lg |= raw[k] & LARGE_BIT;
-                bef += k < part ? (raw[k] & CNT_MASK) : 0;
             }
             cnt[i] = tot | lg;
-            before[i] = bef;
         }
         if (tid < MR_WAVE) {  // (wave 0; lane k < K: part k's scalars)
-            int n = 0, ev = 0;
+            int nl = 0, e = 0;
             if (tid < K) {
-                // (the three scalars of part `tid` through L2 atomics: coherent whatever an L1 holds)
-                int* q = p.part_cnt + ((int64_t)b * K + tid) * pstride + nbins;
-                n = __hip_atomic_fetch_add(q, p.poll_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                ev = __hip_atomic_fetch_add(q + 1, p.poll_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const unsigned their = (unsigned)__hip_atomic_fetch_add(q + 2, p.poll_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (their != xcc) __builtin_trap();  // an image's parts on two XCDs: the exchange above would not be coherent
+                nl = __hip_atomic_load(all + (int64_t)tid * pstride + nbins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                e = __hip_atomic_load(all + (int64_t)tid * pstride + nbins + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            int nl = n, lb = tid < part ? n : 0, e = ev;
 #pragma unroll
             for (int off = 1; off < MAX_PARTS_DEV; off <<= 1) {
-                nl += __shfl_xor(nl, off); lb += __shfl_xor(lb, off); e |= __shfl_xor(e, off);
+                nl += __shfl_xor(nl, off); e |= __shfl_xor(e, off);
             }
-            if (tid == 0) { s_nlarge = nl; s_everywhere = e; s_large_before = lb; }
+            if (tid == 0) { s_nlarge = nl; s_everywhere = e; }
         }
         __syncthreads();
     }
-    const bool lead = part == 0;  // writes what the image has once: bin headers, tile-list entries, the image header
+    constexpr bool lead = true;  // (whoever gets here writes what the image has once: bin headers, tile-list entries, image header)
 
     // exclusive scan of the bin counts (each thread owns a run of consecutive bins); headers out, counters
     // become fill cursors.  The high half of the scanned value counts the bins that hold candidates (every bin,
@@ -484,18 +482,13 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
             else hit32[i] = 0u;
         }
     }
-    if (p.tlist || K > 1) {
-        __syncthreads();  // (pass 2 moves the cursors)
-        if (K > 1)
-            for (int i = i0; i < i1; i++) cnt[i] += before[i];  // this part's place inside each bin's list
-        if (K > 1) __syncthreads();
-    }
+    if (p.tlist) __syncthreads();  // (pass 2 moves the cursors)
     MR_BIN_STAMP(4);
     if (p.dbg & 2) return;
 
     // pass 2: fill
     FaceRec* recs_b = p.recs + (int64_t)b * REC_CAP * p.F;
-    FaceRec* large_b = recs_b + (int64_t)SMALL_MAX_BINS * p.F + s_large_before;
+    FaceRec* large_b = recs_b + (int64_t)SMALL_MAX_BINS * p.F;
     auto fill_face = [&](const int fn, const FaceBox bx) __attribute__((always_inline)) {
         if (bx.x0 > bx.x1) return;
         FaceRec rec;
@@ -514,7 +507,24 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     };
     // (two loops, not one over `lds_boxes ? sbox[j] : box_b[fn]`: the merged pointer is a generic one, and every box
     // then costs two dependent FLAT loads with a full wait each, also when it sits in LDS)
-    if (p.lds_boxes) {
+    if (K > 1) {
+        // the last arriver fills for the whole image, from the boxes all parts left in global memory (FILL_PF trips requested together)
+        constexpr int FILL_PF = 4;
+        for (int base = 0; base < p.F; base += FILL_PF * BIN_TPB) {
+            FaceBox bxs[FILL_PF];
+#pragma unroll
+            for (int k = 0; k < FILL_PF; k++) {
+                const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(box_b) + min(base + k * BIN_TPB + tid, p.F - 1),
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bxs[k] = *reinterpret_cast<const FaceBox*>(&w);
+            }
+#pragma unroll
+            for (int k = 0; k < FILL_PF; k++) {
+                const int fn = base + k * BIN_TPB + tid;
+                if (fn < p.F) fill_face(fn, bxs[k]);
+            }
+        }
+    } else if (p.lds_boxes) {
         for (int j = tid; j < nv; j += BIN_TPB) fill_face(fn_of(j), sbox[j]);
     } else {
         for (int j = tid; j < nv; j += BIN_TPB) fill_face(fn_of(j), box_b[fn_of(j)]);
@@ -786,6 +796,23 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             const int y0 = max((int)(r.y & 0xffffu), ty0) - ty0, y1 = min((int)(r.y >> 16), ty1) - ty0;
             c[18] = __int_as_float(fn);
             c[19] = __int_as_float(x0 | (x1 << 8) | (y0 << 16) | (y1 << 24));
+            // S2's first probe per (edge, row): the column where the edge crosses the row, as a line in the row number --
+            // x(row) = c[24 + 2 k] + row * c[25 + 2 k], tile-local pixel units.  Edge k from vertex k: (xp - a_x) dy = (yp - a_y)
+            // dx, xp = a_x + (yp - a_y) dx / dy; yp advances by 2 / is per row, a pixel is 2 / is wide: the step is dx / dy
+            // columns per row.  It only has to land within a pixel (the exact predicate brackets the span around it); a
+            // horizontal edge gives Inf / NaN, which S2 maps to the row's last column (T is constant along the row then).
+            {
+                const float yp0 = yp_tab[0];
+                const float ex[3] = {f.v[3] - f.v[0], f.v[6] - f.v[3], f.v[0] - f.v[6]};
+                const float ey_[3] = {f.v[4] - f.v[1], f.v[7] - f.v[4], f.v[1] - f.v[7]};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float step = ex[k] * __builtin_amdgcn_rcpf(ey_[k]);
+                    const float xp_at0 = f.v[3 * k] + (yp0 - f.v[3 * k + 1]) * step;
+                    c[24 + 2 * k] = (xp_at0 * fis + fis - 1.0f) * 0.5f - (float)tx0;
+                    c[25 + 2 * k] = step;
+                }
+            }
             // (a record of the image's large list, or of a bin taller than a tile, may miss this tile)
             nrows = (x0 <= x1 && y0 <= y1) ? y1 - y0 + 1 : 0;
         }
@@ -820,13 +847,17 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             int row = 0;
             float ea[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, ey[3] = {0, 0, 0};
             int lx0 = 0, lx1 = -1;
+            float cross[6] = {0, 0, 0, 0, 0, 0}, frow = 0.0f;
             if (act) {
                 const float* c = fc + slot * FC_STRIDE;
+#pragma unroll
+                for (int k = 0; k < 6; k++) cross[k] = c[24 + k];
                 const int bb = __float_as_int(c[19]);
                 row = ((bb >> 16) & 0xff) + (item - ro[slot]);
                 const float ax = c[0], ay = c[1], bx = c[3], by = c[4], cx_ = c[6], cy_ = c[7];
                 lx0 = bb & 0xff; lx1 = (bb >> 8) & 0xff;
                 const float yp = yp_tab[row];
+                frow = (float)row;
                 ea[0] = ax; ea[1] = bx; ea[2] = cx_;
                 dy[0] = by - ay; dy[1] = cy_ - by; dy[2] = ay - cy_;
                 ey[0] = (yp - ay) * (bx - ax); ey[1] = (yp - by) * (cx_ - bx); ey[2] = (yp - cy_) * (ax - cx_);
@@ -845,8 +876,10 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             bool open_any = false;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                // (xp - a) dy = ey  ->  xp = a + ey / dy;  pixel index = (xp is + is - 1) / 2, tile-local
-                const float xs = ((ea[k] + ey[k] * __builtin_amdgcn_rcpf(dy[k])) * fis + fis - 1.0f) * 0.5f - (float)tx0;
+                // (xp - a) dy = ey  ->  xp = a + ey / dy;  pixel index = (xp is + is - 1) / 2, tile-local: the line S1 left
+                // in the face cache (dbg 16384: the per-item closed form of rounds 2-5, for the A / B count)
+                const float xs = (p.dbg & 16384) ? ((ea[k] + ey[k] * __builtin_amdgcn_rcpf(dy[k])) * fis + fis - 1.0f) * 0.5f - (float)tx0
+                                                 : __builtin_fmaf(frow, cross[2 * k + 1], cross[2 * k]);
                 // NaN (dy == 0) -> lx1: T is constant along the row then, the probe at the far end settles it
                 int c = (int)fminf(fmaxf(floorf(xs), (float)lx0), (float)lx1);
                 if (!(xs == xs)) c = lx1;
@@ -1349,7 +1382,7 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     bp.B = B; bp.parts = parts; bp.poll_add = 0;
     bp.part_cnt = (int*)(base + w.off_part_cnt);
     bp.arrive = (unsigned*)(base + w.off_arrive);
-    size_t lds = (size_t)((nbins + 3) & ~3) * sizeof(int) * (parts > 1 ? 2 : 1);
+    size_t lds = (size_t)((nbins + 3) & ~3) * sizeof(int);
     // (boxes of the largest part: its share of the real faces in both orientations, or of the virtual faces)
     const size_t box_lds = (size_t)((F + parts - 1) / parts + 2) * sizeof(FaceBox);
     bp.lds_boxes = (lds + box_lds <= 152 * 1024) ? 1 : 0;

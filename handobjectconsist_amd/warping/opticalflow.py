@@ -424,7 +424,8 @@ def _render_stacked_flow(ndc, faces2, cols, lut, fill_back, image_size, near, fa
     work = cleared_work if cleared_work is not None else torch.empty((max(wbytes, 8),), dtype=torch.uint8, device=dev)
     st = _lib.stream_ptr(dev)
     bound, count_word = _tile_bound(dev, B2, is_) if (USE_SPARSE_TILES and USE_TILE_LIST) else (0, None)
-    render_flags = (_lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0) | (_lib.FLAG_TILE_LIST_CLEARED if cleared_work is not None else 0)
+    render_flags = ((_lib.FLAG_SPARSE_TILES if USE_SPARSE_TILES else 0) | (_lib.FLAG_TILE_LIST_CLEARED if cleared_work is not None else 0)
+                    | _FWD_DBG_FLAGS)
     # the backward's output buffer is cleared by the render's binning pass on its way (its own clearing would be a
     # launch on the backward pass's critical path); a second backward through this node clears its own
     grad_buf = torch.empty((B2, V, 3), **f32) if want_grad else None
@@ -535,6 +536,7 @@ USE_UNIT_GRADIENT = True
 # ... and with the backward's workgroups handed out over the covered-tile lists the forward's finalize launch compacts (ABI 7):
 # workgroups per image in proportion to its covered tiles.  False: a fixed number per image, each listing the image's tiles.
 USE_SCATTER_WORK = os.environ.get("HOC_SCATTER_WORK", "1") != "0"
+_FWD_DBG_FLAGS = int(os.environ.get("HOC_FWD_DBG", "0")) << 8  # profiling switches of the forward kernels (csrc/raster_fwd.hip: dbg)
 # ... and with the render's per-face pass folded into its binning pass (the pair prologue clears the tile list's header, which
 # the per-face pass's first thread does otherwise): one launch and one dependent round trip less per pair.
 USE_FUSED_RECORDS = True

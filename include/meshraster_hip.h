@@ -81,7 +81,7 @@ typedef void* mr_stream_t;
  *    binning pass's workgroups, several per image since round 5); mr_flow_pair_prologue_parts takes clear_bytes;
  * 7: scatter_work of mr_flow_pair_forward_grad_tiles / mr_flow_pair_backward_unit_tiles (the covered-tile lists the
  *    backward's workgroups are handed out over), mr_flow_pair_scatter_work_bytes. */
-#define MR_ABI_VERSION 7
+#define MR_ABI_VERSION 8
 MR_API int mr_abi_version(void);
 /* 1 if the calling thread's CURRENT HIP device is a gfx950, else 0.
  * Device contract of every entry point below: kernels are launched on the calling thread's current HIP
@@ -199,6 +199,13 @@ MR_API int mr_render_backward(const float* faces, const float* textures,
                        int image_size, int texture_size, float near_, float far_, float eps,
                        int return_rgb, int return_alpha, int return_depth, int flags,
                        mr_stream_t stream);
+
+/* Profiling aid of the pixel-map term (kernel D by strips): mr_render_backward launched with `flags | (1024 << 8)` adds the
+ * number of TERMS its walk evaluates -- one term = one evaluation of the sweep body of upstream's backward_pixel_map
+ * (rasterize.py:269-281): every position of an "out" sweep, every position of an "in" sweep whose pixel belongs to the face
+ * -- to a device-side counter.  This call synchronises the device, copies the counter to *terms_host (host memory) and, with
+ * `reset`, clears it.  bench.py prices the launch against terms x 10 lane-instructions (`d_e_f.frac_of_algorithmic_issue`). */
+MR_API int mr_pixel_map_terms(uint64_t* terms_host, int reset);
 
 /* Vertex-colour mode (SURVEY 8f "f1"): the render of opticalflow.get_opticalflow, where the
  * face textures are the 2x2x2 vertex-colour textures of batch_vertex_textures

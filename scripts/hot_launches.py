@@ -25,7 +25,7 @@ def hot():
     l.backward()
 for _ in range(3): hot()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=os.environ.get("HOC_ATEN_OPS", "0") == "1") as prof:
     hot()
     torch.cuda.synchronize()
 evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
@@ -72,3 +72,13 @@ if os.environ.get("HOC_HOST_PROFILE", "0") == "1":
     pr.disable()
     torch.cuda.synchronize()
     pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+
+if os.environ.get("HOC_ATEN_OPS", "0") == "1":
+    # which ATen operators of the pass launch something (the launches that are not this library's kernels: copies, fills, reductions)
+    ops = collections.Counter()
+    for e in prof.events():
+        if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::") and len(getattr(e, "kernels", [])) > 0:
+            ops[e.name + " " + str([tuple(s) if s else s for s in (e.input_shapes or [])][:3])] += 1
+    for k, v in ops.most_common(30):
+        print(f"{v:4d} x {k}")
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=25, max_name_column_width=60))
