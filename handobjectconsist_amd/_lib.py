@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmeshraster_hip.so")
+# (HOC_LIB_PATH: another build of the same ABI -- scripts/build_variant.py makes A / B libraries for one-box kernel comparisons)
+LIB_PATH = os.environ.get("HOC_LIB_PATH") or os.path.join(_HERE, "libmeshraster_hip.so")
 ABI_VERSION = 8  # MR_ABI_VERSION of include/meshraster_hip.h
 FLAG_REFERENCE_ALGO = 1
 FLAG_SPARSE_TILES = 2
@@ -73,6 +74,11 @@ SIGNATURES = {
     "mr_flow_pair_forward_grad_tiles": (_I, [_P] * 4 + [_L] + [_P] * 12 + [_I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _L, _L, _P, _P, _P, _P, _P]),
     "mr_flow_pair_backward_unit_tiles": (_I, [_P] * 9 + [_I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P]),
     "mr_flow_pair_scatter_work_bytes": (_L, [_I, _I]),
+    "mr_pair_step_struct_bytes": (_L, []),
+    "mr_pair_step_field_offsets": (_I, [_P, _I]),
+    "mr_pair_step_sizes": (_I, [_P, _P, _P, _P]),
+    "mr_pair_step_forward": (_I, [_P, _P]),
+    "mr_pair_step_backward": (_I, [_P, _P]),
     "mr_frames_to_batch_workspace_bytes": (_L, [_I, _I, _I]),
     "mr_frames_to_batch": (_I, [_P] * 3 + [_F] * 6 + [_P, _L, _P, _P] + [_I] * 6 + [_P]),
     "mr_bn_act_forward": (_I, [_P] * 6 + [_F, _I, _I, _I, _P, _I, _I, _I, _P]),

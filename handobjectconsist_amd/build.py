@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["raster_fwd.hip", "raster_bwd.hip", "warp.hip", "vertex_stage.hip", "mano_lbs.hip", "meshreg_post.hip",
-           "frame_batch.hip", "frozen_bn.hip", "stem_pool.hip"]
+           "frame_batch.hip", "frozen_bn.hip", "stem_pool.hip", "pair_step.hip"]
 LIB_PATH = os.path.join(_HERE, "libmeshraster_hip.so")
 # -ffp-contract=off: parity-critical fp32 expressions must round operation by operation
 # exactly like the CPU oracle (SURVEY 7 "bit-faithful coverage").

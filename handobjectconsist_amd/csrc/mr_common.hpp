@@ -453,6 +453,19 @@ __host__ __device__ inline ScatterWork scatter_work_at(void* buf, int images) {
     return w;
 }
 
+// inclusive sum over the lanes of a wave (int): row shifts and the two row broadcasts of the gfx9 DPP unit -- six vector
+// instructions, no LDS crossbar (a lane without a source adds 0).  Call it with ALL lanes of the wave active.
+__device__ __forceinline__ int wave_incl_sum(int v, int lane = 0) {
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a
 // contiguous range of logical ids so the tiles / faces of one image share one L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {

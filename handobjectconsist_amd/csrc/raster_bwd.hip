@@ -799,6 +799,12 @@ struct ScatterTilesParams {
     const float* sums;        // [split,4] of the pair loss's forward
     const float* gl_fwd;      // [split] incoming gradients of loss_fwd / loss_bwd (gl_bwd nullable)
     const float* gl_bwd;
+    // UNIT (mr_pair_step_backward): two more incoming gradients, added to both directions' coefficients: of loss_bwd + loss_fwd
+    // [split] and of the mean over the batch [1] (a sample's share = *gl_mean / mean_div), each nullable
+    const float* gl_sum;
+    const float* gl_mean;
+    float mean_div;
+    int mean_of;              // 1: the mean is over loss_fwd only -- no share for the other direction
     float pair_thresh;
     // UNIT (mr_flow_pair_backward_unit_tiles): the forward (mr_flow_pair_forward_grad_tiles) left the pair loss's gradient for
     // a coefficient of 1, masks applied; this launch multiplies by grad_loss / count of the image -- no taps, no pass 1
@@ -853,19 +859,6 @@ __device__ unsigned long long mr_dbg_st[4096 * 8];  // profiling builds: phase s
 #else
 #define MR_ST_STAMP(k) do { } while (0)
 #endif
-
-// inclusive sum over the lanes of a wave (int): row shifts and the two row broadcasts of the gfx9 DPP unit -- six vector
-// instructions, no LDS crossbar (a lane without a source adds 0)
-__device__ __forceinline__ int wave_incl_sum(int v, int lane) {
-    (void)lane;
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
-    return v;
-}
 
 template <bool FLOWGRAD, bool REC, bool PAIR, bool UNIT = false, bool WORK = false>
 __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp) {
@@ -992,6 +985,8 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
         const float* gl = dir ? sp.gl_fwd : sp.gl_bwd;
         u_cnt = sp.sums[pb * 4 + (dir ? 1 : 3)];
         u_gl = gl ? gl[pb] : 0.0f;
+        if (sp.gl_sum) u_gl += sp.gl_sum[pb];
+        if (sp.gl_mean && (dir || !sp.mean_of)) u_gl += sp.gl_mean[0] / sp.mean_div;
         u_max = sp.unit_max[b];
     }
     // the list of covered tiles (block-wide compaction of the coverage bytes); the waves that share an image then take
@@ -1027,7 +1022,7 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
         // |unit| <= unit_max rounds to at most fl(unit_max * |ucoef|) (rounding is monotone): the bound of the fixed point.
         // A zero coefficient leaves the image without a gradient whatever the unit gradient holds.
         const float* gl = (b >= sp.split) ? sp.gl_fwd : sp.gl_bwd;
-        ucoef = gl ? u_gl / ((u_cnt == 0.0f) ? 1.0f : u_cnt) : 0.0f;
+        ucoef = (gl || sp.gl_sum || sp.gl_mean) ? u_gl / ((u_cnt == 0.0f) ? 1.0f : u_cnt) : 0.0f;
         if (ucoef != 0.0f) mx = __float_as_uint(u_max * ucoef) & 0x7fffffffu;
     }
     if constexpr (PAIR) {
@@ -2733,18 +2728,21 @@ extern "C" int mr_flow_pair_backward_tiles(const int32_t* face_index_map, const 
     return MR_OK;
 }
 
-extern "C" int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, const uint32_t* tile_hit,
-                                                const float* weight_map, const int32_t* vertex_id_map, const float* unit_grad,
-                                                const float* unit_grad_max, const float* sums, const float* grad_loss_fwd,
-                                                const float* grad_loss_bwd, int height, int width, float* grad_vcolors,
-                                                int batch_size, int num_verts, int num_faces, int fill_back, int image_size,
-                                                float eps, int flags, int texel_layout, const void* scatter_work,
-                                                mr_stream_t stream) {
+// mr_flow_pair_backward_unit_tiles with the two extra incoming gradients of mr_pair_step_backward (pair_step.hip): of
+// loss_bwd + loss_fwd and of the batch mean (ScatterTilesParams::gl_sum / gl_mean)
+int mr_flow_pair_backward_unit_tiles_ex(const int32_t* face_index_map, const uint32_t* tile_hit,
+                                        const float* weight_map, const int32_t* vertex_id_map, const float* unit_grad,
+                                        const float* unit_grad_max, const float* sums, const float* grad_loss_fwd,
+                                        const float* grad_loss_bwd, const float* grad_loss_sum, const float* grad_mean,
+                                        int mean_of, int height, int width, float* grad_vcolors,
+                                        int batch_size, int num_verts, int num_faces, int fill_back, int image_size,
+                                        float eps, int flags, int texel_layout, const void* scatter_work,
+                                        mr_stream_t stream) {
     if (batch_size < 0 || (batch_size & 1) || num_faces < 0 || num_verts < 0 || image_size <= 0 || !texel_layout_ok(texel_layout))
         return MR_ERR_BADARG;
     if (!grad_vcolors && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
     if (batch_size == 0 || num_verts == 0) return MR_OK;
-    if (!unit_grad || !unit_grad_max || !sums || !grad_loss_fwd || !tile_hit) return MR_ERR_BADARG;
+    if (!unit_grad || !unit_grad_max || !sums || !(grad_loss_fwd || grad_loss_sum || grad_mean) || !tile_hit) return MR_ERR_BADARG;
     if (height <= 0 || width < 2 || height > image_size || width > image_size || (int64_t)height * width > (1LL << 29))
         return MR_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
@@ -2770,6 +2768,7 @@ extern "C" int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, c
     while (sp.groups < 32 && sp.tiles_x * sp.tiles_y > 48 * sp.groups) sp.groups *= 2;
     switch ((flags >> 12) & 7) { case 1: sp.groups = 2; break; case 2: sp.groups = 4; break; case 3: sp.groups = 16; break; case 4: sp.groups = 32; break; case 5: sp.groups = 8; break; default: break; }
     sp.unit_grad = unit_grad; sp.unit_max = unit_grad_max; sp.sums = sums; sp.gl_fwd = grad_loss_fwd; sp.gl_bwd = grad_loss_bwd;
+    sp.gl_sum = grad_loss_sum; sp.gl_mean = grad_mean; sp.mean_div = (float)(batch_size / 2); sp.mean_of = mean_of;
     const int64_t blocks = (int64_t)batch_size * sp.groups;
     if (blocks > 0x7fffffffLL) return MR_ERR_BADARG;
     // (the covered-tile lists need the workgroup split's head room: grid > images; profiling bit 15 of flags: the listing form)
@@ -2781,6 +2780,20 @@ extern "C" int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, c
     }
     MR_CHECK_LAUNCH();
     return MR_OK;
+}
+
+extern "C" int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, const uint32_t* tile_hit,
+                                                const float* weight_map, const int32_t* vertex_id_map, const float* unit_grad,
+                                                const float* unit_grad_max, const float* sums, const float* grad_loss_fwd,
+                                                const float* grad_loss_bwd, int height, int width, float* grad_vcolors,
+                                                int batch_size, int num_verts, int num_faces, int fill_back, int image_size,
+                                                float eps, int flags, int texel_layout, const void* scatter_work,
+                                                mr_stream_t stream) {
+    if (!grad_loss_fwd && (int64_t)batch_size * num_verts > 0) return MR_ERR_BADARG;
+    return mr_flow_pair_backward_unit_tiles_ex(face_index_map, tile_hit, weight_map, vertex_id_map, unit_grad, unit_grad_max, sums,
+                                               grad_loss_fwd, grad_loss_bwd, nullptr, nullptr, 0, height, width, grad_vcolors,
+                                               batch_size, num_verts, num_faces, fill_back, image_size, eps, flags, texel_layout,
+                                               scatter_work, stream);
 }
 
 extern "C" int mr_pixel_map_terms(uint64_t* terms_host, int reset) {

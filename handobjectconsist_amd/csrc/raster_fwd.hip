@@ -59,10 +59,8 @@ constexpr int TPB = 256;              // threads per workgroup (4 waves)
 constexpr int NB = 32;                // faces per batch (stage S1: one lane per face).  48 and 64 were measured (one
                                       // batch per wave for the ~145 faces of a typical geometry tile): the larger face
                                       // cache costs occupancy (5 / 4 instead of 7 waves per SIMD) and the kernel gets slower
-constexpr int NBP2 = 32;              // next power of two
-constexpr int FC_STRIDE = 31;         // dwords per face-cache slot (odd: conflict-free ds_read_b32): v 9, inv 9, face index,
-                                      // box, refined reciprocals of the three depths, "division-safe" flag, and (round 6) per edge
-                                      // the tile-local pixel column where it crosses the tile's first row + its step per row
+constexpr int FC_STRIDE = 25;         // dwords per face-cache slot (odd: conflict-free ds_read_b32): v 9, inv 9, face index,
+                                      // box, refined reciprocals of the three depths, "division-safe" flag
 constexpr int FQCAP = 512;            // fragment ring capacity (>= 63 + 4 * 64, power of 2)
 
 // Per-image header written by bin_faces_kernel.
@@ -82,15 +80,45 @@ constexpr unsigned HEAVY_RECS = 128;  // swept 32 .. 256 on the metric workload:
 
 // {x0 | x1 << 16, y0 | y1 << 16, (virtual) face index, unused}
 typedef uint4 FaceRec;
-// Vertex-colour mode: the 9 coordinates of REAL face f0 (its own vertex order), dense array with a 48-B stride,
-// so that the tile kernel fetches a face with ONE load phase instead of chasing record -> vertex indices ->
-// vertices.  The reversed copy f0 + F0 is the same record read back to front.  (A 96-B record per live virtual
-// face that also carried the pixel-space inverse and the vertex ids was measured: its scattered partial-line
-// stores cost 12 us per launch and neither S1 nor the resolve step got faster -- they are latency-bound.)
+// Vertex-colour mode: the 9 coordinates of REAL face f0 (its own vertex order), dense array, so that the tile kernel fetches
+// a face with ONE load phase instead of chasing record -> vertex indices -> vertices.  The reversed copy f0 + F0 is the same
+// record read back to front.  Round 6: the record also carries the face's SET-UP -- the pixel-space inverse and the refined
+// reciprocals of the three depths -- for the orientation that is alive (a face and its reversed copy are never both
+// front-facing unless degenerate): S1 spent ~110 of its ~150 vector instructions per record on it, at half-filled waves, for
+// every tile a face touches, and the resolve step the same per covered pixel; the per-face pass computes it ONCE per face
+// with the same device functions (bit-identical).  96 B: {v[9], division-safe flag, orientation code, 0, inv[9], yz[3]};
+// code 0 / 1 = the set-up is that of the face as stored / of its reversed copy, 2 = none (both orientations alive: degenerate
+// faces -- the tile kernel computes it itself, as for any record whose code does not match the orientation it needs).
+// (Round 2 measured a 96-B record per live VIRTUAL face written by a kernel of its own: scattered partial-line stores, 12 us;
+// here consecutive threads write consecutive records.)
 struct __attribute__((aligned(16))) RecVerts {
-    float v[12];
+    float v[24];
 };
-static_assert(sizeof(RecVerts) == 48, "RecVerts is read as three float4");
+static_assert(sizeof(RecVerts) == 96, "RecVerts is read as six float4");
+
+// the record of real face `f` (9 coordinates, its own vertex order); live0 / live1: the face / its reversed copy has a box
+__device__ __forceinline__ void write_face_record(RecVerts* rec, const float* f, bool live0, bool live1, int is) {
+    float4* rv = reinterpret_cast<float4*>(rec);
+    const bool safe = division_safe_face(f, is);  // (may take the shared-reciprocal division paths, mr_common.hpp)
+    const int code = (live0 != live1) ? (live1 ? 1 : 0) : 2;
+    rv[0] = make_float4(f[0], f[1], f[2], f[3]);
+    rv[1] = make_float4(f[4], f[5], f[6], f[7]);
+    rv[2] = make_float4(f[8], safe ? 1.0f : 0.0f, (float)code, 0.0f);
+    if (code == 2) return;
+    float v[9], inv[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = f[code ? (2 - k / 3) * 3 + k % 3 : k];  // (reversed copy: vertices back to front)
+    float yz0 = 0.0f, yz1 = 0.0f, yz2 = 0.0f;
+    if (safe) {
+        face_inverse_shared(v, inv, is);
+        yz0 = rcp_refined(v[2]); yz1 = rcp_refined(v[5]); yz2 = rcp_refined(v[8]);
+    } else {
+        face_inverse(v, inv, is);
+    }
+    rv[3] = make_float4(inv[0], inv[1], inv[2], inv[3]);
+    rv[4] = make_float4(inv[4], inv[5], inv[6], inv[7]);
+    rv[5] = make_float4(inv[8], yz0, yz1, yz2);
+}
 
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -176,19 +204,14 @@ __global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
     const FaceBox b0 = face_box_orient<false>(f, is, sh);  // NaN / back-facing / off-screen -> empty
     FaceBox* box_b = p.boxes + (int64_t)b * p.F;
     box_b[f0] = b0;
-    bool live = b0.x0 <= b0.x1;
+    const bool live0 = b0.x0 <= b0.x1;
+    bool live1 = false;
     if (two) {
         const FaceBox b1 = face_box_orient<true>(f, is, sh);
         box_b[f0 + p.F0] = b1;
-        live = live || b1.x0 <= b1.x1;
+        live1 = b1.x0 <= b1.x1;
     }
-    if (VC && live && !(p.dbg & 16)) {
-        float4* rv = reinterpret_cast<float4*>(p.rverts + (int64_t)b * p.F0 + f0);
-        rv[0] = make_float4(f[0], f[1], f[2], f[3]);
-        rv[1] = make_float4(f[4], f[5], f[6], f[7]);
-        // (second float: the face may take the shared-reciprocal division paths of the tile kernel, mr_common.hpp)
-        rv[2] = make_float4(f[8], division_safe_face(f, is) ? 1.0f : 0.0f, 0.0f, 0.0f);
-    }
+    if (VC && (live0 || live1) && !(p.dbg & 16)) write_face_record(p.rverts + (int64_t)b * p.F0 + f0, f, live0, live1, is);
 }
 
 // Pass B, grid = B, block = BIN_TPB: ONE workgroup bins the boxes of an image to screen tiles entirely in LDS (no
@@ -290,18 +313,14 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
                 face_box_shared(f[k], p.is, sh);
                 const FaceBox b0 = face_box_orient<false>(f[k], p.is, sh);
                 sbox[j] = b0;
-                bool live = b0.x0 <= b0.x1;
+                const bool live0 = b0.x0 <= b0.x1;
+                bool live1 = false;
                 if (two) {
                     const FaceBox b1 = face_box_orient<true>(f[k], p.is, sh);
                     sbox[nr + j] = b1;
-                    live = live || b1.x0 <= b1.x1;
+                    live1 = b1.x0 <= b1.x1;
                 }
-                if (live) {
-                    float4* rv = reinterpret_cast<float4*>(p.rverts + (int64_t)b * p.F0 + r0 + j);
-                    rv[0] = make_float4(f[k][0], f[k][1], f[k][2], f[k][3]);
-                    rv[1] = make_float4(f[k][4], f[k][5], f[k][6], f[k][7]);
-                    rv[2] = make_float4(f[k][8], division_safe_face(f[k], p.is) ? 1.0f : 0.0f, 0.0f, 0.0f);
-                }
+                if (live0 || live1) write_face_record(p.rverts + (int64_t)b * p.F0 + r0 + j, f[k], live0, live1, p.is);
             }
         }
         __syncthreads();
@@ -590,23 +609,37 @@ struct FwdParams {
     int texel;                       // texel layout code of the vertex-colour texture (mr_common.hpp: texel_vertex)
 };
 
-// the 9 coordinates of (virtual) face fn in ONE load phase: from the faces tensor, or (VC) from the gathered
-// coordinates of real face fn mod F0, read back to front for the reversed copy
+// the 9 coordinates of (virtual) face fn and its SET-UP -- pixel-space inverse, refined reciprocals of the depths (yz, defined
+// when the return value, "division-safe", is true) -- in ONE load phase: the per-face pass's record of real face fn mod F0 (VC),
+// read back to front for the reversed copy; the set-up is the record's when it was computed for this orientation, else -- and
+// for the faces tensor of the generic path -- computed here, with the arithmetic the per-face pass uses (bit-identical).
 template <bool VC>
-__device__ __forceinline__ bool load_face_coords(const FwdParams& p, const RecVerts* rv_b, int b, int fn, float* v) {
+__device__ __forceinline__ bool load_face_setup(const FwdParams& p, const RecVerts* rv_b, int b, int fn, float* v, float* inv,
+                                                float* yz) {
     if (!VC) {
         const float* g = p.faces + ((int64_t)b * p.F + fn) * 9;
 #pragma unroll
         for (int k = 0; k < 9; k++) v[k] = g[k];
+        face_inverse(v, inv, p.is);
         return false;  // (the generic path keeps the plain divisions: no per-face pass has vetted its faces)
     } else {
         const bool rev = fn >= p.F0;
         const float4* rv = reinterpret_cast<const float4*>(rv_b + (rev ? fn - p.F0 : fn));
-        const float4 v0 = rv[0], v1 = rv[1], v2 = rv[2];
+        const float4 v0 = rv[0], v1 = rv[1], v2 = rv[2], q0 = rv[3], q1 = rv[4], q2 = rv[5];
         v[0] = rev ? v1.z : v0.x; v[1] = rev ? v1.w : v0.y; v[2] = rev ? v2.x : v0.z;
         v[3] = v0.w; v[4] = v1.x; v[5] = v1.y;
         v[6] = rev ? v0.x : v1.z; v[7] = rev ? v0.y : v1.w; v[8] = rev ? v0.z : v2.x;
-        return v2.y != 0.0f && !(p.dbg & 4096);  // division-safe (dbg 4096: plain divisions everywhere, for the A/B test)
+        const bool safe = v2.y != 0.0f && !(p.dbg & 4096);  // (dbg 4096: plain divisions everywhere, for the A/B test)
+        if (v2.z == (rev ? 1.0f : 0.0f) && !(p.dbg & 4096)) {
+            inv[0] = q0.x; inv[1] = q0.y; inv[2] = q0.z; inv[3] = q0.w; inv[4] = q1.x; inv[5] = q1.y; inv[6] = q1.z; inv[7] = q1.w;
+            inv[8] = q2.x; yz[0] = q2.y; yz[1] = q2.z; yz[2] = q2.w;
+        } else if (safe) {
+            face_inverse_shared(v, inv, p.is);
+            yz[0] = rcp_refined(v[2]); yz[1] = rcp_refined(v[5]); yz[2] = rcp_refined(v[8]);
+        } else {
+            face_inverse(v, inv, p.is);
+        }
+        return safe;
     }
 }
 
@@ -688,7 +721,10 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
     __shared__ float fcache[TPB / MR_WAVE][NB * FC_STRIDE];
     __shared__ unsigned short fragq[TPB / MR_WAVE][FQCAP];  // slot << 8 | row << 5 | x
     __shared__ float xp_tab[TILE_W], yp_tab[TILE_H];
-    __shared__ int rowoff[TPB / MR_WAVE][NB + 1];  // prefix sums of the batch's per-face row counts
+    // the (face, row) items of a wave's batch, in face order: slot | tile row << 5 (round 6; until then a table of the faces' row
+    // offsets that every item searched with five dependent LDS reads: -30 vector instructions per pass of 64 items)
+    __shared__ unsigned char itemtab[TPB / MR_WAVE][NB * TILE_H];
+    __shared__ int hitcnt[TPB / MR_WAVE];
 
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int b = lid / tiles_per_img;
@@ -749,7 +785,7 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
     auto rec_at = [&](int i) -> const FaceRec* { return recs_b + (i < n_bin ? off_bin : off_large) + i; };
     float* fc = fcache[wave];
     unsigned short* fq = fragq[wave];
-    int* ro = rowoff[wave];
+    unsigned char* itab = itemtab[wave];
 
     // S3: one lane per fragment -- barycentrics, near/far, depth test
     int fqh = 0, fqn = 0;  // fragment ring (wave-uniform)
@@ -776,19 +812,15 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
 
     auto process_batch = [&](int first, int count) {
         // S1: one lane per record
-        int nrows = 0;  // rows of the face's bbox inside this tile
+        int nrows = 0, row0 = 0;  // rows of the face's bbox inside this tile, the first of them
         if (lane < count && !(p.dbg & 4)) {
             const FaceRec r = *rec_at(first + lane);
             const int fn = (int)r.z;
             Face f;
-            const bool safe = load_face_coords<VC>(p, rv_b, b, fn, f.v);
+            float yz_[3] = {0.0f, 0.0f, 0.0f};
+            const bool safe = load_face_setup<VC>(p, rv_b, b, fn, f.v, f.inv, yz_);
             float* c = fc + lane * FC_STRIDE;
-            if (safe) {
-                face_inverse_shared(f.v, f.inv, is);
-                c[20] = rcp_refined(f.v[2]); c[21] = rcp_refined(f.v[5]); c[22] = rcp_refined(f.v[8]);
-            } else {
-                face_inverse(f.v, f.inv, is);
-            }
+            if (safe) { c[20] = yz_[0]; c[21] = yz_[1]; c[22] = yz_[2]; }
             c[23] = safe ? 1.0f : 0.0f;
 #pragma unroll
             for (int k = 0; k < 9; k++) { c[k] = f.v[k]; c[9 + k] = f.inv[k]; }
@@ -796,38 +828,16 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             const int y0 = max((int)(r.y & 0xffffu), ty0) - ty0, y1 = min((int)(r.y >> 16), ty1) - ty0;
             c[18] = __int_as_float(fn);
             c[19] = __int_as_float(x0 | (x1 << 8) | (y0 << 16) | (y1 << 24));
-            // S2's first probe per (edge, row): the column where the edge crosses the row, as a line in the row number --
-            // x(row) = c[24 + 2 k] + row * c[25 + 2 k], tile-local pixel units.  Edge k from vertex k: (xp - a_x) dy = (yp - a_y)
-            // dx, xp = a_x + (yp - a_y) dx / dy; yp advances by 2 / is per row, a pixel is 2 / is wide: the step is dx / dy
-            // columns per row.  It only has to land within a pixel (the exact predicate brackets the span around it); a
-            // horizontal edge gives Inf / NaN, which S2 maps to the row's last column (T is constant along the row then).
-            {
-                const float yp0 = yp_tab[0];
-                const float ex[3] = {f.v[3] - f.v[0], f.v[6] - f.v[3], f.v[0] - f.v[6]};
-                const float ey_[3] = {f.v[4] - f.v[1], f.v[7] - f.v[4], f.v[1] - f.v[7]};
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const float step = ex[k] * __builtin_amdgcn_rcpf(ey_[k]);
-                    const float xp_at0 = f.v[3 * k] + (yp0 - f.v[3 * k + 1]) * step;
-                    c[24 + 2 * k] = (xp_at0 * fis + fis - 1.0f) * 0.5f - (float)tx0;
-                    c[25 + 2 * k] = step;
-                }
-            }
             // (a record of the image's large list, or of a bin taller than a tile, may miss this tile)
             nrows = (x0 <= x1 && y0 <= y1) ? y1 - y0 + 1 : 0;
+            row0 = y0;
         }
         // (face, bbox row) items of the batch, compacted: exclusive prefix sum of the row counts -> the
         // S2 lanes take consecutive items, so a pass works on 64 real rows whatever the face sizes
         // (8 lanes per face would leave most of them idle for the 3 - 4-row faces of these meshes)
-        int incl = nrows;
-#pragma unroll
-        for (int off = 1; off < NBP2; off <<= 1) {
-            const int up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
-        }
-        if (lane < NB) ro[lane + 1] = incl;
-        if (lane == 0) ro[0] = 0;
-        const int n_items = __shfl(incl, NB - 1);
+        const int incl = wave_incl_sum(nrows);  // (six DPP adds; the lanes beyond the batch hold 0)
+        for (int r_ = 0; r_ < nrows; r_++) itab[incl - nrows + r_] = (unsigned char)(lane | ((row0 + r_) << 5));
+        const int n_items = __builtin_amdgcn_readlane(incl, NB - 1);
         __builtin_amdgcn_wave_barrier();
         if (p.dbg & (4 | 8)) return;
         // S2: one lane per (face, bbox row) item, 64 items per pass.  Along a row each edge test
@@ -839,25 +849,17 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
         for (int i0 = 0; i0 < n_items; i0 += MR_WAVE) {
             const int item = i0 + lane;
             bool act = item < n_items;
-            // slot = the face whose row range holds this item: largest k with ro[k] <= item (5 halvings of [0, NB))
-            int slot = 0;
-#pragma unroll
-            for (int step = NBP2 / 2; step >= 1; step >>= 1)
-                slot += (ro[min(slot + step, NB)] <= item && slot + step < NB) ? step : 0;
-            int row = 0;
+            const unsigned it_ = act ? (unsigned)itab[item] : 0u;
+            const int slot = (int)(it_ & 31u);
+            const int row = (int)(it_ >> 5);
             float ea[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, ey[3] = {0, 0, 0};
             int lx0 = 0, lx1 = -1;
-            float cross[6] = {0, 0, 0, 0, 0, 0}, frow = 0.0f;
             if (act) {
                 const float* c = fc + slot * FC_STRIDE;
-#pragma unroll
-                for (int k = 0; k < 6; k++) cross[k] = c[24 + k];
                 const int bb = __float_as_int(c[19]);
-                row = ((bb >> 16) & 0xff) + (item - ro[slot]);
                 const float ax = c[0], ay = c[1], bx = c[3], by = c[4], cx_ = c[6], cy_ = c[7];
                 lx0 = bb & 0xff; lx1 = (bb >> 8) & 0xff;
                 const float yp = yp_tab[row];
-                frow = (float)row;
                 ea[0] = ax; ea[1] = bx; ea[2] = cx_;
                 dy[0] = by - ay; dy[1] = cy_ - by; dy[2] = ay - cy_;
                 ey[0] = (yp - ay) * (bx - ax); ey[1] = (yp - by) * (cx_ - bx); ey[2] = (yp - cy_) * (ax - cx_);
@@ -876,10 +878,8 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             bool open_any = false;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                // (xp - a) dy = ey  ->  xp = a + ey / dy;  pixel index = (xp is + is - 1) / 2, tile-local: the line S1 left
-                // in the face cache (dbg 16384: the per-item closed form of rounds 2-5, for the A / B count)
-                const float xs = (p.dbg & 16384) ? ((ea[k] + ey[k] * __builtin_amdgcn_rcpf(dy[k])) * fis + fis - 1.0f) * 0.5f - (float)tx0
-                                                 : __builtin_fmaf(frow, cross[2 * k + 1], cross[2 * k]);
+                // (xp - a) dy = ey  ->  xp = a + ey / dy;  pixel index = (xp is + is - 1) / 2, tile-local
+                const float xs = ((ea[k] + ey[k] * __builtin_amdgcn_rcpf(dy[k])) * fis + fis - 1.0f) * 0.5f - (float)tx0;
                 // NaN (dy == 0) -> lx1: T is constant along the row then, the probe at the far end settles it
                 int c = (int)fminf(fmaxf(floorf(xs), (float)lx0), (float)lx1);
                 if (!(xs == xs)) c = lx1;
@@ -927,13 +927,8 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             constexpr int EMIT = 4;
             while (__ballot(len > 0) != 0ull) {
                 const int c = min(len, EMIT);
-                int incl = c;
-#pragma unroll
-                for (int off = 1; off < MR_WAVE; off <<= 1) {
-                    const int up = __shfl_up(incl, off);
-                    if (lane >= off) incl += up;
-                }
-                const int total = __shfl(incl, MR_WAVE - 1);
+                const int incl = wave_incl_sum(c);
+                const int total = __builtin_amdgcn_readlane(incl, MR_WAVE - 1);
                 const int at = fqh + fqn + incl - c;
                 const unsigned tag = ((unsigned)slot << 8) | ((unsigned)row << 5);
 #pragma unroll
@@ -1007,7 +1002,7 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
         bool active = hitpx;
         if (!(p.dbg & 8192)) {
             unsigned short* hlist = fragq[0];
-            int* hcnt = rowoff[0];
+            int* hcnt = hitcnt;
             const unsigned long long m = __ballot(hitpx);
             if (lane == 0) hcnt[wave] = __popcll(m);
             __syncthreads();
@@ -1038,19 +1033,13 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             fetch_verts<VC>(p, b, fn, f.v, vid);
             face_inverse(f.v, f.inv, is);
         } else {
-            safe = load_face_coords<VC>(p, rv_b, b, fn, f.v);
-            if (VC) {
+            if (VC) {  // (the vertex ids are requested with the record: one round trip)
                 const bool rev = fn >= p.F0;
                 const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + (rev ? fn - p.F0 : fn)) * 3;
                 const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
                 vid[0] = rev ? i2 : i0; vid[1] = i1; vid[2] = rev ? i0 : i2;
             }
-            if (safe) {
-                face_inverse_shared(f.v, f.inv, is);
-                yz[0] = rcp_refined(f.v[2]); yz[1] = rcp_refined(f.v[5]); yz[2] = rcp_refined(f.v[8]);
-            } else {
-                face_inverse(f.v, f.inv, is);
-            }
+            safe = load_face_setup<VC>(p, rv_b, b, fn, f.v, f.inv, yz);
         }
         // barycentrics of the winner, recomputed with the arithmetic of cover()
         float w[3], zp2;
@@ -1291,7 +1280,7 @@ __global__ void __launch_bounds__(256) face_inv_map_kernel(const float* __restri
     for (int k = 0; k < 9; k++) out[i * 9 + k] = inv[k];
 }
 
-// workspace layout: [B] ImageHdr | [B * nbins] BinHdr | [B * F] FaceBox | [B * REC_CAP * F] FaceRec | [B * F] RecVerts
+// workspace layout: [B] ImageHdr | [B * nbins] BinHdr | [B * F] FaceBox | [B * REC_CAP * F] FaceRec | [B * F / 2 .. B * F] RecVerts
 // | TileList | [B * tiles] tile ids    (every byte the tile kernel reads is written by the two setup kernels: no memset)
 struct WorkLayout {
     int nbx, nby, ysh;
@@ -1315,9 +1304,9 @@ static int device_cus() {
     return cus[dev] > 0 ? cus[dev] : 0;
 }
 constexpr int MAX_PARTS = MAX_PARTS_DEV, MAX_PART_CUS = 256;
-static int bin_parts(int B, int F, int cus) {
+static int bin_parts(int B, int F, int cus, int per_cu = 2) {
     int k = 1;
-    while (k < MAX_PARTS && (int64_t)B * k * 2 <= cus && F / (k * 2) >= 256) k *= 2;
+    while (k < MAX_PARTS && (int64_t)B * k * 2 <= (int64_t)per_cu * cus && F / (k * 2) >= 256) k *= 2;
     return k;
 }
 
@@ -1334,7 +1323,7 @@ static WorkLayout work_layout(int B, int F, int is) {
     w.off_boxes = w.off_bins + align256((size_t)B * w.nbx * w.nby * sizeof(BinHdr));
     w.off_recs = w.off_boxes + align256((size_t)B * F * sizeof(FaceBox));
     w.off_rverts = w.off_recs + align256((size_t)B * REC_CAP * F * sizeof(FaceRec));
-    w.off_tlist = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (VC needs F / 2 of it with fill-back)
+    w.off_tlist = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (one per REAL face: F / 2 of it with fill-back)
     // (the images' arrival counters sit right behind the list header: ONE region for the caller of MR_FLAG_TILE_LIST_CLEARED to clear)
     w.off_arrive = w.off_tlist + align256(sizeof(TileList));
     w.off_tile_ids = w.off_arrive + align256((size_t)B * ARRIVE_STRIDE * sizeof(unsigned));
@@ -1377,7 +1366,9 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     bp.F = F; bp.is = is; bp.nbx = w.nbx; bp.nby = w.nby; bp.ysh = w.ysh;
     const int nbins = w.nbx * w.nby;
     // parts per image (bin_boxes_kernel, PARTS): B x parts workgroups, all resident at once; dbg 32: one workgroup per image
-    int parts = (bp.dbg & 32) ? 1 : bin_parts(B, F, std::min(device_cus(), MAX_PART_CUS));
+    // (at most one workgroup per compute unit: two per compute unit -- dbg 64 -- were measured at 2B = 128: 37.7 us against
+    // 28.9 with two parts and 28.5 with one; config 3's 16 renders: 16 parts 23.1 us, one part 26.0)
+    int parts = (bp.dbg & 32) ? 1 : bin_parts(B, F, std::min(device_cus(), MAX_PART_CUS), (bp.dbg & 64) ? 2 : 1);
     if (parts > w.parts) parts = w.parts;
     bp.B = B; bp.parts = parts; bp.poll_add = 0;
     bp.part_cnt = (int*)(base + w.off_part_cnt);

@@ -802,7 +802,9 @@ __global__ void __launch_bounds__(256) pair_consist_finalize_tiles_kernel(const 
                                                                           float* __restrict__ loss_bwd,
                                                                           const unsigned* __restrict__ tile_max,
                                                                           unsigned* __restrict__ image_max,
-                                                                          float* __restrict__ loss_sum, ScatterWork work) {
+                                                                          float* __restrict__ loss_sum, ScatterWork work,
+                                                                          unsigned* __restrict__ mean_ctr,
+                                                                          float* __restrict__ mean_out, int mean_of) {
     __shared__ float red[4][4];
     __shared__ unsigned redm[4][2];
     __shared__ int wcov[2][4];
@@ -872,6 +874,32 @@ __global__ void __launch_bounds__(256) pair_consist_finalize_tiles_kernel(const 
         if (loss_fwd) loss_fwd[b] = a[0] / n1;
         if (loss_bwd) loss_bwd[b] = a[2] / n2;
         if (loss_sum) loss_sum[b] = a[2] / n2 + a[0] / n1;  // pair_consist's warp_loss with use_backward (imgflowarp.py:104-113)
+    }
+    if (mean_out) {  // (uniform)
+        // mr_pair_step_forward: the mean over the batch (warpbranch.py:87-88) by the workgroup that finishes LAST -- no launch of
+        // its own (a 64-lane kernel costs 4.8 us on the timeline).  A sample's value crosses workgroups in an agent-scope atomic
+        // store, the count in an agent-scope atomic add behind it (s_waitcnt in between: the store has completed), the last
+        // arriver reads all B values with agent-scope atomic loads and sums them in a FIXED order (lane-strided partial sums in
+        // index order, then a butterfly): the same bits whichever workgroup comes last.  The counter (a spare word of the render's
+        // tile-list header, cleared with it) is re-zeroed for the next call.
+        __shared__ int s_last_ws;
+        if (threadIdx.x == 0) {
+            const float n1 = (a[1] == 0.0f) ? 1.0f : a[1], n2 = (a[3] == 0.0f) ? 1.0f : a[3];
+            const float mine = mean_of ? a[0] / n1 : a[2] / n2 + a[0] / n1;
+            __hip_atomic_store(mean_out + 1 + b, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned old = __hip_atomic_fetch_add(mean_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last_ws = (old == (unsigned)B - 1u) ? 1 : 0;
+            if (s_last_ws) __hip_atomic_store(mean_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_last_ws && threadIdx.x < 64) {
+            float sacc = 0.0f;
+            for (int i = threadIdx.x; i < B; i += 64) sacc += __hip_atomic_load(mean_out + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sacc += __shfl_xor(sacc, off);
+            if (threadIdx.x == 0) mean_out[0] = sacc / (float)B;
+        }
     }
 }
 
@@ -1193,7 +1221,8 @@ extern "C" int mr_pair_consist_forward_tiles(const float* flow12, const float* f
     hipLaunchKernelGGL(pair_consist_finalize_tiles_kernel, dim3(batch_size), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit12),
                        reinterpret_cast<const uint32_t*>(tile_hit21), batch_size, p.tiles_x * p.tiles_y, sums, loss_fwd, loss_bwd,
-                       (const unsigned*)nullptr, (unsigned*)nullptr, (float*)nullptr, ScatterWork{nullptr, nullptr});
+                       (const unsigned*)nullptr, (unsigned*)nullptr, (float*)nullptr, ScatterWork{nullptr, nullptr},
+                       (unsigned*)nullptr, (float*)nullptr, 0);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1239,7 +1268,7 @@ static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_fl
                                    int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
                                    const void* list_header, const void* list_entries, int64_t list_capacity,
                                    int64_t tile_bound, float* unit_grad, float* unit_grad_max, float* loss_sum,
-                                   void* scatter_work, mr_stream_t stream) {
+                                   void* scatter_work, mr_stream_t stream, float* mean_out = nullptr, int mean_of = 0) {
     if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2 || !flow_out12 || !flow_out21)
         return MR_ERR_BADARG;
     if (batch_size < 0 || image_size <= 0 || flow_bstride < 2LL * image_size * image_size) return MR_ERR_BADARG;
@@ -1271,9 +1300,33 @@ static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_fl
                        reinterpret_cast<const uint32_t*>(tile_hit2), batch_size, tiles_x * tiles_y, sums, loss_fwd, loss_bwd,
                        unit_grad ? (const unsigned*)q.tile_max : (const unsigned*)nullptr,
                        unit_grad ? reinterpret_cast<unsigned*>(unit_grad_max) : (unsigned*)nullptr, loss_sum,
-                       scatter_work_at(unit_grad ? scatter_work : nullptr, 2 * batch_size));
+                       scatter_work_at(unit_grad ? scatter_work : nullptr, 2 * batch_size),
+                       // (the arrival counter of the batch mean: a spare word of the list header the caller cleared with it)
+                       mean_out ? const_cast<unsigned*>(&((const TileList*)list_header)->pad[0]) : (unsigned*)nullptr, mean_out, mean_of);
     MR_CHECK_LAUNCH();
     return MR_OK;
+}
+
+// mr_flow_pair_forward_grad_tiles + the mean over the batch (mr_pair_step_forward, pair_step.hip): mean_out[0] = the mean of
+// loss_bwd + loss_fwd (mean_of = 0) or of loss_fwd (1); mean_out[1 .. B] scratch.  The list header's spare words must have
+// been cleared with the header (MR_FLAG_TILE_LIST_CLEARED's region: the pair prologue does it).
+int mr_flow_pair_forward_grad_tiles_ex(const float* mask_flow1, const float* mask_flow2, const float* flow12, const float* flow21,
+                                       int64_t flow_bstride, const float* flow12_scale, const float* flow21_scale, float* occl1,
+                                       float* occl2, float* flow_out12, float* flow_out21, const uint8_t* tile_hit1,
+                                       const uint8_t* tile_hit2, const float* image_ref, const float* image, const float* jitter_ref,
+                                       const float* jitter, int jitter_channels, void* workspace, int64_t workspace_bytes,
+                                       float* sums, float* loss_fwd, float* loss_bwd, int batch_size, int image_size, int height,
+                                       int width, float distance_thresh, float warp_thresh, float pair_thresh, const void* list_header,
+                                       const void* list_entries, int64_t list_capacity, int64_t tile_bound, float* unit_grad,
+                                       float* unit_grad_max, float* loss_sum, void* scatter_work, float* mean_out, int mean_of,
+                                       mr_stream_t stream) {
+    if (!unit_grad || !unit_grad_max) return MR_ERR_BADARG;
+    return flow_pair_forward_tiles(mask_flow1, mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2,
+                                   flow_out12, flow_out21, tile_hit1, tile_hit2, image_ref, image, jitter_ref, jitter,
+                                   jitter_channels, workspace, workspace_bytes, sums, loss_fwd, loss_bwd, batch_size, image_size,
+                                   height, width, distance_thresh, warp_thresh, pair_thresh, list_header, list_entries,
+                                   list_capacity, tile_bound, unit_grad, unit_grad_max, loss_sum, scatter_work, stream, mean_out,
+                                   mean_of);
 }
 
 extern "C" int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,

@@ -67,6 +67,8 @@ def make_color_fn(jitter=True):
             sat, contrast, hue, bright = color_augm["sat"], color_augm["contrast"], color_augm["hue"], color_augm["bright"]
         if jitter:
             img = apply_jitter(img, brightness=bright, saturation=sat, hue=hue, contrast=contrast)
-        return np.asarray(img), {"sat": sat, "bright": bright, "contrast": contrast, "hue": hue}
+        # (np.array: a WRITABLE copy -- np.asarray of a PIL image is read-only, and unflipped samples hand that very array to
+        # collate / torch.from_numpy)
+        return np.array(img), {"sat": sat, "bright": bright, "contrast": contrast, "hue": hue}
 
     return color_fn

@@ -73,21 +73,24 @@ def _fused_pairs(samples, all_results, hand_face, gt_refs, first_only, renderer,
     ref_image, ref_jitter = _q(samples[0], "image").cuda(), _q(samples[0], "jittermask").cuda()
     parts = _frame_parts(samples, all_results, gt_refs, first_only)
     faces = (hand_face.cuda(), _q(samples[-1], "objfaces").cuda())  # (the LAST frame's faces, warpbranch.py:49-55)
-    losses, flows = [], []
+    losses, flows, means = [], [], []
     for k in range(1, len(samples)):
         res = opticalflow.flow_pair_loss([parts[0], parts[k]], faces, [cams[0], cams[k]], renderer, image_size,
                                          ref_image, _q(samples[k], "image").cuda(), ref_jitter,
-                                         _q(samples[k], "jittermask").cuda(), ignore_face_idxs=hand_ignore_faces, with_sum=True)
+                                         _q(samples[k], "jittermask").cuda(), ignore_face_idxs=hand_ignore_faces, with_sum=True,
+                                         with_mean="sum" if use_backward else "fwd")
         if res is None:
             return None if k == 1 else _raise_mixed()
-        loss_fwd, loss_bwd, pair_flows, loss_sum = res
+        loss_fwd, loss_bwd, pair_flows, loss_sum, mean = res
         losses.append(loss_sum if use_backward else loss_fwd)  # (loss_sum = loss_bwd + loss_fwd, formed by the node itself)
         flows.append(pair_flows)
-    # (one pair -- the trainer's setting --: the stack is a view, not a copy launch)
+        means.append(mean)
+    # (one pair -- the trainer's setting --: the stack is a view, not a copy launch, and the mean over the batch is the
+    # node's own output: warpbranch.py:87-88's stack(...).mean() without a reduction launch and its backward)
     diff_losses = losses[0].unsqueeze(0) if len(losses) == 1 else torch.stack(losses)
     none = [None] * len(losses)
-    return diff_losses.mean(), {"masks": none, "warps": list(none), "recons_flows": flows, "diffs": list(none),
-                                "diff_losses": diff_losses}
+    return (means[0] if len(means) == 1 else diff_losses.mean()), {"masks": none, "warps": list(none), "recons_flows": flows,
+                                                                  "diffs": list(none), "diff_losses": diff_losses}
 
 
 def _raise_mixed():

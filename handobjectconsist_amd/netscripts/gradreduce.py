@@ -43,8 +43,12 @@ for up to 2048 ranks) and is re-zeroed by the last bucket's launch in steps that
 The same code runs for every world size, including 1 (no short cut: the one-rank run is how the cost of the
 path is measured on a one-GPU box).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+_WAIT_EVERY_BUCKET = os.environ.get("HOC_REDUCER_WAIT_EVERY_BUCKET", "0") == "1"
 
 
 class _Bucket:
@@ -183,10 +187,15 @@ class BucketedGradReducer:
         ``p.grad`` = the rank-summed gradient of the pre-scaled loss = the mean gradient (a view into the bucket's flat buffer)."""
         for b in self.buckets[self._next:]:
             self._launch(b)
-        if self.backend == "nccl":
+        if self.backend == "nccl" and not _WAIT_EVERY_BUCKET:
             # RCCL runs a group's collectives on ONE stream in issue order: the last bucket's completion implies the others'.
             # One cross-stream wait instead of one per bucket (each is a barrier packet the compute queue stalls on: nine of
-            # them were most of the 0.65 ms this path cost a one-rank step, profiles/r04_one_rank_reducer_vs_plain.json)
+            # them were most of the 0.65 ms this path cost a one-rank step, profiles/r04_one_rank_reducer_vs_plain.json).
+            # That order is ProcessGroupNCCL's implementation, not its contract: the buckets are issued in list order by
+            # construction (`_launch` is only reached through `_next`), the last one issued is the last of the list -- asserted --
+            # and HOC_REDUCER_WAIT_EVERY_BUCKET=1 restores one wait per bucket (errors / time-outs of the earlier buckets then
+            # surface at their own wait instead of through the watchdog).
+            assert all(b.launched and b.work is not None for b in self.buckets), "a bucket was never issued"
             self.buckets[-1].work.wait()
         else:
             for b in self.buckets:

@@ -271,7 +271,8 @@ def _tiles_of(stacked):
     note = getattr(stacked, "_hoc_coverage", None) if stacked is not None else None
     if note is None or note[2] != stacked._version or len(note) < 4:
         return None
-    return note[3]
+    # (a one-element marker: flows of opticalflow.flow_pair_loss's struct path, whose tile list lived in reusable scratch)
+    return note[3] if (note[3] is not None and len(note[3]) >= 4) else None
 
 
 def pair_consist(

@@ -80,7 +80,8 @@ typedef void* mr_stream_t;
  * 6: mr_render_clear_bytes; MR_FLAG_TILE_LIST_CLEARED covers that many bytes (list header + the arrival counters of the
  *    binning pass's workgroups, several per image since round 5); mr_flow_pair_prologue_parts takes clear_bytes;
  * 7: scatter_work of mr_flow_pair_forward_grad_tiles / mr_flow_pair_backward_unit_tiles (the covered-tile lists the
- *    backward's workgroups are handed out over), mr_flow_pair_scatter_work_bytes. */
+ *    backward's workgroups are handed out over), mr_flow_pair_scatter_work_bytes;
+ * 8: mr_pair_step_* (the frame-pair step behind one argument struct), mr_pixel_map_terms. */
 #define MR_ABI_VERSION 8
 MR_API int mr_abi_version(void);
 /* 1 if the calling thread's CURRENT HIP device is a gfx950, else 0.
@@ -642,6 +643,57 @@ MR_API int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, const
                                             int height, int width, float* grad_vcolors, int batch_size, int num_verts,
                                             int num_faces, int fill_back, int image_size, float eps, int flags,
                                             int texel_layout, const void* scatter_work, mr_stream_t stream);
+
+/* ---- ABI 8: the frame-pair step of the training path behind ONE argument block ---------------------------------------
+ * What opticalflow.flow_pair_loss issues per frame pair -- mr_flow_pair_prologue_parts, mr_render_flow_forward
+ * (MR_FLAG_SPARSE_TILES | MR_FLAG_TILE_LIST_CLEARED, per-pixel records), mr_flow_pair_forward_grad_tiles and, in the backward
+ * pass, mr_flow_pair_backward_unit_tiles + mr_flow_vertices_parts_backward -- as TWO calls that take a pointer to one struct
+ * (round 5's five calls marshalled 30 - 60 scalars each through the caller's FFI: 0.47 - 0.55 ms of host time per pass for
+ * 0.17 ms of device work).  The struct is plain data: a caller fills the size fields once per shape, the pointers per call.
+ * Same kernels, same results as the five calls (opticalflow.py:51-156 + imgflowarp.py:58-115 + pyramidloss.py:56-62 +
+ * lossutils.py:1-8 for one pair with detach_renders=True), plus the mean over the batch that warpbranch.py:87-88 takes.
+ *   scratch: mr_pair_step_sizes' scratch_bytes; everything the forward's launches hand to one another (projected vertices,
+ *     stacked faces, the render's workspace and image planes, the occlusion maps, per-tile partials).  Nothing is read from
+ *     it after mr_pair_step_forward's launches: ONE buffer per stream can serve every call.
+ *   saved: saved_bytes; what mr_pair_step_backward reads (face index map, coverage words at tile_hit_offset -- [2B,
+ *     ceil(is/8), ceil(is/32), 4] bytes --, sampling weights, vertex ids, unit gradient and its bounds, per-sample sums,
+ *     covered-tile lists) and the gradient buffer the render's binning pass clears: one per differentiated forward call.
+ *   flows [2B,height,width,2]: flow12 then flow21, defined under covered tiles only (sparse contract above).
+ *   losses [4B + 1]: loss_fwd[B] | loss_bwd[B] | loss_bwd + loss_fwd [B] | mean over the batch of the third block
+ *     (mean_of = 0) or of the first (mean_of = 1: pair_consist without use_backward) | B words of scratch (the samples'
+ *     values on their way to the workgroup that forms the mean).
+ *   backward: grad_loss_fwd / grad_loss_bwd / grad_loss_sum [B] and grad_mean [1] are the incoming gradients of the four
+ *     blocks of `losses`, each nullable; the coefficient of a sample's direction is their sum (grad_mean / B for the mean).
+ *     grad_verts* nullable (not wanted); all four NULL: nothing to do.  The vertex-colour gradient buffer inside `saved` is
+ *     cleared by the FORWARD call (want_grad != 0) and consumed by the first backward call; a caller that differentiates the
+ *     same forward call again sets MR_PAIR_STEP_GRAD_BUFFER_USED in `flags` for the later calls (the buffer is then cleared
+ *     first).  flags bits 8 and up: profiling switches of the render (forward call only). */
+#define MR_PAIR_STEP_GRAD_BUFFER_USED 1
+typedef struct MrPairStep {
+    int32_t batch_size, num_verts_a, num_verts_b, num_hand_faces, num_obj_faces, hand_faces_batched;
+    int32_t fill_back, image_size, height, width, jitter_channels, cam_batched;
+    int32_t n_lut, bg_stride, texel_layout, want_grad, mean_of, flags;
+    float orig_size, near_, far_, eps, alpha_thresh, distance_thresh, warp_thresh, pair_thresh;
+    const float *verts1a, *verts1b, *verts2a, *verts2b, *K1, *K2, *R, *t, *dist_coeffs;
+    const int64_t *hand_faces, *obj_faces;
+    const float *keep_lut, *background, *image_ref, *image, *jitter_ref, *jitter;
+    void *scratch, *saved;
+    int64_t scratch_bytes, saved_bytes;
+    float *flows, *losses;
+    uint32_t* tile_count_out;
+    int64_t tile_bound;
+    const float *grad_loss_fwd, *grad_loss_bwd, *grad_loss_sum, *grad_mean;
+    float *grad_verts1a, *grad_verts1b, *grad_verts2a, *grad_verts2b;
+} MrPairStep;
+/* sizeof(MrPairStep) and the byte offset of every field in declaration order (at most `capacity` written; returns the
+ * number of fields): what a binding checks its own struct definition against. */
+MR_API int64_t mr_pair_step_struct_bytes(void);
+MR_API int mr_pair_step_field_offsets(int64_t* offsets, int capacity);
+/* Buffer sizes for the size fields of *step (pointers are not looked at); MR_ERR_NOTIMPL where the fused path does not apply
+ * (no tile list for this raster, image_size % 4, more than 2560 vertices). */
+MR_API int mr_pair_step_sizes(const MrPairStep* step, int64_t* scratch_bytes, int64_t* saved_bytes, int64_t* tile_hit_offset);
+MR_API int mr_pair_step_forward(const MrPairStep* step, mr_stream_t stream);
+MR_API int mr_pair_step_backward(const MrPairStep* step, mr_stream_t stream);
 
 /* ---- dataset pipeline: decoded frames -> network-input batch ------------------------------
  * One launch for a whole batch of what meshreg/datasets/handobjset.py:361-379 does per sample on the

@@ -70,6 +70,36 @@ def test_header_prototype_types_match_ctypes_table():
             assert kind(decl) is want, f"{name}: parameter {i} `{' '.join(decl.split())}` is bound as {want.__name__}"
 
 
+def test_pair_step_struct_layout_matches_the_binding():
+    """ABI 8: the one argument block of mr_pair_step_* as the library lays it out (size, offset of every field in declaration
+    order) against the ctypes Structure of warping/pairstep.py and against the header's field list; sizes need no device."""
+    from handobjectconsist_amd import _lib
+    from handobjectconsist_amd.warping import pairstep
+
+    lib = _lib.load()
+    assert ctypes.sizeof(pairstep.MrPairStep) == lib.mr_pair_step_struct_bytes()
+    fields = [f for f, _ in pairstep.MrPairStep._fields_]
+    offs = (ctypes.c_int64 * 128)()
+    assert lib.mr_pair_step_field_offsets(offs, 128) == len(fields)
+    assert [getattr(pairstep.MrPairStep, f).offset for f in fields] == list(offs[:len(fields)])
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct MrPairStep \{(.*?)\} MrPairStep;", src, flags=re.S).group(1)
+    decl_names = re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:,|;)", body)
+    assert decl_names == fields, "header and binding list the fields in different orders"
+    st = pairstep.MrPairStep()
+    for k, v in dict(batch_size=64, num_verts_a=778, num_verts_b=1002, num_hand_faces=1552, num_obj_faces=2000, fill_back=1,
+                     image_size=256, height=256, width=256, jitter_channels=3).items():
+        setattr(st, k, v)
+    sc, sv, th = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    assert lib.mr_pair_step_sizes(ctypes.byref(st), ctypes.byref(sc), ctypes.byref(sv), ctypes.byref(th)) == 0
+    px = 128 * 256 * 256
+    assert sv.value >= px * (4 + 12 + 12 + 8) and sc.value >= px * 4 * 6 and th.value == px * 4
+    st.image_size = 258  # (not a multiple of 4: the fused path does not apply)
+    st.height = st.width = 258
+    assert lib.mr_pair_step_sizes(ctypes.byref(st), ctypes.byref(sc), ctypes.byref(sv), ctypes.byref(th)) == -2
+    assert lib.mr_pair_step_forward(None, None) == -1 and lib.mr_pair_step_backward(None, None) == -1
+
+
 def test_argument_validation_needs_no_device():
     from handobjectconsist_amd import _lib
 

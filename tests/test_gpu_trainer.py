@@ -137,25 +137,29 @@ def test_metric_workload_warpbranch_against_reference_glue(cuda):
         assert results[1][name].grad is None, "the annotated frame must not receive a gradient"
 
 
-@pytest.mark.parametrize("unit", [True, False])
-def test_metric_workload_training_mode_against_the_reference(cuda, monkeypatch, unit):
+@pytest.mark.parametrize("mode", ["step", "unit", "recompute"])
+def test_metric_workload_training_mode_against_the_reference(cuda, monkeypatch, mode):
     """The same reference run against warpbranch.forward AS THE TRAINER CALLS IT (pair_outputs="loss"): the pair is one
-    fused node (opticalflow.flow_pair_loss) -- with the pair loss's gradient formed by the forward launch (``unit``, what
-    training runs) or recomputed by the backward launch -- on NaN-poisoned buffers.  Loss, per-sample pair losses and
+    fused node (opticalflow.flow_pair_loss) -- through the two struct calls of ABI 8 (``step``: what training runs), as the
+    node pair of rounds 4-5 with the pair loss's gradient formed by the forward launch (``unit``) or recomputed by the
+    backward launch (``recompute``) -- on NaN-poisoned buffers.  Loss, per-sample pair losses and
     d loss / d predicted vertices of frame 0 are the reference's; the flows are, wherever the reference's are non-zero."""
     from handobjectconsist_amd import _lib
     from handobjectconsist_amd.models import warpbranch
     from handobjectconsist_amd.optim.pyramidloss import PyramidCriterion
-    from handobjectconsist_amd.warping import opticalflow
+    from handobjectconsist_amd.warping import opticalflow, pairstep
 
     z, m = load("chain_metric.npz")
     B, is_ = m["batch"], m["image_size"]
     s, images, jitters = _metric_scene(z, m)
+    unit = mode != "recompute"
     monkeypatch.setattr(opticalflow, "USE_UNIT_GRADIENT", unit)
+    monkeypatch.setattr(opticalflow, "USE_PAIR_STEP", mode == "step")
     monkeypatch.setattr(opticalflow, "DEBUG_POISON_RENDER_OUTPUTS", True)
     calls = []
-    real_call = _lib.call
+    real_call, real_step = _lib.call, pairstep.pair_step
     monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), real_call(name, *a))[1])
+    monkeypatch.setattr(pairstep, "pair_step", lambda *a, **k: (calls.append("pair_step"), real_step(*a, **k))[1])
     samples, results = [], []
     for k in (0, 1):
         f = "12"[k]
@@ -170,7 +174,10 @@ def test_metric_workload_training_mode_against_the_reference(cuda, monkeypatch, 
     loss.backward()
     fwd, bwd = (("mr_flow_pair_forward_grad_tiles", "mr_flow_pair_backward_unit_tiles") if unit
                 else ("mr_flow_pair_forward_tiles", "mr_flow_pair_backward_tiles"))
-    assert fwd in calls and bwd in calls, "the trainer's setting must take the fused pair node"
+    if mode == "step":
+        assert "pair_step" in calls and fwd not in calls, "the trainer's setting must take the struct path"
+    else:
+        assert fwd in calls and bwd in calls and "pair_step" not in calls, "the trainer's setting must take the fused pair node"
     assert all(x is None for x in pair["masks"]) and all(x is None for x in pair["warps"])  # nothing per-pixel in this mode
     for d in (0, 1):
         got = n(pair["recons_flows"][0][d]).reshape(-1, 2)

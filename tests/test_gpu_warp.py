@@ -855,6 +855,74 @@ def test_scatter_work_lists_equal_the_listing_form(cuda, monkeypatch, B, is_, sh
             assert float(a[B - 1].abs().sum()) == 0.0, "an off-screen mesh has no gradient"
 
 
+@pytest.mark.parametrize("B,is_,H,Wd,Cj,batched_hand", [(3, 256, 256, 256, 3, False), (2, 96, 64, 80, 1, True), (1, 480, 270, 480, 3, False),
+                                                       (5, 128, 128, 128, 1, False)])
+def test_pair_step_equals_the_node_pair(cuda, monkeypatch, B, is_, H, Wd, Cj, batched_hand):
+    """ABI 8: flow_pair_loss on (hand, object) parts through mr_pair_step_forward / _backward (ONE struct call each way, one
+    autograd node, scratch kept by the plan: warping/pairstep.py) against the node pair it replaces on the host
+    (_FlowVertexStageParts + _FlowPairLossFunction, five calls): the same launches, so losses, flows under the covered tiles
+    and coverage bytes bit for bit; the vertex gradients of both parts to the order of the backward's fp32 atomics; the batch
+    mean against torch.mean of the per-sample losses.  NaN / 0xff-poisoned buffers; two passes through the SAME plan (the scratch
+    of the first pass is reused by the second); gradients through loss_fwd, loss_bwd, their sum and the mean at once; a second
+    backward through one forward call (retain_graph: the gradient buffer is no longer the one the forward cleared)."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.warping import opticalflow, pairstep
+
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
+                   no_light=True, light_intensity_ambient=0.8)
+    monkeypatch.setattr(opticalflow, "DEBUG_POISON_RENDER_OUTPUTS", True)
+    wf, wb = torch.linspace(0.5, 1.5, B, device=cuda), torch.linspace(2.0, 0.25, B, device=cuda)
+    ws = torch.linspace(-0.5, 0.75, B, device=cuda)
+    steps = []
+    real_step = pairstep.pair_step
+    monkeypatch.setattr(pairstep, "pair_step", lambda *a, **k: (steps.append(1), real_step(*a, **k))[1])
+
+    def run(seed, step, mean_kind="sum", twice=False):
+        monkeypatch.setattr(opticalflow, "USE_PAIR_STEP", step)
+        s = synth.random_scene(B, seed=seed, image_size=is_)
+        im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, H, Wd, seed + 1)]
+        jm_ref, jm = jm_ref[:, :Cj].contiguous(), jm[:, :Cj].contiguous()
+        hand_faces = t(s["hand_faces"].astype(np.int64), cuda)
+        if batched_hand:
+            hand_faces = hand_faces[None].repeat(B, 1, 1)
+        obj_faces = t(s["obj_faces"].astype(np.int64)[None].repeat(B, 0), cuda)
+        leaves = [t(s[k], cuda).requires_grad_(True) for k in ("hand_verts1", "obj_verts1", "hand_verts2", "obj_verts2")]
+        res = opticalflow.flow_pair_loss([(leaves[0], leaves[1]), (leaves[2], leaves[3])], (hand_faces, obj_faces),
+                                         [t(s["K1"], cuda), t(s["K2"], cuda)], ren, (Wd, H), im_ref, im, jm_ref, jm,
+                                         ignore_face_idxs=synth.HAND_IGNORE_FACES, with_sum=True, with_mean=mean_kind)
+        assert res is not None
+        lf, lb, flows, lsum, mean = res
+        total = (lf * wf).sum() + (lb * wb).sum() + (lsum * ws).sum() + 3.0 * mean
+        grads = torch.autograd.grad(total, leaves, retain_graph=twice)
+        if twice:
+            again = torch.autograd.grad(total, leaves)
+            for g, g2 in zip(grads, again):
+                close(g2.cpu().numpy(), g.cpu().numpy(), 1e-5, 1e-6 * float(g.abs().max()) + 1e-30, "second backward through one forward")
+        base = flows[0]._base
+        hit = base._hoc_coverage[0]
+        words = hit.contiguous().view(torch.int32).view(2 * B, (is_ + 7) // 8, (is_ + 31) // 32).cpu().numpy() != 0
+        yy, xx = np.mgrid[0:H, 0:Wd]
+        defined = torch.from_numpy(words[:, (is_ - 1 - yy) >> 3, xx >> 5]).to(cuda)
+        assert torch.isnan(base.detach()[~defined]).all(), "nothing is written under uncovered tiles"
+        return lf.detach(), lb.detach(), lsum.detach(), base.detach()[defined], hit.clone(), mean.detach(), grads
+
+    for seed, mean_kind, twice in ((31, "sum", False), (32, "fwd", True)):
+        del steps[:]
+        got = run(seed, True, mean_kind, twice)
+        assert steps, "the struct path must have been taken"
+        del steps[:]
+        ref = run(seed, False, mean_kind)
+        assert not steps
+        for x, y, what in zip(got[:5], ref[:5], ("loss_fwd", "loss_bwd", "loss_bwd + loss_fwd", "flows", "coverage bytes")):
+            assert torch.equal(x, y), (what, seed)
+        assert float(ref[0].abs().sum()) > 0
+        assert abs(float(got[5]) - float(ref[5])) <= 2e-6 * max(abs(float(ref[5])), 1e-12), "batch mean"
+        for x, y, what in zip(got[6], ref[6], ("hand 1", "object 1", "hand 2", "object 2")):
+            assert torch.isfinite(x).all() and float(y.abs().sum()) > 0, what
+            close(x.cpu().numpy(), y.cpu().numpy(), 1e-5, 1e-6 * float(y.abs().max()), "d/d vertices of " + what)
+
+
 @pytest.mark.parametrize("B,is_", [(2, 96), (3, 256), (1, 480)])
 def test_per_face_pass_inside_the_binning_pass(cuda, monkeypatch, B, is_):
     """flow_pair_loss on (hand, object) parts: the pair prologue clears the header of the render's tile list and the render
@@ -891,6 +959,8 @@ def test_per_face_pass_inside_the_binning_pass(cuda, monkeypatch, B, is_):
         return real_call(name, *a)
 
     monkeypatch.setattr(_lib, "call", spy)
+
+    monkeypatch.setattr(opticalflow, "USE_PAIR_STEP", False)  # (the node pair's five calls: the struct path has its own test below)
 
     def run(fused_records):
         monkeypatch.setattr(opticalflow, "USE_FUSED_RECORDS", fused_records)
