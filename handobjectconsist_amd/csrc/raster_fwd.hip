@@ -80,45 +80,19 @@ constexpr unsigned HEAVY_RECS = 128;  // swept 32 .. 256 on the metric workload:
 
 // {x0 | x1 << 16, y0 | y1 << 16, (virtual) face index, unused}
 typedef uint4 FaceRec;
-// Vertex-colour mode: the 9 coordinates of REAL face f0 (its own vertex order), dense array, so that the tile kernel fetches
-// a face with ONE load phase instead of chasing record -> vertex indices -> vertices.  The reversed copy f0 + F0 is the same
-// record read back to front.  Round 6: the record also carries the face's SET-UP -- the pixel-space inverse and the refined
-// reciprocals of the three depths -- for the orientation that is alive (a face and its reversed copy are never both
-// front-facing unless degenerate): S1 spent ~110 of its ~150 vector instructions per record on it, at half-filled waves, for
-// every tile a face touches, and the resolve step the same per covered pixel; the per-face pass computes it ONCE per face
-// with the same device functions (bit-identical).  96 B: {v[9], division-safe flag, orientation code, 0, inv[9], yz[3]};
-// code 0 / 1 = the set-up is that of the face as stored / of its reversed copy, 2 = none (both orientations alive: degenerate
-// faces -- the tile kernel computes it itself, as for any record whose code does not match the orientation it needs).
-// (Round 2 measured a 96-B record per live VIRTUAL face written by a kernel of its own: scattered partial-line stores, 12 us;
-// here consecutive threads write consecutive records.)
+// Vertex-colour mode: the 9 coordinates of REAL face f0 (its own vertex order), dense array with a 48-B stride,
+// so that the tile kernel fetches a face with ONE load phase instead of chasing record -> vertex indices ->
+// vertices.  The reversed copy f0 + F0 is the same record read back to front.  (A 96-B record per live virtual
+// face that also carried the pixel-space inverse and the vertex ids was measured in round 2: its scattered partial-line
+// stores cost 12 us per launch and neither S1 nor the resolve step got faster -- they are latency-bound.  Round 6 measured
+// it again with the set-up -- inverse + depth reciprocals of the live orientation -- written by the per-face pass inside the
+// binning kernel, coalesced: the tile kernel's vector instructions fell from 27.8 M to 24.2 M per launch (S1 4.5 -> 2.4,
+// resolve 6.3 -> 5.0) and its duration from 62.5 to 61.7 us, while the binning kernel, which IS issue-bound on the 128
+// compute units it occupies, went from 28.5 to 37.2 us: profiles/r06_face_setup_records_experiment.txt.)
 struct __attribute__((aligned(16))) RecVerts {
-    float v[24];
+    float v[12];
 };
-static_assert(sizeof(RecVerts) == 96, "RecVerts is read as six float4");
-
-// the record of real face `f` (9 coordinates, its own vertex order); live0 / live1: the face / its reversed copy has a box
-__device__ __forceinline__ void write_face_record(RecVerts* rec, const float* f, bool live0, bool live1, int is) {
-    float4* rv = reinterpret_cast<float4*>(rec);
-    const bool safe = division_safe_face(f, is);  // (may take the shared-reciprocal division paths, mr_common.hpp)
-    const int code = (live0 != live1) ? (live1 ? 1 : 0) : 2;
-    rv[0] = make_float4(f[0], f[1], f[2], f[3]);
-    rv[1] = make_float4(f[4], f[5], f[6], f[7]);
-    rv[2] = make_float4(f[8], safe ? 1.0f : 0.0f, (float)code, 0.0f);
-    if (code == 2) return;
-    float v[9], inv[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) v[k] = f[code ? (2 - k / 3) * 3 + k % 3 : k];  // (reversed copy: vertices back to front)
-    float yz0 = 0.0f, yz1 = 0.0f, yz2 = 0.0f;
-    if (safe) {
-        face_inverse_shared(v, inv, is);
-        yz0 = rcp_refined(v[2]); yz1 = rcp_refined(v[5]); yz2 = rcp_refined(v[8]);
-    } else {
-        face_inverse(v, inv, is);
-    }
-    rv[3] = make_float4(inv[0], inv[1], inv[2], inv[3]);
-    rv[4] = make_float4(inv[4], inv[5], inv[6], inv[7]);
-    rv[5] = make_float4(inv[8], yz0, yz1, yz2);
-}
+static_assert(sizeof(RecVerts) == 48, "RecVerts is read as three float4");
 
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -204,14 +178,19 @@ __global__ void __launch_bounds__(256) face_records_kernel(BinParams p) {
     const FaceBox b0 = face_box_orient<false>(f, is, sh);  // NaN / back-facing / off-screen -> empty
     FaceBox* box_b = p.boxes + (int64_t)b * p.F;
     box_b[f0] = b0;
-    const bool live0 = b0.x0 <= b0.x1;
-    bool live1 = false;
+    bool live = b0.x0 <= b0.x1;
     if (two) {
         const FaceBox b1 = face_box_orient<true>(f, is, sh);
         box_b[f0 + p.F0] = b1;
-        live1 = b1.x0 <= b1.x1;
+        live = live || b1.x0 <= b1.x1;
     }
-    if (VC && (live0 || live1) && !(p.dbg & 16)) write_face_record(p.rverts + (int64_t)b * p.F0 + f0, f, live0, live1, is);
+    if (VC && live && !(p.dbg & 16)) {
+        float4* rv = reinterpret_cast<float4*>(p.rverts + (int64_t)b * p.F0 + f0);
+        rv[0] = make_float4(f[0], f[1], f[2], f[3]);
+        rv[1] = make_float4(f[4], f[5], f[6], f[7]);
+        // (second float: the face may take the shared-reciprocal division paths of the tile kernel, mr_common.hpp)
+        rv[2] = make_float4(f[8], division_safe_face(f, is) ? 1.0f : 0.0f, 0.0f, 0.0f);
+    }
 }
 
 // Pass B, grid = B, block = BIN_TPB: ONE workgroup bins the boxes of an image to screen tiles entirely in LDS (no
@@ -313,14 +292,18 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
                 face_box_shared(f[k], p.is, sh);
                 const FaceBox b0 = face_box_orient<false>(f[k], p.is, sh);
                 sbox[j] = b0;
-                const bool live0 = b0.x0 <= b0.x1;
-                bool live1 = false;
+                bool live = b0.x0 <= b0.x1;
                 if (two) {
                     const FaceBox b1 = face_box_orient<true>(f[k], p.is, sh);
                     sbox[nr + j] = b1;
-                    live1 = b1.x0 <= b1.x1;
+                    live = live || b1.x0 <= b1.x1;
                 }
-                if (live0 || live1) write_face_record(p.rverts + (int64_t)b * p.F0 + r0 + j, f[k], live0, live1, p.is);
+                if (live) {
+                    float4* rv = reinterpret_cast<float4*>(p.rverts + (int64_t)b * p.F0 + r0 + j);
+                    rv[0] = make_float4(f[k][0], f[k][1], f[k][2], f[k][3]);
+                    rv[1] = make_float4(f[k][4], f[k][5], f[k][6], f[k][7]);
+                    rv[2] = make_float4(f[k][8], division_safe_face(f[k], p.is) ? 1.0f : 0.0f, 0.0f, 0.0f);
+                }
             }
         }
         __syncthreads();
@@ -609,37 +592,23 @@ struct FwdParams {
     int texel;                       // texel layout code of the vertex-colour texture (mr_common.hpp: texel_vertex)
 };
 
-// the 9 coordinates of (virtual) face fn and its SET-UP -- pixel-space inverse, refined reciprocals of the depths (yz, defined
-// when the return value, "division-safe", is true) -- in ONE load phase: the per-face pass's record of real face fn mod F0 (VC),
-// read back to front for the reversed copy; the set-up is the record's when it was computed for this orientation, else -- and
-// for the faces tensor of the generic path -- computed here, with the arithmetic the per-face pass uses (bit-identical).
+// the 9 coordinates of (virtual) face fn in ONE load phase: from the faces tensor, or (VC) from the gathered
+// coordinates of real face fn mod F0, read back to front for the reversed copy
 template <bool VC>
-__device__ __forceinline__ bool load_face_setup(const FwdParams& p, const RecVerts* rv_b, int b, int fn, float* v, float* inv,
-                                                float* yz) {
+__device__ __forceinline__ bool load_face_coords(const FwdParams& p, const RecVerts* rv_b, int b, int fn, float* v) {
     if (!VC) {
         const float* g = p.faces + ((int64_t)b * p.F + fn) * 9;
 #pragma unroll
         for (int k = 0; k < 9; k++) v[k] = g[k];
-        face_inverse(v, inv, p.is);
         return false;  // (the generic path keeps the plain divisions: no per-face pass has vetted its faces)
     } else {
         const bool rev = fn >= p.F0;
         const float4* rv = reinterpret_cast<const float4*>(rv_b + (rev ? fn - p.F0 : fn));
-        const float4 v0 = rv[0], v1 = rv[1], v2 = rv[2], q0 = rv[3], q1 = rv[4], q2 = rv[5];
+        const float4 v0 = rv[0], v1 = rv[1], v2 = rv[2];
         v[0] = rev ? v1.z : v0.x; v[1] = rev ? v1.w : v0.y; v[2] = rev ? v2.x : v0.z;
         v[3] = v0.w; v[4] = v1.x; v[5] = v1.y;
         v[6] = rev ? v0.x : v1.z; v[7] = rev ? v0.y : v1.w; v[8] = rev ? v0.z : v2.x;
-        const bool safe = v2.y != 0.0f && !(p.dbg & 4096);  // (dbg 4096: plain divisions everywhere, for the A/B test)
-        if (v2.z == (rev ? 1.0f : 0.0f) && !(p.dbg & 4096)) {
-            inv[0] = q0.x; inv[1] = q0.y; inv[2] = q0.z; inv[3] = q0.w; inv[4] = q1.x; inv[5] = q1.y; inv[6] = q1.z; inv[7] = q1.w;
-            inv[8] = q2.x; yz[0] = q2.y; yz[1] = q2.z; yz[2] = q2.w;
-        } else if (safe) {
-            face_inverse_shared(v, inv, p.is);
-            yz[0] = rcp_refined(v[2]); yz[1] = rcp_refined(v[5]); yz[2] = rcp_refined(v[8]);
-        } else {
-            face_inverse(v, inv, p.is);
-        }
-        return safe;
+        return v2.y != 0.0f && !(p.dbg & 4096);  // division-safe (dbg 4096: plain divisions everywhere, for the A/B test)
     }
 }
 
@@ -817,10 +786,14 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             const FaceRec r = *rec_at(first + lane);
             const int fn = (int)r.z;
             Face f;
-            float yz_[3] = {0.0f, 0.0f, 0.0f};
-            const bool safe = load_face_setup<VC>(p, rv_b, b, fn, f.v, f.inv, yz_);
+            const bool safe = load_face_coords<VC>(p, rv_b, b, fn, f.v);
             float* c = fc + lane * FC_STRIDE;
-            if (safe) { c[20] = yz_[0]; c[21] = yz_[1]; c[22] = yz_[2]; }
+            if (safe) {
+                face_inverse_shared(f.v, f.inv, is);
+                c[20] = rcp_refined(f.v[2]); c[21] = rcp_refined(f.v[5]); c[22] = rcp_refined(f.v[8]);
+            } else {
+                face_inverse(f.v, f.inv, is);
+            }
             c[23] = safe ? 1.0f : 0.0f;
 #pragma unroll
             for (int k = 0; k < 9; k++) { c[k] = f.v[k]; c[9 + k] = f.inv[k]; }
@@ -1033,13 +1006,19 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             fetch_verts<VC>(p, b, fn, f.v, vid);
             face_inverse(f.v, f.inv, is);
         } else {
-            if (VC) {  // (the vertex ids are requested with the record: one round trip)
+            safe = load_face_coords<VC>(p, rv_b, b, fn, f.v);
+            if (VC) {
                 const bool rev = fn >= p.F0;
                 const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + (rev ? fn - p.F0 : fn)) * 3;
                 const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
                 vid[0] = rev ? i2 : i0; vid[1] = i1; vid[2] = rev ? i0 : i2;
             }
-            safe = load_face_setup<VC>(p, rv_b, b, fn, f.v, f.inv, yz);
+            if (safe) {
+                face_inverse_shared(f.v, f.inv, is);
+                yz[0] = rcp_refined(f.v[2]); yz[1] = rcp_refined(f.v[5]); yz[2] = rcp_refined(f.v[8]);
+            } else {
+                face_inverse(f.v, f.inv, is);
+            }
         }
         // barycentrics of the winner, recomputed with the arithmetic of cover()
         float w[3], zp2;
@@ -1280,7 +1259,7 @@ __global__ void __launch_bounds__(256) face_inv_map_kernel(const float* __restri
     for (int k = 0; k < 9; k++) out[i * 9 + k] = inv[k];
 }
 
-// workspace layout: [B] ImageHdr | [B * nbins] BinHdr | [B * F] FaceBox | [B * REC_CAP * F] FaceRec | [B * F / 2 .. B * F] RecVerts
+// workspace layout: [B] ImageHdr | [B * nbins] BinHdr | [B * F] FaceBox | [B * REC_CAP * F] FaceRec | [B * F] RecVerts
 // | TileList | [B * tiles] tile ids    (every byte the tile kernel reads is written by the two setup kernels: no memset)
 struct WorkLayout {
     int nbx, nby, ysh;
@@ -1323,7 +1302,7 @@ static WorkLayout work_layout(int B, int F, int is) {
     w.off_boxes = w.off_bins + align256((size_t)B * w.nbx * w.nby * sizeof(BinHdr));
     w.off_recs = w.off_boxes + align256((size_t)B * F * sizeof(FaceBox));
     w.off_rverts = w.off_recs + align256((size_t)B * REC_CAP * F * sizeof(FaceRec));
-    w.off_tlist = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (one per REAL face: F / 2 of it with fill-back)
+    w.off_tlist = w.off_rverts + align256((size_t)B * F * sizeof(RecVerts));  // (VC needs F / 2 of it with fill-back)
     // (the images' arrival counters sit right behind the list header: ONE region for the caller of MR_FLAG_TILE_LIST_CLEARED to clear)
     w.off_arrive = w.off_tlist + align256(sizeof(TileList));
     w.off_tile_ids = w.off_arrive + align256((size_t)B * ARRIVE_STRIDE * sizeof(unsigned));
