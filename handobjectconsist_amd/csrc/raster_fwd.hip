@@ -858,6 +858,8 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
                 if (!(xs == xs)) c = lx1;
                 // straight-line first round: the exact predicate at c and c + 1 (the crossing is almost always
                 // between them); whatever this leaves open goes to the general bracketing loop below
+                // (measured and dropped in round 6: for power-of-two rasters, the pixel centres by arithmetic -- (2 x + 1 - is) times the
+                // exact reciprocal, the same bits -- instead of the two LDS reads that wait for c: 62.2 -> 63.1 us)
                 const float xp0 = xp_tab[c & (TILE_W - 1)], xp1 = xp_tab[(c + 1) & (TILE_W - 1)];
                 const bool t0 = (!(ey[k] < (xp0 - ea[k]) * dy[k])) != dec[k];
                 const bool t1 = c < lx1 && ((!(ey[k] < (xp1 - ea[k]) * dy[k])) != dec[k]);

@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(256) pair_consist_finalize_tiles_kernel(const 
                                                                           float* __restrict__ mean_out, int mean_of) {
     __shared__ float red[4][4];
     __shared__ unsigned redm[4][2];
-    __shared__ int wcov[2][4];
+    __shared__ int wcov[2][4][4];  // [direction][round of the chunk][wave]
     const int b = blockIdx.x;
     float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     unsigned m12 = 0u, m21 = 0u;  // largest unit-gradient magnitude (float bits) of stack images b and B + b
@@ -816,30 +816,53 @@ __global__ void __launch_bounds__(256) pair_consist_finalize_tiles_kernel(const 
         // launch (ScatterWork, mr_common.hpp): this workgroup holds the coverage words of both anyway
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         int base12 = 0, base21 = 0;
-        for (int t0 = 0; t0 < T; t0 += 256) {
-            const int t = t0 + (int)threadIdx.x;
-            const bool in = t < T;
-            const int tc = in ? t : T - 1;
-            const uint32_t h21 = hit21[(int64_t)b * T + tc], h12 = hit12[(int64_t)b * T + tc];
-            const float2 v1 = *reinterpret_cast<const float2*>(partial + ((int64_t)(B + b) * T + tc) * 2);
-            const float2 v2 = *reinterpret_cast<const float2*>(partial + ((int64_t)b * T + tc) * 2);
-            unsigned t21 = 0u, t12 = 0u;
-            if (tile_max) { t21 = tile_max[(int64_t)(B + b) * T + tc]; t12 = tile_max[(int64_t)b * T + tc]; }
-            const bool c21 = in && h21 != 0u, c12 = in && h12 != 0u;
-            if (c21) { a[0] += v1.x; a[1] += v1.y; m21 = max(m21, t21); }
-            if (c12) { a[2] += v2.x; a[3] += v2.y; m12 = max(m12, t12); }
-            const unsigned long long k12 = __ballot(c12), k21 = __ballot(c21);
-            if (lane == 0) { wcov[0][wave] = __popcll(k12); wcov[1][wave] = __popcll(k21); }
-            __syncthreads();
-            int o12 = base12, o21 = base21;
+        // FIN_CH rounds of 256 tiles at a time: their words / partials are requested together and ONE barrier pair serves them
+        // (round 6; a round per barrier pair before: 4 rounds of dependent loads and 8 barriers at 480 x 480, 7.0 us for the 8
+        // workgroups of config 3).  The order of the sums (round by round per thread) and of the lists (ascending) is unchanged.
+        constexpr int FIN_CH = 4;
+        for (int t0 = 0; t0 < T; t0 += 256 * FIN_CH) {
+            uint32_t h21[FIN_CH], h12[FIN_CH];
+            float2 v1[FIN_CH], v2[FIN_CH];
+            unsigned t21[FIN_CH], t12[FIN_CH];
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                o12 += w < wave ? wcov[0][w] : 0; o21 += w < wave ? wcov[1][w] : 0;
-                base12 += wcov[0][w]; base21 += wcov[1][w];
+            for (int u = 0; u < FIN_CH; u++) {
+                h21[u] = 0u; h12[u] = 0u; v1[u] = make_float2(0.0f, 0.0f); v2[u] = v1[u]; t21[u] = 0u; t12[u] = 0u;
+                if (t0 + u * 256 >= T) continue;  // (uniform: a 256-tile raster is ONE round, as before)
+                const int t = t0 + u * 256 + (int)threadIdx.x;
+                const int tc = t < T ? t : T - 1;
+                h21[u] = hit21[(int64_t)b * T + tc]; h12[u] = hit12[(int64_t)b * T + tc];
+                v1[u] = *reinterpret_cast<const float2*>(partial + ((int64_t)(B + b) * T + tc) * 2);
+                v2[u] = *reinterpret_cast<const float2*>(partial + ((int64_t)b * T + tc) * 2);
+                if (tile_max) { t21[u] = tile_max[(int64_t)(B + b) * T + tc]; t12[u] = tile_max[(int64_t)b * T + tc]; }
             }
+            bool c21[FIN_CH], c12[FIN_CH];
+            unsigned long long k12[FIN_CH], k21[FIN_CH];
+#pragma unroll
+            for (int u = 0; u < FIN_CH; u++) {
+                c21[u] = false; c12[u] = false; k12[u] = 0ull; k21[u] = 0ull;
+                if (t0 + u * 256 >= T) continue;
+                const bool in = t0 + u * 256 + (int)threadIdx.x < T;
+                c21[u] = in && h21[u] != 0u; c12[u] = in && h12[u] != 0u;
+                if (c21[u]) { a[0] += v1[u].x; a[1] += v1[u].y; m21 = max(m21, t21[u]); }
+                if (c12[u]) { a[2] += v2[u].x; a[3] += v2[u].y; m12 = max(m12, t12[u]); }
+                k12[u] = __ballot(c12[u]); k21[u] = __ballot(c21[u]);
+                if (lane == 0) { wcov[0][u][wave] = __popcll(k12[u]); wcov[1][u][wave] = __popcll(k21[u]); }
+            }
+            __syncthreads();
             const unsigned long long below = (1ull << lane) - 1ull;
-            if (c12) work.cov[(int64_t)b * T + o12 + __popcll(k12 & below)] = (unsigned short)t;
-            if (c21) work.cov[(int64_t)(B + b) * T + o21 + __popcll(k21 & below)] = (unsigned short)t;
+#pragma unroll
+            for (int u = 0; u < FIN_CH; u++) {
+                if (t0 + u * 256 >= T) continue;
+                int o12 = base12, o21 = base21;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    o12 += w < wave ? wcov[0][u][w] : 0; o21 += w < wave ? wcov[1][u][w] : 0;
+                    base12 += wcov[0][u][w]; base21 += wcov[1][u][w];
+                }
+                const int t = t0 + u * 256 + (int)threadIdx.x;
+                if (c12[u]) work.cov[(int64_t)b * T + o12 + __popcll(k12[u] & below)] = (unsigned short)t;
+                if (c21[u]) work.cov[(int64_t)(B + b) * T + o21 + __popcll(k21[u] & below)] = (unsigned short)t;
+            }
             __syncthreads();
         }
         if (threadIdx.x == 0) { work.n_cov[b] = base12; work.n_cov[B + b] = base21; }

@@ -15,9 +15,19 @@ name, src, repl = sys.argv[1:4]
 out_dir = os.path.join(ROOT, "handobjectconsist_amd", "variants")
 os.makedirs(out_dir, exist_ok=True)
 tmp = tempfile.mkdtemp(prefix="hoc_variant_")
+import hashlib  # noqa: E402
+
+hh = hashlib.sha256()
+for hdr in sorted(f for f in os.listdir(B.CSRC) if f.endswith((".hpp", ".h"))) + [os.path.join("..", "..", "include", "meshraster_hip.h")]:
+    with open(os.path.join(B.CSRC, hdr), "rb") as fh:
+        hh.update(fh.read())
 objs = []
 for s in B.SOURCES:
     path = os.path.join(B.CSRC, s)
+    cached = B._object_for(s, hh.digest())
+    if s != src and os.path.exists(cached):  # (the library's own object of an unchanged source)
+        objs.append(cached)
+        continue
     if s == src:
         text = open(repl).read() if os.path.isfile(repl) else subprocess.run(
             ["git", "-C", ROOT, "show", f"{repl}:handobjectconsist_amd/csrc/{s}"], capture_output=True, text=True, check=True).stdout

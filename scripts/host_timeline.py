@@ -26,6 +26,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--image-size", type=int, default=256)
 ap.add_argument("--image-height", type=int, default=None)
 ap.add_argument("--encoder-dtype", default="f32")
+ap.add_argument("--no-graph", action="store_true", help="the eager step only")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 n, B, is_, ih_ = args.steps, args.batch, args.image_size, args.image_height or args.image_size
@@ -90,6 +91,8 @@ print("eager step (ms): device %.2f   host issue %.2f   host until device done %
 r = rows[len(rows) // 2]
 for name, spans in r[3].items():
     print("  %-9s" % name, "  ".join("%.2f-%.2f" % s for s in spans))
+if args.no_graph:
+    sys.exit(0)
 # the same step as ONE graph launch
 pre.forward = real_forward
 torch.Tensor.backward = real_backward
