@@ -36,7 +36,7 @@ def _json_line(out):
 def test_bench_single_process_line(cuda, tmp_path):
     details = str(tmp_path / "details.json")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--details-out", details] + SMALL,
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+                         capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _json_line(res.stdout)
     for k in CONTRACT:
@@ -90,7 +90,7 @@ def test_bench_under_torchrun_rccl_ddp(cuda):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline",
            "--no-kernel-bench"] + SMALL
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _json_line(res.stdout)
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "dp1"
@@ -107,7 +107,7 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(cuda):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline",
            "--no-kernel-bench"] + SMALL
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _json_line(res.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["parallelism"] == "dp2"
@@ -124,7 +124,7 @@ def test_bench_gpus_2_as_a_plain_script_starts_its_own_ranks(cuda):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--no-kernel-bench"] + SMALL
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _json_line(res.stdout)
     for k in CONTRACT:
@@ -154,7 +154,7 @@ def test_bench_gpus_8_as_a_plain_script(cuda):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "2", "--image-size", "64", "--steps", "2",
            "--warmup", "1", "--no-kernel-bench", "--no-cpu-baseline"]
     t0 = time.time()
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT, env=env)
     wall = time.time() - t0
     assert res.returncode == 0, res.stderr[-3000:]
     line = _json_line(res.stdout)
@@ -198,7 +198,7 @@ def test_config4_per_gpu_workload_under_rccl_ddp(cuda):
            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "32",
            "--image-size", "256", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-bench",
            "--no-stock-trunk"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _json_line(res.stdout)
     assert line["config"]["global_batch"] == 32 and line["value"] > 0 and line["ms_per_step"] > 0
@@ -260,17 +260,18 @@ def test_baseline_configs_3_and_5_full_steps(cuda, name, extra, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch,size,floor", [(32, 640, 0.55), (8, 480, 0.27)])
+@pytest.mark.parametrize("batch,size,floor", [(32, 640, 0.60), (8, 480, 0.275)])
 def test_forward_roofline_at_the_raster_sizes_of_configs_3_and_5(cuda, batch, size, floor):
     """The flow-mode forward of the training step at the raster sizes of BASELINE configs 5 (640 x 640, B = 32) and 3
-    (480 x 480, B = 8): fraction of the 8 TB/s roofline on SURVEY 8(d)'s algorithmic bytes, cold caches.  640: >= 0.55 (0.65-
-    0.67 measured in rounds 4 and 5; 0.31 before round 4, when one face spanning more than eight bins made every tile of its
+    (480 x 480, B = 8): fraction of the 8 TB/s roofline on SURVEY 8(d)'s algorithmic bytes, cold caches.  640: >= 0.60 (0.65-
+    0.67 measured in rounds 4 and 5, 0.70 in round 6; 0.31 before round 4, when one face spanning more than eight bins made every tile of its
     image a listed tile).  480 at B = 8 is 16 renders -- a launch too small to fill 256 compute units: 0.30-0.31 measured (60.7
     us; the binning pass in 16 parts per image since round 5 took 1.6 us off it: its per-face pass and the tile kernel's
-    chain of phases per tile are what the launch consists of), floor 0.27: ten per cent under the measurement."""
+    chain of phases per tile are what the launch consists of; 0.307 = 60.1 us in round 6 with the item table + DPP scans of
+    the tile kernel), floor 0.275: ten per cent under the measurement (box to box the tile kernel differs by that much)."""
     env = dict(os.environ, HOC_KERNEL_GROUPS="render_flow_forward(train outputs,both frames=2B)")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--kernels-only", "--batch", str(batch), "--image-size",
-                          str(size), "--kernel-iters", "20"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                          str(size), "--kernel-iters", "20"], capture_output=True, text=True, timeout=1800, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     k = json.loads(res.stdout)["render_flow_forward(train outputs,both frames=2B)"]
     _keep(f"forward_roofline_{size}.json", k)
