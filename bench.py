@@ -541,7 +541,7 @@ def kernel_bench(dev, B, is_, iters, only=None):
     return out
 
 
-def cpu_baseline(B_sample, is_, B_full, threads=None):
+def cpu_baseline(B_sample, is_, B_full, threads=None, limit_s=150.0):
     """The CPU oracle (oracle/, a port -- the reference has no CPU render path) on a bounded sample of the hot
     path: 2 renders + flow masks + occlusion + pair loss forward, and the texture / flow backward; extrapolated linearly in
     the batch size (images are independent).  One worker PROCESS per image (oracle/cpu_hot_path.py; round 5's thread pool
@@ -567,7 +567,13 @@ def cpu_baseline(B_sample, is_, B_full, threads=None):
             p_.stdin.write("go\n")
             p_.stdin.flush()
         own = []
+        import select
+
         for p_ in procs:
+            # (a level that does not finish within `limit_s` is abandoned: a starved box must not cost the run its line)
+            left = limit_s - (time.perf_counter() - t0)
+            if left <= 0 or not select.select([p_.stdout], [], [], left)[0]:
+                raise TimeoutError(f"cpu_baseline: {n_tasks} worker processes did not finish within {limit_s:.0f} s")
             word = p_.stdout.readline().split()
             if len(word) != 2 or word[0] != "done":
                 raise RuntimeError("cpu_baseline: a worker process failed (oracle/cpu_hot_path.py)")
@@ -595,7 +601,13 @@ def cpu_baseline_at_the_knee(is_, B_full, ncpu, sweep_all=False, gain=1.25, budg
     t_ = min(8, ncpu)
     best = None
     while True:
-        c_ = cpu_baseline(max(1, min(t_, 4 * B_full)), is_, B_full, threads=t_)
+        try:
+            c_ = cpu_baseline(max(1, min(t_, 4 * B_full)), is_, B_full, threads=t_)
+        except TimeoutError as e:
+            sys.stderr.write(f"[bench] {e}\n")
+            if best is None:
+                raise
+            break
         levels.append({"cores": c_["cores"], "value": c_["value"], "s_per_image": c_["seconds_per_image_in_a_worker"]})
         improved = best is None or c_["value"] >= gain * best["value"]
         if improved:  # (a level that buys less than `gain` over the best so far is past the knee: the best stays)
@@ -612,7 +624,7 @@ def cpu_baseline_at_the_knee(is_, B_full, ncpu, sweep_all=False, gain=1.25, budg
     return out
 
 
-def pmc_traffic_in_run(args, timeout=420):
+def pmc_traffic_in_run(args, timeout=240):
     """HBM bytes per launch of the roofline kernels, measured NOW: two `rocprofv3 --pmc` passes (FETCH_SIZE, then
     WRITE_SIZE -- they do not fit one pass, MI355X_MICROARCH.md PMC slots) over `bench.py --roofline-only` as a
     subprocess, mean per dispatch and kernel.  FETCH_SIZE / WRITE_SIZE count KB; on gfx950 FETCH_SIZE reports
@@ -660,7 +672,7 @@ def pmc_traffic_in_run(args, timeout=420):
     return out
 
 
-def in_step_durations(args, timeout=420):
+def in_step_durations(args, timeout=600):
     """Durations of this build's kernels INSIDE training steps: one `rocprofv3 --kernel-trace` pass over
     `bench.py --step-only` (a few steps of the same workload, nothing else in the process), median per kernel name in
     microseconds.  MIOpen's measured solver search and TunableOp are off in that subprocess (it only has to reach the
@@ -1180,7 +1192,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _phase("CPU baseline")
         ncpu = os.cpu_count() or 1
-        cpu = cpu_baseline_at_the_knee(is_, B, ncpu, sweep_all=args.cpu_sweep)
+        try:
+            cpu = cpu_baseline_at_the_knee(is_, B, ncpu, sweep_all=args.cpu_sweep)
+        except (TimeoutError, RuntimeError, OSError) as e:  # (the line must not depend on the host's CPUs being available)
+            sys.stderr.write(f"[bench] cpu_baseline failed: {e}\n")
+            cpu = None
 
     if rank == 0:
         ms = dt / args.steps * 1e3

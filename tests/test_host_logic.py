@@ -467,3 +467,36 @@ def test_cpu_baseline_workers_are_processes_behind_a_common_start():
     assert c["value"] > 0 and c["seconds_per_image_in_a_worker"] > 0 and len(c["sample"]) <= 200
     c = bench.cpu_baseline(1, 32, 1, threads=4)  # fewer images than threads: the rasteriser's OpenMP threads take the rest
     assert c["processes"] == 1 and c["omp_threads_per_process"] == 4 and c["cores"] == 4
+
+
+def test_cpu_baseline_reports_the_knee_of_its_sweep(monkeypatch):
+    """`cores` is the process count at which the figure stops improving (a doubling that buys less than 1.25 x ends the sweep
+    and is NOT the reported level), not what the box claims to have: round 5's GPU boxes report 256 hardware threads and give
+    a container 16.  A level that runs into its time limit ends the sweep with the best level so far; with no level done, the
+    error surfaces."""
+    import bench
+
+    # a box whose quota is 16 cores: throughput doubles to 16 processes, stays flat beyond
+    def fake(B_sample, is_, B_full, threads=None, limit_s=150.0):
+        v = 0.01 * min(threads, 16) * (1.0 if threads <= 16 else 0.99)
+        return {"value": v, "unit": "iters/s", "cores": threads, "kind": "port", "processes": threads, "omp_threads_per_process": 1,
+                "seconds_per_image_in_a_worker": 1.0, "sample": f"{B_sample} images; {threads} processes x 1 OpenMP threads"}
+
+    monkeypatch.setattr(bench, "cpu_baseline", fake)
+    c = bench.cpu_baseline_at_the_knee(256, 64, 256)
+    assert c["cores"] == 16 and [l["cores"] for l in c["sweep"]] == [8, 16, 32] and c["hardware_threads"] == 256
+    assert c["at_8_threads"]["value"] == pytest.approx(0.08) and "knee" in c["sample"] and len(c["sample"]) <= 200
+    c = bench.cpu_baseline_at_the_knee(256, 64, 256, sweep_all=True)  # (--cpu-sweep: every level, the knee still reported)
+    assert c["cores"] == 16 and [l["cores"] for l in c["sweep"]] == [8, 16, 32, 64, 128, 256]
+    assert bench.cpu_baseline_at_the_knee(64, 64, 4)["cores"] == 4  # (a box smaller than the first level)
+
+    def starved(B_sample, is_, B_full, threads=None, limit_s=150.0):
+        if threads > 8:
+            raise TimeoutError("too slow")
+        return fake(B_sample, is_, B_full, threads)
+
+    monkeypatch.setattr(bench, "cpu_baseline", starved)
+    assert bench.cpu_baseline_at_the_knee(256, 64, 256)["cores"] == 8
+    monkeypatch.setattr(bench, "cpu_baseline", lambda *a, **k: (_ for _ in ()).throw(TimeoutError("nothing finished")))
+    with pytest.raises(TimeoutError):
+        bench.cpu_baseline_at_the_knee(256, 64, 256)
