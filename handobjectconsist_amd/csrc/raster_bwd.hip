@@ -1086,7 +1086,7 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
             for (int ch = 0; ch < 3; ch++) mx = max(mx, __float_as_uint(g[j][ch]) & 0x7fffffffu);
     }
     unsigned bm = 0u;
-    bool synced = !WORK;  // WORK: the barrier behind the table zeroing waits in front of the first LDS atomic (pass 2)
+    // (WORK: the barrier behind the table zeroing waits in front of the first LDS atomic of pass 2, behind the tile's loads)
     if constexpr (UNIT) {
         if (!WORK) __syncthreads();  // table zeroed
         MR_ST_STAMP(2);
@@ -1121,10 +1121,13 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
     float* out = p.grad_vcolors + (int64_t)b * p.V * 3;
 
     // pass 2
-    for (int h = part * ST_WAVES + wave; h < n_hits; h += G * ST_WAVES) {
-        const int t = tile_at(h);
+    // (WORK: every wave takes a FIRST trip, with or without a tile -- the workgroup's barrier sits inside it, at ONE place for
+    // all waves; rounds 5's form had the waves without a tile meet the others at a second barrier behind the loop)
+    for (int h = part * ST_WAVES + wave, trip = 0; h < n_hits || (WORK && trip == 0); h += G * ST_WAVES, trip++) {
+        const bool live = h < n_hits;
+        const int t = live ? tile_at(h) : 0;
         const int yi = (t / sp.tiles_x) * ST_TH + r, x = (t % sp.tiles_x) * ST_TW + x4;
-        const bool inside = yi < is && x < is;
+        const bool inside = live && yi < is && x < is;
         int4 f4 = make_int4(-1, -1, -1, -1);
         if (inside) f4 = *reinterpret_cast<const int4*>(fim_b + (int64_t)yi * is + x);
         const int fn[4] = {f4.x, f4.y, f4.z, f4.w};
@@ -1199,10 +1202,8 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
         // selects are slower than the conversion sequence; summing a lane's consecutive pixels of one face in registers
         // before the LDS atomic -- exact, a third fewer atomics, but 54 -> 82 vector registers: three workgroups per compute
         // unit instead of four, or 92 bytes of scratch when capped.)
-        if (!synced) {  // (every wave passes exactly one of these: here in its first trip, or behind the loop)
-            __syncthreads();
-            synced = true;
-        }
+        if (WORK && trip == 0) __syncthreads();  // (table zeroed; the one barrier of pass 2, reached by every wave)
+        if (!live) break;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (fn[j] < 0) continue;
@@ -1247,7 +1248,6 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
                 }
         }
     }
-    if (!synced) __syncthreads();  // (a wave without a tile)
     if (!finite) return;  // block-uniform
     __syncthreads();
     MR_ST_STAMP(3);

@@ -855,9 +855,10 @@ def test_scatter_work_lists_equal_the_listing_form(cuda, monkeypatch, B, is_, sh
             assert float(a[B - 1].abs().sum()) == 0.0, "an off-screen mesh has no gradient"
 
 
-@pytest.mark.parametrize("B,is_,H,Wd,Cj,batched_hand", [(3, 256, 256, 256, 3, False), (2, 96, 64, 80, 1, True), (1, 480, 270, 480, 3, False),
-                                                       (5, 128, 128, 128, 1, False)])
-def test_pair_step_equals_the_node_pair(cuda, monkeypatch, B, is_, H, Wd, Cj, batched_hand):
+@pytest.mark.parametrize("B,is_,H,Wd,Cj,batched_hand,per_sample_cam", [
+    (3, 256, 256, 256, 3, False, False), (2, 96, 64, 80, 1, True, False), (1, 480, 270, 480, 3, False, False),
+    (5, 128, 128, 128, 1, False, False), (3, 128, 128, 96, 3, False, True)])
+def test_pair_step_equals_the_node_pair(cuda, monkeypatch, B, is_, H, Wd, Cj, batched_hand, per_sample_cam):
     """ABI 8: flow_pair_loss on (hand, object) parts through mr_pair_step_forward / _backward (ONE struct call each way, one
     autograd node, scratch kept by the plan: warping/pairstep.py) against the node pair it replaces on the host
     (_FlowVertexStageParts + _FlowPairLossFunction, five calls): the same launches, so losses, flows under the covered tiles
@@ -871,6 +872,12 @@ def test_pair_step_equals_the_node_pair(cuda, monkeypatch, B, is_, H, Wd, Cj, ba
     ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
                    K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
                    no_light=True, light_intensity_ambient=0.8)
+    if per_sample_cam:  # (R / t / dist_coeffs with a batch dimension of B: small rotations about z, shifts, a little distortion)
+        ang = torch.linspace(-0.05, 0.05, B, device=cuda)
+        R = torch.eye(3, device=cuda).repeat(B, 1, 1)
+        R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1] = torch.cos(ang), -torch.sin(ang), torch.sin(ang), torch.cos(ang)
+        ren.R, ren.t = R, torch.linspace(-0.01, 0.01, B, device=cuda)[:, None].repeat(1, 3).contiguous()
+        ren.dist_coeffs = torch.linspace(-0.02, 0.02, B, device=cuda)[:, None] * torch.tensor([1.0, 0.5, 0.1, -0.1, 0.2], device=cuda)
     monkeypatch.setattr(opticalflow, "DEBUG_POISON_RENDER_OUTPUTS", True)
     wf, wb = torch.linspace(0.5, 1.5, B, device=cuda), torch.linspace(2.0, 0.25, B, device=cuda)
     ws = torch.linspace(-0.5, 0.75, B, device=cuda)
