@@ -1350,7 +1350,17 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     // (at most one workgroup per compute unit: two per compute unit -- dbg 64 -- were measured at 2B = 128: 37.7 us against
     // 28.9 with two parts and 28.5 with one; config 3's 16 renders: 16 parts 23.1 us, one part 26.0)
     int parts = (bp.dbg & 32) ? 1 : bin_parts(B, F, std::min(device_cus(), MAX_PART_CUS), (bp.dbg & 64) ? 2 : 1);
+    if (bp.dbg & 4) parts = std::max(1, parts / 2);  // (profiling: half / a quarter / an eighth of the parts)
+    if (bp.dbg & 8) parts = std::max(1, parts / 4);
     if (parts > w.parts) parts = w.parts;
+    // (list_cleared: the caller cleared the tile list's header on this stream -- what the per-face pass's first thread does)
+    const bool fused_records = VC && list_cleared && bp.tlist && bp.F0 > 0 && !(bp.dbg & 16);
+    // The parts pay where they split the PER-FACE pass (fused_records: 64 renders of 256 x 256 22.1 us with 4 parts against 24.3
+    // with one, 16 renders of 480 x 480 21.9 / 24.5, 64 of 640 x 640 31.1 / 35.5; 128 renders: 28.3 / 28.5).  With the boxes
+    // already in memory a part only saves counting, and the exchange costs more than that unless the bins are many: 128 renders
+    // of 256 x 256 19.6 us with two parts, 17.8 with one; 64 renders 16.9 / 15.6; 16 of 480 x 480 18.3 / 17.5; 64 of 640 x 640
+    // (1600 bins) 26.2 / 27.9 (round 6, rocprofv3 over `bench.py --kernels-only` / scripts/hot_only.py, HOC_FWD_DBG sweeps).
+    if (!fused_records && nbins <= 1024 && !(bp.dbg & 1)) parts = 1;
     bp.B = B; bp.parts = parts; bp.poll_add = 0;
     bp.part_cnt = (int*)(base + w.off_part_cnt);
     bp.arrive = (unsigned*)(base + w.off_arrive);
@@ -1363,9 +1373,8 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     fp.nbx = w.nbx; fp.nby = w.nby; fp.ysh = w.ysh;
     if (B == 0) return MR_OK;
     if (B > 65535) return MR_ERR_BADARG;
-    // (list_cleared: the caller cleared the tile list's header on this stream -- what the per-face pass's first thread does)
-    const bool fused_records = VC && list_cleared && bp.tlist && bp.lds_boxes && bp.F0 > 0 && !(bp.dbg & 16);
-    if (fused_records) {
+    const bool fused_records_ok = fused_records && bp.lds_boxes;
+    if (fused_records_ok) {
         // nothing: the per-face pass runs inside the binning kernel
     } else if (bp.F0 > 0) {
         hipLaunchKernelGGL((face_records_kernel<VC>), dim3((unsigned)((bp.F0 + 255) / 256), (unsigned)B), dim3(256), 0, s,
@@ -1389,7 +1398,7 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     }
     // (parts > 1: workgroup i = part (i / 8) % parts of image (i / 8 / parts) * 8 + i % 8 -- an image's parts on one XCD)
     const unsigned grid = parts > 1 ? (unsigned)((B + 7) / 8) * 8u * (unsigned)parts : (unsigned)B;
-    if (fused_records) hipLaunchKernelGGL(bin_boxes_kernel<true>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
+    if (fused_records_ok) hipLaunchKernelGGL(bin_boxes_kernel<true>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
     else hipLaunchKernelGGL(bin_boxes_kernel<false>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
     MR_CHECK_LAUNCH();
     return MR_OK;
