@@ -1084,7 +1084,8 @@ def main():
                     hot()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (captured on the stream of the passes above: the pair step's plan -- keyed by stream -- is the warm one)
+            with torch.cuda.graph(graph, stream=side):
                 hot()
             hot_graph_ms = event_time_ms(graph.replay, 20, 3)
             hot_ms = hot_graph_ms

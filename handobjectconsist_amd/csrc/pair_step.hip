@@ -13,6 +13,7 @@
 #include <cstdint>
 
 #include "mr_common.hpp"
+#include "vertex_stage_device.hpp"
 
 int mr_flow_pair_backward_unit_tiles_ex(const int32_t* face_index_map, const uint32_t* tile_hit, const float* weight_map,
                                         const int32_t* vertex_id_map, const float* unit_grad, const float* unit_grad_max,
@@ -31,7 +32,15 @@ int mr_flow_pair_forward_grad_tiles_ex(const float* mask_flow1, const float* mas
                                        int width, float distance_thresh, float warp_thresh, float pair_thresh, const void* list_header,
                                        const void* list_entries, int64_t list_capacity, int64_t tile_bound, float* unit_grad,
                                        float* unit_grad_max, float* loss_sum, void* scatter_work, float* mean_out, int mean_of,
-                                       mr_stream_t stream);
+                                       int reset_list, mr_stream_t stream);
+
+int mr_render_flow_forward_pair(const float* verts, const int32_t* faces_idx, const float* vcolors, const float* background,
+                                int bg_stride, const float* keep_lut, int n_lut, float alpha_thresh, float* rgb_img, float* alpha_img,
+                                float* mask_img, float* depth_img, float* weight_map, int32_t* face_index_map, uint8_t* tile_hit,
+                                void* workspace, int64_t workspace_bytes, int batch_size, int num_verts, int num_faces, int fill_back,
+                                int image_size, float near_, float far_, float eps, int flags, int32_t* vertex_id_map, int tile_bound,
+                                uint32_t* tile_count_out, float* zero_fill, int64_t zero_fill_count, int texel_layout,
+                                mr_stream_t stream, const mr::PairPrologue* pro);
 
 namespace mr {
 
@@ -151,20 +160,37 @@ extern "C" int mr_pair_step_forward(const MrPairStep* step, mr_stream_t stream) 
     rc = mr_render_tile_list(rwork, B2, L.F, is, &hdr, &ents, &cap);
     if (rc != MR_OK) return rc;
     const int64_t clear_bytes = mr_render_clear_bytes(B2, L.F, is);
-    // 1. vertex stage of both frames + the stacked faces + the clear of the render's list header (one launch)
-    rc = mr_flow_pair_prologue_parts(a.verts1a, a.verts1b, a.verts2a, a.verts2b, a.num_verts_a, a.num_verts_b, a.K1, a.K2, a.R, a.t,
-                                     a.dist_coeffs, a.cam_batched, a.orig_size, ndc, ndc + (int64_t)B * V * 3, cols,
-                                     cols + (int64_t)B * V * 3, a.hand_faces, a.hand_faces_batched, a.obj_faces, faces2,
-                                     a.num_hand_faces, a.num_obj_faces, B, const_cast<void*>(hdr), clear_bytes, stream);
-    if (rc != MR_OK) return rc;
+    // 1. vertex stage of both frames + the stacked faces + the clear of the render's list header.  Round 6: no launch of its
+    // own -- the vertex stage and the faces ride in the render's binning pass (bin_boxes_kernel PROLOGUE, raster_fwd.hip), and
+    // the list header is left clean by the finalize launch of the PREVIOUS step on this scratch (MR_PAIR_STEP_LIST_CLEAN; a
+    // caller that cannot vouch for that gets a memset in front).  MR_PAIR_STEP_SEPARATE_LAUNCHES: the launch of ABI 8's first form.
+    const bool separate = (a.flags & MR_PAIR_STEP_SEPARATE_LAUNCHES) != 0;
+    PairPrologue pro{};
+    if (separate) {
+        rc = mr_flow_pair_prologue_parts(a.verts1a, a.verts1b, a.verts2a, a.verts2b, a.num_verts_a, a.num_verts_b, a.K1, a.K2, a.R, a.t,
+                                         a.dist_coeffs, a.cam_batched, a.orig_size, ndc, ndc + (int64_t)B * V * 3, cols,
+                                         cols + (int64_t)B * V * 3, a.hand_faces, a.hand_faces_batched, a.obj_faces, faces2,
+                                         a.num_hand_faces, a.num_obj_faces, B, const_cast<void*>(hdr), clear_bytes, stream);
+        if (rc != MR_OK) return rc;
+    } else {
+        if (!(a.orig_size > 0.0f) || B > 65535) return MR_ERR_BADARG;
+        if (!(a.flags & MR_PAIR_STEP_LIST_CLEAN)) {
+            const hipError_t e = hipMemsetAsync(const_cast<void*>(hdr), 0, (size_t)clear_bytes, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        pro.v = VertexStageParams{a.verts1a, a.verts2a, a.verts1b, a.verts2b, a.num_verts_a, a.K1, a.K2, a.R, a.t, a.dist_coeffs,
+                                  a.cam_batched ? 1 : 0, a.orig_size, ndc, ndc + (int64_t)B * V * 3, cols, cols + (int64_t)B * V * 3, B, V};
+        pro.f = StackFacesParams{a.hand_faces, a.hand_faces_batched ? (int64_t)a.num_hand_faces * 3 : (int64_t)0, a.obj_faces,
+                                 a.num_verts_a, faces2, B, a.num_hand_faces, a.num_obj_faces};
+    }
     // 2. the flow-mode render of the 2B stacked meshes (binning pass with the per-face pass inside + tile kernel)
     int64_t bound = a.tile_bound;
     if (bound == 0) bound = -1;
-    rc = mr_render_flow_forward(ndc, faces2, cols, a.background, a.bg_stride, a.keep_lut, a.n_lut, a.alpha_thresh, rgb, alpha, mask,
-                                nullptr, wmap, fim, tile_hit, rwork, L.render_work_bytes, B2, V, L.F0, a.fill_back, is, a.near_, a.far_,
-                                a.eps, MR_FLAG_SPARSE_TILES | MR_FLAG_TILE_LIST_CLEARED | (a.flags & ~0xff), vid,  // (flags >> 8: the render's profiling switches)
-                                (int)(bound > 0x7fffffffLL ? 0x7fffffffLL : bound), a.tile_count_out, grad_buf,
-                                grad_buf ? (int64_t)B2 * V * 3 : 0, a.texel_layout, stream);
+    rc = mr_render_flow_forward_pair(ndc, faces2, cols, a.background, a.bg_stride, a.keep_lut, a.n_lut, a.alpha_thresh, rgb, alpha, mask,
+                                     nullptr, wmap, fim, tile_hit, rwork, L.render_work_bytes, B2, V, L.F0, a.fill_back, is, a.near_, a.far_,
+                                     a.eps, MR_FLAG_SPARSE_TILES | MR_FLAG_TILE_LIST_CLEARED | (a.flags & ~0xff), vid,  // (flags >> 8: the render's profiling switches)
+                                     (int)(bound > 0x7fffffffLL ? 0x7fffffffLL : bound), a.tile_count_out, grad_buf,
+                                     grad_buf ? (int64_t)B2 * V * 3 : 0, a.texel_layout, stream, separate ? nullptr : &pro);
     if (rc != MR_OK) return rc;
     // 3. occlusion + flow epilogue + pair loss forward (+ its unit gradient) over the render's tile list; finalize
     float *loss_fwd = a.losses, *loss_bwd = a.losses + B, *loss_sum = a.losses + 2 * (int64_t)B;
@@ -178,7 +204,8 @@ extern "C" int mr_pair_step_forward(const MrPairStep* step, mr_stream_t stream) 
                                          a.warp_thresh, a.pair_thresh, hdr, ents, cap, bound, unit_grad, unit_max, loss_sum, swork,
                                          // (the finalize launch's last workgroup leaves the mean in losses[3 B]; the B words
                                          // behind it -- the caller's buffer has 4 B + 1 -- carry the samples' values to it)
-                                         a.losses + 3 * (int64_t)B, a.mean_of, stream);
+                                         // (reset_list: the finalize launch leaves the list header's counters zero for the next step)
+                                         a.losses + 3 * (int64_t)B, a.mean_of, 1, stream);
     return rc;
 }
 

@@ -51,6 +51,7 @@
 #include <algorithm>
 
 #include "mr_common.hpp"
+#include "vertex_stage_device.hpp"
 
 namespace mr {
 
@@ -229,8 +230,17 @@ __device__ unsigned long long mr_dbg_bin[1024 * 8];  // profiling builds: phase 
 // below).  The last arriver also re-zeroes the counter for the next launch.
 // The order of the records inside a bin's list differs from the one-workgroup order -- as it already does from run to run (LDS
 // atomics) -- and the image does not depend on it (z-buffer keys).
-template <bool RECORDS>
-__global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
+// PROLOGUE (round 6, pair steps: mr_render_flow_forward_pair): the vertex stage of the frame pair runs HERE instead of in a
+// launch of its own in front (pair_prologue_kernel, 7.4 us for 2B = 128 meshes -- most of it a launch's floor).  The
+// workgroup(s) of stack image b project the image's V vertices into LDS (both frames' 2-D projections for the flow colour, the
+// image's own frame through nr.projection: pair_vertex_of_frame -- vertex_stage_device.hpp, the arithmetic of
+// flow_vertices_forward_body), part 0 writes the image's flow colours for the tile kernel, and every part converts its own range
+// of the pair's int64 faces (written back as the image's int32 rows of the stacked faces, which the tile kernel's resolve
+// reads).  The per-face pass then gathers its vertices from LDS instead of from global memory.  Nothing crosses workgroups: the
+// parts of an image each compute all of its vertices (1780 x ~250 instructions over 1024 threads).
+template <bool RECORDS, bool PROLOGUE>
+__device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPrologue& pro) {
+    static_assert(RECORDS || !PROLOGUE, "the prologue feeds the per-face pass");
     MR_BIN_STAMP(0);
     extern __shared__ int bin_smem[];
     __shared__ int s_large, s_nlarge, s_lbase, s_hbase, s_bbase, s_everywhere, s_last;
@@ -251,6 +261,8 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
     const int nbins = p.nbx * p.nby, nbins4 = (nbins + 3) & ~3;
     int* cnt = bin_smem;
     FaceBox* sbox = reinterpret_cast<FaceBox*>(bin_smem + nbins4);
+    // PROLOGUE: the image's projected vertices [V][3], behind the boxes of the largest part (launch_bins sizes both)
+    float* sverts = reinterpret_cast<float*>(sbox + ((p.F + K - 1) / K + 2));
     FaceBox* box_b = p.boxes + (int64_t)b * p.F;
     // this part's faces: real faces [r0, r0 + nr) and (RECORDS with fill-back) their reversed copies F0 + [r0, r0 + nr), or
     // (!RECORDS) virtual faces [r0, r0 + nr); local index j < nv -> face fn_of(j)
@@ -269,20 +281,57 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         // the per-face pass (face_records_kernel<true>'s arithmetic): indices of REC_PF faces per thread requested together,
         // then their vertices, then the boxes of both orientations into the LDS copy
         constexpr int REC_PF = 4;
-        for (int base = 0; base < nr; base += REC_PF * BIN_TPB) {
-            int id[REC_PF][3];
+        int id[REC_PF][3];
+        // (PROLOGUE: stack image b is frame b / (B / 2) of pair b % (B / 2); its faces come from the pair's int64 tensors)
+        const int pairs = p.B >> 1, pb = PROLOGUE ? b % max(pairs, 1) : 0, frame = PROLOGUE ? b / max(pairs, 1) : 0;
+        auto load_ids = [&](int base) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < REC_PF; k++) {
-                const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + r0 + min(base + k * BIN_TPB + tid, nr - 1)) * 3;
-                id[k][0] = ix[0]; id[k][1] = ix[1]; id[k][2] = ix[2];
+                const int fr = r0 + min(base + k * BIN_TPB + tid, nr - 1);
+                if constexpr (PROLOGUE) {
+#pragma unroll
+                    for (int v = 0; v < 3; v++) id[k][v] = pair_face_index(pro.f, pb, fr, v);
+                } else {
+                    const int32_t* ix = p.fidx + ((int64_t)b * p.F0 + fr) * 3;
+                    id[k][0] = ix[0]; id[k][1] = ix[1]; id[k][2] = ix[2];
+                }
+            }
+        };
+        if constexpr (PROLOGUE) {
+            if (nr > 0) load_ids(0);  // (in flight beside the vertex stage below)
+            PairCamera cam;
+            load_pair_camera(pro.v, pb, cam);
+            float* cols_b = (frame == 0 ? pro.v.cols12 : pro.v.cols21) + (int64_t)pb * p.V * 3;
+            for (int vi = tid; vi < p.V; vi += BIN_TPB) {
+                float n[3], c[2];
+                pair_vertex_of_frame(pro.v, cam, pb, vi, frame, n, c);
+                sverts[vi * 3] = n[0]; sverts[vi * 3 + 1] = n[1]; sverts[vi * 3 + 2] = n[2];
+                if (part == 0) { cols_b[vi * 3] = c[0]; cols_b[vi * 3 + 1] = c[1]; cols_b[vi * 3 + 2] = 1.0f; }
+            }
+            __syncthreads();
+        }
+        for (int base = 0; base < nr; base += REC_PF * BIN_TPB) {
+            if (!PROLOGUE || base > 0) load_ids(base);
+            if constexpr (PROLOGUE) {
+                int32_t* f2 = pro.f.out + ((int64_t)b * p.F0 + r0) * 3;
+#pragma unroll
+                for (int k = 0; k < REC_PF; k++) {
+                    const int j = base + k * BIN_TPB + tid;
+                    if (j < nr) { f2[j * 3] = id[k][0]; f2[j * 3 + 1] = id[k][1]; f2[j * 3 + 2] = id[k][2]; }
+                }
             }
             float f[REC_PF][9];
 #pragma unroll
             for (int k = 0; k < REC_PF; k++)
 #pragma unroll
                 for (int v = 0; v < 3; v++) {
-                    const float* g = p.verts + ((int64_t)b * p.V + id[k][v]) * 3;
-                    f[k][3 * v] = g[0]; f[k][3 * v + 1] = g[1]; f[k][3 * v + 2] = g[2];
+                    if constexpr (PROLOGUE) {
+                        const float* g = sverts + id[k][v] * 3;
+                        f[k][3 * v] = g[0]; f[k][3 * v + 1] = g[1]; f[k][3 * v + 2] = g[2];
+                    } else {
+                        const float* g = p.verts + ((int64_t)b * p.V + id[k][v]) * 3;
+                        f[k][3 * v] = g[0]; f[k][3 * v + 1] = g[1]; f[k][3 * v + 2] = g[2];
+                    }
                 }
 #pragma unroll
             for (int k = 0; k < REC_PF; k++) {
@@ -539,6 +588,14 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
         for (int k = 0; k < 6; k++) h.pad[k] = 0;
         p.hdrs[b] = h;
     }
+}
+
+template <bool RECORDS>
+__global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
+    bin_boxes_body<RECORDS, false>(p, PairPrologue{});
+}
+__global__ void __launch_bounds__(BIN_TPB) bin_boxes_prologue_kernel(BinParams p, PairPrologue pro) {
+    bin_boxes_body<true, true>(p, pro);
 }
 
 struct FwdParams {
@@ -1321,9 +1378,12 @@ static WorkLayout work_layout(int B, int F, int is) {
 // set when one is built
 // `dense_list`: build the list for a DENSE launch (every pixel written): the tiles without candidates are listed too, in
 // an id array of their own, instead of getting zero coverage bytes
+// `pro` (pair steps): the frame pair's vertex stage, to run inside the binning pass where that pass takes its fused-records
+// form and the vertices fit its LDS (bin_boxes_kernel PROLOGUE) -- else as the launch of its own, in front, from here
 template <bool VC>
 static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int F, int is, hipStream_t s,
-                       uint8_t* tile_hit = nullptr, bool dense_list = false, bool list_cleared = false) {
+                       uint8_t* tile_hit = nullptr, bool dense_list = false, bool list_cleared = false,
+                       const PairPrologue* pro = nullptr) {
     const WorkLayout w = work_layout(B, F, is);
     if (w.nbx > MAX_BINS) return MR_ERR_BADARG;  // (image_size <= 16384 keeps a row of bins within the counters)
     char* base = (char*)workspace;
@@ -1374,6 +1434,17 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     if (B == 0) return MR_OK;
     if (B > 65535) return MR_ERR_BADARG;
     const bool fused_records_ok = fused_records && bp.lds_boxes;
+    bool pro_fused = false;
+    if (pro) {
+        const size_t v_lds = (size_t)bp.V * 3 * sizeof(float);
+        if (VC && fused_records_ok && (B & 1) == 0 && lds + v_lds <= 152 * 1024 && !(bp.dbg & 128)) {
+            pro_fused = true;
+            lds += v_lds;
+        } else {
+            const int rc = mr_launch_pair_prologue(*pro, s);
+            if (rc != MR_OK) return rc;
+        }
+    }
     if (fused_records_ok) {
         // nothing: the per-face pass runs inside the binning kernel
     } else if (bp.F0 > 0) {
@@ -1393,12 +1464,16 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_boxes_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_boxes_prologue_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) return (int)e;
         allowed = 152 * 1024;
     }
     // (parts > 1: workgroup i = part (i / 8) % parts of image (i / 8 / parts) * 8 + i % 8 -- an image's parts on one XCD)
     const unsigned grid = parts > 1 ? (unsigned)((B + 7) / 8) * 8u * (unsigned)parts : (unsigned)B;
-    if (fused_records_ok) hipLaunchKernelGGL(bin_boxes_kernel<true>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
+    if (pro_fused) hipLaunchKernelGGL(bin_boxes_prologue_kernel, dim3(grid), dim3(BIN_TPB), lds, s, bp, *pro);
+    else if (fused_records_ok) hipLaunchKernelGGL(bin_boxes_kernel<true>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
     else hipLaunchKernelGGL(bin_boxes_kernel<false>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
     MR_CHECK_LAUNCH();
     return MR_OK;
@@ -1666,6 +1741,19 @@ extern "C" __attribute__((visibility("default"))) int mr_debug_bin_times(void* d
 }
 #endif
 
+// mr_render_flow_forward of the 2B stacked meshes of a frame pair whose vertex stage has NOT run yet (mr_pair_step_forward,
+// pair_step.hip): `verts` (unused where the stage runs inside the binning pass), `faces_idx` and `vcolors` are the buffers that
+// stage fills -- pro->v.ndc1 / cols12 and pro->f.out point into them
+int mr_render_flow_forward_pair(const float* verts, const int32_t* faces_idx, const float* vcolors,
+                                const float* background, int bg_stride, const float* keep_lut, int n_lut,
+                                float alpha_thresh, float* rgb_img, float* alpha_img, float* mask_img,
+                                float* depth_img, float* weight_map, int32_t* face_index_map, uint8_t* tile_hit,
+                                void* workspace, int64_t workspace_bytes, int batch_size,
+                                int num_verts, int num_faces, int fill_back, int image_size, float near_,
+                                float far_, float eps, int flags, int32_t* vertex_id_map, int tile_bound,
+                                uint32_t* tile_count_out, float* zero_fill, int64_t zero_fill_count,
+                                int texel_layout, mr_stream_t stream, const mr::PairPrologue* pro);
+
 extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
                                       const float* background, int bg_stride, const float* keep_lut, int n_lut,
                                       float alpha_thresh, float* rgb_img, float* alpha_img, float* mask_img,
@@ -1675,6 +1763,22 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
                                       float far_, float eps, int flags, int32_t* vertex_id_map, int tile_bound,
                                       uint32_t* tile_count_out, float* zero_fill, int64_t zero_fill_count,
                                       int texel_layout, mr_stream_t stream) {
+    return mr_render_flow_forward_pair(verts, faces_idx, vcolors, background, bg_stride, keep_lut, n_lut, alpha_thresh, rgb_img,
+                                       alpha_img, mask_img, depth_img, weight_map, face_index_map, tile_hit, workspace,
+                                       workspace_bytes, batch_size, num_verts, num_faces, fill_back, image_size, near_, far_, eps,
+                                       flags, vertex_id_map, tile_bound, tile_count_out, zero_fill, zero_fill_count, texel_layout,
+                                       stream, nullptr);
+}
+
+int mr_render_flow_forward_pair(const float* verts, const int32_t* faces_idx, const float* vcolors,
+                                const float* background, int bg_stride, const float* keep_lut, int n_lut,
+                                float alpha_thresh, float* rgb_img, float* alpha_img, float* mask_img,
+                                float* depth_img, float* weight_map, int32_t* face_index_map, uint8_t* tile_hit,
+                                void* workspace, int64_t workspace_bytes, int batch_size,
+                                int num_verts, int num_faces, int fill_back, int image_size, float near_,
+                                float far_, float eps, int flags, int32_t* vertex_id_map, int tile_bound,
+                                uint32_t* tile_count_out, float* zero_fill, int64_t zero_fill_count,
+                                int texel_layout, mr_stream_t stream, const mr::PairPrologue* pro) {
     const int F = fill_back ? 2 * num_faces : num_faces;
     if (!texel_layout_ok(texel_layout)) return MR_ERR_BADARG;
     if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
@@ -1690,6 +1794,8 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
         return MR_OK;
     }
     if (batch_size > 65535) return MR_ERR_BADARG;
+    if (pro && ((batch_size & 1) || pro->v.B * 2 != batch_size || pro->v.V != num_verts || pro->f.Fh + pro->f.Fo != num_faces))
+        return MR_ERR_BADARG;
     FwdParams p{};
     BinParams bp{};
     bp.verts = verts; bp.fidx = faces_idx; bp.V = num_verts; bp.F0 = num_faces; bp.fill_back = fill_back;
@@ -1698,7 +1804,7 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
     if ((flags & MR_FLAG_SPARSE_TILES) && !tile_hit) return MR_ERR_BADARG;
     const bool listed = (flags & MR_FLAG_SPARSE_TILES) && tile_bound != 0;
     const int rc = launch_bins<true>(bp, p, workspace, batch_size, F, image_size, s, listed ? tile_hit : nullptr, false,
-                                     (flags & MR_FLAG_TILE_LIST_CLEARED) != 0);
+                                     (flags & MR_FLAG_TILE_LIST_CLEARED) != 0, pro);
     if (rc != MR_OK) return rc;
     p.tile_count_out = p.tlist ? tile_count_out : nullptr;
     p.background = background; p.bg_stride = bg_stride;

@@ -11,63 +11,9 @@
 // projected vertices -- and with them every coverage / validity decision downstream -- agree with the
 // op-by-op path to the last bit in practice.
 #include "mr_common.hpp"
+#include "vertex_stage_device.hpp"
 
 namespace mr {
-
-struct VertexStageParams {
-    const float* verts1;  // [B,V,3] camera frame -- or, with part B given, the first `split` vertices [B,split,3]
-    const float* verts2;
-    const float* verts1b; // nullable: vertices split .. V - 1 of every mesh [B,V-split,3] (hand | object: the concatenation
-    const float* verts2b; //           torch.cat([hand, obj], 1) of warpbranch.py:49-55 done by index instead of by a copy)
-    int split;
-    const float* K1;      // [B,3,3]
-    const float* K2;
-    const float* R;       // [Bc,3,3]  (Bc = 1 or B)
-    const float* t;       // [Bc,3]
-    const float* dist;    // [Bc,5]
-    int cam_bstride;      // 0 (broadcast) or 1
-    float orig_size;
-    float* ndc1;          // [B,V,3]
-    float* ndc2;
-    float* cols12;        // [B,V,3] = (p2 - p1, 1)
-    float* cols21;        // [B,V,3] = (p1 - p2, 1)
-    int B, V;
-};
-
-__device__ __forceinline__ float dot3(const float* a, const float* b) {
-    return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]));
-}
-
-// batch_proj2d: (K v)[:2] / (K v)[2]
-__device__ __forceinline__ void proj2d(const float* K, const float* v, float* h, float& px, float& py) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) h[i] = dot3(K + 3 * i, v);
-    px = h[0] / h[2];
-    py = h[1] / h[2];
-}
-
-// nr.projection
-__device__ __forceinline__ void ndc_project(const float* K, const float* R, const float* t, const float* d, float os,
-                                            const float* v, float* out) {
-    float c[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) c[i] = dot3(R + 3 * i, v) + t[i];
-    const float z = c[2];
-    const float x_ = c[0] / (z + 1e-9f), y_ = c[1] / (z + 1e-9f);
-    const float k1 = d[0], k2 = d[1], p1 = d[2], p2 = d[3], k3 = d[4];
-    const float r = sqrtf(x_ * x_ + y_ * y_);
-    const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2;
-    const float rad = 1.0f + k1 * r2 + k2 * r4 + k3 * r6;
-    const float x__ = x_ * rad + 2.0f * p1 * x_ * y_ + p2 * (r2 + 2.0f * (x_ * x_));
-    const float y__ = y_ * rad + p1 * (r2 + 2.0f * (y_ * y_)) + 2.0f * p2 * x_ * y_;
-    const float xy1[3] = {x__, y__, 1.0f};
-    float u = dot3(K, xy1);
-    float w = dot3(K + 3, xy1);
-    w = os - w;
-    out[0] = 2.0f * (u - os / 2.0f) / os;
-    out[1] = 2.0f * (w - os / 2.0f) / os;
-    out[2] = z;
-}
 
 __device__ __forceinline__ void flow_vertices_forward_body(const VertexStageParams& p, int bx) {
     const int b = blockIdx.y;
@@ -151,14 +97,6 @@ __global__ void __launch_bounds__(256) flow_vertices_backward_kernel(const float
 // faces of the concatenated hand + object mesh of a frame pair, as the stacked render takes them: int32 [2B, Fh + Fo, 3],
 // rows [0, B) and [B, 2B) identical (both frames of a pair share the faces, warpbranch.py:49-55), object indices offset
 // by the hand's vertex count -- hand_face.repeat + (obj_faces + Vh) + cat + cat + dtype conversion in one pass
-struct StackFacesParams {
-    const int64_t* hand_faces;
-    int64_t hand_bstride;
-    const int64_t* obj_faces;
-    int offset;
-    int32_t* out;
-    int B, Fh, Fo;
-};
 __device__ __forceinline__ void stack_pair_faces_body(const StackFacesParams& q, int bx) {
     const int b = blockIdx.y;
     const int i = bx * blockDim.x + threadIdx.x;
@@ -186,6 +124,17 @@ __global__ void __launch_bounds__(256) pair_prologue_kernel(VertexStageParams p,
 }  // namespace mr
 
 using namespace mr;
+
+// the pair's set-up launch from its argument blocks (raster_fwd.hip's launch_bins: where the binning pass cannot take the
+// vertex stage in); no clearing
+int mr::mr_launch_pair_prologue(const mr::PairPrologue& pro, hipStream_t s) {
+    const int vb = (pro.v.V + 255) / 256, fb = ((pro.f.Fh + pro.f.Fo) * 3 + 255) / 256;
+    if (pro.v.B <= 0 || pro.v.B > 65535 || !pro.v.ndc1 || !pro.v.ndc2 || !pro.v.cols12 || !pro.v.cols21) return MR_ERR_BADARG;
+    hipLaunchKernelGGL(pair_prologue_kernel, dim3((unsigned)(vb + fb), (unsigned)pro.v.B), dim3(256), 0, s, pro.v, pro.f, vb,
+                       (uint4*)nullptr, 0);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+}
 
 extern "C" int mr_flow_vertices_forward(const float* verts1, const float* verts2, const float* K1, const float* K2,
                                         const float* R, const float* t, const float* dist_coeffs, int cam_batched,

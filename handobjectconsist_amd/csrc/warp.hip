@@ -804,7 +804,12 @@ __global__ void __launch_bounds__(256) pair_consist_finalize_tiles_kernel(const 
                                                                           unsigned* __restrict__ image_max,
                                                                           float* __restrict__ loss_sum, ScatterWork work,
                                                                           unsigned* __restrict__ mean_ctr,
-                                                                          float* __restrict__ mean_out, int mean_of) {
+                                                                          float* __restrict__ mean_out, int mean_of,
+                                                                          unsigned* __restrict__ list_reset) {
+    // list_reset (mr_pair_step_forward): the three counters of the render's tile-list header.  This launch is the last of the
+    // pair's forward side, and nothing behind the fused warp forward reads them: zeroed here, the NEXT pair step on this
+    // scratch finds its list header clean (MR_PAIR_STEP_LIST_CLEAN) without a clearing launch in front of its binning pass.
+    if (list_reset && blockIdx.x == 0 && threadIdx.x < 3) list_reset[threadIdx.x] = 0u;
     __shared__ float red[4][4];
     __shared__ unsigned redm[4][2];
     __shared__ int wcov[2][4][4];  // [direction][round of the chunk][wave]
@@ -1245,7 +1250,7 @@ extern "C" int mr_pair_consist_forward_tiles(const float* flow12, const float* f
                        (const float*)workspace, reinterpret_cast<const uint32_t*>(tile_hit12),
                        reinterpret_cast<const uint32_t*>(tile_hit21), batch_size, p.tiles_x * p.tiles_y, sums, loss_fwd, loss_bwd,
                        (const unsigned*)nullptr, (unsigned*)nullptr, (float*)nullptr, ScatterWork{nullptr, nullptr},
-                       (unsigned*)nullptr, (float*)nullptr, 0);
+                       (unsigned*)nullptr, (float*)nullptr, 0, (unsigned*)nullptr);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1291,7 +1296,8 @@ static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_fl
                                    int height, int width, float distance_thresh, float warp_thresh, float pair_thresh,
                                    const void* list_header, const void* list_entries, int64_t list_capacity,
                                    int64_t tile_bound, float* unit_grad, float* unit_grad_max, float* loss_sum,
-                                   void* scatter_work, mr_stream_t stream, float* mean_out = nullptr, int mean_of = 0) {
+                                   void* scatter_work, mr_stream_t stream, float* mean_out = nullptr, int mean_of = 0,
+                                   int reset_list = 0) {
     if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2 || !flow_out12 || !flow_out21)
         return MR_ERR_BADARG;
     if (batch_size < 0 || image_size <= 0 || flow_bstride < 2LL * image_size * image_size) return MR_ERR_BADARG;
@@ -1325,7 +1331,8 @@ static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_fl
                        unit_grad ? reinterpret_cast<unsigned*>(unit_grad_max) : (unsigned*)nullptr, loss_sum,
                        scatter_work_at(unit_grad ? scatter_work : nullptr, 2 * batch_size),
                        // (the arrival counter of the batch mean: a spare word of the list header the caller cleared with it)
-                       mean_out ? const_cast<unsigned*>(&((const TileList*)list_header)->pad[0]) : (unsigned*)nullptr, mean_out, mean_of);
+                       mean_out ? const_cast<unsigned*>(&((const TileList*)list_header)->pad[0]) : (unsigned*)nullptr, mean_out, mean_of,
+                       reset_list ? const_cast<unsigned*>(&((const TileList*)list_header)->n_heavy) : (unsigned*)nullptr);
     MR_CHECK_LAUNCH();
     return MR_OK;
 }
@@ -1342,14 +1349,14 @@ int mr_flow_pair_forward_grad_tiles_ex(const float* mask_flow1, const float* mas
                                        int width, float distance_thresh, float warp_thresh, float pair_thresh, const void* list_header,
                                        const void* list_entries, int64_t list_capacity, int64_t tile_bound, float* unit_grad,
                                        float* unit_grad_max, float* loss_sum, void* scatter_work, float* mean_out, int mean_of,
-                                       mr_stream_t stream) {
+                                       int reset_list, mr_stream_t stream) {
     if (!unit_grad || !unit_grad_max) return MR_ERR_BADARG;
     return flow_pair_forward_tiles(mask_flow1, mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2,
                                    flow_out12, flow_out21, tile_hit1, tile_hit2, image_ref, image, jitter_ref, jitter,
                                    jitter_channels, workspace, workspace_bytes, sums, loss_fwd, loss_bwd, batch_size, image_size,
                                    height, width, distance_thresh, warp_thresh, pair_thresh, list_header, list_entries,
                                    list_capacity, tile_bound, unit_grad, unit_grad_max, loss_sum, scatter_work, stream, mean_out,
-                                   mean_of);
+                                   mean_of, reset_list);
 }
 
 extern "C" int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,

@@ -544,6 +544,7 @@ USE_UNIT_GRADIENT = True
 # workgroups per image in proportion to its covered tiles.  False: a fixed number per image, each listing the image's tiles.
 USE_SCATTER_WORK = os.environ.get("HOC_SCATTER_WORK", "1") != "0"
 _FWD_DBG_FLAGS = int(os.environ.get("HOC_FWD_DBG", "0")) << 8  # profiling switches of the forward kernels (csrc/raster_fwd.hip: dbg)
+_PAIR_STEP_FLAGS = int(os.environ.get("HOC_PAIR_STEP_FLAGS", "0")) & 0xfe  # MrPairStep.flags, e.g. 2 = MR_PAIR_STEP_SEPARATE_LAUNCHES (A / B runs)
 # ... and with the render's per-face pass folded into its binning pass (the pair prologue clears the tile list's header, which
 # the per-face pass's first thread does otherwise): one launch and one dependent round trip less per pair.
 USE_FUSED_RECORDS = True
@@ -721,7 +722,7 @@ def flow_pair_loss(verts_cam, faces, camintrs, neurenderer, orig_img_size, image
         lut = _keep_lut(ignore_face_idxs, dev) if ignore_face_idxs is not None else None
         res = pairstep.pair_step((h1, o1), (h2, o2), hand_face, obj_faces, camintrs[0].to(dev), camintrs[1].to(dev), neurenderer,
                                  is_, H, W, image_ref, image, jitter_mask_ref, jitter_mask, lut, mean_of_fwd_only=(with_mean == "fwd"),
-                                 poison=DEBUG_POISON_RENDER_OUTPUTS, flags=_FWD_DBG_FLAGS)
+                                 poison=DEBUG_POISON_RENDER_OUTPUTS, flags=_FWD_DBG_FLAGS | _PAIR_STEP_FLAGS)
         if res is not None:
             mean, loss_sum, loss_fwd, loss_bwd, flows, tile_hit = res
             # (the render's tile list lives in the plan's scratch, which the next call reuses: the note carries the coverage only)

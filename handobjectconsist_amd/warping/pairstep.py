@@ -33,6 +33,8 @@ INPUT_FIELDS = ("verts1a", "verts1b", "verts2a", "verts2b", "K1", "K2", "R", "t"
 GRAD_FIELDS = ("grad_loss_fwd", "grad_loss_bwd", "grad_loss_sum", "grad_mean", "grad_verts1a", "grad_verts1b", "grad_verts2a",
                "grad_verts2b")
 GRAD_BUFFER_USED = 1  # MR_PAIR_STEP_GRAD_BUFFER_USED
+SEPARATE_LAUNCHES = 2  # MR_PAIR_STEP_SEPARATE_LAUNCHES: every stage a launch of its own (tests, profiling)
+LIST_CLEAN = 4  # MR_PAIR_STEP_LIST_CLEAN: the scratch's tile-list header was left clean by the previous forward call on it
 
 
 class MrPairStep(ctypes.Structure):
@@ -82,6 +84,10 @@ class _Plan:
             raise RuntimeError(f"mr_pair_step_sizes failed: {rc}")
         self.scratch_bytes, self.saved_bytes, self.tile_hit_offset = int(sc.value), int(sv.value), int(th.value)
         self.scratch = None
+        # the render's tile-list header inside the scratch is re-zeroed by the LAST launch of a forward call: the next call on
+        # this plan says so (LIST_CLEAN) and goes without a clearing launch.  False: never used, poisoned, or a call failed.
+        self.list_clean = False
+        self.base_flags = int(self.st.flags) & ~(GRAD_BUFFER_USED | LIST_CLEAN)
         self.st_addr, self.st_b_addr = _c.c_void_p(_c.addressof(self.st)), _c.c_void_p(_c.addressof(self.st_b))
         B, is_ = self.st.batch_size, self.st.image_size
         self.B, self.H, self.W, self.is_ = B, self.st.height, self.st.width, is_
@@ -131,6 +137,7 @@ class _PairStepFunction(torch.autograd.Function):
             saved[:2 * B * plan.is_ * plan.is_ * 4].view(torch.int32).fill_(-2 ** 31)  # (the face index map leads the buffer)
             scratch.fill_(255)
             flows.fill_(float("nan"))
+            plan.list_clean = False
         st.verts1a, st.verts1b, st.verts2a, st.verts2b = h1.data_ptr(), o1.data_ptr(), h2.data_ptr(), o2.data_ptr()
         st.K1, st.K2 = K1.data_ptr(), K2.data_ptr()
         R, t, dist, bg, lut = consts
@@ -146,6 +153,8 @@ class _PairStepFunction(torch.autograd.Function):
         st.tile_count_out = plan.count_word.data_ptr() if plan.count_word is not None else None
         want = any(ctx.needs_input_grad[:4])
         st.want_grad = 1 if want else 0
+        st.flags = plan.base_flags | (LIST_CLEAN if plan.list_clean else 0)
+        plan.list_clean = False  # (until this call has returned MR_OK)
         if dev.index != torch.cuda.current_device():
             with torch.cuda.device(dev):
                 rc = plan.fwd(plan.st_addr, plan.stream)
@@ -153,6 +162,7 @@ class _PairStepFunction(torch.autograd.Function):
             rc = plan.fwd(plan.st_addr, plan.stream)
         if rc != 0:
             raise RuntimeError(f"mr_pair_step_forward failed: {rc}")
+        plan.list_clean = True
         ctx.plan, ctx.used = plan, False
         if want:
             ctx.save_for_backward(saved, h1, o1, h2, o2, K1, K2)
@@ -175,7 +185,8 @@ class _PairStepFunction(torch.autograd.Function):
         grads = [torch.empty_like(x) if w else None for x, w in zip((h1, o1, h2, o2), ctx.needs_input_grad[:4])]
         st.grad_verts1a, st.grad_verts1b, st.grad_verts2a, st.grad_verts2b = [g.data_ptr() if g is not None else None for g in grads]
         st.want_grad = 1
-        st.flags = GRAD_BUFFER_USED if ctx.used else 0  # (a second backward through this node: the buffer is cleared first)
+        # (a second backward through this node: the buffer is cleared first; the plan's own bits -- SEPARATE_LAUNCHES -- stay)
+        st.flags = plan.base_flags | (GRAD_BUFFER_USED if ctx.used else 0)
         ctx.used = True
         if plan.dev.index != torch.cuda.current_device():
             with torch.cuda.device(plan.dev):

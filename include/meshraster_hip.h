@@ -669,6 +669,15 @@ MR_API int mr_flow_pair_backward_unit_tiles(const int32_t* face_index_map, const
  *     same forward call again sets MR_PAIR_STEP_GRAD_BUFFER_USED in `flags` for the later calls (the buffer is then cleared
  *     first).  flags bits 8 and up: profiling switches of the render (forward call only). */
 #define MR_PAIR_STEP_GRAD_BUFFER_USED 1
+/* flags bit 1 (forward call): every stage as a launch of its own, as in ABI 8's first form -- the vertex stage + stacked faces
+ * (mr_flow_pair_prologue_parts, which also clears the list header) otherwise run inside the render's binning pass.  Same
+ * results bit for bit; for tests and profiling. */
+#define MR_PAIR_STEP_SEPARATE_LAUNCHES 2
+/* flags bit 2 (forward call): the caller vouches that the tile-list header inside `scratch` is clean -- `scratch` was last
+ * used by a mr_pair_step_forward call of the same sizes that returned MR_OK (its last launch re-zeroes the header), on this
+ * stream or one ordered before it.  Without the bit the call clears the header first (one more launch).  A scratch buffer that
+ * was never used, was written by anybody else or saw a failed call is NOT clean. */
+#define MR_PAIR_STEP_LIST_CLEAN 4
 typedef struct MrPairStep {
     int32_t batch_size, num_verts_a, num_verts_b, num_hand_faces, num_obj_faces, hand_faces_batched;
     int32_t fill_back, image_size, height, width, jitter_channels, cam_batched;

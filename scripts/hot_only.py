@@ -59,7 +59,7 @@ if not a.no_graph:
             hot()
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=side):  # (the stream of the passes above: the pair step's plan is keyed by stream)
         hot()
     for _ in range(3):
         g.replay()

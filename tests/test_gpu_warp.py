@@ -1077,3 +1077,77 @@ def test_fused_pair_node_on_ragged_rasters_and_as_parts(cuda, B, is_, H, Wd, Cj)
         assert torch.equal(flow_f[defined], flow_d[defined]), f"flows (parts: {parts})"
         assert float(flow_d[~defined].abs().sum()) == 0.0  # (the dense flows are exactly zero where nothing is written)
         close(grad_f.cpu().numpy(), grad_d.cpu().numpy(), 1e-5, 1e-6 * float(grad_d.abs().max()), f"vertex gradient (parts: {parts})")
+
+
+@pytest.mark.parametrize("B,is_,Cj,batched_hand,per_sample_cam", [(3, 256, 3, False, False), (8, 128, 1, True, True), (2, 96, 3, False, False),
+                                                                 (5, 480, 1, False, True), (1, 64, 3, False, False)])
+def test_pair_step_prologue_in_the_binning_pass(cuda, monkeypatch, B, is_, Cj, batched_hand, per_sample_cam):
+    """Round 6: the pair's vertex stage + stacked faces run inside the render's binning pass (bin_boxes_kernel PROLOGUE: the
+    image's projected vertices live in LDS only) and the tile-list header is left clean by the previous call's finalize launch
+    (MR_PAIR_STEP_LIST_CLEAN) -- against MR_PAIR_STEP_SEPARATE_LAUNCHES, the prologue launch of ABI 8's first form.  The same
+    arithmetic on the same inputs: losses, flows under the covered tiles and coverage bytes bit for bit, vertex gradients to the
+    order of the scatter's fp32 atomics.  Three calls through ONE plan per form: the first clears the header itself (the
+    scratch was never used), the second and third rely on the clean header their predecessor left -- also behind a poisoned
+    scratch (0xff everywhere: the host drops LIST_CLEAN) and with a different scene (a stale list would show)."""
+    from handobjectconsist_amd.neurender.renderer import Renderer
+    from handobjectconsist_amd.warping import opticalflow, pairstep
+
+    ren = Renderer(image_size=is_, R=torch.eye(3, device=cuda)[None], t=torch.zeros(1, 3, device=cuda),
+                   K=torch.ones(1, 3, 3, device=cuda), orig_size=is_, anti_aliasing=False, fill_back=True, near=0.1,
+                   no_light=True, light_intensity_ambient=0.8)
+    if per_sample_cam:
+        ang = torch.linspace(-0.05, 0.05, B, device=cuda)
+        R = torch.eye(3, device=cuda).repeat(B, 1, 1)
+        R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1] = torch.cos(ang), -torch.sin(ang), torch.sin(ang), torch.cos(ang)
+        ren.R, ren.t = R, torch.linspace(-0.01, 0.01, B, device=cuda)[:, None].repeat(1, 3).contiguous()
+        ren.dist_coeffs = torch.linspace(-0.02, 0.02, B, device=cuda)[:, None] * torch.tensor([1.0, 0.5, 0.1, -0.1, 0.2], device=cuda)
+    pairstep._PLANS.clear()  # (plans of earlier tests: theirs have been used, this test starts from a scratch nobody has touched)
+    seen = []
+    real_fwd = pairstep._PairStepFunction.forward
+
+    def spy(ctx, h1, o1, h2, o2, call):
+        out = real_fwd(ctx, h1, o1, h2, o2, call)
+        seen.append(int(call[0].st.flags))
+        return out
+
+    monkeypatch.setattr(pairstep._PairStepFunction, "forward", staticmethod(spy))
+    w = torch.linspace(0.5, 1.5, B, device=cuda)
+
+    def run(flags, seed, poison):
+        monkeypatch.setattr(opticalflow, "_PAIR_STEP_FLAGS", flags)
+        monkeypatch.setattr(opticalflow, "DEBUG_POISON_RENDER_OUTPUTS", poison)
+        s = synth.random_scene(B, seed=seed, image_size=is_)
+        im_ref, im, jm_ref, jm = [t(a, cuda) for a in synth.random_images(B, is_, is_, seed + 1)]
+        jm_ref, jm = jm_ref[:, :Cj].contiguous(), jm[:, :Cj].contiguous()
+        hand_faces = t(s["hand_faces"].astype(np.int64), cuda)
+        if batched_hand:
+            hand_faces = hand_faces[None].repeat(B, 1, 1)
+        obj_faces = t(s["obj_faces"].astype(np.int64)[None].repeat(B, 0), cuda)
+        leaves = [t(s[k], cuda).requires_grad_(True) for k in ("hand_verts1", "obj_verts1", "hand_verts2", "obj_verts2")]
+        res = opticalflow.flow_pair_loss([(leaves[0], leaves[1]), (leaves[2], leaves[3])], (hand_faces, obj_faces),
+                                         [t(s["K1"], cuda), t(s["K2"], cuda)], ren, (is_, is_), im_ref, im, jm_ref, jm,
+                                         ignore_face_idxs=synth.HAND_IGNORE_FACES, with_sum=True, with_mean="sum")
+        assert res is not None
+        lf, lb, flows, lsum, mean = res
+        grads = torch.autograd.grad((lf * w).sum() + 0.5 * (lb * w).sum() + 2.0 * mean, leaves)
+        base = flows[0]._base
+        hit = base._hoc_coverage[0]
+        words = hit.contiguous().view(torch.int32).view(2 * B, (is_ + 7) // 8, (is_ + 31) // 32).cpu().numpy() != 0
+        yy, xx = np.mgrid[0:is_, 0:is_]
+        defined = torch.from_numpy(words[:, (is_ - 1 - yy) >> 3, xx >> 5]).to(cuda)
+        return lf.detach(), lb.detach(), mean.detach(), base.detach()[defined], hit.clone(), grads
+
+    calls = ((91, False), (92, True), (93, False))
+    got = [run(0, seed, poison) for seed, poison in calls]
+    fused_flags = list(seen)
+    del seen[:]
+    ref = [run(pairstep.SEPARATE_LAUNCHES, seed, poison) for seed, poison in calls]
+    assert [f & pairstep.LIST_CLEAN for f in fused_flags] == [0, 0, pairstep.LIST_CLEAN], "first use and poisoned scratch: not clean"
+    assert all(f & pairstep.SEPARATE_LAUNCHES for f in seen) and not any(f & pairstep.SEPARATE_LAUNCHES for f in fused_flags)
+    for g, r, (seed, _p) in zip(got, ref, calls):
+        for x, y, what in zip(g[:5], r[:5], ("loss_fwd", "loss_bwd", "mean", "flows", "coverage bytes")):
+            assert torch.equal(x, y), (what, seed)
+        assert float(r[0].abs().sum()) > 0
+        for x, y, what in zip(g[5], r[5], ("hand 1", "object 1", "hand 2", "object 2")):
+            assert torch.isfinite(x).all() and float(y.abs().sum()) > 0, what
+            close(x.cpu().numpy(), y.cpu().numpy(), 1e-5, 1e-6 * float(y.abs().max()), f"d/d vertices of {what}, scene {seed}")
