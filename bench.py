@@ -130,7 +130,10 @@ ROOF_KERNELS = {ROOF_BWD: ["unit_scatter_tiles_kernel"], ROOF_BWD_R4A: ["pair_sc
                 ROOF_FWD: ["face_records_kernel<true>", "bin_boxes_kernel<false>", "raster_tile_kernel<true, true>"]}
 # ... and as the training step launches the same render: the pair prologue has cleared the tile list's header, the per-face
 # pass runs inside the binning kernel (MR_FLAG_TILE_LIST_CLEARED)
-ROOF_KERNELS_IN_STEP = {ROOF_FWD: ["bin_boxes_kernel<true>", "raster_tile_kernel<true, true>"]}
+# (round 6: the binning launch of a pair step also runs the pair's vertex stage + stacked faces -- bin_boxes_prologue_kernel,
+# which takes the place of pair_prologue_kernel + bin_boxes_kernel<true>; the in-step figure of the forward includes that work)
+ROOF_KERNELS_IN_STEP = {ROOF_FWD: ["bin_boxes_prologue_kernel", "raster_tile_kernel<true, true>"]}
+ROOF_KERNELS_IN_STEP_ALT = {ROOF_FWD: ["bin_boxes_kernel<true>", "raster_tile_kernel<true, true>"]}  # (MR_PAIR_STEP_SEPARATE_LAUNCHES)
 # compulsory bytes per pixel of a covered tile: face index 4 + vertex ids 12 + sampling weights 12 + ...
 ROOF_BWD_PER_PIXEL = {ROOF_BWD: (36, "... + unit gradient 8"),
                       ROOF_BWD_R4A: (80, "... + three masks 12 + final flow 8 + source 12 + target 12 + two jitter values 8 (its scratch "
@@ -732,6 +735,8 @@ def roofline_block(name, k, pmc, units, in_step=None):
             "launch_ms": k["ms"], "launch_ms_cache_warm": k["ms_cache_warm"],
             "units_per_launch": units, "device_kernels": ROOF_KERNELS[name]}
     step_names = ROOF_KERNELS_IN_STEP.get(name, ROOF_KERNELS[name])
+    if in_step and not all(d in in_step for d in step_names):
+        step_names = ROOF_KERNELS_IN_STEP_ALT.get(name, ROOF_KERNELS[name])
     if in_step and not all(d in in_step for d in step_names):
         step_names = ROOF_KERNELS[name]
     if in_step and all(d in in_step for d in step_names):

@@ -108,6 +108,29 @@ constexpr int REC_CAP = SMALL_MAX_BINS + 1;  // record capacity per image, in un
 constexpr int MAX_PARTS_DEV = 16;            // most workgroups per image of the binning pass (= MAX_PARTS of launch_bins)
 constexpr int ARRIVE_STRIDE = 32;            // words between the arrival counters of two images
 
+// PROLOGUE (pair steps): the parts of an image split its faces AT the hand / object boundary -- Kh parts share the Fh hand faces,
+// K - Kh the Fo object faces, in proportion -- so that a part needs only the vertices of ITS side in LDS (hand faces index the
+// hand's vertices, object faces the object's: warpbranch.py:49-55, the contract of the stacked mesh): one trip of the vertex
+// stage per part instead of two at the metric workload.  Returns the part's real faces [r0, r0 + nr) and its side (0 hand, 1 object,
+// -1: no split -- one part, or a mesh with one side only).
+__host__ __device__ inline int pair_part_range(int part, int K, int Fh, int Fo, int& r0, int& nr) {
+    const int F0 = Fh + Fo;
+    if (K < 2 || Fh <= 0 || Fo <= 0) {
+        r0 = (int)((int64_t)F0 * part / K); nr = (int)((int64_t)F0 * (part + 1) / K) - r0;
+        return -1;
+    }
+    int Kh = (int)(((int64_t)K * Fh + F0 / 2) / F0);
+    Kh = Kh < 1 ? 1 : (Kh > K - 1 ? K - 1 : Kh);
+    if (part < Kh) {
+        r0 = (int)((int64_t)Fh * part / Kh); nr = (int)((int64_t)Fh * (part + 1) / Kh) - r0;
+        return 0;
+    }
+    const int q = part - Kh, Ko = K - Kh;
+    r0 = (int)((int64_t)Fo * q / Ko); nr = (int)((int64_t)Fo * (q + 1) / Ko) - r0;
+    r0 += Fh;
+    return 1;
+}
+
 struct BinParams {
     const float* faces;      // !VC: [B,F,3,3]
     const float* verts;      // VC: [B,V,3]
@@ -134,7 +157,7 @@ struct BinParams {
     int64_t zero_count;
     // round 5: `parts` workgroups per image, each binning a contiguous range of the image's faces (see bin_boxes_kernel)
     int B, parts;
-    int poll_add;            // (unused since round 6: the parts no longer poll)
+    int box_cap;             // boxes the LDS copy holds (the largest part's; PROLOGUE: the projected vertices sit behind them)
     int* part_cnt;           // [B, parts, nbins + 4]: a part's raw bin counters + {its large faces, its "everywhere" flag}
     unsigned* arrive;        // [B * ARRIVE_STRIDE] arrival counters of the images' parts, a 128-byte line each; ZERO on entry (per-face
                              // pass / the caller's clear) and again on exit (the last part to arrive re-zeroes its image's)
@@ -262,12 +285,14 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
     int* cnt = bin_smem;
     FaceBox* sbox = reinterpret_cast<FaceBox*>(bin_smem + nbins4);
     // PROLOGUE: the image's projected vertices [V][3], behind the boxes of the largest part (launch_bins sizes both)
-    float* sverts = reinterpret_cast<float*>(sbox + ((p.F + K - 1) / K + 2));
+    float* sverts = reinterpret_cast<float*>(sbox + p.box_cap);
     FaceBox* box_b = p.boxes + (int64_t)b * p.F;
     // this part's faces: real faces [r0, r0 + nr) and (RECORDS with fill-back) their reversed copies F0 + [r0, r0 + nr), or
     // (!RECORDS) virtual faces [r0, r0 + nr); local index j < nv -> face fn_of(j)
     const int nsplit = RECORDS ? p.F0 : p.F;
-    const int r0 = (int)((int64_t)nsplit * part / K), nr = (int)((int64_t)nsplit * (part + 1) / K) - r0;
+    int r0 = (int)((int64_t)nsplit * part / K), nr = (int)((int64_t)nsplit * (part + 1) / K) - r0;
+    int side = -1;  // PROLOGUE: the part's faces are all hand faces (0) / all object faces (1): pair_part_range
+    if constexpr (PROLOGUE) side = pair_part_range(part, K, pro.f.Fh, pro.f.Fo, r0, nr);
     const bool two = RECORDS && p.fill_back != 0;
     const int nv = two ? 2 * nr : nr;
     auto fn_of = [&](int j) { return j < nr ? r0 + j : p.F0 + r0 + (j - nr); };
@@ -302,11 +327,14 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
             PairCamera cam;
             load_pair_camera(pro.v, pb, cam);
             float* cols_b = (frame == 0 ? pro.v.cols12 : pro.v.cols21) + (int64_t)pb * p.V * 3;
-            for (int vi = tid; vi < p.V; vi += BIN_TPB) {
+            // the vertices of the part's side only (all of them without a split); the FIRST part of a side writes its colours
+            const int v_lo = side == 1 ? pro.v.split : 0, v_hi = side == 0 ? pro.v.split : p.V;
+            const bool writes = side < 0 ? part == 0 : (r0 == 0 || r0 == pro.f.Fh);
+            for (int vi = v_lo + tid; vi < v_hi; vi += BIN_TPB) {
                 float n[3], c[2];
                 pair_vertex_of_frame(pro.v, cam, pb, vi, frame, n, c);
                 sverts[vi * 3] = n[0]; sverts[vi * 3 + 1] = n[1]; sverts[vi * 3 + 2] = n[2];
-                if (part == 0) { cols_b[vi * 3] = c[0]; cols_b[vi * 3 + 1] = c[1]; cols_b[vi * 3 + 2] = 1.0f; }
+                if (writes) { cols_b[vi * 3] = c[0]; cols_b[vi * 3 + 1] = c[1]; cols_b[vi * 3 + 2] = 1.0f; }
             }
             __syncthreads();
         }
@@ -1421,12 +1449,23 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     // of 256 x 256 19.6 us with two parts, 17.8 with one; 64 renders 16.9 / 15.6; 16 of 480 x 480 18.3 / 17.5; 64 of 640 x 640
     // (1600 bins) 26.2 / 27.9 (round 6, rocprofv3 over `bench.py --kernels-only` / scripts/hot_only.py, HOC_FWD_DBG sweeps).
     if (!fused_records && nbins <= 1024 && !(bp.dbg & 1)) parts = 1;
-    bp.B = B; bp.parts = parts; bp.poll_add = 0;
+    bp.B = B; bp.parts = parts;
     bp.part_cnt = (int*)(base + w.off_part_cnt);
     bp.arrive = (unsigned*)(base + w.off_arrive);
     size_t lds = (size_t)((nbins + 3) & ~3) * sizeof(int);
     // (boxes of the largest part: its share of the real faces in both orientations, or of the virtual faces)
-    const size_t box_lds = (size_t)((F + parts - 1) / parts + 2) * sizeof(FaceBox);
+    int box_cap = (F + parts - 1) / parts + 2;
+    if (pro) {  // (the parts of a pair step split at the hand / object boundary: pair_part_range)
+        int most = 0;
+        for (int k = 0; k < parts; k++) {
+            int r0, nr;
+            pair_part_range(k, parts, pro->f.Fh, pro->f.Fo, r0, nr);
+            most = std::max(most, nr);
+        }
+        box_cap = std::max(box_cap, (bp.fill_back ? 2 * most : most) + 2);
+    }
+    bp.box_cap = box_cap;
+    const size_t box_lds = (size_t)box_cap * sizeof(FaceBox);
     bp.lds_boxes = (lds + box_lds <= 152 * 1024) ? 1 : 0;
     if (bp.lds_boxes) lds += box_lds;
     fp.hdrs = bp.hdrs; fp.bins = bp.bins; fp.recs = bp.recs; fp.rverts = bp.rverts;

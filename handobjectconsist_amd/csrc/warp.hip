@@ -696,7 +696,7 @@ struct FlowPairFwdParams {
 };
 
 template <bool GRAD>
-__global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFwdParams q) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) flow_pair_forward_tiles_kernel(FlowPairFwdParams q) {
     __shared__ float red[2][4][2];
     __shared__ unsigned redm[2][4];
     const OcclTilesParams& p = q.o;
@@ -707,40 +707,46 @@ __global__ void __launch_bounds__(256) flow_pair_forward_tiles_kernel(FlowPairFw
     unsigned round = 0;
     for (; j < sl.n_local; j += sl.stride) {
         const TileAt t = tile_at(p.list.ids[sl.slot(j, p.list.cap)].x, p.B, p.tiles_x, T, is, p.hit[0], p.hit[1]);
+        // Round 6: the pixel's own values are requested TOGETHER with the tile's coverage word, not behind it (nine dependent
+        // round trips per tile -- list header, entry, word, own values, byte at q, planes at q, byte at r, mask at r, taps --
+        // were this kernel: six now, occl_from_own_together takes two more out).  What the planes hold under a row pair
+        // without a covered pixel is discarded below; the addresses are inside the planes whatever the word says.
+        const bool inside = t.x < is && t.ry < is;
+        const int a = t.dir, o_ = 1 - t.dir;
+        const float* ma = p.mask[a] + (int64_t)t.b * hw;
+        const float* fab = p.flow[a] + (int64_t)t.b * p.fbstride;
+        const float* sab = p.scale[a] ? p.scale[a] + (int64_t)t.b * hw : nullptr;
+        const int64_t pix = (int64_t)t.y * is + t.x;
+        const bool in_crop = inside && t.y < H && t.x < W;
+        const int64_t pixc = (int64_t)t.y * W + t.x;
+        // direction 0 = frame 1's grid: flow12 warps `image` towards image_ref, gated by jitter_ref; direction 1: the reverse
+        const float* src = t.dir ? q.image_ref : q.image;
+        const float* tgt = t.dir ? q.image : q.image_ref;
+        const float* jit = t.dir ? q.jitter : q.jitter_ref;
+        DirRaw2 raw{};
+        float ma_p = 0.0f, sc = 1.0f, f0 = 0.0f, f1 = 0.0f;
+        if (in_crop) pair_load_own(tgt, jit, q.Cj, t.b, pixc, hw_img, raw);
+        if (inside) {
+            ma_p = ma[pix];
+            if (sab) sc = sab[pix];
+            f0 = fab[pix]; f1 = fab[hw + pix];
+        }
+        pin(ma_p); pin(sc); pin(f0); pin(f1);  // (requested in front of the branch on the word, not sunk behind it)
         if (t.word == 0u) continue;  // (uniform)
         float sum = 0.0f, cnt = 0.0f;
         unsigned gmx = 0u;
-        if (t.x < is && t.ry < is) {
-            const int a = t.dir, o_ = 1 - t.dir;
-            const float* ma = p.mask[a] + (int64_t)t.b * hw;
+        if (inside) {
             const float* mb = p.mask[o_] + (int64_t)t.b * hw;
-            const float* fab = p.flow[a] + (int64_t)t.b * p.fbstride;
             const float* fba = p.flow[o_] + (int64_t)t.b * p.fbstride;
-            const float* sab = p.scale[a] ? p.scale[a] + (int64_t)t.b * hw : nullptr;
             const float* sba = p.scale[o_] ? p.scale[o_] + (int64_t)t.b * hw : nullptr;
             const uint8_t* ha = p.hit[a] + (int64_t)t.b * T * 4;
             const uint8_t* hb = p.hit[o_] + (int64_t)t.b * T * 4;
-            const int64_t pix = (int64_t)t.y * is + t.x;
-            const bool in_crop = t.y < H && t.x < W;
-            const int64_t pixc = (int64_t)t.y * W + t.x;
-            // direction 0 = frame 1's grid: flow12 warps `image` towards image_ref, gated by jitter_ref; direction 1: the reverse
-            const float* src = t.dir ? q.image_ref : q.image;
-            const float* tgt = t.dir ? q.image : q.image_ref;
-            const float* jit = t.dir ? q.jitter : q.jitter_ref;
-            DirRaw2 raw{};
-            if (in_crop && t.row_covered) pair_load_own(tgt, jit, q.Cj, t.b, pixc, hw_img, raw);
-            // the pixel's own rendered values, all requested at once (the planes are defined wherever the row pair holds
-            // a covered pixel): mask, scale, the two displacement planes
-            float ma_p = 0.0f, sc = 1.0f, f0 = 0.0f, f1 = 0.0f;
-            if (t.row_covered) {
-                ma_p = ma[pix];
-                if (sab) sc = sab[pix];
-                f0 = fab[pix]; f1 = fab[hw + pix];
-            }
+            // (the planes are defined wherever the row pair holds a covered pixel: elsewhere the values above are dropped)
+            if (!t.row_covered) { ma_p = 0.0f; sc = 1.0f; f0 = 0.0f; f1 = 0.0f; }
             float o = 0.0f;
             if (t.row_covered && ma_p != 0.0f)
-                o = occl_from_own(ma_p, sab ? f0 * sc : f0, sab ? f1 * sc : f1, ma, mb, fba, sba, hw, is, is, t.x, t.y,
-                                  p.dist_thresh, p.wthresh, ha, hb, p.tiles_x);
+                o = occl_from_own_together(ma_p, sab ? f0 * sc : f0, sab ? f1 * sc : f1, ma, mb, fba, sba, hw, is, is, t.x, t.y,
+                                           p.dist_thresh, p.wthresh, ha, hb, p.tiles_x);
             p.occl[a][(int64_t)t.b * hw + pix] = o;
             if (in_crop) {
                 const float post = o != 0.0f ? ma_p * o : 0.0f;

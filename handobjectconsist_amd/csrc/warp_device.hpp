@@ -288,6 +288,63 @@ __device__ __forceinline__ float occl_from_own(float ma_p, float fx, float fy, c
     return mask * motion;
 }
 
+// occl_from_own with every hop's loads requested TOGETHER with the coverage byte that guards them (round 6, the fused warp
+// forward): the byte of q's row pair, the other frame's mask, scale and displacement at q go out at once -- then r's byte and
+// mask_a(r).  The guarded form above waits for a byte before it asks for the planes behind it: four dependent round trips
+// (byte at q -> planes at q -> byte at r -> mask at r) where this one has two.  What an uncovered row pair's planes hold (with
+// MR_FLAG_SPARSE_TILES: whatever the buffer held) is read and DISCARDED by a select; every address is inside the planes
+// (q and r are in-bounds pixels by the m2 / m1 tests).  Same values, same arithmetic, same result.
+__device__ __forceinline__ float occl_from_own_together(float ma_p, float fx, float fy, const float* __restrict__ mask_a,
+                                                        const float* __restrict__ mask_b, const float* __restrict__ flow_ba,
+                                                        const float* __restrict__ scale_ba, int64_t hw, int H, int W, int xx,
+                                                        int yy, float dist_thresh, float wthresh,
+                                                        const uint8_t* __restrict__ hit_a, const uint8_t* __restrict__ hit_b,
+                                                        int tiles_x) {
+    float ix, iy;
+    sample_pos((float)xx, (float)yy, fx, fy, W, H, ix, iy);
+    int qx, qy;
+    nearest_idx(ix, iy, qx, qy);
+    float wg[3] = {0.0f, 0.0f, 0.0f};  // channels x, y, mask of warp_ab at q
+    float m2 = inb(qx, qy, W, H) ? 1.0f : 0.0f;
+    if (m2 < wthresh) m2 = 0.0f;
+    if (m2 > 0.0f) {
+        const int64_t qpix = (int64_t)qy * W + qx;
+        const int qry = H - 1 - qy;
+        float cov_q = (float)hit_b[((qry >> 3) * tiles_x + (qx >> 5)) * 4 + ((qry & 7) >> 1)];
+        float sb = scale_ba ? scale_ba[qpix] : 1.0f;
+        float fbx = flow_ba[qpix], fby = flow_ba[hw + qpix], mb_q = mask_b[qpix];
+        pin(cov_q); pin(sb); pin(fbx); pin(fby); pin(mb_q);
+        // nothing rendered around q: mask_b(q) = 0 zeroes the warped grid, hence the result
+        if (cov_q == 0.0f) return 0.0f;
+        // first warp: sample grid_a at q + flow_ba(q)
+        float jx, jy;
+        sample_pos((float)qx, (float)qy, scale_ba ? fbx * sb : fbx, scale_ba ? fby * sb : fby, W, H, jx, jy);
+        int rx, ry;
+        nearest_idx(jx, jy, rx, ry);
+        float m1 = inb(rx, ry, W, H) ? 1.0f : 0.0f;
+        if (m1 < wthresh) m1 = 0.0f;
+        if (m1 > 0.0f) {
+            const int rry = H - 1 - ry;
+            float cov_r = (float)hit_a[((rry >> 3) * tiles_x + (rx >> 5)) * 4 + ((rry & 7) >> 1)];
+            float ma_raw = mask_a[(int64_t)ry * W + rx];
+            pin(cov_r); pin(ma_raw);
+            const float ma_r = cov_r != 0.0f ? ma_raw : 0.0f;
+            wg[0] = ((float)rx / (float)W) * m1 * mb_q;
+            wg[1] = ((float)ry / (float)H) * m1 * mb_q;
+            wg[2] = ma_r * m1 * mb_q;
+        }
+    }
+    float w3[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) w3[k] = wg[k] * m2 * ma_p;
+    const float g0 = (float)xx / (float)W, g1 = (float)yy / (float)H;
+    const float mask = ma_p * w3[2];
+    const float dx = (w3[0] - g0) * mask, dy = (w3[1] - g1) * mask;
+    const float displ = sqrtf(dx * dx + dy * dy);
+    const float motion = (displ < dist_thresh) ? 1.0f : 0.0f;
+    return mask * motion;
+}
+
 // ---------------------------------------------------------------------------------------
 // pair loss, one direction at one pixel
 // ---------------------------------------------------------------------------------------
