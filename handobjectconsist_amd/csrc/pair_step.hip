@@ -32,7 +32,7 @@ int mr_flow_pair_forward_grad_tiles_ex(const float* mask_flow1, const float* mas
                                        int width, float distance_thresh, float warp_thresh, float pair_thresh, const void* list_header,
                                        const void* list_entries, int64_t list_capacity, int64_t tile_bound, float* unit_grad,
                                        float* unit_grad_max, float* loss_sum, void* scatter_work, float* mean_out, int mean_of,
-                                       int reset_list, mr_stream_t stream);
+                                       int reset_list, const void* records, mr_stream_t stream);
 
 int mr_render_flow_forward_pair(const float* verts, const int32_t* faces_idx, const float* vcolors, const float* background,
                                 int bg_stride, const float* keep_lut, int n_lut, float alpha_thresh, float* rgb_img, float* alpha_img,
@@ -40,7 +40,7 @@ int mr_render_flow_forward_pair(const float* verts, const int32_t* faces_idx, co
                                 void* workspace, int64_t workspace_bytes, int batch_size, int num_verts, int num_faces, int fill_back,
                                 int image_size, float near_, float far_, float eps, int flags, int32_t* vertex_id_map, int tile_bound,
                                 uint32_t* tile_count_out, float* zero_fill, int64_t zero_fill_count, int texel_layout,
-                                mr_stream_t stream, const mr::PairPrologue* pro);
+                                mr_stream_t stream, const mr::PairPrologue* pro, void* records);
 
 namespace mr {
 
@@ -80,6 +80,7 @@ static int pair_step_layout(const MrPairStep& a, PairStepLayout& L) {
     auto take = [&](int64_t bytes) { const int64_t at = o; o += ps_align(bytes > 16 ? bytes : 16); return at; };
     L.ndc = take(B2 * V * 12); L.cols = take(B2 * V * 12); L.faces2 = take(B2 * F0 * 12);
     L.rgb = take(B2 * 3 * px * 4); L.alpha = take(B2 * px * 4); L.mask = take(B2 * px * 4); L.occl = take(B2 * px * 4);
+    if (L.alpha != L.rgb + B2 * 3 * px * 4) return MR_ERR_BADARG;  // (the pixel records span the colour + alpha planes' room)
     L.render_work = take(L.render_work_bytes); L.pair_work = take(L.pair_work_bytes);
     L.scratch_total = o;
     o = 0;
@@ -186,11 +187,17 @@ extern "C" int mr_pair_step_forward(const MrPairStep* step, mr_stream_t stream) 
     // 2. the flow-mode render of the 2B stacked meshes (binning pass with the per-face pass inside + tile kernel)
     int64_t bound = a.tile_bound;
     if (bound == 0) bound = -1;
-    rc = mr_render_flow_forward_pair(ndc, faces2, cols, a.background, a.bg_stride, a.keep_lut, a.n_lut, a.alpha_thresh, rgb, alpha, mask,
+    // (round 6: what the render hands to the fused warp forward is ONE 16-byte record per pixel {displacement x, y, alpha,
+    // mask} instead of four planes -- in the room of the colour + alpha planes, which have exactly its size; the first form
+    // keeps the planes)
+    static_assert(sizeof(float) * 4 == 16, "record = four floats");
+    void* records = separate ? nullptr : (void*)rgb;
+    rc = mr_render_flow_forward_pair(ndc, faces2, cols, a.background, a.bg_stride, a.keep_lut, a.n_lut, a.alpha_thresh,
+                                     records ? nullptr : rgb, records ? nullptr : alpha, records ? nullptr : mask,
                                      nullptr, wmap, fim, tile_hit, rwork, L.render_work_bytes, B2, V, L.F0, a.fill_back, is, a.near_, a.far_,
                                      a.eps, MR_FLAG_SPARSE_TILES | MR_FLAG_TILE_LIST_CLEARED | (a.flags & ~0xff), vid,  // (flags >> 8: the render's profiling switches)
                                      (int)(bound > 0x7fffffffLL ? 0x7fffffffLL : bound), a.tile_count_out, grad_buf,
-                                     grad_buf ? (int64_t)B2 * V * 3 : 0, a.texel_layout, stream, separate ? nullptr : &pro);
+                                     grad_buf ? (int64_t)B2 * V * 3 : 0, a.texel_layout, stream, separate ? nullptr : &pro, records);
     if (rc != MR_OK) return rc;
     // 3. occlusion + flow epilogue + pair loss forward (+ its unit gradient) over the render's tile list; finalize
     float *loss_fwd = a.losses, *loss_bwd = a.losses + B, *loss_sum = a.losses + 2 * (int64_t)B;
@@ -198,14 +205,14 @@ extern "C" int mr_pair_step_forward(const MrPairStep* step, mr_stream_t stream) 
     float* flow12 = a.flows;
     float* flow21 = a.flows + (int64_t)B * a.height * a.width * 2;
     rc = mr_flow_pair_forward_grad_tiles_ex(mask, alpha + (int64_t)B * px, rgb, rgb + (int64_t)B * 3 * px, 3 * px, mask,
-                                         mask + (int64_t)B * px, occl, occl + (int64_t)B * px, flow12, flow21, tile_hit,
+                                         mask + (int64_t)B * px, records ? nullptr : occl, records ? nullptr : occl + (int64_t)B * px, flow12, flow21, tile_hit,
                                          tile_hit + th_half, a.image_ref, a.image, a.jitter_ref, a.jitter, a.jitter_channels, pwork,
                                          L.pair_work_bytes, sums, loss_fwd, loss_bwd, B, is, a.height, a.width, a.distance_thresh,
                                          a.warp_thresh, a.pair_thresh, hdr, ents, cap, bound, unit_grad, unit_max, loss_sum, swork,
                                          // (the finalize launch's last workgroup leaves the mean in losses[3 B]; the B words
                                          // behind it -- the caller's buffer has 4 B + 1 -- carry the samples' values to it)
                                          // (reset_list: the finalize launch leaves the list header's counters zero for the next step)
-                                         a.losses + 3 * (int64_t)B, a.mean_of, 1, stream);
+                                         a.losses + 3 * (int64_t)B, a.mean_of, 1, records, stream);
     return rc;
 }
 

@@ -647,6 +647,9 @@ struct FwdParams {
     int n_lut;
     float alpha_thresh;
     int rgb_channels;      // 3, or 2: the third colour plane is left untouched
+    float4* rec4;          // pair steps (round 6), nullable: [B,is,is] image orientation, ONE 16-byte record per pixel {colour 0,
+                           // colour 1, alpha, mask} INSTEAD of the rgb / alpha / mask planes -- the fused warp forward then asks for
+                           // a pixel's four values in one load instead of four (it is bound by its count of memory requests)
     int32_t* vid_map;      // VC flow mode, nullable: [B,is,is,3] raster orientation: the winner's vertex ids; with it
                            // `weight` receives the three SAMPLING weights of the colour taps instead of the
                            // barycentrics -- all the colour backward needs, in one load round trip per pixel
@@ -1040,6 +1043,10 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
                 p.fim[ri] = -1;
                 if (p.weight && !p.sparse_wd) { p.weight[ri * 3 + 0] = 0.0f; p.weight[ri * 3 + 1] = 0.0f; p.weight[ri * 3 + 2] = 0.0f; }
                 if (p.depth && !p.sparse_wd) p.depth[ii] = p.far_;
+                if (p.rec4) {
+                    const float* bg = p.background + (int64_t)b * p.bg_stride;
+                    p.rec4[ii] = make_float4(bg[0], bg[1], 0.0f, 0.0f);
+                }
                 if (p.alpha) p.alpha[ii] = 0.0f;
                 if (p.mask) p.mask[ii] = 0.0f;
                 if (p.rgb) {
@@ -1123,12 +1130,14 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
         }
         if (p.depth) p.depth[ii] = zp;
         if (p.alpha) p.alpha[ii] = 1.0f;
-        if (p.mask) {  // flow_mask_kernel's arithmetic: (alpha > thresh) * (face + 1 inside the table ? lut : 1)
+        float mask_v = 0.0f;
+        if (p.mask || p.rec4) {  // flow_mask_kernel's arithmetic: (alpha > thresh) * (face + 1 inside the table ? lut : 1)
             float m = (1.0f > p.alpha_thresh) ? 1.0f : 0.0f;
             if (p.keep_lut) m = m * ((fn + 1 >= 0 && fn + 1 < p.n_lut) ? p.keep_lut[fn + 1] : 1.0f);
-            p.mask[ii] = m;
+            if (p.mask) p.mask[ii] = m;
+            mask_v = m;
         }
-        if (p.rgb) {
+        if (p.rgb || p.rec4) {
             const int ts = p.ts;
             float tif[3];
             if (shared_w && mag_within(zp, -30, 30)) {  // tex_coords with depth / z_k through the depths' reciprocals
@@ -1192,9 +1201,10 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
             const float* bg = p.background + (int64_t)b * p.bg_stride;
             const int64_t plane = (int64_t)is * is;
             const int64_t o = ((int64_t)b * 3 * is + (is - 1 - py)) * is + px;
+            if (p.rec4) p.rec4[ii] = make_float4(c[0] * 1.0f + 0.0f * bg[0], c[1] * 1.0f + 0.0f * bg[1], 1.0f, mask_v);
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                if (k < p.rgb_channels) p.rgb[o + k * plane] = c[k] * 1.0f + 0.0f * bg[k];
+                if (p.rgb && k < p.rgb_channels) p.rgb[o + k * plane] = c[k] * 1.0f + 0.0f * bg[k];
         }
     }
 }
@@ -1791,7 +1801,7 @@ int mr_render_flow_forward_pair(const float* verts, const int32_t* faces_idx, co
                                 int num_verts, int num_faces, int fill_back, int image_size, float near_,
                                 float far_, float eps, int flags, int32_t* vertex_id_map, int tile_bound,
                                 uint32_t* tile_count_out, float* zero_fill, int64_t zero_fill_count,
-                                int texel_layout, mr_stream_t stream, const mr::PairPrologue* pro);
+                                int texel_layout, mr_stream_t stream, const mr::PairPrologue* pro, void* records);
 
 extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_idx, const float* vcolors,
                                       const float* background, int bg_stride, const float* keep_lut, int n_lut,
@@ -1806,7 +1816,7 @@ extern "C" int mr_render_flow_forward(const float* verts, const int32_t* faces_i
                                        alpha_img, mask_img, depth_img, weight_map, face_index_map, tile_hit, workspace,
                                        workspace_bytes, batch_size, num_verts, num_faces, fill_back, image_size, near_, far_, eps,
                                        flags, vertex_id_map, tile_bound, tile_count_out, zero_fill, zero_fill_count, texel_layout,
-                                       stream, nullptr);
+                                       stream, nullptr, nullptr);
 }
 
 int mr_render_flow_forward_pair(const float* verts, const int32_t* faces_idx, const float* vcolors,
@@ -1817,13 +1827,18 @@ int mr_render_flow_forward_pair(const float* verts, const int32_t* faces_idx, co
                                 int num_verts, int num_faces, int fill_back, int image_size, float near_,
                                 float far_, float eps, int flags, int32_t* vertex_id_map, int tile_bound,
                                 uint32_t* tile_count_out, float* zero_fill, int64_t zero_fill_count,
-                                int texel_layout, mr_stream_t stream, const mr::PairPrologue* pro) {
+                                int texel_layout, mr_stream_t stream, const mr::PairPrologue* pro, void* records) {
     const int F = fill_back ? 2 * num_faces : num_faces;
     if (!texel_layout_ok(texel_layout)) return MR_ERR_BADARG;
     if (batch_size < 0 || num_faces < 0 || num_verts < 0 || image_size <= 0 || image_size > 16384) return MR_ERR_BADARG;
     if (((!verts || !faces_idx || !vcolors) && num_faces > 0) || !face_index_map || !workspace) return MR_ERR_BADARG;
     if (vertex_id_map && !weight_map) return MR_ERR_BADARG;
-    if (!rgb_img || !alpha_img || !mask_img || !background || !(eps >= 1e-6f)) return MR_ERR_BADARG;
+    // (`records`: [B,is,is] 16-byte records {colour 0, colour 1, alpha, mask} in place of the three planes -- listed sparse
+    // launches only: the dense background stream writes planes)
+    if (records ? (rgb_img || alpha_img || mask_img || ((uintptr_t)records & 15) || !(flags & MR_FLAG_SPARSE_TILES) || tile_bound == 0)
+                : (!rgb_img || !alpha_img || !mask_img))
+        return MR_ERR_BADARG;
+    if (!background || !(eps >= 1e-6f)) return MR_ERR_BADARG;
     if ((bg_stride != 0 && bg_stride != 3) || (keep_lut && n_lut <= 0)) return MR_ERR_BADARG;
     if (workspace_bytes < mr_render_workspace_bytes(batch_size, F, image_size)) return MR_ERR_BADARG;
     if (zero_fill_count < 0 || (zero_fill_count > 0 && !zero_fill)) return MR_ERR_BADARG;
@@ -1848,7 +1863,8 @@ int mr_render_flow_forward_pair(const float* verts, const int32_t* faces_idx, co
     p.tile_count_out = p.tlist ? tile_count_out : nullptr;
     p.background = background; p.bg_stride = bg_stride;
     p.rgb = rgb_img; p.rgb_channels = 2;
-    p.alpha = alpha_img; p.mask = mask_img;
+    p.alpha = alpha_img; p.mask = mask_img; p.rec4 = (float4*)records;
+    if (records && !p.tlist) return MR_ERR_NOTIMPL;  // (no tile list for this raster: pair_step_layout has asked before)
     p.depth = depth_img; p.weight = weight_map; p.sparse_wd = 1; p.tile_hit = tile_hit; p.vid_map = vertex_id_map;
     p.sparse_tiles = (flags & MR_FLAG_SPARSE_TILES) ? 1 : 0;
     if (p.sparse_tiles && !tile_hit) return MR_ERR_BADARG;

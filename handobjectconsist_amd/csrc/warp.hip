@@ -693,9 +693,12 @@ struct FlowPairFwdParams {
     // (the backward multiplies by grad_loss / count, one scalar per image), and the tile's largest magnitude
     float* unit_grad;         // [2B, H, W, 2] (written under the covered tiles)
     unsigned* tile_max;       // [2B, T] float bits
+    // REC (mr_pair_step_forward, round 6): the render left ONE 16-byte record per pixel {displacement x, y, alpha, mask} instead
+    // of the planes of o.mask / o.flow / o.scale (unused then; o.occl may be NULL: nobody reads a pair step's occlusion maps)
+    const float4* rec;        // [2B, is, is] image orientation: frame 1's B images, then frame 2's
 };
 
-template <bool GRAD>
+template <bool GRAD, bool REC = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) flow_pair_forward_tiles_kernel(FlowPairFwdParams q) {
     __shared__ float red[2][4][2];
     __shared__ unsigned redm[2][4];
@@ -713,9 +716,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         // without a covered pixel is discarded below; the addresses are inside the planes whatever the word says.
         const bool inside = t.x < is && t.ry < is;
         const int a = t.dir, o_ = 1 - t.dir;
-        const float* ma = p.mask[a] + (int64_t)t.b * hw;
-        const float* fab = p.flow[a] + (int64_t)t.b * p.fbstride;
-        const float* sab = p.scale[a] ? p.scale[a] + (int64_t)t.b * hw : nullptr;
+        const float* ma = REC ? nullptr : p.mask[a] + (int64_t)t.b * hw;
+        const float* fab = REC ? nullptr : p.flow[a] + (int64_t)t.b * p.fbstride;
+        const float* sab = (!REC && p.scale[a]) ? p.scale[a] + (int64_t)t.b * hw : nullptr;
+        const float4* rec_a = REC ? q.rec + ((int64_t)a * p.B + t.b) * hw : nullptr;
         const int64_t pix = (int64_t)t.y * is + t.x;
         const bool in_crop = inside && t.y < H && t.x < W;
         const int64_t pixc = (int64_t)t.y * W + t.x;
@@ -727,27 +731,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         float ma_p = 0.0f, sc = 1.0f, f0 = 0.0f, f1 = 0.0f;
         if (in_crop) pair_load_own(tgt, jit, q.Cj, t.b, pixc, hw_img, raw);
         if (inside) {
-            ma_p = ma[pix];
-            if (sab) sc = sab[pix];
-            f0 = fab[pix]; f1 = fab[hw + pix];
+            if constexpr (REC) {
+                const float4 own = rec_a[pix];
+                f0 = own.x; f1 = own.y; sc = own.w; ma_p = record_mask(own, a);
+            } else {
+                ma_p = ma[pix];
+                if (sab) sc = sab[pix];
+                f0 = fab[pix]; f1 = fab[hw + pix];
+            }
         }
         pin(ma_p); pin(sc); pin(f0); pin(f1);  // (requested in front of the branch on the word, not sunk behind it)
         if (t.word == 0u) continue;  // (uniform)
         float sum = 0.0f, cnt = 0.0f;
         unsigned gmx = 0u;
         if (inside) {
-            const float* mb = p.mask[o_] + (int64_t)t.b * hw;
-            const float* fba = p.flow[o_] + (int64_t)t.b * p.fbstride;
-            const float* sba = p.scale[o_] ? p.scale[o_] + (int64_t)t.b * hw : nullptr;
             const uint8_t* ha = p.hit[a] + (int64_t)t.b * T * 4;
             const uint8_t* hb = p.hit[o_] + (int64_t)t.b * T * 4;
             // (the planes are defined wherever the row pair holds a covered pixel: elsewhere the values above are dropped)
             if (!t.row_covered) { ma_p = 0.0f; sc = 1.0f; f0 = 0.0f; f1 = 0.0f; }
             float o = 0.0f;
-            if (t.row_covered && ma_p != 0.0f)
-                o = occl_from_own_together(ma_p, sab ? f0 * sc : f0, sab ? f1 * sc : f1, ma, mb, fba, sba, hw, is, is, t.x, t.y,
-                                           p.dist_thresh, p.wthresh, ha, hb, p.tiles_x);
-            p.occl[a][(int64_t)t.b * hw + pix] = o;
+            if constexpr (REC) {
+                if (t.row_covered && ma_p != 0.0f)
+                    o = occl_from_own_records(ma_p, f0 * sc, f1 * sc, rec_a, q.rec + ((int64_t)o_ * p.B + t.b) * hw, a, is, is, t.x, t.y,
+                                              p.dist_thresh, p.wthresh, ha, hb, p.tiles_x);
+            } else {
+                const float* mb = p.mask[o_] + (int64_t)t.b * hw;
+                const float* fba = p.flow[o_] + (int64_t)t.b * p.fbstride;
+                const float* sba = p.scale[o_] ? p.scale[o_] + (int64_t)t.b * hw : nullptr;
+                if (t.row_covered && ma_p != 0.0f)
+                    o = occl_from_own_together(ma_p, sab ? f0 * sc : f0, sab ? f1 * sc : f1, ma, mb, fba, sba, hw, is, is, t.x, t.y,
+                                               p.dist_thresh, p.wthresh, ha, hb, p.tiles_x);
+            }
+            if (p.occl[a]) p.occl[a][(int64_t)t.b * hw + pix] = o;
             if (in_crop) {
                 const float post = o != 0.0f ? ma_p * o : 0.0f;
                 float2 r = make_float2(0.0f, 0.0f);
@@ -1303,10 +1318,13 @@ static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_fl
                                    const void* list_header, const void* list_entries, int64_t list_capacity,
                                    int64_t tile_bound, float* unit_grad, float* unit_grad_max, float* loss_sum,
                                    void* scatter_work, mr_stream_t stream, float* mean_out = nullptr, int mean_of = 0,
-                                   int reset_list = 0) {
-    if (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2 || !flow_out12 || !flow_out21)
+                                   int reset_list = 0, const void* records = nullptr) {
+    // (`records`, mr_pair_step_forward: the render's 16-byte pixel records [2B,is,is] in place of the mask / flow / scale
+    // planes, which are not looked at then; occl1 / occl2 may be NULL -- the occlusion maps are not kept)
+    if (records ? (!unit_grad || ((uintptr_t)records & 15)) : (!mask_flow1 || !mask_flow2 || !flow12 || !flow21 || !occl1 || !occl2))
         return MR_ERR_BADARG;
-    if (batch_size < 0 || image_size <= 0 || flow_bstride < 2LL * image_size * image_size) return MR_ERR_BADARG;
+    if (!flow_out12 || !flow_out21) return MR_ERR_BADARG;
+    if (batch_size < 0 || image_size <= 0 || (!records && flow_bstride < 2LL * image_size * image_size)) return MR_ERR_BADARG;
     const int rc = pair_tiles_args_ok(flow_out12, flow_out21, image_ref, image, jitter_ref, jitter, jitter_channels, batch_size,
                                       height, width, tile_hit1, tile_hit2, image_size, list_header, list_entries, list_capacity);
     if (rc != MR_OK) return rc;
@@ -1323,7 +1341,11 @@ static int flow_pair_forward_tiles(const float* mask_flow1, const float* mask_fl
     q.partial = (float*)workspace; q.thresh = pair_thresh;
     q.unit_grad = unit_grad;
     q.tile_max = reinterpret_cast<unsigned*>(q.partial + 2LL * batch_size * tiles_x * tiles_y * 2);
-    if (unit_grad)
+    q.rec = (const float4*)records;
+    if (records)
+        hipLaunchKernelGGL((flow_pair_forward_tiles_kernel<true, true>), dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
+                           (hipStream_t)stream, q);
+    else if (unit_grad)
         hipLaunchKernelGGL(flow_pair_forward_tiles_kernel<true>, dim3(listed_grid(tile_bound, list_capacity)), dim3(256), 0,
                            (hipStream_t)stream, q);
     else
@@ -1355,14 +1377,14 @@ int mr_flow_pair_forward_grad_tiles_ex(const float* mask_flow1, const float* mas
                                        int width, float distance_thresh, float warp_thresh, float pair_thresh, const void* list_header,
                                        const void* list_entries, int64_t list_capacity, int64_t tile_bound, float* unit_grad,
                                        float* unit_grad_max, float* loss_sum, void* scatter_work, float* mean_out, int mean_of,
-                                       int reset_list, mr_stream_t stream) {
+                                       int reset_list, const void* records, mr_stream_t stream) {
     if (!unit_grad || !unit_grad_max) return MR_ERR_BADARG;
     return flow_pair_forward_tiles(mask_flow1, mask_flow2, flow12, flow21, flow_bstride, flow12_scale, flow21_scale, occl1, occl2,
                                    flow_out12, flow_out21, tile_hit1, tile_hit2, image_ref, image, jitter_ref, jitter,
                                    jitter_channels, workspace, workspace_bytes, sums, loss_fwd, loss_bwd, batch_size, image_size,
                                    height, width, distance_thresh, warp_thresh, pair_thresh, list_header, list_entries,
                                    list_capacity, tile_bound, unit_grad, unit_grad_max, loss_sum, scatter_work, stream, mean_out,
-                                   mean_of, reset_list);
+                                   mean_of, reset_list, records);
 }
 
 extern "C" int mr_flow_pair_forward_tiles(const float* mask_flow1, const float* mask_flow2, const float* flow12,

@@ -345,6 +345,61 @@ __device__ __forceinline__ float occl_from_own_together(float ma_p, float fx, fl
     return mask * motion;
 }
 
+// ... and on the 16-byte pixel records of a pair step's render (round 6; raster_fwd.hip FwdParams::rec4: {displacement x,
+// displacement y, alpha, mask} per pixel, image orientation) instead of four planes per frame: what the forward-backward check
+// reads at q is ONE record of the other frame, at r one word of this frame's.  mr_pair_step_forward's assignment of planes
+// (pair_step.hip) is fixed here: frame 1 is masked by its mask plane (record .w), frame 2 by its alpha plane (.z); both
+// displacements are scaled by their frame's mask plane (.w).  Arithmetic and order of operations: occl_from_own's.
+__device__ __forceinline__ float record_mask(const float4& r, int frame) { return frame == 0 ? r.w : r.z; }
+__device__ __forceinline__ float occl_from_own_records(float ma_p, float fx, float fy, const float4* __restrict__ rec_a,
+                                                       const float4* __restrict__ rec_b, int frame_a, int H, int W, int xx, int yy,
+                                                       float dist_thresh, float wthresh, const uint8_t* __restrict__ hit_a,
+                                                       const uint8_t* __restrict__ hit_b, int tiles_x) {
+    float ix, iy;
+    sample_pos((float)xx, (float)yy, fx, fy, W, H, ix, iy);
+    int qx, qy;
+    nearest_idx(ix, iy, qx, qy);
+    float wg[3] = {0.0f, 0.0f, 0.0f};  // channels x, y, mask of warp_ab at q
+    float m2 = inb(qx, qy, W, H) ? 1.0f : 0.0f;
+    if (m2 < wthresh) m2 = 0.0f;
+    if (m2 > 0.0f) {
+        const int64_t qpix = (int64_t)qy * W + qx;
+        const int qry = H - 1 - qy;
+        float cov_q = (float)hit_b[((qry >> 3) * tiles_x + (qx >> 5)) * 4 + ((qry & 7) >> 1)];
+        float4 rq = rec_b[qpix];
+        pin(cov_q); pin(rq.x); pin(rq.y); pin(rq.z); pin(rq.w);
+        // nothing rendered around q: mask_b(q) = 0 zeroes the warped grid, hence the result
+        if (cov_q == 0.0f) return 0.0f;
+        const float sb = rq.w, mb_q = record_mask(rq, 1 - frame_a);
+        // first warp: sample grid_a at q + flow_ba(q)
+        float jx, jy;
+        sample_pos((float)qx, (float)qy, rq.x * sb, rq.y * sb, W, H, jx, jy);
+        int rx, ry;
+        nearest_idx(jx, jy, rx, ry);
+        float m1 = inb(rx, ry, W, H) ? 1.0f : 0.0f;
+        if (m1 < wthresh) m1 = 0.0f;
+        if (m1 > 0.0f) {
+            const int rry = H - 1 - ry;
+            float cov_r = (float)hit_a[((rry >> 3) * tiles_x + (rx >> 5)) * 4 + ((rry & 7) >> 1)];
+            float ma_raw = reinterpret_cast<const float*>(rec_a + ((int64_t)ry * W + rx))[frame_a == 0 ? 3 : 2];
+            pin(cov_r); pin(ma_raw);
+            const float ma_r = cov_r != 0.0f ? ma_raw : 0.0f;
+            wg[0] = ((float)rx / (float)W) * m1 * mb_q;
+            wg[1] = ((float)ry / (float)H) * m1 * mb_q;
+            wg[2] = ma_r * m1 * mb_q;
+        }
+    }
+    float w3[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) w3[k] = wg[k] * m2 * ma_p;
+    const float g0 = (float)xx / (float)W, g1 = (float)yy / (float)H;
+    const float mask = ma_p * w3[2];
+    const float dx = (w3[0] - g0) * mask, dy = (w3[1] - g1) * mask;
+    const float displ = sqrtf(dx * dx + dy * dy);
+    const float motion = (displ < dist_thresh) ? 1.0f : 0.0f;
+    return mask * motion;
+}
+
 // ---------------------------------------------------------------------------------------
 // pair loss, one direction at one pixel
 // ---------------------------------------------------------------------------------------
