@@ -139,6 +139,7 @@ ROOF_BWD_PER_PIXEL = {ROOF_BWD: (36, "... + unit gradient 8"),
                       ROOF_BWD_R4A: (80, "... + three masks 12 + final flow 8 + source 12 + target 12 + two jitter values 8 (its scratch "
                                          "stays in the L2 of the workgroup that writes and re-reads it)"),
                       ROOF_BWD_PLAIN: (48, "... + flow gradient 8 + three masks 12")}
+WARP_TILES_KERNELS_IN_STEP = {"flow_pair_forward_tiles_kernel<true>": "flow_pair_forward_tiles_kernel<true, true>"}
 WARP_TILES_KERNELS = ("occlusion_flow_tiles_kernel", "pair_consist_forward_tiles_kernel", "pair_consist_backward_tiles_kernel",
                       "flow_pair_forward_tiles_kernel<false>", "flow_pair_forward_tiles_kernel<true>")
 
@@ -1182,9 +1183,11 @@ def main():
             if dk in pmc:
                 w.update({"traffic": pmc[dk]["hbm_bytes"], "traffic_low": pmc[dk]["hbm_bytes_low"],
                           "write_bytes": int(pmc[dk]["WRITE_SIZE_KB"] * 1024), "fetch_bytes_as_reported": int(pmc[dk]["FETCH_SIZE_KB"] * 1024)})
-            if dk in in_step:
-                w.update({"in_step_us": in_step[dk]["median_us"],
-                          "frac_in_step": round(w["bytes"] / (in_step[dk]["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
+            # (inside a pair step the fused warp forward reads the render's 16-byte pixel records: the <true, true> instantiation)
+            sk = WARP_TILES_KERNELS_IN_STEP.get(dk, dk) if WARP_TILES_KERNELS_IN_STEP.get(dk, dk) in in_step else dk
+            if sk in in_step:
+                w.update({"in_step_us": in_step[sk]["median_us"], "in_step_kernel": sk,
+                          "frac_in_step": round(w["bytes"] / (in_step[sk]["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
             warp_tiles[name] = w
         in_step_line = in_step or None
         # what the driver's record keeps of this line is `roofline` / `cpu_baseline`: the figures a reader needs ride inside
