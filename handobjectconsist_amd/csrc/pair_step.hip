@@ -49,7 +49,7 @@ static inline int64_t ps_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
 // where everything sits inside the two buffers (byte offsets, 256-byte aligned)
 struct PairStepLayout {
     // scratch
-    int64_t ndc, cols, faces2, rgb, alpha, mask, occl, render_work, pair_work, scratch_total;
+    int64_t ndc, cols, faces2, rgb, alpha, mask, occl, rec, render_work, pair_work, scratch_total;
     int64_t render_work_bytes, pair_work_bytes;
     // saved
     int64_t fim, tile_hit, wmap, vid, unit_grad, unit_max, sums, scatter_work, grad_buf, saved_total;
@@ -80,7 +80,7 @@ static int pair_step_layout(const MrPairStep& a, PairStepLayout& L) {
     auto take = [&](int64_t bytes) { const int64_t at = o; o += ps_align(bytes > 16 ? bytes : 16); return at; };
     L.ndc = take(B2 * V * 12); L.cols = take(B2 * V * 12); L.faces2 = take(B2 * F0 * 12);
     L.rgb = take(B2 * 3 * px * 4); L.alpha = take(B2 * px * 4); L.mask = take(B2 * px * 4); L.occl = take(B2 * px * 4);
-    if (L.alpha != L.rgb + B2 * 3 * px * 4) return MR_ERR_BADARG;  // (the pixel records span the colour + alpha planes' room)
+    L.rec = take(B2 * px * 16);  // (round 6: the render's 16-byte pixel records; the planes above serve MR_PAIR_STEP_SEPARATE_LAUNCHES)
     L.render_work = take(L.render_work_bytes); L.pair_work = take(L.pair_work_bytes);
     L.scratch_total = o;
     o = 0;
@@ -188,10 +188,8 @@ extern "C" int mr_pair_step_forward(const MrPairStep* step, mr_stream_t stream) 
     int64_t bound = a.tile_bound;
     if (bound == 0) bound = -1;
     // (round 6: what the render hands to the fused warp forward is ONE 16-byte record per pixel {displacement x, y, alpha,
-    // mask} instead of four planes -- in the room of the colour + alpha planes, which have exactly its size; the first form
-    // keeps the planes)
-    static_assert(sizeof(float) * 4 == 16, "record = four floats");
-    void* records = separate ? nullptr : (void*)rgb;
+    // mask} instead of four planes; the first form keeps the planes)
+    void* records = separate ? nullptr : (void*)(sc + L.rec);
     rc = mr_render_flow_forward_pair(ndc, faces2, cols, a.background, a.bg_stride, a.keep_lut, a.n_lut, a.alpha_thresh,
                                      records ? nullptr : rgb, records ? nullptr : alpha, records ? nullptr : mask,
                                      nullptr, wmap, fim, tile_hit, rwork, L.render_work_bytes, B2, V, L.F0, a.fill_back, is, a.near_, a.far_,

@@ -94,6 +94,13 @@ def test_pair_step_struct_layout_matches_the_binding():
     assert lib.mr_pair_step_sizes(ctypes.byref(st), ctypes.byref(sc), ctypes.byref(sv), ctypes.byref(th)) == 0
     px = 128 * 256 * 256
     assert sv.value >= px * (4 + 12 + 12 + 8) and sc.value >= px * 4 * 6 and th.value == px * 4
+    # (every raster the fused path takes: sizes only, whatever the planes' sizes are modulo the regions' 256-byte alignment --
+    # a region aliased onto two others refused 36 x 36 and friends for an hour of round 6, found by tests/test_gpu_fuzz.py)
+    for B, is_, h, w in ((1, 12, 12, 12), (3, 36, 36, 20), (2, 100, 64, 100), (5, 132, 132, 132), (8, 480, 270, 480), (1, 4, 4, 4)):
+        st.batch_size, st.image_size, st.height, st.width = B, is_, h, w
+        assert lib.mr_pair_step_sizes(ctypes.byref(st), ctypes.byref(sc), ctypes.byref(sv), ctypes.byref(th)) == 0, (B, is_)
+        assert sc.value >= 2 * B * is_ * is_ * (4 * 6 + 16) and 0 <= th.value - 2 * B * is_ * is_ * 4 < 256 and th.value % 256 == 0
+    st.batch_size = 64
     st.image_size = 258  # (not a multiple of 4: the fused path does not apply)
     st.height = st.width = 258
     assert lib.mr_pair_step_sizes(ctypes.byref(st), ctypes.byref(sc), ctypes.byref(sv), ctypes.byref(th)) == -2
