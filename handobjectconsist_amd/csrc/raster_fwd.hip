@@ -158,6 +158,7 @@ struct BinParams {
     // round 5: `parts` workgroups per image, each binning a contiguous range of the image's faces (see bin_boxes_kernel)
     int B, parts;
     int box_cap;             // boxes the LDS copy holds (the largest part's; PROLOGUE: the projected vertices sit behind them)
+    int split_fh, split_fo;  // > 0: the parts split the real faces at the hand / object boundary (pair_part_range; pair steps)
     int* part_cnt;           // [B, parts, nbins + 4]: a part's raw bin counters + {its large faces, its "everywhere" flag}
     unsigned* arrive;        // [B * ARRIVE_STRIDE] arrival counters of the images' parts, a 128-byte line each; ZERO on entry (per-face
                              // pass / the caller's clear) and again on exit (the last part to arrive re-zeroes its image's)
@@ -261,9 +262,19 @@ __device__ unsigned long long mr_dbg_bin[1024 * 8];  // profiling builds: phase 
 // of the pair's int64 faces (written back as the image's int32 rows of the stacked faces, which the tile kernel's resolve
 // reads).  The per-face pass then gathers its vertices from LDS instead of from global memory.  Nothing crosses workgroups: the
 // parts of an image each compute all of its vertices (1780 x ~250 instructions over 1024 threads).
-template <bool RECORDS, bool PROLOGUE>
+// PHASE (round 6, K > 1): the parts' exchange across a KERNEL boundary instead of through the memory side inside one launch.
+// PHASE 1 = per-face pass + counting pass; the part leaves its counters, scalars and boxes in global memory with plain stores
+// and is done.  PHASE 2 (a second launch of the same grid) = every part reads ALL parts' counters of its image, derives the
+// merged counts, the scan and -- from the counts of the parts in front of it -- its OWN fill cursors per bin, and fills the records
+// of its OWN faces; part 0 also writes what the image has once (bin headers, tile-list entries, image header).  The last-arriver
+// form (PHASE 0 with K > 1) paid three dependent memory-side hops (~2 us each: publish -> arrival counter -> read back) and then
+// ran merge, scan and the fill of the WHOLE image on one workgroup while the image's other parts had left; a launch boundary
+// costs about as much as the hops, and behind it all parts work.  The order of a bin's records differs (by part, then by LDS
+// atomic order) -- as it does from run to run -- and the image does not depend on it (z-buffer keys).
+template <bool RECORDS, bool PROLOGUE, int PHASE = 0>
 __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPrologue& pro) {
     static_assert(RECORDS || !PROLOGUE, "the prologue feeds the per-face pass");
+    static_assert(PHASE == 0 || !PROLOGUE || PHASE == 1, "the fill launch has no vertex stage");
     MR_BIN_STAMP(0);
     extern __shared__ int bin_smem[];
     __shared__ int s_large, s_nlarge, s_lbase, s_hbase, s_bbase, s_everywhere, s_last;
@@ -272,7 +283,7 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
     __shared__ unsigned long long wsum[BIN_TPB / MR_WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = p.parts;
-    if (p.zero_fill)
+    if (PHASE != 2 && p.zero_fill)
         for (int64_t i = (int64_t)blockIdx.x * BIN_TPB + tid; i < p.zero_count; i += (int64_t)gridDim.x * BIN_TPB) p.zero_fill[i] = 0.0f;
     int b = blockIdx.x, part = 0;
     if (K > 1) {  // workgroup -> (image, part): the parts of image b on XCD b % 8
@@ -291,8 +302,8 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
     // (!RECORDS) virtual faces [r0, r0 + nr); local index j < nv -> face fn_of(j)
     const int nsplit = RECORDS ? p.F0 : p.F;
     int r0 = (int)((int64_t)nsplit * part / K), nr = (int)((int64_t)nsplit * (part + 1) / K) - r0;
-    int side = -1;  // PROLOGUE: the part's faces are all hand faces (0) / all object faces (1): pair_part_range
-    if constexpr (PROLOGUE) side = pair_part_range(part, K, pro.f.Fh, pro.f.Fo, r0, nr);
+    int side = -1;  // pair steps: the part's faces are all hand faces (0) / all object faces (1): pair_part_range
+    if (RECORDS && p.split_fh > 0) side = pair_part_range(part, K, p.split_fh, p.split_fo, r0, nr);
     const bool two = RECORDS && p.fill_back != 0;
     const int nv = two ? 2 * nr : nr;
     auto fn_of = [&](int j) { return j < nr ? r0 + j : p.F0 + r0 + (j - nr); };
@@ -302,7 +313,7 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
     __syncthreads();
     MR_BIN_STAMP(1);
 
-    if constexpr (RECORDS) {
+    if constexpr (RECORDS && PHASE != 2) {
         // the per-face pass (face_records_kernel<true>'s arithmetic): indices of REC_PF faces per thread requested together,
         // then their vertices, then the boxes of both orientations into the LDS copy
         constexpr int REC_PF = 4;
@@ -389,7 +400,7 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
     // addresses): one load round trip per BIN_PF x 1024 faces instead of one per trip -- a hand + object mesh (7104
     // virtual faces) is seven trips, i.e. seven dependent round trips of the single workgroup an image has.
     constexpr int BIN_PF = 8;
-    for (int base = 0; base < nv; base += BIN_PF * BIN_TPB) {
+    for (int base = 0; base < nv && PHASE != 2; base += BIN_PF * BIN_TPB) {
         FaceBox bxs[BIN_PF];
 #pragma unroll
         for (int k = 0; k < BIN_PF; k++) {
@@ -426,7 +437,57 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
 
     const int per = (nbins + BIN_TPB - 1) / BIN_TPB;
     const int i0 = min(tid * per, nbins), i1 = min(i0 + per, nbins);
-    if (K > 1) {
+    int before[MAX_BINS / BIN_TPB];  // PHASE 2: records the parts IN FRONT of this one put into the thread's bins
+#pragma unroll
+    for (int u = 0; u < MAX_BINS / BIN_TPB; u++) before[u] = 0;
+    if (K > 1 && PHASE == 1) {
+        // the count launch: this part's raw counters, scalars and (RECORDS: they exist in LDS only) boxes to global memory,
+        // plain stores -- the fill launch behind the kernel boundary reads them
+        const int pstride = (nbins + 4 + 31) & ~31;
+        int* pub = p.part_cnt + ((int64_t)b * K + part) * pstride;
+        for (int i = tid; i < nbins; i += BIN_TPB) pub[i] = cnt[i];
+        if (tid == 0) { pub[nbins] = s_nlarge; pub[nbins + 1] = s_everywhere; }
+        if (RECORDS)
+            for (int j = tid; j < nv; j += BIN_TPB) box_b[fn_of(j)] = sbox[j];
+        return;
+    }
+    if (K > 1 && PHASE == 2) {
+        // the fill launch: all parts' counters of the thread's bins (plain loads: written before the kernel boundary) -> merged
+        // counts for the scan, and the share of the parts in front of this one = where ITS records start inside a bin's list
+        const int pstride = (nbins + 4 + 31) & ~31;
+        const int* all = p.part_cnt + (int64_t)b * K * pstride;
+        for (int i = i0; i < i1; i++) {
+            int raw[MAX_PARTS_DEV];
+#pragma unroll
+            for (int k = 0; k < MAX_PARTS_DEV; k++) raw[k] = k < K ? all[(int64_t)k * pstride + i] : 0;
+            int tot = 0, lg = 0, bef = 0;
+#pragma unroll
+            for (int k = 0; k < MAX_PARTS_DEV; k++) {
+                tot += raw[k] & CNT_MASK;
+                lg |= raw[k] & LARGE_BIT;
+                bef += k < part ? (raw[k] & CNT_MASK) : 0;
+            }
+            cnt[i] = tot | lg;
+#pragma unroll
+            for (int u = 0; u < MAX_BINS / BIN_TPB; u++)
+                if (u == i - i0) before[u] = bef;
+        }
+        if (tid < MR_WAVE) {  // (wave 0; lane k < K: part k's scalars)
+            int nl = 0, e = 0, nlb = 0;
+            if (tid < K) {
+                nl = all[(int64_t)tid * pstride + nbins];
+                e = all[(int64_t)tid * pstride + nbins + 1];
+                nlb = tid < part ? nl : 0;
+            }
+#pragma unroll
+            for (int off = 1; off < MAX_PARTS_DEV; off <<= 1) {
+                nl += __shfl_xor(nl, off); e |= __shfl_xor(e, off); nlb += __shfl_xor(nlb, off);
+            }
+            if (tid == 0) { s_nlarge = nl; s_everywhere = e; s_large = nlb; }  // (its large faces go behind the earlier parts')
+        }
+        __syncthreads();
+    }
+    if (K > 1 && PHASE == 0) {
         // publish this part's counters, scalars and (RECORDS: they exist in LDS only) boxes; count it on the image's arrival
         // counter; every part but the last one to arrive is done.  Everything that crosses workgroups here goes through
         // AGENT-scope atomic stores / loads (sc1: written through to / read from the memory side, past the XCD's L2) and the
@@ -488,7 +549,8 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
         }
         __syncthreads();
     }
-    constexpr bool lead = true;  // (whoever gets here writes what the image has once: bin headers, tile-list entries, image header)
+    // (whoever gets here writes what the image has once -- bin headers, tile-list entries, image header; of the fill launch's parts: part 0)
+    const bool lead = PHASE != 2 || K == 1 || part == 0;
 
     // exclusive scan of the bin counts (each thread owns a run of consecutive bins); headers out, counters
     // become fill cursors.  The high half of the scanned value counts the bins that hold candidates (every bin,
@@ -534,7 +596,10 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
             h.off = (unsigned)base; h.cnt = (unsigned)c;
             bh[i] = h;
         }
-        cnt[i] = base;
+        int bef = 0;  // (selected, not indexed: the array stays in registers)
+#pragma unroll
+        for (int u = 0; u < MAX_BINS / BIN_TPB; u++) bef = (PHASE == 2 && u == i - i0) ? before[u] : bef;
+        cnt[i] = base + bef;  // (fill cursor; part 0's -- the tile list's writer -- is the bin's offset)
         base += c;
         livebits |= ((c > 0 || lg) ? 1u : 0u) << (i - i0);
         lgbits |= (lg ? 1u : 0u) << (i - i0);
@@ -586,7 +651,20 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
     };
     // (two loops, not one over `lds_boxes ? sbox[j] : box_b[fn]`: the merged pointer is a generic one, and every box
     // then costs two dependent FLAT loads with a full wait each, also when it sits in LDS)
-    if (K > 1) {
+    if (K > 1 && PHASE == 2) {
+        // the fill launch: every part fills the records of ITS faces, from the boxes its count launch left (FILL_PF trips together)
+        constexpr int FILL_PF = 4;
+        for (int base = 0; base < nv; base += FILL_PF * BIN_TPB) {
+            FaceBox bxs[FILL_PF];
+#pragma unroll
+            for (int k = 0; k < FILL_PF; k++) bxs[k] = box_b[fn_of(min(base + k * BIN_TPB + tid, nv - 1))];
+#pragma unroll
+            for (int k = 0; k < FILL_PF; k++) {
+                const int j = base + k * BIN_TPB + tid;
+                if (j < nv) fill_face(fn_of(j), bxs[k]);
+            }
+        }
+    } else if (K > 1) {
         // the last arriver fills for the whole image, from the boxes all parts left in global memory (FILL_PF trips requested together)
         constexpr int FILL_PF = 4;
         for (int base = 0; base < p.F; base += FILL_PF * BIN_TPB) {
@@ -624,6 +702,18 @@ __global__ void __launch_bounds__(BIN_TPB) bin_boxes_kernel(BinParams p) {
 }
 __global__ void __launch_bounds__(BIN_TPB) bin_boxes_prologue_kernel(BinParams p, PairPrologue pro) {
     bin_boxes_body<true, true>(p, pro);
+}
+// the parts' two launches (PHASE): count (with or without the pair's vertex stage in front), fill
+template <bool RECORDS>
+__global__ void __launch_bounds__(BIN_TPB) bin_count_kernel(BinParams p) {
+    bin_boxes_body<RECORDS, false, 1>(p, PairPrologue{});
+}
+__global__ void __launch_bounds__(BIN_TPB) bin_count_prologue_kernel(BinParams p, PairPrologue pro) {
+    bin_boxes_body<true, true, 1>(p, pro);
+}
+template <bool RECORDS>
+__global__ void __launch_bounds__(BIN_TPB) bin_fill_kernel(BinParams p) {
+    bin_boxes_body<RECORDS, false, 2>(p, PairPrologue{});
 }
 
 struct FwdParams {
@@ -1447,7 +1537,7 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
     // parts per image (bin_boxes_kernel, PARTS): B x parts workgroups, all resident at once; dbg 32: one workgroup per image
     // (at most one workgroup per compute unit: two per compute unit -- dbg 64 -- were measured at 2B = 128: 37.7 us against
     // 28.9 with two parts and 28.5 with one; config 3's 16 renders: 16 parts 23.1 us, one part 26.0)
-    int parts = (bp.dbg & 32) ? 1 : bin_parts(B, F, std::min(device_cus(), MAX_PART_CUS), (bp.dbg & 64) ? 2 : 1);
+    int parts = (bp.dbg & 32) ? 1 : bin_parts(B, F, std::min(device_cus(), MAX_PART_CUS), 1);
     if (bp.dbg & 4) parts = std::max(1, parts / 2);  // (profiling: half / a quarter / an eighth of the parts)
     if (bp.dbg & 8) parts = std::max(1, parts / 4);
     if (parts > w.parts) parts = w.parts;
@@ -1475,6 +1565,7 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
         box_cap = std::max(box_cap, (bp.fill_back ? 2 * most : most) + 2);
     }
     bp.box_cap = box_cap;
+    bp.split_fh = pro ? pro->f.Fh : 0; bp.split_fo = pro ? pro->f.Fo : 0;
     const size_t box_lds = (size_t)box_cap * sizeof(FaceBox);
     bp.lds_boxes = (lds + box_lds <= 152 * 1024) ? 1 : 0;
     if (bp.lds_boxes) lds += box_lds;
@@ -1513,15 +1604,31 @@ static int launch_bins(BinParams bp, FwdParams& fp, void* workspace, int B, int 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_boxes_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bin_boxes_prologue_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        const void* more[] = {reinterpret_cast<const void*>(&bin_boxes_prologue_kernel), reinterpret_cast<const void*>(&bin_count_prologue_kernel),
+                              reinterpret_cast<const void*>(&bin_count_kernel<false>), reinterpret_cast<const void*>(&bin_count_kernel<true>),
+                              reinterpret_cast<const void*>(&bin_fill_kernel<false>), reinterpret_cast<const void*>(&bin_fill_kernel<true>)};
+        for (const void* f : more)
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) return (int)e;
         allowed = 152 * 1024;
     }
     // (parts > 1: workgroup i = part (i / 8) % parts of image (i / 8 / parts) * 8 + i % 8 -- an image's parts on one XCD)
     const unsigned grid = parts > 1 ? (unsigned)((B + 7) / 8) * 8u * (unsigned)parts : (unsigned)B;
-    if (pro_fused) hipLaunchKernelGGL(bin_boxes_prologue_kernel, dim3(grid), dim3(BIN_TPB), lds, s, bp, *pro);
+    // (eight parts or more: the parts' exchange across a kernel boundary -- count launch, fill launch.  Measured on one box, pair
+    // steps, device time per hot-path pass: 16 renders of 480 x 480 in 16 parts 27.7 us as one launch, 13.0 + 8.7 as two (0.097 ->
+    // 0.092 ms); 32 renders in 8 parts and 64 in 4: no difference (0.0811 / 0.0818, 0.1109 / 0.1112); 128 renders of 256 x 256 in
+    // 2 parts 33.4 against 22.4 + 13.1 -- with few parts the last arriver's serial share is small and the second launch's floor
+    // is not.  dbg 64: the last-arriver form whatever the parts)
+    const bool two_launches = parts >= 8 && !(bp.dbg & 64);
+    if (two_launches) {
+        if (pro_fused) hipLaunchKernelGGL(bin_count_prologue_kernel, dim3(grid), dim3(BIN_TPB), lds, s, bp, *pro);
+        else if (fused_records_ok) hipLaunchKernelGGL(bin_count_kernel<true>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
+        else hipLaunchKernelGGL(bin_count_kernel<false>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
+        MR_CHECK_LAUNCH();
+        const size_t lds2 = (size_t)((nbins + 3) & ~3) * sizeof(int);  // (counters only: the fill launch keeps no boxes in LDS)
+        if (fused_records_ok) hipLaunchKernelGGL(bin_fill_kernel<true>, dim3(grid), dim3(BIN_TPB), lds2, s, bp);
+        else hipLaunchKernelGGL(bin_fill_kernel<false>, dim3(grid), dim3(BIN_TPB), lds2, s, bp);
+    } else if (pro_fused) hipLaunchKernelGGL(bin_boxes_prologue_kernel, dim3(grid), dim3(BIN_TPB), lds, s, bp, *pro);
     else if (fused_records_ok) hipLaunchKernelGGL(bin_boxes_kernel<true>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
     else hipLaunchKernelGGL(bin_boxes_kernel<false>, dim3(grid), dim3(BIN_TPB), lds, s, bp);
     MR_CHECK_LAUNCH();

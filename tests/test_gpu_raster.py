@@ -1078,6 +1078,7 @@ def test_dense_forwards_over_the_tile_list_equal_one_workgroup_per_tile(cuda, B,
 
 FLAG_ONE_WORKGROUP_PER_IMAGE = 32 << 24  # (profiling / A-B bit of the binning pass: raster_fwd.hip, launch_bins)
 FLAG_FORCE_PARTS = 1 << 24  # (launch_bins: several workgroups per image also where one is the default)
+FLAG_PARTS_IN_ONE_LAUNCH = 64 << 24  # (launch_bins: the last-arriver form also where four or more parts take two launches, round 6)
 
 
 @pytest.mark.parametrize("B,is_", [(2, 256), (13, 96), (40, 64), (3, 480)])
@@ -1131,7 +1132,9 @@ def test_binning_pass_in_parts_equals_one_workgroup_per_image(cuda, B, is_):
         # (FLAG_FORCE_PARTS: since round 6 the standalone entry points bin rasters of up to 1024 tiles with one workgroup per
         # image -- the parts only pay where they split the per-face pass, i.e. on the training path's fused launch, which
         # tests/test_gpu_warp.py drives; the switch keeps this comparison on the parts)
-        for flags in (FLAG_FORCE_PARTS, FLAG_FORCE_PARTS, 0):  # (twice: the second call finds the first one's counters in a REUSED allocation)
+        # (round 6: four or more parts exchange their counters across a kernel boundary -- count launch, fill launch; fewer, or
+        # FLAG_PARTS_IN_ONE_LAUNCH, through the memory side with the last arriver finishing the image: both forms here)
+        for flags in (FLAG_FORCE_PARTS, FLAG_FORCE_PARTS, FLAG_FORCE_PARTS | FLAG_PARTS_IN_ONE_LAUNCH, 0):  # (twice: the second call finds the first one's counters in a REUSED allocation)
             parts, n_parts = run(kind, flags)
             for a, b_, name in zip(one, parts, ("rgb", "alpha", "mask", "depth", "weights", "face_index_map", "vertex ids", "coverage")):
                 assert torch.equal(a, b_), f"{name} differs ({kind})"
