@@ -133,7 +133,9 @@ ROOF_KERNELS = {ROOF_BWD: ["unit_scatter_tiles_kernel"], ROOF_BWD_R4A: ["pair_sc
 # (round 6: the binning launch of a pair step also runs the pair's vertex stage + stacked faces -- bin_boxes_prologue_kernel,
 # which takes the place of pair_prologue_kernel + bin_boxes_kernel<true>; the in-step figure of the forward includes that work)
 ROOF_KERNELS_IN_STEP = {ROOF_FWD: ["bin_boxes_prologue_kernel", "raster_tile_kernel<true, true>"]}
-ROOF_KERNELS_IN_STEP_ALT = {ROOF_FWD: ["bin_boxes_kernel<true>", "raster_tile_kernel<true, true>"]}  # (MR_PAIR_STEP_SEPARATE_LAUNCHES)
+# (eight or more parts per image -- config 3's 16 renders: count launch + fill launch; MR_PAIR_STEP_SEPARATE_LAUNCHES: round 6's first form)
+ROOF_KERNELS_IN_STEP_ALT = {ROOF_FWD: [["bin_count_prologue_kernel", "bin_fill_kernel<true>", "raster_tile_kernel<true, true>"],
+                                       ["bin_boxes_kernel<true>", "raster_tile_kernel<true, true>"]]}
 # compulsory bytes per pixel of a covered tile: face index 4 + vertex ids 12 + sampling weights 12 + ...
 ROOF_BWD_PER_PIXEL = {ROOF_BWD: (36, "... + unit gradient 8"),
                       ROOF_BWD_R4A: (80, "... + three masks 12 + final flow 8 + source 12 + target 12 + two jitter values 8 (its scratch "
@@ -736,10 +738,9 @@ def roofline_block(name, k, pmc, units, in_step=None):
             "launch_ms": k["ms"], "launch_ms_cache_warm": k["ms_cache_warm"],
             "units_per_launch": units, "device_kernels": ROOF_KERNELS[name]}
     step_names = ROOF_KERNELS_IN_STEP.get(name, ROOF_KERNELS[name])
-    if in_step and not all(d in in_step for d in step_names):
-        step_names = ROOF_KERNELS_IN_STEP_ALT.get(name, ROOF_KERNELS[name])
-    if in_step and not all(d in in_step for d in step_names):
-        step_names = ROOF_KERNELS[name]
+    for alt in ROOF_KERNELS_IN_STEP_ALT.get(name, []) + [ROOF_KERNELS[name]]:
+        if in_step and not all(d in in_step for d in step_names):
+            step_names = alt
     if in_step and all(d in in_step for d in step_names):
         us = sum(in_step[d]["median_us"] for d in step_names)
         roof.update({"in_step_us": round(us, 2), "frac_in_step": round(roof["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
