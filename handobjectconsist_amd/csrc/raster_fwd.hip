@@ -256,12 +256,13 @@ __device__ unsigned long long mr_dbg_bin[1024 * 8];  // profiling builds: phase 
 // atomics) -- and the image does not depend on it (z-buffer keys).
 // PROLOGUE (round 6, pair steps: mr_render_flow_forward_pair): the vertex stage of the frame pair runs HERE instead of in a
 // launch of its own in front (pair_prologue_kernel, 7.4 us for 2B = 128 meshes -- most of it a launch's floor).  The
-// workgroup(s) of stack image b project the image's V vertices into LDS (both frames' 2-D projections for the flow colour, the
+// workgroup(s) of stack image b project the image's vertices into LDS (both frames' 2-D projections for the flow colour, the
 // image's own frame through nr.projection: pair_vertex_of_frame -- vertex_stage_device.hpp, the arithmetic of
-// flow_vertices_forward_body), part 0 writes the image's flow colours for the tile kernel, and every part converts its own range
-// of the pair's int64 faces (written back as the image's int32 rows of the stacked faces, which the tile kernel's resolve
-// reads).  The per-face pass then gathers its vertices from LDS instead of from global memory.  Nothing crosses workgroups: the
-// parts of an image each compute all of its vertices (1780 x ~250 instructions over 1024 threads).
+// flow_vertices_forward_body), the first part of a side writes that side's flow colours for the tile kernel, and every part
+// converts its own range of the pair's int64 faces (written back as the image's int32 rows of the stacked faces, which the tile
+// kernel's resolve reads).  The per-face pass then gathers its vertices from LDS instead of from global memory.  Nothing
+// crosses workgroups: a part computes the vertices of ITS side of the mesh itself (pair_part_range: the parts split at the
+// hand / object boundary; 778 or 1002 x ~250 instructions over 1024 threads), a single part all of them.
 // PHASE (round 6, K > 1): the parts' exchange across a KERNEL boundary instead of through the memory side inside one launch.
 // PHASE 1 = per-face pass + counting pass; the part leaves its counters, scalars and boxes in global memory with plain stores
 // and is done.  PHASE 2 (a second launch of the same grid) = every part reads ALL parts' counters of its image, derives the
