@@ -581,11 +581,16 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
         total64 += ws;
     }
     int base = (int)(unsigned)(base64 & 0xffffffffull);
+    // The image's places in the launch's tile list: three device-scope atomics whose results are needed only when the entries are
+    // written -- BEHIND the fill pass (round 6: the ~2 us memory-side round trip used to sit between the scan and the fill, with
+    // the whole workgroup waiting at the barrier behind it; scripts/pair_bin_timeline.py).  The results stay in thread 0's
+    // registers until then.
+    int got_h = 0, got_l = 0, got_b = 0;
     if (p.tlist && lead && tid == 0) {
         const unsigned n_ne = (unsigned)(total64 >> 32) & 0xffffu, n_hv = (unsigned)(total64 >> 48);
-        s_hbase = (int)atomicAdd(&p.tlist->n_heavy, n_hv);
-        s_lbase = (int)atomicAdd(&p.tlist->n_light, n_ne - n_hv);
-        if (p.bg_ids) s_bbase = (int)atomicAdd(&p.tlist->n_bg, (unsigned)nbins - n_ne);
+        got_h = (int)atomicAdd(&p.tlist->n_heavy, n_hv);
+        got_l = (int)atomicAdd(&p.tlist->n_light, n_ne - n_hv);
+        if (p.bg_ids) got_b = (int)atomicAdd(&p.tlist->n_bg, (unsigned)nbins - n_ne);
     }
     BinHdr* bh = p.bins + (int64_t)b * nbins;
     unsigned livebits = 0u, lgbits = 0u;  // (per <= MAX_BINS / BIN_TPB = 8 bins per thread)
@@ -607,9 +612,12 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
     }
     __syncthreads();
     MR_BIN_STAMP(3);
-    if (p.tlist && lead) {
+    auto write_tile_list = [&]() __attribute__((always_inline)) {
+        if (!(p.tlist && lead)) return;  // (uniform)
         // the image's tiles with candidates go to the launch's tile list (a bin IS a tile here: ysh == 0), the
         // others get their (zero) coverage bytes now -- no workgroup is dispatched for them
+        if (tid == 0) { s_hbase = got_h; s_lbase = got_l; s_bbase = got_b; }
+        __syncthreads();
         const unsigned hv_before = (unsigned)(base64 >> 48), ne_before = (unsigned)(base64 >> 32) & 0xffffu;
         unsigned at_h = (unsigned)s_hbase + hv_before;                                   // heavy part: from the front
         unsigned at_l = (unsigned)p.tile_cap + (unsigned)s_lbase + (ne_before - hv_before);  // light part: second half
@@ -618,18 +626,20 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
         for (int i = i0; i < i1; i++) {
             const bool live = (livebits >> (i - i0)) & 1u;
             const unsigned nlarge = ((lgbits >> (i - i0)) & 1u) ? (unsigned)s_nlarge : 0u;
-            // (cnt[] holds the bins' offsets until pass 2 starts; `base` is the end of this run)
-            const unsigned off = (unsigned)cnt[i], end = (unsigned)(i + 1 < i1 ? cnt[i + 1] : base);
-            const uint4 ent = make_uint4((unsigned)(b * nbins + i), off, end - off, nlarge);
-            if (live && end - off + nlarge >= HEAVY_RECS) p.tile_ids[at_h++] = ent;
+            // (the bin's offset and count: the header this thread wrote above -- the LDS cursors have moved on by now)
+            const BinHdr h = bh[i];
+            const uint4 ent = make_uint4((unsigned)(b * nbins + i), h.off, h.cnt, nlarge);
+            if (live && h.cnt + nlarge >= HEAVY_RECS) p.tile_ids[at_h++] = ent;
             else if (live) p.tile_ids[at_l++] = ent;
             else if (p.bg_ids) p.bg_ids[at_b++] = (unsigned)(b * nbins + i);
             else hit32[i] = 0u;
         }
-    }
-    if (p.tlist) __syncthreads();  // (pass 2 moves the cursors)
+    };
     MR_BIN_STAMP(4);
-    if (p.dbg & 2) return;
+    if (p.dbg & 2) {  // (profiling: the binning pass without its fill)
+        write_tile_list();
+        return;
+    }
 
     // pass 2: fill
     FaceRec* recs_b = p.recs + (int64_t)b * REC_CAP * p.F;
@@ -666,8 +676,10 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
             }
         }
     } else if (K > 1) {
-        // the last arriver fills for the whole image, from the boxes all parts left in global memory (FILL_PF trips requested together)
-        constexpr int FILL_PF = 4;
+        // the last arriver fills for the whole image, from the boxes all parts left in global memory (FILL_PF trips requested
+        // together: a hand + object mesh's 7104 boxes in ONE memory-side round trip -- two of ~2 us each with four per thread,
+        // scripts/pair_bin_timeline.py)
+        constexpr int FILL_PF = 8;
         for (int base = 0; base < p.F; base += FILL_PF * BIN_TPB) {
             FaceBox bxs[FILL_PF];
 #pragma unroll
@@ -688,6 +700,7 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
         for (int j = tid; j < nv; j += BIN_TPB) fill_face(fn_of(j), box_b[fn_of(j)]);
     }
     MR_BIN_STAMP(5);
+    write_tile_list();
     if (lead && tid == 0) {
         ImageHdr h;
         h.n_live = 0; h.n_large = s_nlarge;
