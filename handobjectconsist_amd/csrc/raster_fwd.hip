@@ -324,6 +324,9 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
         auto load_ids = [&](int base) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < REC_PF; k++) {
+                // (a slot none of the workgroup's threads has a face for is skipped -- uniform: a part of 2000 faces uses two of
+                // the four, one of 222 a single one; their clamped duplicate requests cost the count launch 2 us at config 3)
+                if (base + k * BIN_TPB >= nr) continue;
                 const int fr = r0 + min(base + k * BIN_TPB + tid, nr - 1);
                 if constexpr (PROLOGUE) {
 #pragma unroll
@@ -365,6 +368,7 @@ __device__ __forceinline__ void bin_boxes_body(const BinParams& p, const PairPro
             for (int k = 0; k < REC_PF; k++)
 #pragma unroll
                 for (int v = 0; v < 3; v++) {
+                    if (base + k * BIN_TPB >= nr) continue;  // (uniform: see load_ids)
                     if constexpr (PROLOGUE) {
                         const float* g = sverts + id[k][v] * 3;
                         f[k][3 * v] = g[0]; f[k][3 * v + 1] = g[1]; f[k][3 * v + 2] = g[2];
