@@ -1298,10 +1298,13 @@ __device__ __forceinline__ void raster_one_tile(const FwdParams& p, const unsign
                     }
                 }
                 if (p.vid_map) {
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        p.vid_map[ri * 3 + k] = cid[k];
-                        if (p.weight) p.weight[ri * 3 + k] = wgs[k];
+                    // (the three ids, then the three weights: two 12-byte stores -- interleaved, the two arrays' possible overlap
+                    // kept the compiler at six 4-byte ones)
+                    int32_t* vm = p.vid_map + ri * 3;
+                    vm[0] = cid[0]; vm[1] = cid[1]; vm[2] = cid[2];
+                    if (p.weight) {
+                        float* wm = p.weight + ri * 3;
+                        wm[0] = wgs[0]; wm[1] = wgs[1]; wm[2] = wgs[2];
                     }
                 }
             }
