@@ -1204,6 +1204,10 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
         // unit instead of four, or 92 bytes of scratch when capped.)
         if (WORK && trip == 0) __syncthreads();  // (table zeroed; the one barrier of pass 2, reached by every wave)
         if (!live) break;
+        // (the finite / non-finite choice -- block-uniform -- is made ONCE around the 24 additions, not inside each of them: the
+        // fixed-point path is straight-line code the compiler can interleave, 48 basic blocks otherwise)
+        auto add_all = [&](auto fin) __attribute__((always_inline)) {
+        constexpr bool FIN = decltype(fin)::value;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (fn[j] < 0) continue;
@@ -1239,7 +1243,7 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
                     // (records name the vertex behind tap k themselves; else: the texel layout table)
                     const int vtx = REC ? vid[j][k] : sel3(vid[j][0], vid[j][1], vid[j][2], texel_vertex(p.texel, k, fn[j] >= p.F0));
                     const int cell = vtx * NCH + ch;
-                    if (finite) {
+                    if constexpr (FIN) {
                         const double d = __builtin_fma((double)v, fix_scale, 6755399441055744.0);
                         if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&vtab[cell]), (unsigned long long)__double_as_longlong(d));
                     } else if (v != 0.0f) {
@@ -1247,6 +1251,8 @@ __device__ __forceinline__ void scatter_tiles_body(const ScatterTilesParams& sp)
                     }
                 }
         }
+        };
+        if (finite) add_all(std::true_type{}); else add_all(std::false_type{});
     }
     if (!finite) return;  // block-uniform
     __syncthreads();
