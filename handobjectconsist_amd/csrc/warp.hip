@@ -544,7 +544,8 @@ __global__ void __launch_bounds__(256) pair_consist_backward_kernel(PairBwdParam
 // the stack, 32 x 8 raster tile) is one workgroup's work in all three kernels, one pixel per thread, and nothing is
 // dispatched, read or written for the rest of the screen.  Granularity of the contract: a tile whose 4-byte coverage
 // word is non-zero gets all its pixels (inside the crop) written; tiles with a zero word -- listed or not -- get
-// NOTHING, and no reader may look there.  Same XCD slices as the render's tile kernel (list_slice): what it wrote for
+// NOTHING, and no reader may use what it finds there (round 6: the fused forward reads a value next to the byte that guards it
+// and drops it by a select -- addresses inside the planes, contents never used).  Same XCD slices as the render's tile kernel (list_slice): what it wrote for
 // a tile is read back behind the same L2.
 struct OcclTilesParams {
     const float* mask[2];    // mask_flow1 / mask_flow2  [B,is,is]
